@@ -1,0 +1,72 @@
+"""ctypes binding of oracle/libzkr_oracle.so -- CPU ORACLE, TEST INFRASTRUCTURE ONLY
+(see oracle/zkr_oracle.c header).  Build with `make -C oracle`."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(_HERE, "libzkr_oracle.so")
+        if not os.path.exists(path):
+            raise RuntimeError("oracle/libzkr_oracle.so missing: run `make -C oracle` (or __graft_entry__.build())")
+        L = ctypes.CDLL(path)
+        L.zo_ntt.argtypes = [ctypes.c_char_p, ctypes.c_uint, ctypes.c_int]
+        L.zo_ntt.restype = None
+        for f in (L.zo_msm_g1, L.zo_msm_g2):
+            f.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p]
+            f.restype = ctypes.c_int
+        L.zo_calc_h.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p]
+        L.zo_calc_h.restype = ctypes.c_int
+        L.zo_prove.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p,
+                               ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double)]
+        L.zo_prove.restype = ctypes.c_int
+        for f in (L.zo_fq_mul_std, L.zo_fr_mul_std):
+            f.argtypes = [ctypes.c_char_p] * 3
+            f.restype = None
+        _lib = L
+    return _lib
+
+
+def ntt(data: bytes, inverse=False) -> bytes:
+    n = len(data) // 32
+    logn = n.bit_length() - 1
+    assert 1 << logn == n
+    buf = ctypes.create_string_buffer(bytes(data), len(data))
+    lib().zo_ntt(buf, logn, 1 if inverse else 0)
+    return buf.raw
+
+
+def msm_g1(points: bytes, scalars: bytes):
+    n = len(scalars) // 32
+    out = ctypes.create_string_buffer(64)
+    inf = lib().zo_msm_g1(bytes(points), bytes(scalars), n, out)
+    return None if inf else out.raw
+
+
+def msm_g2(points: bytes, scalars: bytes):
+    n = len(scalars) // 32
+    out = ctypes.create_string_buffer(128)
+    inf = lib().zo_msm_g2(bytes(points), bytes(scalars), n, out)
+    return None if inf else out.raw
+
+
+def calc_h(pk: bytes, witness: bytes) -> bytes:
+    m = int.from_bytes(pk[8:12], "little")
+    out = ctypes.create_string_buffer(32 * m)
+    rc = lib().zo_calc_h(pk, len(pk), witness, len(witness) // 32, out)
+    if rc:
+        raise RuntimeError("zo_calc_h failed: %d" % rc)
+    return out.raw
+
+
+def prove(pk: bytes, witness: bytes, r: int, s: int, want_timings=False):
+    out = ctypes.create_string_buffer(256)
+    tm = (ctypes.c_double * 3)()
+    rc = lib().zo_prove(pk, len(pk), witness, len(witness) // 32, r.to_bytes(32, "little"), s.to_bytes(32, "little"), out, tm)
+    if rc:
+        raise RuntimeError("zo_prove failed: %d" % rc)
+    return (out.raw, list(tm)) if want_timings else out.raw
