@@ -1,0 +1,116 @@
+/* zkr.h -- C ABI of libzkr_hip.so, the MI355X (gfx950) Groth16 prover behind
+ * `wasmBn128.groth16GenProof(witnessBin, provingKeyBin)`.
+ *
+ * Drop-in boundary (reference call sites, /root/reference = kendricktan/simple-zk-rollups):
+ *   operator/src/snarks/common.ts:23   const wasmBn128 = await buildBn128();
+ *   operator/src/snarks/common.ts:27   witnessBin   = binarifyWitness(witness)      (binarify.ts:10-48)
+ *   operator/src/snarks/common.ts:28   provingKeyBin= binarifyProvingKey(provingKey) (binarify.ts:50-207)
+ *   operator/src/snarks/common.ts:29   proof = await wasmBn128.groth16GenProof(witnessBin, provingKeyBin)
+ *   scripts/index.js:40,46             second copy of the same call
+ * The N-API shim (simple-zk-rollups_amd/napi/zkr_napi.c) binds exactly these entry points; see
+ * INTEGRATION.md for the one-line change in common.ts.
+ *
+ * Conventions: plain pointers and sizes, no C++/torch types.  Every function returns 0 on success
+ * and a negative zkr_status on failure; zkr_last_error() gives a thread-local message.  All field
+ * elements cross the boundary as 32-byte little-endian integers.  "std" = standard form,
+ * "mont" = Montgomery form (x * 2^256 mod p), exactly as binarify.ts:78-90 writes key material.
+ * There is NO CPU fallback: without a usable HIP device every compute entry point fails with
+ * ZKR_ERR_NO_DEVICE.
+ */
+#ifndef ZKR_H
+#define ZKR_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  ZKR_OK = 0,
+  ZKR_ERR_NO_DEVICE = -1,   /* no HIP device / HIP runtime error at init */
+  ZKR_ERR_BAD_KEY = -2,     /* provingKeyBin header/size/section mismatch (binarify.ts:115-141) */
+  ZKR_ERR_BAD_WITNESS = -3, /* witness length != nVars * 32 */
+  ZKR_ERR_HIP = -4,         /* HIP runtime failure during a call */
+  ZKR_ERR_ARG = -5,         /* null pointer / out-of-range argument */
+  ZKR_ERR_DEGENERATE = -6   /* a proof element is the point at infinity (cannot be serialised) */
+} zkr_status;
+
+typedef struct zkr_key zkr_key; /* device-resident proving key (one contiguous HBM arena + workspace) */
+
+/* ---- lifecycle ------------------------------------------------------------------------------ */
+const char *zkr_last_error(void);
+const char *zkr_version(void);
+/* Number of HIP devices visible (0 when none; never fails). */
+int zkr_device_count(void);
+
+/* Parse a websnark-format proving key (the ArrayBuffer of binarifyProvingKey, binarify.ts:143-206),
+ * build the device layout (CSR QAP rows, compacted Montgomery point tables, twiddles) and upload it
+ * to `device`.  Replaces the per-call parse inside groth16GenProof (common.ts:28-29). */
+int zkr_key_load_websnark(const void *pk_bin, size_t pk_len, int device, zkr_key **out);
+void zkr_key_free(zkr_key *key);
+
+/* Key geometry: out[0]=nVars out[1]=nPublic out[2]=domainSize out[3]=nnzA out[4]=nnzB
+ * out[5..9]=points kept (non-infinity) in the A,B1,B2,C,H tables. */
+int zkr_key_info(const zkr_key *key, uint64_t out[10]);
+
+/* Multi-GPU replication: the key is ONE position-independent arena in HBM.
+ * rank 0:  zkr_key_arena(key,&ptr,&len)  -> broadcast `len`, then the bytes (RCCL over xGMI)
+ * rank k:  zkr_key_adopt_arena(dev_ptr,len,device,&key)  (takes a device pointer holding the bytes;
+ *          the caller keeps ownership of that memory and must keep it alive until zkr_key_free). */
+int zkr_key_arena(const zkr_key *key, void **dev_ptr, size_t *len);
+int zkr_key_adopt_arena(void *dev_ptr, size_t len, int device, zkr_key **out);
+
+/* ---- the hot path --------------------------------------------------------------------------- */
+/* One Groth16 proof.  witness_std: nVars x 32 B standard form (binarifyWitness layout, host memory).
+ * r32/s32: blinding scalars (32 B LE, < r); pass NULL for both to draw them from the OS CSPRNG as
+ * the reference does.  proof_out: 256 B = pi_a (x,y) | pi_b (x.re,x.im,y.re,y.im) | pi_c (x,y),
+ * affine, standard form -- the eight integers groth16GenProof returns as decimal strings
+ * (consumed at common.ts:31-32,44-48).
+ * stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) or NULL for the key's own. */
+int zkr_prove(zkr_key *key, const void *witness_std, size_t witness_len, const uint8_t *r32, const uint8_t *s32,
+              uint8_t proof_out[256], void *stream);
+
+/* Same, witness already resident in HBM on the key's device (nVars x 32 B, std form). */
+int zkr_prove_device(zkr_key *key, const void *d_witness_std, const uint8_t *r32, const uint8_t *s32,
+                     uint8_t proof_out[256], void *stream);
+
+/* ---- stage hooks (tests, profiling) ----------------------------------------------------------- */
+/* In-place NTT of n = 2^logn standard-form elements in host memory; natural order in and out. */
+int zkr_ntt(void *data_std, unsigned logn, int inverse, int device);
+/* sum_i scalars[i] * points[i].  points: Montgomery affine as in the key sections (64 B G1 / 128 B G2;
+ * x == 0 encodes infinity, binarify.ts:92-102); scalars: std 32 B.  out: std affine; *is_inf set when
+ * the sum is the point at infinity. */
+int zkr_msm_g1(const void *points_mont, const void *scalars_std, size_t n, uint8_t out[64], int *is_inf, int device);
+int zkr_msm_g2(const void *points_mont, const void *scalars_std, size_t n, uint8_t out[128], int *is_inf, int device);
+/* h = upper-half coefficients of A(x)B(x), natural order, std form, m x 32 B. */
+int zkr_calc_h(zkr_key *key, const void *witness_std, size_t witness_len, void *h_out);
+
+/* Per-stage device timing, measured with hipEvents on the launch stream.  Stage names:
+ * "ingest","spmv","ntt","msm_sort","msm_accum","msm_reduce","assemble","total". */
+int zkr_prof_enable(zkr_key *key, int on);
+int zkr_prof_reset(zkr_key *key);
+int zkr_prof_get(zkr_key *key, const char *stage, double *ms_total, uint64_t *launches);
+
+/* ---- synthetic workload + device-side setup (benchmarks) -------------- */
+/* Rollup-shaped seeded R1CS + witness + Groth16 key generated from seeded toxic waste, key points
+ * computed ON DEVICE by fixed-base multiplication (the websnark binary is never materialised, so
+ * this works past its 4 GiB u32-offset limit).  witness_out: malloc'ed nVars x 32 B std (free with
+ * zkr_free).  aux_out (optional, may be NULL): malloc'ed blob for the checker --
+ *   u64 nVars | 5 x 32 B toxic (t,alfa,beta,gamma,delta) | nVars x 32 B a_s | b_s | c_s  (std form)
+ *   | (nPublic+1) x 64 B IC points (std affine) | 128 B vk_gamma_2 (std) */
+int zkr_synth_key(unsigned log_m, unsigned n_public, uint64_t circuit_seed, uint64_t toxic_seed, int device,
+                  zkr_key **key_out, void **witness_out, size_t *witness_len, void **aux_out, size_t *aux_len);
+/* Same circuit + setup rendered as a websnark-format key on the host (small sizes; tests). */
+int zkr_synth_websnark(unsigned log_m, unsigned n_public, uint64_t circuit_seed, uint64_t toxic_seed, int device,
+                       void **pk_out, size_t *pk_len, void **witness_out, size_t *witness_len);
+void zkr_free(void *p);
+
+/* Integer-ALU microbenchmark: sustained Fq Montgomery multiplications per second on `device`
+ * (each = 136 32x32 multiply-adds); used for the secondary (VALU) roofline. */
+int zkr_bench_fq_mul(int device, double *gmuls_per_s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZKR_H */

@@ -1,0 +1,66 @@
+// host_arith_shim.cpp -- exposes the device field/curve templates, compiled for the HOST, through a
+// tiny C ABI so tests/test_host_arith.py can check them against the oracle without a GPU.
+// Not part of the product path (the product is libzkr_hip.so).
+#include "hostops.hpp"
+using namespace zkr;
+
+extern "C" {
+// op: 0 mul, 1 add, 2 sub, 3 inv(a), 4 neg(a), 5 sqr(a); inputs/outputs standard form
+void zkt_fp(int field, int op, const uint8_t *a, const uint8_t *b, uint8_t *out) {
+  if (field == 0) {
+    Fq x = to_mont(load_fp<FqParams>(a)), y = to_mont(load_fp<FqParams>(b)), r;
+    switch (op) { case 0: r = mul(x, y); break; case 1: r = add(x, y); break; case 2: r = sub(x, y); break;
+                  case 3: r = inv(x); break; case 4: r = neg(x); break; default: r = sqr(x); }
+    store_fp(out, from_mont(r));
+  } else {
+    Fr x = to_mont(load_fp<FrParams>(a)), y = to_mont(load_fp<FrParams>(b)), r;
+    switch (op) { case 0: r = mul(x, y); break; case 1: r = add(x, y); break; case 2: r = sub(x, y); break;
+                  case 3: r = inv(x); break; case 4: r = neg(x); break; default: r = sqr(x); }
+    store_fp(out, from_mont(r));
+  }
+}
+// a, b: 64 B standard (re, im); op 0 mul, 1 sqr(a), 2 inv(a)
+void zkt_fq2(int op, const uint8_t *a, const uint8_t *b, uint8_t *out) {
+  Fq2 x{to_mont(load_fp<FqParams>(a)), to_mont(load_fp<FqParams>(a + 32))};
+  Fq2 y{to_mont(load_fp<FqParams>(b)), to_mont(load_fp<FqParams>(b + 32))};
+  Fq2 r = op == 0 ? mul(x, y) : op == 1 ? sqr(x) : inv(x);
+  store_fp(out, from_mont(r.a));
+  store_fp(out + 32, from_mont(r.b));
+}
+// k*P with mixed adds only (exercises add_mixed incl. its doubling branch) -> std affine; returns 1 if infinity
+int zkt_g1_mul(const uint8_t *p_mont, const uint8_t *k32, uint8_t *out) {
+  G1Affine p = load_g1(p_mont);
+  U256 k = load_u256(k32);
+  G1XYZZ acc = G1XYZZ::inf();
+  for (int i = 255; i >= 0; i--) {
+    acc = dbl_xyzz(acc);
+    if ((k.v[i >> 5] >> (i & 31)) & 1) acc = add_mixed(acc, p);
+  }
+  if (acc.is_inf()) return 1;
+  store_g1_std(out, to_affine(acc));
+  return 0;
+}
+int zkt_g2_mul(const uint8_t *p_mont, const uint8_t *k32, uint8_t *out) {
+  G2Affine p = load_g2(p_mont);
+  U256 k = load_u256(k32);
+  G2XYZZ acc = scalar_mul(to_xyzz(p), k);
+  if (acc.is_inf()) return 1;
+  store_g2_std(out, to_affine(acc));
+  return 0;
+}
+// (a*P) + (b*P) through add_full / add_mixed(neg) corner cases: returns std affine of a*P + sign*b*P
+int zkt_g1_lincomb(const uint8_t *p_mont, uint32_t a, uint32_t b, int negate_b, uint8_t *out) {
+  G1Affine p = load_g1(p_mont);
+  G1XYZZ pa = mul_small(to_xyzz(p), a), pb = mul_small(to_xyzz(p), b);
+  G1XYZZ r;
+  if (!pb.is_inf()) {
+    G1Affine qb = to_affine(pb);
+    r = add_mixed(pa, qb, negate_b != 0);
+  } else {
+    r = pa;
+  }
+  if (r.is_inf()) return 1;
+  store_g1_std(out, to_affine(r));
+  return 0;
+}
+}

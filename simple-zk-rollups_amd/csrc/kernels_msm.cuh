@@ -1,0 +1,279 @@
+// kernels_msm.cuh -- multi-scalar multiplication over G1 / G2 (Pippenger bucket method) and the
+// fixed-base kernels of the device-side setup.
+//
+// Path: the five multiexps of websnark's groth16GenProof (call site
+// /root/reference/operator/src/snarks/common.ts:29).  Integer VALU work only (v_mad_u64_u32): no MFMA.
+//
+// Pipeline per MSM (all on one stream, no host round trip until the K window sums come back):
+//   count    : signed c-bit digits of every scalar -> histogram over K * 2^(c-1) buckets
+//   scan     : exclusive prefix sum -> bucket offsets; buckets larger than `big_thresh` are listed
+//   scatter  : (point index, sign) entries grouped by bucket (counting sort)
+//   accum    : one thread per bucket, XYZZ += affine point (8M+2S), points gathered from the key table
+//   big      : one workgroup per oversized bucket (0/1-heavy witnesses), LDS tree of XYZZ sums
+//   reduce   : sum_b b*B_b per window: thread per group of g buckets (running sums) + small multiple
+//   final    : one workgroup per window adds the group results -> K window sums (host does Horner)
+#pragma once
+#include "curve.cuh"
+
+namespace zkr {
+
+constexpr int MSM_THREADS = 256;
+constexpr int MSM_MAX_WINDOWS = 64;
+
+template <class F> struct PointBytes;
+template <> struct PointBytes<Fq> { static constexpr int N16 = 4; };   // 64 B affine
+template <> struct PointBytes<Fq2> { static constexpr int N16 = 8; };  // 128 B affine
+
+template <class T>
+__device__ __forceinline__ T load_pod(const T *p) {
+  static_assert(sizeof(T) % 16 == 0, "16-byte granules");
+  T r;
+  const uint4 *q = reinterpret_cast<const uint4 *>(p);
+  uint4 *d = reinterpret_cast<uint4 *>(&r);
+#pragma unroll
+  for (unsigned i = 0; i < sizeof(T) / 16; i++) d[i] = q[i];
+  return r;
+}
+template <class T>
+__device__ __forceinline__ void store_pod(T *p, const T &v) {
+  static_assert(sizeof(T) % 16 == 0, "16-byte granules");
+  uint4 *q = reinterpret_cast<uint4 *>(p);
+  const uint4 *s = reinterpret_cast<const uint4 *>(&v);
+#pragma unroll
+  for (unsigned i = 0; i < sizeof(T) / 16; i++) q[i] = s[i];
+}
+
+struct MsmGeom {
+  uint32_t n;        // points
+  int c;             // window bits
+  int K;             // windows
+  uint32_t nbw;      // buckets per window = 2^(c-1)
+  uint32_t big_thresh;
+  int glog;          // reduce group = 2^glog buckets
+};
+
+// Signed-digit recoding state: scalar kept in 8 registers and shifted right by c each window so the
+// digit is always the low bits (no runtime-indexed register array -> no scratch).
+struct DigitIter {
+  uint32_t s[8];
+  uint32_t carry;
+  __device__ __forceinline__ void init(const uint32_t *p) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+    uint4 a = q[0], b = q[1];
+    s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w; s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
+    carry = 0;
+  }
+  __device__ __forceinline__ bool is_zero() const {
+    return (s[0] | s[1] | s[2] | s[3] | s[4] | s[5] | s[6] | s[7] | carry) == 0;
+  }
+  // returns signed digit in [-2^(c-1), 2^(c-1)]
+  __device__ __forceinline__ int next(int c) {
+    uint32_t raw = (s[0] & ((1u << c) - 1)) + carry;
+#pragma unroll
+    for (int i = 0; i < 7; i++) s[i] = (s[i] >> c) | (s[i + 1] << (32 - c));
+    s[7] >>= c;
+    int d = (int)raw;
+    if (raw > (1u << (c - 1))) { d -= (1 << c); carry = 1; } else { carry = 0; }
+    return d;
+  }
+};
+
+__device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
+
+// histogram of bucket occupancies.  Digit +-1 (booleans, w_0 = 1) is aggregated per wavefront so that
+// thousands of lanes do not serialise on one L2 atomic.
+static __global__ __launch_bounds__(MSM_THREADS) void msm_count_kernel(const Fr *scalars, const uint32_t *sidx, MsmGeom g, uint32_t *counts) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool live = i < g.n;
+  DigitIter it;
+  if (live) it.init(scalars[sidx ? sidx[i] : i].v); else { for (int k = 0; k < 8; k++) it.s[k] = 0; it.carry = 0; }
+  for (int k = 0; k < g.K; k++) {
+    int d = it.next(g.c);
+    bool one = live && (d == 1 || d == -1);
+    unsigned long long m = __ballot(one);
+    if (m) {
+      if (one && lane_id() == (uint32_t)__ffsll((long long)m) - 1) atomicAdd(&counts[k * g.nbw], (uint32_t)__popcll(m));
+    }
+    if (live && d != 0 && !one) atomicAdd(&counts[k * g.nbw + (uint32_t)(d < 0 ? -d : d) - 1], 1u);
+  }
+}
+
+// single-workgroup exclusive scan of nb counts -> offsets[0..nb], cursor = offsets; lists big buckets
+static __global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t *counts, uint32_t *offsets, uint32_t *cursor, uint32_t nb,
+                                                        uint32_t big_thresh, uint32_t *big_list, uint32_t *big_count, uint32_t big_cap) {
+  __shared__ uint32_t part[1024];
+  uint32_t t = threadIdx.x;
+  uint32_t per = (nb + 1023) / 1024;
+  uint32_t lo = t * per, hi = min(lo + per, nb);
+  uint32_t s = 0;
+  for (uint32_t b = lo; b < hi; b++) s += counts[b];
+  part[t] = s;
+  __syncthreads();
+  for (uint32_t off = 1; off < 1024; off <<= 1) {
+    uint32_t v = t >= off ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  uint32_t run = part[t] - s;
+  for (uint32_t b = lo; b < hi; b++) {
+    uint32_t cnt = counts[b];
+    offsets[b] = run;
+    cursor[b] = run;
+    if (cnt > big_thresh) {
+      uint32_t k = atomicAdd(big_count, 1u);
+      if (k < big_cap) big_list[k] = b;
+    }
+    run += cnt;
+  }
+  if (t == 1023) offsets[nb] = part[1023];
+}
+
+// entries[pos] = (point index << 1) | sign, grouped by bucket
+static __global__ __launch_bounds__(MSM_THREADS) void msm_scatter_kernel(const Fr *scalars, const uint32_t *sidx, MsmGeom g, uint32_t *cursor, uint32_t *entries) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool live = i < g.n;
+  DigitIter it;
+  if (live) it.init(scalars[sidx ? sidx[i] : i].v); else { for (int k = 0; k < 8; k++) it.s[k] = 0; it.carry = 0; }
+  for (int k = 0; k < g.K; k++) {
+    int d = it.next(g.c);
+    bool one = live && (d == 1 || d == -1);
+    unsigned long long m = __ballot(one);
+    if (m) {
+      uint32_t leader = (uint32_t)__ffsll((long long)m) - 1;
+      uint32_t base = 0;
+      if (one && lane_id() == leader) base = atomicAdd(&cursor[k * g.nbw], (uint32_t)__popcll(m));
+      base = __shfl(base, leader);
+      if (one) {
+        uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane_id()) - 1));
+        entries[base + rank] = (i << 1) | (d < 0 ? 1u : 0u);
+      }
+    }
+    if (live && d != 0 && !one) {
+      uint32_t pos = atomicAdd(&cursor[k * g.nbw + (uint32_t)(d < 0 ? -d : d) - 1], 1u);
+      entries[pos] = (i << 1) | (d < 0 ? 1u : 0u);
+    }
+  }
+}
+
+// bucket accumulation: thread per bucket
+template <class F, int MINW>
+static __global__ __launch_bounds__(MSM_THREADS, MINW) void msm_accum_kernel(const Affine<F> *points, const uint32_t *offsets, const uint32_t *entries,
+                                                                     uint32_t nb, uint32_t big_thresh, XYZZ<F> *buckets) {
+  uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nb) return;
+  uint32_t o0 = offsets[b], o1 = offsets[b + 1];
+  if (o1 - o0 > big_thresh) return;  // msm_big_kernel owns it
+  XYZZ<F> acc = XYZZ<F>::inf();
+  for (uint32_t j = o0; j < o1; j++) {
+    uint32_t e = entries[j];
+    Affine<F> p = load_pod(points + (e >> 1));
+    acc = add_mixed(acc, p, (e & 1) != 0);
+  }
+  store_pod(buckets + b, acc);
+}
+
+// oversized buckets: workgroup per bucket, strided accumulation then LDS tree
+template <class F, int MINW>
+static __global__ __launch_bounds__(MSM_THREADS, MINW) void msm_big_kernel(const Affine<F> *points, const uint32_t *offsets, const uint32_t *entries,
+                                                                   const uint32_t *big_list, const uint32_t *big_count, uint32_t big_cap,
+                                                                   XYZZ<F> *buckets) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  XYZZ<F> *sh = reinterpret_cast<XYZZ<F> *>(smem);
+  uint32_t nbig = min(*big_count, big_cap);
+  for (uint32_t w = blockIdx.x; w < nbig; w += gridDim.x) {
+    uint32_t b = big_list[w];
+    uint32_t o0 = offsets[b], o1 = offsets[b + 1];
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (uint32_t j = o0 + threadIdx.x; j < o1; j += MSM_THREADS) {
+      uint32_t e = entries[j];
+      Affine<F> p = load_pod(points + (e >> 1));
+      acc = add_mixed(acc, p, (e & 1) != 0);
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (uint32_t s = MSM_THREADS / 2; s > 0; s >>= 1) {
+      if (threadIdx.x < s) sh[threadIdx.x] = add_full(sh[threadIdx.x], sh[threadIdx.x + s]);
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) store_pod(buckets + b, sh[0]);
+    __syncthreads();
+  }
+}
+
+// per group of 2^glog buckets of one window: sum_j (digit value) * B_j
+template <class F, int MINW>
+static __global__ __launch_bounds__(MSM_THREADS, MINW) void msm_reduce_kernel(const XYZZ<F> *buckets, MsmGeom g, XYZZ<F> *group_out) {
+  uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t groups_per_window = g.nbw >> g.glog;
+  if (gid >= groups_per_window * (uint32_t)g.K) return;
+  uint32_t k = gid / groups_per_window, t = gid % groups_per_window;
+  uint32_t gs = 1u << g.glog;
+  const XYZZ<F> *B = buckets + (size_t)k * g.nbw + (size_t)t * gs;
+  XYZZ<F> run = XYZZ<F>::inf(), T = XYZZ<F>::inf();
+  for (int j = (int)gs - 1; j >= 0; j--) {
+    run = add_full(run, load_pod(B + j));
+    T = add_full(T, run);
+  }
+  // bucket j of this group holds digit value t*gs + j + 1:  T = sum (j+1) B_j, run = sum B_j
+  if (t) T = add_full(T, mul_small(run, t * gs));
+  store_pod(group_out + gid, T);
+}
+
+// workgroup per window: add the group results
+template <class F, int MINW>
+static __global__ __launch_bounds__(MSM_THREADS, MINW) void msm_final_kernel(const XYZZ<F> *group_out, uint32_t groups_per_window, XYZZ<F> *window_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  XYZZ<F> *sh = reinterpret_cast<XYZZ<F> *>(smem);
+  const XYZZ<F> *G = group_out + (size_t)blockIdx.x * groups_per_window;
+  XYZZ<F> acc = XYZZ<F>::inf();
+  for (uint32_t j = threadIdx.x; j < groups_per_window; j += MSM_THREADS) acc = add_full(acc, load_pod(G + j));
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (uint32_t s = MSM_THREADS / 2; s > 0; s >>= 1) {
+    if (threadIdx.x < s) sh[threadIdx.x] = add_full(sh[threadIdx.x], sh[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) store_pod(window_out + blockIdx.x, sh[0]);
+}
+
+// ---------------------------------------------------------------- device-side setup
+// out[i] = scalar[i] * G through a fixed-base table T[j][d] = d * 2^(8j) * G (j < 32, d < 256; d = 0 unused),
+// converted to the affine Montgomery wire form (infinity -> x = 0, y = one; binarify.ts:92-102).
+template <class F, int MINW>
+static __global__ __launch_bounds__(MSM_THREADS, MINW) void fixed_base_kernel(const Affine<F> *table, const Fr *scalars, size_t n, Affine<F> *out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  DigitIter it;
+  it.init(scalars[i].v);
+  XYZZ<F> acc = XYZZ<F>::inf();
+  for (int j = 0; j < 32; j++) {
+    uint32_t d = it.s[0] & 255u;
+#pragma unroll
+    for (int k = 0; k < 7; k++) it.s[k] = (it.s[k] >> 8) | (it.s[k + 1] << 24);
+    it.s[7] >>= 8;
+    if (d) acc = add_mixed(acc, load_pod(table + j * 256 + d));
+  }
+  store_pod(out + i, to_affine(acc));
+}
+
+// out[j] = in[idx[j]]  (table compaction / permutation at key build)
+template <class T>
+static __global__ void gather_kernel(const T *in, const uint32_t *idx, size_t n, T *out) {
+  size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  store_pod(out + j, load_pod(in + idx[j]));
+}
+
+// VALU roofline microbenchmark: dependent chains of Fq Montgomery products, 4 independent chains/lane
+static __global__ __launch_bounds__(MSM_THREADS) void fq_mul_bench_kernel(Fq *io, int iters) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  Fq a = load_pod(io + i), b = a, c = a, d = a;
+  b.v[0] ^= 1; c.v[1] ^= 2; d.v[2] ^= 3;
+  for (int k = 0; k < iters; k++) {
+    a = mul(a, b); b = mul(b, c); c = mul(c, d); d = mul(d, a);
+  }
+  store_pod(io + i, add(add(a, b), add(c, d)));
+}
+
+}  // namespace zkr

@@ -1,0 +1,194 @@
+// kernels_ntt.cuh -- BN254 Fr NTT passes, QAP row evaluation and the element-wise stages of calcH.
+//
+// Path: websnark groth16GenProof's calcH (called at /root/reference/operator/src/snarks/common.ts:29;
+// algorithm SURVEY.md App. B steps 1-3).  Vectors stay in STANDARD form in HBM, every constant
+// (twiddles, QAP coefficients) is in Montgomery form, so montmul(data, const) needs no conversions.
+//
+// NTT decomposition (prototyped index-for-index in tests/test_ntt_plan.py):
+//   radix-2 network split into passes; one pass = all stages with span 2^j, j in [lo,hi), executed
+//   inside LDS on a tile of 2^(hi-lo) rows x W columns (W consecutive elements -> 32*W contiguous
+//   bytes per row in HBM).  DIF passes run top-down (natural in -> bit-reversed out), DIT passes
+//   bottom-up (bit-reversed in -> natural out), so no explicit permutation is ever done.
+//   LDS tile is limb-major (SoA): lane l touches bank (l mod 32) for every ds_read_b32 -> conflict free.
+//   Twiddles w_{2s}^x come from one table per key (w_{2m}^k, k<m, serves all spans up to m and the
+//   coset factors) plus a 32 KB table w_2048^k shared by every contiguous pass (L1/L2 resident).
+#pragma once
+#include "curve.cuh"
+
+namespace zkr {
+
+constexpr int NTT_THREADS = 256;
+constexpr int NTT_TILE_LOG = 11;   // 2048 elements = 64 KB of LDS per workgroup (2 workgroups / CU)
+constexpr int NTT_STRIDED_LOG = 9; // stages per strided pass
+constexpr int NTT_W_LOG = 2;       // 4 columns = 128 B contiguous per row in a strided pass
+constexpr int TWL_LOG = 10;        // local table: w_2048^k, k < 1024
+
+struct Vec32 { uint4 a, b; };
+
+__device__ __forceinline__ Fr load_fr(const Fr *p) {
+  const uint4 *q = reinterpret_cast<const uint4 *>(p);
+  uint4 a = q[0], b = q[1];
+  Fr r;
+  r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+  r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+  return r;
+}
+__device__ __forceinline__ void store_fr(Fr *p, const Fr &r) {
+  uint4 *q = reinterpret_cast<uint4 *>(p);
+  q[0] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
+  q[1] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
+}
+
+// w_{2s}^x (inverse: w_{2s}^-x) from a table T[k] = w_{2^(tlog+1)}^k, k < 2^tlog; needs slog <= tlog, x < s
+__device__ __forceinline__ Fr tw_lookup(const Fr *table, int tlog, int slog, uint32_t x, bool inverse) {
+  uint32_t idx = x << (tlog - slog);
+  if (!inverse) return load_fr(table + idx);
+  if (idx == 0) return Fr::one();
+  return neg(load_fr(table + ((1u << tlog) - idx)));  // w^(2^tlog) = -1
+}
+
+enum NttPre { PRE_NONE = 0, PRE_COSET = 1, PRE_MUL = 2 };
+
+struct NttPassArgs {
+  const Fr *in0;   // input (may alias out)
+  const Fr *in1;   // second operand for PRE_MUL
+  Fr *out;
+  const Fr *tw;    // w_{2^(tlog+1)}^k table
+  const Fr *twl;   // w_2048^k table
+  int tlog;        // log2 of tw entries
+  int L;           // transform size 2^L
+  int lo, hi;      // stages [lo,hi)
+  int wlog;        // log2 columns per tile (0 when lo == 0)
+  int inverse;     // use inverse twiddles
+  int pre;         // NttPre
+};
+
+// one pass; grid = 2^L / tile, block = NTT_THREADS, dynamic LDS = 32 * tile bytes
+template <bool DIF>
+static __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  const int nb = a.hi - a.lo;
+  const uint32_t rows = 1u << nb, W = 1u << a.wlog;
+  const uint32_t tile = rows << a.wlog;
+  const uint32_t lb = (1u << a.lo) >> a.wlog;  // tiles per q
+  const uint32_t q = blockIdx.x / lb, l0 = (blockIdx.x % lb) << a.wlog;
+  const size_t base = ((size_t)q << a.hi) + l0;
+
+  for (uint32_t e = threadIdx.x; e < tile; e += NTT_THREADS) {
+    uint32_t r = e >> a.wlog, c = e & (W - 1);
+    size_t gi = base + ((size_t)r << a.lo) + c;
+    Fr x = load_fr(a.in0 + gi);
+    if (a.pre == PRE_COSET) {
+      uint32_t br = __brev((uint32_t)gi) >> (32 - a.L);  // coefficient index of a bit-reversed position
+      x = mul(x, load_fr(a.tw + ((size_t)br << (a.tlog - a.L))));
+    } else if (a.pre == PRE_MUL) {
+      x = mul(x, load_fr(a.in1 + gi));
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) lds[k * tile + e] = x.v[k];
+  }
+  __syncthreads();
+
+  const uint32_t nbf = tile >> 1;
+  for (int jj = 0; jj < nb; jj++) {
+    const int j = DIF ? nb - 1 - jj : jj;
+    const uint32_t sl = 1u << j;
+    const int slog = j + a.lo;  // log2 of the global span
+    const Fr *table = slog <= TWL_LOG ? a.twl : a.tw;
+    const int tlog = slog <= TWL_LOG ? TWL_LOG : a.tlog;
+    for (uint32_t b = threadIdx.x; b < nbf; b += NTT_THREADS) {
+      uint32_t c = b & (W - 1), kk = b >> a.wlog;
+      uint32_t r0 = ((kk >> j) << (j + 1)) | (kk & (sl - 1));
+      uint32_t e0 = (r0 << a.wlog) + c, e1 = e0 + (sl << a.wlog);
+      uint32_t imods = ((kk & (sl - 1)) << a.lo) + l0 + c;  // i mod s
+      Fr w = tw_lookup(table, tlog, slog, imods, a.inverse != 0);
+      Fr u, v;
+#pragma unroll
+      for (int k = 0; k < 8; k++) { u.v[k] = lds[k * tile + e0]; v.v[k] = lds[k * tile + e1]; }
+      Fr x0, x1;
+      if (DIF) {
+        x0 = add(u, v);
+        x1 = mul(sub(u, v), w);
+      } else {
+        v = mul(v, w);
+        x0 = add(u, v);
+        x1 = sub(u, v);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; k++) { lds[k * tile + e0] = x0.v[k]; lds[k * tile + e1] = x1.v[k]; }
+    }
+    __syncthreads();
+  }
+
+  for (uint32_t e = threadIdx.x; e < tile; e += NTT_THREADS) {
+    uint32_t r = e >> a.wlog, c = e & (W - 1);
+    size_t gi = base + ((size_t)r << a.lo) + c;
+    Fr x;
+#pragma unroll
+    for (int k = 0; k < 8; k++) x.v[k] = lds[k * tile + e];
+    store_fr(a.out + gi, x);
+  }
+}
+
+// T[k] = g^k (Montgomery), k < n, g given in Montgomery form: thread k does square-and-multiply
+static __global__ void twiddle_table_kernel(Fr *T, uint32_t n, Fr g) {
+  uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  Fr r = Fr::one(), b = g;
+  for (uint32_t e = k; e; e >>= 1) {
+    if (e & 1) r = mul(r, b);
+    b = sqr(b);
+  }
+  store_fr(T + k, r);
+}
+
+// witness ingest: reduce every 256-bit word below r (values from calculateWitness already are; this
+// makes the path total for any buffer binarifyWitness can produce, binarify.ts:18-26)
+static __global__ void ingest_kernel(const Fr *in, Fr *out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fr x = load_fr(in + i);
+#pragma unroll 1
+  for (int k = 0; k < 5; k++) x = reduce_once(x);  // 2^256 < 6r
+  store_fr(out + i, x);
+}
+
+// QAP evaluation on the domain: out[c] = sum_k coef[k] * w[col[k]] over CSR row c.
+// coef Montgomery, w standard -> out standard.  One thread per constraint row (rows are 1-3 terms,
+// with occasional 64-term packing rows).
+static __global__ void spmv_kernel(const uint32_t *row_ptr, const uint32_t *col, const Fr *coef, const Fr *w, Fr *out, uint32_t m) {
+  uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= m) return;
+  uint32_t k0 = row_ptr[c], k1 = row_ptr[c + 1];
+  Fr acc = Fr::zero();
+  for (uint32_t k = k0; k < k1; k++) acc = add(acc, mul(load_fr(coef + k), load_fr(w + col[k])));
+  store_fr(out + c, acc);
+}
+
+// h (bit-reversed order) = C1*S' - C2 * g^-i * D'   (DESIGN.md "calcH on the GPU"); S', D' are the
+// unscaled inverse-DIF outputs of a.b and A(gw^c).B(gw^c); i = bitrev(pos).
+static __global__ void combine_h_kernel(const Fr *S, const Fr *D, Fr *h, const Fr *tw, int tlog, int L, Fr c1, Fr c2) {
+  uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pos >= (1u << L)) return;
+  uint32_t i = __brev(pos) >> (32 - L);
+  Fr ginv = tw_lookup(tw, tlog, L, i, true);  // g^-i, g = w_{2m}
+  Fr s = mul(load_fr(S + pos), c1);
+  Fr d = mul(mul(load_fr(D + pos), ginv), c2);
+  store_fr(h + pos, sub(s, d));
+}
+
+// out[i] = in[bitrev(i)]  (test hooks only)
+static __global__ void bitrev_copy_kernel(const Fr *in, Fr *out, int L) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (1u << L)) return;
+  uint32_t j = L ? __brev(i) >> (32 - L) : 0;
+  store_fr(out + i, load_fr(in + j));
+}
+// x[i] *= c
+static __global__ void scale_kernel(Fr *x, size_t n, Fr c) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  store_fr(x + i, mul(load_fr(x + i), c));
+}
+
+}  // namespace zkr

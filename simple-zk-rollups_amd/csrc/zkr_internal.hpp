@@ -1,0 +1,103 @@
+// zkr_internal.hpp -- host-side structures shared by the translation units of libzkr_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/zkr.h"
+#include "hostops.hpp"
+
+namespace zkr {
+
+void set_error(const char *fmt, ...);
+#define ZKR_HIP_CHECK(expr)                                                                 \
+  do {                                                                                      \
+    hipError_t _e = (expr);                                                                 \
+    if (_e != hipSuccess) {                                                                 \
+      set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return ZKR_ERR_HIP;                                                                   \
+    }                                                                                       \
+  } while (0)
+
+enum { T_A = 0, T_B1 = 1, T_B2 = 2, T_C = 3, T_H = 4, N_TABLES = 5 };
+
+// The device key is ONE position-independent arena: header + sections addressed by byte offsets,
+// so a replica on another GPU is a single broadcast of [arena, arena+len).
+struct ArenaHeader {
+  uint64_t magic;      // "ZKRKEY01"
+  uint64_t total_len;
+  uint32_t n, p, m, logm;
+  uint32_t nnzA, nnzB;
+  uint32_t npts[N_TABLES];
+  uint32_t tlog;       // twiddle table entries = 2^tlog (= m)
+  uint64_t off_tw, off_twl;
+  uint64_t off_rowptr[2], off_col[2], off_coef[2];
+  uint64_t off_pts[N_TABLES], off_sidx[N_TABLES];
+  uint8_t alfa1[64], beta1[64], delta1[64];  // Montgomery affine, as in the websnark key header
+  uint8_t beta2[128], delta2[128];
+  uint8_t pad[64];
+};
+static_assert(sizeof(ArenaHeader) <= 1024, "header fits its slot");
+constexpr size_t ARENA_HEADER_BYTES = 1024;
+constexpr uint64_t ARENA_MAGIC = 0x313059454b524b5aull;
+
+struct MsmWorkspace {
+  uint32_t *counts = nullptr, *offsets = nullptr, *cursor = nullptr, *entries = nullptr;
+  uint32_t *big_list = nullptr, *big_count = nullptr;
+  void *buckets = nullptr, *group_out = nullptr, *window_out = nullptr;
+  void *h_window = nullptr;  // pinned host copy of the window sums
+  size_t max_nb = 0, max_entries = 0;
+};
+
+struct ProfStage {
+  std::string name;
+  double ms = 0;
+  uint64_t launches = 0;
+};
+struct ProfSpan {
+  int stage;
+  hipEvent_t e0, e1;
+};
+
+struct MsmPlan {
+  int c, K, glog;
+  uint32_t nbw, nb, big_thresh;
+};
+
+}  // namespace zkr
+
+struct zkr_key {
+  int device = 0;
+  unsigned char *arena = nullptr;
+  size_t arena_len = 0;
+  bool owns_arena = true;
+  zkr::ArenaHeader h;
+  hipStream_t stream = nullptr;
+  // workspace
+  zkr::Fr *d_wraw = nullptr, *d_w = nullptr, *va = nullptr, *vb = nullptr, *ca = nullptr, *cb = nullptr, *d_h = nullptr;
+  zkr::MsmWorkspace ws[zkr::N_TABLES];  // one per table so the five MSMs can be enqueued back to back
+  zkr::MsmPlan plan[zkr::N_TABLES];
+  // profiling
+  bool prof_on = false;
+  std::vector<zkr::ProfStage> stages;
+  std::vector<zkr::ProfSpan> spans;
+  std::vector<hipEvent_t> event_pool;
+  size_t event_next = 0;
+};
+
+namespace zkr {
+// zkr_key.hip
+int key_build(int device, uint32_t n, uint32_t p, uint32_t m, const std::vector<uint32_t> rowptr[2], const std::vector<uint32_t> col[2],
+              const std::vector<uint8_t> coef[2], const void *const tbl_src[N_TABLES], const bool tbl_src_on_device[N_TABLES],
+              const std::vector<uint32_t> tbl_srcidx[N_TABLES], const std::vector<uint32_t> tbl_sidx[N_TABLES], const uint8_t *consts448,
+              zkr_key **out);
+int key_alloc_workspace(zkr_key *k);
+int fixed_base_points(int device, bool g2, const uint8_t *scalars_std, size_t n, void **d_out);  // device array of affine Montgomery points
+// zkr_prove.hip
+int prof_begin(zkr_key *k, hipStream_t s, const char *stage);
+void prof_end(zkr_key *k, hipStream_t s, int span);
+int prof_collect(zkr_key *k);
+int run_ntt(hipStream_t s, const Fr *in0, const Fr *in1, Fr *out, const Fr *tw, const Fr *twl, int tlog, int L, bool dif, bool inverse, int pre);
+int calc_h_device(zkr_key *k, hipStream_t s);  // d_w -> d_h (bit-reversed)
+MsmPlan msm_plan(size_t n);
+}  // namespace zkr

@@ -1,0 +1,379 @@
+// zkr_key.hip -- proving-key ingestion: websnark binary -> device arena (CSR QAP rows, compacted
+// Montgomery point tables, twiddle tables), replication hooks, workspace, fixed-base setup kernels.
+//
+// Replaces the key handling inside groth16GenProof (/root/reference/operator/src/snarks/common.ts:28-29);
+// input layout is the one binarifyProvingKey writes (/root/reference/operator/src/utils/binarify.ts:143-206).
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include "kernels_msm.cuh"
+#include "kernels_ntt.cuh"
+#include "zkr_internal.hpp"
+
+namespace zkr {
+
+static thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+static inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// w_{2^k} in Montgomery form: 5^((r-1)/2^k) (5 = smallest quadratic non-residue mod r)
+static Fr fr_root_of_unity(unsigned k) {
+  Fr five = Fr::zero();
+  five.v[0] = 5;
+  Fr g = to_mont(five);
+  uint32_t e[8];
+  for (int i = 0; i < 8; i++) e[i] = FrParams::P[i];
+  e[0] -= 1;
+  // e >>= 28
+  for (int i = 0; i < 8; i++) e[i] = (e[i] >> 28) | (i < 7 ? e[i + 1] << 4 : 0);
+  Fr r = Fr::one(), b = g;
+  for (int i = 0; i < 256; i++) {
+    if ((e[i >> 5] >> (i & 31)) & 1) r = mul(r, b);
+    b = sqr(b);
+  }
+  for (unsigned j = k; j < 28; j++) r = sqr(r);
+  return r;
+}
+Fr host_root_of_unity(unsigned k) { return fr_root_of_unity(k); }
+
+MsmPlan msm_plan(size_t n) {
+  MsmPlan pl;
+  int lg = 0;
+  while (((size_t)1 << lg) < n) lg++;
+  int c = lg - 4;
+  if (c < 4) c = 4;
+  if (c > 16) c = 16;
+  if (const char *e = getenv("ZKR_MSM_C")) { int v = atoi(e); if (v >= 2 && v <= 20) c = v; }
+  pl.c = c;
+  pl.K = (255 + c - 1) / c;
+  pl.nbw = 1u << (c - 1);
+  pl.nb = pl.nbw * (uint32_t)pl.K;
+  pl.glog = c - 1 < 4 ? c - 1 : 4;
+  uint32_t mean = (uint32_t)(n / pl.nbw) + 1;
+  pl.big_thresh = mean * 8 > 256 ? mean * 8 : 256;
+  if (const char *e = getenv("ZKR_MSM_BIG")) { int v = atoi(e); if (v >= 1) pl.big_thresh = (uint32_t)v; }
+  return pl;
+}
+
+static int alloc_msm_ws(MsmWorkspace &ws, size_t n, const MsmPlan &pl, size_t xyzz_bytes) {
+  size_t nb = pl.nb;
+  ZKR_HIP_CHECK(hipMalloc(&ws.counts, (nb + 1) * 4));
+  ZKR_HIP_CHECK(hipMalloc(&ws.offsets, (nb + 1) * 4));
+  ZKR_HIP_CHECK(hipMalloc(&ws.cursor, (nb + 1) * 4));
+  ZKR_HIP_CHECK(hipMalloc(&ws.entries, (n * pl.K + 1) * 4));
+  ZKR_HIP_CHECK(hipMalloc(&ws.big_list, 4096 * 4));
+  ZKR_HIP_CHECK(hipMalloc(&ws.big_count, 4));
+  ZKR_HIP_CHECK(hipMalloc(&ws.buckets, nb * xyzz_bytes));
+  ZKR_HIP_CHECK(hipMalloc(&ws.group_out, (size_t)(pl.nbw >> pl.glog) * pl.K * xyzz_bytes));
+  ZKR_HIP_CHECK(hipMalloc(&ws.window_out, MSM_MAX_WINDOWS * xyzz_bytes));
+  ZKR_HIP_CHECK(hipHostMalloc(&ws.h_window, MSM_MAX_WINDOWS * xyzz_bytes, hipHostMallocDefault));
+  ws.max_nb = nb;
+  ws.max_entries = n * pl.K;
+  return 0;
+}
+int msm_ws_alloc(MsmWorkspace &ws, size_t n, const MsmPlan &pl, size_t xyzz_bytes) { return alloc_msm_ws(ws, n, pl, xyzz_bytes); }
+void msm_ws_free(MsmWorkspace &ws) {
+  hipFree(ws.counts); hipFree(ws.offsets); hipFree(ws.cursor); hipFree(ws.entries); hipFree(ws.big_list); hipFree(ws.big_count);
+  hipFree(ws.buckets); hipFree(ws.group_out); hipFree(ws.window_out);
+  if (ws.h_window) hipHostFree(ws.h_window);
+  ws = MsmWorkspace();
+}
+
+int key_alloc_workspace(zkr_key *k) {
+  ZKR_HIP_CHECK(hipSetDevice(k->device));
+  const ArenaHeader &h = k->h;
+  ZKR_HIP_CHECK(hipStreamCreateWithFlags(&k->stream, hipStreamNonBlocking));
+  ZKR_HIP_CHECK(hipMalloc(&k->d_wraw, (size_t)h.n * 32));
+  ZKR_HIP_CHECK(hipMalloc(&k->d_w, (size_t)h.n * 32));
+  Fr **vecs[5] = {&k->va, &k->vb, &k->ca, &k->cb, &k->d_h};
+  for (auto v : vecs) ZKR_HIP_CHECK(hipMalloc(v, (size_t)h.m * 32));
+  for (int t = 0; t < N_TABLES; t++) {
+    k->plan[t] = msm_plan(h.npts[t]);
+    int rc = alloc_msm_ws(k->ws[t], h.npts[t], k->plan[t], t == T_B2 ? sizeof(G2XYZZ) : sizeof(G1XYZZ));
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+// Builds the arena.  tbl_src[t]: full source table (host or device memory, affine Montgomery, 64/128 B
+// per point); tbl_srcidx[t][j]: source index of kept point j; tbl_sidx[t][j]: index of its scalar.
+int key_build(int device, uint32_t n, uint32_t p, uint32_t m, const std::vector<uint32_t> rowptr[2], const std::vector<uint32_t> col[2],
+              const std::vector<uint8_t> coef[2], const void *const tbl_src[N_TABLES], const bool tbl_src_on_device[N_TABLES],
+              const std::vector<uint32_t> tbl_srcidx[N_TABLES], const std::vector<uint32_t> tbl_sidx[N_TABLES], const uint8_t *consts448,
+              zkr_key **out) {
+  ZKR_HIP_CHECK(hipSetDevice(device));
+  ArenaHeader h;
+  memset(&h, 0, sizeof(h));
+  h.magic = ARENA_MAGIC;
+  h.n = n; h.p = p; h.m = m;
+  h.logm = 0;
+  while ((1u << h.logm) < m) h.logm++;
+  h.tlog = h.logm;
+  h.nnzA = (uint32_t)col[0].size();
+  h.nnzB = (uint32_t)col[1].size();
+  memcpy(h.alfa1, consts448, 64); memcpy(h.beta1, consts448 + 64, 64); memcpy(h.delta1, consts448 + 128, 64);
+  memcpy(h.beta2, consts448 + 192, 128); memcpy(h.delta2, consts448 + 320, 128);
+  size_t off = ARENA_HEADER_BYTES;
+  auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return (uint64_t)o; };
+  h.off_tw = take((size_t)m * 32);
+  h.off_twl = take((size_t)(1u << TWL_LOG) * 32);
+  for (int s = 0; s < 2; s++) {
+    h.off_rowptr[s] = take(((size_t)m + 1) * 4);
+    h.off_col[s] = take(col[s].size() * 4 + 4);
+    h.off_coef[s] = take(coef[s].size() + 32);
+  }
+  for (int t = 0; t < N_TABLES; t++) {
+    h.npts[t] = (uint32_t)tbl_srcidx[t].size();
+    size_t pb = t == T_B2 ? 128 : 64;
+    h.off_pts[t] = take((size_t)h.npts[t] * pb + pb);
+    h.off_sidx[t] = take((size_t)h.npts[t] * 4 + 4);
+  }
+  h.total_len = off;
+
+  unsigned char *arena = nullptr;
+  ZKR_HIP_CHECK(hipMalloc(&arena, off));
+  ZKR_HIP_CHECK(hipMemcpy(arena, &h, sizeof(h), hipMemcpyHostToDevice));
+  for (int s = 0; s < 2; s++) {
+    ZKR_HIP_CHECK(hipMemcpy(arena + h.off_rowptr[s], rowptr[s].data(), rowptr[s].size() * 4, hipMemcpyHostToDevice));
+    if (!col[s].empty()) {
+      ZKR_HIP_CHECK(hipMemcpy(arena + h.off_col[s], col[s].data(), col[s].size() * 4, hipMemcpyHostToDevice));
+      ZKR_HIP_CHECK(hipMemcpy(arena + h.off_coef[s], coef[s].data(), coef[s].size(), hipMemcpyHostToDevice));
+    }
+  }
+  for (int t = 0; t < N_TABLES; t++) {
+    size_t np = h.npts[t], pb = t == T_B2 ? 128 : 64;
+    if (!np) continue;
+    ZKR_HIP_CHECK(hipMemcpy(arena + h.off_sidx[t], tbl_sidx[t].data(), np * 4, hipMemcpyHostToDevice));
+    if (tbl_src_on_device[t]) {
+      uint32_t *d_idx = nullptr;
+      ZKR_HIP_CHECK(hipMalloc(&d_idx, np * 4));
+      ZKR_HIP_CHECK(hipMemcpy(d_idx, tbl_srcidx[t].data(), np * 4, hipMemcpyHostToDevice));
+      unsigned grid = (unsigned)((np + 255) / 256);
+      if (t == T_B2)
+        gather_kernel<G2Affine><<<grid, 256>>>((const G2Affine *)tbl_src[t], d_idx, np, (G2Affine *)(arena + h.off_pts[t]));
+      else
+        gather_kernel<G1Affine><<<grid, 256>>>((const G1Affine *)tbl_src[t], d_idx, np, (G1Affine *)(arena + h.off_pts[t]));
+      ZKR_HIP_CHECK(hipGetLastError());
+      ZKR_HIP_CHECK(hipDeviceSynchronize());
+      hipFree(d_idx);
+    } else {
+      std::vector<uint8_t> stage(np * pb);
+      const uint8_t *src = (const uint8_t *)tbl_src[t];
+      for (size_t j = 0; j < np; j++) memcpy(&stage[j * pb], src + (size_t)tbl_srcidx[t][j] * pb, pb);
+      ZKR_HIP_CHECK(hipMemcpy(arena + h.off_pts[t], stage.data(), np * pb, hipMemcpyHostToDevice));
+    }
+  }
+  // twiddles on device: T[k] = w_{2m}^k and w_2048^k
+  twiddle_table_kernel<<<(m + 255) / 256, 256>>>((Fr *)(arena + h.off_tw), m, fr_root_of_unity(h.logm + 1));
+  twiddle_table_kernel<<<((1u << TWL_LOG) + 255) / 256, 256>>>((Fr *)(arena + h.off_twl), 1u << TWL_LOG, fr_root_of_unity(TWL_LOG + 1));
+  ZKR_HIP_CHECK(hipGetLastError());
+  ZKR_HIP_CHECK(hipDeviceSynchronize());
+
+  zkr_key *k = new zkr_key();
+  k->device = device;
+  k->arena = arena;
+  k->arena_len = off;
+  k->owns_arena = true;
+  k->h = h;
+  int rc = key_alloc_workspace(k);
+  if (rc) { zkr_key_free(k); return rc; }
+  *out = k;
+  return 0;
+}
+
+// scalars (host, std form) * generator -> device array of affine Montgomery points (caller hipFree's)
+template <class F>
+static int fixed_base_impl(int device, const Affine<F> &gen, const uint8_t *scalars_std, size_t n, void **d_out) {
+  ZKR_HIP_CHECK(hipSetDevice(device));
+  // T[j][d] = d * 2^(8j) * G on the host (8160 group operations, once per generator)
+  std::vector<Affine<F>> table(32 * 256);
+  XYZZ<F> base = to_xyzz(gen);
+  for (int j = 0; j < 32; j++) {
+    XYZZ<F> cur = XYZZ<F>::inf();
+    for (int d = 1; d < 256; d++) {
+      cur = add_full(cur, base);
+      table[j * 256 + d] = to_affine(cur);
+    }
+    table[j * 256] = Affine<F>{F::zero(), F::one()};
+    for (int b = 0; b < 8; b++) base = dbl_xyzz(base);
+  }
+  Affine<F> *d_table = nullptr, *d_pts = nullptr;
+  Fr *d_sc = nullptr;
+  ZKR_HIP_CHECK(hipMalloc(&d_table, table.size() * sizeof(Affine<F>)));
+  ZKR_HIP_CHECK(hipMalloc(&d_pts, (n + 1) * sizeof(Affine<F>)));
+  ZKR_HIP_CHECK(hipMalloc(&d_sc, (n + 1) * 32));
+  ZKR_HIP_CHECK(hipMemcpy(d_table, table.data(), table.size() * sizeof(Affine<F>), hipMemcpyHostToDevice));
+  ZKR_HIP_CHECK(hipMemcpy(d_sc, scalars_std, n * 32, hipMemcpyHostToDevice));
+  constexpr int MINW = sizeof(F) == 32 ? 2 : 1;
+  fixed_base_kernel<F, MINW><<<(unsigned)((n + 255) / 256), 256>>>(d_table, d_sc, n, d_pts);
+  ZKR_HIP_CHECK(hipGetLastError());
+  ZKR_HIP_CHECK(hipDeviceSynchronize());
+  hipFree(d_table);
+  hipFree(d_sc);
+  *d_out = d_pts;
+  return 0;
+}
+
+int fixed_base_points(int device, bool g2, const uint8_t *scalars_std, size_t n, void **d_out) {
+  if (!g2) {
+    G1Affine g{Fq::one(), add(Fq::one(), Fq::one())};  // (1, 2), TxVerifier.sol:24-26
+    return fixed_base_impl<Fq>(device, g, scalars_std, n, d_out);
+  }
+  // G2 generator, snarkjs order [re, im] (TxVerifier.sol:30-35 lists [im, re])
+  static const uint32_t GX0[8] = {0xd992f6edu, 0x46debd5cu, 0xf75edaddu, 0x674322d4u, 0x5e5c4479u, 0x426a0066u, 0x121f1e76u, 0x1800deefu};
+  static const uint32_t GX1[8] = {0xaef312c2u, 0x97e485b7u, 0x35a9e712u, 0xf1aa4933u, 0x31fb5d25u, 0x7260bfb7u, 0x920d483au, 0x198e9393u};
+  static const uint32_t GY0[8] = {0x66fa7daau, 0x4ce6cc01u, 0x0c43d37bu, 0xe3d1e769u, 0x8dcb408fu, 0x4aab7180u, 0xdb8c6debu, 0x12c85ea5u};
+  static const uint32_t GY1[8] = {0xd122975bu, 0x55acdadcu, 0x70b38ef3u, 0xbc4b3133u, 0x690c3395u, 0xec9e99adu, 0x585ff075u, 0x090689d0u};
+  G2Affine g;
+  memcpy(g.x.a.v, GX0, 32); memcpy(g.x.b.v, GX1, 32); memcpy(g.y.a.v, GY0, 32); memcpy(g.y.b.v, GY1, 32);
+  g.x.a = to_mont(g.x.a); g.x.b = to_mont(g.x.b); g.y.a = to_mont(g.y.a); g.y.b = to_mont(g.y.b);
+  return fixed_base_impl<Fq2>(device, g, scalars_std, n, d_out);
+}
+
+}  // namespace zkr
+
+using namespace zkr;
+
+extern "C" {
+
+const char *zkr_last_error(void) { return g_err; }
+const char *zkr_version(void) { return "zkr-hip 0.1 (gfx950)"; }
+
+int zkr_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+static uint32_t rd32(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); return v; }
+static bool all_zero(const uint8_t *p, size_t n) { for (size_t i = 0; i < n; i++) if (p[i]) return false; return true; }
+
+int zkr_key_load_websnark(const void *pk_bin, size_t pk_len, int device, zkr_key **out) {
+  if (!pk_bin || !out) { set_error("null argument"); return ZKR_ERR_ARG; }
+  if (zkr_device_count() <= device || device < 0) { set_error("no HIP device %d (found %d); libzkr_hip has no CPU fallback", device, zkr_device_count()); return ZKR_ERR_NO_DEVICE; }
+  const uint8_t *pk = (const uint8_t *)pk_bin;
+  if (pk_len < 488) { set_error("proving key shorter than its fixed header (488 bytes)"); return ZKR_ERR_BAD_KEY; }
+  uint32_t n = rd32(pk), p = rd32(pk + 4), m = rd32(pk + 8);
+  uint32_t ptr[7];
+  for (int i = 0; i < 7; i++) ptr[i] = rd32(pk + 12 + 4 * i);
+  if (n == 0 || p + 1 > n || m < 2 || (m & (m - 1))) { set_error("bad key geometry nVars=%u nPublic=%u domainSize=%u", n, p, m); return ZKR_ERR_BAD_KEY; }
+  if (ptr[0] != 488) { set_error("polsA pointer %u != 488", ptr[0]); return ZKR_ERR_BAD_KEY; }
+  // point sections have fixed sizes (binarify.ts:129-138)
+  uint64_t expect_end = (uint64_t)ptr[2] + 64ull * n + 64ull * n + 128ull * n + 64ull * (n - p - 1) + 64ull * m;
+  if (ptr[3] != ptr[2] + 64ull * n || ptr[4] != ptr[3] + 64ull * n || ptr[5] != ptr[4] + 128ull * n || ptr[6] != ptr[5] + 64ull * (n - p - 1) ||
+      expect_end != pk_len) {
+    set_error("section pointers/length inconsistent with nVars=%u nPublic=%u domainSize=%u (len %zu)", n, p, m, pk_len);
+    return ZKR_ERR_BAD_KEY;
+  }
+  // column-major sparse pols -> CSR rows
+  std::vector<uint32_t> rowptr[2], col[2];
+  std::vector<uint8_t> coef[2];
+  for (int s = 0; s < 2; s++) {
+    size_t o = ptr[s], end = ptr[s + 1];
+    std::vector<uint32_t> cnt(m + 1, 0);
+    size_t nnz = 0;
+    for (uint32_t sig = 0; sig < n; sig++) {
+      if (o + 4 > end) { set_error("pols section %d truncated", s); return ZKR_ERR_BAD_KEY; }
+      uint32_t kk = rd32(pk + o);
+      o += 4;
+      if (o + 36ull * kk > end) { set_error("pols section %d truncated", s); return ZKR_ERR_BAD_KEY; }
+      for (uint32_t e = 0; e < kk; e++, o += 36) {
+        uint32_t c = rd32(pk + o);
+        if (c >= m) { set_error("constraint index %u >= domainSize %u", c, m); return ZKR_ERR_BAD_KEY; }
+        cnt[c + 1]++;
+      }
+      nnz += kk;
+    }
+    if (o != end) { set_error("pols section %d has trailing bytes", s); return ZKR_ERR_BAD_KEY; }
+    rowptr[s].assign(m + 1, 0);
+    for (uint32_t c = 0; c < m; c++) rowptr[s][c + 1] = rowptr[s][c] + cnt[c + 1];
+    col[s].resize(nnz);
+    coef[s].resize(nnz * 32);
+    std::vector<uint32_t> cur(rowptr[s].begin(), rowptr[s].end() - 1);
+    o = ptr[s];
+    for (uint32_t sig = 0; sig < n; sig++) {
+      uint32_t kk = rd32(pk + o);
+      o += 4;
+      for (uint32_t e = 0; e < kk; e++, o += 36) {
+        uint32_t c = rd32(pk + o), pos = cur[c]++;
+        col[s][pos] = sig;
+        memcpy(&coef[s][(size_t)pos * 32], pk + o + 4, 32);
+      }
+    }
+  }
+  // point tables: drop points at infinity (x == 0), remember which scalar each kept point multiplies
+  const void *src[N_TABLES] = {pk + ptr[2], pk + ptr[3], pk + ptr[4], pk + ptr[5], pk + ptr[6]};
+  const bool on_dev[N_TABLES] = {false, false, false, false, false};
+  std::vector<uint32_t> srcidx[N_TABLES], sidx[N_TABLES];
+  for (uint32_t i = 0; i < n; i++) {
+    if (!all_zero(pk + ptr[2] + 64ull * i, 32)) { srcidx[T_A].push_back(i); sidx[T_A].push_back(i); }
+    if (!all_zero(pk + ptr[3] + 64ull * i, 32)) { srcidx[T_B1].push_back(i); sidx[T_B1].push_back(i); }
+    if (!all_zero(pk + ptr[4] + 128ull * i, 64)) { srcidx[T_B2].push_back(i); sidx[T_B2].push_back(i); }
+  }
+  for (uint32_t i = 0; i + p + 1 < n; i++)
+    if (!all_zero(pk + ptr[5] + 64ull * i, 32)) { srcidx[T_C].push_back(i); sidx[T_C].push_back(i + p + 1); }
+  uint32_t logm = 0;
+  while ((1u << logm) < m) logm++;
+  for (uint32_t j = 0; j < m; j++) {  // h is produced in bit-reversed order: pair position j with hExps[bitrev(j)]
+    uint32_t i = 0;
+    for (uint32_t b = 0; b < logm; b++) i |= ((j >> b) & 1) << (logm - 1 - b);
+    if (!all_zero(pk + ptr[6] + 64ull * i, 32)) { srcidx[T_H].push_back(i); sidx[T_H].push_back(j); }
+  }
+  return key_build(device, n, p, m, rowptr, col, coef, src, on_dev, srcidx, sidx, pk + 40, out);
+}
+
+void zkr_key_free(zkr_key *k) {
+  if (!k) return;
+  hipSetDevice(k->device);
+  if (k->stream) hipStreamSynchronize(k->stream);
+  for (int t = 0; t < N_TABLES; t++) msm_ws_free(k->ws[t]);
+  hipFree(k->d_wraw); hipFree(k->d_w); hipFree(k->va); hipFree(k->vb); hipFree(k->ca); hipFree(k->cb); hipFree(k->d_h);
+  for (auto e : k->event_pool) hipEventDestroy(e);
+  if (k->stream) hipStreamDestroy(k->stream);
+  if (k->owns_arena) hipFree(k->arena);
+  delete k;
+}
+
+int zkr_key_info(const zkr_key *k, uint64_t out[10]) {
+  if (!k || !out) { set_error("null argument"); return ZKR_ERR_ARG; }
+  out[0] = k->h.n; out[1] = k->h.p; out[2] = k->h.m; out[3] = k->h.nnzA; out[4] = k->h.nnzB;
+  for (int t = 0; t < N_TABLES; t++) out[5 + t] = k->h.npts[t];
+  return 0;
+}
+
+int zkr_key_arena(const zkr_key *k, void **dev_ptr, size_t *len) {
+  if (!k || !dev_ptr || !len) { set_error("null argument"); return ZKR_ERR_ARG; }
+  *dev_ptr = k->arena;
+  *len = k->arena_len;
+  return 0;
+}
+
+int zkr_key_adopt_arena(void *dev_ptr, size_t len, int device, zkr_key **out) {
+  if (!dev_ptr || !out) { set_error("null argument"); return ZKR_ERR_ARG; }
+  if (zkr_device_count() <= device || device < 0) { set_error("no HIP device %d", device); return ZKR_ERR_NO_DEVICE; }
+  ZKR_HIP_CHECK(hipSetDevice(device));
+  ArenaHeader h;
+  if (len < ARENA_HEADER_BYTES) { set_error("arena too small"); return ZKR_ERR_BAD_KEY; }
+  ZKR_HIP_CHECK(hipMemcpy(&h, dev_ptr, sizeof(h), hipMemcpyDeviceToHost));
+  if (h.magic != ARENA_MAGIC || h.total_len != len) { set_error("arena header mismatch (magic/len)"); return ZKR_ERR_BAD_KEY; }
+  zkr_key *k = new zkr_key();
+  k->device = device;
+  k->arena = (unsigned char *)dev_ptr;
+  k->arena_len = len;
+  k->owns_arena = false;
+  k->h = h;
+  int rc = key_alloc_workspace(k);
+  if (rc) { zkr_key_free(k); return rc; }
+  *out = k;
+  return 0;
+}
+
+void zkr_free(void *p) { free(p); }
+
+}  // extern "C"

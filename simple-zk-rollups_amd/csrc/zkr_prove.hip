@@ -1,0 +1,461 @@
+// zkr_prove.hip -- the hot path: one Groth16 proof on one MI355X.
+//
+// Replaces `await wasmBn128.groth16GenProof(witnessBin, provingKeyBin)`
+// (/root/reference/operator/src/snarks/common.ts:29, scripts/index.js:46).  Stages:
+//   ingest -> QAP rows (SpMV) -> 6 NTTs of size m (h = upper half of A.B) -> 5 MSMs -> host assembly.
+// Everything up to the K window sums of each MSM runs on the GPU on ONE stream with no host
+// round trip; the host then does ~20 group operations per MSM (Horner over windows) and the
+// blinding arithmetic of App. B step 4 (six 254-bit scalar multiplications).
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+#include "kernels_msm.cuh"
+#include "kernels_ntt.cuh"
+#include "zkr_internal.hpp"
+
+namespace zkr {
+int msm_ws_alloc(MsmWorkspace &ws, size_t n, const MsmPlan &pl, size_t xyzz_bytes);
+void msm_ws_free(MsmWorkspace &ws);
+Fr host_root_of_unity(unsigned k);
+
+// ------------------------------------------------------------------ profiling (hipEvents on the launch stream)
+static const char *STAGES[] = {"ingest", "spmv", "ntt", "msm_sort", "msm_accum_g1", "msm_accum_g2", "msm_reduce", "total"};
+static int stage_index(const char *name) {
+  for (int i = 0; i < (int)(sizeof(STAGES) / sizeof(STAGES[0])); i++)
+    if (!strcmp(STAGES[i], name)) return i;
+  return -1;
+}
+static hipEvent_t next_event(zkr_key *k) {
+  if (k->event_next == k->event_pool.size()) {
+    hipEvent_t e;
+    hipEventCreate(&e);
+    k->event_pool.push_back(e);
+  }
+  return k->event_pool[k->event_next++];
+}
+int prof_begin(zkr_key *k, hipStream_t s, const char *stage) {
+  if (!k || !k->prof_on) return -1;
+  ProfSpan sp;
+  sp.stage = stage_index(stage);
+  sp.e0 = next_event(k);
+  sp.e1 = next_event(k);
+  hipEventRecord(sp.e0, s);
+  k->spans.push_back(sp);
+  return (int)k->spans.size() - 1;
+}
+void prof_end(zkr_key *k, hipStream_t s, int span) {
+  if (span < 0) return;
+  hipEventRecord(k->spans[span].e1, s);
+}
+int prof_collect(zkr_key *k) {  // call after the stream is synchronised
+  if (!k->prof_on) return 0;
+  if (k->stages.empty())
+    for (auto nm : STAGES) { ProfStage st; st.name = nm; k->stages.push_back(st); }
+  for (auto &sp : k->spans) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, sp.e0, sp.e1) == hipSuccess && sp.stage >= 0) {
+      k->stages[sp.stage].ms += ms;
+      k->stages[sp.stage].launches++;
+    }
+  }
+  k->spans.clear();
+  k->event_next = 0;
+  return 0;
+}
+
+// ------------------------------------------------------------------ NTT driver
+struct PassSpec { int lo, hi, wlog; };
+static std::vector<PassSpec> ntt_plan(int L) {
+  // contiguous pass: low min(L, 11) stages; the rest in balanced chunks of <= 9 stages, listed top-down
+  std::vector<PassSpec> v;
+  int lows = L < NTT_TILE_LOG ? L : NTT_TILE_LOG;
+  int rem = L - lows;
+  if (rem > 0) {
+    int nch = (rem + NTT_STRIDED_LOG - 1) / NTT_STRIDED_LOG;
+    int hi = L;
+    for (int i = 0; i < nch; i++) {
+      int nb = (rem + (nch - i) - 1) / (nch - i);
+      int lo = hi - nb;
+      int wlog = NTT_TILE_LOG - nb;
+      if (wlog > lo) wlog = lo;
+      v.push_back({lo, hi, wlog});
+      hi = lo;
+      rem -= nb;
+    }
+  }
+  v.push_back({0, lows, 0});
+  return v;
+}
+
+int run_ntt(hipStream_t s, const Fr *in0, const Fr *in1, Fr *out, const Fr *tw, const Fr *twl, int tlog, int L, bool dif, bool inverse, int pre) {
+  std::vector<PassSpec> plan = ntt_plan(L);
+  if (!dif) std::reverse(plan.begin(), plan.end());
+  bool first = true;
+  for (auto &ps : plan) {
+    NttPassArgs a;
+    a.in0 = first ? in0 : out;
+    a.in1 = first ? in1 : nullptr;
+    a.out = out;
+    a.tw = tw; a.twl = twl; a.tlog = tlog; a.L = L;
+    a.lo = ps.lo; a.hi = ps.hi; a.wlog = ps.wlog;
+    a.inverse = inverse ? 1 : 0;
+    a.pre = first ? pre : PRE_NONE;
+    uint32_t tile = 1u << (ps.hi - ps.lo + ps.wlog);
+    uint32_t grid = (1u << L) / tile;
+    size_t lds = (size_t)tile * 32;
+    if (dif) ntt_pass_kernel<true><<<grid, NTT_THREADS, lds, s>>>(a);
+    else ntt_pass_kernel<false><<<grid, NTT_THREADS, lds, s>>>(a);
+    first = false;
+  }
+  ZKR_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+static Fr fr_from_u64(uint64_t x) {
+  Fr r = Fr::zero();
+  r.v[0] = (uint32_t)x;
+  r.v[1] = (uint32_t)(x >> 32);
+  return r;
+}
+
+// d_w (std, reduced) -> d_h (std, bit-reversed order).  See DESIGN.md "calcH on the GPU".
+int calc_h_device(zkr_key *k, hipStream_t s) {
+  const ArenaHeader &h = k->h;
+  const unsigned char *ar = k->arena;
+  const Fr *tw = (const Fr *)(ar + h.off_tw), *twl = (const Fr *)(ar + h.off_twl);
+  int L = (int)h.logm, tlog = (int)h.tlog;
+  uint32_t m = h.m;
+  int sp = prof_begin(k, s, "spmv");
+  Fr *evals[2] = {k->va, k->vb};
+  for (int i = 0; i < 2; i++)
+    spmv_kernel<<<(m + 255) / 256, 256, 0, s>>>((const uint32_t *)(ar + h.off_rowptr[i]), (const uint32_t *)(ar + h.off_col[i]),
+                                               (const Fr *)(ar + h.off_coef[i]), k->d_w, evals[i], m);
+  prof_end(k, s, sp);
+  sp = prof_begin(k, s, "ntt");
+  int rc;
+  // coefficients (x m, bit-reversed), then evaluations on the coset g*w^c (x m, natural)
+  if ((rc = run_ntt(s, k->va, nullptr, k->ca, tw, twl, tlog, L, true, true, PRE_NONE))) return rc;
+  if ((rc = run_ntt(s, k->vb, nullptr, k->cb, tw, twl, tlog, L, true, true, PRE_NONE))) return rc;
+  if ((rc = run_ntt(s, k->ca, nullptr, k->ca, tw, twl, tlog, L, false, false, PRE_COSET))) return rc;
+  if ((rc = run_ntt(s, k->cb, nullptr, k->cb, tw, twl, tlog, L, false, false, PRE_COSET))) return rc;
+  // D' = iNTT(A(gw^c).B(gw^c)) and S' = iNTT(a.b), both unscaled and bit-reversed
+  if ((rc = run_ntt(s, k->ca, k->cb, k->ca, tw, twl, tlog, L, true, true, PRE_MUL))) return rc;
+  if ((rc = run_ntt(s, k->va, k->vb, k->va, tw, twl, tlog, L, true, true, PRE_MUL))) return rc;
+  // constants: S' = m S / R, D' = m^3 D g^i / R  ->  h = S'*R^2/(2m) (*1/R)  -  D' g^-i * R^2/(2 m^3) (*1/R)
+  Fr r2 = Fr::r2();
+  Fr minv = inv(to_mont(fr_from_u64(m)));        // Montgomery(1/m)
+  Fr half = inv(to_mont(fr_from_u64(2)));        // Montgomery(1/2)
+  Fr c1v = mul(mul(r2, half), minv);             // value R^2/(2m) ... as plain integer: from_mont of Montgomery product chain
+  // r2 is the integer R^2 mod r = Montgomery(R).  mul(r2, half) = Montgomery(R/2); times minv = Montgomery(R/(2m)).
+  // We need the plain integer R^2/(2m) = Montgomery(R/(2m)) exactly, so c1v is already the constant to pass.
+  Fr c2v = mul(mul(c1v, minv), minv);            // Montgomery(R/(2m^3)) = integer R^2/(2m^3)
+  combine_h_kernel<<<(m + 255) / 256, 256, 0, s>>>(k->va, k->ca, k->d_h, tw, tlog, L, c1v, c2v);
+  prof_end(k, s, sp);
+  ZKR_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------ MSM driver
+template <class F> struct MsmCfg;
+template <> struct MsmCfg<Fq> { static constexpr int ACC_W = 4, RED_W = 2; static constexpr const char *ACC_STAGE = "msm_accum_g1"; };
+template <> struct MsmCfg<Fq2> { static constexpr int ACC_W = 2, RED_W = 1; static constexpr const char *ACC_STAGE = "msm_accum_g2"; };
+
+template <class F>
+static int msm_enqueue(zkr_key *prof, hipStream_t s, const Affine<F> *pts, const uint32_t *sidx, const Fr *scalars, uint32_t n,
+                       const MsmPlan &pl, MsmWorkspace &ws) {
+  if (n == 0) return 0;
+  MsmGeom g;
+  g.n = n; g.c = pl.c; g.K = pl.K; g.nbw = pl.nbw; g.big_thresh = pl.big_thresh; g.glog = pl.glog;
+  int sp = prof_begin(prof, s, "msm_sort");
+  ZKR_HIP_CHECK(hipMemsetAsync(ws.counts, 0, ((size_t)pl.nb + 1) * 4, s));
+  ZKR_HIP_CHECK(hipMemsetAsync(ws.big_count, 0, 4, s));
+  unsigned grid_n = (n + MSM_THREADS - 1) / MSM_THREADS;
+  msm_count_kernel<<<grid_n, MSM_THREADS, 0, s>>>(scalars, sidx, g, ws.counts);
+  msm_scan_kernel<<<1, 1024, 0, s>>>(ws.counts, ws.offsets, ws.cursor, pl.nb, pl.big_thresh, ws.big_list, ws.big_count, 4096);
+  msm_scatter_kernel<<<grid_n, MSM_THREADS, 0, s>>>(scalars, sidx, g, ws.cursor, ws.entries);
+  prof_end(prof, s, sp);
+  sp = prof_begin(prof, s, MsmCfg<F>::ACC_STAGE);
+  msm_accum_kernel<F, MsmCfg<F>::ACC_W><<<(pl.nb + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, s>>>(pts, ws.offsets, ws.entries, pl.nb, pl.big_thresh,
+                                                                                                      (XYZZ<F> *)ws.buckets);
+  msm_big_kernel<F, MsmCfg<F>::RED_W><<<64, MSM_THREADS, MSM_THREADS * sizeof(XYZZ<F>), s>>>(pts, ws.offsets, ws.entries, ws.big_list, ws.big_count, 4096,
+                                                                                            (XYZZ<F> *)ws.buckets);
+  prof_end(prof, s, sp);
+  sp = prof_begin(prof, s, "msm_reduce");
+  uint32_t gpw = pl.nbw >> pl.glog;
+  uint32_t ngroups = gpw * (uint32_t)pl.K;
+  msm_reduce_kernel<F, MsmCfg<F>::RED_W><<<(ngroups + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, s>>>((const XYZZ<F> *)ws.buckets, g, (XYZZ<F> *)ws.group_out);
+  msm_final_kernel<F, MsmCfg<F>::RED_W><<<pl.K, MSM_THREADS, MSM_THREADS * sizeof(XYZZ<F>), s>>>((const XYZZ<F> *)ws.group_out, gpw, (XYZZ<F> *)ws.window_out);
+  prof_end(prof, s, sp);
+  ZKR_HIP_CHECK(hipMemcpyAsync(ws.h_window, ws.window_out, (size_t)pl.K * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, s));
+  ZKR_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// Horner over the K window sums (host): sum_k 2^(ck) W_k
+template <class F>
+static XYZZ<F> msm_finish(uint32_t n, const MsmPlan &pl, const MsmWorkspace &ws) {
+  if (n == 0) return XYZZ<F>::inf();
+  const XYZZ<F> *W = (const XYZZ<F> *)ws.h_window;
+  XYZZ<F> acc = W[pl.K - 1];
+  for (int k = pl.K - 2; k >= 0; k--) {
+    for (int b = 0; b < pl.c; b++) acc = dbl_xyzz(acc);
+    acc = add_full(acc, W[k]);
+  }
+  return acc;
+}
+
+static bool u256_lt(const uint32_t *a, const uint32_t *b) {
+  for (int i = 7; i >= 0; i--)
+    if (a[i] != b[i]) return a[i] < b[i];
+  return false;
+}
+
+static int draw_blinding(uint8_t out[32]) {
+  FILE *f = fopen("/dev/urandom", "rb");
+  if (!f) { set_error("cannot open /dev/urandom"); return ZKR_ERR_ARG; }
+  for (;;) {
+    if (fread(out, 1, 32, f) != 32) { fclose(f); set_error("short read from /dev/urandom"); return ZKR_ERR_ARG; }
+    out[31] &= 0x3f;
+    uint32_t v[8];
+    memcpy(v, out, 32);
+    if (u256_lt(v, FrParams::P)) break;
+  }
+  fclose(f);
+  return 0;
+}
+
+static int prove_on_device(zkr_key *k, const Fr *d_wsrc, const uint8_t *r32, const uint8_t *s32, uint8_t proof_out[256], hipStream_t s) {
+  ZKR_HIP_CHECK(hipSetDevice(k->device));
+  const ArenaHeader &h = k->h;
+  const unsigned char *ar = k->arena;
+  uint8_t rb[32], sb[32];
+  if (r32 && s32) {
+    memcpy(rb, r32, 32);
+    memcpy(sb, s32, 32);
+    uint32_t rv[8], sv[8];
+    memcpy(rv, rb, 32); memcpy(sv, sb, 32);
+    if (!u256_lt(rv, FrParams::P) || !u256_lt(sv, FrParams::P)) { set_error("blinding scalar >= r"); return ZKR_ERR_ARG; }
+  } else if (!r32 && !s32) {
+    int rc;
+    if ((rc = draw_blinding(rb)) || (rc = draw_blinding(sb))) return rc;
+  } else { set_error("pass both r and s or neither"); return ZKR_ERR_ARG; }
+
+  int tot = prof_begin(k, s, "total");
+  int sp = prof_begin(k, s, "ingest");
+  ingest_kernel<<<(h.n + 255) / 256, 256, 0, s>>>(d_wsrc, k->d_w, h.n);
+  prof_end(k, s, sp);
+  int rc;
+  if ((rc = calc_h_device(k, s))) return rc;
+  const Fr *scal[N_TABLES] = {k->d_w, k->d_w, k->d_w, k->d_w, k->d_h};
+  for (int t = 0; t < N_TABLES; t++) {
+    const uint32_t *sidx = (const uint32_t *)(ar + h.off_sidx[t]);
+    if (t == T_B2) rc = msm_enqueue<Fq2>(k, s, (const G2Affine *)(ar + h.off_pts[t]), sidx, scal[t], h.npts[t], k->plan[t], k->ws[t]);
+    else rc = msm_enqueue<Fq>(k, s, (const G1Affine *)(ar + h.off_pts[t]), sidx, scal[t], h.npts[t], k->plan[t], k->ws[t]);
+    if (rc) return rc;
+  }
+  prof_end(k, s, tot);
+  ZKR_HIP_CHECK(hipStreamSynchronize(s));
+  prof_collect(k);
+
+  // ---- host assembly
+  G1XYZZ A = msm_finish<Fq>(h.npts[T_A], k->plan[T_A], k->ws[T_A]);
+  G1XYZZ B1 = msm_finish<Fq>(h.npts[T_B1], k->plan[T_B1], k->ws[T_B1]);
+  G2XYZZ B2 = msm_finish<Fq2>(h.npts[T_B2], k->plan[T_B2], k->ws[T_B2]);
+  G1XYZZ C = msm_finish<Fq>(h.npts[T_C], k->plan[T_C], k->ws[T_C]);
+  G1XYZZ H = msm_finish<Fq>(h.npts[T_H], k->plan[T_H], k->ws[T_H]);
+  G1XYZZ alfa1 = to_xyzz(load_g1(h.alfa1)), beta1 = to_xyzz(load_g1(h.beta1)), delta1 = to_xyzz(load_g1(h.delta1));
+  G2XYZZ beta2 = to_xyzz(load_g2(h.beta2)), delta2 = to_xyzz(load_g2(h.delta2));
+  U256 r = load_u256(rb), sc = load_u256(sb);
+  G1XYZZ pia = add_full(add_full(A, alfa1), scalar_mul(delta1, r));
+  G2XYZZ pib = add_full(add_full(B2, beta2), scalar_mul(delta2, sc));
+  G1XYZZ pib1 = add_full(add_full(B1, beta1), scalar_mul(delta1, sc));
+  G1XYZZ pic = add_full(C, H);
+  pic = add_full(pic, scalar_mul(pia, sc));
+  pic = add_full(pic, scalar_mul(pib1, r));
+  Fr rs = neg(mul(to_mont(load_fp<FrParams>(rb)), to_mont(load_fp<FrParams>(sb))));
+  Fr rs_std = from_mont(rs);
+  U256 rsu;
+  memcpy(rsu.v, rs_std.v, 32);
+  pic = add_full(pic, scalar_mul(delta1, rsu));
+  if (pia.is_inf() || pib.is_inf() || pic.is_inf()) { set_error("degenerate proof element (point at infinity)"); return ZKR_ERR_DEGENERATE; }
+  store_g1_std(proof_out, to_affine(pia));
+  store_g2_std(proof_out + 64, to_affine(pib));
+  store_g1_std(proof_out + 192, to_affine(pic));
+  return 0;
+}
+
+}  // namespace zkr
+
+using namespace zkr;
+
+extern "C" {
+
+int zkr_prove_device(zkr_key *key, const void *d_witness_std, const uint8_t *r32, const uint8_t *s32, uint8_t proof_out[256], void *stream) {
+  if (!key || !d_witness_std || !proof_out) { set_error("null argument"); return ZKR_ERR_ARG; }
+  return prove_on_device(key, (const Fr *)d_witness_std, r32, s32, proof_out, stream ? (hipStream_t)stream : key->stream);
+}
+
+int zkr_prove(zkr_key *key, const void *witness_std, size_t witness_len, const uint8_t *r32, const uint8_t *s32, uint8_t proof_out[256], void *stream) {
+  if (!key || !witness_std || !proof_out) { set_error("null argument"); return ZKR_ERR_ARG; }
+  if (witness_len != (size_t)key->h.n * 32) { set_error("witness is %zu bytes, key expects nVars*32 = %zu", witness_len, (size_t)key->h.n * 32); return ZKR_ERR_BAD_WITNESS; }
+  ZKR_HIP_CHECK(hipSetDevice(key->device));
+  hipStream_t s = stream ? (hipStream_t)stream : key->stream;
+  ZKR_HIP_CHECK(hipMemcpyAsync(key->d_wraw, witness_std, witness_len, hipMemcpyHostToDevice, s));
+  return prove_on_device(key, key->d_wraw, r32, s32, proof_out, s);
+}
+
+int zkr_calc_h(zkr_key *key, const void *witness_std, size_t witness_len, void *h_out) {
+  if (!key || !witness_std || !h_out) { set_error("null argument"); return ZKR_ERR_ARG; }
+  if (witness_len != (size_t)key->h.n * 32) { set_error("witness length mismatch"); return ZKR_ERR_BAD_WITNESS; }
+  ZKR_HIP_CHECK(hipSetDevice(key->device));
+  hipStream_t s = key->stream;
+  ZKR_HIP_CHECK(hipMemcpyAsync(key->d_wraw, witness_std, witness_len, hipMemcpyHostToDevice, s));
+  ingest_kernel<<<(key->h.n + 255) / 256, 256, 0, s>>>(key->d_wraw, key->d_w, key->h.n);
+  int rc = calc_h_device(key, s);
+  if (rc) return rc;
+  bitrev_copy_kernel<<<(key->h.m + 255) / 256, 256, 0, s>>>(key->d_h, key->ca, (int)key->h.logm);
+  ZKR_HIP_CHECK(hipMemcpyAsync(h_out, key->ca, (size_t)key->h.m * 32, hipMemcpyDeviceToHost, s));
+  ZKR_HIP_CHECK(hipStreamSynchronize(s));
+  prof_collect(key);
+  return 0;
+}
+
+int zkr_ntt(void *data_std, unsigned logn, int inverse, int device) {
+  if (!data_std || logn < 1 || logn > 27) { set_error("bad argument"); return ZKR_ERR_ARG; }
+  if (zkr_device_count() <= device || device < 0) { set_error("no HIP device %d; libzkr_hip has no CPU fallback", device); return ZKR_ERR_NO_DEVICE; }
+  ZKR_HIP_CHECK(hipSetDevice(device));
+  size_t n = (size_t)1 << logn;
+  Fr *d = nullptr, *d2 = nullptr, *tw = nullptr, *twl = nullptr;
+  ZKR_HIP_CHECK(hipMalloc(&d, n * 32));
+  ZKR_HIP_CHECK(hipMalloc(&d2, n * 32));
+  ZKR_HIP_CHECK(hipMalloc(&tw, n * 32));
+  ZKR_HIP_CHECK(hipMalloc(&twl, (size_t)(1u << TWL_LOG) * 32));
+  ZKR_HIP_CHECK(hipMemcpy(d, data_std, n * 32, hipMemcpyHostToDevice));
+  twiddle_table_kernel<<<(unsigned)((n + 255) / 256), 256>>>(tw, (uint32_t)n, host_root_of_unity(logn + 1));
+  twiddle_table_kernel<<<((1u << TWL_LOG) + 255) / 256, 256>>>(twl, 1u << TWL_LOG, host_root_of_unity(TWL_LOG + 1));
+  int rc = run_ntt(nullptr, d, nullptr, d, tw, twl, (int)logn, (int)logn, true, inverse != 0, PRE_NONE);  // natural -> bit-reversed
+  if (!rc) {
+    bitrev_copy_kernel<<<(unsigned)((n + 255) / 256), 256>>>(d, d2, (int)logn);
+    if (inverse) scale_kernel<<<(unsigned)((n + 255) / 256), 256>>>(d2, n, inv(to_mont(fr_from_u64(n))));
+    hipError_t e = hipMemcpy(data_std, d2, n * 32, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { set_error("copy back failed: %s", hipGetErrorString(e)); rc = ZKR_ERR_HIP; }
+  }
+  hipFree(d); hipFree(d2); hipFree(tw); hipFree(twl);
+  return rc;
+}
+
+}  // extern "C"
+
+template <class F>
+static int msm_hook(const void *points_mont, const void *scalars_std, size_t n, uint8_t *out, int *is_inf, int device) {
+  if (!points_mont || !scalars_std || !out || !is_inf) { set_error("null argument"); return ZKR_ERR_ARG; }
+  if (zkr_device_count() <= device || device < 0) { set_error("no HIP device %d; libzkr_hip has no CPU fallback", device); return ZKR_ERR_NO_DEVICE; }
+  ZKR_HIP_CHECK(hipSetDevice(device));
+  const size_t pb = sizeof(Affine<F>);
+  const uint8_t *pts = (const uint8_t *)points_mont;
+  std::vector<uint32_t> sidx;
+  std::vector<uint8_t> compact;
+  for (size_t i = 0; i < n; i++) {
+    bool inf = true;
+    for (size_t b = 0; b < pb / 2 && inf; b++) inf = pts[i * pb + b] == 0;
+    if (inf) continue;
+    sidx.push_back((uint32_t)i);
+    compact.insert(compact.end(), pts + i * pb, pts + (i + 1) * pb);
+  }
+  uint32_t np = (uint32_t)sidx.size();
+  XYZZ<F> res = XYZZ<F>::inf();
+  if (np) {
+    MsmPlan pl = msm_plan(np);
+    MsmWorkspace ws;
+    int rc = msm_ws_alloc(ws, np, pl, sizeof(XYZZ<F>));
+    if (rc) return rc;
+    Affine<F> *d_pts = nullptr;
+    uint32_t *d_sidx = nullptr;
+    Fr *d_sc = nullptr, *d_sc2 = nullptr;
+    ZKR_HIP_CHECK(hipMalloc(&d_pts, compact.size()));
+    ZKR_HIP_CHECK(hipMalloc(&d_sidx, (size_t)np * 4));
+    ZKR_HIP_CHECK(hipMalloc(&d_sc, n * 32));
+    ZKR_HIP_CHECK(hipMalloc(&d_sc2, n * 32));
+    ZKR_HIP_CHECK(hipMemcpy(d_pts, compact.data(), compact.size(), hipMemcpyHostToDevice));
+    ZKR_HIP_CHECK(hipMemcpy(d_sidx, sidx.data(), (size_t)np * 4, hipMemcpyHostToDevice));
+    ZKR_HIP_CHECK(hipMemcpy(d_sc, scalars_std, n * 32, hipMemcpyHostToDevice));
+    ingest_kernel<<<(unsigned)((n + 255) / 256), 256>>>(d_sc, d_sc2, n);
+    rc = msm_enqueue<F>(nullptr, nullptr, d_pts, d_sidx, d_sc2, np, pl, ws);
+    if (!rc) {
+      hipError_t e = hipDeviceSynchronize();
+      if (e != hipSuccess) { set_error("msm failed: %s", hipGetErrorString(e)); rc = ZKR_ERR_HIP; }
+    }
+    if (!rc) res = msm_finish<F>(np, pl, ws);
+    hipFree(d_pts); hipFree(d_sidx); hipFree(d_sc); hipFree(d_sc2);
+    msm_ws_free(ws);
+    if (rc) return rc;
+  }
+  *is_inf = res.is_inf() ? 1 : 0;
+  memset(out, 0, pb);
+  if (!res.is_inf()) {
+    Affine<F> a = to_affine(res);
+    if constexpr (sizeof(F) == 32) store_g1_std(out, *reinterpret_cast<G1Affine *>(&a));
+    else store_g2_std(out, *reinterpret_cast<G2Affine *>(&a));
+  }
+  return 0;
+}
+
+extern "C" {
+
+int zkr_msm_g1(const void *points_mont, const void *scalars_std, size_t n, uint8_t out[64], int *is_inf, int device) {
+  return msm_hook<Fq>(points_mont, scalars_std, n, out, is_inf, device);
+}
+int zkr_msm_g2(const void *points_mont, const void *scalars_std, size_t n, uint8_t out[128], int *is_inf, int device) {
+  return msm_hook<Fq2>(points_mont, scalars_std, n, out, is_inf, device);
+}
+
+int zkr_prof_enable(zkr_key *key, int on) {
+  if (!key) { set_error("null argument"); return ZKR_ERR_ARG; }
+  key->prof_on = on != 0;
+  return 0;
+}
+int zkr_prof_reset(zkr_key *key) {
+  if (!key) { set_error("null argument"); return ZKR_ERR_ARG; }
+  for (auto &st : key->stages) { st.ms = 0; st.launches = 0; }
+  return 0;
+}
+int zkr_prof_get(zkr_key *key, const char *stage, double *ms_total, uint64_t *launches) {
+  if (!key || !stage || !ms_total || !launches) { set_error("null argument"); return ZKR_ERR_ARG; }
+  *ms_total = 0;
+  *launches = 0;
+  for (auto &st : key->stages)
+    if (st.name == stage) { *ms_total = st.ms; *launches = st.launches; return 0; }
+  if (stage_index(stage) >= 0) return 0;  // known stage, nothing recorded yet
+  set_error("unknown stage '%s'", stage);
+  return ZKR_ERR_ARG;
+}
+
+int zkr_bench_fq_mul(int device, double *gmuls_per_s) {
+  if (!gmuls_per_s) { set_error("null argument"); return ZKR_ERR_ARG; }
+  if (zkr_device_count() <= device || device < 0) { set_error("no HIP device %d", device); return ZKR_ERR_NO_DEVICE; }
+  ZKR_HIP_CHECK(hipSetDevice(device));
+  const unsigned blocks = 256 * 8, iters = 512;
+  size_t nthreads = (size_t)blocks * MSM_THREADS;
+  Fq *d = nullptr;
+  ZKR_HIP_CHECK(hipMalloc(&d, nthreads * 32));
+  std::vector<uint32_t> init(nthreads * 8);
+  for (size_t i = 0; i < init.size(); i++) init[i] = (uint32_t)(i * 2654435761u) & ((i & 7) == 7 ? 0x0fffffffu : 0xffffffffu);
+  ZKR_HIP_CHECK(hipMemcpy(d, init.data(), nthreads * 32, hipMemcpyHostToDevice));
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  fq_mul_bench_kernel<<<blocks, MSM_THREADS>>>(d, 16);  // warm up
+  hipEventRecord(e0, nullptr);
+  fq_mul_bench_kernel<<<blocks, MSM_THREADS>>>(d, (int)iters);
+  hipEventRecord(e1, nullptr);
+  ZKR_HIP_CHECK(hipEventSynchronize(e1));
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  hipFree(d);
+  *gmuls_per_s = (double)nthreads * iters * 4 / (ms * 1e-3) / 1e9;
+  return 0;
+}
+
+}  // extern "C"

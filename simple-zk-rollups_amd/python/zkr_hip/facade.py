@@ -1,0 +1,64 @@
+"""Python mirror of the reference's proof facade for the hot path.
+
+Reference: /root/reference/operator/src/snarks/common.ts:10-53 (createProofGenerator) and the
+websnark surface it uses (buildBn128().groth16GenProof, common.ts:23,29).  Same names, argument
+meaning and error behaviour; circuit compilation and witness calculation (common.ts:12-21) stay
+with the caller, as the north-star leaves them unchanged.
+"""
+from .binding import ProvingKey, ZkrError
+
+SNARK_FIELD_SIZE = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+
+
+def proof_json_from_bytes(pb: bytes):
+    """256-byte C-ABI proof -> the object groth16GenProof resolves to."""
+    v = [str(int.from_bytes(pb[32 * i:32 * i + 32], "little")) for i in range(8)]
+    return {"pi_a": [v[0], v[1], "1"], "pi_b": [[v[2], v[3]], [v[4], v[5]], ["1", "0"]], "pi_c": [v[6], v[7], "1"]}
+
+
+def solidity_proof(proof, public_signals):
+    """common.ts:43-50: drop the projective coordinate, swap (re, im) -> (im, re) in pi_b, inputs mod r."""
+    return {"a": list(proof["pi_a"][:2]), "b": [list(reversed(x)) for x in proof["pi_b"]][:2],
+            "c": list(proof["pi_c"][:2]), "inputs": [str(int(x) % SNARK_FIELD_SIZE) for x in public_signals]}
+
+
+class Bn128:
+    """What `await buildBn128()` returns; only groth16GenProof is used by the reference."""
+
+    def __init__(self, device=0):
+        self.device = device
+        self._cache = {}
+
+    def groth16GenProof(self, witness_bin: bytes, proving_key_bin: bytes, r=None, s=None):
+        # the reference re-parses the key on every call (common.ts:28-29); cache the device key by buffer identity
+        ck = (len(proving_key_bin), hash(bytes(proving_key_bin[:4096])), hash(bytes(proving_key_bin[-4096:])))
+        key = self._cache.get(ck)
+        if key is None:
+            key = ProvingKey.load_websnark(proving_key_bin, self.device)
+            self._cache = {ck: key}
+        return proof_json_from_bytes(key.prove(witness_bin, r, s))
+
+
+def build_bn128(device=0):
+    return Bn128(device)
+
+
+def groth16_gen_proof(witness_bin, proving_key_bin, device=0, r=None, s=None):
+    return build_bn128(device).groth16GenProof(witness_bin, proving_key_bin, r, s)
+
+
+def create_proof_generator(proving_key_bin, verifying_key, is_valid, n_public, device=0):
+    """common.ts:10-53 with the circuit/witness steps supplied by the caller: returns
+    fn(witness: list[int]) -> {proof, solidityProof}; raises Error("Invalid proof generated")
+    (common.ts:36-38) when `is_valid(vk, proof, publicSignals)` rejects the proof."""
+    bn = build_bn128(device)
+
+    def gen(witness, r=None, s=None):
+        public_signals = witness[1:n_public + 1]  # common.ts:18-21
+        witness_bin = b"".join(int(x).to_bytes(32, "little") for x in witness)  # binarifyWitness, binarify.ts:10-48
+        proof = bn.groth16GenProof(witness_bin, proving_key_bin, r, s)
+        if not is_valid(verifying_key, proof, public_signals):
+            raise ZkrError(-100, "Invalid proof generated")
+        return {"proof": proof, "solidityProof": solidity_proof(proof, public_signals)}
+
+    return gen

@@ -1,0 +1,182 @@
+"""GPU parity of each stage against the CPU oracle, through the C ABI (include/zkr.h)."""
+import random
+
+import pytest
+
+import coracle
+import groth16 as g
+from bn254 import Q, R, G1_GEN, G2_GEN, g1_mul, g2_mul, g1_add
+
+pytestmark = pytest.mark.gpu
+MONT = 1 << 256
+
+
+def _le(v):
+    return int(v).to_bytes(32, "little")
+
+
+def _g1_bytes(P):  # Montgomery wire form; None -> snarkjs zero [0,1,0]
+    if P is None:
+        return _le(0) + _le(MONT % Q)
+    return _le(P[0] * MONT % Q) + _le(P[1] * MONT % Q)
+
+
+def _g2_bytes(P):
+    if P is None:
+        return _le(0) + _le(0) + _le(MONT % Q) + _le(0)
+    return b"".join(_le(c * MONT % Q) for c in (P[0][0], P[0][1], P[1][0], P[1][1]))
+
+
+def test_fq_mul_microbench_runs():
+    import zkr_hip
+    assert zkr_hip.bench_fq_mul() > 0.1  # G mul/s
+
+
+@pytest.mark.parametrize("logn", [1, 2, 5, 10, 11, 12, 14])
+def test_ntt_matches_oracle(logn):
+    import zkr_hip
+    rnd = random.Random(logn)
+    n = 1 << logn
+    v = [rnd.randrange(R) for _ in range(n)]
+    v[0] = R - 1
+    data = b"".join(_le(x) for x in v)
+    assert zkr_hip.ntt(data) == coracle.ntt(data)
+    assert zkr_hip.ntt(data, inverse=True) == coracle.ntt(data, inverse=True)
+
+
+def test_ntt_roundtrip_and_linearity_2_20():
+    import zkr_hip
+    rnd = random.Random(20)
+    n = 1 << 20
+    a = [rnd.randrange(R) for _ in range(n)]
+    da = b"".join(_le(x) for x in a)
+    fa = zkr_hip.ntt(da)
+    assert zkr_hip.ntt(fa, inverse=True) == da
+    # X[0] = sum a_i ; x[0] of inverse = mean
+    assert int.from_bytes(fa[:32], "little") == sum(a) % R
+    # spot check against the C oracle (full transform)
+    assert fa == coracle.ntt(da)
+
+
+def _points_g1(n, rnd, with_inf=True):
+    pts, P = [], G1_GEN
+    for i in range(n):
+        pts.append(None if with_inf and i % 7 == 3 else P)
+        P = g1_add(P, G1_GEN) if i % 5 else g1_mul(P, 3)
+    return pts
+
+
+@pytest.mark.parametrize("n", [1, 2, 65, 1000, 20000])
+def test_msm_g1_matches_oracle(n):
+    import zkr_hip
+    rnd = random.Random(n)
+    pts = _points_g1(min(n, 300), rnd)
+    pts = [pts[i % len(pts)] for i in range(n)]  # duplicates included on purpose
+    sc = [rnd.randrange(R) for _ in range(n)]
+    for i in range(0, n, 11):
+        sc[i] = rnd.choice([0, 1, 1, 2, R - 1, (1 << 64) - 1, 1 << 253])
+    pb = b"".join(_g1_bytes(P) for P in pts)
+    sb = b"".join(_le(x) for x in sc)
+    assert zkr_hip.msm_g1(pb, sb) == coracle.msm_g1(pb, sb)
+
+
+def test_msm_g1_all_ones_goes_through_big_bucket_path():
+    import zkr_hip
+    n = 6000
+    pts = _points_g1(200, None, with_inf=False)
+    pts = [pts[i % 200] for i in range(n)]
+    sc = [1] * n
+    sc[5] = 0
+    pb = b"".join(_g1_bytes(P) for P in pts)
+    sb = b"".join(_le(x) for x in sc)
+    assert zkr_hip.msm_g1(pb, sb) == coracle.msm_g1(pb, sb)
+
+
+def test_msm_g1_cancels_to_infinity():
+    import zkr_hip
+    P = g1_mul(G1_GEN, 12345)
+    pb = _g1_bytes(P) * 2
+    sb = _le(5) + _le(R - 5)
+    assert zkr_hip.msm_g1(pb, sb) is None
+    assert coracle.msm_g1(pb, sb) is None
+
+
+@pytest.mark.parametrize("n", [1, 3, 500, 5000])
+def test_msm_g2_matches_oracle(n):
+    import zkr_hip
+    rnd = random.Random(n)
+    base = [g2_mul(G2_GEN, rnd.randrange(1, R)) for _ in range(min(n, 40))]
+    pts = [None if i % 9 == 4 else base[i % len(base)] for i in range(n)]
+    sc = [rnd.randrange(R) for _ in range(n)]
+    for i in range(0, n, 13):
+        sc[i] = rnd.choice([0, 1, R - 1, 7])
+    pb = b"".join(_g2_bytes(P) for P in pts)
+    sb = b"".join(_le(x) for x in sc)
+    assert zkr_hip.msm_g2(pb, sb) == coracle.msm_g2(pb, sb)
+
+
+def test_calc_h_and_prove_small_key_from_python_oracle(small_case):
+    import zkr_hip
+    c = small_case
+    key = zkr_hip.ProvingKey.load_websnark(c["pkb"])
+    info = key.info()
+    assert (info["nVars"], info["nPublic"], info["domainSize"]) == (c["pk"]["nVars"], 7, 128)
+    h = g.calc_h_websnark(c["pk"], c["w"])
+    assert key.calc_h(c["wb"]) == b"".join(_le(x) for x in h)
+    proof = key.prove(c["wb"], c["r"], c["s"])
+    expect = g.proof_from_toxic(c["circ"], c["tox"], c["w"], c["r"], c["s"])
+    assert proof == g.proof_bytes(expect)           # bit-exact with the closed form
+    assert proof == coracle.prove(c["pkb"], c["wb"], c["r"], c["s"])
+    pj = zkr_hip.proof_json_from_bytes(proof)
+    pts = dict(pi_a=(int(pj["pi_a"][0]), int(pj["pi_a"][1])),
+               pi_b=((int(pj["pi_b"][0][0]), int(pj["pi_b"][0][1])), (int(pj["pi_b"][1][0]), int(pj["pi_b"][1][1]))),
+               pi_c=(int(pj["pi_c"][0]), int(pj["pi_c"][1])))
+    assert g.is_valid(c["vk"], pts, c["w"][1:8])    # TxVerifier.sol:258-276 equation
+    # unsatisfied witness: same (invalid) proof as the reference algorithm yields
+    w2 = list(c["w"])
+    w2[20] = (w2[20] + 5) % R
+    wb2 = g.binarify_witness(w2)
+    assert key.prove(wb2, c["r"], c["s"]) == coracle.prove(c["pkb"], wb2, c["r"], c["s"])
+    # random blinding: valid but different each call
+    p1, p2 = key.prove(c["wb"]), key.prove(c["wb"])
+    assert p1 != p2
+
+
+def test_error_paths(small_case):
+    import zkr_hip
+    c = small_case
+    with pytest.raises(zkr_hip.ZkrError):
+        zkr_hip.ProvingKey.load_websnark(c["pkb"][:-1])
+    key = zkr_hip.ProvingKey.load_websnark(c["pkb"])
+    with pytest.raises(zkr_hip.ZkrError):
+        key.prove(c["wb"][:-32], 1, 2)
+    with pytest.raises(zkr_hip.ZkrError):
+        key.prove(c["wb"], R, 2)
+
+
+@pytest.mark.parametrize("log_m,p", [(6, 5), (10, 7), (13, 73)])
+def test_synth_generator_and_device_setup_match_oracle(log_m, p):
+    """product-side generator + device fixed-base setup == oracle generator + setup, byte for byte"""
+    import zkr_hip
+    pkb, wb = zkr_hip.synth_websnark(log_m, p, 0x5A4B0001, 0x5A4B00FF)
+    if log_m <= 10:
+        circ = g.synth_circuit(1 << log_m, p, 0x5A4B0001)
+        assert g.binarify_witness(circ["witness"]) == wb
+        pk, _ = g.setup(circ, g.toxic_from_seed(0x5A4B00FF))
+        assert g.binarify_proving_key(g.to_json_key(pk)) == pkb
+    rng = g.SplitMix64(log_m)
+    r, s = rng.fr(), rng.fr()
+    key = zkr_hip.ProvingKey.load_websnark(pkb)
+    proof = key.prove(wb, r, s)
+    assert proof == coracle.prove(pkb, wb, r, s)
+    # the arena-built key (no websnark binary) gives the same proof
+    key2, wb2, aux = zkr_hip.ProvingKey.synth(log_m, p, 0x5A4B0001, 0x5A4B00FF)
+    assert wb2 == wb
+    assert key2.prove(wb, r, s) == proof
+    # a replica adopted from the arena bytes proves identically
+    import torch
+    ptr, n = key2.arena()
+    from zkr_hip.batch import _tensor_from_ptr
+    replica_mem = _tensor_from_ptr(ptr, n, 0).clone()
+    key3 = zkr_hip.ProvingKey.adopt_arena(replica_mem.data_ptr(), n, 0, keepalive=replica_mem)
+    assert key3.prove(wb, r, s) == proof
