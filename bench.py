@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""bench.py -- Groth16 proofs/sec of the MI355X prover on the synthetic rollup circuit.
+
+Contract: python bench.py --gpus N --steps K --warmup W   (N>1: launched by torch.distributed.run,
+one rank per GPU).  A step = one proof (QAP rows -> 6 NTTs -> 5 MSMs -> assembly) of the m = 2^20
+rollup-shaped circuit with 73 public inputs (BASELINE.json configs[1]); witnesses are resident in
+HBM when the timed region starts.  N>1: the key is generated on rank 0 and broadcast over RCCL, each
+rank proves its own K witnesses (weak scaling, no data-path collective).  Prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "simple-zk-rollups_amd", "python"))
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+CIRCUIT_SEED, TOXIC_SEED, N_PUBLIC = 0x5A4B0001, 0x5A4B00FF, 73
+
+
+def cpu_baseline(sample_log_m, target_log_m):
+    """The C oracle (single thread) on a bounded sample of the same workload: same generator, smaller
+    domain; proofs/s scaled linearly in m to the benchmarked size (the algorithm is O(m log m) NTT +
+    O(m * 254/c) group operations, so linear scaling slightly favours the CPU)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import coracle
+    import zkr_hip
+    pkb, wb = zkr_hip.synth_websnark(sample_log_m, N_PUBLIC, CIRCUIT_SEED, TOXIC_SEED, device=0)
+    t0 = time.time()
+    _, tm = coracle.prove(pkb, wb, 12345, 67890, want_timings=True)
+    dt = time.time() - t0
+    scale = 2.0 ** (target_log_m - sample_log_m)
+    return {"value": 1.0 / (dt * scale), "unit": "proofs/s", "cores": 1, "kind": "port",
+            "sample": "oracle/zkr_oracle.c zo_prove, 1 thread, m=2^%d rollup-shaped key: %.2f s/proof (calcH %.2f s, MSM %.2f s); "
+                      "value = 1/(t * 2^%d) i.e. linearly scaled to m=2^%d" % (sample_log_m, dt, tm[0], tm[1],
+                                                                              target_log_m - sample_log_m, target_log_m)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--log-m", type=int, default=20)
+    ap.add_argument("--cpu-sample-log-m", type=int, default=17)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import zkr_hip
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    # ---- key: generated on rank 0 (points computed on the GPU), replicated by one broadcast of the arena
+    t_setup = time.time()
+    key = None
+    if rank == 0:
+        key, w0, _ = zkr_hip.ProvingKey.synth(args.log_m, N_PUBLIC, CIRCUIT_SEED, TOXIC_SEED, device=local, want_aux=False)
+    t_bcast = time.time()
+    key = zkr_hip.broadcast_key(key, rank, world, local)
+    torch.cuda.synchronize()
+    bcast_s = time.time() - t_bcast
+    info = key.info()
+    arena_bytes = key.arena()[1]
+
+    # ---- witnesses of this rank, resident in HBM before timing starts (distinct per rank and step, up to 4)
+    n_wit = max(1, min(4, args.steps))
+    wits = []
+    for i in range(n_wit):
+        wseed = CIRCUIT_SEED if (rank == 0 and i == 0) else CIRCUIT_SEED + 1000 * rank + i
+        wb = w0 if (rank == 0 and i == 0) else zkr_hip.synth_witness(args.log_m, N_PUBLIC, CIRCUIT_SEED, wseed)
+        wits.append(torch.frombuffer(bytearray(wb), dtype=torch.uint8).cuda(local))
+    setup_s = time.time() - t_setup
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(i):
+        return key.prove_device(wits[i % n_wit].data_ptr(), r=1000003 + i, s=2000003 + i, stream=stream)
+
+    for i in range(args.warmup):
+        step(i)
+    key.prof_enable(True)
+    key.prof_reset()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    prof = key.prof()
+    key.prof_enable(False)
+
+    if rank == 0:
+        total_proofs = args.steps * world
+        value = total_proofs / elapsed
+        # ---- roofline of the dominant kernel (DESIGN.md "Measurement"): algorithmic bytes = every base point
+        # and every scalar of the MSM read once (64 B G1 / 128 B G2 point + 32 B scalar)
+        g1_pts = info["ptsA"] + info["ptsB1"] + info["ptsC"] + info["ptsH"]
+        cands = {
+            "msm_accum_kernel<Fq>": ("msm_accum_g1", 96.0 * g1_pts / 4.0, 10.0 * g1_pts / 4.0),
+            "msm_accum_kernel<Fq2>": ("msm_accum_g2", 160.0 * info["ptsB2"], 28.0 * info["ptsB2"]),
+        }
+        dom, best = None, -1.0
+        for name, (st, _, _) in cands.items():
+            if prof[st][0] > best:
+                dom, best = name, prof[st][0]
+        st, bytes_per_launch, fqmul_per_point_window = cands[dom]
+        ms_total, launches = prof[st]
+        avg_ms = ms_total / max(launches, 1)
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "avg_launch_ms": avg_ms, "launches": launches,
+                    "algorithmic_bytes_per_launch": bytes_per_launch,
+                    "note": "Pippenger bucket accumulation is integer-VALU bound (v_mad_u64_u32), not HBM bound; see valu"}
+        try:
+            peak_gmul = zkr_hip.bench_fq_mul(local)
+            windows = (255 + 15) // 16 if max(info["ptsA"], 1) >= (1 << 20) else None
+            roofline["valu"] = {"peak_fq_mul_per_s_G": peak_gmul, "unit": "G Fq-mul/s (136 mad32 each)"}
+            if windows:
+                gm = fqmul_per_point_window * windows / (avg_ms * 1e-3) / 1e9
+                roofline["valu"].update({"achieved_fq_mul_per_s_G": gm, "frac": gm / peak_gmul})
+        except Exception as e:  # microbench is informative only
+            roofline["valu"] = {"error": str(e)}
+        per_proof_ms = {k: (v[0] / args.steps) for k, v in prof.items()}
+        out = {
+            "metric": "Groth16 proofs/sec (rollup batch circuit)", "value": value, "unit": "proofs/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u32x8 Montgomery (254-bit integer)", "data": "synthetic",
+            "config": {"workload": "2^%d-constraint synthetic rollup circuit, 1 proof per step per GPU" % args.log_m,
+                       "log_m": args.log_m, "n_public": N_PUBLIC, "nVars": info["nVars"], "nnzA": info["nnzA"], "nnzB": info["nnzB"],
+                       "parallelism": "proof-sharded x%d (key arena broadcast once over RCCL)" % world},
+            "roofline": roofline,
+            "stage_ms_per_proof": per_proof_ms,
+            "key": {"arena_bytes": arena_bytes, "setup_s": setup_s, "bcast_s": bcast_s if world > 1 else None},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample_log_m, args.log_m)
+            out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
+        print(json.dumps(out))
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

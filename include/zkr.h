@@ -87,7 +87,8 @@ int zkr_msm_g2(const void *points_mont, const void *scalars_std, size_t n, uint8
 int zkr_calc_h(zkr_key *key, const void *witness_std, size_t witness_len, void *h_out);
 
 /* Per-stage device timing, measured with hipEvents on the launch stream.  Stage names:
- * "ingest","spmv","ntt","msm_sort","msm_accum","msm_reduce","assemble","total". */
+ * "ingest","spmv","ntt","msm_sort","msm_accum_g1","msm_accum_g2","msm_big","msm_reduce","total".
+ * "msm_accum_g1"/"msm_accum_g2" bracket exactly one msm_accum_kernel launch each time. */
 int zkr_prof_enable(zkr_key *key, int on);
 int zkr_prof_reset(zkr_key *key);
 int zkr_prof_get(zkr_key *key, const char *stage, double *ms_total, uint64_t *launches);
@@ -104,6 +105,10 @@ int zkr_synth_key(unsigned log_m, unsigned n_public, uint64_t circuit_seed, uint
 /* Same circuit + setup rendered as a websnark-format key on the host (small sizes; tests). */
 int zkr_synth_websnark(unsigned log_m, unsigned n_public, uint64_t circuit_seed, uint64_t toxic_seed, int device,
                        void **pk_out, size_t *pk_len, void **witness_out, size_t *witness_len);
+/* Another satisfying witness of the same synthetic circuit (host only, no GPU): structure comes from
+ * circuit_seed, free values from witness_seed (zkr_synth_key uses witness_seed = circuit_seed). */
+int zkr_synth_witness(unsigned log_m, unsigned n_public, uint64_t circuit_seed, uint64_t witness_seed, void **witness_out,
+                      size_t *witness_len);
 void zkr_free(void *p);
 
 /* Integer-ALU microbenchmark: sustained Fq Montgomery multiplications per second on `device`

@@ -46,15 +46,19 @@ class SplitMix64:
                 return v
 
 
-def synth_circuit(m, p, seed):
+def synth_circuit(m, p, seed, witness_seed=None):
     """Rollup-shaped synthetic R1CS with witness by forward evaluation (SURVEY.md 8(d) config 2,
     Appendix D): ~93 % MiMC-like multiplication rows with 1-3 nnz per A/B/C row, 3 % boolean
     rows, 2 % small (64-bit) values, and a 64-term packing row every 2048 rows.
+    Structure (row kinds, wiring, coefficients) is drawn from SplitMix64(seed); free witness values
+    (public inputs, booleans, small values) from SplitMix64(witness_seed ^ 0x77697473), so one key
+    serves a batch of different witnesses.  witness_seed defaults to seed.
     Returns dict(nVars, nPublic, nConstraints, rows=[(A,B,C)], witness=[...]); A/B/C are
-    lists of (signal, coef).  Mirrors zkr_synth_circuit in csrc/workload.cpp draw for draw."""
+    lists of (signal, coef).  Mirrors synth_circuit in csrc/workload.hip draw for draw."""
     rng = SplitMix64(seed)
+    rv = SplitMix64((seed if witness_seed is None else witness_seed) ^ 0x77697473)
     nC = m - p - 1
-    w = [1] + [rng.fr() for _ in range(p)]
+    w = [1] + [rv.fr() for _ in range(p)]
     rows = []
     for c in range(nC):
         n = len(w)
@@ -71,12 +75,12 @@ def synth_circuit(m, p, seed):
             w.append(acc)
             rows.append((sorted(A.items()), [(0, 1)], [(new, 1)]))
         elif kind < 3:
-            b = rng.u64() & 1
+            b = rv.u64() & 1
             new = n
             w.append(b)
             rows.append(([(new, 1)], [(0, R - 1), (new, 1)], []))
         elif kind < 5:
-            v = rng.u64()
+            v = rv.u64()
             new = n
             w.append(v)
             rows.append(([(new, 1)], [(0, 1)], [(new, 1)]))
@@ -572,3 +576,50 @@ def proof_bytes(proof):
 
 def sha256(b):
     return hashlib.sha256(b).hexdigest()
+
+
+# ----------------------------------------------------------------------------- checker for device-generated keys
+def parse_synth_aux(aux: bytes):
+    """Decode the checker blob of zkr_synth_key (include/zkr.h): toxic waste, per-signal discrete logs
+    a_s, b_s, c_s, the IC points and vk_gamma_2."""
+    n = int.from_bytes(aux[:8], "little")
+    o = 8
+    rd = lambda k: int.from_bytes(aux[o + 32 * k:o + 32 * k + 32], "little")
+    tox = dict(t=rd(0), alfa=rd(1), beta=rd(2), gamma=rd(3), delta=rd(4))
+    o += 160
+    vec = lambda: [int.from_bytes(aux[o + 32 * i:o + 32 * i + 32], "little") for i in range(n)]
+    a = vec(); o += 32 * n
+    b = vec(); o += 32 * n
+    c = vec(); o += 32 * n
+    rest = aux[o:]
+    n_ic = (len(rest) - 128) // 64
+    ic = [(int.from_bytes(rest[64 * i:64 * i + 32], "little"), int.from_bytes(rest[64 * i + 32:64 * i + 64], "little")) for i in range(n_ic)]
+    g = rest[64 * n_ic:]
+    gv = [int.from_bytes(g[32 * i:32 * i + 32], "little") for i in range(4)]
+    return dict(n=n, tox=tox, a=a, b=b, c=c, ic=ic, gamma2=((gv[0], gv[1]), (gv[2], gv[3])))
+
+
+def proof_from_aux(aux, witness_bytes, n_public, r, s):
+    """Toxic-waste closed form of the proof (satisfying witness) and the verifying key, for keys whose
+    group elements were computed on the GPU: no MSM, no NTT -- field dot products + 3 scalar muls."""
+    ax = parse_synth_aux(aux)
+    n, tox = ax["n"], ax["tox"]
+    w = [int.from_bytes(witness_bytes[32 * i:32 * i + 32], "little") for i in range(n)]
+    At = sum(x * y for x, y in zip(w, ax["a"])) % R
+    Bt = sum(x * y for x, y in zip(w, ax["b"])) % R
+    Ct = sum(x * y for x, y in zip(w, ax["c"])) % R
+    d = tox["delta"]
+    dinv = inv(d, R)
+    a_log = (tox["alfa"] + At + r * d) % R
+    b_log = (tox["beta"] + Bt + s * d) % R
+    p = n_public
+    pub = sum(w[i] * ((tox["beta"] * ax["a"][i] + tox["alfa"] * ax["b"][i] + ax["c"][i]) % R) for i in range(p + 1)) % R
+    allk = (tox["beta"] * At + tox["alfa"] * Bt + Ct) % R
+    cpriv = (allk - pub) * dinv % R
+    c_log = (cpriv + (At * Bt - Ct) * dinv + s * a_log + r * b_log - r * s % R * d) % R
+    fb1, fb2 = _fb()
+    proof = dict(pi_a=fb1.mul(a_log), pi_b=fb2.mul(b_log), pi_c=fb1.mul(c_log))
+    vk = dict(nPublic=p, IC=ax["ic"], vk_alfa_1=fb1.mul(tox["alfa"]), vk_beta_2=fb2.mul(tox["beta"]),
+              vk_gamma_2=ax["gamma2"], vk_delta_2=fb2.mul(d))
+    assert vk["vk_gamma_2"] == fb2.mul(tox["gamma"])
+    return proof, vk, w[1:p + 1]

@@ -60,12 +60,13 @@ static Fr dot(const std::vector<Term> &t, size_t b, size_t e, const std::vector<
 }
 
 // draw-for-draw mirror of oracle/groth16.py:synth_circuit
-static void synth_circuit(Circuit &c, uint32_t m, uint32_t p, uint64_t seed) {
+static void synth_circuit(Circuit &c, uint32_t m, uint32_t p, uint64_t seed, uint64_t witness_seed) {
   SplitMix64 rng(seed);
+  SplitMix64 rv(witness_seed ^ 0x77697473ull);  // free witness values: own stream, so one key serves many witnesses
   c.m = m; c.p = p; c.nC = m - p - 1;
   c.w.reserve(m + 8);
   c.w.push_back(Fr::one());
-  for (uint32_t i = 0; i < p; i++) c.w.push_back(rng.fr());
+  for (uint32_t i = 0; i < p; i++) c.w.push_back(rv.fr());
   const Fr one = Fr::one(), minus1 = neg(Fr::one());
   c.rowA.push_back(0); c.rowB.push_back(0); c.rowC.push_back(0);
   for (uint32_t row = 0; row < c.nC; row++) {
@@ -86,13 +87,13 @@ static void synth_circuit(Circuit &c, uint32_t m, uint32_t p, uint64_t seed) {
       c.tB.push_back({0, one});
       c.tC.push_back({n, one});
     } else if (kind < 3) {
-      uint64_t bit = rng.u64() & 1;
+      uint64_t bit = rv.u64() & 1;
       c.w.push_back(bit ? one : Fr::zero());
       c.tA.push_back({n, one});
       c.tB.push_back({0, minus1});
       c.tB.push_back({n, one});
     } else if (kind < 5) {
-      c.w.push_back(fr_u64(rng.u64()));
+      c.w.push_back(fr_u64(rv.u64()));
       c.tA.push_back({n, one});
       c.tB.push_back({0, one});
       c.tC.push_back({n, one});
@@ -195,7 +196,7 @@ struct Generated {
 static int generate(unsigned log_m, unsigned n_public, uint64_t circuit_seed, uint64_t toxic_seed, int device, Generated &g) {
   if (log_m < 2 || log_m > 26 || n_public + 2 > (1u << log_m)) { set_error("bad synthetic geometry log_m=%u nPublic=%u", log_m, n_public); return ZKR_ERR_ARG; }
   if (zkr_device_count() <= device || device < 0) { set_error("no HIP device %d; key points are computed on the GPU (no CPU fallback)", device); return ZKR_ERR_NO_DEVICE; }
-  synth_circuit(g.circ, 1u << log_m, n_public, circuit_seed);
+  synth_circuit(g.circ, 1u << log_m, n_public, circuit_seed, circuit_seed);
   SplitMix64 rng(toxic_seed);
   g.tox.t = rng.fr(); g.tox.alfa = rng.fr(); g.tox.beta = rng.fr(); g.tox.gamma = rng.fr(); g.tox.delta = rng.fr();
   setup_scalars(g.circ, g.tox, g.sc);
@@ -320,6 +321,19 @@ int zkr_synth_key(unsigned log_m, unsigned n_public, uint64_t circuit_seed, uint
     *aux_out = o;
     *aux_len = len;
   }
+  return 0;
+}
+
+int zkr_synth_witness(unsigned log_m, unsigned n_public, uint64_t circuit_seed, uint64_t witness_seed, void **witness_out, size_t *witness_len) {
+  if (!witness_out || !witness_len) { set_error("null argument"); return ZKR_ERR_ARG; }
+  if (log_m < 2 || log_m > 26 || n_public + 2 > (1u << log_m)) { set_error("bad synthetic geometry"); return ZKR_ERR_ARG; }
+  Circuit c;
+  synth_circuit(c, 1u << log_m, n_public, circuit_seed, witness_seed);
+  std::vector<uint8_t> wb;
+  to_std_bytes(c.w, wb);
+  *witness_out = malloc(wb.size());
+  memcpy(*witness_out, wb.data(), wb.size());
+  *witness_len = wb.size();
   return 0;
 }
 

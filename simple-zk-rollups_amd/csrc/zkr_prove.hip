@@ -19,7 +19,7 @@ void msm_ws_free(MsmWorkspace &ws);
 Fr host_root_of_unity(unsigned k);
 
 // ------------------------------------------------------------------ profiling (hipEvents on the launch stream)
-static const char *STAGES[] = {"ingest", "spmv", "ntt", "msm_sort", "msm_accum_g1", "msm_accum_g2", "msm_reduce", "total"};
+static const char *STAGES[] = {"ingest", "spmv", "ntt", "msm_sort", "msm_accum_g1", "msm_accum_g2", "msm_big", "msm_reduce", "total"};
 static int stage_index(const char *name) {
   for (int i = 0; i < (int)(sizeof(STAGES) / sizeof(STAGES[0])); i++)
     if (!strcmp(STAGES[i], name)) return i;
@@ -177,6 +177,8 @@ static int msm_enqueue(zkr_key *prof, hipStream_t s, const Affine<F> *pts, const
   sp = prof_begin(prof, s, MsmCfg<F>::ACC_STAGE);
   msm_accum_kernel<F, MsmCfg<F>::ACC_W><<<(pl.nb + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, s>>>(pts, ws.offsets, ws.entries, pl.nb, pl.big_thresh,
                                                                                                       (XYZZ<F> *)ws.buckets);
+  prof_end(prof, s, sp);
+  sp = prof_begin(prof, s, "msm_big");
   msm_big_kernel<F, MsmCfg<F>::RED_W><<<64, MSM_THREADS, MSM_THREADS * sizeof(XYZZ<F>), s>>>(pts, ws.offsets, ws.entries, ws.big_list, ws.big_count, 4096,
                                                                                             (XYZZ<F> *)ws.buckets);
   prof_end(prof, s, sp);

@@ -5,7 +5,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "csrc", "libzkr_hip.so"))
 PROOF_BYTES = 256
-STAGES = ("ingest", "spmv", "ntt", "msm_sort", "msm_accum_g1", "msm_accum_g2", "msm_reduce", "total")
+STAGES = ("ingest", "spmv", "ntt", "msm_sort", "msm_accum_g1", "msm_accum_g2", "msm_big", "msm_reduce", "total")
 _lib = None
 
 
@@ -48,6 +48,7 @@ def lib():
                                 c.POINTER(vp), c.POINTER(sz)]
     L.zkr_synth_websnark.argtypes = [c.c_uint, c.c_uint, c.c_uint64, c.c_uint64, i, c.POINTER(vp), c.POINTER(sz),
                                      c.POINTER(vp), c.POINTER(sz)]
+    L.zkr_synth_witness.argtypes = [c.c_uint, c.c_uint, c.c_uint64, c.c_uint64, c.POINTER(vp), c.POINTER(sz)]
     L.zkr_free.argtypes = [vp]
     L.zkr_free.restype = None
     L.zkr_bench_fq_mul.argtypes = [i, c.POINTER(c.c_double)]
@@ -199,6 +200,13 @@ def synth_websnark(log_m, n_public, circuit_seed, toxic_seed, device=0):
     _check(lib().zkr_synth_websnark(log_m, n_public, circuit_seed, toxic_seed, device, ctypes.byref(p), ctypes.byref(pl),
                                     ctypes.byref(w), ctypes.byref(wl)))
     return _take(p, pl.value), _take(w, wl.value)
+
+
+def synth_witness(log_m, n_public, circuit_seed, witness_seed):
+    """Another satisfying witness of the synthetic circuit (host only)."""
+    w, wl = ctypes.c_void_p(), ctypes.c_size_t()
+    _check(lib().zkr_synth_witness(log_m, n_public, circuit_seed, witness_seed, ctypes.byref(w), ctypes.byref(wl)))
+    return _take(w, wl.value)
 
 
 def bench_fq_mul(device=0) -> float:

@@ -1,0 +1,34 @@
+"""BASELINE.json full-size configuration (m = 2^20) through size-independent properties: the proof must
+equal the toxic-waste closed form bit-for-bit and satisfy the TxVerifier.sol pairing equation."""
+import pytest
+
+import groth16 as g
+
+pytestmark = pytest.mark.gpu
+
+
+def _proof_points(pb):
+    v = [int.from_bytes(pb[32 * i:32 * i + 32], "little") for i in range(8)]
+    return dict(pi_a=(v[0], v[1]), pi_b=((v[2], v[3]), (v[4], v[5])), pi_c=(v[6], v[7]))
+
+
+@pytest.mark.parametrize("log_m", [16, 20])
+def test_fullsize_proof_equals_closed_form_and_verifies(log_m):
+    import zkr_hip
+    p = 73
+    key, wb, aux = zkr_hip.ProvingKey.synth(log_m, p, 0x5A4B0001, 0x5A4B00FF)
+    rng = g.SplitMix64(99 + log_m)
+    r, s = rng.fr(), rng.fr()
+    proof = key.prove(wb, r, s)
+    expect, vk, pub = g.proof_from_aux(aux, wb, p, r, s)
+    assert proof == g.proof_bytes(expect)
+    assert g.is_valid(vk, _proof_points(proof), pub)
+    bad = list(pub)
+    bad[3] = (bad[3] + 1) % g.R
+    assert not g.is_valid(vk, _proof_points(proof), bad)  # withdrawverifier.test.ts:42-68 pattern
+    # a second witness of the same circuit on the same key
+    wb2 = zkr_hip.synth_witness(log_m, p, 0x5A4B0001, 4242)
+    proof2 = key.prove(wb2, r, s)
+    expect2, _, pub2 = g.proof_from_aux(aux, wb2, p, r, s)
+    assert proof2 == g.proof_bytes(expect2) and proof2 != proof
+    assert g.is_valid(vk, _proof_points(proof2), pub2)
