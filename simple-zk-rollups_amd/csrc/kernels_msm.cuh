@@ -19,6 +19,7 @@ namespace zkr {
 
 constexpr int MSM_THREADS = 256;
 constexpr int MSM_MAX_WINDOWS = 64;
+constexpr uint32_t BIG_CAP = 1024;  // oversized buckets tracked per MSM
 
 template <class F> struct PointBytes;
 template <> struct PointBytes<Fq> { static constexpr int N16 = 4; };   // 64 B affine
@@ -98,15 +99,35 @@ static __global__ __launch_bounds__(MSM_THREADS) void msm_count_kernel(const Fr 
   }
 }
 
-// single-workgroup exclusive scan of nb counts -> offsets[0..nb], cursor = offsets; lists big buckets
-static __global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t *counts, uint32_t *offsets, uint32_t *cursor, uint32_t nb,
-                                                        uint32_t big_thresh, uint32_t *big_list, uint32_t *big_count, uint32_t big_cap) {
+// exclusive scan of nb bucket counts in three launches (block sums -> scan of block sums -> apply);
+// SCAN_BLOCK counts per workgroup.  Also lists buckets larger than big_thresh.
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_PER_THREAD = 8;
+constexpr int SCAN_BLOCK = SCAN_THREADS * SCAN_PER_THREAD;
+
+static __global__ __launch_bounds__(SCAN_THREADS) void msm_scan_sums_kernel(const uint32_t *counts, uint32_t nb, uint32_t *block_sums) {
+  __shared__ uint32_t part[SCAN_THREADS];
+  uint32_t base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_PER_THREAD;
+  uint32_t s = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_PER_THREAD; k++) s += base + k < nb ? counts[base + k] : 0;
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (uint32_t off = SCAN_THREADS / 2; off > 0; off >>= 1) {
+    if (threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = part[0];
+}
+
+// in-place exclusive scan of nblocks block sums by one workgroup; writes the grand total to *total
+static __global__ __launch_bounds__(1024) void msm_scan_top_kernel(uint32_t *block_sums, uint32_t nblocks, uint32_t *total) {
   __shared__ uint32_t part[1024];
   uint32_t t = threadIdx.x;
-  uint32_t per = (nb + 1023) / 1024;
-  uint32_t lo = t * per, hi = min(lo + per, nb);
+  uint32_t per = (nblocks + 1023) / 1024;
+  uint32_t lo = t * per, hi = min(lo + per, nblocks);
   uint32_t s = 0;
-  for (uint32_t b = lo; b < hi; b++) s += counts[b];
+  for (uint32_t b = lo; b < hi; b++) s += block_sums[b];
   part[t] = s;
   __syncthreads();
   for (uint32_t off = 1; off < 1024; off <<= 1) {
@@ -116,17 +137,42 @@ static __global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t *c
     __syncthreads();
   }
   uint32_t run = part[t] - s;
-  for (uint32_t b = lo; b < hi; b++) {
-    uint32_t cnt = counts[b];
-    offsets[b] = run;
-    cursor[b] = run;
-    if (cnt > big_thresh) {
-      uint32_t k = atomicAdd(big_count, 1u);
-      if (k < big_cap) big_list[k] = b;
-    }
-    run += cnt;
+  for (uint32_t b = lo; b < hi; b++) { uint32_t c = block_sums[b]; block_sums[b] = run; run += c; }
+  if (t == 1023) *total = part[1023];
+}
+
+constexpr uint32_t BIG_MARK = 0xffffffffu;  // counts[b] after the scan: bucket b is owned by msm_big_kernel
+static __global__ __launch_bounds__(SCAN_THREADS) void msm_scan_apply_kernel(uint32_t *counts, const uint32_t *block_sums, const uint32_t *total,
+                                                                           uint32_t *offsets, uint32_t *cursor, uint32_t nb, uint32_t big_thresh,
+                                                                           uint32_t *big_list, uint32_t *big_count, uint32_t big_cap) {
+  __shared__ uint32_t part[SCAN_THREADS];
+  uint32_t base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_PER_THREAD;
+  uint32_t c[SCAN_PER_THREAD];
+  uint32_t s = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_PER_THREAD; k++) { c[k] = base + k < nb ? counts[base + k] : 0; s += c[k]; }
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (uint32_t off = 1; off < SCAN_THREADS; off <<= 1) {
+    uint32_t v = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
   }
-  if (t == 1023) offsets[nb] = part[1023];
+  uint32_t run = block_sums[blockIdx.x] + part[threadIdx.x] - s;
+#pragma unroll
+  for (int k = 0; k < SCAN_PER_THREAD; k++) {
+    if (base + k < nb) {
+      offsets[base + k] = run;
+      cursor[base + k] = run;
+      if (c[k] > big_thresh) {
+        uint32_t slot = atomicAdd(big_count, 1u);
+        if (slot < big_cap) { big_list[slot] = base + k; counts[base + k] = BIG_MARK; }  // beyond the cap the bucket stays with msm_accum_kernel
+      }
+      run += c[k];
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) offsets[nb] = *total;
 }
 
 // entries[pos] = (point index << 1) | sign, grouped by bucket
@@ -159,11 +205,11 @@ static __global__ __launch_bounds__(MSM_THREADS) void msm_scatter_kernel(const F
 // bucket accumulation: thread per bucket
 template <class F, int MINW>
 static __global__ __launch_bounds__(MSM_THREADS, MINW) void msm_accum_kernel(const Affine<F> *points, const uint32_t *offsets, const uint32_t *entries,
-                                                                     uint32_t nb, uint32_t big_thresh, XYZZ<F> *buckets) {
+                                                                     uint32_t nb, const uint32_t *counts, XYZZ<F> *buckets) {
   uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nb) return;
+  if (counts[b] == BIG_MARK) return;  // msm_big_kernel owns it
   uint32_t o0 = offsets[b], o1 = offsets[b + 1];
-  if (o1 - o0 > big_thresh) return;  // msm_big_kernel owns it
   XYZZ<F> acc = XYZZ<F>::inf();
   for (uint32_t j = o0; j < o1; j++) {
     uint32_t e = entries[j];
@@ -173,19 +219,24 @@ static __global__ __launch_bounds__(MSM_THREADS, MINW) void msm_accum_kernel(con
   store_pod(buckets + b, acc);
 }
 
-// oversized buckets: workgroup per bucket, strided accumulation then LDS tree
+// oversized buckets (0/1-heavy witnesses): BIG_SPLIT workgroups share one bucket, each does a strided
+// accumulation and an LDS tree; msm_big_finish_kernel adds the BIG_SPLIT partial sums.
+constexpr int BIG_SPLIT = 8;
+constexpr int BIG_SLOTS = 64;  // bucket slots per launch round (grid = BIG_SLOTS * BIG_SPLIT)
+
 template <class F, int MINW>
 static __global__ __launch_bounds__(MSM_THREADS, MINW) void msm_big_kernel(const Affine<F> *points, const uint32_t *offsets, const uint32_t *entries,
                                                                    const uint32_t *big_list, const uint32_t *big_count, uint32_t big_cap,
-                                                                   XYZZ<F> *buckets) {
+                                                                   XYZZ<F> *partials) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   XYZZ<F> *sh = reinterpret_cast<XYZZ<F> *>(smem);
   uint32_t nbig = min(*big_count, big_cap);
-  for (uint32_t w = blockIdx.x; w < nbig; w += gridDim.x) {
+  uint32_t sub = blockIdx.x % BIG_SPLIT;
+  for (uint32_t w = blockIdx.x / BIG_SPLIT; w < nbig; w += BIG_SLOTS) {
     uint32_t b = big_list[w];
     uint32_t o0 = offsets[b], o1 = offsets[b + 1];
     XYZZ<F> acc = XYZZ<F>::inf();
-    for (uint32_t j = o0 + threadIdx.x; j < o1; j += MSM_THREADS) {
+    for (uint32_t j = o0 + sub * MSM_THREADS + threadIdx.x; j < o1; j += MSM_THREADS * BIG_SPLIT) {
       uint32_t e = entries[j];
       Affine<F> p = load_pod(points + (e >> 1));
       acc = add_mixed(acc, p, (e & 1) != 0);
@@ -196,9 +247,19 @@ static __global__ __launch_bounds__(MSM_THREADS, MINW) void msm_big_kernel(const
       if (threadIdx.x < s) sh[threadIdx.x] = add_full(sh[threadIdx.x], sh[threadIdx.x + s]);
       __syncthreads();
     }
-    if (threadIdx.x == 0) store_pod(buckets + b, sh[0]);
+    if (threadIdx.x == 0) store_pod(partials + (size_t)w * BIG_SPLIT + sub, sh[0]);
     __syncthreads();
   }
+}
+
+template <class F, int MINW>
+static __global__ __launch_bounds__(64, MINW) void msm_big_finish_kernel(const XYZZ<F> *partials, const uint32_t *big_list, const uint32_t *big_count,
+                                                                         uint32_t big_cap, XYZZ<F> *buckets) {
+  uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= min(*big_count, big_cap)) return;
+  XYZZ<F> acc = load_pod(partials + (size_t)w * BIG_SPLIT);
+  for (int k = 1; k < BIG_SPLIT; k++) acc = add_full(acc, load_pod(partials + (size_t)w * BIG_SPLIT + k));
+  store_pod(buckets + big_list[w], acc);
 }
 
 // per group of 2^glog buckets of one window: sum_j (digit value) * B_j

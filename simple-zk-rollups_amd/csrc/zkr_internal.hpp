@@ -43,7 +43,8 @@ constexpr uint64_t ARENA_MAGIC = 0x313059454b524b5aull;
 
 struct MsmWorkspace {
   uint32_t *counts = nullptr, *offsets = nullptr, *cursor = nullptr, *entries = nullptr;
-  uint32_t *big_list = nullptr, *big_count = nullptr;
+  uint32_t *big_list = nullptr, *big_count = nullptr, *block_sums = nullptr;
+  void *big_partials = nullptr;
   void *buckets = nullptr, *group_out = nullptr, *window_out = nullptr;
   void *h_window = nullptr;  // pinned host copy of the window sums
   size_t max_nb = 0, max_entries = 0;
@@ -73,6 +74,8 @@ struct zkr_key {
   bool owns_arena = true;
   zkr::ArenaHeader h;
   hipStream_t stream = nullptr;
+  hipStream_t msm_stream[zkr::N_TABLES] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // the five MSMs run concurrently
+  hipEvent_t ev_w = nullptr, ev_h = nullptr, ev_done[zkr::N_TABLES] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   // workspace
   zkr::Fr *d_wraw = nullptr, *d_w = nullptr, *va = nullptr, *vb = nullptr, *ca = nullptr, *cb = nullptr, *d_h = nullptr;
   zkr::MsmWorkspace ws[zkr::N_TABLES];  // one per table so the five MSMs can be enqueued back to back

@@ -67,8 +67,10 @@ static int alloc_msm_ws(MsmWorkspace &ws, size_t n, const MsmPlan &pl, size_t xy
   ZKR_HIP_CHECK(hipMalloc(&ws.offsets, (nb + 1) * 4));
   ZKR_HIP_CHECK(hipMalloc(&ws.cursor, (nb + 1) * 4));
   ZKR_HIP_CHECK(hipMalloc(&ws.entries, (n * pl.K + 1) * 4));
-  ZKR_HIP_CHECK(hipMalloc(&ws.big_list, 4096 * 4));
-  ZKR_HIP_CHECK(hipMalloc(&ws.big_count, 4));
+  ZKR_HIP_CHECK(hipMalloc(&ws.big_list, BIG_CAP * 4));
+  ZKR_HIP_CHECK(hipMalloc(&ws.big_count, 8));
+  ZKR_HIP_CHECK(hipMalloc(&ws.block_sums, (nb / SCAN_BLOCK + 2) * 4));
+  ZKR_HIP_CHECK(hipMalloc(&ws.big_partials, (size_t)BIG_CAP * BIG_SPLIT * xyzz_bytes));
   ZKR_HIP_CHECK(hipMalloc(&ws.buckets, nb * xyzz_bytes));
   ZKR_HIP_CHECK(hipMalloc(&ws.group_out, (size_t)(pl.nbw >> pl.glog) * pl.K * xyzz_bytes));
   ZKR_HIP_CHECK(hipMalloc(&ws.window_out, MSM_MAX_WINDOWS * xyzz_bytes));
@@ -79,7 +81,7 @@ static int alloc_msm_ws(MsmWorkspace &ws, size_t n, const MsmPlan &pl, size_t xy
 }
 int msm_ws_alloc(MsmWorkspace &ws, size_t n, const MsmPlan &pl, size_t xyzz_bytes) { return alloc_msm_ws(ws, n, pl, xyzz_bytes); }
 void msm_ws_free(MsmWorkspace &ws) {
-  hipFree(ws.counts); hipFree(ws.offsets); hipFree(ws.cursor); hipFree(ws.entries); hipFree(ws.big_list); hipFree(ws.big_count);
+  hipFree(ws.counts); hipFree(ws.offsets); hipFree(ws.cursor); hipFree(ws.entries); hipFree(ws.big_list); hipFree(ws.big_count); hipFree(ws.block_sums); hipFree(ws.big_partials);
   hipFree(ws.buckets); hipFree(ws.group_out); hipFree(ws.window_out);
   if (ws.h_window) hipHostFree(ws.h_window);
   ws = MsmWorkspace();
@@ -89,6 +91,12 @@ int key_alloc_workspace(zkr_key *k) {
   ZKR_HIP_CHECK(hipSetDevice(k->device));
   const ArenaHeader &h = k->h;
   ZKR_HIP_CHECK(hipStreamCreateWithFlags(&k->stream, hipStreamNonBlocking));
+  for (int t = 0; t < N_TABLES; t++) {
+    ZKR_HIP_CHECK(hipStreamCreateWithFlags(&k->msm_stream[t], hipStreamNonBlocking));
+    ZKR_HIP_CHECK(hipEventCreateWithFlags(&k->ev_done[t], hipEventDisableTiming));
+  }
+  ZKR_HIP_CHECK(hipEventCreateWithFlags(&k->ev_w, hipEventDisableTiming));
+  ZKR_HIP_CHECK(hipEventCreateWithFlags(&k->ev_h, hipEventDisableTiming));
   ZKR_HIP_CHECK(hipMalloc(&k->d_wraw, (size_t)h.n * 32));
   ZKR_HIP_CHECK(hipMalloc(&k->d_w, (size_t)h.n * 32));
   Fr **vecs[5] = {&k->va, &k->vb, &k->ca, &k->cb, &k->d_h};
@@ -332,6 +340,12 @@ void zkr_key_free(zkr_key *k) {
   if (!k) return;
   hipSetDevice(k->device);
   if (k->stream) hipStreamSynchronize(k->stream);
+  for (int t = 0; t < N_TABLES; t++) {
+    if (k->msm_stream[t]) { hipStreamSynchronize(k->msm_stream[t]); hipStreamDestroy(k->msm_stream[t]); }
+    if (k->ev_done[t]) hipEventDestroy(k->ev_done[t]);
+  }
+  if (k->ev_w) hipEventDestroy(k->ev_w);
+  if (k->ev_h) hipEventDestroy(k->ev_h);
   for (int t = 0; t < N_TABLES; t++) msm_ws_free(k->ws[t]);
   hipFree(k->d_wraw); hipFree(k->d_w); hipFree(k->va); hipFree(k->vb); hipFree(k->ca); hipFree(k->cb); hipFree(k->d_h);
   for (auto e : k->event_pool) hipEventDestroy(e);

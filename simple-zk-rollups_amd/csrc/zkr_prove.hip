@@ -168,19 +168,24 @@ static int msm_enqueue(zkr_key *prof, hipStream_t s, const Affine<F> *pts, const
   g.n = n; g.c = pl.c; g.K = pl.K; g.nbw = pl.nbw; g.big_thresh = pl.big_thresh; g.glog = pl.glog;
   int sp = prof_begin(prof, s, "msm_sort");
   ZKR_HIP_CHECK(hipMemsetAsync(ws.counts, 0, ((size_t)pl.nb + 1) * 4, s));
-  ZKR_HIP_CHECK(hipMemsetAsync(ws.big_count, 0, 4, s));
+  ZKR_HIP_CHECK(hipMemsetAsync(ws.big_count, 0, 8, s));
   unsigned grid_n = (n + MSM_THREADS - 1) / MSM_THREADS;
   msm_count_kernel<<<grid_n, MSM_THREADS, 0, s>>>(scalars, sidx, g, ws.counts);
-  msm_scan_kernel<<<1, 1024, 0, s>>>(ws.counts, ws.offsets, ws.cursor, pl.nb, pl.big_thresh, ws.big_list, ws.big_count, 4096);
+  unsigned scan_blocks = (pl.nb + SCAN_BLOCK - 1) / SCAN_BLOCK;
+  msm_scan_sums_kernel<<<scan_blocks, SCAN_THREADS, 0, s>>>(ws.counts, pl.nb, ws.block_sums);
+  msm_scan_top_kernel<<<1, 1024, 0, s>>>(ws.block_sums, scan_blocks, ws.big_count + 1);
+  msm_scan_apply_kernel<<<scan_blocks, SCAN_THREADS, 0, s>>>(ws.counts, ws.block_sums, ws.big_count + 1, ws.offsets, ws.cursor, pl.nb, pl.big_thresh,
+                                                            ws.big_list, ws.big_count, BIG_CAP);
   msm_scatter_kernel<<<grid_n, MSM_THREADS, 0, s>>>(scalars, sidx, g, ws.cursor, ws.entries);
   prof_end(prof, s, sp);
   sp = prof_begin(prof, s, MsmCfg<F>::ACC_STAGE);
-  msm_accum_kernel<F, MsmCfg<F>::ACC_W><<<(pl.nb + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, s>>>(pts, ws.offsets, ws.entries, pl.nb, pl.big_thresh,
+  msm_accum_kernel<F, MsmCfg<F>::ACC_W><<<(pl.nb + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, s>>>(pts, ws.offsets, ws.entries, pl.nb, ws.counts,
                                                                                                       (XYZZ<F> *)ws.buckets);
   prof_end(prof, s, sp);
   sp = prof_begin(prof, s, "msm_big");
-  msm_big_kernel<F, MsmCfg<F>::RED_W><<<64, MSM_THREADS, MSM_THREADS * sizeof(XYZZ<F>), s>>>(pts, ws.offsets, ws.entries, ws.big_list, ws.big_count, 4096,
-                                                                                            (XYZZ<F> *)ws.buckets);
+  msm_big_kernel<F, MsmCfg<F>::RED_W><<<BIG_SLOTS * BIG_SPLIT, MSM_THREADS, MSM_THREADS * sizeof(XYZZ<F>), s>>>(pts, ws.offsets, ws.entries, ws.big_list, ws.big_count,
+                                                                                                             BIG_CAP, (XYZZ<F> *)ws.big_partials);
+  msm_big_finish_kernel<F, MsmCfg<F>::RED_W><<<BIG_CAP / 64, 64, 0, s>>>((const XYZZ<F> *)ws.big_partials, ws.big_list, ws.big_count, BIG_CAP, (XYZZ<F> *)ws.buckets);
   prof_end(prof, s, sp);
   sp = prof_begin(prof, s, "msm_reduce");
   uint32_t gpw = pl.nbw >> pl.glog;
@@ -246,14 +251,27 @@ static int prove_on_device(zkr_key *k, const Fr *d_wsrc, const uint8_t *r32, con
   int sp = prof_begin(k, s, "ingest");
   ingest_kernel<<<(h.n + 255) / 256, 256, 0, s>>>(d_wsrc, k->d_w, h.n);
   prof_end(k, s, sp);
+  // witness MSMs (A, B1, B2, C) depend only on the ingested witness and run beside calcH; the H MSM waits for h.
+  // Each MSM has its own stream so latency-bound stages (scan, oversized buckets, bucket reduction) of one
+  // overlap the throughput-bound bucket accumulation of another.
+  ZKR_HIP_CHECK(hipEventRecord(k->ev_w, s));
+  for (int t = 0; t < N_TABLES; t++)
+    if (t != T_H) ZKR_HIP_CHECK(hipStreamWaitEvent(k->msm_stream[t], k->ev_w, 0));
   int rc;
   if ((rc = calc_h_device(k, s))) return rc;
+  ZKR_HIP_CHECK(hipEventRecord(k->ev_h, s));
+  ZKR_HIP_CHECK(hipStreamWaitEvent(k->msm_stream[T_H], k->ev_h, 0));
   const Fr *scal[N_TABLES] = {k->d_w, k->d_w, k->d_w, k->d_w, k->d_h};
-  for (int t = 0; t < N_TABLES; t++) {
+  static const int order[N_TABLES] = {T_B2, T_A, T_B1, T_C, T_H};  // longest first
+  for (int oi = 0; oi < N_TABLES; oi++) {
+    int t = order[oi];
+    hipStream_t ms = k->msm_stream[t];
     const uint32_t *sidx = (const uint32_t *)(ar + h.off_sidx[t]);
-    if (t == T_B2) rc = msm_enqueue<Fq2>(k, s, (const G2Affine *)(ar + h.off_pts[t]), sidx, scal[t], h.npts[t], k->plan[t], k->ws[t]);
-    else rc = msm_enqueue<Fq>(k, s, (const G1Affine *)(ar + h.off_pts[t]), sidx, scal[t], h.npts[t], k->plan[t], k->ws[t]);
+    if (t == T_B2) rc = msm_enqueue<Fq2>(k, ms, (const G2Affine *)(ar + h.off_pts[t]), sidx, scal[t], h.npts[t], k->plan[t], k->ws[t]);
+    else rc = msm_enqueue<Fq>(k, ms, (const G1Affine *)(ar + h.off_pts[t]), sidx, scal[t], h.npts[t], k->plan[t], k->ws[t]);
     if (rc) return rc;
+    ZKR_HIP_CHECK(hipEventRecord(k->ev_done[t], ms));
+    ZKR_HIP_CHECK(hipStreamWaitEvent(s, k->ev_done[t], 0));
   }
   prof_end(k, s, tot);
   ZKR_HIP_CHECK(hipStreamSynchronize(s));

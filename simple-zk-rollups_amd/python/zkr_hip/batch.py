@@ -10,30 +10,17 @@ def shard_indices(count, rank, world):
     return list(range(rank, count, world))
 
 
-def broadcast_key(key, rank, world, device, dist=None):
-    """rank 0 holds `key`; every other rank receives the arena bytes and adopts them.
-    Returns a ProvingKey on every rank (rank 0: the same object)."""
-    from .binding import ProvingKey
-    if world == 1:
-        return key
-    import torch.distributed as d
-    dist = dist or d
-    dev = torch.device("cuda", device)
-    n = torch.zeros(1, dtype=torch.int64, device=dev)
+def broadcast_arena(arena, rank, dist, device):
+    """Broadcast a uint8 tensor (the key arena) from rank 0; other ranks pass None and get a new tensor
+    on `device`.  Two collectives: the length, then the bytes."""
+    n = torch.zeros(1, dtype=torch.int64, device=device)
     if rank == 0:
-        ptr, length = key.arena()
-        n[0] = length
+        n[0] = arena.numel()
     dist.broadcast(n, src=0)
-    length = int(n.item())
-    if rank == 0:
-        # view the existing arena as a tensor without copying
-        arena = _tensor_from_ptr(ptr, length, device)
-        dist.broadcast(arena, src=0)
-        return key
-    buf = torch.empty(length, dtype=torch.uint8, device=dev)
-    dist.broadcast(buf, src=0)
-    torch.cuda.synchronize(dev)
-    return ProvingKey.adopt_arena(buf.data_ptr(), length, device, keepalive=buf)
+    if rank != 0:
+        arena = torch.empty(int(n.item()), dtype=torch.uint8, device=device)
+    dist.broadcast(arena, src=0)
+    return arena
 
 
 class _CudaArray:
@@ -42,15 +29,47 @@ class _CudaArray:
 
 
 def _tensor_from_ptr(ptr, nbytes, device):
+    """Zero-copy uint8 view of device memory owned by the C library."""
     with torch.cuda.device(device):
         return torch.as_tensor(_CudaArray(ptr, nbytes), device=torch.device("cuda", device))
 
 
+def broadcast_key(key, rank, world, device, dist=None):
+    """rank 0 holds `key`; every other rank receives the arena bytes and adopts them
+    (zkr_key_adopt_arena).  Returns a ProvingKey on every rank (rank 0: the same object)."""
+    from .binding import ProvingKey
+    if world == 1:
+        return key
+    if dist is None:
+        import torch.distributed as dist
+    dev = torch.device("cuda", device)
+    if rank == 0:
+        ptr, length = key.arena()
+        broadcast_arena(_tensor_from_ptr(ptr, length, device), 0, dist, dev)
+        return key
+    buf = broadcast_arena(None, rank, dist, dev)
+    torch.cuda.synchronize(dev)
+    return ProvingKey.adopt_arena(buf.data_ptr(), buf.numel(), device, keepalive=buf)
+
+
 def prove_batch(key, witnesses, blinding, rank=0, world=1):
-    """Prove the proofs of this rank's shard.  witnesses: list of bytes; blinding: list of (r, s).
-    Returns {index: proof_bytes} for the local shard."""
+    """Prove this rank's shard.  witnesses: list of bytes (or None for proofs of other ranks);
+    blinding: list of (r, s).  Returns {index: proof_bytes} for the local shard."""
     out = {}
     for i in shard_indices(len(witnesses), rank, world):
         r, s = blinding[i]
         out[i] = key.prove(witnesses[i], r, s)
     return out
+
+
+def gather_proofs(local, count, dist=None):
+    """Collect {index: proof} dicts on every rank (256 B per proof; not on the data path)."""
+    if dist is None:
+        return local
+    parts = [None] * dist.get_world_size()
+    dist.all_gather_object(parts, local)
+    merged = {}
+    for p in parts:
+        merged.update(p)
+    assert sorted(merged) == list(range(count)), "every proof index must be produced exactly once"
+    return merged

@@ -22,7 +22,7 @@ for name in ("TxVerifier", "WithdrawVerifier"):
         "g1": {k: [x, y] for k, x, y in g1},
         "g2": {k: [[a, b], [c, d]] for k, a, b, c, d in g2},
         "g2_generator": [[gen.group(1), gen.group(2)], [gen.group(3), gen.group(4)]],
-        "n_inputs": int(re.search(r"uint\[(\d+)\] memory input", src).group(1)),
+        "n_inputs": int(re.findall(r"uint\[(\d+)\] memory input\s*\)", src)[-1]),
     }
 path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "verifier_points.json")
 json.dump(out, open(path, "w"), indent=1)

@@ -1,0 +1,86 @@
+"""CPU, world_size 2, gloo: the N>1 path of the batch driver -- arena broadcast, proof sharding with no
+data-path collective, result gather, max-over-ranks timing.  (On the GPU box the same code runs over
+RCCL; the adopted arena is exercised by tests/test_gpu_stages.py.)"""
+import hashlib
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+class _FakeKey:
+    """Stands in for ProvingKey on CPU: 'proves' by hashing (arena, witness, r, s)."""
+
+    def __init__(self, arena):
+        self.tag = hashlib.sha256(bytes(arena.numpy().tobytes())).digest()
+
+    def prove(self, witness, r, s):
+        return hashlib.sha256(self.tag + witness + int(r).to_bytes(32, "little") + int(s).to_bytes(32, "little")).digest() * 8
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "simple-zk-rollups_amd", "python"))
+    import zkr_hip
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(1234)
+    arena = torch.randint(0, 256, (100_003,), dtype=torch.uint8, generator=g) if rank == 0 else None
+    arena = zkr_hip.broadcast_arena(arena, rank, dist, torch.device("cpu"))
+    key = _FakeKey(arena)
+    count = 9
+    witnesses = [bytes([i]) * 64 for i in range(count)]
+    blinding = [(100 + i, 200 + i) for i in range(count)]
+    local = zkr_hip.prove_batch(key, witnesses, blinding, rank, world)
+    assert sorted(local) == zkr_hip.shard_indices(count, rank, world)
+    merged = zkr_hip.gather_proofs(local, count, dist)
+    t = torch.tensor([1.0 + rank], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, hashlib.sha256(b"".join(merged[i] for i in range(count))).hexdigest(), float(t.item()), arena.numel()))
+
+
+def test_two_rank_batch_over_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    res.sort()
+    assert res[0][1] == res[1][1]            # both ranks hold the same full set of proofs
+    assert res[0][2] == res[1][2] == 2.0     # max over ranks
+    assert res[0][3] == res[1][3] == 100_003
+
+    # single-process reference: same proofs without any sharding
+    import zkr_hip
+    g = torch.Generator().manual_seed(1234)
+    key = _FakeKey(torch.randint(0, 256, (100_003,), dtype=torch.uint8, generator=g))
+    allp = zkr_hip.prove_batch(key, [bytes([i]) * 64 for i in range(9)], [(100 + i, 200 + i) for i in range(9)])
+    assert hashlib.sha256(b"".join(allp[i] for i in range(9))).hexdigest() == res[0][1]
+
+
+def test_shard_indices_partition():
+    import zkr_hip
+    for count in (0, 1, 7, 64):
+        for world in (1, 2, 4, 8):
+            seen = sorted(i for r in range(world) for i in zkr_hip.shard_indices(count, r, world))
+            assert seen == list(range(count))
+    assert zkr_hip.shard_indices(64, 3, 8) == [3, 11, 19, 27, 35, 43, 51, 59]  # BASELINE config 4: 8 proofs per GPU

@@ -1,0 +1,142 @@
+"""CPU: index-for-index Python model of the HIP NTT pass structure (csrc/kernels_ntt.cuh ntt_pass_kernel,
+zkr_prove.hip ntt_plan) and of the calcH pipeline constants, checked against the oracle NTT / calcH."""
+import random
+
+import groth16 as g
+from bn254 import R
+
+
+def bitrev(x, L):
+    return int(bin(x)[2:].zfill(L)[::-1], 2) if L else 0
+
+
+def make_tw(m):
+    w = g.root_of_unity(2 * m)
+    t = [1] * m
+    for k in range(1, m):
+        t[k] = t[k - 1] * w % R
+    return t
+
+
+def tw_lookup(table, tlog, slog, x, inverse):
+    idx = x << (tlog - slog)
+    if not inverse:
+        return table[idx]
+    return 1 if idx == 0 else (-table[(1 << tlog) - idx]) % R
+
+
+def ntt_plan(L, tile_log, strided_log):
+    v = []
+    lows = min(L, tile_log)
+    rem = L - lows
+    if rem > 0:
+        nch = (rem + strided_log - 1) // strided_log
+        hi = L
+        for i in range(nch):
+            nb = (rem + (nch - i) - 1) // (nch - i)
+            lo = hi - nb
+            v.append((lo, hi, min(tile_log - nb, lo)))
+            hi = lo
+            rem -= nb
+    v.append((0, lows, 0))
+    return v
+
+
+def ntt_pass(x, L, lo, hi, wlog, dif, inverse, tw, tlog, twl, twl_log):
+    nb, W = hi - lo, 1 << wlog
+    rows = 1 << nb
+    tile = rows << wlog
+    lb = (1 << lo) >> wlog
+    for blk in range((1 << L) // tile):
+        q, l0 = blk // lb, (blk % lb) << wlog
+        base = (q << hi) + l0
+        lds = [x[base + ((e >> wlog) << lo) + (e & (W - 1))] for e in range(tile)]
+        for jj in range(nb):
+            j = nb - 1 - jj if dif else jj
+            sl, slog = 1 << j, j + lo
+            table, tl = (twl, twl_log) if slog <= twl_log else (tw, tlog)
+            for b in range(tile >> 1):
+                c, kk = b & (W - 1), b >> wlog
+                r0 = ((kk >> j) << (j + 1)) | (kk & (sl - 1))
+                e0 = (r0 << wlog) + c
+                e1 = e0 + (sl << wlog)
+                imods = ((kk & (sl - 1)) << lo) + l0 + c
+                w = tw_lookup(table, tl, slog, imods, inverse)
+                u, v = lds[e0], lds[e1]
+                if dif:
+                    lds[e0], lds[e1] = (u + v) % R, (u - v) * w % R
+                else:
+                    v = v * w % R
+                    lds[e0], lds[e1] = (u + v) % R, (u - v) % R
+        for e in range(tile):
+            x[base + ((e >> wlog) << lo) + (e & (W - 1))] = lds[e]
+
+
+def run_ntt(x, L, dif, inverse, tw, tlog, twl, twl_log, tile_log=4, strided_log=3):
+    plan = ntt_plan(L, tile_log, strided_log)
+    if not dif:
+        plan = plan[::-1]
+    for lo, hi, wlog in plan:
+        ntt_pass(x, L, lo, hi, wlog, dif, inverse, tw, tlog, twl, twl_log)
+
+
+def test_pass_structure_matches_oracle_ntt():
+    rnd = random.Random(5)
+    twl_log = 3                      # scaled-down local table (device: 10), tile 2^4 (device: 2^11)
+    twl = make_tw(1 << twl_log)
+    for L in (1, 3, 4, 6, 9, 11):
+        m = 1 << L
+        tw = make_tw(m)
+        v = [rnd.randrange(R) for _ in range(m)]
+        ref = g.ntt(v)
+        x = list(v)
+        run_ntt(x, L, True, False, tw, L, twl, twl_log)
+        assert [x[bitrev(i, L)] for i in range(m)] == ref, L
+        y = [ref[bitrev(i, L)] for i in range(m)]
+        run_ntt(y, L, False, True, tw, L, twl, twl_log)
+        minv = pow(m, R - 2, R)
+        assert [a * minv % R for a in y] == v, L
+
+
+def test_device_plan_shapes():
+    for L in range(1, 28):
+        plan = ntt_plan(L, 11, 9)
+        assert plan[-1] == (0, min(L, 11), 0)
+        bits = sorted((lo, hi) for lo, hi, _ in plan)
+        assert bits[0][0] == 0 and bits[-1][1] == L and all(a[1] == b[0] for a, b in zip(bits, bits[1:]))
+        for lo, hi, wlog in plan[:-1]:
+            assert hi - lo <= 9 and hi - lo + wlog <= 11 and wlog <= lo and lo >= 11
+
+
+def test_calc_h_pipeline_constants():
+    """the GPU route: 2 iNTT(DIF) -> coset scale by tw[bitrev] -> 2 NTT(DIT) -> 2 iNTT(DIF) of products -> combine"""
+    circ = g.synth_circuit(64, 5, 0x5A4B0001)
+    sc = g.setup_scalars(circ, g.toxic_from_seed(1))
+    pk = dict(nVars=circ["nVars"], nPublic=5, domainSize=64, polsA=sc["polsA"], polsB=sc["polsB"])
+    m, L = 64, 6
+    tw, twl = make_tw(m), make_tw(8)
+    MONT = (1 << 256) % R
+    Rinv = pow(MONT, R - 2, R)
+    montmul = lambda a, b: a * b * Rinv % R
+    for w in (circ["witness"], [(x + (i == 10)) % R for i, x in enumerate(circ["witness"])]):
+        a, b = g.qap_evaluate(pk, w)
+        A, B = list(a), list(b)
+        run_ntt(A, L, True, True, tw, L, twl, 3)
+        run_ntt(B, L, True, True, tw, L, twl, 3)
+        A = [A[p] * tw[bitrev(p, L)] % R for p in range(m)]
+        B = [B[p] * tw[bitrev(p, L)] % R for p in range(m)]
+        run_ntt(A, L, False, False, tw, L, twl, 3)
+        run_ntt(B, L, False, False, tw, L, twl, 3)
+        U = [montmul(x, y) for x, y in zip(A, B)]
+        V = [montmul(x, y) for x, y in zip(a, b)]
+        run_ntt(U, L, True, True, tw, L, twl, 3)
+        run_ntt(V, L, True, True, tw, L, twl, 3)
+        minv, half = pow(m, R - 2, R), pow(2, R - 2, R)
+        c1 = MONT * MONT % R * half % R * minv % R
+        c2 = c1 * minv % R * minv % R
+        h_br = []
+        for pos in range(m):
+            i = bitrev(pos, L)
+            ginv_mont = MONT if i == 0 else (-tw[m - i] * MONT) % R
+            h_br.append((montmul(V[pos], c1) - montmul(montmul(U[pos], ginv_mont), c2)) % R)
+        assert [h_br[bitrev(i, L)] for i in range(m)] == g.calc_h_websnark(pk, w)
