@@ -1,0 +1,23 @@
+// Types for the Node.js host of the MI355X Groth16 prover (mirrors the websnark / snarkjs surfaces the
+// reference uses: operator/src/snarks/common.ts:4-5,23,29).
+export interface Groth16Proof {
+  pi_a: [string, string, string];
+  pi_b: [[string, string], [string, string], [string, string]];
+  pi_c: [string, string, string];
+  protocol?: "groth";
+}
+export interface ProveOptions { r?: bigint | string; s?: bigint | string; device?: number; }
+export interface Bn128 {
+  /** websnark-compatible: ArrayBuffers produced by binarifyWitness / binarifyProvingKey. */
+  groth16GenProof(witnessBin: ArrayBuffer | Uint8Array, provingKeyBin: ArrayBuffer | Uint8Array, opts?: ProveOptions): Promise<Groth16Proof>;
+  keyInfo(): { nVars: number; nPublic: number; domainSize: number; nnzA: number; nnzB: number } | null;
+  terminate(): void;
+}
+export function buildBn128(device?: number): Promise<Bn128>;
+export function genProof(provingKey: any, witness: Array<bigint | string>, opts?: ProveOptions): Promise<{ proof: Groth16Proof; publicSignals: string[] }>;
+export function binarifyWitness(witness: Array<bigint | string>): ArrayBuffer;
+export function binarifyProvingKey(provingKey: any): ArrayBuffer;
+export function solidityProof(proof: Groth16Proof, publicSignals: Array<bigint | string>): { a: string[]; b: string[][]; c: string[]; inputs: string[] };
+export function proofFromBytes(proofBytes: Uint8Array): Groth16Proof;
+export function deviceCount(): number;
+export function version(): string;

@@ -1,0 +1,143 @@
+"use strict";
+// Host side of the MI355X Groth16 prover for Node.js (CommonJS; tsc is not needed to consume it,
+// index.d.ts carries the types).  Same surface as the two things the reference uses:
+//   websnark  : buildBn128() -> { groth16GenProof(witnessBin, provingKeyBin) }      (operator/src/snarks/common.ts:5,23,29)
+//   snarkjs   : groth.genProof(provingKey, witness) -> { proof, publicSignals }      (north-star "witness in, {proof, publicSignals} out")
+// plus binarifyWitness / binarifyProvingKey, the native-BigInt equivalents of operator/src/utils/binarify.ts.
+// All arithmetic happens in csrc/libzkr_hip.so on the GPU; there is no JS or CPU fallback prover.
+const path = require("path");
+
+const Q = 21888242871839275222246405745257275088696311157297823662689037894645226208583n;
+const R = 21888242871839275222246405745257275088548364400416034343698204186575808495617n;
+const MONT = 1n << 256n;
+
+let addon = null;
+let deviceCount = -1;
+function native() {
+  if (addon) return addon;
+  const a = require(path.join(__dirname, "napi", "zkr_napi.node"));
+  deviceCount = a.load(process.env.ZKR_HIP_LIB || path.join(__dirname, "csrc", "libzkr_hip.so"));
+  addon = a;
+  return addon;
+}
+
+function leBytesToDecimal(buf, off) {
+  let v = 0n;
+  for (let i = 31; i >= 0; i--) v = (v << 8n) | BigInt(buf[off + i]);
+  return v.toString();
+}
+
+function proofFromBytes(pb) {
+  const s = [];
+  for (let i = 0; i < 8; i++) s.push(leBytesToDecimal(pb, 32 * i));
+  return { pi_a: [s[0], s[1], "1"], pi_b: [[s[2], s[3]], [s[4], s[5]], ["1", "0"]], pi_c: [s[6], s[7], "1"] };
+}
+
+function bigintToLe32(v) {
+  const out = Buffer.alloc(32);
+  let x = BigInt(v);
+  for (let i = 0; i < 32; i++) { out[i] = Number(x & 0xffn); x >>= 8n; }
+  return out;
+}
+
+function keyFingerprint(buf) {
+  // cheap identity for the per-instance key cache: length + FNV-1a of the header and the tail
+  const u8 = buf instanceof ArrayBuffer ? new Uint8Array(buf) : new Uint8Array(buf.buffer, buf.byteOffset, buf.byteLength);
+  let h = 0x811c9dc5;
+  const mix = (b) => { h ^= b; h = Math.imul(h, 0x01000193) >>> 0; };
+  const n = u8.length;
+  for (let i = 0; i < Math.min(n, 4096); i++) mix(u8[i]);
+  for (let i = Math.max(0, n - 4096); i < n; i++) mix(u8[i]);
+  return n + ":" + h;
+}
+
+class Bn128 {
+  constructor(device) { this.device = device || 0; this._fp = null; this._key = null; }
+
+  // websnark signature.  The reference re-parses the key on every call (common.ts:28-29); here the parsed,
+  // uploaded key is kept while the same buffer keeps arriving.  opts.r / opts.s (BigInt|string) fix the blinding.
+  async groth16GenProof(witnessBin, provingKeyBin, opts) {
+    const a = native();
+    const fp = keyFingerprint(provingKeyBin);
+    if (fp !== this._fp) { this._key = a.keyLoad(provingKeyBin, this.device); this._fp = fp; }
+    const r = opts && opts.r !== undefined ? bigintToLe32(opts.r) : null;
+    const s = opts && opts.s !== undefined ? bigintToLe32(opts.s) : null;
+    const pb = await a.prove(this._key, witnessBin, r, s);
+    return proofFromBytes(pb);
+  }
+
+  keyInfo() {
+    if (!this._key) return null;
+    const v = native().keyInfo(this._key);
+    return { nVars: v[0], nPublic: v[1], domainSize: v[2], nnzA: v[3], nnzB: v[4] };
+  }
+
+  terminate() { this._key = null; this._fp = null; }
+}
+
+async function buildBn128(device) {
+  native();
+  return new Bn128(device);
+}
+
+// ---- binarify.ts equivalents on native BigInt (operator/src/utils/binarify.ts:10-48, 50-207)
+function binarifyWitness(witness) {
+  const out = Buffer.alloc(witness.length * 32);
+  witness.forEach((w, i) => bigintToLe32(BigInt(w)).copy(out, 32 * i));
+  return out.buffer.slice(out.byteOffset, out.byteOffset + out.byteLength);
+}
+
+function binarifyProvingKey(pk) {
+  const n = pk.nVars, p = pk.nPublic, m = pk.domainSize;
+  const polSize = (pol) => 36 * Object.keys(pol).length + 4;
+  let size = 40 + 3 * 64 + 2 * 128;
+  for (let i = 0; i < n; i++) size += polSize(pk.polsA[i]) + polSize(pk.polsB[i]);
+  size += n * 64 * 2 + n * 128 + (n - p - 1) * 64 + m * 64;
+  const buf = Buffer.alloc(size);
+  let off = 0;
+  const u32 = (v) => { buf.writeUInt32LE(Number(v), off); off += 4; };
+  const fq = (v) => { bigintToLe32((BigInt(v) * MONT) % Q).copy(buf, off); off += 32; };
+  const fr = (v) => { bigintToLe32((BigInt(v) * MONT) % R).copy(buf, off); off += 32; };
+  const pt = (P) => { fq(P[0]); fq(P[1]); };
+  const pt2 = (P) => { fq(P[0][0]); fq(P[0][1]); fq(P[1][0]); fq(P[1][1]); };
+  const pol = (d) => { const keys = Object.keys(d); u32(keys.length); for (const k of keys) { u32(k); fr(d[k]); } };
+  u32(n); u32(p); u32(m);
+  const ptrAt = off; off += 28;
+  pt(pk.vk_alfa_1); pt(pk.vk_beta_1); pt(pk.vk_delta_1); pt2(pk.vk_beta_2); pt2(pk.vk_delta_2);
+  const ptrs = [];
+  ptrs.push(off); for (let i = 0; i < n; i++) pol(pk.polsA[i]);
+  ptrs.push(off); for (let i = 0; i < n; i++) pol(pk.polsB[i]);
+  ptrs.push(off); for (let i = 0; i < n; i++) pt(pk.A[i]);
+  ptrs.push(off); for (let i = 0; i < n; i++) pt(pk.B1[i]);
+  ptrs.push(off); for (let i = 0; i < n; i++) pt2(pk.B2[i]);
+  ptrs.push(off); for (let i = p + 1; i < n; i++) pt(pk.C[i]);
+  ptrs.push(off); for (let i = 0; i < m; i++) pt(pk.hExps[i]);
+  if (off !== size) throw new Error("binarifyProvingKey: size mismatch");
+  ptrs.forEach((v, i) => buf.writeUInt32LE(v, ptrAt + 4 * i));
+  return buf.buffer.slice(buf.byteOffset, buf.byteOffset + buf.byteLength);
+}
+
+// snarkjs-0.1.20 groth.genProof shape on top of the same core
+async function genProof(provingKey, witness, opts) {
+  const bn = await buildBn128(opts && opts.device);
+  const proof = await bn.groth16GenProof(binarifyWitness(witness), binarifyProvingKey(provingKey), opts);
+  proof.protocol = "groth";
+  const publicSignals = witness.slice(1, provingKey.nPublic + 1).map((x) => BigInt(x).toString());
+  return { proof, publicSignals };
+}
+
+// operator/src/snarks/common.ts:43-50
+function solidityProof(proof, publicSignals) {
+  return {
+    a: proof.pi_a.slice(0, 2),
+    b: proof.pi_b.map((x) => x.slice().reverse()).slice(0, 2),
+    c: proof.pi_c.slice(0, 2),
+    inputs: publicSignals.map((x) => (BigInt(x) % R).toString()),
+  };
+}
+
+module.exports = {
+  buildBn128, genProof, binarifyWitness, binarifyProvingKey, solidityProof, proofFromBytes,
+  deviceCount: () => { native(); return deviceCount; },
+  version: () => native().version(),
+};

@@ -1,0 +1,206 @@
+/* zkr_napi.c -- thin N-API addon binding the C ABI of include/zkr.h for Node.js.
+ *
+ * It is the FFI a maintainer of kendricktan/simple-zk-rollups adds so that
+ *   import { buildBn128 } from "websnark"            (operator/src/snarks/common.ts:5, scripts/index.js:19)
+ * can become  require("simple-zk-rollups_amd")  with the same surface (see ../index.js).
+ * Plain C against <node_api.h>; libzkr_hip.so is dlopen'ed at run time, so the addon itself loads on a
+ * machine without ROCm and reports the problem as a rejected promise / thrown Error.
+ */
+#include <dlfcn.h>
+#include <node_api.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct zkr_key zkr_key;
+static struct {
+  void *handle;
+  const char *(*last_error)(void);
+  const char *(*version)(void);
+  int (*device_count)(void);
+  int (*key_load_websnark)(const void *, size_t, int, zkr_key **);
+  void (*key_free)(zkr_key *);
+  int (*key_info)(const zkr_key *, uint64_t *);
+  int (*prove)(zkr_key *, const void *, size_t, const uint8_t *, const uint8_t *, uint8_t *, void *);
+} Z;
+
+#define NAPI_OK(call)                                                     \
+  do {                                                                    \
+    if ((call) != napi_ok) {                                              \
+      napi_throw_error(env, NULL, "zkr_napi: N-API call failed: " #call); \
+      return NULL;                                                        \
+    }                                                                     \
+  } while (0)
+
+static napi_value throw_msg(napi_env env, const char *msg) {
+  napi_throw_error(env, "ZKR", msg);
+  return NULL;
+}
+
+/* load(libPath) -> number of HIP devices */
+static napi_value js_load(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  char path[4096];
+  size_t n = 0;
+  NAPI_OK(napi_get_value_string_utf8(env, argv[0], path, sizeof(path), &n));
+  if (!Z.handle) {
+    void *h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+    if (!h) {
+      char msg[4600];
+      strcpy(msg, "cannot load libzkr_hip.so (there is no CPU fallback): ");
+      strncat(msg, dlerror(), 4000);
+      return throw_msg(env, msg);
+    }
+#define SYM(field, name)                                                        \
+  *(void **)(&Z.field) = dlsym(h, name);                                        \
+  if (!Z.field) return throw_msg(env, "libzkr_hip.so lacks symbol " name);
+    SYM(last_error, "zkr_last_error") SYM(version, "zkr_version") SYM(device_count, "zkr_device_count")
+    SYM(key_load_websnark, "zkr_key_load_websnark") SYM(key_free, "zkr_key_free") SYM(key_info, "zkr_key_info") SYM(prove, "zkr_prove")
+    Z.handle = h;
+  }
+  napi_value out;
+  NAPI_OK(napi_create_int32(env, Z.device_count(), &out));
+  return out;
+}
+
+static napi_value js_version(napi_env env, napi_callback_info info) {
+  (void)info;
+  if (!Z.handle) return throw_msg(env, "libzkr_hip.so not loaded");
+  napi_value out;
+  NAPI_OK(napi_create_string_utf8(env, Z.version(), NAPI_AUTO_LENGTH, &out));
+  return out;
+}
+
+static int get_bytes(napi_env env, napi_value v, const uint8_t **data, size_t *len) {
+  bool is;
+  if (napi_is_arraybuffer(env, v, &is) == napi_ok && is) return napi_get_arraybuffer_info(env, v, (void **)data, len) == napi_ok;
+  if (napi_is_buffer(env, v, &is) == napi_ok && is) return napi_get_buffer_info(env, v, (void **)data, len) == napi_ok;
+  if (napi_is_typedarray(env, v, &is) == napi_ok && is) {
+    napi_typedarray_type t;
+    napi_value ab;
+    size_t off, count;
+    if (napi_get_typedarray_info(env, v, &t, &count, (void **)data, &ab, &off) != napi_ok) return 0;
+    *len = count * (t == napi_uint8_array || t == napi_int8_array || t == napi_uint8_clamped_array ? 1 : t == napi_uint32_array || t == napi_int32_array || t == napi_float32_array ? 4 : 8);
+    return 1;
+  }
+  return 0;
+}
+
+static void key_finalize(napi_env env, void *data, void *hint) {
+  (void)env; (void)hint;
+  if (data && Z.key_free) Z.key_free((zkr_key *)data);
+}
+
+/* keyLoad(provingKeyBin, device) -> external handle (synchronous: parse + upload once per key) */
+static napi_value js_key_load(napi_env env, napi_callback_info info) {
+  size_t argc = 2;
+  napi_value argv[2];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  if (!Z.handle) return throw_msg(env, "libzkr_hip.so not loaded");
+  const uint8_t *pk; size_t len; int32_t dev = 0;
+  if (!get_bytes(env, argv[0], &pk, &len)) return throw_msg(env, "provingKeyBin must be an ArrayBuffer / Buffer / TypedArray");
+  if (argc > 1) napi_get_value_int32(env, argv[1], &dev);
+  zkr_key *key = NULL;
+  int rc = Z.key_load_websnark(pk, len, dev, &key);
+  if (rc) return throw_msg(env, Z.last_error());
+  napi_value ext;
+  NAPI_OK(napi_create_external(env, key, key_finalize, NULL, &ext));
+  return ext;
+}
+
+static napi_value js_key_info(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  zkr_key *key;
+  NAPI_OK(napi_get_value_external(env, argv[0], (void **)&key));
+  uint64_t v[10];
+  if (Z.key_info(key, v)) return throw_msg(env, Z.last_error());
+  napi_value arr;
+  NAPI_OK(napi_create_array_with_length(env, 10, &arr));
+  for (uint32_t i = 0; i < 10; i++) {
+    napi_value x;
+    NAPI_OK(napi_create_double(env, (double)v[i], &x));
+    NAPI_OK(napi_set_element(env, arr, i, x));
+  }
+  return arr;
+}
+
+typedef struct {
+  napi_async_work work;
+  napi_deferred deferred;
+  napi_ref key_ref, wit_ref;
+  zkr_key *key;
+  const uint8_t *wit;
+  size_t wit_len;
+  int have_rs;
+  uint8_t r[32], s[32], proof[256];
+  int rc;
+  char err[512];
+} prove_job;
+
+static void prove_execute(napi_env env, void *data) {  /* libuv worker thread: the event loop is not blocked */
+  (void)env;
+  prove_job *j = (prove_job *)data;
+  j->rc = Z.prove(j->key, j->wit, j->wit_len, j->have_rs ? j->r : NULL, j->have_rs ? j->s : NULL, j->proof, NULL);
+  if (j->rc) { strncpy(j->err, Z.last_error(), sizeof(j->err) - 1); j->err[sizeof(j->err) - 1] = 0; }
+}
+
+static void prove_complete(napi_env env, napi_status status, void *data) {
+  prove_job *j = (prove_job *)data;
+  napi_value v;
+  if (status == napi_ok && j->rc == 0) {
+    void *out;
+    napi_create_buffer_copy(env, 256, j->proof, &out, &v);
+    napi_resolve_deferred(env, j->deferred, v);
+  } else {
+    napi_value msg;
+    napi_create_string_utf8(env, j->rc ? j->err : "proof job cancelled", NAPI_AUTO_LENGTH, &msg);
+    napi_create_error(env, NULL, msg, &v);
+    napi_reject_deferred(env, j->deferred, v);
+  }
+  napi_delete_reference(env, j->key_ref);
+  napi_delete_reference(env, j->wit_ref);
+  napi_delete_async_work(env, j->work);
+  free(j);
+}
+
+/* prove(key, witnessBin, r32|null, s32|null) -> Promise<Buffer(256)>; the witness buffer is pinned by a
+ * reference until the promise settles (the reference's caller may reuse it only afterwards). */
+static napi_value js_prove(napi_env env, napi_callback_info info) {
+  size_t argc = 4;
+  napi_value argv[4];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  if (!Z.handle) return throw_msg(env, "libzkr_hip.so not loaded");
+  prove_job *j = (prove_job *)calloc(1, sizeof(prove_job));
+  NAPI_OK(napi_get_value_external(env, argv[0], (void **)&j->key));
+  if (!get_bytes(env, argv[1], &j->wit, &j->wit_len)) { free(j); return throw_msg(env, "witnessBin must be an ArrayBuffer / Buffer / TypedArray"); }
+  const uint8_t *p; size_t n;
+  if (argc >= 4 && get_bytes(env, argv[2], &p, &n) && n == 32) {
+    memcpy(j->r, p, 32);
+    if (!get_bytes(env, argv[3], &p, &n) || n != 32) { free(j); return throw_msg(env, "r and s must both be 32-byte buffers"); }
+    memcpy(j->s, p, 32);
+    j->have_rs = 1;
+  }
+  napi_value promise, name;
+  NAPI_OK(napi_create_promise(env, &j->deferred, &promise));
+  NAPI_OK(napi_create_reference(env, argv[0], 1, &j->key_ref));
+  NAPI_OK(napi_create_reference(env, argv[1], 1, &j->wit_ref));
+  NAPI_OK(napi_create_string_utf8(env, "zkr_prove", NAPI_AUTO_LENGTH, &name));
+  NAPI_OK(napi_create_async_work(env, NULL, name, prove_execute, prove_complete, j, &j->work));
+  NAPI_OK(napi_queue_async_work(env, j->work));
+  return promise;
+}
+
+static napi_value init(napi_env env, napi_value exports) {
+  napi_property_descriptor props[] = {
+      {"load", NULL, js_load, NULL, NULL, NULL, napi_default, NULL},       {"version", NULL, js_version, NULL, NULL, NULL, napi_default, NULL},
+      {"keyLoad", NULL, js_key_load, NULL, NULL, NULL, napi_default, NULL}, {"keyInfo", NULL, js_key_info, NULL, NULL, NULL, napi_default, NULL},
+      {"prove", NULL, js_prove, NULL, NULL, NULL, napi_default, NULL},
+  };
+  napi_define_properties(env, exports, sizeof(props) / sizeof(props[0]), props);
+  return exports;
+}
+NAPI_MODULE(NODE_GYP_MODULE_NAME, init)

@@ -1,0 +1,98 @@
+"""The Node.js host (simple-zk-rollups_amd/index.js + napi/zkr_napi.node): codec parity on CPU, proving on GPU."""
+import json
+import os
+import shutil
+import subprocess
+
+import pytest
+
+import groth16 as g
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "simple-zk-rollups_amd")
+NODE = shutil.which("node")
+pytestmark = pytest.mark.skipif(NODE is None or not os.path.exists(os.path.join(PKG, "napi", "zkr_napi.node")),
+                                reason="node or the N-API addon is not available")
+
+
+def _stringify(x):
+    if isinstance(x, bool) or x is None:
+        return x
+    if isinstance(x, int):
+        return str(x)
+    if isinstance(x, dict):
+        return {str(k): _stringify(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_stringify(v) for v in x]
+    return x
+
+
+def _node(script, *args, check=True):
+    r = subprocess.run([NODE, "-e", script, *args], cwd=PKG, capture_output=True, text=True, timeout=300)
+    if check and r.returncode != 0:
+        raise AssertionError(r.stderr)
+    return r
+
+
+def _key_json(tmp_path, small_case):
+    c = small_case
+    jk = _stringify(g.to_json_key(c["pk"]))
+    # snarkjs numeric fields stay numbers (binarify.ts reads provingKey.nVars etc. as numbers)
+    for f in ("nVars", "nPublic", "domainSize", "domainBits"):
+        jk[f] = int(jk[f])
+    p = tmp_path / "pk.json"
+    p.write_text(json.dumps(dict(pk=jk, witness=[str(x) for x in c["w"]], r=str(c["r"]), s=str(c["s"]))))
+    return str(p)
+
+
+def test_js_binarify_matches_reference_layouts(tmp_path, small_case):
+    """index.js binarifyWitness / binarifyProvingKey == the byte layouts of binarify.ts (as restated by the oracle)."""
+    path = _key_json(tmp_path, small_case)
+    out = _node("""
+      const z = require('./index.js'); const fs = require('fs'); const crypto = require('crypto');
+      const d = JSON.parse(fs.readFileSync(process.argv[1]));
+      const sha = (ab) => crypto.createHash('sha256').update(Buffer.from(ab)).digest('hex');
+      console.log(JSON.stringify({pk: sha(z.binarifyProvingKey(d.pk)), w: sha(z.binarifyWitness(d.witness)), v: z.version(), n: z.deviceCount()}));
+    """, path).stdout
+    res = json.loads(out)
+    assert res["pk"] == g.sha256(small_case["pkb"]) and res["w"] == g.sha256(small_case["wb"])
+    assert res["v"].startswith("zkr-hip")
+
+
+def test_js_rejects_without_gpu(tmp_path, small_case):
+    import zkr_hip
+    if zkr_hip.device_count() > 0:
+        pytest.skip("a HIP device is present")
+    path = _key_json(tmp_path, small_case)
+    out = _node("""
+      const z = require('./index.js'); const fs = require('fs');
+      const d = JSON.parse(fs.readFileSync(process.argv[1]));
+      z.genProof(d.pk, d.witness).then(() => console.log('resolved')).catch(e => console.log('rejected: ' + e.message));
+    """, path).stdout
+    assert out.startswith("rejected:") and "no CPU fallback" in out
+
+
+@pytest.mark.gpu
+def test_js_groth16GenProof_on_gpu_matches_oracle(tmp_path, small_case):
+    c = small_case
+    path = _key_json(tmp_path, c)
+    out = _node("""
+      const z = require('./index.js'); const fs = require('fs');
+      const d = JSON.parse(fs.readFileSync(process.argv[1]));
+      (async () => {
+        const bn = await z.buildBn128();
+        const wb = z.binarifyWitness(d.witness), pb = z.binarifyProvingKey(d.pk);
+        const p1 = await bn.groth16GenProof(wb, pb, {r: d.r, s: d.s});
+        const p2 = await bn.groth16GenProof(wb, pb);                 // random blinding, cached key
+        const g = await z.genProof(d.pk, d.witness, {r: d.r, s: d.s});
+        console.log(JSON.stringify({p1, p2, g, sol: z.solidityProof(p1, g.publicSignals), info: bn.keyInfo()}));
+      })().catch(e => { console.error(e); process.exit(1); });
+    """, path).stdout
+    res = json.loads(out)
+    expect = g.proof_to_json(g.proof_from_toxic(c["circ"], c["tox"], c["w"], c["r"], c["s"]))
+    assert res["p1"] == expect
+    assert res["p2"] != expect and res["p2"]["pi_a"][2] == "1"
+    assert {k: v for k, v in res["g"]["proof"].items() if k != "protocol"} == expect and res["g"]["proof"]["protocol"] == "groth"
+    assert res["g"]["publicSignals"] == [str(x) for x in c["w"][1:8]]
+    assert res["sol"] == g.solidity_proof(expect, c["w"][1:8])
+    assert res["info"]["nVars"] == c["pk"]["nVars"]
