@@ -126,30 +126,192 @@ ZKR_HD Fp<PM> dbl(const Fp<PM> &a) {
   return add(a, a);
 }
 
-// Montgomery product a*b/2^256 mod p, CIOS with the two inner loops fused (valid because the top
-// bit of p is clear, so the running sum never needs a ninth limb).  136 multiply-adds.
+// 96-bit column accumulator (c2 : lo) += sum_k x_k * y_k.  On gfx950 every term is exactly two VALU
+// instructions: v_mad_u64_u32 adds the 64-bit product into the low pair and leaves the carry in VCC,
+// v_addc_co_u32 folds it into the third word -- no register shuffling between multiply-adds (the
+// compiler's own lowering of the 64-bit carry chain costs ~3 v_mov + one 64-bit add per multiply-add).
+// One asm statement per column half keeps hipcc's per-statement s_nop pad off the critical path.
+// Pure VALU, no memory operands, VCC declared clobbered (cdna_hip_programming.md 5.7).
+ZKR_HD void mac96_1(uint64_t &lo, uint32_t &c2, uint32_t x0, uint32_t y0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(c2) : "v"(x0), "v"(y0) : "vcc");
+#else
+  { uint64_t p = (uint64_t)x0 * y0; lo += p; c2 += lo < p; }
+#endif
+}
+template <uint32_t Y0>
+ZKR_HD void mac96c_1(uint64_t &lo, uint32_t &c2, uint32_t x0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(c2) : "v"(x0), "s"(Y0) : "vcc");
+#else
+  { uint64_t p = (uint64_t)x0 * Y0; lo += p; c2 += lo < p; }
+#endif
+}
+ZKR_HD void mac96_2(uint64_t &lo, uint32_t &c2, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(c2) : "v"(x0), "v"(y0), "v"(x1), "v"(y1) : "vcc");
+#else
+  { uint64_t p = (uint64_t)x0 * y0; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x1 * y1; lo += p; c2 += lo < p; }
+#endif
+}
+template <uint32_t Y0, uint32_t Y1>
+ZKR_HD void mac96c_2(uint64_t &lo, uint32_t &c2, uint32_t x0, uint32_t x1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(c2) : "v"(x0), "s"(Y0), "v"(x1), "s"(Y1) : "vcc");
+#else
+  { uint64_t p = (uint64_t)x0 * Y0; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x1 * Y1; lo += p; c2 += lo < p; }
+#endif
+}
+ZKR_HD void mac96_3(uint64_t &lo, uint32_t &c2, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, uint32_t x2, uint32_t y2) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %6, %7, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(c2) : "v"(x0), "v"(y0), "v"(x1), "v"(y1), "v"(x2), "v"(y2) : "vcc");
+#else
+  { uint64_t p = (uint64_t)x0 * y0; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x1 * y1; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x2 * y2; lo += p; c2 += lo < p; }
+#endif
+}
+template <uint32_t Y0, uint32_t Y1, uint32_t Y2>
+ZKR_HD void mac96c_3(uint64_t &lo, uint32_t &c2, uint32_t x0, uint32_t x1, uint32_t x2) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %6, %7, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(c2) : "v"(x0), "s"(Y0), "v"(x1), "s"(Y1), "v"(x2), "s"(Y2) : "vcc");
+#else
+  { uint64_t p = (uint64_t)x0 * Y0; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x1 * Y1; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x2 * Y2; lo += p; c2 += lo < p; }
+#endif
+}
+ZKR_HD void mac96_4(uint64_t &lo, uint32_t &c2, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, uint32_t x2, uint32_t y2, uint32_t x3, uint32_t y3) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %6, %7, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %8, %9, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(c2) : "v"(x0), "v"(y0), "v"(x1), "v"(y1), "v"(x2), "v"(y2), "v"(x3), "v"(y3) : "vcc");
+#else
+  { uint64_t p = (uint64_t)x0 * y0; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x1 * y1; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x2 * y2; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x3 * y3; lo += p; c2 += lo < p; }
+#endif
+}
+template <uint32_t Y0, uint32_t Y1, uint32_t Y2, uint32_t Y3>
+ZKR_HD void mac96c_4(uint64_t &lo, uint32_t &c2, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %6, %7, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %8, %9, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(c2) : "v"(x0), "s"(Y0), "v"(x1), "s"(Y1), "v"(x2), "s"(Y2), "v"(x3), "s"(Y3) : "vcc");
+#else
+  { uint64_t p = (uint64_t)x0 * Y0; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x1 * Y1; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x2 * Y2; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x3 * Y3; lo += p; c2 += lo < p; }
+#endif
+}
+ZKR_HD void mac96_5(uint64_t &lo, uint32_t &c2, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, uint32_t x2, uint32_t y2, uint32_t x3, uint32_t y3, uint32_t x4, uint32_t y4) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %6, %7, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %8, %9, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %10, %11, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(c2) : "v"(x0), "v"(y0), "v"(x1), "v"(y1), "v"(x2), "v"(y2), "v"(x3), "v"(y3), "v"(x4), "v"(y4) : "vcc");
+#else
+  { uint64_t p = (uint64_t)x0 * y0; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x1 * y1; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x2 * y2; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x3 * y3; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x4 * y4; lo += p; c2 += lo < p; }
+#endif
+}
+template <uint32_t Y0, uint32_t Y1, uint32_t Y2, uint32_t Y3, uint32_t Y4>
+ZKR_HD void mac96c_5(uint64_t &lo, uint32_t &c2, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t x4) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %6, %7, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %8, %9, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %10, %11, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(c2) : "v"(x0), "s"(Y0), "v"(x1), "s"(Y1), "v"(x2), "s"(Y2), "v"(x3), "s"(Y3), "v"(x4), "s"(Y4) : "vcc");
+#else
+  { uint64_t p = (uint64_t)x0 * Y0; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x1 * Y1; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x2 * Y2; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x3 * Y3; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x4 * Y4; lo += p; c2 += lo < p; }
+#endif
+}
+ZKR_HD void mac96_6(uint64_t &lo, uint32_t &c2, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, uint32_t x2, uint32_t y2, uint32_t x3, uint32_t y3, uint32_t x4, uint32_t y4, uint32_t x5, uint32_t y5) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %6, %7, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %8, %9, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %10, %11, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %12, %13, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(c2) : "v"(x0), "v"(y0), "v"(x1), "v"(y1), "v"(x2), "v"(y2), "v"(x3), "v"(y3), "v"(x4), "v"(y4), "v"(x5), "v"(y5) : "vcc");
+#else
+  { uint64_t p = (uint64_t)x0 * y0; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x1 * y1; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x2 * y2; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x3 * y3; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x4 * y4; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x5 * y5; lo += p; c2 += lo < p; }
+#endif
+}
+template <uint32_t Y0, uint32_t Y1, uint32_t Y2, uint32_t Y3, uint32_t Y4, uint32_t Y5>
+ZKR_HD void mac96c_6(uint64_t &lo, uint32_t &c2, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t x4, uint32_t x5) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %6, %7, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %8, %9, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %10, %11, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %12, %13, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(c2) : "v"(x0), "s"(Y0), "v"(x1), "s"(Y1), "v"(x2), "s"(Y2), "v"(x3), "s"(Y3), "v"(x4), "s"(Y4), "v"(x5), "s"(Y5) : "vcc");
+#else
+  { uint64_t p = (uint64_t)x0 * Y0; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x1 * Y1; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x2 * Y2; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x3 * Y3; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x4 * Y4; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x5 * Y5; lo += p; c2 += lo < p; }
+#endif
+}
+ZKR_HD void mac96_7(uint64_t &lo, uint32_t &c2, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, uint32_t x2, uint32_t y2, uint32_t x3, uint32_t y3, uint32_t x4, uint32_t y4, uint32_t x5, uint32_t y5, uint32_t x6, uint32_t y6) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %6, %7, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %8, %9, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %10, %11, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %12, %13, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %14, %15, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(c2) : "v"(x0), "v"(y0), "v"(x1), "v"(y1), "v"(x2), "v"(y2), "v"(x3), "v"(y3), "v"(x4), "v"(y4), "v"(x5), "v"(y5), "v"(x6), "v"(y6) : "vcc");
+#else
+  { uint64_t p = (uint64_t)x0 * y0; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x1 * y1; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x2 * y2; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x3 * y3; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x4 * y4; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x5 * y5; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x6 * y6; lo += p; c2 += lo < p; }
+#endif
+}
+template <uint32_t Y0, uint32_t Y1, uint32_t Y2, uint32_t Y3, uint32_t Y4, uint32_t Y5, uint32_t Y6>
+ZKR_HD void mac96c_7(uint64_t &lo, uint32_t &c2, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t x4, uint32_t x5, uint32_t x6) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %6, %7, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %8, %9, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %10, %11, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %12, %13, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %14, %15, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(c2) : "v"(x0), "s"(Y0), "v"(x1), "s"(Y1), "v"(x2), "s"(Y2), "v"(x3), "s"(Y3), "v"(x4), "s"(Y4), "v"(x5), "s"(Y5), "v"(x6), "s"(Y6) : "vcc");
+#else
+  { uint64_t p = (uint64_t)x0 * Y0; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x1 * Y1; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x2 * Y2; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x3 * Y3; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x4 * Y4; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x5 * Y5; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x6 * Y6; lo += p; c2 += lo < p; }
+#endif
+}
+ZKR_HD void mac96_8(uint64_t &lo, uint32_t &c2, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, uint32_t x2, uint32_t y2, uint32_t x3, uint32_t y3, uint32_t x4, uint32_t y4, uint32_t x5, uint32_t y5, uint32_t x6, uint32_t y6, uint32_t x7, uint32_t y7) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %6, %7, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %8, %9, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %10, %11, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %12, %13, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %14, %15, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %16, %17, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(c2) : "v"(x0), "v"(y0), "v"(x1), "v"(y1), "v"(x2), "v"(y2), "v"(x3), "v"(y3), "v"(x4), "v"(y4), "v"(x5), "v"(y5), "v"(x6), "v"(y6), "v"(x7), "v"(y7) : "vcc");
+#else
+  { uint64_t p = (uint64_t)x0 * y0; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x1 * y1; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x2 * y2; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x3 * y3; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x4 * y4; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x5 * y5; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x6 * y6; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x7 * y7; lo += p; c2 += lo < p; }
+#endif
+}
+template <uint32_t Y0, uint32_t Y1, uint32_t Y2, uint32_t Y3, uint32_t Y4, uint32_t Y5, uint32_t Y6, uint32_t Y7>
+ZKR_HD void mac96c_8(uint64_t &lo, uint32_t &c2, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t x4, uint32_t x5, uint32_t x6, uint32_t x7) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %6, %7, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %8, %9, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %10, %11, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %12, %13, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %14, %15, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %16, %17, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(c2) : "v"(x0), "s"(Y0), "v"(x1), "s"(Y1), "v"(x2), "s"(Y2), "v"(x3), "s"(Y3), "v"(x4), "s"(Y4), "v"(x5), "s"(Y5), "v"(x6), "s"(Y6), "v"(x7), "s"(Y7) : "vcc");
+#else
+  { uint64_t p = (uint64_t)x0 * Y0; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x1 * Y1; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x2 * Y2; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x3 * Y3; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x4 * Y4; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x5 * Y5; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x6 * Y6; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x7 * Y7; lo += p; c2 += lo < p; }
+#endif
+}
+
+// Montgomery product a*b/2^256 mod p by product scanning (FIPS): columns k = 0..14 of a*b + m*p are
+// summed in a 96-bit accumulator; m[k] = column_k * (-p^-1) mod 2^32 zeroes the low word of each of the
+// first eight columns.  136 multiply-adds, 2 VALU instructions each.
 template <class PM>
 ZKR_HD Fp<PM> mul(const Fp<PM> &a, const Fp<PM> &b) {
-  uint32_t t[8];
-#pragma unroll
-  for (int i = 0; i < 8; i++) t[i] = 0;
-#pragma unroll
-  for (int i = 0; i < 8; i++) {
-    uint64_t A = (uint64_t)a.v[0] * b.v[i] + t[0];
-    uint32_t m = (uint32_t)A * PM::INV;
-    uint64_t C = (uint64_t)m * PM::P[0] + (uint32_t)A;
-    A >>= 32;
-    C >>= 32;
-#pragma unroll
-    for (int j = 1; j < 8; j++) {
-      A += (uint64_t)a.v[j] * b.v[i] + t[j];
-      C += (uint64_t)m * PM::P[j] + (uint32_t)A;
-      t[j - 1] = (uint32_t)C;
-      A >>= 32;
-      C >>= 32;
-    }
-    t[7] = (uint32_t)(A + C);
-  }
+  const uint32_t *x = a.v, *y = b.v;
+  constexpr const uint32_t *P = PM::P;
+  uint32_t m[8], t[8];
+  uint64_t lo = 0;
+  uint32_t c2 = 0;
+#define ZKR_NEXT_COL lo = (lo >> 32) | ((uint64_t)c2 << 32); c2 = 0;
+#define ZKR_FIN_LOW(K) m[K] = (uint32_t)lo * PM::INV; mac96c_1<P[0]>(lo, c2, m[K]); ZKR_NEXT_COL
+  mac96_1(lo, c2, x[0], y[0]);
+  ZKR_FIN_LOW(0)
+  mac96_2(lo, c2, x[0], y[1], x[1], y[0]);
+  mac96c_1<P[1]>(lo, c2, m[0]);
+  ZKR_FIN_LOW(1)
+  mac96_3(lo, c2, x[0], y[2], x[1], y[1], x[2], y[0]);
+  mac96c_2<P[2], P[1]>(lo, c2, m[0], m[1]);
+  ZKR_FIN_LOW(2)
+  mac96_4(lo, c2, x[0], y[3], x[1], y[2], x[2], y[1], x[3], y[0]);
+  mac96c_3<P[3], P[2], P[1]>(lo, c2, m[0], m[1], m[2]);
+  ZKR_FIN_LOW(3)
+  mac96_5(lo, c2, x[0], y[4], x[1], y[3], x[2], y[2], x[3], y[1], x[4], y[0]);
+  mac96c_4<P[4], P[3], P[2], P[1]>(lo, c2, m[0], m[1], m[2], m[3]);
+  ZKR_FIN_LOW(4)
+  mac96_6(lo, c2, x[0], y[5], x[1], y[4], x[2], y[3], x[3], y[2], x[4], y[1], x[5], y[0]);
+  mac96c_5<P[5], P[4], P[3], P[2], P[1]>(lo, c2, m[0], m[1], m[2], m[3], m[4]);
+  ZKR_FIN_LOW(5)
+  mac96_7(lo, c2, x[0], y[6], x[1], y[5], x[2], y[4], x[3], y[3], x[4], y[2], x[5], y[1], x[6], y[0]);
+  mac96c_6<P[6], P[5], P[4], P[3], P[2], P[1]>(lo, c2, m[0], m[1], m[2], m[3], m[4], m[5]);
+  ZKR_FIN_LOW(6)
+  mac96_8(lo, c2, x[0], y[7], x[1], y[6], x[2], y[5], x[3], y[4], x[4], y[3], x[5], y[2], x[6], y[1], x[7], y[0]);
+  mac96c_7<P[7], P[6], P[5], P[4], P[3], P[2], P[1]>(lo, c2, m[0], m[1], m[2], m[3], m[4], m[5], m[6]);
+  ZKR_FIN_LOW(7)
+  mac96_7(lo, c2, x[1], y[7], x[2], y[6], x[3], y[5], x[4], y[4], x[5], y[3], x[6], y[2], x[7], y[1]);
+  mac96c_7<P[7], P[6], P[5], P[4], P[3], P[2], P[1]>(lo, c2, m[1], m[2], m[3], m[4], m[5], m[6], m[7]);
+  t[0] = (uint32_t)lo; ZKR_NEXT_COL
+  mac96_6(lo, c2, x[2], y[7], x[3], y[6], x[4], y[5], x[5], y[4], x[6], y[3], x[7], y[2]);
+  mac96c_6<P[7], P[6], P[5], P[4], P[3], P[2]>(lo, c2, m[2], m[3], m[4], m[5], m[6], m[7]);
+  t[1] = (uint32_t)lo; ZKR_NEXT_COL
+  mac96_5(lo, c2, x[3], y[7], x[4], y[6], x[5], y[5], x[6], y[4], x[7], y[3]);
+  mac96c_5<P[7], P[6], P[5], P[4], P[3]>(lo, c2, m[3], m[4], m[5], m[6], m[7]);
+  t[2] = (uint32_t)lo; ZKR_NEXT_COL
+  mac96_4(lo, c2, x[4], y[7], x[5], y[6], x[6], y[5], x[7], y[4]);
+  mac96c_4<P[7], P[6], P[5], P[4]>(lo, c2, m[4], m[5], m[6], m[7]);
+  t[3] = (uint32_t)lo; ZKR_NEXT_COL
+  mac96_3(lo, c2, x[5], y[7], x[6], y[6], x[7], y[5]);
+  mac96c_3<P[7], P[6], P[5]>(lo, c2, m[5], m[6], m[7]);
+  t[4] = (uint32_t)lo; ZKR_NEXT_COL
+  mac96_2(lo, c2, x[6], y[7], x[7], y[6]);
+  mac96c_2<P[7], P[6]>(lo, c2, m[6], m[7]);
+  t[5] = (uint32_t)lo; ZKR_NEXT_COL
+  mac96_1(lo, c2, x[7], y[7]);
+  mac96c_1<P[7]>(lo, c2, m[7]);
+  t[6] = (uint32_t)lo; ZKR_NEXT_COL
+  t[7] = (uint32_t)lo;  // column 15 is empty and (a*b + m*p)/2^256 < 2p < 2^255
+#undef ZKR_NEXT_COL
+#undef ZKR_FIN_LOW
   Fp<PM> r;
 #pragma unroll
   for (int i = 0; i < 8; i++) r.v[i] = t[i];
