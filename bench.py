@@ -132,7 +132,8 @@ def main():
                     "note": "Pippenger bucket accumulation is integer-VALU bound (v_mad_u64_u32), not HBM bound; see valu"}
         try:
             peak_gmul = zkr_hip.bench_fq_mul(local)
-            windows = (255 + 15) // 16 if max(info["ptsA"], 1) >= (1 << 20) else None
+            c_bits = min(16, max(4, (max(info["ptsA"], 2) - 1).bit_length() - 4))  # msm_plan() in csrc/zkr_key.hip
+            windows = (255 + c_bits - 1) // c_bits
             roofline["valu"] = {"peak_fq_mul_per_s_G": peak_gmul, "unit": "G Fq-mul/s (136 mad32 each)"}
             if windows:
                 gm = fqmul_per_point_window * windows / (avg_ms * 1e-3) / 1e9

@@ -202,13 +202,33 @@ static __global__ __launch_bounds__(MSM_THREADS) void msm_scatter_kernel(const F
   }
 }
 
-// bucket accumulation: thread per bucket
+// bucket accumulation: thread per bucket.  Bucket sizes are ~Poisson(n / 2^(c-1)), so a wavefront would run
+// at the pace of its fullest bucket; the workgroup therefore ranks its 256 buckets by size in LDS first
+// and lane i takes the i-th largest, which makes the 64 lanes of a wavefront near-equal in trip count.
 template <class F, int MINW>
 static __global__ __launch_bounds__(MSM_THREADS, MINW) void msm_accum_kernel(const Affine<F> *points, const uint32_t *offsets, const uint32_t *entries,
                                                                      uint32_t nb, const uint32_t *counts, XYZZ<F> *buckets) {
-  uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ uint32_t s_cnt[MSM_THREADS];
+  __shared__ uint32_t s_order[MSM_THREADS];
+  const uint32_t b0 = blockIdx.x * MSM_THREADS, tid = threadIdx.x;
+  uint32_t my = 0;  // size of bucket b0 + tid; empty / out-of-range / msm_big_kernel-owned buckets sort last
+  if (b0 + tid < nb) {
+    uint32_t c = counts[b0 + tid];
+    my = c == BIG_MARK ? 0 : c;
+  }
+  s_cnt[tid] = my;
+  __syncthreads();
+  uint32_t rank = 0;
+  for (uint32_t j = 0; j < MSM_THREADS; j++) {
+    uint32_t o = s_cnt[j];
+    rank += (o > my) || (o == my && j < tid);
+  }
+  s_order[rank] = tid;
+  __syncthreads();
+  const uint32_t b = b0 + s_order[tid];
   if (b >= nb) return;
-  if (counts[b] == BIG_MARK) return;  // msm_big_kernel owns it
+  const bool big = counts[b] == BIG_MARK;
+  if (big) return;  // msm_big_kernel owns it
   uint32_t o0 = offsets[b], o1 = offsets[b + 1];
   XYZZ<F> acc = XYZZ<F>::inf();
   for (uint32_t j = o0; j < o1; j++) {

@@ -7,6 +7,7 @@
 // round trip; the host then does ~20 group operations per MSM (Horner over windows) and the
 // blinding arithmetic of App. B step 4 (six 254-bit scalar multiplications).
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include "kernels_msm.cuh"
@@ -263,15 +264,18 @@ static int prove_on_device(zkr_key *k, const Fr *d_wsrc, const uint8_t *r32, con
   ZKR_HIP_CHECK(hipStreamWaitEvent(k->msm_stream[T_H], k->ev_h, 0));
   const Fr *scal[N_TABLES] = {k->d_w, k->d_w, k->d_w, k->d_w, k->d_h};
   static const int order[N_TABLES] = {T_B2, T_A, T_B1, T_C, T_H};  // longest first
+  static const bool serial = getenv("ZKR_SERIAL") != nullptr;       // profiling aid: one stream, isolated kernel durations
   for (int oi = 0; oi < N_TABLES; oi++) {
     int t = order[oi];
-    hipStream_t ms = k->msm_stream[t];
+    hipStream_t ms = serial ? s : k->msm_stream[t];
     const uint32_t *sidx = (const uint32_t *)(ar + h.off_sidx[t]);
     if (t == T_B2) rc = msm_enqueue<Fq2>(k, ms, (const G2Affine *)(ar + h.off_pts[t]), sidx, scal[t], h.npts[t], k->plan[t], k->ws[t]);
     else rc = msm_enqueue<Fq>(k, ms, (const G1Affine *)(ar + h.off_pts[t]), sidx, scal[t], h.npts[t], k->plan[t], k->ws[t]);
     if (rc) return rc;
-    ZKR_HIP_CHECK(hipEventRecord(k->ev_done[t], ms));
-    ZKR_HIP_CHECK(hipStreamWaitEvent(s, k->ev_done[t], 0));
+    if (!serial) {
+      ZKR_HIP_CHECK(hipEventRecord(k->ev_done[t], ms));
+      ZKR_HIP_CHECK(hipStreamWaitEvent(s, k->ev_done[t], 0));
+    }
   }
   prof_end(k, s, tot);
   ZKR_HIP_CHECK(hipStreamSynchronize(s));
