@@ -1,0 +1,37 @@
+"""Per-kernel HBM traffic from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; rocpd SQLite output).
+python profiles/summarize_pmc.py <fetch.db> <write.db>
+Units/corrections as MI355X_MICROARCH.md "HBM" prescribes: FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950
+FETCH_SIZE reads exactly half of a wide (16 B/lane) coalesced stream, so reads are doubled; WRITE_SIZE is
+uncalibrated.  The ingest_kernel rows (known traffic: n*32 B read + n*32 B written, coalesced 16 B/lane)
+are printed as the calibration check for this access width."""
+import re
+import sqlite3
+import sys
+
+
+def load(path):
+    db = sqlite3.connect(path)
+    q = ("select s.kernel_name, p.value from rocpd_pmc_event p join rocpd_kernel_dispatch d on p.event_id = d.event_id "
+         "join rocpd_info_kernel_symbol s on d.kernel_id = s.id")
+    agg = {}
+    for name, val in db.execute(q):
+        m = re.search(r"L\d+([a-z_0-9]+kernel)", name)
+        k = m.group(1) if m else name[:40]
+        if "Fq2" in name:
+            k += "<Fq2>"
+        elif "FqParams" in name and ("msm_" in name or "fixed_base" in name or "gather" in name):
+            k += "<Fq>"
+        a = agg.setdefault(k, [0, 0.0])
+        a[0] += 1
+        a[1] += val
+    return agg
+
+
+fetch, write = load(sys.argv[1]), load(sys.argv[2])
+print("| kernel | launches | FETCH_SIZE KiB/launch | read MB/launch (x2 gfx950) | WRITE_SIZE KiB/launch | write MB/launch | HBM MB/launch |")
+print("|---|---|---|---|---|---|---|")
+for k in sorted(fetch, key=lambda k: -(2 * fetch[k][1] + write.get(k, [0, 0])[1])):
+    n, f = fetch[k]
+    w = write.get(k, [n, 0.0])[1]
+    fr, wr = f / n, w / max(write.get(k, [n])[0], 1)
+    print("| `%s` | %d | %.0f | %.2f | %.0f | %.2f | %.2f |" % (k, n, fr, 2 * fr * 1024 / 1e6, wr, wr * 1024 / 1e6, (2 * fr + wr) * 1024 / 1e6))

@@ -33,7 +33,7 @@ ZKR_HD XYZZ<F> to_xyzz(const Affine<F> &p) {
 
 // 2*(affine p) -> XYZZ   (dbl-2008-s-1 specialised to Z = 1)
 template <class F>
-ZKR_HD_COLD XYZZ<F> dbl_affine(const Affine<F> &p) {
+ZKR_HD XYZZ<F> dbl_affine(const Affine<F> &p) {
   F u = dbl(p.y);
   F v = sqr(u);
   F w = mul(u, v);
