@@ -108,6 +108,16 @@ def main():
     prof = key.prof()
     key.prof_enable(False)
 
+    # host-buffer boundary (zkr_prove: pageable witness over PCIe inside the call) -- reported, never `value`
+    pcie_rate = None
+    if rank == 0 and world == 1:
+        hw = bytes(wits[0].cpu().numpy().tobytes())
+        key.prove(hw, 5, 7)
+        t1 = time.perf_counter()
+        for i in range(3):
+            key.prove(hw, 11 + i, 13 + i)
+        pcie_rate = 3.0 / (time.perf_counter() - t1)
+
     if rank == 0:
         total_proofs = args.steps * world
         value = total_proofs / elapsed
@@ -126,8 +136,17 @@ def main():
         ms_total, launches = prof[st]
         avg_ms = ms_total / max(launches, 1)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+        traffic, traffic_src = None, None
+        try:  # HBM bytes per launch from the committed PMC passes (bench.py cannot collect PMCs itself)
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
+            if pmc["config"]["log_m"] == args.log_m:
+                traffic = pmc["kernels"][dom.replace("<Fq>", "<Fq>")]["hbm_bytes_per_launch"]
+                traffic_src = "profiles/r1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 read correction)"
+        except Exception:
+            pass
         roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "avg_launch_ms": avg_ms, "launches": launches,
+                    "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+                    "avg_launch_ms": avg_ms, "launches": launches,
                     "algorithmic_bytes_per_launch": bytes_per_launch,
                     "note": "Pippenger bucket accumulation is integer-VALU bound (v_mad_u64_u32), not HBM bound; see valu"}
         try:
@@ -151,6 +170,7 @@ def main():
             "roofline": roofline,
             "stage_ms_per_proof": per_proof_ms,
             "key": {"arena_bytes": arena_bytes, "setup_s": setup_s, "bcast_s": bcast_s if world > 1 else None},
+            "pcie_inclusive_proofs_per_s": pcie_rate,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample_log_m, args.log_m)
