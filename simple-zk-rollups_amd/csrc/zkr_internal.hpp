@@ -35,7 +35,8 @@ struct ArenaHeader {
   uint64_t off_pts[N_TABLES], off_sidx[N_TABLES];
   uint8_t alfa1[64], beta1[64], delta1[64];  // Montgomery affine, as in the websnark key header
   uint8_t beta2[128], delta2[128];
-  uint8_t pad[64];
+  uint32_t share_b;    // B1 and B2 keep the same signals (always true for honest keys): one digit sort serves both
+  uint8_t pad[60];
 };
 static_assert(sizeof(ArenaHeader) <= 1024, "header fits its slot");
 constexpr size_t ARENA_HEADER_BYTES = 1024;
@@ -75,7 +76,9 @@ struct zkr_key {
   zkr::ArenaHeader h;
   hipStream_t stream = nullptr;
   hipStream_t msm_stream[zkr::N_TABLES] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // the five MSMs run concurrently
+  hipStream_t sort_stream = nullptr;  // all digit sorts, back to back (fabric-atomic bound: they only contend with each other)
   hipEvent_t ev_w = nullptr, ev_h = nullptr, ev_done[zkr::N_TABLES] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_sorted[zkr::N_TABLES] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   // workspace
   zkr::Fr *d_wraw = nullptr, *d_w = nullptr, *va = nullptr, *vb = nullptr, *ca = nullptr, *cb = nullptr, *d_h = nullptr;
   zkr::MsmWorkspace ws[zkr::N_TABLES];  // one per table so the five MSMs can be enqueued back to back

@@ -94,7 +94,9 @@ int key_alloc_workspace(zkr_key *k) {
   for (int t = 0; t < N_TABLES; t++) {
     ZKR_HIP_CHECK(hipStreamCreateWithFlags(&k->msm_stream[t], hipStreamNonBlocking));
     ZKR_HIP_CHECK(hipEventCreateWithFlags(&k->ev_done[t], hipEventDisableTiming));
+    ZKR_HIP_CHECK(hipEventCreateWithFlags(&k->ev_sorted[t], hipEventDisableTiming));
   }
+  ZKR_HIP_CHECK(hipStreamCreateWithFlags(&k->sort_stream, hipStreamNonBlocking));
   ZKR_HIP_CHECK(hipEventCreateWithFlags(&k->ev_w, hipEventDisableTiming));
   ZKR_HIP_CHECK(hipEventCreateWithFlags(&k->ev_h, hipEventDisableTiming));
   ZKR_HIP_CHECK(hipMalloc(&k->d_wraw, (size_t)h.n * 32));
@@ -143,6 +145,7 @@ int key_build(int device, uint32_t n, uint32_t p, uint32_t m, const std::vector<
     h.off_sidx[t] = take((size_t)h.npts[t] * 4 + 4);
   }
   h.total_len = off;
+  h.share_b = tbl_sidx[T_B1] == tbl_sidx[T_B2] ? 1 : 0;
 
   unsigned char *arena = nullptr;
   ZKR_HIP_CHECK(hipMalloc(&arena, off));
@@ -343,7 +346,9 @@ void zkr_key_free(zkr_key *k) {
   for (int t = 0; t < N_TABLES; t++) {
     if (k->msm_stream[t]) { hipStreamSynchronize(k->msm_stream[t]); hipStreamDestroy(k->msm_stream[t]); }
     if (k->ev_done[t]) hipEventDestroy(k->ev_done[t]);
+    if (k->ev_sorted[t]) hipEventDestroy(k->ev_sorted[t]);
   }
+  if (k->sort_stream) { hipStreamSynchronize(k->sort_stream); hipStreamDestroy(k->sort_stream); }
   if (k->ev_w) hipEventDestroy(k->ev_w);
   if (k->ev_h) hipEventDestroy(k->ev_h);
   for (int t = 0; t < N_TABLES; t++) msm_ws_free(k->ws[t]);

@@ -161,9 +161,8 @@ template <class F> struct MsmCfg;
 template <> struct MsmCfg<Fq> { static constexpr int ACC_W = 4, RED_W = 2; static constexpr const char *ACC_STAGE = "msm_accum_g1"; };
 template <> struct MsmCfg<Fq2> { static constexpr int ACC_W = 2, RED_W = 1; static constexpr const char *ACC_STAGE = "msm_accum_g2"; };
 
-template <class F>
-static int msm_enqueue(zkr_key *prof, hipStream_t s, const Affine<F> *pts, const uint32_t *sidx, const Fr *scalars, uint32_t n,
-                       const MsmPlan &pl, MsmWorkspace &ws) {
+// digit sort of one scalar set: histogram -> scan -> counting-sort scatter (fabric-atomic bound)
+static int msm_sort_enqueue(zkr_key *prof, hipStream_t s, const uint32_t *sidx, const Fr *scalars, uint32_t n, const MsmPlan &pl, MsmWorkspace &ws) {
   if (n == 0) return 0;
   MsmGeom g;
   g.n = n; g.c = pl.c; g.K = pl.K; g.nbw = pl.nbw; g.big_thresh = pl.big_thresh; g.glog = pl.glog;
@@ -179,14 +178,25 @@ static int msm_enqueue(zkr_key *prof, hipStream_t s, const Affine<F> *pts, const
                                                             ws.big_list, ws.big_count, BIG_CAP);
   msm_scatter_kernel<<<grid_n, MSM_THREADS, 0, s>>>(scalars, sidx, g, ws.cursor, ws.entries);
   prof_end(prof, s, sp);
-  sp = prof_begin(prof, s, MsmCfg<F>::ACC_STAGE);
-  msm_accum_kernel<F, MsmCfg<F>::ACC_W><<<(pl.nb + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, s>>>(pts, ws.offsets, ws.entries, pl.nb, ws.counts,
+  ZKR_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// bucket accumulation + reduction of one point table over a finished sort (`srt` may belong to another
+// table with the same point set: B1 and B2 share one); results land in ws.h_window
+template <class F>
+static int msm_accum_enqueue(zkr_key *prof, hipStream_t s, const Affine<F> *pts, uint32_t n, const MsmPlan &pl, const MsmWorkspace &srt, MsmWorkspace &ws) {
+  if (n == 0) return 0;
+  MsmGeom g;
+  g.n = n; g.c = pl.c; g.K = pl.K; g.nbw = pl.nbw; g.big_thresh = pl.big_thresh; g.glog = pl.glog;
+  int sp = prof_begin(prof, s, MsmCfg<F>::ACC_STAGE);
+  msm_accum_kernel<F, MsmCfg<F>::ACC_W><<<(pl.nb + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, s>>>(pts, srt.offsets, srt.entries, pl.nb, srt.counts,
                                                                                                       (XYZZ<F> *)ws.buckets);
   prof_end(prof, s, sp);
   sp = prof_begin(prof, s, "msm_big");
-  msm_big_kernel<F, MsmCfg<F>::RED_W><<<BIG_SLOTS * BIG_SPLIT, MSM_THREADS, MSM_THREADS * sizeof(XYZZ<F>), s>>>(pts, ws.offsets, ws.entries, ws.big_list, ws.big_count,
+  msm_big_kernel<F, MsmCfg<F>::RED_W><<<BIG_SLOTS * BIG_SPLIT, MSM_THREADS, MSM_THREADS * sizeof(XYZZ<F>), s>>>(pts, srt.offsets, srt.entries, srt.big_list, srt.big_count,
                                                                                                              BIG_CAP, (XYZZ<F> *)ws.big_partials);
-  msm_big_finish_kernel<F, MsmCfg<F>::RED_W><<<BIG_CAP / 64, 64, 0, s>>>((const XYZZ<F> *)ws.big_partials, ws.big_list, ws.big_count, BIG_CAP, (XYZZ<F> *)ws.buckets);
+  msm_big_finish_kernel<F, MsmCfg<F>::RED_W><<<BIG_CAP / 64, 64, 0, s>>>((const XYZZ<F> *)ws.big_partials, srt.big_list, srt.big_count, BIG_CAP, (XYZZ<F> *)ws.buckets);
   prof_end(prof, s, sp);
   sp = prof_begin(prof, s, "msm_reduce");
   uint32_t gpw = pl.nbw >> pl.glog;
@@ -197,6 +207,14 @@ static int msm_enqueue(zkr_key *prof, hipStream_t s, const Affine<F> *pts, const
   ZKR_HIP_CHECK(hipMemcpyAsync(ws.h_window, ws.window_out, (size_t)pl.K * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, s));
   ZKR_HIP_CHECK(hipGetLastError());
   return 0;
+}
+
+template <class F>
+static int msm_enqueue(zkr_key *prof, hipStream_t s, const Affine<F> *pts, const uint32_t *sidx, const Fr *scalars, uint32_t n,
+                       const MsmPlan &pl, MsmWorkspace &ws) {
+  int rc = msm_sort_enqueue(prof, s, sidx, scalars, n, pl, ws);
+  if (rc) return rc;
+  return msm_accum_enqueue<F>(prof, s, pts, n, pl, ws, ws);
 }
 
 // Horner over the K window sums (host): sum_k 2^(ck) W_k
@@ -252,31 +270,57 @@ static int prove_on_device(zkr_key *k, const Fr *d_wsrc, const uint8_t *r32, con
   int sp = prof_begin(k, s, "ingest");
   ingest_kernel<<<(h.n + 255) / 256, 256, 0, s>>>(d_wsrc, k->d_w, h.n);
   prof_end(k, s, sp);
-  // witness MSMs (A, B1, B2, C) depend only on the ingested witness and run beside calcH; the H MSM waits for h.
-  // Each MSM has its own stream so latency-bound stages (scan, oversized buckets, bucket reduction) of one
-  // overlap the throughput-bound bucket accumulation of another.
+  // Schedule.  The witness MSMs (A, B1, B2, C) depend only on the ingested witness and run beside calcH; the H
+  // MSM waits for h.  All digit sorts go back to back on ONE stream (they are fabric-atomic bound and only
+  // contend with each other); each table's accumulation/reduction runs on its own stream behind its sort, so
+  // the VALU-bound accumulation of table i overlaps the sort of table i+1 and the latency-bound reduction of
+  // table i-1.  B1 and B2 keep the same signals, so one sort serves both (h.share_b).
+  static const bool serial = getenv("ZKR_SERIAL") != nullptr;  // profiling aid: one stream, isolated kernel durations
+  hipStream_t ss = serial ? s : k->sort_stream;
   ZKR_HIP_CHECK(hipEventRecord(k->ev_w, s));
-  for (int t = 0; t < N_TABLES; t++)
-    if (t != T_H) ZKR_HIP_CHECK(hipStreamWaitEvent(k->msm_stream[t], k->ev_w, 0));
-  int rc;
-  if ((rc = calc_h_device(k, s))) return rc;
-  ZKR_HIP_CHECK(hipEventRecord(k->ev_h, s));
-  ZKR_HIP_CHECK(hipStreamWaitEvent(k->msm_stream[T_H], k->ev_h, 0));
+  if (!serial) ZKR_HIP_CHECK(hipStreamWaitEvent(ss, k->ev_w, 0));
   const Fr *scal[N_TABLES] = {k->d_w, k->d_w, k->d_w, k->d_w, k->d_h};
-  static const int order[N_TABLES] = {T_B2, T_A, T_B1, T_C, T_H};  // longest first
-  static const bool serial = getenv("ZKR_SERIAL") != nullptr;       // profiling aid: one stream, isolated kernel durations
-  for (int oi = 0; oi < N_TABLES; oi++) {
-    int t = order[oi];
+  const bool share_b = h.share_b != 0 && h.npts[T_B1] == h.npts[T_B2];
+  int sort_src[N_TABLES] = {T_A, T_B1, share_b ? T_B1 : T_B2, T_C, T_H};
+  auto sort_table = [&](int t) -> int {
+    int rc = msm_sort_enqueue(k, ss, (const uint32_t *)(ar + h.off_sidx[t]), scal[t], h.npts[t], k->plan[t], k->ws[t]);
+    if (rc) return rc;
+    if (!serial) ZKR_HIP_CHECK(hipEventRecord(k->ev_sorted[t], ss));
+    return 0;
+  };
+  auto accum_table = [&](int t) -> int {
     hipStream_t ms = serial ? s : k->msm_stream[t];
-    const uint32_t *sidx = (const uint32_t *)(ar + h.off_sidx[t]);
-    if (t == T_B2) rc = msm_enqueue<Fq2>(k, ms, (const G2Affine *)(ar + h.off_pts[t]), sidx, scal[t], h.npts[t], k->plan[t], k->ws[t]);
-    else rc = msm_enqueue<Fq>(k, ms, (const G1Affine *)(ar + h.off_pts[t]), sidx, scal[t], h.npts[t], k->plan[t], k->ws[t]);
+    if (!serial) ZKR_HIP_CHECK(hipStreamWaitEvent(ms, k->ev_sorted[sort_src[t]], 0));
+    int rc;
+    if (t == T_B2) rc = msm_accum_enqueue<Fq2>(k, ms, (const G2Affine *)(ar + h.off_pts[t]), h.npts[t], k->plan[t], k->ws[sort_src[t]], k->ws[t]);
+    else rc = msm_accum_enqueue<Fq>(k, ms, (const G1Affine *)(ar + h.off_pts[t]), h.npts[t], k->plan[t], k->ws[sort_src[t]], k->ws[t]);
     if (rc) return rc;
     if (!serial) {
       ZKR_HIP_CHECK(hipEventRecord(k->ev_done[t], ms));
       ZKR_HIP_CHECK(hipStreamWaitEvent(s, k->ev_done[t], 0));
     }
+    return 0;
+  };
+  int rc;
+  if (serial) {
+    if ((rc = calc_h_device(k, s))) return rc;
   }
+  // sorts in the order their accumulations should start: B (G2 is the longest), A, C, then H once h exists
+  if ((rc = sort_table(T_B1))) return rc;
+  if (!share_b && (rc = sort_table(T_B2))) return rc;
+  if ((rc = accum_table(T_B2))) return rc;
+  if ((rc = sort_table(T_A))) return rc;
+  if ((rc = accum_table(T_B1))) return rc;
+  if ((rc = accum_table(T_A))) return rc;
+  if ((rc = sort_table(T_C))) return rc;
+  if ((rc = accum_table(T_C))) return rc;
+  if (!serial) {
+    if ((rc = calc_h_device(k, s))) return rc;  // enqueued on the main stream: runs concurrently with everything above
+    ZKR_HIP_CHECK(hipEventRecord(k->ev_h, s));
+    ZKR_HIP_CHECK(hipStreamWaitEvent(ss, k->ev_h, 0));
+  }
+  if ((rc = sort_table(T_H))) return rc;
+  if ((rc = accum_table(T_H))) return rc;
   prof_end(k, s, tot);
   ZKR_HIP_CHECK(hipStreamSynchronize(s));
   prof_collect(k);
