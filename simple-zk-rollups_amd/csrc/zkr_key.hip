@@ -92,7 +92,7 @@ int key_alloc_workspace(zkr_key *k) {
   const ArenaHeader &h = k->h;
   ZKR_HIP_CHECK(hipStreamCreateWithFlags(&k->stream, hipStreamNonBlocking));
   for (int t = 0; t < N_TABLES; t++) {
-    ZKR_HIP_CHECK(hipStreamCreateWithFlags(&k->msm_stream[t], hipStreamNonBlocking));
+    if (t < 2) ZKR_HIP_CHECK(hipStreamCreateWithFlags(&k->msm_stream[t], hipStreamNonBlocking));  // X, Y (4 streams in all: HW queue limit)
     ZKR_HIP_CHECK(hipEventCreateWithFlags(&k->ev_done[t], hipEventDisableTiming));
     ZKR_HIP_CHECK(hipEventCreateWithFlags(&k->ev_sorted[t], hipEventDisableTiming));
   }

@@ -270,15 +270,19 @@ static int prove_on_device(zkr_key *k, const Fr *d_wsrc, const uint8_t *r32, con
   int sp = prof_begin(k, s, "ingest");
   ingest_kernel<<<(h.n + 255) / 256, 256, 0, s>>>(d_wsrc, k->d_w, h.n);
   prof_end(k, s, sp);
-  // Schedule.  The witness MSMs (A, B1, B2, C) depend only on the ingested witness and run beside calcH; the H
-  // MSM waits for h.  All digit sorts go back to back on ONE stream (they are fabric-atomic bound and only
-  // contend with each other); each table's accumulation/reduction runs on its own stream behind its sort, so
-  // the VALU-bound accumulation of table i overlaps the sort of table i+1 and the latency-bound reduction of
-  // table i-1.  B1 and B2 keep the same signals, so one sort serves both (h.share_b).
+  // Schedule on FOUR streams (HIP multiplexes streams onto 4 hardware queues by default; more streams than
+  // queues silently serialise): main = calcH, `ss` = all digit sorts back to back (fabric-atomic bound, they
+  // only contend with each other), X and Y = bucket accumulation + reduction.  The VALU-bound accumulation of
+  // one table overlaps the sort of the next and the latency-bound reduction running on the other stream.
+  // B1 and B2 keep the same signals, so one sort serves both (h.share_b).
   static const bool serial = getenv("ZKR_SERIAL") != nullptr;  // profiling aid: one stream, isolated kernel durations
   hipStream_t ss = serial ? s : k->sort_stream;
+  hipStream_t sx = serial ? s : k->msm_stream[0], sy = serial ? s : k->msm_stream[1];
   ZKR_HIP_CHECK(hipEventRecord(k->ev_w, s));
   if (!serial) ZKR_HIP_CHECK(hipStreamWaitEvent(ss, k->ev_w, 0));
+  int rc;
+  if ((rc = calc_h_device(k, s))) return rc;  // first in its queue: runs beside the witness sorts
+  ZKR_HIP_CHECK(hipEventRecord(k->ev_h, s));
   const Fr *scal[N_TABLES] = {k->d_w, k->d_w, k->d_w, k->d_w, k->d_h};
   const bool share_b = h.share_b != 0 && h.npts[T_B1] == h.npts[T_B2];
   int sort_src[N_TABLES] = {T_A, T_B1, share_b ? T_B1 : T_B2, T_C, T_H};
@@ -288,39 +292,31 @@ static int prove_on_device(zkr_key *k, const Fr *d_wsrc, const uint8_t *r32, con
     if (!serial) ZKR_HIP_CHECK(hipEventRecord(k->ev_sorted[t], ss));
     return 0;
   };
-  auto accum_table = [&](int t) -> int {
-    hipStream_t ms = serial ? s : k->msm_stream[t];
+  auto accum_table = [&](int t, hipStream_t ms) -> int {
     if (!serial) ZKR_HIP_CHECK(hipStreamWaitEvent(ms, k->ev_sorted[sort_src[t]], 0));
     int rc;
     if (t == T_B2) rc = msm_accum_enqueue<Fq2>(k, ms, (const G2Affine *)(ar + h.off_pts[t]), h.npts[t], k->plan[t], k->ws[sort_src[t]], k->ws[t]);
     else rc = msm_accum_enqueue<Fq>(k, ms, (const G1Affine *)(ar + h.off_pts[t]), h.npts[t], k->plan[t], k->ws[sort_src[t]], k->ws[t]);
-    if (rc) return rc;
-    if (!serial) {
-      ZKR_HIP_CHECK(hipEventRecord(k->ev_done[t], ms));
-      ZKR_HIP_CHECK(hipStreamWaitEvent(s, k->ev_done[t], 0));
-    }
-    return 0;
+    return rc;
   };
-  int rc;
-  if (serial) {
-    if ((rc = calc_h_device(k, s))) return rc;
-  }
-  // sorts in the order their accumulations should start: B (G2 is the longest), A, C, then H once h exists
+  // sort order = order in which accumulations should start: B (G2 is the longest), A, H (h is ready by then), C
   if ((rc = sort_table(T_B1))) return rc;
   if (!share_b && (rc = sort_table(T_B2))) return rc;
-  if ((rc = accum_table(T_B2))) return rc;
+  if ((rc = accum_table(T_B2, sx))) return rc;
+  if ((rc = accum_table(T_B1, sy))) return rc;
   if ((rc = sort_table(T_A))) return rc;
-  if ((rc = accum_table(T_B1))) return rc;
-  if ((rc = accum_table(T_A))) return rc;
-  if ((rc = sort_table(T_C))) return rc;
-  if ((rc = accum_table(T_C))) return rc;
-  if (!serial) {
-    if ((rc = calc_h_device(k, s))) return rc;  // enqueued on the main stream: runs concurrently with everything above
-    ZKR_HIP_CHECK(hipEventRecord(k->ev_h, s));
-    ZKR_HIP_CHECK(hipStreamWaitEvent(ss, k->ev_h, 0));
-  }
+  if ((rc = accum_table(T_A, sy))) return rc;
+  if (!serial) ZKR_HIP_CHECK(hipStreamWaitEvent(ss, k->ev_h, 0));
   if ((rc = sort_table(T_H))) return rc;
-  if ((rc = accum_table(T_H))) return rc;
+  if ((rc = accum_table(T_H, sx))) return rc;
+  if ((rc = sort_table(T_C))) return rc;
+  if ((rc = accum_table(T_C, sy))) return rc;
+  if (!serial) {
+    ZKR_HIP_CHECK(hipEventRecord(k->ev_done[0], sx));
+    ZKR_HIP_CHECK(hipEventRecord(k->ev_done[1], sy));
+    ZKR_HIP_CHECK(hipStreamWaitEvent(s, k->ev_done[0], 0));
+    ZKR_HIP_CHECK(hipStreamWaitEvent(s, k->ev_done[1], 0));
+  }
   prof_end(k, s, tot);
   ZKR_HIP_CHECK(hipStreamSynchronize(s));
   prof_collect(k);
