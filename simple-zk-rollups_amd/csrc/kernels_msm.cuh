@@ -5,9 +5,11 @@
 // /root/reference/operator/src/snarks/common.ts:29).  Integer VALU work only (v_mad_u64_u32): no MFMA.
 //
 // Pipeline per MSM (all on one stream, no host round trip until the K window sums come back):
-//   count    : signed c-bit digits of every scalar -> histogram over K * 2^(c-1) buckets
-//   scan     : exclusive prefix sum -> bucket offsets; buckets larger than `big_thresh` are listed
-//   scatter  : (point index, sign) entries grouped by bucket (counting sort)
+//   digits   : signed c-bit digits of every scalar, once per scalar vector (u16 codes, window-major)
+//   hist     : workgroup per (window, chunk): bucket occupancies counted with LDS atomics
+//   scan     : per-bucket prefix over chunks, then exclusive prefix sum -> bucket offsets; buckets larger
+//              than `big_thresh` are listed
+//   scatter  : (point index, sign) entries grouped by bucket, cursors in LDS (counting sort)
 //   accum    : one thread per bucket, XYZZ += affine point (8M+2S), points gathered from the key table
 //   big      : one workgroup per oversized bucket (0/1-heavy witnesses), LDS tree of XYZZ sums
 //   reduce   : sum_b b*B_b per window: thread per group of g buckets (running sums) + small multiple
@@ -81,21 +83,78 @@ struct DigitIter {
 
 __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
 
-// histogram of bucket occupancies.  Digit +-1 (booleans, w_0 = 1) is aggregated per wavefront so that
-// thousands of lanes do not serialise on one L2 atomic.
-static __global__ __launch_bounds__(MSM_THREADS) void msm_count_kernel(const Fr *scalars, const uint32_t *sidx, MsmGeom g, uint32_t *counts) {
+// ---------------------------------------------------------------- digit sort (LDS counting sort per window)
+// Stage 1, once per SCALAR VECTOR (w serves the A, B1, B2 and C tables): signed c-bit digits of every
+// scalar as u16 codes, window-major: dig[k * stride + i] = 0 (digit 0: no entry) or
+// 1 + ((|d| - 1) << 1 | (d < 0)).  |d| <= 2^(c-1) <= 32768 and d > -2^(c-1), so the code fits 16 bits.
+static __global__ __launch_bounds__(MSM_THREADS) void msm_digits_kernel(const Fr *scalars, uint32_t n, int c, int K, size_t stride, uint16_t *dig) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  bool live = i < g.n;
+  if (i >= n) return;
   DigitIter it;
-  if (live) it.init(scalars[sidx ? sidx[i] : i].v); else { for (int k = 0; k < 8; k++) it.s[k] = 0; it.carry = 0; }
-  for (int k = 0; k < g.K; k++) {
-    int d = it.next(g.c);
-    bool one = live && (d == 1 || d == -1);
-    unsigned long long m = __ballot(one);
-    if (m) {
-      if (one && lane_id() == (uint32_t)__ffsll((long long)m) - 1) atomicAdd(&counts[k * g.nbw], (uint32_t)__popcll(m));
+  it.init(scalars[i].v);
+  for (int k = 0; k < K; k++) {
+    int d = it.next(c);
+    uint32_t mag = (uint32_t)(d < 0 ? -d : d);
+    dig[(size_t)k * stride + i] = d == 0 ? (uint16_t)0 : (uint16_t)(1u + (((mag - 1u) << 1) | (d < 0 ? 1u : 0u)));
+  }
+}
+
+// Stages 2 and 4 run one workgroup per (window k, chunk j of the table): the window's 2^(c-1) bucket
+// counters live in LDS (128 KB at c = 16, one workgroup per CU), so the 16 M increments of a 2^20-point
+// MSM are LDS atomics instead of L2/fabric atomics.  blockIdx -> (k, j) keeps all chunks of a window on one
+// XCD (block b runs on XCD b % 8; K is a multiple of 8 at full size) so their scattered 4-byte entry
+// writes merge in one L2.
+constexpr int SORT_THREADS = 1024;
+
+// cnt[(k * J + j) * nbw + b] = occupancy of bucket b of window k within chunk j
+static __global__ __launch_bounds__(SORT_THREADS) void msm_hist_kernel(const uint16_t *dig, size_t stride, const uint32_t *sidx, uint32_t n, int K, uint32_t nbw,
+                                                                     uint32_t J, uint32_t chunk, uint32_t *cnt) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t s_bkt[];
+  const uint32_t k = blockIdx.x % (uint32_t)K, j = blockIdx.x / (uint32_t)K;
+  for (uint32_t b = threadIdx.x; b < nbw; b += SORT_THREADS) s_bkt[b] = 0;
+  __syncthreads();
+  const uint16_t *dk = dig + (size_t)k * stride;
+  uint32_t i0 = j * chunk, i1 = min(i0 + chunk, n);
+  for (uint32_t i = i0 + threadIdx.x; i < i1; i += SORT_THREADS) {
+    uint32_t code = dk[sidx ? sidx[i] : i];
+    if (code) atomicAdd(&s_bkt[(code - 1u) >> 1], 1u);
+  }
+  __syncthreads();
+  uint32_t *out = cnt + ((size_t)k * J + j) * nbw;
+  for (uint32_t b = threadIdx.x; b < nbw; b += SORT_THREADS) out[b] = s_bkt[b];
+}
+
+// per bucket: exclusive prefix over the J chunks (in place) and the bucket total -> counts[]
+static __global__ __launch_bounds__(MSM_THREADS) void msm_colscan_kernel(uint32_t *cnt, uint32_t nb, uint32_t nbw, uint32_t J, uint32_t *counts) {
+  uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= nb) return;
+  uint32_t k = g / nbw, b = g % nbw;
+  uint32_t *col = cnt + (size_t)k * J * nbw + b;
+  uint32_t run = 0;
+  for (uint32_t j = 0; j < J; j++) {
+    uint32_t v = col[(size_t)j * nbw];
+    col[(size_t)j * nbw] = run;
+    run += v;
+  }
+  counts[g] = run;
+}
+
+// entries[pos] = (point index << 1) | sign, grouped by bucket: LDS cursors = bucket offset + chunk prefix
+static __global__ __launch_bounds__(SORT_THREADS) void msm_scatter_kernel(const uint16_t *dig, size_t stride, const uint32_t *sidx, uint32_t n, int K, uint32_t nbw,
+                                                                        uint32_t J, uint32_t chunk, const uint32_t *cnt, const uint32_t *offsets, uint32_t *entries) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t s_bkt[];
+  const uint32_t k = blockIdx.x % (uint32_t)K, j = blockIdx.x / (uint32_t)K;
+  const uint32_t *pre = cnt + ((size_t)k * J + j) * nbw, *off = offsets + (size_t)k * nbw;
+  for (uint32_t b = threadIdx.x; b < nbw; b += SORT_THREADS) s_bkt[b] = off[b] + pre[b];
+  __syncthreads();
+  const uint16_t *dk = dig + (size_t)k * stride;
+  uint32_t i0 = j * chunk, i1 = min(i0 + chunk, n);
+  for (uint32_t i = i0 + threadIdx.x; i < i1; i += SORT_THREADS) {
+    uint32_t code = dk[sidx ? sidx[i] : i];
+    if (code) {
+      uint32_t pos = atomicAdd(&s_bkt[(code - 1u) >> 1], 1u);
+      entries[pos] = (i << 1) | ((code - 1u) & 1u);
     }
-    if (live && d != 0 && !one) atomicAdd(&counts[k * g.nbw + (uint32_t)(d < 0 ? -d : d) - 1], 1u);
   }
 }
 
@@ -143,7 +202,7 @@ static __global__ __launch_bounds__(1024) void msm_scan_top_kernel(uint32_t *blo
 
 constexpr uint32_t BIG_MARK = 0xffffffffu;  // counts[b] after the scan: bucket b is owned by msm_big_kernel
 static __global__ __launch_bounds__(SCAN_THREADS) void msm_scan_apply_kernel(uint32_t *counts, const uint32_t *block_sums, const uint32_t *total,
-                                                                           uint32_t *offsets, uint32_t *cursor, uint32_t nb, uint32_t big_thresh,
+                                                                           uint32_t *offsets, uint32_t nb, uint32_t big_thresh,
                                                                            uint32_t *big_list, uint32_t *big_count, uint32_t big_cap) {
   __shared__ uint32_t part[SCAN_THREADS];
   uint32_t base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_PER_THREAD;
@@ -164,7 +223,6 @@ static __global__ __launch_bounds__(SCAN_THREADS) void msm_scan_apply_kernel(uin
   for (int k = 0; k < SCAN_PER_THREAD; k++) {
     if (base + k < nb) {
       offsets[base + k] = run;
-      cursor[base + k] = run;
       if (c[k] > big_thresh) {
         uint32_t slot = atomicAdd(big_count, 1u);
         if (slot < big_cap) { big_list[slot] = base + k; counts[base + k] = BIG_MARK; }  // beyond the cap the bucket stays with msm_accum_kernel
@@ -173,33 +231,6 @@ static __global__ __launch_bounds__(SCAN_THREADS) void msm_scan_apply_kernel(uin
     }
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) offsets[nb] = *total;
-}
-
-// entries[pos] = (point index << 1) | sign, grouped by bucket
-static __global__ __launch_bounds__(MSM_THREADS) void msm_scatter_kernel(const Fr *scalars, const uint32_t *sidx, MsmGeom g, uint32_t *cursor, uint32_t *entries) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  bool live = i < g.n;
-  DigitIter it;
-  if (live) it.init(scalars[sidx ? sidx[i] : i].v); else { for (int k = 0; k < 8; k++) it.s[k] = 0; it.carry = 0; }
-  for (int k = 0; k < g.K; k++) {
-    int d = it.next(g.c);
-    bool one = live && (d == 1 || d == -1);
-    unsigned long long m = __ballot(one);
-    if (m) {
-      uint32_t leader = (uint32_t)__ffsll((long long)m) - 1;
-      uint32_t base = 0;
-      if (one && lane_id() == leader) base = atomicAdd(&cursor[k * g.nbw], (uint32_t)__popcll(m));
-      base = __shfl(base, leader);
-      if (one) {
-        uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane_id()) - 1));
-        entries[base + rank] = (i << 1) | (d < 0 ? 1u : 0u);
-      }
-    }
-    if (live && d != 0 && !one) {
-      uint32_t pos = atomicAdd(&cursor[k * g.nbw + (uint32_t)(d < 0 ? -d : d) - 1], 1u);
-      entries[pos] = (i << 1) | (d < 0 ? 1u : 0u);
-    }
-  }
 }
 
 // bucket accumulation: thread per bucket.  Bucket sizes are ~Poisson(n / 2^(c-1)), so a wavefront would run

@@ -43,7 +43,9 @@ constexpr size_t ARENA_HEADER_BYTES = 1024;
 constexpr uint64_t ARENA_MAGIC = 0x313059454b524b5aull;
 
 struct MsmWorkspace {
-  uint32_t *counts = nullptr, *offsets = nullptr, *cursor = nullptr, *entries = nullptr;
+  uint32_t *counts = nullptr, *offsets = nullptr, *entries = nullptr;
+  uint32_t *chunk_cnt = nullptr;  // [K][J][nbw] per-chunk bucket occupancies, then per-bucket prefixes over chunks
+  uint16_t *own_dig = nullptr;    // digit codes when the workspace is not attached to a key (stage hooks)
   uint32_t *big_list = nullptr, *big_count = nullptr, *block_sums = nullptr;
   void *big_partials = nullptr;
   void *buckets = nullptr, *group_out = nullptr, *window_out = nullptr;
@@ -64,6 +66,7 @@ struct ProfSpan {
 struct MsmPlan {
   int c, K, glog;
   uint32_t nbw, nb, big_thresh;
+  uint32_t J, chunk;  // digit sort: J chunks of `chunk` points per window
 };
 
 }  // namespace zkr
@@ -81,6 +84,7 @@ struct zkr_key {
   hipEvent_t ev_sorted[zkr::N_TABLES] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   // workspace
   zkr::Fr *d_wraw = nullptr, *d_w = nullptr, *va = nullptr, *vb = nullptr, *ca = nullptr, *cb = nullptr, *d_h = nullptr;
+  uint16_t *dig_w = nullptr, *dig_h = nullptr;  // signed-digit codes of w (shared by A, B1, B2, C) and of h, window-major
   zkr::MsmWorkspace ws[zkr::N_TABLES];  // one per table so the five MSMs can be enqueued back to back
   zkr::MsmPlan plan[zkr::N_TABLES];
   // profiling
@@ -105,5 +109,5 @@ void prof_end(zkr_key *k, hipStream_t s, int span);
 int prof_collect(zkr_key *k);
 int run_ntt(hipStream_t s, const Fr *in0, const Fr *in1, Fr *out, const Fr *tw, const Fr *twl, int tlog, int L, bool dif, bool inverse, int pre);
 int calc_h_device(zkr_key *k, hipStream_t s);  // d_w -> d_h (bit-reversed)
-MsmPlan msm_plan(size_t n);
+MsmPlan msm_plan(size_t n_scalars, size_t n_points);
 }  // namespace zkr

@@ -42,10 +42,12 @@ static Fr fr_root_of_unity(unsigned k) {
 }
 Fr host_root_of_unity(unsigned k) { return fr_root_of_unity(k); }
 
-MsmPlan msm_plan(size_t n) {
+// Window size from the length of the SCALAR vector (tables that share scalars share the digit codes,
+// kernels_msm.cuh msm_digits_kernel); chunking and the oversized-bucket threshold from the table itself.
+MsmPlan msm_plan(size_t n_scalars, size_t n) {
   MsmPlan pl;
   int lg = 0;
-  while (((size_t)1 << lg) < n) lg++;
+  while (((size_t)1 << lg) < n_scalars) lg++;
   int c = lg - 4;
   if (c < 4) c = 4;
   if (c > 16) c = 16;
@@ -58,6 +60,15 @@ MsmPlan msm_plan(size_t n) {
   uint32_t mean = (uint32_t)(n / pl.nbw) + 1;
   pl.big_thresh = mean * 8 > 256 ? mean * 8 : 256;
   if (const char *e = getenv("ZKR_MSM_BIG")) { int v = atoi(e); if (v >= 1) pl.big_thresh = (uint32_t)v; }
+  // one workgroup per (window, chunk): about one per CU at full size, never chunks smaller than 4096 points
+  uint32_t J = (uint32_t)((n + 4095) / 4096);
+  uint32_t jmax = (uint32_t)(256 / pl.K) ? (uint32_t)(256 / pl.K) : 1u;
+  if (J > jmax) J = jmax;
+  if (J < 1) J = 1;
+  if (const char *e = getenv("ZKR_MSM_J")) { int v = atoi(e); if (v >= 1 && v <= 256) J = (uint32_t)v; }
+  pl.J = J;
+  pl.chunk = (uint32_t)((n + J - 1) / J);
+  if (pl.chunk == 0) pl.chunk = 1;
   return pl;
 }
 
@@ -65,7 +76,7 @@ static int alloc_msm_ws(MsmWorkspace &ws, size_t n, const MsmPlan &pl, size_t xy
   size_t nb = pl.nb;
   ZKR_HIP_CHECK(hipMalloc(&ws.counts, (nb + 1) * 4));
   ZKR_HIP_CHECK(hipMalloc(&ws.offsets, (nb + 1) * 4));
-  ZKR_HIP_CHECK(hipMalloc(&ws.cursor, (nb + 1) * 4));
+  ZKR_HIP_CHECK(hipMalloc(&ws.chunk_cnt, (size_t)pl.K * pl.J * pl.nbw * 4 + 4));
   ZKR_HIP_CHECK(hipMalloc(&ws.entries, (n * pl.K + 1) * 4));
   ZKR_HIP_CHECK(hipMalloc(&ws.big_list, BIG_CAP * 4));
   ZKR_HIP_CHECK(hipMalloc(&ws.big_count, 8));
@@ -81,7 +92,7 @@ static int alloc_msm_ws(MsmWorkspace &ws, size_t n, const MsmPlan &pl, size_t xy
 }
 int msm_ws_alloc(MsmWorkspace &ws, size_t n, const MsmPlan &pl, size_t xyzz_bytes) { return alloc_msm_ws(ws, n, pl, xyzz_bytes); }
 void msm_ws_free(MsmWorkspace &ws) {
-  hipFree(ws.counts); hipFree(ws.offsets); hipFree(ws.cursor); hipFree(ws.entries); hipFree(ws.big_list); hipFree(ws.big_count); hipFree(ws.block_sums); hipFree(ws.big_partials);
+  hipFree(ws.counts); hipFree(ws.offsets); hipFree(ws.chunk_cnt); hipFree(ws.own_dig); hipFree(ws.entries); hipFree(ws.big_list); hipFree(ws.big_count); hipFree(ws.block_sums); hipFree(ws.big_partials);
   hipFree(ws.buckets); hipFree(ws.group_out); hipFree(ws.window_out);
   if (ws.h_window) hipHostFree(ws.h_window);
   ws = MsmWorkspace();
@@ -104,10 +115,12 @@ int key_alloc_workspace(zkr_key *k) {
   Fr **vecs[5] = {&k->va, &k->vb, &k->ca, &k->cb, &k->d_h};
   for (auto v : vecs) ZKR_HIP_CHECK(hipMalloc(v, (size_t)h.m * 32));
   for (int t = 0; t < N_TABLES; t++) {
-    k->plan[t] = msm_plan(h.npts[t]);
+    k->plan[t] = msm_plan(t == T_H ? h.m : h.n, h.npts[t]);
     int rc = alloc_msm_ws(k->ws[t], h.npts[t], k->plan[t], t == T_B2 ? sizeof(G2XYZZ) : sizeof(G1XYZZ));
     if (rc) return rc;
   }
+  ZKR_HIP_CHECK(hipMalloc(&k->dig_w, (size_t)k->plan[T_A].K * h.n * 2 + 2));
+  ZKR_HIP_CHECK(hipMalloc(&k->dig_h, (size_t)k->plan[T_H].K * h.m * 2 + 2));
   return 0;
 }
 
@@ -352,6 +365,7 @@ void zkr_key_free(zkr_key *k) {
   if (k->ev_w) hipEventDestroy(k->ev_w);
   if (k->ev_h) hipEventDestroy(k->ev_h);
   for (int t = 0; t < N_TABLES; t++) msm_ws_free(k->ws[t]);
+  hipFree(k->dig_w); hipFree(k->dig_h);
   hipFree(k->d_wraw); hipFree(k->d_w); hipFree(k->va); hipFree(k->vb); hipFree(k->ca); hipFree(k->cb); hipFree(k->d_h);
   for (auto e : k->event_pool) hipEventDestroy(e);
   if (k->stream) hipStreamDestroy(k->stream);

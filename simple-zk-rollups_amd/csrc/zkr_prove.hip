@@ -161,22 +161,44 @@ template <class F> struct MsmCfg;
 template <> struct MsmCfg<Fq> { static constexpr int ACC_W = 4, RED_W = 2; static constexpr const char *ACC_STAGE = "msm_accum_g1"; };
 template <> struct MsmCfg<Fq2> { static constexpr int ACC_W = 2, RED_W = 1; static constexpr const char *ACC_STAGE = "msm_accum_g2"; };
 
-// digit sort of one scalar set: histogram -> scan -> counting-sort scatter (fabric-atomic bound)
-static int msm_sort_enqueue(zkr_key *prof, hipStream_t s, const uint32_t *sidx, const Fr *scalars, uint32_t n, const MsmPlan &pl, MsmWorkspace &ws) {
+// signed-digit codes of one scalar vector (window-major u16), shared by every table over those scalars
+static int msm_digits_enqueue(zkr_key *prof, hipStream_t s, const Fr *scalars, uint32_t n, const MsmPlan &pl, uint16_t *dig) {
   if (n == 0) return 0;
-  MsmGeom g;
-  g.n = n; g.c = pl.c; g.K = pl.K; g.nbw = pl.nbw; g.big_thresh = pl.big_thresh; g.glog = pl.glog;
   int sp = prof_begin(prof, s, "msm_sort");
-  ZKR_HIP_CHECK(hipMemsetAsync(ws.counts, 0, ((size_t)pl.nb + 1) * 4, s));
+  msm_digits_kernel<<<(n + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, s>>>(scalars, n, pl.c, pl.K, (size_t)n, dig);
+  prof_end(prof, s, sp);
+  ZKR_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// the window's bucket counters / cursors live in LDS: 4 * 2^(c-1) bytes, up to 128 KB (> the 64 KB default cap)
+static int sort_lds_opt_in() {
+  static int rc = [] {
+    hipError_t e = hipFuncSetAttribute((const void *)msm_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)msm_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    return e == hipSuccess ? 0 : 1;
+  }();
+  if (rc) { set_error("cannot opt in to 128 KB of LDS for the digit sort"); return ZKR_ERR_HIP; }
+  return 0;
+}
+
+// digit sort of one table: LDS histogram per (window, chunk) -> scans -> LDS-cursor scatter
+static int msm_sort_enqueue(zkr_key *prof, hipStream_t s, const uint32_t *sidx, const uint16_t *dig, size_t dig_stride, uint32_t n, const MsmPlan &pl, MsmWorkspace &ws) {
+  if (n == 0) return 0;
+  int rc = sort_lds_opt_in();
+  if (rc) return rc;
+  int sp = prof_begin(prof, s, "msm_sort");
   ZKR_HIP_CHECK(hipMemsetAsync(ws.big_count, 0, 8, s));
-  unsigned grid_n = (n + MSM_THREADS - 1) / MSM_THREADS;
-  msm_count_kernel<<<grid_n, MSM_THREADS, 0, s>>>(scalars, sidx, g, ws.counts);
+  const unsigned sort_grid = (unsigned)pl.K * pl.J;
+  const size_t lds = (size_t)pl.nbw * 4;
+  msm_hist_kernel<<<sort_grid, SORT_THREADS, lds, s>>>(dig, dig_stride, sidx, n, pl.K, pl.nbw, pl.J, pl.chunk, ws.chunk_cnt);
+  msm_colscan_kernel<<<(pl.nb + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, s>>>(ws.chunk_cnt, pl.nb, pl.nbw, pl.J, ws.counts);
   unsigned scan_blocks = (pl.nb + SCAN_BLOCK - 1) / SCAN_BLOCK;
   msm_scan_sums_kernel<<<scan_blocks, SCAN_THREADS, 0, s>>>(ws.counts, pl.nb, ws.block_sums);
   msm_scan_top_kernel<<<1, 1024, 0, s>>>(ws.block_sums, scan_blocks, ws.big_count + 1);
-  msm_scan_apply_kernel<<<scan_blocks, SCAN_THREADS, 0, s>>>(ws.counts, ws.block_sums, ws.big_count + 1, ws.offsets, ws.cursor, pl.nb, pl.big_thresh,
+  msm_scan_apply_kernel<<<scan_blocks, SCAN_THREADS, 0, s>>>(ws.counts, ws.block_sums, ws.big_count + 1, ws.offsets, pl.nb, pl.big_thresh,
                                                             ws.big_list, ws.big_count, BIG_CAP);
-  msm_scatter_kernel<<<grid_n, MSM_THREADS, 0, s>>>(scalars, sidx, g, ws.cursor, ws.entries);
+  msm_scatter_kernel<<<sort_grid, SORT_THREADS, lds, s>>>(dig, dig_stride, sidx, n, pl.K, pl.nbw, pl.J, pl.chunk, ws.chunk_cnt, ws.offsets, ws.entries);
   prof_end(prof, s, sp);
   ZKR_HIP_CHECK(hipGetLastError());
   return 0;
@@ -209,11 +231,14 @@ static int msm_accum_enqueue(zkr_key *prof, hipStream_t s, const Affine<F> *pts,
   return 0;
 }
 
+// stage-hook path: one table with its own scalars (n_scalars of them; sidx maps kept points to scalars)
 template <class F>
-static int msm_enqueue(zkr_key *prof, hipStream_t s, const Affine<F> *pts, const uint32_t *sidx, const Fr *scalars, uint32_t n,
+static int msm_enqueue(zkr_key *prof, hipStream_t s, const Affine<F> *pts, const uint32_t *sidx, const Fr *scalars, uint32_t n_scalars, uint32_t n,
                        const MsmPlan &pl, MsmWorkspace &ws) {
-  int rc = msm_sort_enqueue(prof, s, sidx, scalars, n, pl, ws);
+  if (!ws.own_dig) ZKR_HIP_CHECK(hipMalloc(&ws.own_dig, (size_t)pl.K * n_scalars * 2 + 2));
+  int rc = msm_digits_enqueue(prof, s, scalars, n_scalars, pl, ws.own_dig);
   if (rc) return rc;
+  if ((rc = msm_sort_enqueue(prof, s, sidx, ws.own_dig, n_scalars, n, pl, ws))) return rc;
   return msm_accum_enqueue<F>(prof, s, pts, n, pl, ws, ws);
 }
 
@@ -283,11 +308,13 @@ static int prove_on_device(zkr_key *k, const Fr *d_wsrc, const uint8_t *r32, con
   int rc;
   if ((rc = calc_h_device(k, s))) return rc;  // first in its queue: runs beside the witness sorts
   ZKR_HIP_CHECK(hipEventRecord(k->ev_h, s));
-  const Fr *scal[N_TABLES] = {k->d_w, k->d_w, k->d_w, k->d_w, k->d_h};
+  const uint16_t *dig[N_TABLES] = {k->dig_w, k->dig_w, k->dig_w, k->dig_w, k->dig_h};
+  const size_t dig_stride[N_TABLES] = {h.n, h.n, h.n, h.n, h.m};
+  if ((rc = msm_digits_enqueue(k, ss, k->d_w, h.n, k->plan[T_A], k->dig_w))) return rc;
   const bool share_b = h.share_b != 0 && h.npts[T_B1] == h.npts[T_B2];
   int sort_src[N_TABLES] = {T_A, T_B1, share_b ? T_B1 : T_B2, T_C, T_H};
   auto sort_table = [&](int t) -> int {
-    int rc = msm_sort_enqueue(k, ss, (const uint32_t *)(ar + h.off_sidx[t]), scal[t], h.npts[t], k->plan[t], k->ws[t]);
+    int rc = msm_sort_enqueue(k, ss, (const uint32_t *)(ar + h.off_sidx[t]), dig[t], dig_stride[t], h.npts[t], k->plan[t], k->ws[t]);
     if (rc) return rc;
     if (!serial) ZKR_HIP_CHECK(hipEventRecord(k->ev_sorted[t], ss));
     return 0;
@@ -307,6 +334,7 @@ static int prove_on_device(zkr_key *k, const Fr *d_wsrc, const uint8_t *r32, con
   if ((rc = sort_table(T_A))) return rc;
   if ((rc = accum_table(T_A, sy))) return rc;
   if (!serial) ZKR_HIP_CHECK(hipStreamWaitEvent(ss, k->ev_h, 0));
+  if ((rc = msm_digits_enqueue(k, ss, k->d_h, h.m, k->plan[T_H], k->dig_h))) return rc;
   if ((rc = sort_table(T_H))) return rc;
   if ((rc = accum_table(T_H, sx))) return rc;
   if ((rc = sort_table(T_C))) return rc;
@@ -429,7 +457,7 @@ static int msm_hook(const void *points_mont, const void *scalars_std, size_t n, 
   uint32_t np = (uint32_t)sidx.size();
   XYZZ<F> res = XYZZ<F>::inf();
   if (np) {
-    MsmPlan pl = msm_plan(np);
+    MsmPlan pl = msm_plan(n, np);
     MsmWorkspace ws;
     int rc = msm_ws_alloc(ws, np, pl, sizeof(XYZZ<F>));
     if (rc) return rc;
@@ -444,7 +472,7 @@ static int msm_hook(const void *points_mont, const void *scalars_std, size_t n, 
     ZKR_HIP_CHECK(hipMemcpy(d_sidx, sidx.data(), (size_t)np * 4, hipMemcpyHostToDevice));
     ZKR_HIP_CHECK(hipMemcpy(d_sc, scalars_std, n * 32, hipMemcpyHostToDevice));
     ingest_kernel<<<(unsigned)((n + 255) / 256), 256>>>(d_sc, d_sc2, n);
-    rc = msm_enqueue<F>(nullptr, nullptr, d_pts, d_sidx, d_sc2, np, pl, ws);
+    rc = msm_enqueue<F>(nullptr, nullptr, d_pts, d_sidx, d_sc2, (uint32_t)n, np, pl, ws);
     if (!rc) {
       hipError_t e = hipDeviceSynchronize();
       if (e != hipSuccess) { set_error("msm failed: %s", hipGetErrorString(e)); rc = ZKR_ERR_HIP; }
