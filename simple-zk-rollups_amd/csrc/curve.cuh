@@ -81,9 +81,9 @@ ZKR_HD XYZZ<F> add_mixed(const XYZZ<F> &acc, const Affine<F> &q_in, bool neg_q =
   return XYZZ<F>{x3, y3, mul(acc.zz, pp), mul(acc.zzz, ppp)};
 }
 
-// full add, both XYZZ (bucket reduction running sums): 12M + 2S
+// full add, both XYZZ (bucket reduction running sums): 12M + 2S; inlined form for the reduction kernels
 template <class F>
-ZKR_HD_COLD XYZZ<F> add_full(const XYZZ<F> &a, const XYZZ<F> &b) {
+ZKR_HD XYZZ<F> add_full_inl(const XYZZ<F> &a, const XYZZ<F> &b) {
   if (a.is_inf()) return b;
   if (b.is_inf()) return a;
   F u1 = mul(a.x, b.zz);
@@ -102,6 +102,12 @@ ZKR_HD_COLD XYZZ<F> add_full(const XYZZ<F> &a, const XYZZ<F> &b) {
   F x3 = sub(sub(sqr(r), ppp), dbl(qq));
   F y3 = sub(mul(r, sub(qq, x3)), mul(s1, ppp));
   return XYZZ<F>{x3, y3, mul(mul(a.zz, b.zz), pp), mul(mul(a.zzz, b.zzz), ppp)};
+}
+
+// out-of-line form for cold paths (host assembly, setup): keeps those builds small
+template <class F>
+ZKR_HD_COLD XYZZ<F> add_full(const XYZZ<F> &a, const XYZZ<F> &b) {
+  return add_full_inl(a, b);
 }
 
 // k * p for a small unsigned k (bucket-group offsets): left-to-right double-and-add

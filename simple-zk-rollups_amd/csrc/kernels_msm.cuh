@@ -10,10 +10,11 @@
 //   scan     : per-bucket prefix over chunks, then exclusive prefix sum -> bucket offsets; buckets larger
 //              than `big_thresh` are listed
 //   scatter  : (point index, sign) entries grouped by bucket, cursors in LDS (counting sort)
-//   accum    : one thread per bucket, XYZZ += affine point (8M+2S), points gathered from the key table
+//   order    : bucket ids sorted by occupancy, fullest first (counting sort over size classes)
+//   accum    : one thread per bucket in that order, XYZZ += affine point (8M+2S), points gathered from the key table
 //   big      : one workgroup per oversized bucket (0/1-heavy witnesses), LDS tree of XYZZ sums
-//   reduce   : sum_b b*B_b per window: thread per group of g buckets (running sums) + small multiple
-//   final    : one workgroup per window adds the group results -> K window sums (host does Horner)
+//   reduce   : sum_b b*B_b per window in three launches (group running sums, bit-subset sums, per-window
+//              Horner) -> K window sums (the host does the Horner over windows)
 #pragma once
 #include "curve.cuh"
 
@@ -200,11 +201,15 @@ static __global__ __launch_bounds__(1024) void msm_scan_top_kernel(uint32_t *blo
   if (t == 1023) *total = part[1023];
 }
 
+constexpr uint32_t SIZE_BINS = 1024;  // bucket size classes for the fullest-first ordering (sizes >= SIZE_BINS-1 share the top class)
+__device__ __forceinline__ uint32_t size_bin(uint32_t c) { return c < SIZE_BINS - 1 ? c : SIZE_BINS - 1; }
 constexpr uint32_t BIG_MARK = 0xffffffffu;  // counts[b] after the scan: bucket b is owned by msm_big_kernel
 static __global__ __launch_bounds__(SCAN_THREADS) void msm_scan_apply_kernel(uint32_t *counts, const uint32_t *block_sums, const uint32_t *total,
                                                                            uint32_t *offsets, uint32_t nb, uint32_t big_thresh,
-                                                                           uint32_t *big_list, uint32_t *big_count, uint32_t big_cap) {
+                                                                           uint32_t *big_list, uint32_t *big_count, uint32_t big_cap, uint32_t *size_hist) {
   __shared__ uint32_t part[SCAN_THREADS];
+  __shared__ uint32_t s_hist[SIZE_BINS];
+  for (uint32_t b = threadIdx.x; b < SIZE_BINS; b += SCAN_THREADS) s_hist[b] = 0;
   uint32_t base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_PER_THREAD;
   uint32_t c[SCAN_PER_THREAD];
   uint32_t s = 0;
@@ -223,48 +228,90 @@ static __global__ __launch_bounds__(SCAN_THREADS) void msm_scan_apply_kernel(uin
   for (int k = 0; k < SCAN_PER_THREAD; k++) {
     if (base + k < nb) {
       offsets[base + k] = run;
+      bool big = false;
       if (c[k] > big_thresh) {
         uint32_t slot = atomicAdd(big_count, 1u);
-        if (slot < big_cap) { big_list[slot] = base + k; counts[base + k] = BIG_MARK; }  // beyond the cap the bucket stays with msm_accum_kernel
+        if (slot < big_cap) { big_list[slot] = base + k; counts[base + k] = BIG_MARK; big = true; }  // beyond the cap the bucket stays with msm_accum_kernel
       }
+      atomicAdd(&s_hist[big ? 0u : size_bin(c[k])], 1u);
       run += c[k];
     }
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) offsets[nb] = *total;
+  __syncthreads();
+  for (uint32_t b = threadIdx.x; b < SIZE_BINS; b += SCAN_THREADS)
+    if (s_hist[b]) atomicAdd(&size_hist[b], s_hist[b]);
 }
 
-// bucket accumulation: thread per bucket.  Bucket sizes are ~Poisson(n / 2^(c-1)), so a wavefront would run
-// at the pace of its fullest bucket; the workgroup therefore ranks its 256 buckets by size in LDS first
-// and lane i takes the i-th largest, which makes the 64 lanes of a wavefront near-equal in trip count.
+// order[] = all bucket ids sorted by occupancy, fullest first (counting sort over SIZE_BINS size classes;
+// msm_big_kernel-owned and empty buckets go last).  Same 2048-bucket partition as the scan.  size_hist is
+// complete when this runs; `taken` (zeroed) hands out ranges inside each size class.
+static __global__ __launch_bounds__(SCAN_THREADS) void msm_order_kernel(const uint32_t *counts, uint32_t nb, const uint32_t *size_hist, uint32_t *taken, uint32_t *order) {
+  __shared__ uint32_t s_start[SIZE_BINS];  // first: global histogram -> start of each class (descending sizes)
+  __shared__ uint32_t s_hist[SIZE_BINS];   // local histogram, then base of this workgroup's range in each class
+  __shared__ uint32_t part[SCAN_THREADS];
+  constexpr uint32_t PER = SIZE_BINS / SCAN_THREADS;
+  const uint32_t t = threadIdx.x;
+  // descending exclusive prefix: class SIZE_BINS-1 starts at 0
+  uint32_t v[PER], sum = 0;
+#pragma unroll
+  for (uint32_t q = 0; q < PER; q++) { v[q] = size_hist[SIZE_BINS - 1 - (t * PER + q)]; sum += v[q]; }
+  part[t] = sum;
+  for (uint32_t b = t; b < SIZE_BINS; b += SCAN_THREADS) s_hist[b] = 0;
+  __syncthreads();
+  for (uint32_t off = 1; off < SCAN_THREADS; off <<= 1) {
+    uint32_t u = t >= off ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += u;
+    __syncthreads();
+  }
+  uint32_t run = part[t] - sum;
+#pragma unroll
+  for (uint32_t q = 0; q < PER; q++) { s_start[SIZE_BINS - 1 - (t * PER + q)] = run; run += v[q]; }
+  // local ranks
+  uint32_t base = blockIdx.x * SCAN_BLOCK + t * SCAN_PER_THREAD;
+  uint32_t bin[SCAN_PER_THREAD], rank[SCAN_PER_THREAD];
+#pragma unroll
+  for (int k = 0; k < SCAN_PER_THREAD; k++) {
+    if (base + k < nb) {
+      uint32_t c = counts[base + k];
+      bin[k] = c == BIG_MARK ? 0u : size_bin(c);
+      rank[k] = atomicAdd(&s_hist[bin[k]], 1u);
+    }
+  }
+  __syncthreads();
+  for (uint32_t b = t; b < SIZE_BINS; b += SCAN_THREADS) {
+    uint32_t h = s_hist[b];
+    if (h) s_hist[b] = s_start[b] + atomicAdd(&taken[b], h);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < SCAN_PER_THREAD; k++)
+    if (base + k < nb) order[s_hist[bin[k]] + rank[k]] = base + k;
+}
+
+// bucket accumulation: thread per bucket, buckets taken in `order` (fullest first): the 64 lanes of a
+// wavefront get buckets of (almost) equal occupancy, so no lane idles while another finishes, and the long
+// buckets start first.  The next entry and its point are fetched while the current addition runs.
 template <class F, int MINW>
 static __global__ __launch_bounds__(MSM_THREADS, MINW) void msm_accum_kernel(const Affine<F> *points, const uint32_t *offsets, const uint32_t *entries,
-                                                                     uint32_t nb, const uint32_t *counts, XYZZ<F> *buckets) {
-  __shared__ uint32_t s_cnt[MSM_THREADS];
-  __shared__ uint32_t s_order[MSM_THREADS];
-  const uint32_t b0 = blockIdx.x * MSM_THREADS, tid = threadIdx.x;
-  uint32_t my = 0;  // size of bucket b0 + tid; empty / out-of-range / msm_big_kernel-owned buckets sort last
-  if (b0 + tid < nb) {
-    uint32_t c = counts[b0 + tid];
-    my = c == BIG_MARK ? 0 : c;
-  }
-  s_cnt[tid] = my;
-  __syncthreads();
-  uint32_t rank = 0;
-  for (uint32_t j = 0; j < MSM_THREADS; j++) {
-    uint32_t o = s_cnt[j];
-    rank += (o > my) || (o == my && j < tid);
-  }
-  s_order[rank] = tid;
-  __syncthreads();
-  const uint32_t b = b0 + s_order[tid];
-  if (b >= nb) return;
-  const bool big = counts[b] == BIG_MARK;
-  if (big) return;  // msm_big_kernel owns it
+                                                                     uint32_t nb, const uint32_t *counts, const uint32_t *order, XYZZ<F> *buckets) {
+  const uint32_t t = blockIdx.x * MSM_THREADS + threadIdx.x;
+  if (t >= nb) return;
+  const uint32_t b = order[t];
+  if (counts[b] == BIG_MARK) return;  // msm_big_kernel owns it
   uint32_t o0 = offsets[b], o1 = offsets[b + 1];
   XYZZ<F> acc = XYZZ<F>::inf();
-  for (uint32_t j = o0; j < o1; j++) {
-    uint32_t e = entries[j];
+  if (o0 < o1) {
+    uint32_t e = entries[o0];
     Affine<F> p = load_pod(points + (e >> 1));
+    for (uint32_t j = o0 + 1; j < o1; j++) {
+      uint32_t en = entries[j];
+      Affine<F> pn = load_pod(points + (en >> 1));
+      acc = add_mixed(acc, p, (e & 1) != 0);
+      e = en;
+      p = pn;
+    }
     acc = add_mixed(acc, p, (e & 1) != 0);
   }
   store_pod(buckets + b, acc);
@@ -313,40 +360,70 @@ static __global__ __launch_bounds__(64, MINW) void msm_big_finish_kernel(const X
   store_pod(buckets + big_list[w], acc);
 }
 
-// per group of 2^glog buckets of one window: sum_j (digit value) * B_j
+// ---------------------------------------------------------------- bucket reduction: W_k = sum_b (b+1) * B_{k,b}
+// Three short launches per MSM; g = 2^glog buckets per group, ng = nbw / g groups per window:
+//   reduce1 : thread per group, running sums over its g buckets -> R_t = sum_j B_{t,j}, T_t = sum_j (j+1) B_{t,j}
+//             so that W_k = sum_t T_t + g * sum_t t * R_t            (2 additions per bucket, chains of 2g)
+//   reduce2 : workgroup per (window, task): Q_j = sum of the R_t whose index t has bit j set (log2 ng tasks)
+//             and the two halves of sum_t T_t -- plain sums: strided accumulation + LDS tree
+//   reduce3 : thread per window: Horner over the Q_j, glog doublings, + the T halves -> window sum W_k
+// (the host finishes with the Horner over the K windows: sequential doublings are ~20x faster there).
+// group_out: per window R[ng] then T[ng];  task_out: per window Q[nglog] then T-half[2].
 template <class F, int MINW>
-static __global__ __launch_bounds__(MSM_THREADS, MINW) void msm_reduce_kernel(const XYZZ<F> *buckets, MsmGeom g, XYZZ<F> *group_out) {
+static __global__ __launch_bounds__(MSM_THREADS, MINW) void msm_reduce1_kernel(const XYZZ<F> *buckets, MsmGeom g, XYZZ<F> *group_out) {
   uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t groups_per_window = g.nbw >> g.glog;
-  if (gid >= groups_per_window * (uint32_t)g.K) return;
-  uint32_t k = gid / groups_per_window, t = gid % groups_per_window;
-  uint32_t gs = 1u << g.glog;
+  const uint32_t ng = g.nbw >> g.glog, gs = 1u << g.glog;
+  if (gid >= ng * (uint32_t)g.K) return;
+  uint32_t k = gid / ng, t = gid % ng;
   const XYZZ<F> *B = buckets + (size_t)k * g.nbw + (size_t)t * gs;
-  XYZZ<F> run = XYZZ<F>::inf(), T = XYZZ<F>::inf();
-  for (int j = (int)gs - 1; j >= 0; j--) {
-    run = add_full(run, load_pod(B + j));
-    T = add_full(T, run);
+  XYZZ<F> run = load_pod(B + gs - 1), T = run;
+  for (int j = (int)gs - 2; j >= 0; j--) {
+    run = add_full_inl(run, load_pod(B + j));
+    T = add_full_inl(T, run);
   }
-  // bucket j of this group holds digit value t*gs + j + 1:  T = sum (j+1) B_j, run = sum B_j
-  if (t) T = add_full(T, mul_small(run, t * gs));
-  store_pod(group_out + gid, T);
+  store_pod(group_out + ((size_t)k * 2) * ng + t, run);
+  store_pod(group_out + ((size_t)k * 2 + 1) * ng + t, T);
 }
 
-// workgroup per window: add the group results
 template <class F, int MINW>
-static __global__ __launch_bounds__(MSM_THREADS, MINW) void msm_final_kernel(const XYZZ<F> *group_out, uint32_t groups_per_window, XYZZ<F> *window_out) {
+static __global__ __launch_bounds__(MSM_THREADS, MINW) void msm_reduce2_kernel(const XYZZ<F> *group_out, MsmGeom g, XYZZ<F> *task_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   XYZZ<F> *sh = reinterpret_cast<XYZZ<F> *>(smem);
-  const XYZZ<F> *G = group_out + (size_t)blockIdx.x * groups_per_window;
+  const uint32_t nglog = (uint32_t)(g.c - 1 - g.glog), ng = 1u << nglog, ntask = nglog + 2;
+  const uint32_t k = blockIdx.x / ntask, j = blockIdx.x % ntask;
   XYZZ<F> acc = XYZZ<F>::inf();
-  for (uint32_t j = threadIdx.x; j < groups_per_window; j += MSM_THREADS) acc = add_full(acc, load_pod(G + j));
+  if (j < nglog) {  // the u-th index with bit j set, u < ng/2
+    const XYZZ<F> *R = group_out + ((size_t)k * 2) * ng;
+    for (uint32_t u = threadIdx.x; u < ng / 2; u += MSM_THREADS) {
+      uint32_t t = ((u >> j) << (j + 1)) | (1u << j) | (u & ((1u << j) - 1u));
+      acc = add_full_inl(acc, load_pod(R + t));
+    }
+  } else {
+    const XYZZ<F> *T = group_out + ((size_t)k * 2 + 1) * ng;
+    uint32_t h = j - nglog, lo = h * ng / 2, hi = (h + 1) * ng / 2;
+    for (uint32_t t = lo + threadIdx.x; t < hi; t += MSM_THREADS) acc = add_full_inl(acc, load_pod(T + t));
+  }
   sh[threadIdx.x] = acc;
   __syncthreads();
   for (uint32_t s = MSM_THREADS / 2; s > 0; s >>= 1) {
-    if (threadIdx.x < s) sh[threadIdx.x] = add_full(sh[threadIdx.x], sh[threadIdx.x + s]);
+    if (threadIdx.x < s) sh[threadIdx.x] = add_full_inl(sh[threadIdx.x], sh[threadIdx.x + s]);
     __syncthreads();
   }
-  if (threadIdx.x == 0) store_pod(window_out + blockIdx.x, sh[0]);
+  if (threadIdx.x == 0) store_pod(task_out + blockIdx.x, sh[0]);
+}
+
+template <class F, int MINW>
+static __global__ __launch_bounds__(64, MINW) void msm_reduce3_kernel(const XYZZ<F> *task_out, MsmGeom g, XYZZ<F> *window_out) {
+  uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= (uint32_t)g.K) return;
+  const int nglog = g.c - 1 - g.glog;
+  const XYZZ<F> *Q = task_out + (size_t)k * (nglog + 2);
+  XYZZ<F> acc = XYZZ<F>::inf();
+  for (int j = nglog - 1; j >= 0; j--) acc = add_full(dbl_xyzz(acc), load_pod(Q + j));
+  for (int j = 0; j < g.glog; j++) acc = dbl_xyzz(acc);
+  acc = add_full(acc, load_pod(Q + nglog));
+  acc = add_full(acc, load_pod(Q + nglog + 1));
+  store_pod(window_out + k, acc);
 }
 
 // ---------------------------------------------------------------- device-side setup

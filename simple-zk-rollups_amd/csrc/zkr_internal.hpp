@@ -44,11 +44,12 @@ constexpr uint64_t ARENA_MAGIC = 0x313059454b524b5aull;
 
 struct MsmWorkspace {
   uint32_t *counts = nullptr, *offsets = nullptr, *entries = nullptr;
+  uint32_t *size_hist = nullptr, *order = nullptr;  // [2][SIZE_BINS] size-class histogram + hand-out counters; bucket ids fullest first
   uint32_t *chunk_cnt = nullptr;  // [K][J][nbw] per-chunk bucket occupancies, then per-bucket prefixes over chunks
   uint16_t *own_dig = nullptr;    // digit codes when the workspace is not attached to a key (stage hooks)
   uint32_t *big_list = nullptr, *big_count = nullptr, *block_sums = nullptr;
   void *big_partials = nullptr;
-  void *buckets = nullptr, *group_out = nullptr, *window_out = nullptr;
+  void *buckets = nullptr, *group_out = nullptr, *task_out = nullptr, *window_out = nullptr;
   void *h_window = nullptr;  // pinned host copy of the window sums
   size_t max_nb = 0, max_entries = 0;
 };

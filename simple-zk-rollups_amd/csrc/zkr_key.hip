@@ -56,7 +56,7 @@ MsmPlan msm_plan(size_t n_scalars, size_t n) {
   pl.K = (255 + c - 1) / c;
   pl.nbw = 1u << (c - 1);
   pl.nb = pl.nbw * (uint32_t)pl.K;
-  pl.glog = c - 1 < 4 ? c - 1 : 4;
+  pl.glog = c - 1 < 3 ? c - 1 : 3;  // bucket reduction: groups of 8 buckets (kernels_msm.cuh msm_reduce1_kernel)
   uint32_t mean = (uint32_t)(n / pl.nbw) + 1;
   pl.big_thresh = mean * 8 > 256 ? mean * 8 : 256;
   if (const char *e = getenv("ZKR_MSM_BIG")) { int v = atoi(e); if (v >= 1) pl.big_thresh = (uint32_t)v; }
@@ -76,6 +76,8 @@ static int alloc_msm_ws(MsmWorkspace &ws, size_t n, const MsmPlan &pl, size_t xy
   size_t nb = pl.nb;
   ZKR_HIP_CHECK(hipMalloc(&ws.counts, (nb + 1) * 4));
   ZKR_HIP_CHECK(hipMalloc(&ws.offsets, (nb + 1) * 4));
+  ZKR_HIP_CHECK(hipMalloc(&ws.size_hist, 2 * SIZE_BINS * 4));
+  ZKR_HIP_CHECK(hipMalloc(&ws.order, (nb + 1) * 4));
   ZKR_HIP_CHECK(hipMalloc(&ws.chunk_cnt, (size_t)pl.K * pl.J * pl.nbw * 4 + 4));
   ZKR_HIP_CHECK(hipMalloc(&ws.entries, (n * pl.K + 1) * 4));
   ZKR_HIP_CHECK(hipMalloc(&ws.big_list, BIG_CAP * 4));
@@ -83,7 +85,8 @@ static int alloc_msm_ws(MsmWorkspace &ws, size_t n, const MsmPlan &pl, size_t xy
   ZKR_HIP_CHECK(hipMalloc(&ws.block_sums, (nb / SCAN_BLOCK + 2) * 4));
   ZKR_HIP_CHECK(hipMalloc(&ws.big_partials, (size_t)BIG_CAP * BIG_SPLIT * xyzz_bytes));
   ZKR_HIP_CHECK(hipMalloc(&ws.buckets, nb * xyzz_bytes));
-  ZKR_HIP_CHECK(hipMalloc(&ws.group_out, (size_t)(pl.nbw >> pl.glog) * pl.K * xyzz_bytes));
+  ZKR_HIP_CHECK(hipMalloc(&ws.group_out, (size_t)(pl.nbw >> pl.glog) * 2 * pl.K * xyzz_bytes));
+  ZKR_HIP_CHECK(hipMalloc(&ws.task_out, (size_t)(pl.c + 2) * pl.K * xyzz_bytes));
   ZKR_HIP_CHECK(hipMalloc(&ws.window_out, MSM_MAX_WINDOWS * xyzz_bytes));
   ZKR_HIP_CHECK(hipHostMalloc(&ws.h_window, MSM_MAX_WINDOWS * xyzz_bytes, hipHostMallocDefault));
   ws.max_nb = nb;
@@ -92,8 +95,8 @@ static int alloc_msm_ws(MsmWorkspace &ws, size_t n, const MsmPlan &pl, size_t xy
 }
 int msm_ws_alloc(MsmWorkspace &ws, size_t n, const MsmPlan &pl, size_t xyzz_bytes) { return alloc_msm_ws(ws, n, pl, xyzz_bytes); }
 void msm_ws_free(MsmWorkspace &ws) {
-  hipFree(ws.counts); hipFree(ws.offsets); hipFree(ws.chunk_cnt); hipFree(ws.own_dig); hipFree(ws.entries); hipFree(ws.big_list); hipFree(ws.big_count); hipFree(ws.block_sums); hipFree(ws.big_partials);
-  hipFree(ws.buckets); hipFree(ws.group_out); hipFree(ws.window_out);
+  hipFree(ws.counts); hipFree(ws.offsets); hipFree(ws.chunk_cnt); hipFree(ws.size_hist); hipFree(ws.order); hipFree(ws.own_dig); hipFree(ws.entries); hipFree(ws.big_list); hipFree(ws.big_count); hipFree(ws.block_sums); hipFree(ws.big_partials);
+  hipFree(ws.buckets); hipFree(ws.group_out); hipFree(ws.task_out); hipFree(ws.window_out);
   if (ws.h_window) hipHostFree(ws.h_window);
   ws = MsmWorkspace();
 }

@@ -189,6 +189,7 @@ static int msm_sort_enqueue(zkr_key *prof, hipStream_t s, const uint32_t *sidx, 
   if (rc) return rc;
   int sp = prof_begin(prof, s, "msm_sort");
   ZKR_HIP_CHECK(hipMemsetAsync(ws.big_count, 0, 8, s));
+  ZKR_HIP_CHECK(hipMemsetAsync(ws.size_hist, 0, 2 * SIZE_BINS * 4, s));
   const unsigned sort_grid = (unsigned)pl.K * pl.J;
   const size_t lds = (size_t)pl.nbw * 4;
   msm_hist_kernel<<<sort_grid, SORT_THREADS, lds, s>>>(dig, dig_stride, sidx, n, pl.K, pl.nbw, pl.J, pl.chunk, ws.chunk_cnt);
@@ -197,7 +198,8 @@ static int msm_sort_enqueue(zkr_key *prof, hipStream_t s, const uint32_t *sidx, 
   msm_scan_sums_kernel<<<scan_blocks, SCAN_THREADS, 0, s>>>(ws.counts, pl.nb, ws.block_sums);
   msm_scan_top_kernel<<<1, 1024, 0, s>>>(ws.block_sums, scan_blocks, ws.big_count + 1);
   msm_scan_apply_kernel<<<scan_blocks, SCAN_THREADS, 0, s>>>(ws.counts, ws.block_sums, ws.big_count + 1, ws.offsets, pl.nb, pl.big_thresh,
-                                                            ws.big_list, ws.big_count, BIG_CAP);
+                                                            ws.big_list, ws.big_count, BIG_CAP, ws.size_hist);
+  msm_order_kernel<<<scan_blocks, SCAN_THREADS, 0, s>>>(ws.counts, pl.nb, ws.size_hist, ws.size_hist + SIZE_BINS, ws.order);
   msm_scatter_kernel<<<sort_grid, SORT_THREADS, lds, s>>>(dig, dig_stride, sidx, n, pl.K, pl.nbw, pl.J, pl.chunk, ws.chunk_cnt, ws.offsets, ws.entries);
   prof_end(prof, s, sp);
   ZKR_HIP_CHECK(hipGetLastError());
@@ -213,7 +215,7 @@ static int msm_accum_enqueue(zkr_key *prof, hipStream_t s, const Affine<F> *pts,
   g.n = n; g.c = pl.c; g.K = pl.K; g.nbw = pl.nbw; g.big_thresh = pl.big_thresh; g.glog = pl.glog;
   int sp = prof_begin(prof, s, MsmCfg<F>::ACC_STAGE);
   msm_accum_kernel<F, MsmCfg<F>::ACC_W><<<(pl.nb + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, s>>>(pts, srt.offsets, srt.entries, pl.nb, srt.counts,
-                                                                                                      (XYZZ<F> *)ws.buckets);
+                                                                                                      srt.order, (XYZZ<F> *)ws.buckets);
   prof_end(prof, s, sp);
   sp = prof_begin(prof, s, "msm_big");
   msm_big_kernel<F, MsmCfg<F>::RED_W><<<BIG_SLOTS * BIG_SPLIT, MSM_THREADS, MSM_THREADS * sizeof(XYZZ<F>), s>>>(pts, srt.offsets, srt.entries, srt.big_list, srt.big_count,
@@ -221,10 +223,11 @@ static int msm_accum_enqueue(zkr_key *prof, hipStream_t s, const Affine<F> *pts,
   msm_big_finish_kernel<F, MsmCfg<F>::RED_W><<<BIG_CAP / 64, 64, 0, s>>>((const XYZZ<F> *)ws.big_partials, srt.big_list, srt.big_count, BIG_CAP, (XYZZ<F> *)ws.buckets);
   prof_end(prof, s, sp);
   sp = prof_begin(prof, s, "msm_reduce");
-  uint32_t gpw = pl.nbw >> pl.glog;
-  uint32_t ngroups = gpw * (uint32_t)pl.K;
-  msm_reduce_kernel<F, MsmCfg<F>::RED_W><<<(ngroups + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, s>>>((const XYZZ<F> *)ws.buckets, g, (XYZZ<F> *)ws.group_out);
-  msm_final_kernel<F, MsmCfg<F>::RED_W><<<pl.K, MSM_THREADS, MSM_THREADS * sizeof(XYZZ<F>), s>>>((const XYZZ<F> *)ws.group_out, gpw, (XYZZ<F> *)ws.window_out);
+  uint32_t ngroups = (pl.nbw >> pl.glog) * (uint32_t)pl.K;
+  uint32_t ntask = (uint32_t)(pl.c - 1 - pl.glog) + 2;
+  msm_reduce1_kernel<F, MsmCfg<F>::RED_W><<<(ngroups + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, s>>>((const XYZZ<F> *)ws.buckets, g, (XYZZ<F> *)ws.group_out);
+  msm_reduce2_kernel<F, MsmCfg<F>::RED_W><<<(unsigned)pl.K * ntask, MSM_THREADS, MSM_THREADS * sizeof(XYZZ<F>), s>>>((const XYZZ<F> *)ws.group_out, g, (XYZZ<F> *)ws.task_out);
+  msm_reduce3_kernel<F, MsmCfg<F>::RED_W><<<(pl.K + 63) / 64, 64, 0, s>>>((const XYZZ<F> *)ws.task_out, g, (XYZZ<F> *)ws.window_out);
   prof_end(prof, s, sp);
   ZKR_HIP_CHECK(hipMemcpyAsync(ws.h_window, ws.window_out, (size_t)pl.K * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, s));
   ZKR_HIP_CHECK(hipGetLastError());
