@@ -46,7 +46,7 @@ ZKR_HD XYZZ<F> dbl_affine(const Affine<F> &p) {
 }
 
 template <class F>
-ZKR_HD_COLD XYZZ<F> dbl_xyzz(const XYZZ<F> &p) {
+ZKR_HD XYZZ<F> dbl_xyzz_inl(const XYZZ<F> &p) {
   if (p.is_inf()) return p;
   F u = dbl(p.y);
   F v = sqr(u);
@@ -57,6 +57,11 @@ ZKR_HD_COLD XYZZ<F> dbl_xyzz(const XYZZ<F> &p) {
   F x3 = sub(sqr(m), dbl(s));
   F y3 = sub(mul(m, sub(s, x3)), mul(w, p.y));
   return XYZZ<F>{x3, y3, mul(v, p.zz), mul(w, p.zzz)};
+}
+
+template <class F>
+ZKR_HD_COLD XYZZ<F> dbl_xyzz(const XYZZ<F> &p) {
+  return dbl_xyzz_inl(p);
 }
 
 // acc + q, q affine and NOT infinity (callers filter infinity).  neg_q adds -q instead.

@@ -326,6 +326,7 @@ template <class F, int MINW>
 static __global__ __launch_bounds__(MSM_THREADS, MINW) void msm_big_kernel(const Affine<F> *points, const uint32_t *offsets, const uint32_t *entries,
                                                                    const uint32_t *big_list, const uint32_t *big_count, uint32_t big_cap,
                                                                    XYZZ<F> *partials) {
+  __builtin_amdgcn_s_setprio(3);  // few long-running wavefronts on the critical path: win VALU arbitration against the bulk accumulation
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   XYZZ<F> *sh = reinterpret_cast<XYZZ<F> *>(smem);
   uint32_t nbig = min(*big_count, big_cap);
@@ -353,6 +354,7 @@ static __global__ __launch_bounds__(MSM_THREADS, MINW) void msm_big_kernel(const
 template <class F, int MINW>
 static __global__ __launch_bounds__(64, MINW) void msm_big_finish_kernel(const XYZZ<F> *partials, const uint32_t *big_list, const uint32_t *big_count,
                                                                          uint32_t big_cap, XYZZ<F> *buckets) {
+  __builtin_amdgcn_s_setprio(3);  // few long-running wavefronts on the critical path: win VALU arbitration against the bulk accumulation
   uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= min(*big_count, big_cap)) return;
   XYZZ<F> acc = load_pod(partials + (size_t)w * BIG_SPLIT);
@@ -366,11 +368,12 @@ static __global__ __launch_bounds__(64, MINW) void msm_big_finish_kernel(const X
 //             so that W_k = sum_t T_t + g * sum_t t * R_t            (2 additions per bucket, chains of 2g)
 //   reduce2 : workgroup per (window, task): Q_j = sum of the R_t whose index t has bit j set (log2 ng tasks)
 //             and the two halves of sum_t T_t -- plain sums: strided accumulation + LDS tree
-//   reduce3 : thread per window: Horner over the Q_j, glog doublings, + the T halves -> window sum W_k
+//   reduce3 : 16 lanes per window: 2^(j+glog) Q_j by doublings in parallel, + the T halves, LDS tree -> W_k
 // (the host finishes with the Horner over the K windows: sequential doublings are ~20x faster there).
 // group_out: per window R[ng] then T[ng];  task_out: per window Q[nglog] then T-half[2].
 template <class F, int MINW>
 static __global__ __launch_bounds__(MSM_THREADS, MINW) void msm_reduce1_kernel(const XYZZ<F> *buckets, MsmGeom g, XYZZ<F> *group_out) {
+  __builtin_amdgcn_s_setprio(3);  // few long-running wavefronts on the critical path: win VALU arbitration against the bulk accumulation
   uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t ng = g.nbw >> g.glog, gs = 1u << g.glog;
   if (gid >= ng * (uint32_t)g.K) return;
@@ -387,6 +390,7 @@ static __global__ __launch_bounds__(MSM_THREADS, MINW) void msm_reduce1_kernel(c
 
 template <class F, int MINW>
 static __global__ __launch_bounds__(MSM_THREADS, MINW) void msm_reduce2_kernel(const XYZZ<F> *group_out, MsmGeom g, XYZZ<F> *task_out) {
+  __builtin_amdgcn_s_setprio(3);  // few long-running wavefronts on the critical path: win VALU arbitration against the bulk accumulation
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   XYZZ<F> *sh = reinterpret_cast<XYZZ<F> *>(smem);
   const uint32_t nglog = (uint32_t)(g.c - 1 - g.glog), ng = 1u << nglog, ntask = nglog + 2;
@@ -412,18 +416,29 @@ static __global__ __launch_bounds__(MSM_THREADS, MINW) void msm_reduce2_kernel(c
   if (threadIdx.x == 0) store_pod(task_out + blockIdx.x, sh[0]);
 }
 
+// 16 lanes per window (4 windows per wavefront): lane j < nglog turns Q_j into 2^(j+glog) Q_j by doublings,
+// lanes nglog, nglog+1 carry the T halves; a 4-level LDS tree adds the 16 lanes.  (A single-lane Horner would
+// chain nglog additions behind the doublings.)
+constexpr int RED3_LANES = 16;
 template <class F, int MINW>
 static __global__ __launch_bounds__(64, MINW) void msm_reduce3_kernel(const XYZZ<F> *task_out, MsmGeom g, XYZZ<F> *window_out) {
-  uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= (uint32_t)g.K) return;
-  const int nglog = g.c - 1 - g.glog;
-  const XYZZ<F> *Q = task_out + (size_t)k * (nglog + 2);
+  __builtin_amdgcn_s_setprio(3);
+  __shared__ XYZZ<F> sh[64];
+  const uint32_t lane = threadIdx.x % RED3_LANES, k = blockIdx.x * (64 / RED3_LANES) + threadIdx.x / RED3_LANES;
+  const uint32_t nglog = (uint32_t)(g.c - 1 - g.glog);
   XYZZ<F> acc = XYZZ<F>::inf();
-  for (int j = nglog - 1; j >= 0; j--) acc = add_full(dbl_xyzz(acc), load_pod(Q + j));
-  for (int j = 0; j < g.glog; j++) acc = dbl_xyzz(acc);
-  acc = add_full(acc, load_pod(Q + nglog));
-  acc = add_full(acc, load_pod(Q + nglog + 1));
-  store_pod(window_out + k, acc);
+  if (k < (uint32_t)g.K && lane < nglog + 2) {
+    acc = load_pod(task_out + (size_t)k * (nglog + 2) + lane);
+    if (lane < nglog)
+      for (uint32_t j = 0; j < lane + (uint32_t)g.glog; j++) acc = dbl_xyzz_inl(acc);
+  }
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (uint32_t s = RED3_LANES / 2; s > 0; s >>= 1) {
+    if (lane < s) sh[threadIdx.x] = add_full_inl(sh[threadIdx.x], sh[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (lane == 0 && k < (uint32_t)g.K) store_pod(window_out + k, sh[threadIdx.x]);
 }
 
 // ---------------------------------------------------------------- device-side setup

@@ -79,10 +79,10 @@ struct zkr_key {
   bool owns_arena = true;
   zkr::ArenaHeader h;
   hipStream_t stream = nullptr;
-  hipStream_t msm_stream[zkr::N_TABLES] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // the five MSMs run concurrently
-  hipStream_t sort_stream = nullptr;  // all digit sorts, back to back (fabric-atomic bound: they only contend with each other)
-  hipEvent_t ev_w = nullptr, ev_h = nullptr, ev_done[zkr::N_TABLES] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipStream_t ntt_stream = nullptr;                // calcH beside the witness sorts
+  hipStream_t red_stream[2] = {nullptr, nullptr};  // reduction chains of the G2 table / of the G1 tables ([1] is ntt_stream)
   hipEvent_t ev_sorted[zkr::N_TABLES] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_w = nullptr, ev_h = nullptr, ev_done[zkr::N_TABLES] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   // workspace
   zkr::Fr *d_wraw = nullptr, *d_w = nullptr, *va = nullptr, *vb = nullptr, *ca = nullptr, *cb = nullptr, *d_h = nullptr;
   uint16_t *dig_w = nullptr, *dig_h = nullptr;  // signed-digit codes of w (shared by A, B1, B2, C) and of h, window-major

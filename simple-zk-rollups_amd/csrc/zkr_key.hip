@@ -105,12 +105,14 @@ int key_alloc_workspace(zkr_key *k) {
   ZKR_HIP_CHECK(hipSetDevice(k->device));
   const ArenaHeader &h = k->h;
   ZKR_HIP_CHECK(hipStreamCreateWithFlags(&k->stream, hipStreamNonBlocking));
+  ZKR_HIP_CHECK(hipStreamCreateWithFlags(&k->ntt_stream, hipStreamNonBlocking));
+  ZKR_HIP_CHECK(hipStreamCreateWithFlags(&k->red_stream[0], hipStreamNonBlocking));
+  if (getenv("ZKR_FOUR_STREAMS")) ZKR_HIP_CHECK(hipStreamCreateWithFlags(&k->red_stream[1], hipStreamNonBlocking));
+  else k->red_stream[1] = k->ntt_stream;  // calcH is long finished when the first G1 table needs its reduction
   for (int t = 0; t < N_TABLES; t++) {
-    if (t < 2) ZKR_HIP_CHECK(hipStreamCreateWithFlags(&k->msm_stream[t], hipStreamNonBlocking));  // X, Y (4 streams in all: HW queue limit)
     ZKR_HIP_CHECK(hipEventCreateWithFlags(&k->ev_done[t], hipEventDisableTiming));
     ZKR_HIP_CHECK(hipEventCreateWithFlags(&k->ev_sorted[t], hipEventDisableTiming));
   }
-  ZKR_HIP_CHECK(hipStreamCreateWithFlags(&k->sort_stream, hipStreamNonBlocking));
   ZKR_HIP_CHECK(hipEventCreateWithFlags(&k->ev_w, hipEventDisableTiming));
   ZKR_HIP_CHECK(hipEventCreateWithFlags(&k->ev_h, hipEventDisableTiming));
   ZKR_HIP_CHECK(hipMalloc(&k->d_wraw, (size_t)h.n * 32));
@@ -360,11 +362,12 @@ void zkr_key_free(zkr_key *k) {
   hipSetDevice(k->device);
   if (k->stream) hipStreamSynchronize(k->stream);
   for (int t = 0; t < N_TABLES; t++) {
-    if (k->msm_stream[t]) { hipStreamSynchronize(k->msm_stream[t]); hipStreamDestroy(k->msm_stream[t]); }
     if (k->ev_done[t]) hipEventDestroy(k->ev_done[t]);
     if (k->ev_sorted[t]) hipEventDestroy(k->ev_sorted[t]);
   }
-  if (k->sort_stream) { hipStreamSynchronize(k->sort_stream); hipStreamDestroy(k->sort_stream); }
+  if (k->red_stream[1] && k->red_stream[1] != k->ntt_stream) { hipStreamSynchronize(k->red_stream[1]); hipStreamDestroy(k->red_stream[1]); }
+  if (k->ntt_stream) { hipStreamSynchronize(k->ntt_stream); hipStreamDestroy(k->ntt_stream); }
+  if (k->red_stream[0]) { hipStreamSynchronize(k->red_stream[0]); hipStreamDestroy(k->red_stream[0]); }
   if (k->ev_w) hipEventDestroy(k->ev_w);
   if (k->ev_h) hipEventDestroy(k->ev_h);
   for (int t = 0; t < N_TABLES; t++) msm_ws_free(k->ws[t]);

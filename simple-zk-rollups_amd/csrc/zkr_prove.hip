@@ -206,20 +206,39 @@ static int msm_sort_enqueue(zkr_key *prof, hipStream_t s, const uint32_t *sidx, 
   return 0;
 }
 
-// bucket accumulation + reduction of one point table over a finished sort (`srt` may belong to another
-// table with the same point set: B1 and B2 share one); results land in ws.h_window
+// bucket accumulation of one point table over a finished sort (`srt` may belong to another table with the
+// same point set: B1 and B2 share one)
 template <class F>
 static int msm_accum_enqueue(zkr_key *prof, hipStream_t s, const Affine<F> *pts, uint32_t n, const MsmPlan &pl, const MsmWorkspace &srt, MsmWorkspace &ws) {
   if (n == 0) return 0;
-  MsmGeom g;
-  g.n = n; g.c = pl.c; g.K = pl.K; g.nbw = pl.nbw; g.big_thresh = pl.big_thresh; g.glog = pl.glog;
   int sp = prof_begin(prof, s, MsmCfg<F>::ACC_STAGE);
   msm_accum_kernel<F, MsmCfg<F>::ACC_W><<<(pl.nb + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, s>>>(pts, srt.offsets, srt.entries, pl.nb, srt.counts,
                                                                                                       srt.order, (XYZZ<F> *)ws.buckets);
   prof_end(prof, s, sp);
-  sp = prof_begin(prof, s, "msm_big");
+  ZKR_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// oversized buckets (digit +-1 of 0/1-heavy witnesses): needs only the sort, so it runs beside the table's accumulation
+template <class F>
+static int msm_big_enqueue(zkr_key *prof, hipStream_t s, const Affine<F> *pts, uint32_t n, const MsmPlan &pl, const MsmWorkspace &srt, MsmWorkspace &ws) {
+  if (n == 0) return 0;
+  int sp = prof_begin(prof, s, "msm_big");
   msm_big_kernel<F, MsmCfg<F>::RED_W><<<BIG_SLOTS * BIG_SPLIT, MSM_THREADS, MSM_THREADS * sizeof(XYZZ<F>), s>>>(pts, srt.offsets, srt.entries, srt.big_list, srt.big_count,
                                                                                                              BIG_CAP, (XYZZ<F> *)ws.big_partials);
+  prof_end(prof, s, sp);
+  ZKR_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// big-bucket partial sums -> buckets, bucket reduction, window sums -> ws.h_window: short launches of few,
+// long-running wavefronts (raised wave priority), meant to run beside the next table's accumulation
+template <class F>
+static int msm_reduce_enqueue(zkr_key *prof, hipStream_t s, uint32_t n, const MsmPlan &pl, const MsmWorkspace &srt, MsmWorkspace &ws) {
+  if (n == 0) return 0;
+  MsmGeom g;
+  g.n = n; g.c = pl.c; g.K = pl.K; g.nbw = pl.nbw; g.big_thresh = pl.big_thresh; g.glog = pl.glog;
+  int sp = prof_begin(prof, s, "msm_big");
   msm_big_finish_kernel<F, MsmCfg<F>::RED_W><<<BIG_CAP / 64, 64, 0, s>>>((const XYZZ<F> *)ws.big_partials, srt.big_list, srt.big_count, BIG_CAP, (XYZZ<F> *)ws.buckets);
   prof_end(prof, s, sp);
   sp = prof_begin(prof, s, "msm_reduce");
@@ -227,7 +246,7 @@ static int msm_accum_enqueue(zkr_key *prof, hipStream_t s, const Affine<F> *pts,
   uint32_t ntask = (uint32_t)(pl.c - 1 - pl.glog) + 2;
   msm_reduce1_kernel<F, MsmCfg<F>::RED_W><<<(ngroups + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, s>>>((const XYZZ<F> *)ws.buckets, g, (XYZZ<F> *)ws.group_out);
   msm_reduce2_kernel<F, MsmCfg<F>::RED_W><<<(unsigned)pl.K * ntask, MSM_THREADS, MSM_THREADS * sizeof(XYZZ<F>), s>>>((const XYZZ<F> *)ws.group_out, g, (XYZZ<F> *)ws.task_out);
-  msm_reduce3_kernel<F, MsmCfg<F>::RED_W><<<(pl.K + 63) / 64, 64, 0, s>>>((const XYZZ<F> *)ws.task_out, g, (XYZZ<F> *)ws.window_out);
+  msm_reduce3_kernel<F, MsmCfg<F>::RED_W><<<((unsigned)pl.K * RED3_LANES + 63) / 64, 64, 0, s>>>((const XYZZ<F> *)ws.task_out, g, (XYZZ<F> *)ws.window_out);
   prof_end(prof, s, sp);
   ZKR_HIP_CHECK(hipMemcpyAsync(ws.h_window, ws.window_out, (size_t)pl.K * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, s));
   ZKR_HIP_CHECK(hipGetLastError());
@@ -242,7 +261,9 @@ static int msm_enqueue(zkr_key *prof, hipStream_t s, const Affine<F> *pts, const
   int rc = msm_digits_enqueue(prof, s, scalars, n_scalars, pl, ws.own_dig);
   if (rc) return rc;
   if ((rc = msm_sort_enqueue(prof, s, sidx, ws.own_dig, n_scalars, n, pl, ws))) return rc;
-  return msm_accum_enqueue<F>(prof, s, pts, n, pl, ws, ws);
+  if ((rc = msm_big_enqueue<F>(prof, s, pts, n, pl, ws, ws))) return rc;
+  if ((rc = msm_accum_enqueue<F>(prof, s, pts, n, pl, ws, ws))) return rc;
+  return msm_reduce_enqueue<F>(prof, s, n, pl, ws, ws);
 }
 
 // Horner over the K window sums (host): sum_k 2^(ck) W_k
@@ -298,55 +319,69 @@ static int prove_on_device(zkr_key *k, const Fr *d_wsrc, const uint8_t *r32, con
   int sp = prof_begin(k, s, "ingest");
   ingest_kernel<<<(h.n + 255) / 256, 256, 0, s>>>(d_wsrc, k->d_w, h.n);
   prof_end(k, s, sp);
-  // Schedule on FOUR streams (HIP multiplexes streams onto 4 hardware queues by default; more streams than
-  // queues silently serialise): main = calcH, `ss` = all digit sorts back to back (fabric-atomic bound, they
-  // only contend with each other), X and Y = bucket accumulation + reduction.  The VALU-bound accumulation of
-  // one table overlaps the sort of the next and the latency-bound reduction running on the other stream.
-  // B1 and B2 keep the same signals, so one sort serves both (h.share_b).
+  // Schedule on three streams (HIP multiplexes streams onto a few hardware queues; streams sharing one serialise):
+  //   s  : the heavy chain -- digit codes, then per table its digit sort and its bucket accumulation; B2 first
+  //        (its reduction chain is the longest), B1 reuses that sort (h.share_b), H last (needs h);
+  //   sn : QAP rows + the six NTTs (calcH), then the oversized-bucket and reduction chains of the G1 tables;
+  //   rx : oversized-bucket and reduction chain of the G2 table.
+  // Every accumulation saturates the VALUs on its own.  The reduction chains are few long-running wavefronts
+  // (raised wave priority) that run under the following accumulations and get the machine mostly to themselves
+  // while the next table is being sorted; the oversized buckets need only the sort and run beside the accumulation.
   static const bool serial = getenv("ZKR_SERIAL") != nullptr;  // profiling aid: one stream, isolated kernel durations
-  hipStream_t ss = serial ? s : k->sort_stream;
-  hipStream_t sx = serial ? s : k->msm_stream[0], sy = serial ? s : k->msm_stream[1];
-  ZKR_HIP_CHECK(hipEventRecord(k->ev_w, s));
-  if (!serial) ZKR_HIP_CHECK(hipStreamWaitEvent(ss, k->ev_w, 0));
+  hipStream_t sn = serial ? s : k->ntt_stream;
+  hipStream_t rx = serial ? s : k->red_stream[0], ry = serial ? s : k->red_stream[1];
   int rc;
-  if ((rc = calc_h_device(k, s))) return rc;  // first in its queue: runs beside the witness sorts
-  ZKR_HIP_CHECK(hipEventRecord(k->ev_h, s));
+  ZKR_HIP_CHECK(hipEventRecord(k->ev_w, s));
+  if (!serial) ZKR_HIP_CHECK(hipStreamWaitEvent(sn, k->ev_w, 0));
+  if ((rc = calc_h_device(k, sn))) return rc;
+  ZKR_HIP_CHECK(hipEventRecord(k->ev_h, sn));
   const uint16_t *dig[N_TABLES] = {k->dig_w, k->dig_w, k->dig_w, k->dig_w, k->dig_h};
   const size_t dig_stride[N_TABLES] = {h.n, h.n, h.n, h.n, h.m};
-  if ((rc = msm_digits_enqueue(k, ss, k->d_w, h.n, k->plan[T_A], k->dig_w))) return rc;
   const bool share_b = h.share_b != 0 && h.npts[T_B1] == h.npts[T_B2];
   int sort_src[N_TABLES] = {T_A, T_B1, share_b ? T_B1 : T_B2, T_C, T_H};
   auto sort_table = [&](int t) -> int {
-    int rc = msm_sort_enqueue(k, ss, (const uint32_t *)(ar + h.off_sidx[t]), dig[t], dig_stride[t], h.npts[t], k->plan[t], k->ws[t]);
+    int rc = msm_sort_enqueue(k, s, (const uint32_t *)(ar + h.off_sidx[t]), dig[t], dig_stride[t], h.npts[t], k->plan[t], k->ws[t]);
     if (rc) return rc;
-    if (!serial) ZKR_HIP_CHECK(hipEventRecord(k->ev_sorted[t], ss));
+    if (!serial) ZKR_HIP_CHECK(hipEventRecord(k->ev_sorted[t], s));
     return 0;
   };
-  auto accum_table = [&](int t, hipStream_t ms) -> int {
-    if (!serial) ZKR_HIP_CHECK(hipStreamWaitEvent(ms, k->ev_sorted[sort_src[t]], 0));
+  auto accum_table = [&](int t, hipStream_t rs) -> int {
+    const MsmWorkspace &srt = k->ws[sort_src[t]];
+    const void *pts = ar + h.off_pts[t];
     int rc;
-    if (t == T_B2) rc = msm_accum_enqueue<Fq2>(k, ms, (const G2Affine *)(ar + h.off_pts[t]), h.npts[t], k->plan[t], k->ws[sort_src[t]], k->ws[t]);
-    else rc = msm_accum_enqueue<Fq>(k, ms, (const G1Affine *)(ar + h.off_pts[t]), h.npts[t], k->plan[t], k->ws[sort_src[t]], k->ws[t]);
+    if (!serial) ZKR_HIP_CHECK(hipStreamWaitEvent(rs, k->ev_sorted[sort_src[t]], 0));
+    if (t == T_B2) rc = msm_big_enqueue<Fq2>(k, rs, (const G2Affine *)pts, h.npts[t], k->plan[t], srt, k->ws[t]);
+    else rc = msm_big_enqueue<Fq>(k, rs, (const G1Affine *)pts, h.npts[t], k->plan[t], srt, k->ws[t]);
+    if (rc) return rc;
+    if (t == T_B2) rc = msm_accum_enqueue<Fq2>(k, s, (const G2Affine *)pts, h.npts[t], k->plan[t], srt, k->ws[t]);
+    else rc = msm_accum_enqueue<Fq>(k, s, (const G1Affine *)pts, h.npts[t], k->plan[t], srt, k->ws[t]);
+    if (rc) return rc;
+    if (!serial) {
+      ZKR_HIP_CHECK(hipEventRecord(k->ev_done[t], s));
+      ZKR_HIP_CHECK(hipStreamWaitEvent(rs, k->ev_done[t], 0));
+    }
+    if (t == T_B2) rc = msm_reduce_enqueue<Fq2>(k, rs, h.npts[t], k->plan[t], srt, k->ws[t]);
+    else rc = msm_reduce_enqueue<Fq>(k, rs, h.npts[t], k->plan[t], srt, k->ws[t]);
     return rc;
   };
-  // sort order = order in which accumulations should start: B (G2 is the longest), A, H (h is ready by then), C
+  if ((rc = msm_digits_enqueue(k, s, k->d_w, h.n, k->plan[T_A], k->dig_w))) return rc;
   if ((rc = sort_table(T_B1))) return rc;
   if (!share_b && (rc = sort_table(T_B2))) return rc;
-  if ((rc = accum_table(T_B2, sx))) return rc;
-  if ((rc = accum_table(T_B1, sy))) return rc;
+  if ((rc = accum_table(T_B2, rx))) return rc;
+  if ((rc = accum_table(T_B1, ry))) return rc;
   if ((rc = sort_table(T_A))) return rc;
-  if ((rc = accum_table(T_A, sy))) return rc;
-  if (!serial) ZKR_HIP_CHECK(hipStreamWaitEvent(ss, k->ev_h, 0));
-  if ((rc = msm_digits_enqueue(k, ss, k->d_h, h.m, k->plan[T_H], k->dig_h))) return rc;
-  if ((rc = sort_table(T_H))) return rc;
-  if ((rc = accum_table(T_H, sx))) return rc;
+  if ((rc = accum_table(T_A, ry))) return rc;
   if ((rc = sort_table(T_C))) return rc;
-  if ((rc = accum_table(T_C, sy))) return rc;
+  if ((rc = accum_table(T_C, ry))) return rc;
+  if (!serial) ZKR_HIP_CHECK(hipStreamWaitEvent(s, k->ev_h, 0));
+  if ((rc = msm_digits_enqueue(k, s, k->d_h, h.m, k->plan[T_H], k->dig_h))) return rc;
+  if ((rc = sort_table(T_H))) return rc;
+  if ((rc = accum_table(T_H, ry))) return rc;
   if (!serial) {
-    ZKR_HIP_CHECK(hipEventRecord(k->ev_done[0], sx));
-    ZKR_HIP_CHECK(hipEventRecord(k->ev_done[1], sy));
-    ZKR_HIP_CHECK(hipStreamWaitEvent(s, k->ev_done[0], 0));
-    ZKR_HIP_CHECK(hipStreamWaitEvent(s, k->ev_done[1], 0));
+    ZKR_HIP_CHECK(hipEventRecord(k->ev_w, rx));  // ev_w / ev_h are free again: the two join events
+    ZKR_HIP_CHECK(hipEventRecord(k->ev_h, ry));
+    ZKR_HIP_CHECK(hipStreamWaitEvent(s, k->ev_w, 0));
+    ZKR_HIP_CHECK(hipStreamWaitEvent(s, k->ev_h, 0));
   }
   prof_end(k, s, tot);
   ZKR_HIP_CHECK(hipStreamSynchronize(s));
