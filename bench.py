@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--log-m", type=int, default=20)
     ap.add_argument("--cpu-sample-log-m", type=int, default=17)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true", help="synchronous proofs, one at a time (latency)")
     args = ap.parse_args()
 
     import torch
@@ -84,20 +85,25 @@ def main():
     setup_s = time.time() - t_setup
     stream = torch.cuda.current_stream().cuda_stream
 
-    def step(i):
-        return key.prove_device(wits[i % n_wit].data_ptr(), r=1000003 + i, s=2000003 + i, stream=stream)
+    # The proofs of a rollup batch are independent: they are pipelined two deep (zkr_prove_submit /
+    # zkr_prove_collect), so the GPU work of proof i+1 is enqueued before the host assembles proof i.
+    # --no-pipeline times fully synchronous proofs (single-proof latency).
+    def run(first, count):
+        if args.no_pipeline:
+            return [key.prove_device(wits[i % n_wit].data_ptr(), r=1000003 + i, s=2000003 + i, stream=stream) for i in range(first, first + count)]
+        idx = range(first, first + count)
+        return key.prove_batch_device([wits[i % n_wit].data_ptr() for i in idx], [1000003 + i for i in idx], [2000003 + i for i in idx], stream)
 
-    for i in range(args.warmup):
-        step(i)
+    run(0, args.warmup)
     key.prof_enable(True)
     key.prof_reset()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
+    proofs = run(0, args.steps)
     torch.cuda.synchronize()
+    assert len(proofs) == args.steps
     if dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0

@@ -75,6 +75,15 @@ int zkr_prove(zkr_key *key, const void *witness_std, size_t witness_len, const u
 int zkr_prove_device(zkr_key *key, const void *d_witness_std, const uint8_t *r32, const uint8_t *s32,
                      uint8_t proof_out[256], void *stream);
 
+/* Pipelined form for batches of independent proofs (rollup batch, BASELINE config 4): zkr_prove_submit enqueues
+ * the whole GPU side of one proof and returns at once with a ticket; zkr_prove_collect waits for that proof and
+ * does the host assembly.  A key holds two proof workspaces, so the GPU work of proof i+1 (submitted before
+ * collecting proof i) covers proof i's reduction tail and host assembly.  The witness buffer must stay untouched
+ * until the ticket is collected.  Submitting with both workspaces in flight fails with ZKR_ERR_ARG.
+ * zkr_prove_device(...) == submit + collect. */
+int zkr_prove_submit(zkr_key *key, const void *d_witness_std, const uint8_t *r32, const uint8_t *s32, void *stream, int *ticket);
+int zkr_prove_collect(zkr_key *key, int ticket, uint8_t proof_out[256]);
+
 /* ---- stage hooks (tests, profiling) ----------------------------------------------------------- */
 /* In-place NTT of n = 2^logn standard-form elements in host memory; natural order in and out. */
 int zkr_ntt(void *data_std, unsigned logn, int inverse, int device);

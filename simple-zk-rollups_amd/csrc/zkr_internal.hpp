@@ -72,6 +72,26 @@ struct MsmPlan {
 
 }  // namespace zkr
 
+namespace zkr {
+// Everything one proof in flight owns: witness + calcH vectors, digit codes, the five MSM workspaces, its
+// events and timing spans.  A key has PROOF_SLOTS of them so that the GPU work of the next proof is enqueued
+// (zkr_prove_submit) while the host still assembles the previous one (zkr_prove_collect).
+constexpr int PROOF_SLOTS = 2;
+struct ProofSlot {
+  Fr *d_wraw = nullptr, *d_w = nullptr, *va = nullptr, *vb = nullptr, *ca = nullptr, *cb = nullptr, *d_h = nullptr;
+  uint16_t *dig_w = nullptr, *dig_h = nullptr;  // signed-digit codes of w (shared by A, B1, B2, C) and of h, window-major
+  MsmWorkspace ws[N_TABLES];
+  hipEvent_t ev_w = nullptr, ev_h = nullptr, ev_fin = nullptr;
+  hipEvent_t ev_done[N_TABLES] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_sorted[N_TABLES] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  uint8_t rb[32], sb[32];  // blinding scalars of the proof in flight
+  bool busy = false;
+  std::vector<ProfSpan> spans;
+  std::vector<hipEvent_t> event_pool;
+  size_t event_next = 0;
+};
+}  // namespace zkr
+
 struct zkr_key {
   int device = 0;
   unsigned char *arena = nullptr;
@@ -79,21 +99,14 @@ struct zkr_key {
   bool owns_arena = true;
   zkr::ArenaHeader h;
   hipStream_t stream = nullptr;
-  hipStream_t ntt_stream = nullptr;                // calcH beside the witness sorts
+  hipStream_t ntt_stream = nullptr;                // calcH beside the witness sorts, then the G1 reduction chains
   hipStream_t red_stream[2] = {nullptr, nullptr};  // reduction chains of the G2 table / of the G1 tables ([1] is ntt_stream)
-  hipEvent_t ev_sorted[zkr::N_TABLES] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-  hipEvent_t ev_w = nullptr, ev_h = nullptr, ev_done[zkr::N_TABLES] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-  // workspace
-  zkr::Fr *d_wraw = nullptr, *d_w = nullptr, *va = nullptr, *vb = nullptr, *ca = nullptr, *cb = nullptr, *d_h = nullptr;
-  uint16_t *dig_w = nullptr, *dig_h = nullptr;  // signed-digit codes of w (shared by A, B1, B2, C) and of h, window-major
-  zkr::MsmWorkspace ws[zkr::N_TABLES];  // one per table so the five MSMs can be enqueued back to back
+  zkr::ProofSlot slot[zkr::PROOF_SLOTS];
+  int next_slot = 0;
   zkr::MsmPlan plan[zkr::N_TABLES];
   // profiling
   bool prof_on = false;
   std::vector<zkr::ProfStage> stages;
-  std::vector<zkr::ProfSpan> spans;
-  std::vector<hipEvent_t> event_pool;
-  size_t event_next = 0;
 };
 
 namespace zkr {
@@ -105,10 +118,14 @@ int key_build(int device, uint32_t n, uint32_t p, uint32_t m, const std::vector<
 int key_alloc_workspace(zkr_key *k);
 int fixed_base_points(int device, bool g2, const uint8_t *scalars_std, size_t n, void **d_out);  // device array of affine Montgomery points
 // zkr_prove.hip
-int prof_begin(zkr_key *k, hipStream_t s, const char *stage);
-void prof_end(zkr_key *k, hipStream_t s, int span);
-int prof_collect(zkr_key *k);
+struct Prof {  // where a launch helper records its timing spans (null key: stage hooks, no timing)
+  zkr_key *k;
+  ProofSlot *sl;
+};
+int prof_begin(Prof pf, hipStream_t s, const char *stage);
+void prof_end(Prof pf, hipStream_t s, int span);
+int prof_collect(zkr_key *k, ProofSlot &sl);
 int run_ntt(hipStream_t s, const Fr *in0, const Fr *in1, Fr *out, const Fr *tw, const Fr *twl, int tlog, int L, bool dif, bool inverse, int pre);
-int calc_h_device(zkr_key *k, hipStream_t s);  // d_w -> d_h (bit-reversed)
+int calc_h_device(zkr_key *k, ProofSlot &sl, hipStream_t s);  // sl.d_w -> sl.d_h (bit-reversed)
 MsmPlan msm_plan(size_t n_scalars, size_t n_points);
 }  // namespace zkr

@@ -109,23 +109,26 @@ int key_alloc_workspace(zkr_key *k) {
   ZKR_HIP_CHECK(hipStreamCreateWithFlags(&k->red_stream[0], hipStreamNonBlocking));
   if (getenv("ZKR_FOUR_STREAMS")) ZKR_HIP_CHECK(hipStreamCreateWithFlags(&k->red_stream[1], hipStreamNonBlocking));
   else k->red_stream[1] = k->ntt_stream;  // calcH is long finished when the first G1 table needs its reduction
-  for (int t = 0; t < N_TABLES; t++) {
-    ZKR_HIP_CHECK(hipEventCreateWithFlags(&k->ev_done[t], hipEventDisableTiming));
-    ZKR_HIP_CHECK(hipEventCreateWithFlags(&k->ev_sorted[t], hipEventDisableTiming));
+  for (int t = 0; t < N_TABLES; t++) k->plan[t] = msm_plan(t == T_H ? h.m : h.n, h.npts[t]);
+  for (ProofSlot &sl : k->slot) {
+    for (int t = 0; t < N_TABLES; t++) {
+      ZKR_HIP_CHECK(hipEventCreateWithFlags(&sl.ev_done[t], hipEventDisableTiming));
+      ZKR_HIP_CHECK(hipEventCreateWithFlags(&sl.ev_sorted[t], hipEventDisableTiming));
+    }
+    ZKR_HIP_CHECK(hipEventCreateWithFlags(&sl.ev_w, hipEventDisableTiming));
+    ZKR_HIP_CHECK(hipEventCreateWithFlags(&sl.ev_h, hipEventDisableTiming));
+    ZKR_HIP_CHECK(hipEventCreateWithFlags(&sl.ev_fin, hipEventDisableTiming));
+    ZKR_HIP_CHECK(hipMalloc(&sl.d_wraw, (size_t)h.n * 32));
+    ZKR_HIP_CHECK(hipMalloc(&sl.d_w, (size_t)h.n * 32));
+    Fr **vecs[5] = {&sl.va, &sl.vb, &sl.ca, &sl.cb, &sl.d_h};
+    for (auto v : vecs) ZKR_HIP_CHECK(hipMalloc(v, (size_t)h.m * 32));
+    for (int t = 0; t < N_TABLES; t++) {
+      int rc = alloc_msm_ws(sl.ws[t], h.npts[t], k->plan[t], t == T_B2 ? sizeof(G2XYZZ) : sizeof(G1XYZZ));
+      if (rc) return rc;
+    }
+    ZKR_HIP_CHECK(hipMalloc(&sl.dig_w, (size_t)k->plan[T_A].K * h.n * 2 + 2));
+    ZKR_HIP_CHECK(hipMalloc(&sl.dig_h, (size_t)k->plan[T_H].K * h.m * 2 + 2));
   }
-  ZKR_HIP_CHECK(hipEventCreateWithFlags(&k->ev_w, hipEventDisableTiming));
-  ZKR_HIP_CHECK(hipEventCreateWithFlags(&k->ev_h, hipEventDisableTiming));
-  ZKR_HIP_CHECK(hipMalloc(&k->d_wraw, (size_t)h.n * 32));
-  ZKR_HIP_CHECK(hipMalloc(&k->d_w, (size_t)h.n * 32));
-  Fr **vecs[5] = {&k->va, &k->vb, &k->ca, &k->cb, &k->d_h};
-  for (auto v : vecs) ZKR_HIP_CHECK(hipMalloc(v, (size_t)h.m * 32));
-  for (int t = 0; t < N_TABLES; t++) {
-    k->plan[t] = msm_plan(t == T_H ? h.m : h.n, h.npts[t]);
-    int rc = alloc_msm_ws(k->ws[t], h.npts[t], k->plan[t], t == T_B2 ? sizeof(G2XYZZ) : sizeof(G1XYZZ));
-    if (rc) return rc;
-  }
-  ZKR_HIP_CHECK(hipMalloc(&k->dig_w, (size_t)k->plan[T_A].K * h.n * 2 + 2));
-  ZKR_HIP_CHECK(hipMalloc(&k->dig_h, (size_t)k->plan[T_H].K * h.m * 2 + 2));
   return 0;
 }
 
@@ -360,21 +363,24 @@ int zkr_key_load_websnark(const void *pk_bin, size_t pk_len, int device, zkr_key
 void zkr_key_free(zkr_key *k) {
   if (!k) return;
   hipSetDevice(k->device);
-  if (k->stream) hipStreamSynchronize(k->stream);
-  for (int t = 0; t < N_TABLES; t++) {
-    if (k->ev_done[t]) hipEventDestroy(k->ev_done[t]);
-    if (k->ev_sorted[t]) hipEventDestroy(k->ev_sorted[t]);
+  hipStream_t streams[4] = {k->stream, k->red_stream[0], k->red_stream[1] != k->ntt_stream ? k->red_stream[1] : nullptr, k->ntt_stream};
+  for (hipStream_t st : streams)
+    if (st) hipStreamSynchronize(st);
+  for (ProofSlot &sl : k->slot) {
+    for (int t = 0; t < N_TABLES; t++) {
+      if (sl.ev_done[t]) hipEventDestroy(sl.ev_done[t]);
+      if (sl.ev_sorted[t]) hipEventDestroy(sl.ev_sorted[t]);
+      msm_ws_free(sl.ws[t]);
+    }
+    if (sl.ev_w) hipEventDestroy(sl.ev_w);
+    if (sl.ev_h) hipEventDestroy(sl.ev_h);
+    if (sl.ev_fin) hipEventDestroy(sl.ev_fin);
+    hipFree(sl.dig_w); hipFree(sl.dig_h);
+    hipFree(sl.d_wraw); hipFree(sl.d_w); hipFree(sl.va); hipFree(sl.vb); hipFree(sl.ca); hipFree(sl.cb); hipFree(sl.d_h);
+    for (auto e : sl.event_pool) hipEventDestroy(e);
   }
-  if (k->red_stream[1] && k->red_stream[1] != k->ntt_stream) { hipStreamSynchronize(k->red_stream[1]); hipStreamDestroy(k->red_stream[1]); }
-  if (k->ntt_stream) { hipStreamSynchronize(k->ntt_stream); hipStreamDestroy(k->ntt_stream); }
-  if (k->red_stream[0]) { hipStreamSynchronize(k->red_stream[0]); hipStreamDestroy(k->red_stream[0]); }
-  if (k->ev_w) hipEventDestroy(k->ev_w);
-  if (k->ev_h) hipEventDestroy(k->ev_h);
-  for (int t = 0; t < N_TABLES; t++) msm_ws_free(k->ws[t]);
-  hipFree(k->dig_w); hipFree(k->dig_h);
-  hipFree(k->d_wraw); hipFree(k->d_w); hipFree(k->va); hipFree(k->vb); hipFree(k->ca); hipFree(k->cb); hipFree(k->d_h);
-  for (auto e : k->event_pool) hipEventDestroy(e);
-  if (k->stream) hipStreamDestroy(k->stream);
+  for (hipStream_t st : streams)
+    if (st) hipStreamDestroy(st);
   if (k->owns_arena) hipFree(k->arena);
   delete k;
 }

@@ -26,41 +26,40 @@ static int stage_index(const char *name) {
     if (!strcmp(STAGES[i], name)) return i;
   return -1;
 }
-static hipEvent_t next_event(zkr_key *k) {
-  if (k->event_next == k->event_pool.size()) {
+static hipEvent_t next_event(ProofSlot &sl) {
+  if (sl.event_next == sl.event_pool.size()) {
     hipEvent_t e;
     hipEventCreate(&e);
-    k->event_pool.push_back(e);
+    sl.event_pool.push_back(e);
   }
-  return k->event_pool[k->event_next++];
+  return sl.event_pool[sl.event_next++];
 }
-int prof_begin(zkr_key *k, hipStream_t s, const char *stage) {
-  if (!k || !k->prof_on) return -1;
+int prof_begin(Prof pf, hipStream_t s, const char *stage) {
+  if (!pf.k || !pf.sl || !pf.k->prof_on) return -1;
   ProfSpan sp;
   sp.stage = stage_index(stage);
-  sp.e0 = next_event(k);
-  sp.e1 = next_event(k);
+  sp.e0 = next_event(*pf.sl);
+  sp.e1 = next_event(*pf.sl);
   hipEventRecord(sp.e0, s);
-  k->spans.push_back(sp);
-  return (int)k->spans.size() - 1;
+  pf.sl->spans.push_back(sp);
+  return (int)pf.sl->spans.size() - 1;
 }
-void prof_end(zkr_key *k, hipStream_t s, int span) {
+void prof_end(Prof pf, hipStream_t s, int span) {
   if (span < 0) return;
-  hipEventRecord(k->spans[span].e1, s);
+  hipEventRecord(pf.sl->spans[span].e1, s);
 }
-int prof_collect(zkr_key *k) {  // call after the stream is synchronised
-  if (!k->prof_on) return 0;
+int prof_collect(zkr_key *k, ProofSlot &sl) {  // call after the slot's work has completed
   if (k->stages.empty())
     for (auto nm : STAGES) { ProfStage st; st.name = nm; k->stages.push_back(st); }
-  for (auto &sp : k->spans) {
+  for (auto &sp : sl.spans) {
     float ms = 0;
     if (hipEventElapsedTime(&ms, sp.e0, sp.e1) == hipSuccess && sp.stage >= 0) {
       k->stages[sp.stage].ms += ms;
       k->stages[sp.stage].launches++;
     }
   }
-  k->spans.clear();
-  k->event_next = 0;
+  sl.spans.clear();
+  sl.event_next = 0;
   return 0;
 }
 
@@ -120,28 +119,29 @@ static Fr fr_from_u64(uint64_t x) {
 }
 
 // d_w (std, reduced) -> d_h (std, bit-reversed order).  See DESIGN.md "calcH on the GPU".
-int calc_h_device(zkr_key *k, hipStream_t s) {
+int calc_h_device(zkr_key *k, ProofSlot &sl, hipStream_t s) {
+  const Prof pf{k, &sl};
   const ArenaHeader &h = k->h;
   const unsigned char *ar = k->arena;
   const Fr *tw = (const Fr *)(ar + h.off_tw), *twl = (const Fr *)(ar + h.off_twl);
   int L = (int)h.logm, tlog = (int)h.tlog;
   uint32_t m = h.m;
-  int sp = prof_begin(k, s, "spmv");
-  Fr *evals[2] = {k->va, k->vb};
+  int sp = prof_begin(pf, s, "spmv");
+  Fr *evals[2] = {sl.va, sl.vb};
   for (int i = 0; i < 2; i++)
     spmv_kernel<<<(m + 255) / 256, 256, 0, s>>>((const uint32_t *)(ar + h.off_rowptr[i]), (const uint32_t *)(ar + h.off_col[i]),
-                                               (const Fr *)(ar + h.off_coef[i]), k->d_w, evals[i], m);
-  prof_end(k, s, sp);
-  sp = prof_begin(k, s, "ntt");
+                                               (const Fr *)(ar + h.off_coef[i]), sl.d_w, evals[i], m);
+  prof_end(pf, s, sp);
+  sp = prof_begin(pf, s, "ntt");
   int rc;
   // coefficients (x m, bit-reversed), then evaluations on the coset g*w^c (x m, natural)
-  if ((rc = run_ntt(s, k->va, nullptr, k->ca, tw, twl, tlog, L, true, true, PRE_NONE))) return rc;
-  if ((rc = run_ntt(s, k->vb, nullptr, k->cb, tw, twl, tlog, L, true, true, PRE_NONE))) return rc;
-  if ((rc = run_ntt(s, k->ca, nullptr, k->ca, tw, twl, tlog, L, false, false, PRE_COSET))) return rc;
-  if ((rc = run_ntt(s, k->cb, nullptr, k->cb, tw, twl, tlog, L, false, false, PRE_COSET))) return rc;
+  if ((rc = run_ntt(s, sl.va, nullptr, sl.ca, tw, twl, tlog, L, true, true, PRE_NONE))) return rc;
+  if ((rc = run_ntt(s, sl.vb, nullptr, sl.cb, tw, twl, tlog, L, true, true, PRE_NONE))) return rc;
+  if ((rc = run_ntt(s, sl.ca, nullptr, sl.ca, tw, twl, tlog, L, false, false, PRE_COSET))) return rc;
+  if ((rc = run_ntt(s, sl.cb, nullptr, sl.cb, tw, twl, tlog, L, false, false, PRE_COSET))) return rc;
   // D' = iNTT(A(gw^c).B(gw^c)) and S' = iNTT(a.b), both unscaled and bit-reversed
-  if ((rc = run_ntt(s, k->ca, k->cb, k->ca, tw, twl, tlog, L, true, true, PRE_MUL))) return rc;
-  if ((rc = run_ntt(s, k->va, k->vb, k->va, tw, twl, tlog, L, true, true, PRE_MUL))) return rc;
+  if ((rc = run_ntt(s, sl.ca, sl.cb, sl.ca, tw, twl, tlog, L, true, true, PRE_MUL))) return rc;
+  if ((rc = run_ntt(s, sl.va, sl.vb, sl.va, tw, twl, tlog, L, true, true, PRE_MUL))) return rc;
   // constants: S' = m S / R, D' = m^3 D g^i / R  ->  h = S'*R^2/(2m) (*1/R)  -  D' g^-i * R^2/(2 m^3) (*1/R)
   Fr r2 = Fr::r2();
   Fr minv = inv(to_mont(fr_from_u64(m)));        // Montgomery(1/m)
@@ -150,8 +150,8 @@ int calc_h_device(zkr_key *k, hipStream_t s) {
   // r2 is the integer R^2 mod r = Montgomery(R).  mul(r2, half) = Montgomery(R/2); times minv = Montgomery(R/(2m)).
   // We need the plain integer R^2/(2m) = Montgomery(R/(2m)) exactly, so c1v is already the constant to pass.
   Fr c2v = mul(mul(c1v, minv), minv);            // Montgomery(R/(2m^3)) = integer R^2/(2m^3)
-  combine_h_kernel<<<(m + 255) / 256, 256, 0, s>>>(k->va, k->ca, k->d_h, tw, tlog, L, c1v, c2v);
-  prof_end(k, s, sp);
+  combine_h_kernel<<<(m + 255) / 256, 256, 0, s>>>(sl.va, sl.ca, sl.d_h, tw, tlog, L, c1v, c2v);
+  prof_end(pf, s, sp);
   ZKR_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -162,11 +162,11 @@ template <> struct MsmCfg<Fq> { static constexpr int ACC_W = 4, RED_W = 2; stati
 template <> struct MsmCfg<Fq2> { static constexpr int ACC_W = 2, RED_W = 1; static constexpr const char *ACC_STAGE = "msm_accum_g2"; };
 
 // signed-digit codes of one scalar vector (window-major u16), shared by every table over those scalars
-static int msm_digits_enqueue(zkr_key *prof, hipStream_t s, const Fr *scalars, uint32_t n, const MsmPlan &pl, uint16_t *dig) {
+static int msm_digits_enqueue(Prof pf, hipStream_t s, const Fr *scalars, uint32_t n, const MsmPlan &pl, uint16_t *dig) {
   if (n == 0) return 0;
-  int sp = prof_begin(prof, s, "msm_sort");
+  int sp = prof_begin(pf, s, "msm_sort");
   msm_digits_kernel<<<(n + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, s>>>(scalars, n, pl.c, pl.K, (size_t)n, dig);
-  prof_end(prof, s, sp);
+  prof_end(pf, s, sp);
   ZKR_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -183,11 +183,11 @@ static int sort_lds_opt_in() {
 }
 
 // digit sort of one table: LDS histogram per (window, chunk) -> scans -> LDS-cursor scatter
-static int msm_sort_enqueue(zkr_key *prof, hipStream_t s, const uint32_t *sidx, const uint16_t *dig, size_t dig_stride, uint32_t n, const MsmPlan &pl, MsmWorkspace &ws) {
+static int msm_sort_enqueue(Prof pf, hipStream_t s, const uint32_t *sidx, const uint16_t *dig, size_t dig_stride, uint32_t n, const MsmPlan &pl, MsmWorkspace &ws) {
   if (n == 0) return 0;
   int rc = sort_lds_opt_in();
   if (rc) return rc;
-  int sp = prof_begin(prof, s, "msm_sort");
+  int sp = prof_begin(pf, s, "msm_sort");
   ZKR_HIP_CHECK(hipMemsetAsync(ws.big_count, 0, 8, s));
   ZKR_HIP_CHECK(hipMemsetAsync(ws.size_hist, 0, 2 * SIZE_BINS * 4, s));
   const unsigned sort_grid = (unsigned)pl.K * pl.J;
@@ -201,7 +201,7 @@ static int msm_sort_enqueue(zkr_key *prof, hipStream_t s, const uint32_t *sidx, 
                                                             ws.big_list, ws.big_count, BIG_CAP, ws.size_hist);
   msm_order_kernel<<<scan_blocks, SCAN_THREADS, 0, s>>>(ws.counts, pl.nb, ws.size_hist, ws.size_hist + SIZE_BINS, ws.order);
   msm_scatter_kernel<<<sort_grid, SORT_THREADS, lds, s>>>(dig, dig_stride, sidx, n, pl.K, pl.nbw, pl.J, pl.chunk, ws.chunk_cnt, ws.offsets, ws.entries);
-  prof_end(prof, s, sp);
+  prof_end(pf, s, sp);
   ZKR_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -209,24 +209,24 @@ static int msm_sort_enqueue(zkr_key *prof, hipStream_t s, const uint32_t *sidx, 
 // bucket accumulation of one point table over a finished sort (`srt` may belong to another table with the
 // same point set: B1 and B2 share one)
 template <class F>
-static int msm_accum_enqueue(zkr_key *prof, hipStream_t s, const Affine<F> *pts, uint32_t n, const MsmPlan &pl, const MsmWorkspace &srt, MsmWorkspace &ws) {
+static int msm_accum_enqueue(Prof pf, hipStream_t s, const Affine<F> *pts, uint32_t n, const MsmPlan &pl, const MsmWorkspace &srt, MsmWorkspace &ws) {
   if (n == 0) return 0;
-  int sp = prof_begin(prof, s, MsmCfg<F>::ACC_STAGE);
+  int sp = prof_begin(pf, s, MsmCfg<F>::ACC_STAGE);
   msm_accum_kernel<F, MsmCfg<F>::ACC_W><<<(pl.nb + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, s>>>(pts, srt.offsets, srt.entries, pl.nb, srt.counts,
                                                                                                       srt.order, (XYZZ<F> *)ws.buckets);
-  prof_end(prof, s, sp);
+  prof_end(pf, s, sp);
   ZKR_HIP_CHECK(hipGetLastError());
   return 0;
 }
 
 // oversized buckets (digit +-1 of 0/1-heavy witnesses): needs only the sort, so it runs beside the table's accumulation
 template <class F>
-static int msm_big_enqueue(zkr_key *prof, hipStream_t s, const Affine<F> *pts, uint32_t n, const MsmPlan &pl, const MsmWorkspace &srt, MsmWorkspace &ws) {
+static int msm_big_enqueue(Prof pf, hipStream_t s, const Affine<F> *pts, uint32_t n, const MsmPlan &pl, const MsmWorkspace &srt, MsmWorkspace &ws) {
   if (n == 0) return 0;
-  int sp = prof_begin(prof, s, "msm_big");
+  int sp = prof_begin(pf, s, "msm_big");
   msm_big_kernel<F, MsmCfg<F>::RED_W><<<BIG_SLOTS * BIG_SPLIT, MSM_THREADS, MSM_THREADS * sizeof(XYZZ<F>), s>>>(pts, srt.offsets, srt.entries, srt.big_list, srt.big_count,
                                                                                                              BIG_CAP, (XYZZ<F> *)ws.big_partials);
-  prof_end(prof, s, sp);
+  prof_end(pf, s, sp);
   ZKR_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -234,20 +234,20 @@ static int msm_big_enqueue(zkr_key *prof, hipStream_t s, const Affine<F> *pts, u
 // big-bucket partial sums -> buckets, bucket reduction, window sums -> ws.h_window: short launches of few,
 // long-running wavefronts (raised wave priority), meant to run beside the next table's accumulation
 template <class F>
-static int msm_reduce_enqueue(zkr_key *prof, hipStream_t s, uint32_t n, const MsmPlan &pl, const MsmWorkspace &srt, MsmWorkspace &ws) {
+static int msm_reduce_enqueue(Prof pf, hipStream_t s, uint32_t n, const MsmPlan &pl, const MsmWorkspace &srt, MsmWorkspace &ws) {
   if (n == 0) return 0;
   MsmGeom g;
   g.n = n; g.c = pl.c; g.K = pl.K; g.nbw = pl.nbw; g.big_thresh = pl.big_thresh; g.glog = pl.glog;
-  int sp = prof_begin(prof, s, "msm_big");
+  int sp = prof_begin(pf, s, "msm_big");
   msm_big_finish_kernel<F, MsmCfg<F>::RED_W><<<BIG_CAP / 64, 64, 0, s>>>((const XYZZ<F> *)ws.big_partials, srt.big_list, srt.big_count, BIG_CAP, (XYZZ<F> *)ws.buckets);
-  prof_end(prof, s, sp);
-  sp = prof_begin(prof, s, "msm_reduce");
+  prof_end(pf, s, sp);
+  sp = prof_begin(pf, s, "msm_reduce");
   uint32_t ngroups = (pl.nbw >> pl.glog) * (uint32_t)pl.K;
   uint32_t ntask = (uint32_t)(pl.c - 1 - pl.glog) + 2;
   msm_reduce1_kernel<F, MsmCfg<F>::RED_W><<<(ngroups + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, s>>>((const XYZZ<F> *)ws.buckets, g, (XYZZ<F> *)ws.group_out);
   msm_reduce2_kernel<F, MsmCfg<F>::RED_W><<<(unsigned)pl.K * ntask, MSM_THREADS, MSM_THREADS * sizeof(XYZZ<F>), s>>>((const XYZZ<F> *)ws.group_out, g, (XYZZ<F> *)ws.task_out);
   msm_reduce3_kernel<F, MsmCfg<F>::RED_W><<<((unsigned)pl.K * RED3_LANES + 63) / 64, 64, 0, s>>>((const XYZZ<F> *)ws.task_out, g, (XYZZ<F> *)ws.window_out);
-  prof_end(prof, s, sp);
+  prof_end(pf, s, sp);
   ZKR_HIP_CHECK(hipMemcpyAsync(ws.h_window, ws.window_out, (size_t)pl.K * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, s));
   ZKR_HIP_CHECK(hipGetLastError());
   return 0;
@@ -255,15 +255,15 @@ static int msm_reduce_enqueue(zkr_key *prof, hipStream_t s, uint32_t n, const Ms
 
 // stage-hook path: one table with its own scalars (n_scalars of them; sidx maps kept points to scalars)
 template <class F>
-static int msm_enqueue(zkr_key *prof, hipStream_t s, const Affine<F> *pts, const uint32_t *sidx, const Fr *scalars, uint32_t n_scalars, uint32_t n,
+static int msm_enqueue(Prof pf, hipStream_t s, const Affine<F> *pts, const uint32_t *sidx, const Fr *scalars, uint32_t n_scalars, uint32_t n,
                        const MsmPlan &pl, MsmWorkspace &ws) {
   if (!ws.own_dig) ZKR_HIP_CHECK(hipMalloc(&ws.own_dig, (size_t)pl.K * n_scalars * 2 + 2));
-  int rc = msm_digits_enqueue(prof, s, scalars, n_scalars, pl, ws.own_dig);
+  int rc = msm_digits_enqueue(pf, s, scalars, n_scalars, pl, ws.own_dig);
   if (rc) return rc;
-  if ((rc = msm_sort_enqueue(prof, s, sidx, ws.own_dig, n_scalars, n, pl, ws))) return rc;
-  if ((rc = msm_big_enqueue<F>(prof, s, pts, n, pl, ws, ws))) return rc;
-  if ((rc = msm_accum_enqueue<F>(prof, s, pts, n, pl, ws, ws))) return rc;
-  return msm_reduce_enqueue<F>(prof, s, n, pl, ws, ws);
+  if ((rc = msm_sort_enqueue(pf, s, sidx, ws.own_dig, n_scalars, n, pl, ws))) return rc;
+  if ((rc = msm_big_enqueue<F>(pf, s, pts, n, pl, ws, ws))) return rc;
+  if ((rc = msm_accum_enqueue<F>(pf, s, pts, n, pl, ws, ws))) return rc;
+  return msm_reduce_enqueue<F>(pf, s, n, pl, ws, ws);
 }
 
 // Horner over the K window sums (host): sum_k 2^(ck) W_k
@@ -299,26 +299,27 @@ static int draw_blinding(uint8_t out[32]) {
   return 0;
 }
 
-static int prove_on_device(zkr_key *k, const Fr *d_wsrc, const uint8_t *r32, const uint8_t *s32, uint8_t proof_out[256], hipStream_t s) {
+// Enqueue the whole GPU side of one proof on the slot's buffers; returns without waiting.
+static int prove_submit(zkr_key *k, ProofSlot &sl, const Fr *d_wsrc, const uint8_t *r32, const uint8_t *s32, hipStream_t s) {
   ZKR_HIP_CHECK(hipSetDevice(k->device));
   const ArenaHeader &h = k->h;
   const unsigned char *ar = k->arena;
-  uint8_t rb[32], sb[32];
+  const Prof pf{k, &sl};
   if (r32 && s32) {
-    memcpy(rb, r32, 32);
-    memcpy(sb, s32, 32);
+    memcpy(sl.rb, r32, 32);
+    memcpy(sl.sb, s32, 32);
     uint32_t rv[8], sv[8];
-    memcpy(rv, rb, 32); memcpy(sv, sb, 32);
+    memcpy(rv, sl.rb, 32); memcpy(sv, sl.sb, 32);
     if (!u256_lt(rv, FrParams::P) || !u256_lt(sv, FrParams::P)) { set_error("blinding scalar >= r"); return ZKR_ERR_ARG; }
   } else if (!r32 && !s32) {
     int rc;
-    if ((rc = draw_blinding(rb)) || (rc = draw_blinding(sb))) return rc;
+    if ((rc = draw_blinding(sl.rb)) || (rc = draw_blinding(sl.sb))) return rc;
   } else { set_error("pass both r and s or neither"); return ZKR_ERR_ARG; }
 
-  int tot = prof_begin(k, s, "total");
-  int sp = prof_begin(k, s, "ingest");
-  ingest_kernel<<<(h.n + 255) / 256, 256, 0, s>>>(d_wsrc, k->d_w, h.n);
-  prof_end(k, s, sp);
+  int tot = prof_begin(pf, s, "total");
+  int sp = prof_begin(pf, s, "ingest");
+  ingest_kernel<<<(h.n + 255) / 256, 256, 0, s>>>(d_wsrc, sl.d_w, h.n);
+  prof_end(pf, s, sp);
   // Schedule on three streams (HIP multiplexes streams onto a few hardware queues; streams sharing one serialise):
   //   s  : the heavy chain -- digit codes, then per table its digit sort and its bucket accumulation; B2 first
   //        (its reduction chain is the longest), B1 reuses that sort (h.share_b), H last (needs h);
@@ -327,44 +328,46 @@ static int prove_on_device(zkr_key *k, const Fr *d_wsrc, const uint8_t *r32, con
   // Every accumulation saturates the VALUs on its own.  The reduction chains are few long-running wavefronts
   // (raised wave priority) that run under the following accumulations and get the machine mostly to themselves
   // while the next table is being sorted; the oversized buckets need only the sort and run beside the accumulation.
+  // With two proofs in flight (zkr_prove_submit) the next proof's heavy chain follows this one's directly and
+  // covers the tail of its reduction chains and its host assembly.
   static const bool serial = getenv("ZKR_SERIAL") != nullptr;  // profiling aid: one stream, isolated kernel durations
   hipStream_t sn = serial ? s : k->ntt_stream;
   hipStream_t rx = serial ? s : k->red_stream[0], ry = serial ? s : k->red_stream[1];
   int rc;
-  ZKR_HIP_CHECK(hipEventRecord(k->ev_w, s));
-  if (!serial) ZKR_HIP_CHECK(hipStreamWaitEvent(sn, k->ev_w, 0));
-  if ((rc = calc_h_device(k, sn))) return rc;
-  ZKR_HIP_CHECK(hipEventRecord(k->ev_h, sn));
-  const uint16_t *dig[N_TABLES] = {k->dig_w, k->dig_w, k->dig_w, k->dig_w, k->dig_h};
+  ZKR_HIP_CHECK(hipEventRecord(sl.ev_w, s));
+  if (!serial) ZKR_HIP_CHECK(hipStreamWaitEvent(sn, sl.ev_w, 0));
+  if ((rc = calc_h_device(k, sl, sn))) return rc;
+  ZKR_HIP_CHECK(hipEventRecord(sl.ev_h, sn));
+  const uint16_t *dig[N_TABLES] = {sl.dig_w, sl.dig_w, sl.dig_w, sl.dig_w, sl.dig_h};
   const size_t dig_stride[N_TABLES] = {h.n, h.n, h.n, h.n, h.m};
   const bool share_b = h.share_b != 0 && h.npts[T_B1] == h.npts[T_B2];
   int sort_src[N_TABLES] = {T_A, T_B1, share_b ? T_B1 : T_B2, T_C, T_H};
   auto sort_table = [&](int t) -> int {
-    int rc = msm_sort_enqueue(k, s, (const uint32_t *)(ar + h.off_sidx[t]), dig[t], dig_stride[t], h.npts[t], k->plan[t], k->ws[t]);
+    int rc = msm_sort_enqueue(pf, s, (const uint32_t *)(ar + h.off_sidx[t]), dig[t], dig_stride[t], h.npts[t], k->plan[t], sl.ws[t]);
     if (rc) return rc;
-    if (!serial) ZKR_HIP_CHECK(hipEventRecord(k->ev_sorted[t], s));
+    if (!serial) ZKR_HIP_CHECK(hipEventRecord(sl.ev_sorted[t], s));
     return 0;
   };
   auto accum_table = [&](int t, hipStream_t rs) -> int {
-    const MsmWorkspace &srt = k->ws[sort_src[t]];
+    const MsmWorkspace &srt = sl.ws[sort_src[t]];
     const void *pts = ar + h.off_pts[t];
     int rc;
-    if (!serial) ZKR_HIP_CHECK(hipStreamWaitEvent(rs, k->ev_sorted[sort_src[t]], 0));
-    if (t == T_B2) rc = msm_big_enqueue<Fq2>(k, rs, (const G2Affine *)pts, h.npts[t], k->plan[t], srt, k->ws[t]);
-    else rc = msm_big_enqueue<Fq>(k, rs, (const G1Affine *)pts, h.npts[t], k->plan[t], srt, k->ws[t]);
+    if (!serial) ZKR_HIP_CHECK(hipStreamWaitEvent(rs, sl.ev_sorted[sort_src[t]], 0));
+    if (t == T_B2) rc = msm_big_enqueue<Fq2>(pf, rs, (const G2Affine *)pts, h.npts[t], k->plan[t], srt, sl.ws[t]);
+    else rc = msm_big_enqueue<Fq>(pf, rs, (const G1Affine *)pts, h.npts[t], k->plan[t], srt, sl.ws[t]);
     if (rc) return rc;
-    if (t == T_B2) rc = msm_accum_enqueue<Fq2>(k, s, (const G2Affine *)pts, h.npts[t], k->plan[t], srt, k->ws[t]);
-    else rc = msm_accum_enqueue<Fq>(k, s, (const G1Affine *)pts, h.npts[t], k->plan[t], srt, k->ws[t]);
+    if (t == T_B2) rc = msm_accum_enqueue<Fq2>(pf, s, (const G2Affine *)pts, h.npts[t], k->plan[t], srt, sl.ws[t]);
+    else rc = msm_accum_enqueue<Fq>(pf, s, (const G1Affine *)pts, h.npts[t], k->plan[t], srt, sl.ws[t]);
     if (rc) return rc;
     if (!serial) {
-      ZKR_HIP_CHECK(hipEventRecord(k->ev_done[t], s));
-      ZKR_HIP_CHECK(hipStreamWaitEvent(rs, k->ev_done[t], 0));
+      ZKR_HIP_CHECK(hipEventRecord(sl.ev_done[t], s));
+      ZKR_HIP_CHECK(hipStreamWaitEvent(rs, sl.ev_done[t], 0));
     }
-    if (t == T_B2) rc = msm_reduce_enqueue<Fq2>(k, rs, h.npts[t], k->plan[t], srt, k->ws[t]);
-    else rc = msm_reduce_enqueue<Fq>(k, rs, h.npts[t], k->plan[t], srt, k->ws[t]);
+    if (t == T_B2) rc = msm_reduce_enqueue<Fq2>(pf, rs, h.npts[t], k->plan[t], srt, sl.ws[t]);
+    else rc = msm_reduce_enqueue<Fq>(pf, rs, h.npts[t], k->plan[t], srt, sl.ws[t]);
     return rc;
   };
-  if ((rc = msm_digits_enqueue(k, s, k->d_w, h.n, k->plan[T_A], k->dig_w))) return rc;
+  if ((rc = msm_digits_enqueue(pf, s, sl.d_w, h.n, k->plan[T_A], sl.dig_w))) return rc;
   if ((rc = sort_table(T_B1))) return rc;
   if (!share_b && (rc = sort_table(T_B2))) return rc;
   if ((rc = accum_table(T_B2, rx))) return rc;
@@ -373,26 +376,40 @@ static int prove_on_device(zkr_key *k, const Fr *d_wsrc, const uint8_t *r32, con
   if ((rc = accum_table(T_A, ry))) return rc;
   if ((rc = sort_table(T_C))) return rc;
   if ((rc = accum_table(T_C, ry))) return rc;
-  if (!serial) ZKR_HIP_CHECK(hipStreamWaitEvent(s, k->ev_h, 0));
-  if ((rc = msm_digits_enqueue(k, s, k->d_h, h.m, k->plan[T_H], k->dig_h))) return rc;
+  if (!serial) ZKR_HIP_CHECK(hipStreamWaitEvent(s, sl.ev_h, 0));
+  if ((rc = msm_digits_enqueue(pf, s, sl.d_h, h.m, k->plan[T_H], sl.dig_h))) return rc;
   if ((rc = sort_table(T_H))) return rc;
   if ((rc = accum_table(T_H, ry))) return rc;
+  // completion = both reduction streams done.  The heavy stream `s` is NOT made to wait for them, so the next
+  // proof's chain can follow directly; callers that order later work after `s` go through prove_collect.
   if (!serial) {
-    ZKR_HIP_CHECK(hipEventRecord(k->ev_w, rx));  // ev_w / ev_h are free again: the two join events
-    ZKR_HIP_CHECK(hipEventRecord(k->ev_h, ry));
-    ZKR_HIP_CHECK(hipStreamWaitEvent(s, k->ev_w, 0));
-    ZKR_HIP_CHECK(hipStreamWaitEvent(s, k->ev_h, 0));
+    ZKR_HIP_CHECK(hipEventRecord(sl.ev_w, rx));  // ev_w / ev_h are free again: the two join events
+    ZKR_HIP_CHECK(hipEventRecord(sl.ev_h, ry));
+    ZKR_HIP_CHECK(hipStreamWaitEvent(rx, sl.ev_h, 0));
+    prof_end(pf, rx, tot);
+    ZKR_HIP_CHECK(hipEventRecord(sl.ev_fin, rx));
+  } else {
+    prof_end(pf, s, tot);
+    ZKR_HIP_CHECK(hipEventRecord(sl.ev_fin, s));
   }
-  prof_end(k, s, tot);
-  ZKR_HIP_CHECK(hipStreamSynchronize(s));
-  prof_collect(k);
+  sl.busy = true;
+  return 0;
+}
 
-  // ---- host assembly
-  G1XYZZ A = msm_finish<Fq>(h.npts[T_A], k->plan[T_A], k->ws[T_A]);
-  G1XYZZ B1 = msm_finish<Fq>(h.npts[T_B1], k->plan[T_B1], k->ws[T_B1]);
-  G2XYZZ B2 = msm_finish<Fq2>(h.npts[T_B2], k->plan[T_B2], k->ws[T_B2]);
-  G1XYZZ C = msm_finish<Fq>(h.npts[T_C], k->plan[T_C], k->ws[T_C]);
-  G1XYZZ H = msm_finish<Fq>(h.npts[T_H], k->plan[T_H], k->ws[T_H]);
+// Wait for the slot's GPU work, then the host assembly.
+static int prove_collect(zkr_key *k, ProofSlot &sl, uint8_t proof_out[256]) {
+  if (!sl.busy) { set_error("no proof in flight in this slot"); return ZKR_ERR_ARG; }
+  ZKR_HIP_CHECK(hipSetDevice(k->device));
+  const ArenaHeader &h = k->h;
+  sl.busy = false;
+  ZKR_HIP_CHECK(hipEventSynchronize(sl.ev_fin));
+  if (k->prof_on) prof_collect(k, sl);
+  const uint8_t *rb = sl.rb, *sb = sl.sb;
+  G1XYZZ A = msm_finish<Fq>(h.npts[T_A], k->plan[T_A], sl.ws[T_A]);
+  G1XYZZ B1 = msm_finish<Fq>(h.npts[T_B1], k->plan[T_B1], sl.ws[T_B1]);
+  G2XYZZ B2 = msm_finish<Fq2>(h.npts[T_B2], k->plan[T_B2], sl.ws[T_B2]);
+  G1XYZZ C = msm_finish<Fq>(h.npts[T_C], k->plan[T_C], sl.ws[T_C]);
+  G1XYZZ H = msm_finish<Fq>(h.npts[T_H], k->plan[T_H], sl.ws[T_H]);
   G1XYZZ alfa1 = to_xyzz(load_g1(h.alfa1)), beta1 = to_xyzz(load_g1(h.beta1)), delta1 = to_xyzz(load_g1(h.delta1));
   G2XYZZ beta2 = to_xyzz(load_g2(h.beta2)), delta2 = to_xyzz(load_g2(h.delta2));
   U256 r = load_u256(rb), sc = load_u256(sb);
@@ -420,33 +437,70 @@ using namespace zkr;
 
 extern "C" {
 
+// the synchronous calls use whichever slot is free (a caller may hold one submitted proof across them)
+static ProofSlot *free_slot(zkr_key *key, int *ticket) {
+  for (int i = 0; i < PROOF_SLOTS; i++) {
+    int t = (key->next_slot + i) % PROOF_SLOTS;
+    if (!key->slot[t].busy) { key->next_slot = (t + 1) % PROOF_SLOTS; if (ticket) *ticket = t; return &key->slot[t]; }
+  }
+  set_error("all %d proof slots are in flight: collect one first", PROOF_SLOTS);
+  return nullptr;
+}
+
+int zkr_prove_submit(zkr_key *key, const void *d_witness_std, const uint8_t *r32, const uint8_t *s32, void *stream, int *ticket) {
+  if (!key || !d_witness_std || !ticket) { set_error("null argument"); return ZKR_ERR_ARG; }
+  int t = -1;
+  ProofSlot *sl = free_slot(key, &t);
+  if (!sl) return ZKR_ERR_ARG;
+  int rc = prove_submit(key, *sl, (const Fr *)d_witness_std, r32, s32, stream ? (hipStream_t)stream : key->stream);
+  if (rc) return rc;
+  *ticket = t;
+  return 0;
+}
+
+int zkr_prove_collect(zkr_key *key, int ticket, uint8_t proof_out[256]) {
+  if (!key || !proof_out || ticket < 0 || ticket >= PROOF_SLOTS) { set_error("bad argument"); return ZKR_ERR_ARG; }
+  return prove_collect(key, key->slot[ticket], proof_out);
+}
+
 int zkr_prove_device(zkr_key *key, const void *d_witness_std, const uint8_t *r32, const uint8_t *s32, uint8_t proof_out[256], void *stream) {
   if (!key || !d_witness_std || !proof_out) { set_error("null argument"); return ZKR_ERR_ARG; }
-  return prove_on_device(key, (const Fr *)d_witness_std, r32, s32, proof_out, stream ? (hipStream_t)stream : key->stream);
+  ProofSlot *sl = free_slot(key, nullptr);
+  if (!sl) return ZKR_ERR_ARG;
+  int rc = prove_submit(key, *sl, (const Fr *)d_witness_std, r32, s32, stream ? (hipStream_t)stream : key->stream);
+  if (rc) return rc;
+  return prove_collect(key, *sl, proof_out);
 }
 
 int zkr_prove(zkr_key *key, const void *witness_std, size_t witness_len, const uint8_t *r32, const uint8_t *s32, uint8_t proof_out[256], void *stream) {
   if (!key || !witness_std || !proof_out) { set_error("null argument"); return ZKR_ERR_ARG; }
   if (witness_len != (size_t)key->h.n * 32) { set_error("witness is %zu bytes, key expects nVars*32 = %zu", witness_len, (size_t)key->h.n * 32); return ZKR_ERR_BAD_WITNESS; }
   ZKR_HIP_CHECK(hipSetDevice(key->device));
+  ProofSlot *sl = free_slot(key, nullptr);
+  if (!sl) return ZKR_ERR_ARG;
   hipStream_t s = stream ? (hipStream_t)stream : key->stream;
-  ZKR_HIP_CHECK(hipMemcpyAsync(key->d_wraw, witness_std, witness_len, hipMemcpyHostToDevice, s));
-  return prove_on_device(key, key->d_wraw, r32, s32, proof_out, s);
+  ZKR_HIP_CHECK(hipMemcpyAsync(sl->d_wraw, witness_std, witness_len, hipMemcpyHostToDevice, s));
+  int rc = prove_submit(key, *sl, sl->d_wraw, r32, s32, s);
+  if (rc) return rc;
+  return prove_collect(key, *sl, proof_out);
 }
 
 int zkr_calc_h(zkr_key *key, const void *witness_std, size_t witness_len, void *h_out) {
   if (!key || !witness_std || !h_out) { set_error("null argument"); return ZKR_ERR_ARG; }
   if (witness_len != (size_t)key->h.n * 32) { set_error("witness length mismatch"); return ZKR_ERR_BAD_WITNESS; }
   ZKR_HIP_CHECK(hipSetDevice(key->device));
+  ProofSlot *slp = free_slot(key, nullptr);
+  if (!slp) return ZKR_ERR_ARG;
+  ProofSlot &sl = *slp;
   hipStream_t s = key->stream;
-  ZKR_HIP_CHECK(hipMemcpyAsync(key->d_wraw, witness_std, witness_len, hipMemcpyHostToDevice, s));
-  ingest_kernel<<<(key->h.n + 255) / 256, 256, 0, s>>>(key->d_wraw, key->d_w, key->h.n);
-  int rc = calc_h_device(key, s);
+  ZKR_HIP_CHECK(hipMemcpyAsync(sl.d_wraw, witness_std, witness_len, hipMemcpyHostToDevice, s));
+  ingest_kernel<<<(key->h.n + 255) / 256, 256, 0, s>>>(sl.d_wraw, sl.d_w, key->h.n);
+  int rc = calc_h_device(key, sl, s);
   if (rc) return rc;
-  bitrev_copy_kernel<<<(key->h.m + 255) / 256, 256, 0, s>>>(key->d_h, key->ca, (int)key->h.logm);
-  ZKR_HIP_CHECK(hipMemcpyAsync(h_out, key->ca, (size_t)key->h.m * 32, hipMemcpyDeviceToHost, s));
+  bitrev_copy_kernel<<<(key->h.m + 255) / 256, 256, 0, s>>>(sl.d_h, sl.ca, (int)key->h.logm);
+  ZKR_HIP_CHECK(hipMemcpyAsync(h_out, sl.ca, (size_t)key->h.m * 32, hipMemcpyDeviceToHost, s));
   ZKR_HIP_CHECK(hipStreamSynchronize(s));
-  prof_collect(key);
+  if (key->prof_on) prof_collect(key, sl);
   return 0;
 }
 
@@ -510,7 +564,7 @@ static int msm_hook(const void *points_mont, const void *scalars_std, size_t n, 
     ZKR_HIP_CHECK(hipMemcpy(d_sidx, sidx.data(), (size_t)np * 4, hipMemcpyHostToDevice));
     ZKR_HIP_CHECK(hipMemcpy(d_sc, scalars_std, n * 32, hipMemcpyHostToDevice));
     ingest_kernel<<<(unsigned)((n + 255) / 256), 256>>>(d_sc, d_sc2, n);
-    rc = msm_enqueue<F>(nullptr, nullptr, d_pts, d_sidx, d_sc2, (uint32_t)n, np, pl, ws);
+    rc = msm_enqueue<F>(Prof{nullptr, nullptr}, nullptr, d_pts, d_sidx, d_sc2, (uint32_t)n, np, pl, ws);
     if (!rc) {
       hipError_t e = hipDeviceSynchronize();
       if (e != hipSuccess) { set_error("msm failed: %s", hipGetErrorString(e)); rc = ZKR_ERR_HIP; }

@@ -37,6 +37,8 @@ def lib():
     L.zkr_key_adopt_arena.argtypes = [vp, sz, i, c.POINTER(vp)]
     L.zkr_prove.argtypes = [vp, u8p, sz, u8p, u8p, u8p, vp]
     L.zkr_prove_device.argtypes = [vp, vp, u8p, u8p, u8p, vp]
+    L.zkr_prove_submit.argtypes = [vp, vp, u8p, u8p, vp, c.POINTER(i)]
+    L.zkr_prove_collect.argtypes = [vp, i, u8p]
     L.zkr_ntt.argtypes = [u8p, c.c_uint, i, i]
     L.zkr_msm_g1.argtypes = [u8p, u8p, sz, u8p, c.POINTER(i), i]
     L.zkr_msm_g2.argtypes = [u8p, u8p, sz, u8p, c.POINTER(i), i]
@@ -142,6 +144,31 @@ class ProvingKey:
         sb = None if s is None else int(s).to_bytes(32, "little")
         _check(lib().zkr_prove_device(self._h, ctypes.c_void_p(d_witness_ptr), rb, sb, out, ctypes.c_void_p(stream or 0)))
         return out.raw
+
+    def prove_submit(self, d_witness_ptr, r=None, s=None, stream=None) -> int:
+        """Enqueue the GPU side of one proof, return a ticket (zkr_prove_submit); at most two in flight."""
+        rb = None if r is None else int(r).to_bytes(32, "little")
+        sb = None if s is None else int(s).to_bytes(32, "little")
+        ticket = ctypes.c_int(-1)
+        _check(lib().zkr_prove_submit(self._h, ctypes.c_void_p(d_witness_ptr), rb, sb, ctypes.c_void_p(stream or 0), ctypes.byref(ticket)))
+        return ticket.value
+
+    def prove_collect(self, ticket) -> bytes:
+        out = ctypes.create_string_buffer(PROOF_BYTES)
+        _check(lib().zkr_prove_collect(self._h, int(ticket), out))
+        return out.raw
+
+    def prove_batch_device(self, d_witness_ptrs, rs=None, ss=None, stream=None):
+        """Independent proofs of one batch, pipelined two deep: proof i+1 is submitted before proof i is collected."""
+        out, pending = [], None
+        for j, ptr in enumerate(d_witness_ptrs):
+            t = self.prove_submit(ptr, None if rs is None else rs[j], None if ss is None else ss[j], stream)
+            if pending is not None:
+                out.append(self.prove_collect(pending))
+            pending = t
+        if pending is not None:
+            out.append(self.prove_collect(pending))
+        return out
 
     def calc_h(self, witness: bytes) -> bytes:
         m = self.info()["domainSize"]

@@ -32,3 +32,34 @@ def test_fullsize_proof_equals_closed_form_and_verifies(log_m):
     expect2, _, pub2 = g.proof_from_aux(aux, wb2, p, r, s)
     assert proof2 == g.proof_bytes(expect2) and proof2 != proof
     assert g.is_valid(vk, _proof_points(proof2), pub2)
+
+
+@pytest.mark.parametrize("log_m", [12, 18])
+def test_pipelined_batch_equals_synchronous_proofs(log_m):
+    """zkr_prove_submit / zkr_prove_collect with two proofs in flight: every proof of the batch is bit-identical
+    to the synchronous call with the same witness and blinding (and so to the closed form)."""
+    import torch
+    import zkr_hip
+    p = 73
+    key, wb, aux = zkr_hip.ProvingKey.synth(log_m, p, 0x5A4B0001, 0x5A4B00FF)
+    wbs = [wb] + [zkr_hip.synth_witness(log_m, p, 0x5A4B0001, 7000 + i) for i in range(4)]
+    rng = g.SplitMix64(5 + log_m)
+    rs, ss = [rng.fr() for _ in wbs], [rng.fr() for _ in wbs]
+    dw = [torch.frombuffer(bytearray(w), dtype=torch.uint8).cuda() for w in wbs]
+    batch = key.prove_batch_device([t.data_ptr() for t in dw], rs, ss)
+    assert len(batch) == len(wbs)
+    for w, r, s, got in zip(wbs, rs, ss, batch):
+        assert got == key.prove(w, r, s)
+        expect, _, _ = g.proof_from_aux(aux, w, p, r, s)
+        assert got == g.proof_bytes(expect)
+    # a third submit with two in flight is refused; collecting frees the slot
+    t0 = key.prove_submit(dw[0].data_ptr(), rs[0], ss[0])
+    t1 = key.prove_submit(dw[1].data_ptr(), rs[1], ss[1])
+    with pytest.raises(zkr_hip.ZkrError):
+        key.prove_submit(dw[2].data_ptr(), rs[2], ss[2])
+    assert key.prove_collect(t0) == batch[0]
+    t2 = key.prove_submit(dw[2].data_ptr(), rs[2], ss[2])
+    assert key.prove_collect(t1) == batch[1]
+    assert key.prove_collect(t2) == batch[2]
+    with pytest.raises(zkr_hip.ZkrError):
+        key.prove_collect(t2)
