@@ -1,20 +1,25 @@
-// kernels_msm.cuh -- multi-scalar multiplication over G1 / G2 (Pippenger bucket method) and the
-// fixed-base kernels of the device-side setup.
+// kernels_msm.cuh -- multi-scalar multiplication over G1 / G2 (Pippenger bucket method over precomputed
+// window tables) and the fixed-base kernels of the device-side setup.
 //
 // Path: the five multiexps of websnark's groth16GenProof (call site
 // /root/reference/operator/src/snarks/common.ts:29).  Integer VALU work only (v_mad_u64_u32): no MFMA.
 //
-// Pipeline per MSM (all on one stream, no host round trip until the K window sums come back):
-//   digits   : signed c-bit digits of every scalar, once per scalar vector (u16 codes, window-major)
-//   hist     : workgroup per (window, chunk): bucket occupancies counted with LDS atomics
+// Every key table holds, next to each base point P_i, its multiples 2^(ck) P_i for the K = ceil(255/c) windows
+// (built once at key load, msm_precompute_kernel; 288 GB of HBM make a 13x table cheap).  The signed c-bit
+// digit d of window k of scalar i then contributes sign(d) * (2^(ck) P_i) to bucket |d| of ONE bucket set
+// shared by all windows, so c can be 20 (K = 13 additions per point instead of 16 at c = 16) while the
+// reduction still runs over 2^19 buckets, and no Horner over windows is left.
+//
+// Pipeline per MSM (no host round trip until the result point comes back):
+//   digits   : signed c-bit digits of every scalar, once per scalar vector, as records split by bucket range
+//   hist     : workgroup per (bucket range, chunk): bucket occupancies counted with LDS atomics
 //   scan     : per-bucket prefix over chunks, then exclusive prefix sum -> bucket offsets; buckets larger
 //              than `big_thresh` are listed
-//   scatter  : (point index, sign) entries grouped by bucket, cursors in LDS (counting sort)
 //   order    : bucket ids sorted by occupancy, fullest first (counting sort over size classes)
+//   scatter  : (table index, sign) entries grouped by bucket, cursors in LDS (counting sort)
 //   accum    : one thread per bucket in that order, XYZZ += affine point (8M+2S), points gathered from the key table
-//   big      : one workgroup per oversized bucket (0/1-heavy witnesses), LDS tree of XYZZ sums
-//   reduce   : sum_b b*B_b per window in three launches (group running sums, bit-subset sums, per-window
-//              Horner) -> K window sums (the host does the Horner over windows)
+//   big      : workgroups share an oversized bucket (0/1-heavy witnesses), LDS tree of XYZZ sums
+//   reduce   : sum_b b*B_b in three launches (group running sums, bit-subset sums, finish) -> the MSM result
 #pragma once
 #include "curve.cuh"
 
@@ -48,12 +53,13 @@ __device__ __forceinline__ void store_pod(T *p, const T &v) {
 }
 
 struct MsmGeom {
-  uint32_t n;        // points
+  uint32_t n;        // points (base points of the table; the table holds K * n)
   int c;             // window bits
   int K;             // windows
-  uint32_t nbw;      // buckets per window = 2^(c-1)
+  uint32_t nbw;      // buckets = 2^(c-1), one set shared by all windows
   uint32_t big_thresh;
   int glog;          // reduce group = 2^glog buckets
+  uint32_t S;        // reduce2: workgroups per task
 };
 
 // Signed-digit recoding state: scalar kept in 8 registers and shifted right by c each window so the
@@ -84,77 +90,148 @@ struct DigitIter {
 
 __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
 
-// ---------------------------------------------------------------- digit sort (LDS counting sort per window)
-// Stage 1, once per SCALAR VECTOR (w serves the A, B1, B2 and C tables): signed c-bit digits of every
-// scalar as u16 codes, window-major: dig[k * stride + i] = 0 (digit 0: no entry) or
-// 1 + ((|d| - 1) << 1 | (d < 0)).  |d| <= 2^(c-1) <= 32768 and d > -2^(c-1), so the code fits 16 bits.
-static __global__ __launch_bounds__(MSM_THREADS) void msm_digits_kernel(const Fr *scalars, uint32_t n, int c, int K, size_t stride, uint16_t *dig) {
+// ---------------------------------------------------------------- digit sort
+// Bucket id = |d| - 1 < 2^(c-1) of the signed c-bit digit d; the 2^(c-1) buckets are cut into nR ranges of nbl
+// <= 2^15 buckets, the number of 4-byte counters one workgroup keeps in LDS.
+//
+// Stage 1, once per SCALAR VECTOR (w serves the A, B1, B2 and C tables, h serves H): every non-zero digit
+// becomes a record in the list of its bucket range -- ent_s = scalar index, ent_b = window << 17 | (bucket
+// within the range) << 1 | (d < 0).  Two launches: count per range, then scatter (digits are recomputed; a
+// scalar is 32 bytes and the recoding a few shifts).  Workgroups reserve their span of each list with one
+// atomic per range, so the lists are written in runs.
+constexpr int ENT_WIN_SHIFT = 17;
+constexpr uint32_t MAX_RANGES = 64;
+
+__device__ __forceinline__ uint32_t digit_bucket(int d) { return (uint32_t)(d < 0 ? -d : d) - 1u; }
+
+static __global__ __launch_bounds__(MSM_THREADS) void msm_digits_count_kernel(const Fr *scalars, uint32_t n, int c, int K, int nbl_log, uint32_t nR, uint32_t *rng_cnt) {
+  __shared__ uint32_t s_cnt[MAX_RANGES];
+  if (threadIdx.x < nR) s_cnt[threadIdx.x] = 0;
+  __syncthreads();
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  if (i < n) {
+    DigitIter it;
+    it.init(scalars[i].v);
+    for (int k = 0; k < K; k++) {
+      int d = it.next(c);
+      if (d != 0) atomicAdd(&s_cnt[digit_bucket(d) >> nbl_log], 1u);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < nR && s_cnt[threadIdx.x]) atomicAdd(&rng_cnt[threadIdx.x], s_cnt[threadIdx.x]);
+}
+
+// rng_cnt complete, rng_fill zeroed.  Block 0 also publishes rng_off[0..nR] (exclusive prefix) for the table sorts.
+static __global__ __launch_bounds__(MSM_THREADS) void msm_digits_scatter_kernel(const Fr *scalars, uint32_t n, int c, int K, int nbl_log, uint32_t nR,
+                                                                              const uint32_t *rng_cnt, uint32_t *rng_fill, uint32_t *rng_off,
+                                                                              uint32_t *ent_s, uint32_t *ent_b) {
+  __shared__ uint32_t s_cnt[MAX_RANGES], s_base[MAX_RANGES];
+  if (threadIdx.x < nR) s_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   DigitIter it;
-  it.init(scalars[i].v);
-  for (int k = 0; k < K; k++) {
-    int d = it.next(c);
-    uint32_t mag = (uint32_t)(d < 0 ? -d : d);
-    dig[(size_t)k * stride + i] = d == 0 ? (uint16_t)0 : (uint16_t)(1u + (((mag - 1u) << 1) | (d < 0 ? 1u : 0u)));
+  if (i < n) {
+    it.init(scalars[i].v);
+    for (int k = 0; k < K; k++) {
+      int d = it.next(c);
+      if (d != 0) atomicAdd(&s_cnt[digit_bucket(d) >> nbl_log], 1u);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t run = 0;
+    for (uint32_t r = 0; r < nR; r++) { s_base[r] = run; run += rng_cnt[r]; }
+    if (blockIdx.x == 0) {
+      for (uint32_t r = 0; r < nR; r++) rng_off[r] = s_base[r];
+      rng_off[nR] = run;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < nR) {
+    uint32_t mine = s_cnt[threadIdx.x];
+    s_base[threadIdx.x] += mine ? atomicAdd(&rng_fill[threadIdx.x], mine) : 0u;
+    s_cnt[threadIdx.x] = 0;
+  }
+  __syncthreads();
+  if (i < n) {
+    it.init(scalars[i].v);
+    const uint32_t lo_mask = (1u << nbl_log) - 1u;
+    for (int k = 0; k < K; k++) {
+      int d = it.next(c);
+      if (d != 0) {
+        uint32_t b = digit_bucket(d), r = b >> nbl_log;
+        uint32_t pos = s_base[r] + atomicAdd(&s_cnt[r], 1u);
+        ent_s[pos] = i;
+        ent_b[pos] = ((uint32_t)k << ENT_WIN_SHIFT) | ((b & lo_mask) << 1) | (d < 0 ? 1u : 0u);
+      }
+    }
   }
 }
 
-// Stages 2 and 4 run one workgroup per (window k, chunk j of the table): the window's 2^(c-1) bucket
-// counters live in LDS (128 KB at c = 16, one workgroup per CU), so the 16 M increments of a 2^20-point
-// MSM are LDS atomics instead of L2/fabric atomics.  blockIdx -> (k, j) keeps all chunks of a window on one
-// XCD (block b runs on XCD b % 8; K is a multiple of 8 at full size) so their scattered 4-byte entry
-// writes merge in one L2.
+// Stages 2 and 4, per TABLE: one workgroup per (bucket range r, chunk j of that range's record list), bucket
+// counters / cursors in LDS (up to 128 KB, one workgroup per CU), so the 13.6 M increments of a 2^20-point MSM
+// are LDS atomics instead of L2/fabric atomics.  rank[s] = index of the table's point for scalar s, or
+// RANK_NONE when the table has none (point at infinity in the key: dropped at key build).
 constexpr int SORT_THREADS = 1024;
+constexpr uint32_t SORT_RANGE_MAX = 32768;  // bucket counters per workgroup (x 4 B of LDS)
+constexpr uint32_t RANK_NONE = 0xffffffffu;
 
-// cnt[(k * J + j) * nbw + b] = occupancy of bucket b of window k within chunk j
-static __global__ __launch_bounds__(SORT_THREADS) void msm_hist_kernel(const uint16_t *dig, size_t stride, const uint32_t *sidx, uint32_t n, int K, uint32_t nbw,
-                                                                     uint32_t J, uint32_t chunk, uint32_t *cnt) {
+__device__ __forceinline__ void sort_chunk(const uint32_t *rng_off, uint32_t r, uint32_t j, uint32_t J, uint32_t &e0, uint32_t &e1) {
+  uint32_t lo = rng_off[r], hi = rng_off[r + 1];
+  uint32_t chunk = (hi - lo + J - 1) / J;
+  e0 = min(lo + j * chunk, hi);
+  e1 = min(e0 + chunk, hi);
+}
+
+// cnt[(r * J + j) * nbl + b] = occupancy of bucket r * nbl + b within chunk j
+static __global__ __launch_bounds__(SORT_THREADS) void msm_hist_kernel(const uint32_t *ent_s, const uint32_t *ent_b, const uint32_t *rng_off, const uint32_t *rank,
+                                                                     uint32_t nbl, uint32_t J, uint32_t *cnt) {
   extern __shared__ __attribute__((aligned(16))) uint32_t s_bkt[];
-  const uint32_t k = blockIdx.x % (uint32_t)K, j = blockIdx.x / (uint32_t)K;
-  for (uint32_t b = threadIdx.x; b < nbw; b += SORT_THREADS) s_bkt[b] = 0;
+  const uint32_t j = blockIdx.x % J, r = blockIdx.x / J;
+  for (uint32_t b = threadIdx.x; b < nbl; b += SORT_THREADS) s_bkt[b] = 0;
   __syncthreads();
-  const uint16_t *dk = dig + (size_t)k * stride;
-  uint32_t i0 = j * chunk, i1 = min(i0 + chunk, n);
-  for (uint32_t i = i0 + threadIdx.x; i < i1; i += SORT_THREADS) {
-    uint32_t code = dk[sidx ? sidx[i] : i];
-    if (code) atomicAdd(&s_bkt[(code - 1u) >> 1], 1u);
-  }
+  uint32_t e0, e1;
+  sort_chunk(rng_off, r, j, J, e0, e1);
+  for (uint32_t e = e0 + threadIdx.x; e < e1; e += SORT_THREADS)
+    if (rank[ent_s[e]] != RANK_NONE) atomicAdd(&s_bkt[(ent_b[e] >> 1) & (SORT_RANGE_MAX - 1u)], 1u);
   __syncthreads();
-  uint32_t *out = cnt + ((size_t)k * J + j) * nbw;
-  for (uint32_t b = threadIdx.x; b < nbw; b += SORT_THREADS) out[b] = s_bkt[b];
+  uint32_t *out = cnt + ((size_t)r * J + j) * nbl;
+  for (uint32_t b = threadIdx.x; b < nbl; b += SORT_THREADS) out[b] = s_bkt[b];
 }
 
 // per bucket: exclusive prefix over the J chunks (in place) and the bucket total -> counts[]
-static __global__ __launch_bounds__(MSM_THREADS) void msm_colscan_kernel(uint32_t *cnt, uint32_t nb, uint32_t nbw, uint32_t J, uint32_t *counts) {
+static __global__ __launch_bounds__(MSM_THREADS) void msm_colscan_kernel(uint32_t *cnt, uint32_t nb, uint32_t nbl, uint32_t J, uint32_t *counts) {
   uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= nb) return;
-  uint32_t k = g / nbw, b = g % nbw;
-  uint32_t *col = cnt + (size_t)k * J * nbw + b;
+  uint32_t r = g / nbl, b = g % nbl;
+  uint32_t *col = cnt + (size_t)r * J * nbl + b;
   uint32_t run = 0;
   for (uint32_t j = 0; j < J; j++) {
-    uint32_t v = col[(size_t)j * nbw];
-    col[(size_t)j * nbw] = run;
+    uint32_t v = col[(size_t)j * nbl];
+    col[(size_t)j * nbl] = run;
     run += v;
   }
   counts[g] = run;
 }
 
-// entries[pos] = (point index << 1) | sign, grouped by bucket: LDS cursors = bucket offset + chunk prefix
-static __global__ __launch_bounds__(SORT_THREADS) void msm_scatter_kernel(const uint16_t *dig, size_t stride, const uint32_t *sidx, uint32_t n, int K, uint32_t nbw,
-                                                                        uint32_t J, uint32_t chunk, const uint32_t *cnt, const uint32_t *offsets, uint32_t *entries) {
+// entries[pos] = ((k * n + rank) << 1) | sign  -- index into the table's window levels and the sign of the digit --
+// grouped by bucket: LDS cursors = bucket offset + chunk prefix
+static __global__ __launch_bounds__(SORT_THREADS) void msm_scatter_kernel(const uint32_t *ent_s, const uint32_t *ent_b, const uint32_t *rng_off, const uint32_t *rank,
+                                                                        uint32_t n, uint32_t nbl, uint32_t J, const uint32_t *cnt, const uint32_t *offsets,
+                                                                        uint32_t *entries) {
   extern __shared__ __attribute__((aligned(16))) uint32_t s_bkt[];
-  const uint32_t k = blockIdx.x % (uint32_t)K, j = blockIdx.x / (uint32_t)K;
-  const uint32_t *pre = cnt + ((size_t)k * J + j) * nbw, *off = offsets + (size_t)k * nbw;
-  for (uint32_t b = threadIdx.x; b < nbw; b += SORT_THREADS) s_bkt[b] = off[b] + pre[b];
+  const uint32_t j = blockIdx.x % J, r = blockIdx.x / J;
+  const uint32_t *pre = cnt + ((size_t)r * J + j) * nbl, *off = offsets + (size_t)r * nbl;
+  for (uint32_t b = threadIdx.x; b < nbl; b += SORT_THREADS) s_bkt[b] = off[b] + pre[b];
   __syncthreads();
-  const uint16_t *dk = dig + (size_t)k * stride;
-  uint32_t i0 = j * chunk, i1 = min(i0 + chunk, n);
-  for (uint32_t i = i0 + threadIdx.x; i < i1; i += SORT_THREADS) {
-    uint32_t code = dk[sidx ? sidx[i] : i];
-    if (code) {
-      uint32_t pos = atomicAdd(&s_bkt[(code - 1u) >> 1], 1u);
-      entries[pos] = (i << 1) | ((code - 1u) & 1u);
+  uint32_t e0, e1;
+  sort_chunk(rng_off, r, j, J, e0, e1);
+  for (uint32_t e = e0 + threadIdx.x; e < e1; e += SORT_THREADS) {
+    uint32_t idx = rank[ent_s[e]];
+    if (idx != RANK_NONE) {
+      uint32_t b = ent_b[e];
+      uint32_t pos = atomicAdd(&s_bkt[(b >> 1) & (SORT_RANGE_MAX - 1u)], 1u);
+      entries[pos] = (((b >> ENT_WIN_SHIFT) * n + idx) << 1) | (b & 1u);
     }
   }
 }
@@ -362,50 +439,50 @@ static __global__ __launch_bounds__(64, MINW) void msm_big_finish_kernel(const X
   store_pod(buckets + big_list[w], acc);
 }
 
-// ---------------------------------------------------------------- bucket reduction: W_k = sum_b (b+1) * B_{k,b}
-// Three short launches per MSM; g = 2^glog buckets per group, ng = nbw / g groups per window:
+// ---------------------------------------------------------------- bucket reduction: result = sum_b (b+1) * B_b
+// Three short launches per MSM; g = 2^glog buckets per group, ng = nbw / g groups:
 //   reduce1 : thread per group, running sums over its g buckets -> R_t = sum_j B_{t,j}, T_t = sum_j (j+1) B_{t,j}
-//             so that W_k = sum_t T_t + g * sum_t t * R_t            (2 additions per bucket, chains of 2g)
-//   reduce2 : workgroup per (window, task): Q_j = sum of the R_t whose index t has bit j set (log2 ng tasks)
-//             and the two halves of sum_t T_t -- plain sums: strided accumulation + LDS tree
-//   reduce3 : 16 lanes per window: 2^(j+glog) Q_j by doublings in parallel, + the T halves, LDS tree -> W_k
-// (the host finishes with the Horner over the K windows: sequential doublings are ~20x faster there).
-// group_out: per window R[ng] then T[ng];  task_out: per window Q[nglog] then T-half[2].
+//             so that result = sum_t T_t + g * sum_t t * R_t        (2 additions per bucket, chains of 2g)
+//   reduce2 : workgroup per (task, split): Q_j = sum of the R_t whose index t has bit j set (log2 ng tasks)
+//             and the two halves of sum_t T_t -- plain sums: strided accumulation + LDS tree, S splits per task
+//   reduce3 : one workgroup: adds the splits, turns Q_j into 2^(j+glog) Q_j by doublings (one lane per task,
+//             in parallel), and adds the tasks in an LDS tree -> the MSM result
+// group_out: R[ng] then T[ng];  task_out: [ntask][S] with ntask = log2(ng) + 2.
 template <class F, int MINW>
 static __global__ __launch_bounds__(MSM_THREADS, MINW) void msm_reduce1_kernel(const XYZZ<F> *buckets, MsmGeom g, XYZZ<F> *group_out) {
   __builtin_amdgcn_s_setprio(3);  // few long-running wavefronts on the critical path: win VALU arbitration against the bulk accumulation
-  uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t ng = g.nbw >> g.glog, gs = 1u << g.glog;
-  if (gid >= ng * (uint32_t)g.K) return;
-  uint32_t k = gid / ng, t = gid % ng;
-  const XYZZ<F> *B = buckets + (size_t)k * g.nbw + (size_t)t * gs;
+  if (t >= ng) return;
+  const XYZZ<F> *B = buckets + (size_t)t * gs;
   XYZZ<F> run = load_pod(B + gs - 1), T = run;
   for (int j = (int)gs - 2; j >= 0; j--) {
     run = add_full_inl(run, load_pod(B + j));
     T = add_full_inl(T, run);
   }
-  store_pod(group_out + ((size_t)k * 2) * ng + t, run);
-  store_pod(group_out + ((size_t)k * 2 + 1) * ng + t, T);
+  store_pod(group_out + t, run);
+  store_pod(group_out + (size_t)ng + t, T);
 }
 
 template <class F, int MINW>
 static __global__ __launch_bounds__(MSM_THREADS, MINW) void msm_reduce2_kernel(const XYZZ<F> *group_out, MsmGeom g, XYZZ<F> *task_out) {
-  __builtin_amdgcn_s_setprio(3);  // few long-running wavefronts on the critical path: win VALU arbitration against the bulk accumulation
+  __builtin_amdgcn_s_setprio(3);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   XYZZ<F> *sh = reinterpret_cast<XYZZ<F> *>(smem);
-  const uint32_t nglog = (uint32_t)(g.c - 1 - g.glog), ng = 1u << nglog, ntask = nglog + 2;
-  const uint32_t k = blockIdx.x / ntask, j = blockIdx.x % ntask;
+  const uint32_t nglog = (uint32_t)(g.c - 1 - g.glog), ng = 1u << nglog;
+  const uint32_t j = blockIdx.x / g.S, q = blockIdx.x % g.S;
   XYZZ<F> acc = XYZZ<F>::inf();
-  if (j < nglog) {  // the u-th index with bit j set, u < ng/2
-    const XYZZ<F> *R = group_out + ((size_t)k * 2) * ng;
-    for (uint32_t u = threadIdx.x; u < ng / 2; u += MSM_THREADS) {
+  if (j < nglog) {  // the u-th index with bit j set, u < ng/2; this split takes u in [u0, u1)
+    const uint32_t half = ng / 2, u0 = (uint32_t)((uint64_t)half * q / g.S), u1 = (uint32_t)((uint64_t)half * (q + 1) / g.S);
+    for (uint32_t u = u0 + threadIdx.x; u < u1; u += MSM_THREADS) {
       uint32_t t = ((u >> j) << (j + 1)) | (1u << j) | (u & ((1u << j) - 1u));
-      acc = add_full_inl(acc, load_pod(R + t));
+      acc = add_full_inl(acc, load_pod(group_out + t));
     }
   } else {
-    const XYZZ<F> *T = group_out + ((size_t)k * 2 + 1) * ng;
-    uint32_t h = j - nglog, lo = h * ng / 2, hi = (h + 1) * ng / 2;
-    for (uint32_t t = lo + threadIdx.x; t < hi; t += MSM_THREADS) acc = add_full_inl(acc, load_pod(T + t));
+    const XYZZ<F> *T = group_out + (size_t)ng;
+    const uint32_t h = j - nglog, lo = h * ng / 2, len = (h + 1) * ng / 2 - lo;
+    const uint32_t t0 = lo + (uint32_t)((uint64_t)len * q / g.S), t1 = lo + (uint32_t)((uint64_t)len * (q + 1) / g.S);
+    for (uint32_t t = t0 + threadIdx.x; t < t1; t += MSM_THREADS) acc = add_full_inl(acc, load_pod(T + t));
   }
   sh[threadIdx.x] = acc;
   __syncthreads();
@@ -416,29 +493,52 @@ static __global__ __launch_bounds__(MSM_THREADS, MINW) void msm_reduce2_kernel(c
   if (threadIdx.x == 0) store_pod(task_out + blockIdx.x, sh[0]);
 }
 
-// 16 lanes per window (4 windows per wavefront): lane j < nglog turns Q_j into 2^(j+glog) Q_j by doublings,
-// lanes nglog, nglog+1 carry the T halves; a 4-level LDS tree adds the 16 lanes.  (A single-lane Horner would
-// chain nglog additions behind the doublings.)
-constexpr int RED3_LANES = 16;
+// one workgroup of MSM_THREADS lanes; needs ntask * S <= MSM_THREADS (msm_plan guarantees it)
 template <class F, int MINW>
-static __global__ __launch_bounds__(64, MINW) void msm_reduce3_kernel(const XYZZ<F> *task_out, MsmGeom g, XYZZ<F> *window_out) {
+static __global__ __launch_bounds__(MSM_THREADS, MINW) void msm_reduce3_kernel(const XYZZ<F> *task_out, MsmGeom g, XYZZ<F> *result) {
   __builtin_amdgcn_s_setprio(3);
-  __shared__ XYZZ<F> sh[64];
-  const uint32_t lane = threadIdx.x % RED3_LANES, k = blockIdx.x * (64 / RED3_LANES) + threadIdx.x / RED3_LANES;
-  const uint32_t nglog = (uint32_t)(g.c - 1 - g.glog);
-  XYZZ<F> acc = XYZZ<F>::inf();
-  if (k < (uint32_t)g.K && lane < nglog + 2) {
-    acc = load_pod(task_out + (size_t)k * (nglog + 2) + lane);
-    if (lane < nglog)
-      for (uint32_t j = 0; j < lane + (uint32_t)g.glog; j++) acc = dbl_xyzz_inl(acc);
-  }
-  sh[threadIdx.x] = acc;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  XYZZ<F> *sh = reinterpret_cast<XYZZ<F> *>(smem);
+  const uint32_t nglog = (uint32_t)(g.c - 1 - g.glog), ntask = nglog + 2, S = g.S;
+  const uint32_t j = threadIdx.x / S, q = threadIdx.x % S;
+  sh[threadIdx.x] = j < ntask ? load_pod(task_out + threadIdx.x) : XYZZ<F>::inf();
   __syncthreads();
-  for (uint32_t s = RED3_LANES / 2; s > 0; s >>= 1) {
-    if (lane < s) sh[threadIdx.x] = add_full_inl(sh[threadIdx.x], sh[threadIdx.x + s]);
+  uint32_t s = 1;
+  while (s < S) s <<= 1;
+  for (s >>= 1; s > 0; s >>= 1) {  // the S splits of one task (S need not be a power of two)
+    if (j < ntask && q < s && q + s < S) sh[threadIdx.x] = add_full_inl(sh[threadIdx.x], sh[threadIdx.x + s]);
     __syncthreads();
   }
-  if (lane == 0 && k < (uint32_t)g.K) store_pod(window_out + k, sh[threadIdx.x]);
+  XYZZ<F> acc = XYZZ<F>::inf();
+  if (threadIdx.x < ntask) {  // lane = task
+    acc = sh[threadIdx.x * S];
+    if (threadIdx.x < nglog)
+      for (uint32_t d = 0; d < threadIdx.x + (uint32_t)g.glog; d++) acc = dbl_xyzz_inl(acc);
+  }
+  __syncthreads();
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (s = 16; s > 0; s >>= 1) {  // ntask <= 32
+    if (threadIdx.x < s) sh[threadIdx.x] = add_full_inl(sh[threadIdx.x], sh[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) store_pod(result, sh[0]);
+}
+
+// ---------------------------------------------------------------- window tables (key load)
+// tbl[k * n + i] = 2^(ck) * tbl[i] for k = 1..K-1, affine.  Thread per base point; one field inversion per
+// stored multiple (key-load time only).  The groups have odd order, so a multiple of a finite point is finite.
+template <class F, int MINW>
+static __global__ __launch_bounds__(MSM_THREADS, MINW) void msm_precompute_kernel(Affine<F> *tbl, uint32_t n, int c, int K) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Affine<F> p = load_pod(tbl + i);
+  for (int k = 1; k < K; k++) {
+    XYZZ<F> x = dbl_affine(p);
+    for (int b = 1; b < c; b++) x = dbl_xyzz(x);
+    p = to_affine(x);
+    store_pod(tbl + (size_t)k * n + i, p);
+  }
 }
 
 // ---------------------------------------------------------------- device-side setup

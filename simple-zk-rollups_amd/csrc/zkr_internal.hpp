@@ -32,21 +32,28 @@ struct ArenaHeader {
   uint32_t tlog;       // twiddle table entries = 2^tlog (= m)
   uint64_t off_tw, off_twl;
   uint64_t off_rowptr[2], off_col[2], off_coef[2];
-  uint64_t off_pts[N_TABLES], off_sidx[N_TABLES];
+  uint64_t off_pts[N_TABLES], off_rank[N_TABLES];  // rank: u32 per scalar of the table's vector -> index of its point, RANK_NONE if dropped
   uint8_t alfa1[64], beta1[64], delta1[64];  // Montgomery affine, as in the websnark key header
   uint8_t beta2[128], delta2[128];
   uint32_t share_b;    // B1 and B2 keep the same signals (always true for honest keys): one digit sort serves both
-  uint8_t pad[60];
+  uint32_t win_c[N_TABLES];  // window bits of each table: off_pts[t] holds K = ceil(255/c) x npts[t] points, level k = 2^(ck) * base
+  uint8_t pad[40];
 };
 static_assert(sizeof(ArenaHeader) <= 1024, "header fits its slot");
 constexpr size_t ARENA_HEADER_BYTES = 1024;
 constexpr uint64_t ARENA_MAGIC = 0x313059454b524b5aull;
 
+// digit records of one scalar vector, split by bucket range (kernels_msm.cuh "digit sort", stage 1)
+struct DigitLists {
+  uint32_t *rng = nullptr;  // [MAX_RANGES] counts | [MAX_RANGES] fill cursors | [MAX_RANGES + 1] offsets
+  uint32_t *ent_s = nullptr, *ent_b = nullptr;
+};
+
 struct MsmWorkspace {
   uint32_t *counts = nullptr, *offsets = nullptr, *entries = nullptr;
   uint32_t *size_hist = nullptr, *order = nullptr;  // [2][SIZE_BINS] size-class histogram + hand-out counters; bucket ids fullest first
   uint32_t *chunk_cnt = nullptr;  // [K][J][nbw] per-chunk bucket occupancies, then per-bucket prefixes over chunks
-  uint16_t *own_dig = nullptr;    // digit codes when the workspace is not attached to a key (stage hooks)
+  DigitLists own_dig;             // digit records when the workspace is not attached to a key (stage hooks)
   uint32_t *big_list = nullptr, *big_count = nullptr, *block_sums = nullptr;
   void *big_partials = nullptr;
   void *buckets = nullptr, *group_out = nullptr, *task_out = nullptr, *window_out = nullptr;
@@ -66,8 +73,10 @@ struct ProfSpan {
 
 struct MsmPlan {
   int c, K, glog;
-  uint32_t nbw, nb, big_thresh;
-  uint32_t J, chunk;  // digit sort: J chunks of `chunk` points per window
+  uint32_t nbw, nb, big_thresh;  // nb = nbw = 2^(c-1) buckets, one set shared by the K windows
+  uint32_t nR, nbl;   // digit sort: nR bucket ranges of nbl buckets (LDS counters of one workgroup)
+  uint32_t J;         // digit sort: J chunks per bucket range
+  uint32_t S;         // reduction: workgroups per task in msm_reduce2_kernel
 };
 
 }  // namespace zkr
@@ -79,7 +88,7 @@ namespace zkr {
 constexpr int PROOF_SLOTS = 2;
 struct ProofSlot {
   Fr *d_wraw = nullptr, *d_w = nullptr, *va = nullptr, *vb = nullptr, *ca = nullptr, *cb = nullptr, *d_h = nullptr;
-  uint16_t *dig_w = nullptr, *dig_h = nullptr;  // signed-digit codes of w (shared by A, B1, B2, C) and of h, window-major
+  DigitLists dig_w, dig_h;  // digit records of w (shared by A, B1, B2, C) and of h
   MsmWorkspace ws[N_TABLES];
   hipEvent_t ev_w = nullptr, ev_h = nullptr, ev_fin = nullptr;
   hipEvent_t ev_done[N_TABLES] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -127,5 +136,8 @@ void prof_end(Prof pf, hipStream_t s, int span);
 int prof_collect(zkr_key *k, ProofSlot &sl);
 int run_ntt(hipStream_t s, const Fr *in0, const Fr *in1, Fr *out, const Fr *tw, const Fr *twl, int tlog, int L, bool dif, bool inverse, int pre);
 int calc_h_device(zkr_key *k, ProofSlot &sl, hipStream_t s);  // sl.d_w -> sl.d_h (bit-reversed)
-MsmPlan msm_plan(size_t n_scalars, size_t n_points);
+MsmPlan msm_plan(size_t n_scalars, size_t n_points, int c_fixed = 0);
+int digit_lists_alloc(DigitLists &dl, size_t n_scalars, const MsmPlan &pl);
+void digit_lists_free(DigitLists &dl);
+int msm_precompute(int device, bool g2, void *d_table, uint32_t n, const MsmPlan &pl);  // fills levels 1..K-1 of a table whose level 0 is in place
 }  // namespace zkr

@@ -43,32 +43,41 @@ static Fr fr_root_of_unity(unsigned k) {
 Fr host_root_of_unity(unsigned k) { return fr_root_of_unity(k); }
 
 // Window size from the length of the SCALAR vector (tables that share scalars share the digit codes,
-// kernels_msm.cuh msm_digits_kernel); chunking and the oversized-bucket threshold from the table itself.
-MsmPlan msm_plan(size_t n_scalars, size_t n) {
+// kernels_msm.cuh msm_digits_kernel) unless the key fixes it (c_fixed: the window tables in the arena were built
+// for that c); chunking and the oversized-bucket threshold from the table itself.
+MsmPlan msm_plan(size_t n_scalars, size_t n, int c_fixed) {
   MsmPlan pl;
   int lg = 0;
   while (((size_t)1 << lg) < n_scalars) lg++;
-  int c = lg - 4;
+  int c = lg;  // 2^(c-1) buckets for ~n * 255/c entries: a few dozen entries per bucket
   if (c < 4) c = 4;
-  if (c > 16) c = 16;
-  if (const char *e = getenv("ZKR_MSM_C")) { int v = atoi(e); if (v >= 2 && v <= 20) c = v; }
+  if (c > 20) c = 20;
+  if (const char *e = getenv("ZKR_MSM_C")) { int v = atoi(e); if (v >= 2 && v <= 22) c = v; }
+  if (c_fixed) c = c_fixed;
   pl.c = c;
   pl.K = (255 + c - 1) / c;
   pl.nbw = 1u << (c - 1);
-  pl.nb = pl.nbw * (uint32_t)pl.K;
+  pl.nb = pl.nbw;
   pl.glog = c - 1 < 3 ? c - 1 : 3;  // bucket reduction: groups of 8 buckets (kernels_msm.cuh msm_reduce1_kernel)
-  uint32_t mean = (uint32_t)(n / pl.nbw) + 1;
-  pl.big_thresh = mean * 8 > 256 ? mean * 8 : 256;
+  uint64_t mean = (uint64_t)n * pl.K / pl.nbw + 1;
+  pl.big_thresh = mean * 8 > 256 ? (uint32_t)(mean * 8) : 256;
   if (const char *e = getenv("ZKR_MSM_BIG")) { int v = atoi(e); if (v >= 1) pl.big_thresh = (uint32_t)v; }
-  // one workgroup per (window, chunk): about one per CU at full size, never chunks smaller than 4096 points
+  // digit sort: one workgroup per (bucket range, chunk): about one per CU at full size, chunks of >= 4096 points
+  pl.nbl = pl.nbw < SORT_RANGE_MAX ? pl.nbw : SORT_RANGE_MAX;
+  pl.nR = pl.nbw / pl.nbl;
   uint32_t J = (uint32_t)((n + 4095) / 4096);
-  uint32_t jmax = (uint32_t)(256 / pl.K) ? (uint32_t)(256 / pl.K) : 1u;
+  uint32_t jmax = 256 / pl.nR ? 256 / pl.nR : 1u;
   if (J > jmax) J = jmax;
   if (J < 1) J = 1;
   if (const char *e = getenv("ZKR_MSM_J")) { int v = atoi(e); if (v >= 1 && v <= 256) J = (uint32_t)v; }
   pl.J = J;
-  pl.chunk = (uint32_t)((n + J - 1) / J);
-  if (pl.chunk == 0) pl.chunk = 1;
+  // reduction: every task sums ng/2 .. ng group results; one workgroup per 2048 of them, all tasks together at
+  // most one workgroup per CU (msm_reduce3_kernel takes ntask * S <= MSM_THREADS partial sums)
+  uint32_t ng = pl.nbw >> pl.glog, ntask = (uint32_t)(c - 1 - pl.glog) + 2;
+  uint32_t S = (ng + 2047) / 2048;
+  if (S > 16) S = 16;
+  if (S > MSM_THREADS / ntask) S = MSM_THREADS / ntask;
+  pl.S = S < 1 ? 1 : S;
   return pl;
 }
 
@@ -78,24 +87,34 @@ static int alloc_msm_ws(MsmWorkspace &ws, size_t n, const MsmPlan &pl, size_t xy
   ZKR_HIP_CHECK(hipMalloc(&ws.offsets, (nb + 1) * 4));
   ZKR_HIP_CHECK(hipMalloc(&ws.size_hist, 2 * SIZE_BINS * 4));
   ZKR_HIP_CHECK(hipMalloc(&ws.order, (nb + 1) * 4));
-  ZKR_HIP_CHECK(hipMalloc(&ws.chunk_cnt, (size_t)pl.K * pl.J * pl.nbw * 4 + 4));
+  ZKR_HIP_CHECK(hipMalloc(&ws.chunk_cnt, (size_t)pl.J * pl.nbw * 4 + 4));
   ZKR_HIP_CHECK(hipMalloc(&ws.entries, (n * pl.K + 1) * 4));
   ZKR_HIP_CHECK(hipMalloc(&ws.big_list, BIG_CAP * 4));
   ZKR_HIP_CHECK(hipMalloc(&ws.big_count, 8));
   ZKR_HIP_CHECK(hipMalloc(&ws.block_sums, (nb / SCAN_BLOCK + 2) * 4));
   ZKR_HIP_CHECK(hipMalloc(&ws.big_partials, (size_t)BIG_CAP * BIG_SPLIT * xyzz_bytes));
   ZKR_HIP_CHECK(hipMalloc(&ws.buckets, nb * xyzz_bytes));
-  ZKR_HIP_CHECK(hipMalloc(&ws.group_out, (size_t)(pl.nbw >> pl.glog) * 2 * pl.K * xyzz_bytes));
-  ZKR_HIP_CHECK(hipMalloc(&ws.task_out, (size_t)(pl.c + 2) * pl.K * xyzz_bytes));
+  ZKR_HIP_CHECK(hipMalloc(&ws.group_out, (size_t)(pl.nbw >> pl.glog) * 2 * xyzz_bytes));
+  ZKR_HIP_CHECK(hipMalloc(&ws.task_out, (size_t)(pl.c + 2) * pl.S * xyzz_bytes));
   ZKR_HIP_CHECK(hipMalloc(&ws.window_out, MSM_MAX_WINDOWS * xyzz_bytes));
   ZKR_HIP_CHECK(hipHostMalloc(&ws.h_window, MSM_MAX_WINDOWS * xyzz_bytes, hipHostMallocDefault));
   ws.max_nb = nb;
   ws.max_entries = n * pl.K;
   return 0;
 }
+int digit_lists_alloc(DigitLists &dl, size_t n_scalars, const MsmPlan &pl) {
+  ZKR_HIP_CHECK(hipMalloc(&dl.rng, (3 * MAX_RANGES + 1) * 4));
+  ZKR_HIP_CHECK(hipMalloc(&dl.ent_s, (size_t)pl.K * n_scalars * 4 + 4));
+  ZKR_HIP_CHECK(hipMalloc(&dl.ent_b, (size_t)pl.K * n_scalars * 4 + 4));
+  return 0;
+}
+void digit_lists_free(DigitLists &dl) {
+  hipFree(dl.rng); hipFree(dl.ent_s); hipFree(dl.ent_b);
+  dl = DigitLists();
+}
 int msm_ws_alloc(MsmWorkspace &ws, size_t n, const MsmPlan &pl, size_t xyzz_bytes) { return alloc_msm_ws(ws, n, pl, xyzz_bytes); }
 void msm_ws_free(MsmWorkspace &ws) {
-  hipFree(ws.counts); hipFree(ws.offsets); hipFree(ws.chunk_cnt); hipFree(ws.size_hist); hipFree(ws.order); hipFree(ws.own_dig); hipFree(ws.entries); hipFree(ws.big_list); hipFree(ws.big_count); hipFree(ws.block_sums); hipFree(ws.big_partials);
+  hipFree(ws.counts); hipFree(ws.offsets); hipFree(ws.chunk_cnt); hipFree(ws.size_hist); hipFree(ws.order); digit_lists_free(ws.own_dig); hipFree(ws.entries); hipFree(ws.big_list); hipFree(ws.big_count); hipFree(ws.block_sums); hipFree(ws.big_partials);
   hipFree(ws.buckets); hipFree(ws.group_out); hipFree(ws.task_out); hipFree(ws.window_out);
   if (ws.h_window) hipHostFree(ws.h_window);
   ws = MsmWorkspace();
@@ -109,7 +128,7 @@ int key_alloc_workspace(zkr_key *k) {
   ZKR_HIP_CHECK(hipStreamCreateWithFlags(&k->red_stream[0], hipStreamNonBlocking));
   if (getenv("ZKR_FOUR_STREAMS")) ZKR_HIP_CHECK(hipStreamCreateWithFlags(&k->red_stream[1], hipStreamNonBlocking));
   else k->red_stream[1] = k->ntt_stream;  // calcH is long finished when the first G1 table needs its reduction
-  for (int t = 0; t < N_TABLES; t++) k->plan[t] = msm_plan(t == T_H ? h.m : h.n, h.npts[t]);
+  for (int t = 0; t < N_TABLES; t++) k->plan[t] = msm_plan(t == T_H ? h.m : h.n, h.npts[t], (int)h.win_c[t]);
   for (ProofSlot &sl : k->slot) {
     for (int t = 0; t < N_TABLES; t++) {
       ZKR_HIP_CHECK(hipEventCreateWithFlags(&sl.ev_done[t], hipEventDisableTiming));
@@ -126,9 +145,21 @@ int key_alloc_workspace(zkr_key *k) {
       int rc = alloc_msm_ws(sl.ws[t], h.npts[t], k->plan[t], t == T_B2 ? sizeof(G2XYZZ) : sizeof(G1XYZZ));
       if (rc) return rc;
     }
-    ZKR_HIP_CHECK(hipMalloc(&sl.dig_w, (size_t)k->plan[T_A].K * h.n * 2 + 2));
-    ZKR_HIP_CHECK(hipMalloc(&sl.dig_h, (size_t)k->plan[T_H].K * h.m * 2 + 2));
+    int rc = digit_lists_alloc(sl.dig_w, h.n, k->plan[T_A]);
+    if (!rc) rc = digit_lists_alloc(sl.dig_h, h.m, k->plan[T_H]);
+    if (rc) return rc;
   }
+  return 0;
+}
+
+int msm_precompute(int device, bool g2, void *d_table, uint32_t n, const MsmPlan &pl) {
+  if (n == 0 || pl.K < 2) return 0;
+  ZKR_HIP_CHECK(hipSetDevice(device));
+  unsigned grid = (n + MSM_THREADS - 1) / MSM_THREADS;
+  if (g2) msm_precompute_kernel<Fq2, 1><<<grid, MSM_THREADS>>>((G2Affine *)d_table, n, pl.c, pl.K);
+  else msm_precompute_kernel<Fq, 2><<<grid, MSM_THREADS>>>((G1Affine *)d_table, n, pl.c, pl.K);
+  ZKR_HIP_CHECK(hipGetLastError());
+  ZKR_HIP_CHECK(hipDeviceSynchronize());
   return 0;
 }
 
@@ -159,11 +190,14 @@ int key_build(int device, uint32_t n, uint32_t p, uint32_t m, const std::vector<
     h.off_col[s] = take(col[s].size() * 4 + 4);
     h.off_coef[s] = take(coef[s].size() + 32);
   }
+  MsmPlan plan[N_TABLES];
   for (int t = 0; t < N_TABLES; t++) {
     h.npts[t] = (uint32_t)tbl_srcidx[t].size();
+    plan[t] = msm_plan(t == T_H ? m : n, h.npts[t]);
+    h.win_c[t] = (uint32_t)plan[t].c;
     size_t pb = t == T_B2 ? 128 : 64;
-    h.off_pts[t] = take((size_t)h.npts[t] * pb + pb);
-    h.off_sidx[t] = take((size_t)h.npts[t] * 4 + 4);
+    h.off_pts[t] = take((size_t)h.npts[t] * plan[t].K * pb + pb);  // K window levels per base point
+    h.off_rank[t] = take((size_t)(t == T_H ? m : n) * 4 + 4);
   }
   h.total_len = off;
   h.share_b = tbl_sidx[T_B1] == tbl_sidx[T_B2] ? 1 : 0;
@@ -181,7 +215,11 @@ int key_build(int device, uint32_t n, uint32_t p, uint32_t m, const std::vector<
   for (int t = 0; t < N_TABLES; t++) {
     size_t np = h.npts[t], pb = t == T_B2 ? 128 : 64;
     if (!np) continue;
-    ZKR_HIP_CHECK(hipMemcpy(arena + h.off_sidx[t], tbl_sidx[t].data(), np * 4, hipMemcpyHostToDevice));
+    {  // scalar index -> point index (RANK_NONE: the key has the point at infinity there)
+      std::vector<uint32_t> rank(t == T_H ? m : n, RANK_NONE);
+      for (size_t j = 0; j < np; j++) rank[tbl_sidx[t][j]] = (uint32_t)j;
+      ZKR_HIP_CHECK(hipMemcpy(arena + h.off_rank[t], rank.data(), rank.size() * 4, hipMemcpyHostToDevice));
+    }
     if (tbl_src_on_device[t]) {
       uint32_t *d_idx = nullptr;
       ZKR_HIP_CHECK(hipMalloc(&d_idx, np * 4));
@@ -200,6 +238,8 @@ int key_build(int device, uint32_t n, uint32_t p, uint32_t m, const std::vector<
       for (size_t j = 0; j < np; j++) memcpy(&stage[j * pb], src + (size_t)tbl_srcidx[t][j] * pb, pb);
       ZKR_HIP_CHECK(hipMemcpy(arena + h.off_pts[t], stage.data(), np * pb, hipMemcpyHostToDevice));
     }
+    int rc = msm_precompute(device, t == T_B2, arena + h.off_pts[t], (uint32_t)np, plan[t]);
+    if (rc) { hipFree(arena); return rc; }
   }
   // twiddles on device: T[k] = w_{2m}^k and w_2048^k
   twiddle_table_kernel<<<(m + 255) / 256, 256>>>((Fr *)(arena + h.off_tw), m, fr_root_of_unity(h.logm + 1));
@@ -375,7 +415,7 @@ void zkr_key_free(zkr_key *k) {
     if (sl.ev_w) hipEventDestroy(sl.ev_w);
     if (sl.ev_h) hipEventDestroy(sl.ev_h);
     if (sl.ev_fin) hipEventDestroy(sl.ev_fin);
-    hipFree(sl.dig_w); hipFree(sl.dig_h);
+    digit_lists_free(sl.dig_w); digit_lists_free(sl.dig_h);
     hipFree(sl.d_wraw); hipFree(sl.d_w); hipFree(sl.va); hipFree(sl.vb); hipFree(sl.ca); hipFree(sl.cb); hipFree(sl.d_h);
     for (auto e : sl.event_pool) hipEventDestroy(e);
   }

@@ -161,17 +161,22 @@ template <class F> struct MsmCfg;
 template <> struct MsmCfg<Fq> { static constexpr int ACC_W = 4, RED_W = 2; static constexpr const char *ACC_STAGE = "msm_accum_g1"; };
 template <> struct MsmCfg<Fq2> { static constexpr int ACC_W = 2, RED_W = 1; static constexpr const char *ACC_STAGE = "msm_accum_g2"; };
 
-// signed-digit codes of one scalar vector (window-major u16), shared by every table over those scalars
-static int msm_digits_enqueue(Prof pf, hipStream_t s, const Fr *scalars, uint32_t n, const MsmPlan &pl, uint16_t *dig) {
+// digit records of one scalar vector, split by bucket range; shared by every table over those scalars
+static int msm_digits_enqueue(Prof pf, hipStream_t s, const Fr *scalars, uint32_t n, const MsmPlan &pl, const DigitLists &dl) {
   if (n == 0) return 0;
+  int nbl_log = 0;
+  while ((1u << nbl_log) < pl.nbl) nbl_log++;
   int sp = prof_begin(pf, s, "msm_sort");
-  msm_digits_kernel<<<(n + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, s>>>(scalars, n, pl.c, pl.K, (size_t)n, dig);
+  ZKR_HIP_CHECK(hipMemsetAsync(dl.rng, 0, 2 * MAX_RANGES * 4, s));
+  unsigned grid = (n + MSM_THREADS - 1) / MSM_THREADS;
+  msm_digits_count_kernel<<<grid, MSM_THREADS, 0, s>>>(scalars, n, pl.c, pl.K, nbl_log, pl.nR, dl.rng);
+  msm_digits_scatter_kernel<<<grid, MSM_THREADS, 0, s>>>(scalars, n, pl.c, pl.K, nbl_log, pl.nR, dl.rng, dl.rng + MAX_RANGES, dl.rng + 2 * MAX_RANGES, dl.ent_s, dl.ent_b);
   prof_end(pf, s, sp);
   ZKR_HIP_CHECK(hipGetLastError());
   return 0;
 }
 
-// the window's bucket counters / cursors live in LDS: 4 * 2^(c-1) bytes, up to 128 KB (> the 64 KB default cap)
+// a range's bucket counters / cursors live in LDS: up to 4 * 2^15 bytes = 128 KB (> the 64 KB default cap)
 static int sort_lds_opt_in() {
   static int rc = [] {
     hipError_t e = hipFuncSetAttribute((const void *)msm_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
@@ -183,24 +188,25 @@ static int sort_lds_opt_in() {
 }
 
 // digit sort of one table: LDS histogram per (window, chunk) -> scans -> LDS-cursor scatter
-static int msm_sort_enqueue(Prof pf, hipStream_t s, const uint32_t *sidx, const uint16_t *dig, size_t dig_stride, uint32_t n, const MsmPlan &pl, MsmWorkspace &ws) {
+static int msm_sort_enqueue(Prof pf, hipStream_t s, const uint32_t *rank, const DigitLists &dl, uint32_t n, const MsmPlan &pl, MsmWorkspace &ws) {
   if (n == 0) return 0;
   int rc = sort_lds_opt_in();
   if (rc) return rc;
   int sp = prof_begin(pf, s, "msm_sort");
   ZKR_HIP_CHECK(hipMemsetAsync(ws.big_count, 0, 8, s));
   ZKR_HIP_CHECK(hipMemsetAsync(ws.size_hist, 0, 2 * SIZE_BINS * 4, s));
-  const unsigned sort_grid = (unsigned)pl.K * pl.J;
-  const size_t lds = (size_t)pl.nbw * 4;
-  msm_hist_kernel<<<sort_grid, SORT_THREADS, lds, s>>>(dig, dig_stride, sidx, n, pl.K, pl.nbw, pl.J, pl.chunk, ws.chunk_cnt);
-  msm_colscan_kernel<<<(pl.nb + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, s>>>(ws.chunk_cnt, pl.nb, pl.nbw, pl.J, ws.counts);
+  const unsigned sort_grid = pl.nR * pl.J;
+  const size_t lds = (size_t)pl.nbl * 4;
+  const uint32_t *rng_off = dl.rng + 2 * MAX_RANGES;
+  msm_hist_kernel<<<sort_grid, SORT_THREADS, lds, s>>>(dl.ent_s, dl.ent_b, rng_off, rank, pl.nbl, pl.J, ws.chunk_cnt);
+  msm_colscan_kernel<<<(pl.nb + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, s>>>(ws.chunk_cnt, pl.nb, pl.nbl, pl.J, ws.counts);
   unsigned scan_blocks = (pl.nb + SCAN_BLOCK - 1) / SCAN_BLOCK;
   msm_scan_sums_kernel<<<scan_blocks, SCAN_THREADS, 0, s>>>(ws.counts, pl.nb, ws.block_sums);
   msm_scan_top_kernel<<<1, 1024, 0, s>>>(ws.block_sums, scan_blocks, ws.big_count + 1);
   msm_scan_apply_kernel<<<scan_blocks, SCAN_THREADS, 0, s>>>(ws.counts, ws.block_sums, ws.big_count + 1, ws.offsets, pl.nb, pl.big_thresh,
                                                             ws.big_list, ws.big_count, BIG_CAP, ws.size_hist);
   msm_order_kernel<<<scan_blocks, SCAN_THREADS, 0, s>>>(ws.counts, pl.nb, ws.size_hist, ws.size_hist + SIZE_BINS, ws.order);
-  msm_scatter_kernel<<<sort_grid, SORT_THREADS, lds, s>>>(dig, dig_stride, sidx, n, pl.K, pl.nbw, pl.J, pl.chunk, ws.chunk_cnt, ws.offsets, ws.entries);
+  msm_scatter_kernel<<<sort_grid, SORT_THREADS, lds, s>>>(dl.ent_s, dl.ent_b, rng_off, rank, n, pl.nbl, pl.J, ws.chunk_cnt, ws.offsets, ws.entries);
   prof_end(pf, s, sp);
   ZKR_HIP_CHECK(hipGetLastError());
   return 0;
@@ -237,46 +243,40 @@ template <class F>
 static int msm_reduce_enqueue(Prof pf, hipStream_t s, uint32_t n, const MsmPlan &pl, const MsmWorkspace &srt, MsmWorkspace &ws) {
   if (n == 0) return 0;
   MsmGeom g;
-  g.n = n; g.c = pl.c; g.K = pl.K; g.nbw = pl.nbw; g.big_thresh = pl.big_thresh; g.glog = pl.glog;
+  g.n = n; g.c = pl.c; g.K = pl.K; g.nbw = pl.nbw; g.big_thresh = pl.big_thresh; g.glog = pl.glog; g.S = pl.S;
   int sp = prof_begin(pf, s, "msm_big");
   msm_big_finish_kernel<F, MsmCfg<F>::RED_W><<<BIG_CAP / 64, 64, 0, s>>>((const XYZZ<F> *)ws.big_partials, srt.big_list, srt.big_count, BIG_CAP, (XYZZ<F> *)ws.buckets);
   prof_end(pf, s, sp);
   sp = prof_begin(pf, s, "msm_reduce");
-  uint32_t ngroups = (pl.nbw >> pl.glog) * (uint32_t)pl.K;
+  uint32_t ngroups = pl.nbw >> pl.glog;
   uint32_t ntask = (uint32_t)(pl.c - 1 - pl.glog) + 2;
   msm_reduce1_kernel<F, MsmCfg<F>::RED_W><<<(ngroups + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, s>>>((const XYZZ<F> *)ws.buckets, g, (XYZZ<F> *)ws.group_out);
-  msm_reduce2_kernel<F, MsmCfg<F>::RED_W><<<(unsigned)pl.K * ntask, MSM_THREADS, MSM_THREADS * sizeof(XYZZ<F>), s>>>((const XYZZ<F> *)ws.group_out, g, (XYZZ<F> *)ws.task_out);
-  msm_reduce3_kernel<F, MsmCfg<F>::RED_W><<<((unsigned)pl.K * RED3_LANES + 63) / 64, 64, 0, s>>>((const XYZZ<F> *)ws.task_out, g, (XYZZ<F> *)ws.window_out);
+  msm_reduce2_kernel<F, MsmCfg<F>::RED_W><<<ntask * pl.S, MSM_THREADS, MSM_THREADS * sizeof(XYZZ<F>), s>>>((const XYZZ<F> *)ws.group_out, g, (XYZZ<F> *)ws.task_out);
+  msm_reduce3_kernel<F, MsmCfg<F>::RED_W><<<1, MSM_THREADS, MSM_THREADS * sizeof(XYZZ<F>), s>>>((const XYZZ<F> *)ws.task_out, g, (XYZZ<F> *)ws.window_out);
   prof_end(pf, s, sp);
-  ZKR_HIP_CHECK(hipMemcpyAsync(ws.h_window, ws.window_out, (size_t)pl.K * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, s));
+  ZKR_HIP_CHECK(hipMemcpyAsync(ws.h_window, ws.window_out, sizeof(XYZZ<F>), hipMemcpyDeviceToHost, s));
   ZKR_HIP_CHECK(hipGetLastError());
   return 0;
 }
 
-// stage-hook path: one table with its own scalars (n_scalars of them; sidx maps kept points to scalars)
+// stage-hook path: one table with its own scalars (n_scalars of them; rank maps scalars to kept points)
 template <class F>
-static int msm_enqueue(Prof pf, hipStream_t s, const Affine<F> *pts, const uint32_t *sidx, const Fr *scalars, uint32_t n_scalars, uint32_t n,
+static int msm_enqueue(Prof pf, hipStream_t s, const Affine<F> *pts, const uint32_t *rank, const Fr *scalars, uint32_t n_scalars, uint32_t n,
                        const MsmPlan &pl, MsmWorkspace &ws) {
-  if (!ws.own_dig) ZKR_HIP_CHECK(hipMalloc(&ws.own_dig, (size_t)pl.K * n_scalars * 2 + 2));
-  int rc = msm_digits_enqueue(pf, s, scalars, n_scalars, pl, ws.own_dig);
-  if (rc) return rc;
-  if ((rc = msm_sort_enqueue(pf, s, sidx, ws.own_dig, n_scalars, n, pl, ws))) return rc;
+  int rc;
+  if (!ws.own_dig.rng && (rc = digit_lists_alloc(ws.own_dig, n_scalars, pl))) return rc;
+  if ((rc = msm_digits_enqueue(pf, s, scalars, n_scalars, pl, ws.own_dig))) return rc;
+  if ((rc = msm_sort_enqueue(pf, s, rank, ws.own_dig, n, pl, ws))) return rc;
   if ((rc = msm_big_enqueue<F>(pf, s, pts, n, pl, ws, ws))) return rc;
   if ((rc = msm_accum_enqueue<F>(pf, s, pts, n, pl, ws, ws))) return rc;
   return msm_reduce_enqueue<F>(pf, s, n, pl, ws, ws);
 }
 
-// Horner over the K window sums (host): sum_k 2^(ck) W_k
+// the MSM result point as the reduction left it in the pinned host buffer
 template <class F>
-static XYZZ<F> msm_finish(uint32_t n, const MsmPlan &pl, const MsmWorkspace &ws) {
+static XYZZ<F> msm_finish(uint32_t n, const MsmWorkspace &ws) {
   if (n == 0) return XYZZ<F>::inf();
-  const XYZZ<F> *W = (const XYZZ<F> *)ws.h_window;
-  XYZZ<F> acc = W[pl.K - 1];
-  for (int k = pl.K - 2; k >= 0; k--) {
-    for (int b = 0; b < pl.c; b++) acc = dbl_xyzz(acc);
-    acc = add_full(acc, W[k]);
-  }
-  return acc;
+  return *(const XYZZ<F> *)ws.h_window;
 }
 
 static bool u256_lt(const uint32_t *a, const uint32_t *b) {
@@ -338,12 +338,11 @@ static int prove_submit(zkr_key *k, ProofSlot &sl, const Fr *d_wsrc, const uint8
   if (!serial) ZKR_HIP_CHECK(hipStreamWaitEvent(sn, sl.ev_w, 0));
   if ((rc = calc_h_device(k, sl, sn))) return rc;
   ZKR_HIP_CHECK(hipEventRecord(sl.ev_h, sn));
-  const uint16_t *dig[N_TABLES] = {sl.dig_w, sl.dig_w, sl.dig_w, sl.dig_w, sl.dig_h};
-  const size_t dig_stride[N_TABLES] = {h.n, h.n, h.n, h.n, h.m};
+  const DigitLists *dig[N_TABLES] = {&sl.dig_w, &sl.dig_w, &sl.dig_w, &sl.dig_w, &sl.dig_h};
   const bool share_b = h.share_b != 0 && h.npts[T_B1] == h.npts[T_B2];
   int sort_src[N_TABLES] = {T_A, T_B1, share_b ? T_B1 : T_B2, T_C, T_H};
   auto sort_table = [&](int t) -> int {
-    int rc = msm_sort_enqueue(pf, s, (const uint32_t *)(ar + h.off_sidx[t]), dig[t], dig_stride[t], h.npts[t], k->plan[t], sl.ws[t]);
+    int rc = msm_sort_enqueue(pf, s, (const uint32_t *)(ar + h.off_rank[t]), *dig[t], h.npts[t], k->plan[t], sl.ws[t]);
     if (rc) return rc;
     if (!serial) ZKR_HIP_CHECK(hipEventRecord(sl.ev_sorted[t], s));
     return 0;
@@ -405,11 +404,11 @@ static int prove_collect(zkr_key *k, ProofSlot &sl, uint8_t proof_out[256]) {
   ZKR_HIP_CHECK(hipEventSynchronize(sl.ev_fin));
   if (k->prof_on) prof_collect(k, sl);
   const uint8_t *rb = sl.rb, *sb = sl.sb;
-  G1XYZZ A = msm_finish<Fq>(h.npts[T_A], k->plan[T_A], sl.ws[T_A]);
-  G1XYZZ B1 = msm_finish<Fq>(h.npts[T_B1], k->plan[T_B1], sl.ws[T_B1]);
-  G2XYZZ B2 = msm_finish<Fq2>(h.npts[T_B2], k->plan[T_B2], sl.ws[T_B2]);
-  G1XYZZ C = msm_finish<Fq>(h.npts[T_C], k->plan[T_C], sl.ws[T_C]);
-  G1XYZZ H = msm_finish<Fq>(h.npts[T_H], k->plan[T_H], sl.ws[T_H]);
+  G1XYZZ A = msm_finish<Fq>(h.npts[T_A], sl.ws[T_A]);
+  G1XYZZ B1 = msm_finish<Fq>(h.npts[T_B1], sl.ws[T_B1]);
+  G2XYZZ B2 = msm_finish<Fq2>(h.npts[T_B2], sl.ws[T_B2]);
+  G1XYZZ C = msm_finish<Fq>(h.npts[T_C], sl.ws[T_C]);
+  G1XYZZ H = msm_finish<Fq>(h.npts[T_H], sl.ws[T_H]);
   G1XYZZ alfa1 = to_xyzz(load_g1(h.alfa1)), beta1 = to_xyzz(load_g1(h.beta1)), delta1 = to_xyzz(load_g1(h.delta1));
   G2XYZZ beta2 = to_xyzz(load_g2(h.beta2)), delta2 = to_xyzz(load_g2(h.delta2));
   U256 r = load_u256(rb), sc = load_u256(sb);
@@ -537,16 +536,16 @@ static int msm_hook(const void *points_mont, const void *scalars_std, size_t n, 
   ZKR_HIP_CHECK(hipSetDevice(device));
   const size_t pb = sizeof(Affine<F>);
   const uint8_t *pts = (const uint8_t *)points_mont;
-  std::vector<uint32_t> sidx;
+  std::vector<uint32_t> rank(n, RANK_NONE);
+  uint32_t np = 0;
   std::vector<uint8_t> compact;
   for (size_t i = 0; i < n; i++) {
     bool inf = true;
     for (size_t b = 0; b < pb / 2 && inf; b++) inf = pts[i * pb + b] == 0;
     if (inf) continue;
-    sidx.push_back((uint32_t)i);
+    rank[i] = np++;
     compact.insert(compact.end(), pts + i * pb, pts + (i + 1) * pb);
   }
-  uint32_t np = (uint32_t)sidx.size();
   XYZZ<F> res = XYZZ<F>::inf();
   if (np) {
     MsmPlan pl = msm_plan(n, np);
@@ -556,20 +555,21 @@ static int msm_hook(const void *points_mont, const void *scalars_std, size_t n, 
     Affine<F> *d_pts = nullptr;
     uint32_t *d_sidx = nullptr;
     Fr *d_sc = nullptr, *d_sc2 = nullptr;
-    ZKR_HIP_CHECK(hipMalloc(&d_pts, compact.size()));
-    ZKR_HIP_CHECK(hipMalloc(&d_sidx, (size_t)np * 4));
+    ZKR_HIP_CHECK(hipMalloc(&d_pts, compact.size() * pl.K));  // K window levels
+    ZKR_HIP_CHECK(hipMalloc(&d_sidx, n * 4));
     ZKR_HIP_CHECK(hipMalloc(&d_sc, n * 32));
     ZKR_HIP_CHECK(hipMalloc(&d_sc2, n * 32));
     ZKR_HIP_CHECK(hipMemcpy(d_pts, compact.data(), compact.size(), hipMemcpyHostToDevice));
-    ZKR_HIP_CHECK(hipMemcpy(d_sidx, sidx.data(), (size_t)np * 4, hipMemcpyHostToDevice));
+    ZKR_HIP_CHECK(hipMemcpy(d_sidx, rank.data(), n * 4, hipMemcpyHostToDevice));
     ZKR_HIP_CHECK(hipMemcpy(d_sc, scalars_std, n * 32, hipMemcpyHostToDevice));
+    if ((rc = msm_precompute(device, sizeof(F) != 32, d_pts, np, pl))) return rc;
     ingest_kernel<<<(unsigned)((n + 255) / 256), 256>>>(d_sc, d_sc2, n);
     rc = msm_enqueue<F>(Prof{nullptr, nullptr}, nullptr, d_pts, d_sidx, d_sc2, (uint32_t)n, np, pl, ws);
     if (!rc) {
       hipError_t e = hipDeviceSynchronize();
       if (e != hipSuccess) { set_error("msm failed: %s", hipGetErrorString(e)); rc = ZKR_ERR_HIP; }
     }
-    if (!rc) res = msm_finish<F>(np, pl, ws);
+    if (!rc) res = msm_finish<F>(np, ws);
     hipFree(d_pts); hipFree(d_sidx); hipFree(d_sc); hipFree(d_sc2);
     msm_ws_free(ws);
     if (rc) return rc;
