@@ -67,7 +67,8 @@ int zkr_key_adopt_arena(void *dev_ptr, size_t len, int device, zkr_key **out);
  * the reference does.  proof_out: 256 B = pi_a (x,y) | pi_b (x.re,x.im,y.re,y.im) | pi_c (x,y),
  * affine, standard form -- the eight integers groth16GenProof returns as decimal strings
  * (consumed at common.ts:31-32,44-48).
- * stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) or NULL for the key's own. */
+ * stream: the hipStream_t that produced the witness (e.g. torch.cuda.current_stream().cuda_stream; NULL = the
+ * default stream): the proof starts after the work already enqueued there and then runs on the key's own streams. */
 int zkr_prove(zkr_key *key, const void *witness_std, size_t witness_len, const uint8_t *r32, const uint8_t *s32,
               uint8_t proof_out[256], void *stream);
 

@@ -1,5 +1,5 @@
 """Per-kernel HBM traffic from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; rocpd SQLite output).
-python profiles/summarize_pmc.py <fetch.db> <write.db>
+python profiles/summarize_pmc.py <fetch.db> <write.db> [out.json log_m]
 Units/corrections as MI355X_MICROARCH.md "HBM" prescribes: FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950
 FETCH_SIZE reads exactly half of a wide (16 B/lane) coalesced stream, so reads are doubled; WRITE_SIZE is
 uncalibrated.  The ingest_kernel rows (known traffic: n*32 B read + n*32 B written, coalesced 16 B/lane)
@@ -35,3 +35,15 @@ for k in sorted(fetch, key=lambda k: -(2 * fetch[k][1] + write.get(k, [0, 0])[1]
     w = write.get(k, [n, 0.0])[1]
     fr, wr = f / n, w / max(write.get(k, [n])[0], 1)
     print("| `%s` | %d | %.0f | %.2f | %.0f | %.2f | %.2f |" % (k, n, fr, 2 * fr * 1024 / 1e6, wr, wr * 1024 / 1e6, (2 * fr + wr) * 1024 / 1e6))
+
+if len(sys.argv) > 3:
+    import json
+    out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pipeline (ZKR_SERIAL=1)",
+           "correction": "KiB units; FETCH_SIZE doubled on gfx950 (MI355X_MICROARCH.md HBM section); calibration row: ingest_kernel (n*32 B read + n*32 B written)",
+           "config": {"log_m": int(sys.argv[4]), "n_public": 73}, "round": 1, "kernels": {}}
+    for k in fetch:
+        n, f = fetch[k]
+        wn, w = write.get(k, [n, 0.0])
+        rb, wb = 2 * f / n * 1024, w / max(wn, 1) * 1024
+        out["kernels"][k] = {"launches": n, "read_bytes_per_launch": rb, "write_bytes_per_launch": wb, "hbm_bytes_per_launch": rb + wb}
+    json.dump(out, open(sys.argv[3], "w"), indent=1)

@@ -92,7 +92,7 @@ __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
 
 // ---------------------------------------------------------------- digit sort
 // Bucket id = |d| - 1 < 2^(c-1) of the signed c-bit digit d; the 2^(c-1) buckets are cut into nR ranges of nbl
-// <= 2^15 buckets, the number of 4-byte counters one workgroup keeps in LDS.
+// <= 2^13 buckets, the number of 4-byte counters one workgroup keeps in LDS.
 //
 // Stage 1, once per SCALAR VECTOR (w serves the A, B1, B2 and C tables, h serves H): every non-zero digit
 // becomes a record in the list of its bucket range -- ent_s = scalar index, ent_b = window << 17 | (bucket
@@ -169,11 +169,12 @@ static __global__ __launch_bounds__(MSM_THREADS) void msm_digits_scatter_kernel(
 }
 
 // Stages 2 and 4, per TABLE: one workgroup per (bucket range r, chunk j of that range's record list), bucket
-// counters / cursors in LDS (up to 128 KB, one workgroup per CU), so the 13.6 M increments of a 2^20-point MSM
+// counters / cursors in LDS (32 KB), so the 13.6 M increments of a 2^20-point MSM
 // are LDS atomics instead of L2/fabric atomics.  rank[s] = index of the table's point for scalar s, or
 // RANK_NONE when the table has none (point at infinity in the key: dropped at key build).
-constexpr int SORT_THREADS = 1024;
-constexpr uint32_t SORT_RANGE_MAX = 32768;  // bucket counters per workgroup (x 4 B of LDS)
+constexpr int SORT_THREADS = 256;
+constexpr uint32_t SORT_RANGE_MAX = 8192;  // bucket counters per workgroup (x 4 B of LDS): small footprint, so these
+                                           // memory/LDS-bound workgroups find room on CUs busy with an accumulation
 constexpr uint32_t RANK_NONE = 0xffffffffu;
 
 __device__ __forceinline__ void sort_chunk(const uint32_t *rng_off, uint32_t r, uint32_t j, uint32_t J, uint32_t &e0, uint32_t &e1) {
@@ -371,7 +372,7 @@ static __global__ __launch_bounds__(SCAN_THREADS) void msm_order_kernel(const ui
 // wavefront get buckets of (almost) equal occupancy, so no lane idles while another finishes, and the long
 // buckets start first.  The next entry and its point are fetched while the current addition runs.
 template <class F, int MINW>
-static __global__ __launch_bounds__(MSM_THREADS, MINW) void msm_accum_kernel(const Affine<F> *points, const uint32_t *offsets, const uint32_t *entries,
+static __global__ __launch_bounds__(MSM_THREADS) __attribute__((amdgpu_waves_per_eu(MINW, MINW))) void msm_accum_kernel(const Affine<F> *points, const uint32_t *offsets, const uint32_t *entries,
                                                                      uint32_t nb, const uint32_t *counts, const uint32_t *order, XYZZ<F> *buckets) {
   const uint32_t t = blockIdx.x * MSM_THREADS + threadIdx.x;
   if (t >= nb) return;

@@ -108,8 +108,8 @@ struct zkr_key {
   bool owns_arena = true;
   zkr::ArenaHeader h;
   hipStream_t stream = nullptr;
-  hipStream_t ntt_stream = nullptr;                // calcH beside the witness sorts, then the G1 reduction chains
-  hipStream_t red_stream[2] = {nullptr, nullptr};  // reduction chains of the G2 table / of the G1 tables ([1] is ntt_stream)
+  hipStream_t prep_stream = nullptr;               // digit records, digit sorts, calcH
+  hipStream_t red_stream[2] = {nullptr, nullptr};  // reduction chains of the G2 table / of the G1 tables (the same stream by default)
   zkr::ProofSlot slot[zkr::PROOF_SLOTS];
   int next_slot = 0;
   zkr::MsmPlan plan[zkr::N_TABLES];

@@ -51,8 +51,8 @@ MsmPlan msm_plan(size_t n_scalars, size_t n, int c_fixed) {
   while (((size_t)1 << lg) < n_scalars) lg++;
   int c = lg;  // 2^(c-1) buckets for ~n * 255/c entries: a few dozen entries per bucket
   if (c < 4) c = 4;
-  if (c > 20) c = 20;
-  if (const char *e = getenv("ZKR_MSM_C")) { int v = atoi(e); if (v >= 2 && v <= 22) c = v; }
+  if (c > 20) c = 20;  // MAX_RANGES x SORT_RANGE_MAX = 2^19 buckets
+  if (const char *e = getenv("ZKR_MSM_C")) { int v = atoi(e); if (v >= 2 && v <= 20) c = v; }
   if (c_fixed) c = c_fixed;
   pl.c = c;
   pl.K = (255 + c - 1) / c;
@@ -62,11 +62,11 @@ MsmPlan msm_plan(size_t n_scalars, size_t n, int c_fixed) {
   uint64_t mean = (uint64_t)n * pl.K / pl.nbw + 1;
   pl.big_thresh = mean * 8 > 256 ? (uint32_t)(mean * 8) : 256;
   if (const char *e = getenv("ZKR_MSM_BIG")) { int v = atoi(e); if (v >= 1) pl.big_thresh = (uint32_t)v; }
-  // digit sort: one workgroup per (bucket range, chunk): about one per CU at full size, chunks of >= 4096 points
+  // digit sort: one workgroup per (bucket range, chunk): about four per CU at full size, chunks of >= 4096 points
   pl.nbl = pl.nbw < SORT_RANGE_MAX ? pl.nbw : SORT_RANGE_MAX;
   pl.nR = pl.nbw / pl.nbl;
   uint32_t J = (uint32_t)((n + 4095) / 4096);
-  uint32_t jmax = 256 / pl.nR ? 256 / pl.nR : 1u;
+  uint32_t jmax = 1024 / pl.nR ? 1024 / pl.nR : 1u;
   if (J > jmax) J = jmax;
   if (J < 1) J = 1;
   if (const char *e = getenv("ZKR_MSM_J")) { int v = atoi(e); if (v >= 1 && v <= 256) J = (uint32_t)v; }
@@ -123,11 +123,16 @@ void msm_ws_free(MsmWorkspace &ws) {
 int key_alloc_workspace(zkr_key *k) {
   ZKR_HIP_CHECK(hipSetDevice(k->device));
   const ArenaHeader &h = k->h;
-  ZKR_HIP_CHECK(hipStreamCreateWithFlags(&k->stream, hipStreamNonBlocking));
-  ZKR_HIP_CHECK(hipStreamCreateWithFlags(&k->ntt_stream, hipStreamNonBlocking));
-  ZKR_HIP_CHECK(hipStreamCreateWithFlags(&k->red_stream[0], hipStreamNonBlocking));
-  if (getenv("ZKR_FOUR_STREAMS")) ZKR_HIP_CHECK(hipStreamCreateWithFlags(&k->red_stream[1], hipStreamNonBlocking));
-  else k->red_stream[1] = k->ntt_stream;  // calcH is long finished when the first G1 table needs its reduction
+  // The accumulation stream is the bulk; preparation and reduction chains are short dependent launches whose
+  // delay stalls it (the next sort, the proof's completion), so their workgroups are dispatched first.
+  int prio_lo = 0, prio_hi = 0;
+  ZKR_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));  // numerically lower = higher priority
+  if (getenv("ZKR_NO_PRIO")) prio_hi = prio_lo;
+  ZKR_HIP_CHECK(hipStreamCreateWithPriority(&k->stream, hipStreamNonBlocking, prio_lo));
+  ZKR_HIP_CHECK(hipStreamCreateWithPriority(&k->prep_stream, hipStreamNonBlocking, prio_hi));
+  ZKR_HIP_CHECK(hipStreamCreateWithPriority(&k->red_stream[0], hipStreamNonBlocking, prio_hi));
+  if (getenv("ZKR_FOUR_STREAMS")) ZKR_HIP_CHECK(hipStreamCreateWithPriority(&k->red_stream[1], hipStreamNonBlocking, prio_hi));
+  else k->red_stream[1] = k->red_stream[0];  // streams beyond the hardware queues would only serialise behind others
   for (int t = 0; t < N_TABLES; t++) k->plan[t] = msm_plan(t == T_H ? h.m : h.n, h.npts[t], (int)h.win_c[t]);
   for (ProofSlot &sl : k->slot) {
     for (int t = 0; t < N_TABLES; t++) {
@@ -403,7 +408,7 @@ int zkr_key_load_websnark(const void *pk_bin, size_t pk_len, int device, zkr_key
 void zkr_key_free(zkr_key *k) {
   if (!k) return;
   hipSetDevice(k->device);
-  hipStream_t streams[4] = {k->stream, k->red_stream[0], k->red_stream[1] != k->ntt_stream ? k->red_stream[1] : nullptr, k->ntt_stream};
+  hipStream_t streams[4] = {k->stream, k->red_stream[0], k->red_stream[1] != k->red_stream[0] ? k->red_stream[1] : nullptr, k->prep_stream};
   for (hipStream_t st : streams)
     if (st) hipStreamSynchronize(st);
   for (ProofSlot &sl : k->slot) {

@@ -176,22 +176,9 @@ static int msm_digits_enqueue(Prof pf, hipStream_t s, const Fr *scalars, uint32_
   return 0;
 }
 
-// a range's bucket counters / cursors live in LDS: up to 4 * 2^15 bytes = 128 KB (> the 64 KB default cap)
-static int sort_lds_opt_in() {
-  static int rc = [] {
-    hipError_t e = hipFuncSetAttribute((const void *)msm_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)msm_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    return e == hipSuccess ? 0 : 1;
-  }();
-  if (rc) { set_error("cannot opt in to 128 KB of LDS for the digit sort"); return ZKR_ERR_HIP; }
-  return 0;
-}
-
 // digit sort of one table: LDS histogram per (window, chunk) -> scans -> LDS-cursor scatter
 static int msm_sort_enqueue(Prof pf, hipStream_t s, const uint32_t *rank, const DigitLists &dl, uint32_t n, const MsmPlan &pl, MsmWorkspace &ws) {
   if (n == 0) return 0;
-  int rc = sort_lds_opt_in();
-  if (rc) return rc;
   int sp = prof_begin(pf, s, "msm_sort");
   ZKR_HIP_CHECK(hipMemsetAsync(ws.big_count, 0, 8, s));
   ZKR_HIP_CHECK(hipMemsetAsync(ws.size_hist, 0, 2 * SIZE_BINS * 4, s));
@@ -218,8 +205,15 @@ template <class F>
 static int msm_accum_enqueue(Prof pf, hipStream_t s, const Affine<F> *pts, uint32_t n, const MsmPlan &pl, const MsmWorkspace &srt, MsmWorkspace &ws) {
   if (n == 0) return 0;
   int sp = prof_begin(pf, s, MsmCfg<F>::ACC_STAGE);
-  msm_accum_kernel<F, MsmCfg<F>::ACC_W><<<(pl.nb + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, s>>>(pts, srt.offsets, srt.entries, pl.nb, srt.counts,
-                                                                                                      srt.order, (XYZZ<F> *)ws.buckets);
+  // waves per SIMD: one slot fewer than the register file allows, so that the preparation and reduction
+  // launches of the other streams always find a free wave slot beside a running accumulation
+  static const char *acc_env = getenv(sizeof(F) == 32 ? "ZKR_ACC_W_G1" : "ZKR_ACC_W_G2");
+  static const int acc_w = acc_env ? atoi(acc_env) : MsmCfg<F>::ACC_W;
+  const unsigned grid = (pl.nb + MSM_THREADS - 1) / MSM_THREADS;
+  if (acc_w == MsmCfg<F>::ACC_W)
+    msm_accum_kernel<F, MsmCfg<F>::ACC_W><<<grid, MSM_THREADS, 0, s>>>(pts, srt.offsets, srt.entries, pl.nb, srt.counts, srt.order, (XYZZ<F> *)ws.buckets);
+  else
+    msm_accum_kernel<F, MsmCfg<F>::ACC_W - 1><<<grid, MSM_THREADS, 0, s>>>(pts, srt.offsets, srt.entries, pl.nb, srt.counts, srt.order, (XYZZ<F> *)ws.buckets);
   prof_end(pf, s, sp);
   ZKR_HIP_CHECK(hipGetLastError());
   return 0;
@@ -300,7 +294,7 @@ static int draw_blinding(uint8_t out[32]) {
 }
 
 // Enqueue the whole GPU side of one proof on the slot's buffers; returns without waiting.
-static int prove_submit(zkr_key *k, ProofSlot &sl, const Fr *d_wsrc, const uint8_t *r32, const uint8_t *s32, hipStream_t s) {
+static int prove_submit(zkr_key *k, ProofSlot &sl, const Fr *d_wsrc, const uint8_t *r32, const uint8_t *s32, hipStream_t caller) {
   ZKR_HIP_CHECK(hipSetDevice(k->device));
   const ArenaHeader &h = k->h;
   const unsigned char *ar = k->arena;
@@ -316,42 +310,47 @@ static int prove_submit(zkr_key *k, ProofSlot &sl, const Fr *d_wsrc, const uint8
     if ((rc = draw_blinding(sl.rb)) || (rc = draw_blinding(sl.sb))) return rc;
   } else { set_error("pass both r and s or neither"); return ZKR_ERR_ARG; }
 
-  int tot = prof_begin(pf, s, "total");
-  int sp = prof_begin(pf, s, "ingest");
-  ingest_kernel<<<(h.n + 255) / 256, 256, 0, s>>>(d_wsrc, sl.d_w, h.n);
-  prof_end(pf, s, sp);
-  // Schedule on three streams (HIP multiplexes streams onto a few hardware queues; streams sharing one serialise):
-  //   s  : the heavy chain -- digit codes, then per table its digit sort and its bucket accumulation; B2 first
-  //        (its reduction chain is the longest), B1 reuses that sort (h.share_b), H last (needs h);
-  //   sn : QAP rows + the six NTTs (calcH), then the oversized-bucket and reduction chains of the G1 tables;
-  //   rx : oversized-bucket and reduction chain of the G2 table.
-  // Every accumulation saturates the VALUs on its own.  The reduction chains are few long-running wavefronts
-  // (raised wave priority) that run under the following accumulations and get the machine mostly to themselves
-  // while the next table is being sorted; the oversized buckets need only the sort and run beside the accumulation.
-  // With two proofs in flight (zkr_prove_submit) the next proof's heavy chain follows this one's directly and
-  // covers the tail of its reduction chains and its host assembly.
+  // The caller's stream only orders the witness before the proof (it may carry unrelated work, and with two
+  // proofs in flight it must not chain them).  Schedule on the key's own streams (HIP multiplexes streams onto a
+  // few hardware queues; streams sharing one serialise):
+  //   sp : preparation -- ingest, digit records of w, the digit sorts of B, A and C, calcH (QAP rows + six NTTs),
+  //        digit records of h, the sort of H.  Memory/LDS-bound (and the NTTs), small workgroups;
+  //   s  : the five bucket accumulations back to back, B2 first (its reduction chain is the longest), B1 on the
+  //        same sort (h.share_b), then A, C, H, each waiting only for its table's sort.  Every accumulation
+  //        saturates the VALUs on its own;
+  //   rx : oversized-bucket and reduction chain of the G2 table;  ry : those of the four G1 tables (ry == rx
+  //        unless ZKR_FOUR_STREAMS).  Few long-running wavefronts at raised wave priority that run under the
+  //        following accumulations; the oversized buckets need only the sort and run beside the accumulation.
+  // With two proofs in flight (zkr_prove_submit) the preparation of proof i+1 runs under the accumulations of
+  // proof i, whose reduction tail and host assembly are covered by the accumulations of proof i+1.
   static const bool serial = getenv("ZKR_SERIAL") != nullptr;  // profiling aid: one stream, isolated kernel durations
-  hipStream_t sn = serial ? s : k->ntt_stream;
+  hipStream_t s = k->stream;
+  hipStream_t sp = serial ? s : k->prep_stream;
   hipStream_t rx = serial ? s : k->red_stream[0], ry = serial ? s : k->red_stream[1];
   int rc;
-  ZKR_HIP_CHECK(hipEventRecord(sl.ev_w, s));
-  if (!serial) ZKR_HIP_CHECK(hipStreamWaitEvent(sn, sl.ev_w, 0));
-  if ((rc = calc_h_device(k, sl, sn))) return rc;
-  ZKR_HIP_CHECK(hipEventRecord(sl.ev_h, sn));
+  ZKR_HIP_CHECK(hipEventRecord(sl.ev_w, caller));  // the witness is in place
+  ZKR_HIP_CHECK(hipStreamWaitEvent(sp, sl.ev_w, 0));
+  int tot = prof_begin(pf, sp, "total");
+  int spn = prof_begin(pf, sp, "ingest");
+  ingest_kernel<<<(h.n + 255) / 256, 256, 0, sp>>>(d_wsrc, sl.d_w, h.n);
+  prof_end(pf, sp, spn);
   const DigitLists *dig[N_TABLES] = {&sl.dig_w, &sl.dig_w, &sl.dig_w, &sl.dig_w, &sl.dig_h};
   const bool share_b = h.share_b != 0 && h.npts[T_B1] == h.npts[T_B2];
   int sort_src[N_TABLES] = {T_A, T_B1, share_b ? T_B1 : T_B2, T_C, T_H};
   auto sort_table = [&](int t) -> int {
-    int rc = msm_sort_enqueue(pf, s, (const uint32_t *)(ar + h.off_rank[t]), *dig[t], h.npts[t], k->plan[t], sl.ws[t]);
+    int rc = msm_sort_enqueue(pf, sp, (const uint32_t *)(ar + h.off_rank[t]), *dig[t], h.npts[t], k->plan[t], sl.ws[t]);
     if (rc) return rc;
-    if (!serial) ZKR_HIP_CHECK(hipEventRecord(sl.ev_sorted[t], s));
+    if (!serial) ZKR_HIP_CHECK(hipEventRecord(sl.ev_sorted[t], sp));
     return 0;
   };
   auto accum_table = [&](int t, hipStream_t rs) -> int {
     const MsmWorkspace &srt = sl.ws[sort_src[t]];
     const void *pts = ar + h.off_pts[t];
     int rc;
-    if (!serial) ZKR_HIP_CHECK(hipStreamWaitEvent(rs, sl.ev_sorted[sort_src[t]], 0));
+    if (!serial) {
+      ZKR_HIP_CHECK(hipStreamWaitEvent(rs, sl.ev_sorted[sort_src[t]], 0));
+      ZKR_HIP_CHECK(hipStreamWaitEvent(s, sl.ev_sorted[sort_src[t]], 0));
+    }
     if (t == T_B2) rc = msm_big_enqueue<Fq2>(pf, rs, (const G2Affine *)pts, h.npts[t], k->plan[t], srt, sl.ws[t]);
     else rc = msm_big_enqueue<Fq>(pf, rs, (const G1Affine *)pts, h.npts[t], k->plan[t], srt, sl.ws[t]);
     if (rc) return rc;
@@ -366,25 +365,28 @@ static int prove_submit(zkr_key *k, ProofSlot &sl, const Fr *d_wsrc, const uint8
     else rc = msm_reduce_enqueue<Fq>(pf, rs, h.npts[t], k->plan[t], srt, sl.ws[t]);
     return rc;
   };
-  if ((rc = msm_digits_enqueue(pf, s, sl.d_w, h.n, k->plan[T_A], sl.dig_w))) return rc;
+  // preparation chain
+  if ((rc = msm_digits_enqueue(pf, sp, sl.d_w, h.n, k->plan[T_A], sl.dig_w))) return rc;
   if ((rc = sort_table(T_B1))) return rc;
   if (!share_b && (rc = sort_table(T_B2))) return rc;
+  if ((rc = sort_table(T_A))) return rc;
+  if ((rc = sort_table(T_C))) return rc;
+  if ((rc = calc_h_device(k, sl, sp))) return rc;
+  if ((rc = msm_digits_enqueue(pf, sp, sl.d_h, h.m, k->plan[T_H], sl.dig_h))) return rc;
+  if ((rc = sort_table(T_H))) return rc;
+  // accumulations + reduction chains
   if ((rc = accum_table(T_B2, rx))) return rc;
   if ((rc = accum_table(T_B1, ry))) return rc;
-  if ((rc = sort_table(T_A))) return rc;
   if ((rc = accum_table(T_A, ry))) return rc;
-  if ((rc = sort_table(T_C))) return rc;
   if ((rc = accum_table(T_C, ry))) return rc;
-  if (!serial) ZKR_HIP_CHECK(hipStreamWaitEvent(s, sl.ev_h, 0));
-  if ((rc = msm_digits_enqueue(pf, s, sl.d_h, h.m, k->plan[T_H], sl.dig_h))) return rc;
-  if ((rc = sort_table(T_H))) return rc;
   if ((rc = accum_table(T_H, ry))) return rc;
-  // completion = both reduction streams done.  The heavy stream `s` is NOT made to wait for them, so the next
-  // proof's chain can follow directly; callers that order later work after `s` go through prove_collect.
+  // completion = both reduction streams done.  The accumulation stream `s` is NOT made to wait for them, so the
+  // next proof's accumulations can follow directly; callers get the proof through prove_collect.
   if (!serial) {
-    ZKR_HIP_CHECK(hipEventRecord(sl.ev_w, rx));  // ev_w / ev_h are free again: the two join events
-    ZKR_HIP_CHECK(hipEventRecord(sl.ev_h, ry));
-    ZKR_HIP_CHECK(hipStreamWaitEvent(rx, sl.ev_h, 0));
+    if (ry != rx) {
+      ZKR_HIP_CHECK(hipEventRecord(sl.ev_h, ry));
+      ZKR_HIP_CHECK(hipStreamWaitEvent(rx, sl.ev_h, 0));
+    }
     prof_end(pf, rx, tot);
     ZKR_HIP_CHECK(hipEventRecord(sl.ev_fin, rx));
   } else {
@@ -451,7 +453,7 @@ int zkr_prove_submit(zkr_key *key, const void *d_witness_std, const uint8_t *r32
   int t = -1;
   ProofSlot *sl = free_slot(key, &t);
   if (!sl) return ZKR_ERR_ARG;
-  int rc = prove_submit(key, *sl, (const Fr *)d_witness_std, r32, s32, stream ? (hipStream_t)stream : key->stream);
+  int rc = prove_submit(key, *sl, (const Fr *)d_witness_std, r32, s32, (hipStream_t)stream);
   if (rc) return rc;
   *ticket = t;
   return 0;
@@ -466,7 +468,7 @@ int zkr_prove_device(zkr_key *key, const void *d_witness_std, const uint8_t *r32
   if (!key || !d_witness_std || !proof_out) { set_error("null argument"); return ZKR_ERR_ARG; }
   ProofSlot *sl = free_slot(key, nullptr);
   if (!sl) return ZKR_ERR_ARG;
-  int rc = prove_submit(key, *sl, (const Fr *)d_witness_std, r32, s32, stream ? (hipStream_t)stream : key->stream);
+  int rc = prove_submit(key, *sl, (const Fr *)d_witness_std, r32, s32, (hipStream_t)stream);
   if (rc) return rc;
   return prove_collect(key, *sl, proof_out);
 }
@@ -477,7 +479,7 @@ int zkr_prove(zkr_key *key, const void *witness_std, size_t witness_len, const u
   ZKR_HIP_CHECK(hipSetDevice(key->device));
   ProofSlot *sl = free_slot(key, nullptr);
   if (!sl) return ZKR_ERR_ARG;
-  hipStream_t s = stream ? (hipStream_t)stream : key->stream;
+  hipStream_t s = stream ? (hipStream_t)stream : key->prep_stream;
   ZKR_HIP_CHECK(hipMemcpyAsync(sl->d_wraw, witness_std, witness_len, hipMemcpyHostToDevice, s));
   int rc = prove_submit(key, *sl, sl->d_wraw, r32, s32, s);
   if (rc) return rc;
