@@ -130,15 +130,16 @@ def main():
         # ---- roofline of the dominant kernel (DESIGN.md "Measurement"): algorithmic bytes = every base point
         # and every scalar of the MSM read once (64 B G1 / 128 B G2 point + 32 B scalar)
         g1_pts = info["ptsA"] + info["ptsB1"] + info["ptsC"] + info["ptsH"]
+        win = key.windows()  # K mixed additions per point (one per window level of the key table)
         cands = {
-            "msm_accum_kernel<Fq>": ("msm_accum_g1", 96.0 * g1_pts / 4.0, 10.0 * g1_pts / 4.0),
-            "msm_accum_kernel<Fq2>": ("msm_accum_g2", 160.0 * info["ptsB2"], 28.0 * info["ptsB2"]),
+            "msm_accum_kernel<Fq>": ("msm_accum_g1", 96.0 * g1_pts / 4.0, 10.0 * g1_pts / 4.0 * win["A"][1]),
+            "msm_accum_kernel<Fq2>": ("msm_accum_g2", 160.0 * info["ptsB2"], 28.0 * info["ptsB2"] * win["B2"][1]),
         }
         dom, best = None, -1.0
         for name, (st, _, _) in cands.items():
             if prof[st][0] > best:
                 dom, best = name, prof[st][0]
-        st, bytes_per_launch, fqmul_per_point_window = cands[dom]
+        st, bytes_per_launch, fqmul_per_launch = cands[dom]
         ms_total, launches = prof[st]
         avg_ms = ms_total / max(launches, 1)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
@@ -157,12 +158,10 @@ def main():
                     "note": "Pippenger bucket accumulation is integer-VALU bound (v_mad_u64_u32), not HBM bound; see valu"}
         try:
             peak_gmul = zkr_hip.bench_fq_mul(local)
-            c_bits = min(16, max(4, (max(info["ptsA"], 2) - 1).bit_length() - 4))  # msm_plan() in csrc/zkr_key.hip
-            windows = (255 + c_bits - 1) // c_bits
-            roofline["valu"] = {"peak_fq_mul_per_s_G": peak_gmul, "unit": "G Fq-mul/s (136 mad32 each)"}
-            if windows:
-                gm = fqmul_per_point_window * windows / (avg_ms * 1e-3) / 1e9
-                roofline["valu"].update({"achieved_fq_mul_per_s_G": gm, "frac": gm / peak_gmul})
+            gm = fqmul_per_launch / (avg_ms * 1e-3) / 1e9
+            roofline["valu"] = {"peak_fq_mul_per_s_G": peak_gmul, "unit": "G Fq-mul/s (136 mad32 each)",
+                                "achieved_fq_mul_per_s_G": gm, "frac": gm / peak_gmul,
+                                "window_bits": win["A"][0], "additions_per_point": win["A"][1]}
         except Exception as e:  # microbench is informative only
             roofline["valu"] = {"error": str(e)}
         per_proof_ms = {k: (v[0] / args.steps) for k, v in prof.items()}
@@ -172,7 +171,8 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "u32x8 Montgomery (254-bit integer)", "data": "synthetic",
             "config": {"workload": "2^%d-constraint synthetic rollup circuit, 1 proof per step per GPU" % args.log_m,
                        "log_m": args.log_m, "n_public": N_PUBLIC, "nVars": info["nVars"], "nnzA": info["nnzA"], "nnzB": info["nnzB"],
-                       "parallelism": "proof-sharded x%d (key arena broadcast once over RCCL)" % world},
+                       "parallelism": "proof-sharded x%d (key arena broadcast once over RCCL)" % world,
+                       "proofs_in_flight": 1 if args.no_pipeline else 2},
             "roofline": roofline,
             "stage_ms_per_proof": per_proof_ms,
             "key": {"arena_bytes": arena_bytes, "setup_s": setup_s, "bcast_s": bcast_s if world > 1 else None},

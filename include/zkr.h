@@ -54,6 +54,10 @@ void zkr_key_free(zkr_key *key);
  * out[5..9]=points kept (non-infinity) in the A,B1,B2,C,H tables. */
 int zkr_key_info(const zkr_key *key, uint64_t out[10]);
 
+/* MSM geometry of the device key: window bits c and window count K = ceil(255/c) of the A,B1,B2,C,H tables.  Each
+ * table holds K levels per base point (2^(ck) P), so an MSM costs K mixed additions per point. */
+int zkr_key_windows(const zkr_key *key, uint32_t c_out[5], uint32_t k_out[5]);
+
 /* Multi-GPU replication: the key is ONE position-independent arena in HBM.
  * rank 0:  zkr_key_arena(key,&ptr,&len)  -> broadcast `len`, then the bytes (RCCL over xGMI)
  * rank k:  zkr_key_adopt_arena(dev_ptr,len,device,&key)  (takes a device pointer holding the bytes;

@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <condition_variable>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "../../include/zkr.h"
@@ -94,7 +96,7 @@ struct ProofSlot {
   hipEvent_t ev_done[N_TABLES] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_sorted[N_TABLES] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   uint8_t rb[32], sb[32];  // blinding scalars of the proof in flight
-  bool busy = false;
+  bool busy = false, collecting = false;
   std::vector<ProfSpan> spans;
   std::vector<hipEvent_t> event_pool;
   size_t event_next = 0;
@@ -112,6 +114,8 @@ struct zkr_key {
   hipStream_t red_stream[2] = {nullptr, nullptr};  // reduction chains of the G2 table / of the G1 tables (the same stream by default)
   zkr::ProofSlot slot[zkr::PROOF_SLOTS];
   int next_slot = 0;
+  std::mutex mu;  // slot hand-out, the enqueue phase of a proof (so two host threads do not interleave launches), stage totals
+  std::condition_variable slot_freed;
   zkr::MsmPlan plan[zkr::N_TABLES];
   // profiling
   bool prof_on = false;

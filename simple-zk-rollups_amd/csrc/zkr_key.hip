@@ -437,6 +437,12 @@ int zkr_key_info(const zkr_key *k, uint64_t out[10]) {
   return 0;
 }
 
+int zkr_key_windows(const zkr_key *k, uint32_t c_out[5], uint32_t k_out[5]) {
+  if (!k || !c_out || !k_out) { set_error("null argument"); return ZKR_ERR_ARG; }
+  for (int t = 0; t < N_TABLES; t++) { c_out[t] = (uint32_t)k->plan[t].c; k_out[t] = (uint32_t)k->plan[t].K; }
+  return 0;
+}
+
 int zkr_key_arena(const zkr_key *k, void **dev_ptr, size_t *len) {
   if (!k || !dev_ptr || !len) { set_error("null argument"); return ZKR_ERR_ARG; }
   *dev_ptr = k->arena;

@@ -399,12 +399,19 @@ static int prove_submit(zkr_key *k, ProofSlot &sl, const Fr *d_wsrc, const uint8
 
 // Wait for the slot's GPU work, then the host assembly.
 static int prove_collect(zkr_key *k, ProofSlot &sl, uint8_t proof_out[256]) {
-  if (!sl.busy) { set_error("no proof in flight in this slot"); return ZKR_ERR_ARG; }
+  {
+    std::lock_guard<std::mutex> lk(k->mu);
+    if (!sl.busy || sl.collecting) { set_error("no proof in flight in this slot"); return ZKR_ERR_ARG; }
+    sl.collecting = true;
+  }
+  struct Release {  // the slot is free again when this scope ends, whatever the outcome
+    zkr_key *k; ProofSlot &sl;
+    ~Release() { { std::lock_guard<std::mutex> lk(k->mu); sl.busy = false; sl.collecting = false; } k->slot_freed.notify_one(); }
+  } release{k, sl};
   ZKR_HIP_CHECK(hipSetDevice(k->device));
   const ArenaHeader &h = k->h;
-  sl.busy = false;
   ZKR_HIP_CHECK(hipEventSynchronize(sl.ev_fin));
-  if (k->prof_on) prof_collect(k, sl);
+  if (k->prof_on) { std::lock_guard<std::mutex> lk(k->mu); prof_collect(k, sl); }
   const uint8_t *rb = sl.rb, *sb = sl.sb;
   G1XYZZ A = msm_finish<Fq>(h.npts[T_A], sl.ws[T_A]);
   G1XYZZ B1 = msm_finish<Fq>(h.npts[T_B1], sl.ws[T_B1]);
@@ -432,31 +439,36 @@ static int prove_collect(zkr_key *k, ProofSlot &sl, uint8_t proof_out[256]) {
   return 0;
 }
 
+// Hand out a free proof slot and run `enqueue` on it under the key's lock (two host threads proving on one key --
+// e.g. two libuv workers behind Promise.all -- then pipeline like submit/collect does).  wait: block until a slot
+// frees instead of failing.
+template <class Fn>
+static int with_free_slot(zkr_key *key, bool wait, int *ticket, Fn enqueue) {
+  std::unique_lock<std::mutex> lk(key->mu);
+  for (;;) {
+    for (int i = 0; i < PROOF_SLOTS; i++) {
+      int t = (key->next_slot + i) % PROOF_SLOTS;
+      if (!key->slot[t].busy) {
+        key->next_slot = (t + 1) % PROOF_SLOTS;
+        int rc = enqueue(key->slot[t]);
+        if (!rc && ticket) *ticket = t;
+        return rc;
+      }
+    }
+    if (!wait) { set_error("all %d proof slots are in flight: collect one first", PROOF_SLOTS); return ZKR_ERR_ARG; }
+    key->slot_freed.wait(lk);
+  }
+}
+
 }  // namespace zkr
 
 using namespace zkr;
 
 extern "C" {
 
-// the synchronous calls use whichever slot is free (a caller may hold one submitted proof across them)
-static ProofSlot *free_slot(zkr_key *key, int *ticket) {
-  for (int i = 0; i < PROOF_SLOTS; i++) {
-    int t = (key->next_slot + i) % PROOF_SLOTS;
-    if (!key->slot[t].busy) { key->next_slot = (t + 1) % PROOF_SLOTS; if (ticket) *ticket = t; return &key->slot[t]; }
-  }
-  set_error("all %d proof slots are in flight: collect one first", PROOF_SLOTS);
-  return nullptr;
-}
-
 int zkr_prove_submit(zkr_key *key, const void *d_witness_std, const uint8_t *r32, const uint8_t *s32, void *stream, int *ticket) {
   if (!key || !d_witness_std || !ticket) { set_error("null argument"); return ZKR_ERR_ARG; }
-  int t = -1;
-  ProofSlot *sl = free_slot(key, &t);
-  if (!sl) return ZKR_ERR_ARG;
-  int rc = prove_submit(key, *sl, (const Fr *)d_witness_std, r32, s32, (hipStream_t)stream);
-  if (rc) return rc;
-  *ticket = t;
-  return 0;
+  return with_free_slot(key, false, ticket, [&](ProofSlot &sl) { return prove_submit(key, sl, (const Fr *)d_witness_std, r32, s32, (hipStream_t)stream); });
 }
 
 int zkr_prove_collect(zkr_key *key, int ticket, uint8_t proof_out[256]) {
@@ -466,32 +478,35 @@ int zkr_prove_collect(zkr_key *key, int ticket, uint8_t proof_out[256]) {
 
 int zkr_prove_device(zkr_key *key, const void *d_witness_std, const uint8_t *r32, const uint8_t *s32, uint8_t proof_out[256], void *stream) {
   if (!key || !d_witness_std || !proof_out) { set_error("null argument"); return ZKR_ERR_ARG; }
-  ProofSlot *sl = free_slot(key, nullptr);
-  if (!sl) return ZKR_ERR_ARG;
-  int rc = prove_submit(key, *sl, (const Fr *)d_witness_std, r32, s32, (hipStream_t)stream);
+  int t = -1;
+  int rc = with_free_slot(key, true, &t, [&](ProofSlot &sl) { return prove_submit(key, sl, (const Fr *)d_witness_std, r32, s32, (hipStream_t)stream); });
   if (rc) return rc;
-  return prove_collect(key, *sl, proof_out);
+  return prove_collect(key, key->slot[t], proof_out);
 }
 
 int zkr_prove(zkr_key *key, const void *witness_std, size_t witness_len, const uint8_t *r32, const uint8_t *s32, uint8_t proof_out[256], void *stream) {
   if (!key || !witness_std || !proof_out) { set_error("null argument"); return ZKR_ERR_ARG; }
   if (witness_len != (size_t)key->h.n * 32) { set_error("witness is %zu bytes, key expects nVars*32 = %zu", witness_len, (size_t)key->h.n * 32); return ZKR_ERR_BAD_WITNESS; }
-  ZKR_HIP_CHECK(hipSetDevice(key->device));
-  ProofSlot *sl = free_slot(key, nullptr);
-  if (!sl) return ZKR_ERR_ARG;
-  hipStream_t s = stream ? (hipStream_t)stream : key->prep_stream;
-  ZKR_HIP_CHECK(hipMemcpyAsync(sl->d_wraw, witness_std, witness_len, hipMemcpyHostToDevice, s));
-  int rc = prove_submit(key, *sl, sl->d_wraw, r32, s32, s);
+  int t = -1;
+  int rc = with_free_slot(key, true, &t, [&](ProofSlot &sl) -> int {
+    ZKR_HIP_CHECK(hipSetDevice(key->device));
+    hipStream_t s = stream ? (hipStream_t)stream : key->prep_stream;
+    ZKR_HIP_CHECK(hipMemcpyAsync(sl.d_wraw, witness_std, witness_len, hipMemcpyHostToDevice, s));
+    return prove_submit(key, sl, sl.d_wraw, r32, s32, s);
+  });
   if (rc) return rc;
-  return prove_collect(key, *sl, proof_out);
+  return prove_collect(key, key->slot[t], proof_out);
 }
 
 int zkr_calc_h(zkr_key *key, const void *witness_std, size_t witness_len, void *h_out) {
   if (!key || !witness_std || !h_out) { set_error("null argument"); return ZKR_ERR_ARG; }
   if (witness_len != (size_t)key->h.n * 32) { set_error("witness length mismatch"); return ZKR_ERR_BAD_WITNESS; }
   ZKR_HIP_CHECK(hipSetDevice(key->device));
-  ProofSlot *slp = free_slot(key, nullptr);
-  if (!slp) return ZKR_ERR_ARG;
+  std::unique_lock<std::mutex> lk(key->mu);
+  ProofSlot *slp = nullptr;
+  for (ProofSlot &cand : key->slot)
+    if (!cand.busy) { slp = &cand; break; }
+  if (!slp) { set_error("all proof slots are in flight"); return ZKR_ERR_ARG; }
   ProofSlot &sl = *slp;
   hipStream_t s = key->stream;
   ZKR_HIP_CHECK(hipMemcpyAsync(sl.d_wraw, witness_std, witness_len, hipMemcpyHostToDevice, s));

@@ -10,6 +10,8 @@ export interface ProveOptions { r?: bigint | string; s?: bigint | string; device
 export interface Bn128 {
   /** websnark-compatible: ArrayBuffers produced by binarifyWitness / binarifyProvingKey. */
   groth16GenProof(witnessBin: ArrayBuffer | Uint8Array, provingKeyBin: ArrayBuffer | Uint8Array, opts?: ProveOptions): Promise<Groth16Proof>;
+  /** Independent proofs on one key, pipelined two deep on the GPU. */
+  groth16GenProofBatch(witnessBins: Array<ArrayBuffer | Uint8Array>, provingKeyBin: ArrayBuffer | Uint8Array, opts?: ProveOptions[]): Promise<Groth16Proof[]>;
   keyInfo(): { nVars: number; nPublic: number; domainSize: number; nnzA: number; nnzB: number } | null;
   terminate(): void;
 }

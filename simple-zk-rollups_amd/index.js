@@ -66,6 +66,16 @@ class Bn128 {
     return proofFromBytes(pb);
   }
 
+  // Independent proofs of one rollup batch on the same key.  The calls run on libuv worker threads; the library
+  // keeps two proofs in flight per key (include/zkr.h zkr_prove_submit), so the GPU work of one proof covers the
+  // reduction tail and host assembly of the previous one.  opts[i] (optional) fixes the blinding of proof i.
+  async groth16GenProofBatch(witnessBins, provingKeyBin, opts) {
+    if (witnessBins.length === 0) return [];
+    const first = await this.groth16GenProof(witnessBins[0], provingKeyBin, opts && opts[0]);  // loads / caches the key
+    const rest = await Promise.all(witnessBins.slice(1).map((w, i) => this.groth16GenProof(w, provingKeyBin, opts && opts[i + 1])));
+    return [first, ...rest];
+  }
+
   keyInfo() {
     if (!this._key) return null;
     const v = native().keyInfo(this._key);

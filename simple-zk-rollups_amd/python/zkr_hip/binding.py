@@ -33,6 +33,7 @@ def lib():
     L.zkr_key_free.argtypes = [vp]
     L.zkr_key_free.restype = None
     L.zkr_key_info.argtypes = [vp, c.POINTER(c.c_uint64)]
+    L.zkr_key_windows.argtypes = [vp, c.POINTER(c.c_uint32), c.POINTER(c.c_uint32)]
     L.zkr_key_arena.argtypes = [vp, c.POINTER(vp), c.POINTER(sz)]
     L.zkr_key_adopt_arena.argtypes = [vp, sz, i, c.POINTER(vp)]
     L.zkr_prove.argtypes = [vp, u8p, sz, u8p, u8p, u8p, vp]
@@ -144,6 +145,12 @@ class ProvingKey:
         sb = None if s is None else int(s).to_bytes(32, "little")
         _check(lib().zkr_prove_device(self._h, ctypes.c_void_p(d_witness_ptr), rb, sb, out, ctypes.c_void_p(stream or 0)))
         return out.raw
+
+    def windows(self):
+        """{table: (window bits c, windows K)} for A, B1, B2, C, H."""
+        cs, ks = (ctypes.c_uint32 * 5)(), (ctypes.c_uint32 * 5)()
+        _check(lib().zkr_key_windows(self._h, cs, ks))
+        return {t: (cs[i], ks[i]) for i, t in enumerate(("A", "B1", "B2", "C", "H"))}
 
     def prove_submit(self, d_witness_ptr, r=None, s=None, stream=None) -> int:
         """Enqueue the GPU side of one proof, return a ticket (zkr_prove_submit); at most two in flight."""

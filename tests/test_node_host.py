@@ -96,3 +96,27 @@ def test_js_groth16GenProof_on_gpu_matches_oracle(tmp_path, small_case):
     assert res["g"]["publicSignals"] == [str(x) for x in c["w"][1:8]]
     assert res["sol"] == g.solidity_proof(expect, c["w"][1:8])
     assert res["info"]["nVars"] == c["pk"]["nVars"]
+
+
+@pytest.mark.gpu
+def test_js_batch_runs_concurrent_proofs_on_one_key(tmp_path, small_case):
+    """Promise.all over one key: several libuv workers inside zkr_prove at once (two proofs in flight, the others
+    wait for a slot); every proof equals the closed form for its blinding."""
+    c = small_case
+    path = _key_json(tmp_path, c)
+    out = _node("""
+      const z = require('./index.js'); const fs = require('fs');
+      const d = JSON.parse(fs.readFileSync(process.argv[1]));
+      (async () => {
+        const bn = await z.buildBn128();
+        const wb = z.binarifyWitness(d.witness), pb = z.binarifyProvingKey(d.pk);
+        const opts = [];
+        for (let i = 0; i < 6; i++) opts.push({r: (BigInt(d.r) + BigInt(i)).toString(), s: (BigInt(d.s) + BigInt(2 * i)).toString()});
+        const proofs = await bn.groth16GenProofBatch([wb, wb, wb, wb, wb, wb], pb, opts);
+        console.log(JSON.stringify(proofs));
+      })().catch(e => { console.error(e); process.exit(1); });
+    """, path).stdout
+    proofs = json.loads(out)
+    assert len(proofs) == 6
+    for i, p in enumerate(proofs):
+        assert p == g.proof_to_json(g.proof_from_toxic(c["circ"], c["tox"], c["w"], c["r"] + i, c["s"] + 2 * i))
