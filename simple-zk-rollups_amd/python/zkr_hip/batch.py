@@ -55,8 +55,16 @@ def broadcast_key(key, rank, world, device, dist=None):
 def prove_batch(key, witnesses, blinding, rank=0, world=1):
     """Prove this rank's shard.  witnesses: list of bytes (or None for proofs of other ranks);
     blinding: list of (r, s).  Returns {index: proof_bytes} for the local shard."""
+    mine = shard_indices(len(witnesses), rank, world)
+    if hasattr(key, "prove_batch_device") and torch.cuda.is_available():
+        # witnesses to HBM, then two proofs in flight (zkr_prove_submit / zkr_prove_collect)
+        dev = torch.device("cuda", key.device)
+        dw = [torch.frombuffer(bytearray(witnesses[i]), dtype=torch.uint8).to(dev) for i in mine]
+        torch.cuda.synchronize(dev)
+        proofs = key.prove_batch_device([t.data_ptr() for t in dw], [blinding[i][0] for i in mine], [blinding[i][1] for i in mine])
+        return dict(zip(mine, proofs))
     out = {}
-    for i in shard_indices(len(witnesses), rank, world):
+    for i in mine:
         r, s = blinding[i]
         out[i] = key.prove(witnesses[i], r, s)
     return out

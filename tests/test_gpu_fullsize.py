@@ -12,7 +12,7 @@ def _proof_points(pb):
     return dict(pi_a=(v[0], v[1]), pi_b=((v[2], v[3]), (v[4], v[5])), pi_c=(v[6], v[7]))
 
 
-@pytest.mark.parametrize("log_m", [16, 20])
+@pytest.mark.parametrize("log_m", [16, 20, 22])  # BASELINE.json configs[1] (2^20) and configs[2] (2^22)
 def test_fullsize_proof_equals_closed_form_and_verifies(log_m):
     import zkr_hip
     p = 73
