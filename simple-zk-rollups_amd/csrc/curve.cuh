@@ -98,7 +98,7 @@ ZKR_HD XYZZ<F> add_full_inl(const XYZZ<F> &a, const XYZZ<F> &b) {
   F p = sub(u2, u1);
   F r = sub(s2, s1);
   if (p.is_zero()) {
-    if (r.is_zero()) return dbl_xyzz(a);
+    if (r.is_zero()) return dbl_xyzz_inl(a);
     return XYZZ<F>::inf();
   }
   F pp = sqr(p);

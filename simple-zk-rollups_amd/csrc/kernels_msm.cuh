@@ -176,6 +176,7 @@ constexpr int SORT_THREADS = 256;
 constexpr uint32_t SORT_RANGE_MAX = 8192;  // bucket counters per workgroup (x 4 B of LDS): small footprint, so these
                                            // memory/LDS-bound workgroups find room on CUs busy with an accumulation
 constexpr uint32_t RANK_NONE = 0xffffffffu;
+constexpr int SORT_UNROLL = 8;
 
 __device__ __forceinline__ void sort_chunk(const uint32_t *rng_off, uint32_t r, uint32_t j, uint32_t J, uint32_t &e0, uint32_t &e1) {
   uint32_t lo = rng_off[r], hi = rng_off[r + 1];
@@ -193,8 +194,21 @@ static __global__ __launch_bounds__(SORT_THREADS) void msm_hist_kernel(const uin
   __syncthreads();
   uint32_t e0, e1;
   sort_chunk(rng_off, r, j, J, e0, e1);
-  for (uint32_t e = e0 + threadIdx.x; e < e1; e += SORT_THREADS)
-    if (rank[ent_s[e]] != RANK_NONE) atomicAdd(&s_bkt[(ent_b[e] >> 1) & (SORT_RANGE_MAX - 1u)], 1u);
+  // SORT_UNROLL records per trip: the record loads and the dependent rank gathers of a trip are all issued
+  // before the first LDS atomic, otherwise every record pays the full gather latency in turn
+  for (uint32_t e = e0 + threadIdx.x; e < e1; e += SORT_THREADS * SORT_UNROLL) {
+    uint32_t b[SORT_UNROLL], idx[SORT_UNROLL];
+#pragma unroll
+    for (int u = 0; u < SORT_UNROLL; u++) {
+      uint32_t eu = e + u * SORT_THREADS;
+      bool in = eu < e1;
+      b[u] = in ? ent_b[eu] : 0u;
+      idx[u] = in ? rank[ent_s[eu]] : RANK_NONE;
+    }
+#pragma unroll
+    for (int u = 0; u < SORT_UNROLL; u++)
+      if (idx[u] != RANK_NONE) atomicAdd(&s_bkt[(b[u] >> 1) & (SORT_RANGE_MAX - 1u)], 1u);
+  }
   __syncthreads();
   uint32_t *out = cnt + ((size_t)r * J + j) * nbl;
   for (uint32_t b = threadIdx.x; b < nbl; b += SORT_THREADS) out[b] = s_bkt[b];
@@ -227,12 +241,21 @@ static __global__ __launch_bounds__(SORT_THREADS) void msm_scatter_kernel(const 
   __syncthreads();
   uint32_t e0, e1;
   sort_chunk(rng_off, r, j, J, e0, e1);
-  for (uint32_t e = e0 + threadIdx.x; e < e1; e += SORT_THREADS) {
-    uint32_t idx = rank[ent_s[e]];
-    if (idx != RANK_NONE) {
-      uint32_t b = ent_b[e];
-      uint32_t pos = atomicAdd(&s_bkt[(b >> 1) & (SORT_RANGE_MAX - 1u)], 1u);
-      entries[pos] = (((b >> ENT_WIN_SHIFT) * n + idx) << 1) | (b & 1u);
+  for (uint32_t e = e0 + threadIdx.x; e < e1; e += SORT_THREADS * SORT_UNROLL) {
+    uint32_t b[SORT_UNROLL], idx[SORT_UNROLL];
+#pragma unroll
+    for (int u = 0; u < SORT_UNROLL; u++) {
+      uint32_t eu = e + u * SORT_THREADS;
+      bool in = eu < e1;
+      b[u] = in ? ent_b[eu] : 0u;
+      idx[u] = in ? rank[ent_s[eu]] : RANK_NONE;
+    }
+#pragma unroll
+    for (int u = 0; u < SORT_UNROLL; u++) {
+      if (idx[u] != RANK_NONE) {
+        uint32_t pos = atomicAdd(&s_bkt[(b[u] >> 1) & (SORT_RANGE_MAX - 1u)], 1u);
+        entries[pos] = (((b[u] >> ENT_WIN_SHIFT) * n + idx[u]) << 1) | (b[u] & 1u);
+      }
     }
   }
 }
@@ -421,7 +444,7 @@ static __global__ __launch_bounds__(MSM_THREADS, MINW) void msm_big_kernel(const
     sh[threadIdx.x] = acc;
     __syncthreads();
     for (uint32_t s = MSM_THREADS / 2; s > 0; s >>= 1) {
-      if (threadIdx.x < s) sh[threadIdx.x] = add_full(sh[threadIdx.x], sh[threadIdx.x + s]);
+      if (threadIdx.x < s) sh[threadIdx.x] = add_full_inl(sh[threadIdx.x], sh[threadIdx.x + s]);
       __syncthreads();
     }
     if (threadIdx.x == 0) store_pod(partials + (size_t)w * BIG_SPLIT + sub, sh[0]);
@@ -436,7 +459,7 @@ static __global__ __launch_bounds__(64, MINW) void msm_big_finish_kernel(const X
   uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= min(*big_count, big_cap)) return;
   XYZZ<F> acc = load_pod(partials + (size_t)w * BIG_SPLIT);
-  for (int k = 1; k < BIG_SPLIT; k++) acc = add_full(acc, load_pod(partials + (size_t)w * BIG_SPLIT + k));
+  for (int k = 1; k < BIG_SPLIT; k++) acc = add_full_inl(acc, load_pod(partials + (size_t)w * BIG_SPLIT + k));
   store_pod(buckets + big_list[w], acc);
 }
 

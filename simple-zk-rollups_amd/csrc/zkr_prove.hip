@@ -158,7 +158,7 @@ int calc_h_device(zkr_key *k, ProofSlot &sl, hipStream_t s) {
 
 // ------------------------------------------------------------------ MSM driver
 template <class F> struct MsmCfg;
-template <> struct MsmCfg<Fq> { static constexpr int ACC_W = 4, RED_W = 2; static constexpr const char *ACC_STAGE = "msm_accum_g1"; };
+template <> struct MsmCfg<Fq> { static constexpr int ACC_W = 2, RED_W = 2; static constexpr const char *ACC_STAGE = "msm_accum_g1"; };
 template <> struct MsmCfg<Fq2> { static constexpr int ACC_W = 2, RED_W = 1; static constexpr const char *ACC_STAGE = "msm_accum_g2"; };
 
 // digit records of one scalar vector, split by bucket range; shared by every table over those scalars
@@ -205,15 +205,19 @@ template <class F>
 static int msm_accum_enqueue(Prof pf, hipStream_t s, const Affine<F> *pts, uint32_t n, const MsmPlan &pl, const MsmWorkspace &srt, MsmWorkspace &ws) {
   if (n == 0) return 0;
   int sp = prof_begin(pf, s, MsmCfg<F>::ACC_STAGE);
-  // waves per SIMD: one slot fewer than the register file allows, so that the preparation and reduction
-  // launches of the other streams always find a free wave slot beside a running accumulation
+  // waves per SIMD the compiler budgets registers for (amdgpu_waves_per_eu): measured best at 2 for both G1
+  // (115 G Fq-mul/s isolated vs 112 at 3 and 103 at 4; 92 vs 88 proofs/s) and G2; ZKR_ACC_W_G1 / ZKR_ACC_W_G2 override for experiments
   static const char *acc_env = getenv(sizeof(F) == 32 ? "ZKR_ACC_W_G1" : "ZKR_ACC_W_G2");
   static const int acc_w = acc_env ? atoi(acc_env) : MsmCfg<F>::ACC_W;
   const unsigned grid = (pl.nb + MSM_THREADS - 1) / MSM_THREADS;
-  if (acc_w == MsmCfg<F>::ACC_W)
-    msm_accum_kernel<F, MsmCfg<F>::ACC_W><<<grid, MSM_THREADS, 0, s>>>(pts, srt.offsets, srt.entries, pl.nb, srt.counts, srt.order, (XYZZ<F> *)ws.buckets);
-  else
-    msm_accum_kernel<F, MsmCfg<F>::ACC_W - 1><<<grid, MSM_THREADS, 0, s>>>(pts, srt.offsets, srt.entries, pl.nb, srt.counts, srt.order, (XYZZ<F> *)ws.buckets);
+#define ZKR_ACC_LAUNCH(W) msm_accum_kernel<F, W><<<grid, MSM_THREADS, 0, s>>>(pts, srt.offsets, srt.entries, pl.nb, srt.counts, srt.order, (XYZZ<F> *)ws.buckets)
+  switch (acc_w) {
+    case 1: ZKR_ACC_LAUNCH(1); break;
+    case 3: ZKR_ACC_LAUNCH(3); break;
+    case 4: ZKR_ACC_LAUNCH(4); break;
+    default: ZKR_ACC_LAUNCH(2); break;
+  }
+#undef ZKR_ACC_LAUNCH
   prof_end(pf, s, sp);
   ZKR_HIP_CHECK(hipGetLastError());
   return 0;
