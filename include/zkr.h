@@ -54,6 +54,13 @@ void zkr_key_free(zkr_key *key);
  * out[5..9]=points kept (non-infinity) in the A,B1,B2,C,H tables. */
 int zkr_key_info(const zkr_key *key, uint64_t out[10]);
 
+/* Packed key on disk: the device arena -- CSR rows, window tables, twiddles -- written as is, so a
+ * later process loads it with one read + one upload: no JSON, no binarifyProvingKey (binarify.ts:50-207, per call in
+ * the reference), no re-parse and no window-table rebuild.  The file is position independent; its header carries
+ * a magic and the total length. */
+int zkr_key_save(const zkr_key *key, const char *path);
+int zkr_key_load_file(const char *path, int device, zkr_key **out);
+
 /* MSM geometry of the device key: window bits c and window count K = ceil(255/c) of the A,B1,B2,C,H tables.  Each
  * table holds K levels per base point (2^(ck) P), so an MSM costs K mixed additions per point. */
 int zkr_key_windows(const zkr_key *key, uint32_t c_out[5], uint32_t k_out[5]);

@@ -1,4 +1,4 @@
-// curve.cuh -- short-Weierstrass (a = 0) group law in XYZZ coordinates, generic over the coordinate
+// curve.hpp -- short-Weierstrass (a = 0) group law in XYZZ coordinates, generic over the coordinate
 // field: F = Fq gives G1 (y^2 = x^3 + 3), F = Fq2 gives G2 on the twist.  The formulas never use the
 // curve constant b, so one template serves both groups.
 //
@@ -8,7 +8,7 @@
 // Affine wire format = the key sections written by binarify.ts:92-102: Montgomery coordinates,
 // x == 0 encodes the point at infinity (snarkjs' [0,1,0]; x = 0 is never on either curve).
 #pragma once
-#include "field.cuh"
+#include "field.hpp"
 
 namespace zkr {
 

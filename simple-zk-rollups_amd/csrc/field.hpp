@@ -1,4 +1,4 @@
-// field.cuh -- BN254 Fq / Fr Montgomery arithmetic on 8 x u32 limbs (device and host).
+// field.hpp -- BN254 Fq / Fr Montgomery arithmetic on 8 x u32 limbs (device and host).
 //
 // Written for the CDNA4 VALU: every product is a 32x32+64 multiply-add (v_mad_u64_u32); loops are
 // fully unrolled so an element lives in 8 VGPRs.  No MFMA: this is integer work.

@@ -2,7 +2,7 @@
 // CPU arithmetic test shim.  Uses the same field/curve templates as the device code.
 #pragma once
 #include <string.h>
-#include "curve.cuh"
+#include "curve.hpp"
 
 namespace zkr {
 

@@ -1,4 +1,4 @@
-// kernels_msm.cuh -- multi-scalar multiplication over G1 / G2 (Pippenger bucket method over precomputed
+// kernels_msm.hpp -- multi-scalar multiplication over G1 / G2 (Pippenger bucket method over precomputed
 // window tables) and the fixed-base kernels of the device-side setup.
 //
 // Path: the five multiexps of websnark's groth16GenProof (call site
@@ -21,7 +21,7 @@
 //   big      : workgroups share an oversized bucket (0/1-heavy witnesses), LDS tree of XYZZ sums
 //   reduce   : sum_b b*B_b in three launches (group running sums, bit-subset sums, finish) -> the MSM result
 #pragma once
-#include "curve.cuh"
+#include "curve.hpp"
 
 namespace zkr {
 

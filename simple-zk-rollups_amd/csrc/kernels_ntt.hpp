@@ -1,4 +1,4 @@
-// kernels_ntt.cuh -- BN254 Fr NTT passes, QAP row evaluation and the element-wise stages of calcH.
+// kernels_ntt.hpp -- BN254 Fr NTT passes, QAP row evaluation and the element-wise stages of calcH.
 //
 // Path: websnark groth16GenProof's calcH (called at /root/reference/operator/src/snarks/common.ts:29;
 // algorithm SURVEY.md App. B steps 1-3).  Vectors stay in STANDARD form in HBM, every constant
@@ -13,7 +13,7 @@
 //   Twiddles w_{2s}^x come from one table per key (w_{2m}^k, k<m, serves all spans up to m and the
 //   coset factors) plus a 32 KB table w_2048^k shared by every contiguous pass (L1/L2 resident).
 #pragma once
-#include "curve.cuh"
+#include "curve.hpp"
 
 namespace zkr {
 

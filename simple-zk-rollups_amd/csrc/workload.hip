@@ -1,6 +1,6 @@
 // workload.hip -- seeded synthetic rollup-shaped R1CS, witness, and Groth16 setup (SURVEY.md 8(d)
 // configs 2-5, 8(f-2)).  Host logic here; the key's group elements are computed on the GPU by the
-// fixed-base kernel (kernels_msm.cuh), so no multi-GB websnark binary ever exists on the host.
+// fixed-base kernel (kernels_msm.hpp), so no multi-GB websnark binary ever exists on the host.
 //
 // The reference has no checked-in key or circuit artefact (prover/.gitignore:109), so benchmark
 // inputs must be generated.  Restates `snarkjs setup --protocol groth` (prover/package.json:34,37;

@@ -45,7 +45,7 @@ static_assert(sizeof(ArenaHeader) <= 1024, "header fits its slot");
 constexpr size_t ARENA_HEADER_BYTES = 1024;
 constexpr uint64_t ARENA_MAGIC = 0x313059454b524b5aull;
 
-// digit records of one scalar vector, split by bucket range (kernels_msm.cuh "digit sort", stage 1)
+// digit records of one scalar vector, split by bucket range (kernels_msm.hpp "digit sort", stage 1)
 struct DigitLists {
   uint32_t *rng = nullptr;  // [MAX_RANGES] counts | [MAX_RANGES] fill cursors | [MAX_RANGES + 1] offsets
   uint32_t *ent_s = nullptr, *ent_b = nullptr;

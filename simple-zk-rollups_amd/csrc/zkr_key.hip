@@ -6,8 +6,8 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
-#include "kernels_msm.cuh"
-#include "kernels_ntt.cuh"
+#include "kernels_msm.hpp"
+#include "kernels_ntt.hpp"
 #include "zkr_internal.hpp"
 
 namespace zkr {
@@ -43,7 +43,7 @@ static Fr fr_root_of_unity(unsigned k) {
 Fr host_root_of_unity(unsigned k) { return fr_root_of_unity(k); }
 
 // Window size from the length of the SCALAR vector (tables that share scalars share the digit codes,
-// kernels_msm.cuh msm_digits_kernel) unless the key fixes it (c_fixed: the window tables in the arena were built
+// kernels_msm.hpp msm_digits_kernel) unless the key fixes it (c_fixed: the window tables in the arena were built
 // for that c); chunking and the oversized-bucket threshold from the table itself.
 MsmPlan msm_plan(size_t n_scalars, size_t n, int c_fixed) {
   MsmPlan pl;
@@ -58,7 +58,7 @@ MsmPlan msm_plan(size_t n_scalars, size_t n, int c_fixed) {
   pl.K = (255 + c - 1) / c;
   pl.nbw = 1u << (c - 1);
   pl.nb = pl.nbw;
-  pl.glog = c - 1 < 3 ? c - 1 : 3;  // bucket reduction: groups of 8 buckets (kernels_msm.cuh msm_reduce1_kernel)
+  pl.glog = c - 1 < 3 ? c - 1 : 3;  // bucket reduction: groups of 8 buckets (kernels_msm.hpp msm_reduce1_kernel)
   uint64_t mean = (uint64_t)n * pl.K / pl.nbw + 1;
   pl.big_thresh = mean * 8 > 256 ? (uint32_t)(mean * 8) : 256;
   if (const char *e = getenv("ZKR_MSM_BIG")) { int v = atoi(e); if (v >= 1) pl.big_thresh = (uint32_t)v; }
@@ -465,6 +465,70 @@ int zkr_key_adopt_arena(void *dev_ptr, size_t len, int device, zkr_key **out) {
   k->owns_arena = false;
   k->h = h;
   int rc = key_alloc_workspace(k);
+  if (rc) { zkr_key_free(k); return rc; }
+  *out = k;
+  return 0;
+}
+
+int zkr_key_save(const zkr_key *k, const char *path) {
+  if (!k || !path) { set_error("null argument"); return ZKR_ERR_ARG; }
+  ZKR_HIP_CHECK(hipSetDevice(k->device));
+  FILE *f = fopen(path, "wb");
+  if (!f) { set_error("cannot open %s for writing", path); return ZKR_ERR_ARG; }
+  const size_t CHUNK = (size_t)64 << 20;
+  void *stage = nullptr;
+  hipError_t e = hipHostMalloc(&stage, CHUNK, hipHostMallocDefault);
+  int rc = 0;
+  if (e != hipSuccess) { set_error("pinned staging buffer: %s", hipGetErrorString(e)); rc = ZKR_ERR_HIP; }
+  for (size_t off = 0; !rc && off < k->arena_len; off += CHUNK) {
+    size_t nb = k->arena_len - off < CHUNK ? k->arena_len - off : CHUNK;
+    e = hipMemcpy(stage, k->arena + off, nb, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { set_error("arena download failed: %s", hipGetErrorString(e)); rc = ZKR_ERR_HIP; }
+    else if (fwrite(stage, 1, nb, f) != nb) { set_error("short write to %s", path); rc = ZKR_ERR_ARG; }
+  }
+  if (stage) hipHostFree(stage);
+  if (fclose(f) != 0 && !rc) { set_error("close failed on %s", path); rc = ZKR_ERR_ARG; }
+  return rc;
+}
+
+int zkr_key_load_file(const char *path, int device, zkr_key **out) {
+  if (!path || !out) { set_error("null argument"); return ZKR_ERR_ARG; }
+  if (zkr_device_count() <= device || device < 0) { set_error("no HIP device %d (found %d); libzkr_hip has no CPU fallback", device, zkr_device_count()); return ZKR_ERR_NO_DEVICE; }
+  ZKR_HIP_CHECK(hipSetDevice(device));
+  FILE *f = fopen(path, "rb");
+  if (!f) { set_error("cannot open %s", path); return ZKR_ERR_BAD_KEY; }
+  ArenaHeader h;
+  if (fread(&h, 1, sizeof(h), f) != sizeof(h) || h.magic != ARENA_MAGIC || h.total_len < ARENA_HEADER_BYTES) {
+    fclose(f);
+    set_error("%s is not a packed zkr key (bad header)", path);
+    return ZKR_ERR_BAD_KEY;
+  }
+  fseek(f, 0, SEEK_END);
+  long flen = ftell(f);
+  if (flen < 0 || (uint64_t)flen != h.total_len) { fclose(f); set_error("%s: length %ld != header total %llu", path, flen, (unsigned long long)h.total_len); return ZKR_ERR_BAD_KEY; }
+  fseek(f, 0, SEEK_SET);
+  unsigned char *arena = nullptr;
+  const size_t CHUNK = (size_t)64 << 20;
+  void *stage = nullptr;
+  int rc = 0;
+  hipError_t e = hipMalloc(&arena, h.total_len);
+  if (e == hipSuccess) e = hipHostMalloc(&stage, CHUNK, hipHostMallocDefault);
+  if (e != hipSuccess) { set_error("allocation failed: %s", hipGetErrorString(e)); rc = ZKR_ERR_HIP; }
+  for (size_t off = 0; !rc && off < h.total_len; off += CHUNK) {
+    size_t nb = h.total_len - off < CHUNK ? h.total_len - off : CHUNK;
+    if (fread(stage, 1, nb, f) != nb) { set_error("short read from %s", path); rc = ZKR_ERR_BAD_KEY; }
+    else if ((e = hipMemcpy(arena + off, stage, nb, hipMemcpyHostToDevice)) != hipSuccess) { set_error("arena upload failed: %s", hipGetErrorString(e)); rc = ZKR_ERR_HIP; }
+  }
+  fclose(f);
+  if (stage) hipHostFree(stage);
+  if (rc) { hipFree(arena); return rc; }
+  zkr_key *k = new zkr_key();
+  k->device = device;
+  k->arena = arena;
+  k->arena_len = h.total_len;
+  k->owns_arena = true;
+  k->h = h;
+  rc = key_alloc_workspace(k);
   if (rc) { zkr_key_free(k); return rc; }
   *out = k;
   return 0;

@@ -10,8 +10,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
-#include "kernels_msm.cuh"
-#include "kernels_ntt.cuh"
+#include "kernels_msm.hpp"
+#include "kernels_ntt.hpp"
 #include "zkr_internal.hpp"
 
 namespace zkr {

@@ -33,6 +33,8 @@ def lib():
     L.zkr_key_free.argtypes = [vp]
     L.zkr_key_free.restype = None
     L.zkr_key_info.argtypes = [vp, c.POINTER(c.c_uint64)]
+    L.zkr_key_save.argtypes = [vp, c.c_char_p]
+    L.zkr_key_load_file.argtypes = [c.c_char_p, i, c.POINTER(vp)]
     L.zkr_key_windows.argtypes = [vp, c.POINTER(c.c_uint32), c.POINTER(c.c_uint32)]
     L.zkr_key_arena.argtypes = [vp, c.POINTER(vp), c.POINTER(sz)]
     L.zkr_key_adopt_arena.argtypes = [vp, sz, i, c.POINTER(vp)]
@@ -109,6 +111,16 @@ class ProvingKey:
         h = ctypes.c_void_p()
         _check(lib().zkr_key_adopt_arena(ctypes.c_void_p(dev_ptr), length, device, ctypes.byref(h)))
         return cls(h, device, keepalive)
+
+    @classmethod
+    def load_file(cls, path, device=0):
+        """Packed key written by save(): one read + one upload, no parse, no window-table rebuild."""
+        h = ctypes.c_void_p()
+        _check(lib().zkr_key_load_file(os.fsencode(path), device, ctypes.byref(h)))
+        return cls(h, device)
+
+    def save(self, path):
+        _check(lib().zkr_key_save(self._h, os.fsencode(path)))
 
     def close(self):
         if self._h:

@@ -180,3 +180,24 @@ def test_synth_generator_and_device_setup_match_oracle(log_m, p):
     replica_mem = _tensor_from_ptr(ptr, n, 0).clone()
     key3 = zkr_hip.ProvingKey.adopt_arena(replica_mem.data_ptr(), n, 0, keepalive=replica_mem)
     assert key3.prove(wb, r, s) == proof
+
+
+def test_packed_key_file_roundtrip(tmp_path, small_case):
+    """zkr_key_save / zkr_key_load_file: the reloaded key proves bit-identically; a truncated or
+    foreign file is refused."""
+    import zkr_hip
+    c = small_case
+    key = zkr_hip.ProvingKey.load_websnark(c["pkb"])
+    path = str(tmp_path / "tx.zkrkey")
+    key.save(path)
+    key2 = zkr_hip.ProvingKey.load_file(path)
+    assert key2.info() == key.info() and key2.windows() == key.windows()
+    assert key2.prove(c["wb"], c["r"], c["s"]) == key.prove(c["wb"], c["r"], c["s"]) == coracle.prove(c["pkb"], c["wb"], c["r"], c["s"])
+    blob = open(path, "rb").read()
+    bad = str(tmp_path / "bad.zkrkey")
+    open(bad, "wb").write(blob[:-7])
+    with pytest.raises(zkr_hip.ZkrError):
+        zkr_hip.ProvingKey.load_file(bad)
+    open(bad, "wb").write(b"\0" * 4096)
+    with pytest.raises(zkr_hip.ZkrError):
+        zkr_hip.ProvingKey.load_file(bad)

@@ -1,4 +1,4 @@
-"""CPU: the DEVICE field/curve templates (csrc/field.cuh, curve.cuh) compiled for the host agree with
+"""CPU: the DEVICE field/curve templates (csrc/field.hpp, curve.hpp) compiled for the host agree with
 the oracle -- the same source the gfx950 kernels inline."""
 import ctypes
 import os

@@ -1,4 +1,4 @@
-"""CPU: index-for-index Python model of the HIP NTT pass structure (csrc/kernels_ntt.cuh ntt_pass_kernel,
+"""CPU: index-for-index Python model of the HIP NTT pass structure (csrc/kernels_ntt.hpp ntt_pass_kernel,
 zkr_prove.hip ntt_plan) and of the calcH pipeline constants, checked against the oracle NTT / calcH."""
 import random
 
