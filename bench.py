@@ -38,6 +38,55 @@ def cpu_baseline(sample_log_m, target_log_m):
                                                                               target_log_m - sample_log_m, target_log_m)}
 
 
+def cpu_baseline_js(sample_log_m, target_log_m):
+    """oracle/cpu_ref_js.js: single-thread snarkjs-0.1.20-shaped genProof (one double-and-add scalar
+    multiplication per signal and query, native BigInt) on a small key of the same generator, scaled linearly in
+    m.  snarkjs itself is not installable here; this restates its algorithm and is pinned against
+    the closed form in tests/test_oracle.py."""
+    import shutil
+    import subprocess
+    import tempfile
+    node = shutil.which("node")
+    if node is None:
+        return {"error": "node is not available on this box"}
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import groth16 as g
+    import zkr_hip
+    pkb, wb = zkr_hip.synth_websnark(sample_log_m, N_PUBLIC, CIRCUIT_SEED, TOXIC_SEED, device=0)
+    jk = g.to_json_key(g.parse_proving_key(pkb))
+
+    def js(x):
+        if isinstance(x, bool) or x is None:
+            return x
+        if isinstance(x, int):
+            return str(x)
+        if isinstance(x, dict):
+            return {str(k): js(v) for k, v in x.items()}
+        if isinstance(x, (list, tuple)):
+            return [js(v) for v in x]
+        return x
+    key = js(jk)
+    for f in ("nVars", "nPublic", "domainSize"):
+        key[f] = int(key[f])
+    wit = [str(int.from_bytes(wb[32 * i:32 * i + 32], "little")) for i in range(len(wb) // 32)]
+    with tempfile.NamedTemporaryFile("w", suffix=".json", delete=False) as f:
+        json.dump({"pk": key, "witness": wit, "r": "12345", "s": "67890"}, f)
+        path = f.name
+    try:
+        out = subprocess.run([node, os.path.join(ROOT, "oracle", "cpu_ref_js.js"), path], capture_output=True, text=True, timeout=900)
+    finally:
+        os.unlink(path)
+    if out.returncode != 0:
+        return {"error": out.stderr[-300:]}
+    sec = json.loads(out.stdout)["seconds"]
+    scale = 2.0 ** (target_log_m - sample_log_m)
+    return {"value": 1.0 / (sec["total"] * scale), "unit": "proofs/s", "cores": 1, "kind": "port",
+            "sample": "oracle/cpu_ref_js.js (snarkjs-0.1.20-shaped genProof, node %s, native BigInt, 1 thread), m=2^%d key: %.1f s/proof "
+                      "(calculateH %.1f s, per-signal scalar multiplications %.1f s); value = 1/(t * 2^%d)"
+                      % (subprocess.run([node, "--version"], capture_output=True, text=True).stdout.strip(), sample_log_m, sec["total"],
+                         sec["h"], sec["msm"], target_log_m - sample_log_m)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -46,6 +95,8 @@ def main():
     ap.add_argument("--log-m", type=int, default=20)
     ap.add_argument("--cpu-sample-log-m", type=int, default=17)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--js-sample-log-m", type=int, default=10)
+    ap.add_argument("--no-js-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="synchronous proofs, one at a time (latency)")
     args = ap.parse_args()
 
@@ -181,6 +232,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample_log_m, args.log_m)
             out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
+            if not args.no_js_baseline:
+                out["cpu_baseline"]["snarkjs_style"] = cpu_baseline_js(args.js_sample_log_m, args.log_m)
         print(json.dumps(out))
     if dist:
         dist.barrier()

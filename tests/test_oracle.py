@@ -174,3 +174,38 @@ def test_golden_fixture_reproduces(name):
     proof = coracle.prove(pkb, wb, int(fx["r"]), int(fx["s"]))
     assert proof.hex() == fx["proof_bytes_hex"]
     assert fx["is_valid"] is True
+
+
+def _stringify(x):
+    if isinstance(x, bool) or x is None:
+        return x
+    if isinstance(x, int):
+        return str(x)
+    if isinstance(x, dict):
+        return {str(k): _stringify(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_stringify(v) for v in x]
+    return x
+
+
+def test_js_snarkjs_style_baseline_equals_closed_form(tmp_path, small_case):
+    """oracle/cpu_ref_js.js (single-thread snarkjs-0.1.20-shaped genProof on native BigInt: the CPU baseline of
+    bench.py) produces the closed-form proof, so the time it reports is for the right computation."""
+    import json
+    import shutil
+    import subprocess
+    node = shutil.which("node")
+    if node is None:
+        pytest.skip("node is not available")
+    c = small_case
+    jk = _stringify(g.to_json_key(c["pk"]))
+    for f in ("nVars", "nPublic", "domainSize", "domainBits"):
+        jk[f] = int(jk[f])
+    path = tmp_path / "case.json"
+    path.write_text(json.dumps(dict(pk=jk, witness=[str(x) for x in c["w"]], r=str(c["r"]), s=str(c["s"]))))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([node, os.path.join(root, "oracle", "cpu_ref_js.js"), str(path)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr
+    res = json.loads(out.stdout)
+    assert res["proof"] == g.proof_to_json(g.proof_from_toxic(c["circ"], c["tox"], c["w"], c["r"], c["s"]))
+    assert res["seconds"]["total"] > 0
