@@ -94,6 +94,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log-m", type=int, default=20)
     ap.add_argument("--cpu-sample-log-m", type=int, default=17)
+    ap.add_argument("--shape", choices=["rollup", "dense"], default="rollup",
+                    help="synthetic circuit: rollup-shaped (BASELINE configs[1..3]) or dense random (configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--js-sample-log-m", type=int, default=10)
     ap.add_argument("--no-js-baseline", action="store_true")
@@ -114,6 +116,7 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
+    zkr_hip.synth_set_shape(1 if args.shape == "dense" else 0)
     # ---- key: generated on rank 0 (points computed on the GPU), replicated by one broadcast of the arena
     t_setup = time.time()
     key = None
@@ -220,7 +223,7 @@ def main():
             "metric": "Groth16 proofs/sec (rollup batch circuit)", "value": value, "unit": "proofs/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u32x8 Montgomery (254-bit integer)", "data": "synthetic",
-            "config": {"workload": "2^%d-constraint synthetic rollup circuit, 1 proof per step per GPU" % args.log_m,
+            "config": {"workload": "2^%d-constraint synthetic %s, 1 proof per step per GPU" % (args.log_m, "rollup circuit" if args.shape == "rollup" else "dense random R1CS"),
                        "log_m": args.log_m, "n_public": N_PUBLIC, "nVars": info["nVars"], "nnzA": info["nnzA"], "nnzB": info["nnzB"],
                        "parallelism": "proof-sharded x%d (key arena broadcast once over RCCL)" % world,
                        "proofs_in_flight": 1 if args.no_pipeline else 2},

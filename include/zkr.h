@@ -130,6 +130,10 @@ int zkr_synth_websnark(unsigned log_m, unsigned n_public, uint64_t circuit_seed,
  * circuit_seed, free values from witness_seed (zkr_synth_key uses witness_seed = circuit_seed). */
 int zkr_synth_witness(unsigned log_m, unsigned n_public, uint64_t circuit_seed, uint64_t witness_seed, void **witness_out,
                       size_t *witness_len);
+/* Circuit shape drawn by the three zkr_synth_* calls above (process-wide): 0 = rollup-shaped (default; 1-3 terms
+ * per row, 3 % boolean and 2 % small signals, a third of the signals absent from B), 1 = dense random (BASELINE.json
+ * configs[4]: every row is (4 random signals) x (4 random signals) = new signal; no infinity points in any query). */
+int zkr_synth_set_shape(unsigned shape);
 void zkr_free(void *p);
 
 /* Integer-ALU microbenchmark: sustained Fq Montgomery multiplications per second on `device`

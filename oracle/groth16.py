@@ -46,13 +46,16 @@ class SplitMix64:
                 return v
 
 
-def synth_circuit(m, p, seed, witness_seed=None):
+def synth_circuit(m, p, seed, witness_seed=None, shape=0):
     """Rollup-shaped synthetic R1CS with witness by forward evaluation (SURVEY.md 8(d) config 2,
     Appendix D): ~93 % MiMC-like multiplication rows with 1-3 nnz per A/B/C row, 3 % boolean
     rows, 2 % small (64-bit) values, and a 64-term packing row every 2048 rows.
     Structure (row kinds, wiring, coefficients) is drawn from SplitMix64(seed); free witness values
     (public inputs, booleans, small values) from SplitMix64(witness_seed ^ 0x77697473), so one key
     serves a batch of different witnesses.  witness_seed defaults to seed.
+    shape=1 (BASELINE config 5, "dense random"): every row is (sum of 4 random signals with random coefficients) x
+    (another such sum) = new signal, so every signal has A-, B1- and B2-query points (no infinities: G2 stress) and
+    the QAP rows gather from uniformly random columns.
     Returns dict(nVars, nPublic, nConstraints, rows=[(A,B,C)], witness=[...]); A/B/C are
     lists of (signal, coef).  Mirrors synth_circuit in csrc/workload.hip draw for draw."""
     rng = SplitMix64(seed)
@@ -62,6 +65,17 @@ def synth_circuit(m, p, seed, witness_seed=None):
     rows = []
     for c in range(nC):
         n = len(w)
+        if shape == 1:
+            A, B = {}, {}
+            for d in (A, B):
+                for _ in range(4):
+                    j = rng.u64() % n
+                    d[j] = (d.get(j, 0) + rng.fr()) % R
+            va = sum(cf * w[s] for s, cf in A.items()) % R
+            vb = sum(cf * w[s] for s, cf in B.items()) % R
+            w.append(va * vb % R)
+            rows.append((sorted(A.items()), sorted(B.items()), [(n, 1)]))
+            continue
         kind = rng.u64() % 100
         if c % 2048 == 1000:
             A = {}

@@ -59,6 +59,9 @@ static Fr dot(const std::vector<Term> &t, size_t b, size_t e, const std::vector<
   return acc;
 }
 
+// circuit shape of the zkr_synth_* entry points: 0 = rollup-shaped (default), 1 = dense random (BASELINE config 5)
+static unsigned g_shape = 0;
+
 // draw-for-draw mirror of oracle/groth16.py:synth_circuit
 static void synth_circuit(Circuit &c, uint32_t m, uint32_t p, uint64_t seed, uint64_t witness_seed) {
   SplitMix64 rng(seed);
@@ -71,6 +74,25 @@ static void synth_circuit(Circuit &c, uint32_t m, uint32_t p, uint64_t seed, uin
   c.rowA.push_back(0); c.rowB.push_back(0); c.rowC.push_back(0);
   for (uint32_t row = 0; row < c.nC; row++) {
     uint32_t n = (uint32_t)c.w.size();
+    if (g_shape == 1) {  // (4 random signals, random coefficients) x (4 more) = new signal
+      std::map<uint32_t, Fr> AB[2];
+      for (auto &d : AB)
+        for (int k = 0; k < 4; k++) {
+          uint32_t j = (uint32_t)(rng.u64() % n);
+          Fr cf = rng.fr();
+          auto it = d.find(j);
+          if (it == d.end()) d[j] = cf; else it->second = add(it->second, cf);
+        }
+      size_t ba = c.tA.size(), bb = c.tB.size();
+      for (auto &kv : AB[0]) c.tA.push_back({kv.first, kv.second});
+      for (auto &kv : AB[1]) c.tB.push_back({kv.first, kv.second});
+      c.w.push_back(mul(dot(c.tA, ba, c.tA.size(), c.w), dot(c.tB, bb, c.tB.size(), c.w)));
+      c.tC.push_back({n, one});
+      c.rowA.push_back((uint32_t)c.tA.size());
+      c.rowB.push_back((uint32_t)c.tB.size());
+      c.rowC.push_back((uint32_t)c.tC.size());
+      continue;
+    }
     uint64_t kind = rng.u64() % 100;
     if (row % 2048 == 1000) {
       std::map<uint32_t, Fr> A;
@@ -245,6 +267,12 @@ static uint32_t bitrev32(uint32_t x, unsigned bits) {
 using namespace zkr;
 
 extern "C" {
+
+int zkr_synth_set_shape(unsigned shape) {
+  if (shape > 1) { set_error("unknown synthetic circuit shape %u", shape); return ZKR_ERR_ARG; }
+  g_shape = shape;
+  return 0;
+}
 
 int zkr_synth_key(unsigned log_m, unsigned n_public, uint64_t circuit_seed, uint64_t toxic_seed, int device, zkr_key **key_out,
                   void **witness_out, size_t *witness_len, void **aux_out, size_t *aux_len) {

@@ -54,6 +54,7 @@ def lib():
     L.zkr_synth_websnark.argtypes = [c.c_uint, c.c_uint, c.c_uint64, c.c_uint64, i, c.POINTER(vp), c.POINTER(sz),
                                      c.POINTER(vp), c.POINTER(sz)]
     L.zkr_synth_witness.argtypes = [c.c_uint, c.c_uint, c.c_uint64, c.c_uint64, c.POINTER(vp), c.POINTER(sz)]
+    L.zkr_synth_set_shape.argtypes = [c.c_uint]
     L.zkr_free.argtypes = [vp]
     L.zkr_free.restype = None
     L.zkr_bench_fq_mul.argtypes = [i, c.POINTER(c.c_double)]
@@ -209,6 +210,11 @@ class ProvingKey:
             _check(lib().zkr_prof_get(self._h, st.encode(), ctypes.byref(ms), ctypes.byref(n)))
             out[st] = (ms.value, n.value)
         return out
+
+
+def synth_set_shape(shape: int):
+    """0 = rollup-shaped synthetic circuit (default), 1 = dense random (BASELINE configs[4])."""
+    _check(lib().zkr_synth_set_shape(shape))
 
 
 def ntt(data: bytes, inverse=False, device=0) -> bytes:

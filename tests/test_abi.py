@@ -75,3 +75,19 @@ def test_facade_shapes():
     assert pj == {"pi_a": ["1", "2", "1"], "pi_b": [["3", "4"], ["5", "6"], ["1", "0"]], "pi_c": ["7", "8", "1"]}
     sp = zkr_hip.solidity_proof(pj, [5, zkr_hip.facade.SNARK_FIELD_SIZE + 2])
     assert sp == {"a": ["1", "2"], "b": [["4", "3"], ["6", "5"]], "c": ["7", "8"], "inputs": ["5", "2"]}
+
+
+def test_dense_shape_witness_generator_matches_oracle_on_cpu():
+    """zkr_synth_witness needs no GPU: the dense-random shape (BASELINE configs[4]) draws the same witness as the
+    oracle's generator."""
+    import groth16 as g
+    import zkr_hip
+    zkr_hip.synth_set_shape(1)
+    try:
+        wb = zkr_hip.synth_witness(7, 5, 0x5A4B0005, 0x5A4B0005)
+    finally:
+        zkr_hip.synth_set_shape(0)
+    circ = g.synth_circuit(128, 5, 0x5A4B0005, shape=1)
+    assert g.check_r1cs(circ)
+    assert wb == g.binarify_witness(circ["witness"])
+    assert zkr_hip.synth_witness(7, 5, 0x5A4B0005, 0x5A4B0005) == g.binarify_witness(g.synth_circuit(128, 5, 0x5A4B0005)["witness"])

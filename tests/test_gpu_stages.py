@@ -201,3 +201,31 @@ def test_packed_key_file_roundtrip(tmp_path, small_case):
     open(bad, "wb").write(b"\0" * 4096)
     with pytest.raises(zkr_hip.ZkrError):
         zkr_hip.ProvingKey.load_file(bad)
+
+
+def test_dense_random_shape_matches_oracle_generator():
+    """BASELINE configs[4] shape (dense random R1CS: no infinity points in any query): product-side generator +
+    device setup == oracle generator + setup byte for byte, proof == oracle proof == closed form."""
+    import zkr_hip
+    log_m, p = 8, 5
+    zkr_hip.synth_set_shape(1)
+    try:
+        pkb, wb = zkr_hip.synth_websnark(log_m, p, 0x5A4B0005, 0x5A4B00FF)
+        key2, wb2, _ = zkr_hip.ProvingKey.synth(log_m, p, 0x5A4B0005, 0x5A4B00FF)
+    finally:
+        zkr_hip.synth_set_shape(0)
+    circ = g.synth_circuit(1 << log_m, p, 0x5A4B0005, shape=1)
+    assert g.check_r1cs(circ) and circ["nVars"] == 1 << log_m
+    assert g.binarify_witness(circ["witness"]) == wb == wb2
+    tox = g.toxic_from_seed(0x5A4B00FF)
+    pk, _ = g.setup(circ, tox)
+    assert g.binarify_proving_key(g.to_json_key(pk)) == pkb
+    key = zkr_hip.ProvingKey.load_websnark(pkb)
+    info = key.info()
+    # far fewer infinity points than the rollup shape (a third of B there): only the newest signals are still unused
+    assert info["ptsB1"] == info["ptsB2"] >= 0.75 * circ["nVars"] and info["ptsA"] >= 0.75 * circ["nVars"]
+    rng = g.SplitMix64(55)
+    r, s = rng.fr(), rng.fr()
+    proof = key.prove(wb, r, s)
+    assert proof == coracle.prove(pkb, wb, r, s) == g.proof_bytes(g.proof_from_toxic(circ, tox, circ["witness"], r, s))
+    assert key2.prove(wb, r, s) == proof
