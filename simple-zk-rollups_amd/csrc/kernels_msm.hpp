@@ -409,11 +409,11 @@ static __global__ __launch_bounds__(MSM_THREADS) __attribute__((amdgpu_waves_per
     for (uint32_t j = o0 + 1; j < o1; j++) {
       uint32_t en = entries[j];
       Affine<F> pn = load_pod(points + (en >> 1));
-      acc = add_mixed(acc, p, (e & 1) != 0);
+      if (!p.is_inf()) acc = add_mixed(acc, p, (e & 1) != 0);  // infinity: placeholder of a shared-support table
       e = en;
       p = pn;
     }
-    acc = add_mixed(acc, p, (e & 1) != 0);
+    if (!p.is_inf()) acc = add_mixed(acc, p, (e & 1) != 0);
   }
   store_pod(buckets + b, acc);
 }
@@ -439,7 +439,7 @@ static __global__ __launch_bounds__(MSM_THREADS, MINW) void msm_big_kernel(const
     for (uint32_t j = o0 + sub * MSM_THREADS + threadIdx.x; j < o1; j += MSM_THREADS * BIG_SPLIT) {
       uint32_t e = entries[j];
       Affine<F> p = load_pod(points + (e >> 1));
-      acc = add_mixed(acc, p, (e & 1) != 0);
+      if (!p.is_inf()) acc = add_mixed(acc, p, (e & 1) != 0);
     }
     sh[threadIdx.x] = acc;
     __syncthreads();
@@ -557,6 +557,10 @@ static __global__ __launch_bounds__(MSM_THREADS, MINW) void msm_precompute_kerne
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   Affine<F> p = load_pod(tbl + i);
+  if (p.is_inf()) {  // placeholder of a table laid out over a shared support: infinity at every level
+    for (int k = 1; k < K; k++) store_pod(tbl + (size_t)k * n + i, p);
+    return;
+  }
   for (int k = 1; k < K; k++) {
     XYZZ<F> x = dbl_affine(p);
     for (int b = 1; b < c; b++) x = dbl_xyzz(x);
@@ -590,7 +594,13 @@ template <class T>
 static __global__ void gather_kernel(const T *in, const uint32_t *idx, size_t n, T *out) {
   size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
-  store_pod(out + j, load_pod(in + idx[j]));
+  uint32_t src = idx[j];
+  if (src == 0xffffffffu) {  // no source point: the point at infinity (x = 0)
+    uint4 *q = reinterpret_cast<uint4 *>(out + j);
+    for (unsigned i = 0; i < sizeof(T) / 16; i++) q[i] = make_uint4(0, 0, 0, 0);
+    return;
+  }
+  store_pod(out + j, load_pod(in + src));
 }
 
 // VALU roofline microbenchmark: dependent chains of Fq Montgomery products, 4 independent chains/lane

@@ -195,9 +195,34 @@ int key_build(int device, uint32_t n, uint32_t p, uint32_t m, const std::vector<
     h.off_col[s] = take(col[s].size() * 4 + 4);
     h.off_coef[s] = take(coef[s].size() + 32);
   }
+  // A and C multiply the same scalars and nearly the same signals (C lacks the public ones): when their supports
+  // overlap by >= 90 % both tables are laid out over the UNION of the supports (a missing point is stored as
+  // infinity, x = 0, and skipped by the accumulation), so one digit sort serves both (h.share_ac).
+  const std::vector<uint32_t> *srcidx_eff[N_TABLES], *sidx_eff[N_TABLES];
+  for (int t = 0; t < N_TABLES; t++) { srcidx_eff[t] = &tbl_srcidx[t]; sidx_eff[t] = &tbl_sidx[t]; }
+  std::vector<uint32_t> u_sidx, uA_src, uC_src;
+  {
+    const std::vector<uint32_t> &sa = tbl_sidx[T_A], &sc = tbl_sidx[T_C];
+    size_t i = 0, j = 0, both = 0;
+    while (i < sa.size() || j < sc.size()) {
+      uint32_t a = i < sa.size() ? sa[i] : 0xffffffffu, c = j < sc.size() ? sc[j] : 0xffffffffu;
+      uint32_t s = a < c ? a : c;
+      u_sidx.push_back(s);
+      uA_src.push_back(a == s ? tbl_srcidx[T_A][i] : RANK_NONE);
+      uC_src.push_back(c == s ? tbl_srcidx[T_C][j] : RANK_NONE);
+      both += (a == s && c == s);
+      if (a == s) i++;
+      if (c == s) j++;
+    }
+    if (!u_sidx.empty() && both * 10 >= u_sidx.size() * 9 && !getenv("ZKR_NO_SHARE_AC")) {
+      h.share_ac = 1;
+      srcidx_eff[T_A] = &uA_src; srcidx_eff[T_C] = &uC_src;
+      sidx_eff[T_A] = sidx_eff[T_C] = &u_sidx;
+    }
+  }
   MsmPlan plan[N_TABLES];
   for (int t = 0; t < N_TABLES; t++) {
-    h.npts[t] = (uint32_t)tbl_srcidx[t].size();
+    h.npts[t] = (uint32_t)srcidx_eff[t]->size();
     plan[t] = msm_plan(t == T_H ? m : n, h.npts[t]);
     h.win_c[t] = (uint32_t)plan[t].c;
     size_t pb = t == T_B2 ? 128 : 64;
@@ -222,13 +247,13 @@ int key_build(int device, uint32_t n, uint32_t p, uint32_t m, const std::vector<
     if (!np) continue;
     {  // scalar index -> point index (RANK_NONE: the key has the point at infinity there)
       std::vector<uint32_t> rank(t == T_H ? m : n, RANK_NONE);
-      for (size_t j = 0; j < np; j++) rank[tbl_sidx[t][j]] = (uint32_t)j;
+      for (size_t j = 0; j < np; j++) rank[(*sidx_eff[t])[j]] = (uint32_t)j;
       ZKR_HIP_CHECK(hipMemcpy(arena + h.off_rank[t], rank.data(), rank.size() * 4, hipMemcpyHostToDevice));
     }
     if (tbl_src_on_device[t]) {
       uint32_t *d_idx = nullptr;
       ZKR_HIP_CHECK(hipMalloc(&d_idx, np * 4));
-      ZKR_HIP_CHECK(hipMemcpy(d_idx, tbl_srcidx[t].data(), np * 4, hipMemcpyHostToDevice));
+      ZKR_HIP_CHECK(hipMemcpy(d_idx, srcidx_eff[t]->data(), np * 4, hipMemcpyHostToDevice));
       unsigned grid = (unsigned)((np + 255) / 256);
       if (t == T_B2)
         gather_kernel<G2Affine><<<grid, 256>>>((const G2Affine *)tbl_src[t], d_idx, np, (G2Affine *)(arena + h.off_pts[t]));
@@ -240,7 +265,10 @@ int key_build(int device, uint32_t n, uint32_t p, uint32_t m, const std::vector<
     } else {
       std::vector<uint8_t> stage(np * pb);
       const uint8_t *src = (const uint8_t *)tbl_src[t];
-      for (size_t j = 0; j < np; j++) memcpy(&stage[j * pb], src + (size_t)tbl_srcidx[t][j] * pb, pb);
+      for (size_t j = 0; j < np; j++) {
+        uint32_t si = (*srcidx_eff[t])[j];
+        if (si != RANK_NONE) memcpy(&stage[j * pb], src + (size_t)si * pb, pb);  // else: stays all-zero = infinity (x = 0)
+      }
       ZKR_HIP_CHECK(hipMemcpy(arena + h.off_pts[t], stage.data(), np * pb, hipMemcpyHostToDevice));
     }
     int rc = msm_precompute(device, t == T_B2, arena + h.off_pts[t], (uint32_t)np, plan[t]);

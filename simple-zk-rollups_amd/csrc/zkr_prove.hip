@@ -317,7 +317,7 @@ static int prove_submit(zkr_key *k, ProofSlot &sl, const Fr *d_wsrc, const uint8
   // The caller's stream only orders the witness before the proof (it may carry unrelated work, and with two
   // proofs in flight it must not chain them).  Schedule on the key's own streams (HIP multiplexes streams onto a
   // few hardware queues; streams sharing one serialise):
-  //   sp : preparation -- ingest, digit records of w, the digit sorts of B, A and C, calcH (QAP rows + six NTTs),
+  //   sp : preparation -- ingest, digit records of w, the digit sorts of B and A (C shares A's: h.share_ac), calcH (QAP rows + six NTTs),
   //        digit records of h, the sort of H.  Memory/LDS-bound (and the NTTs), small workgroups;
   //   s  : the five bucket accumulations back to back, B2 first (its reduction chain is the longest), B1 on the
   //        same sort (h.share_b), then A, C, H, each waiting only for its table's sort.  Every accumulation
@@ -340,7 +340,8 @@ static int prove_submit(zkr_key *k, ProofSlot &sl, const Fr *d_wsrc, const uint8
   prof_end(pf, sp, spn);
   const DigitLists *dig[N_TABLES] = {&sl.dig_w, &sl.dig_w, &sl.dig_w, &sl.dig_w, &sl.dig_h};
   const bool share_b = h.share_b != 0 && h.npts[T_B1] == h.npts[T_B2];
-  int sort_src[N_TABLES] = {T_A, T_B1, share_b ? T_B1 : T_B2, T_C, T_H};
+  const bool share_ac = h.share_ac != 0 && h.npts[T_A] == h.npts[T_C];  // A and C laid out over one support
+  int sort_src[N_TABLES] = {T_A, T_B1, share_b ? T_B1 : T_B2, share_ac ? T_A : T_C, T_H};
   auto sort_table = [&](int t) -> int {
     int rc = msm_sort_enqueue(pf, sp, (const uint32_t *)(ar + h.off_rank[t]), *dig[t], h.npts[t], k->plan[t], sl.ws[t]);
     if (rc) return rc;
@@ -374,7 +375,7 @@ static int prove_submit(zkr_key *k, ProofSlot &sl, const Fr *d_wsrc, const uint8
   if ((rc = sort_table(T_B1))) return rc;
   if (!share_b && (rc = sort_table(T_B2))) return rc;
   if ((rc = sort_table(T_A))) return rc;
-  if ((rc = sort_table(T_C))) return rc;
+  if (!share_ac && (rc = sort_table(T_C))) return rc;
   if ((rc = calc_h_device(k, sl, sp))) return rc;
   if ((rc = msm_digits_enqueue(pf, sp, sl.d_h, h.m, k->plan[T_H], sl.dig_h))) return rc;
   if ((rc = sort_table(T_H))) return rc;
