@@ -95,6 +95,8 @@ int zkr_prove_device(zkr_key *key, const void *d_witness_std, const uint8_t *r32
  * zkr_prove_device(...) == submit + collect. */
 int zkr_prove_submit(zkr_key *key, const void *d_witness_std, const uint8_t *r32, const uint8_t *s32, void *stream, int *ticket);
 int zkr_prove_collect(zkr_key *key, int ticket, uint8_t proof_out[256]);
+/* Number of proof workspaces of the key = proofs that can be in flight. */
+int zkr_key_slots(const zkr_key *key);
 
 /* ---- stage hooks (tests, profiling) ----------------------------------------------------------- */
 /* In-place NTT of n = 2^logn standard-form elements in host memory; natural order in and out. */

@@ -171,7 +171,8 @@ static __global__ __launch_bounds__(MSM_THREADS) void msm_digits_scatter_kernel(
 // Stages 2 and 4, per TABLE: one workgroup per (bucket range r, chunk j of that range's record list), bucket
 // counters / cursors in LDS (32 KB), so the 13.6 M increments of a 2^20-point MSM
 // are LDS atomics instead of L2/fabric atomics.  rank[s] = index of the table's point for scalar s, or
-// RANK_NONE when the table has none (point at infinity in the key: dropped at key build).
+// RANK_NONE when the table has none (point at infinity in the key: dropped at key build); rank == null means the
+// identity map (the table has a point for every scalar), which saves the gather.
 constexpr int SORT_THREADS = 256;
 constexpr uint32_t SORT_RANGE_MAX = 8192;  // bucket counters per workgroup (x 4 B of LDS): small footprint, so these
                                            // memory/LDS-bound workgroups find room on CUs busy with an accumulation
@@ -203,7 +204,7 @@ static __global__ __launch_bounds__(SORT_THREADS) void msm_hist_kernel(const uin
       uint32_t eu = e + u * SORT_THREADS;
       bool in = eu < e1;
       b[u] = in ? ent_b[eu] : 0u;
-      idx[u] = in ? rank[ent_s[eu]] : RANK_NONE;
+      idx[u] = in ? (rank ? rank[ent_s[eu]] : 0u) : RANK_NONE;  // rank == null: every scalar has its point (identity map)
     }
 #pragma unroll
     for (int u = 0; u < SORT_UNROLL; u++)
@@ -248,7 +249,7 @@ static __global__ __launch_bounds__(SORT_THREADS) void msm_scatter_kernel(const 
       uint32_t eu = e + u * SORT_THREADS;
       bool in = eu < e1;
       b[u] = in ? ent_b[eu] : 0u;
-      idx[u] = in ? rank[ent_s[eu]] : RANK_NONE;
+      idx[u] = in ? (rank ? rank[ent_s[eu]] : ent_s[eu]) : RANK_NONE;
     }
 #pragma unroll
     for (int u = 0; u < SORT_UNROLL; u++) {

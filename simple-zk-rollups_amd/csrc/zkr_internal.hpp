@@ -40,7 +40,8 @@ struct ArenaHeader {
   uint32_t share_b;    // B1 and B2 keep the same signals (always true for honest keys): one digit sort serves both
   uint32_t win_c[N_TABLES];  // window bits of each table: off_pts[t] holds K = ceil(255/c) x npts[t] points, level k = 2^(ck) * base
   uint32_t share_ac;   // A and C are laid out over the union of their supports (missing points stored as infinity): one digit sort serves both
-  uint8_t pad[36];
+  uint32_t rank_identity[N_TABLES];  // rank[s] == s for every scalar of the table's vector: the sort skips the gather
+  uint8_t pad[16];
 };
 static_assert(sizeof(ArenaHeader) <= 1024, "header fits its slot");
 constexpr size_t ARENA_HEADER_BYTES = 1024;

@@ -248,6 +248,9 @@ int key_build(int device, uint32_t n, uint32_t p, uint32_t m, const std::vector<
     {  // scalar index -> point index (RANK_NONE: the key has the point at infinity there)
       std::vector<uint32_t> rank(t == T_H ? m : n, RANK_NONE);
       for (size_t j = 0; j < np; j++) rank[(*sidx_eff[t])[j]] = (uint32_t)j;
+      bool ident = np == rank.size();
+      for (size_t j = 0; ident && j < np; j++) ident = rank[j] == (uint32_t)j;
+      h.rank_identity[t] = ident ? 1 : 0;
       ZKR_HIP_CHECK(hipMemcpy(arena + h.off_rank[t], rank.data(), rank.size() * 4, hipMemcpyHostToDevice));
     }
     if (tbl_src_on_device[t]) {
@@ -274,6 +277,7 @@ int key_build(int device, uint32_t n, uint32_t p, uint32_t m, const std::vector<
     int rc = msm_precompute(device, t == T_B2, arena + h.off_pts[t], (uint32_t)np, plan[t]);
     if (rc) { hipFree(arena); return rc; }
   }
+  ZKR_HIP_CHECK(hipMemcpy(arena, &h, sizeof(h), hipMemcpyHostToDevice));  // again: rank_identity was filled in above
   // twiddles on device: T[k] = w_{2m}^k and w_2048^k
   twiddle_table_kernel<<<(m + 255) / 256, 256>>>((Fr *)(arena + h.off_tw), m, fr_root_of_unity(h.logm + 1));
   twiddle_table_kernel<<<((1u << TWL_LOG) + 255) / 256, 256>>>((Fr *)(arena + h.off_twl), 1u << TWL_LOG, fr_root_of_unity(TWL_LOG + 1));
@@ -464,6 +468,8 @@ int zkr_key_info(const zkr_key *k, uint64_t out[10]) {
   for (int t = 0; t < N_TABLES; t++) out[5 + t] = k->h.npts[t];
   return 0;
 }
+
+int zkr_key_slots(const zkr_key *k) { return k ? PROOF_SLOTS : 0; }
 
 int zkr_key_windows(const zkr_key *k, uint32_t c_out[5], uint32_t k_out[5]) {
   if (!k || !c_out || !k_out) { set_error("null argument"); return ZKR_ERR_ARG; }

@@ -343,7 +343,8 @@ static int prove_submit(zkr_key *k, ProofSlot &sl, const Fr *d_wsrc, const uint8
   const bool share_ac = h.share_ac != 0 && h.npts[T_A] == h.npts[T_C];  // A and C laid out over one support
   int sort_src[N_TABLES] = {T_A, T_B1, share_b ? T_B1 : T_B2, share_ac ? T_A : T_C, T_H};
   auto sort_table = [&](int t) -> int {
-    int rc = msm_sort_enqueue(pf, sp, (const uint32_t *)(ar + h.off_rank[t]), *dig[t], h.npts[t], k->plan[t], sl.ws[t]);
+    const uint32_t *rank = h.rank_identity[t] ? nullptr : (const uint32_t *)(ar + h.off_rank[t]);
+    int rc = msm_sort_enqueue(pf, sp, rank, *dig[t], h.npts[t], k->plan[t], sl.ws[t]);
     if (rc) return rc;
     if (!serial) ZKR_HIP_CHECK(hipEventRecord(sl.ev_sorted[t], sp));
     return 0;

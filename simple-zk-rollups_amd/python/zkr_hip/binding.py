@@ -35,6 +35,7 @@ def lib():
     L.zkr_key_info.argtypes = [vp, c.POINTER(c.c_uint64)]
     L.zkr_key_save.argtypes = [vp, c.c_char_p]
     L.zkr_key_load_file.argtypes = [c.c_char_p, i, c.POINTER(vp)]
+    L.zkr_key_slots.argtypes = [vp]
     L.zkr_key_windows.argtypes = [vp, c.POINTER(c.c_uint32), c.POINTER(c.c_uint32)]
     L.zkr_key_arena.argtypes = [vp, c.POINTER(vp), c.POINTER(sz)]
     L.zkr_key_adopt_arena.argtypes = [vp, sz, i, c.POINTER(vp)]
@@ -178,17 +179,24 @@ class ProvingKey:
         _check(lib().zkr_prove_collect(self._h, int(ticket), out))
         return out.raw
 
-    def prove_batch_device(self, d_witness_ptrs, rs=None, ss=None, stream=None):
-        """Independent proofs of one batch, pipelined two deep: proof i+1 is submitted before proof i is collected."""
-        out, pending = [], None
+    def prove_batch_device(self, d_witness_ptrs, rs=None, ss=None, stream=None, depth=None):
+        """Independent proofs of one batch, pipelined: up to `depth` proofs (default: every proof slot of the key) are
+        submitted before the oldest is collected."""
+        import collections
+        import os
+        depth = depth or int(os.environ.get("ZKR_PIPELINE_DEPTH", "0")) or self.slots()
+        out, pending = [], collections.deque()
         for j, ptr in enumerate(d_witness_ptrs):
-            t = self.prove_submit(ptr, None if rs is None else rs[j], None if ss is None else ss[j], stream)
-            if pending is not None:
-                out.append(self.prove_collect(pending))
-            pending = t
-        if pending is not None:
-            out.append(self.prove_collect(pending))
+            if len(pending) == depth:
+                out.append(self.prove_collect(pending.popleft()))
+            pending.append(self.prove_submit(ptr, None if rs is None else rs[j], None if ss is None else ss[j], stream))
+        while pending:
+            out.append(self.prove_collect(pending.popleft()))
         return out
+
+    def slots(self):
+        """Proofs the key can hold in flight (zkr_prove_submit before zkr_prove_collect)."""
+        return lib().zkr_key_slots(self._h)
 
     def calc_h(self, witness: bytes) -> bytes:
         m = self.info()["domainSize"]
