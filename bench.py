@@ -121,7 +121,9 @@ def main():
     t_setup = time.time()
     key = None
     if rank == 0:
-        key, w0, _ = zkr_hip.ProvingKey.synth(args.log_m, N_PUBLIC, CIRCUIT_SEED, TOXIC_SEED, device=local, want_aux=False)
+        key, w0, aux = zkr_hip.ProvingKey.synth(args.log_m, N_PUBLIC, CIRCUIT_SEED, TOXIC_SEED, device=local, want_aux=True)
+        vk_bin = key.synth_vk(aux)  # for the native acceptance check after the timed region
+        del aux
     t_bcast = time.time()
     key = zkr_hip.broadcast_key(key, rank, world, local)
     torch.cuda.synchronize()
@@ -167,6 +169,18 @@ def main():
         elapsed = float(t.item())
     prof = key.prof()
     key.prof_enable(False)
+
+    # acceptance check outside the timed region: the native host verifier (zkr_verify: the pairing equation of
+    # common.ts:30-38 / TxVerifier.sol:258-276) on the first proofs of rank 0
+    verified = None
+    if rank == 0:
+        verified = 0
+        for i in range(min(n_wit, args.steps, 3)):
+            hw = wits[i].cpu().numpy().tobytes()
+            pub = [int.from_bytes(hw[32 * j:32 * j + 32], "little") for j in range(1, N_PUBLIC + 1)]
+            if not zkr_hip.verify(vk_bin, proofs[i], pub):
+                raise SystemExit("proof %d of the timed region does not verify" % i)
+            verified += 1
 
     # host-buffer boundary (zkr_prove: pageable witness over PCIe inside the call) -- reported, never `value`
     pcie_rate = None
@@ -231,6 +245,7 @@ def main():
             "stage_ms_per_proof": per_proof_ms,
             "key": {"arena_bytes": arena_bytes, "setup_s": setup_s, "bcast_s": bcast_s if world > 1 else None},
             "pcie_inclusive_proofs_per_s": pcie_rate,
+            "proofs_verified": verified,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample_log_m, args.log_m)

@@ -98,6 +98,17 @@ int zkr_prove_collect(zkr_key *key, int ticket, uint8_t proof_out[256]);
 /* Number of proof workspaces of the key = proofs that can be in flight. */
 int zkr_key_slots(const zkr_key *key);
 
+/* ---- acceptance check (host only, no GPU) ---------------------------------------------------------
+ * The pairing equation `groth.isValid(vk, proof, publicSignals)` evaluates at common.ts:30-38 and
+ * TxVerifier.verify evaluates on chain (TxVerifier.sol:258-276):
+ *   vk_x = IC_0 + sum_i input_i IC_{i+1};  e(-A, B) e(alfa, beta) e(vk_x, gamma) e(C, delta) == 1.
+ * vk_bin: 64 B vk_alfa_1 | 128 B vk_beta_2 | 128 B vk_gamma_2 | 128 B vk_delta_2 | u32 nIC | nIC x 64 B IC, every
+ * coordinate a 32-byte LE standard-form integer, G2 as (x.re, x.im, y.re, y.im) (the order of the snarkjs JSON
+ * key; index.js / facade.py convert the JSON).  proof: the 256 bytes zkr_prove returns.  public_std: nIC - 1
+ * inputs, 32 B each.  *valid = 1 / 0; inputs >= r (TxVerifier.sol:265) and off-curve proof points give 0.
+ * Returns an error only for a malformed key or a wrong input count. */
+int zkr_verify(const void *vk_bin, size_t vk_len, const uint8_t proof[256], const void *public_std, size_t n_public, int *valid);
+
 /* ---- stage hooks (tests, profiling) ----------------------------------------------------------- */
 /* In-place NTT of n = 2^logn standard-form elements in host memory; natural order in and out. */
 int zkr_ntt(void *data_std, unsigned logn, int inverse, int device);
@@ -125,6 +136,9 @@ int zkr_prof_get(zkr_key *key, const char *stage, double *ms_total, uint64_t *la
  *   | (nPublic+1) x 64 B IC points (std affine) | 128 B vk_gamma_2 (std) */
 int zkr_synth_key(unsigned log_m, unsigned n_public, uint64_t circuit_seed, uint64_t toxic_seed, int device,
                   zkr_key **key_out, void **witness_out, size_t *witness_len, void **aux_out, size_t *aux_len);
+/* Verifying key of a zkr_synth_key key in the vk_bin layout of zkr_verify (malloc'ed, free with zkr_free);
+ * aux = the checker blob zkr_synth_key returned for this key. */
+int zkr_synth_vk(const zkr_key *key, const void *aux, size_t aux_len, void **vk_out, size_t *vk_len);
 /* Same circuit + setup rendered as a websnark-format key on the host (small sizes; tests). */
 int zkr_synth_websnark(unsigned log_m, unsigned n_public, uint64_t circuit_seed, uint64_t toxic_seed, int device,
                        void **pk_out, size_t *pk_len, void **witness_out, size_t *witness_len);

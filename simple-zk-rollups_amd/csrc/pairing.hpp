@@ -1,0 +1,171 @@
+// pairing.hpp -- BN254 optimal ate pairing on the HOST, for the Groth16 acceptance check.
+//
+// Replaces `groth.isValid(vk, proof, publicSignals)` (/root/reference/operator/src/snarks/common.ts:30-34, snarkjs)
+// and mirrors what the on-chain verifier computes with precompile 8
+// (/root/reference/contracts/contracts/TxVerifier.sol:91-115, 258-276).  SURVEY.md 8(a5) / 8(f-4): CPU only, a few
+// milliseconds per proof, not a GPU target.  Built from the same field templates as the device code (field.hpp).
+//
+// Tower: Fq2 = Fq[u]/(u^2+1) (field.hpp), Fq6 = Fq2[v]/(v^3 - xi) with xi = 9 + u, Fq12 = Fq6[w]/(w^2 - v).
+// D-type twist: (x', y') -> (x' w^2, y' w^3).  A line through the twisted point T with Fq2-slope lam, evaluated at
+// P = (xP, yP) in G1, is  yP + (-lam xP) w + (lam xT - yT) w^3  =  ((yP, 0, 0), (-lam xP, lam xT - yT, 0)).
+// Affine Miller loop over 6x+2 with the two Frobenius correction steps, final exponentiation by plain
+// square-and-multiply -- the same route as the checker in oracle/bn254.py, kept simple on purpose.
+#pragma once
+#include "curve.hpp"
+
+namespace zkr {
+namespace pairing {
+
+static inline Fq fq_from_limbs(const uint32_t (&l)[8]) {
+  Fq r;
+  for (int i = 0; i < 8; i++) r.v[i] = l[i];
+  return to_mont(r);
+}
+static inline Fq fq_small(uint32_t x) {
+  Fq r = Fq::zero();
+  r.v[0] = x;
+  return to_mont(r);
+}
+static inline Fq2 conj(const Fq2 &a) { return Fq2{a.a, neg(a.b)}; }
+static inline Fq2 mul_fq(const Fq2 &a, const Fq &k) { return Fq2{mul(a.a, k), mul(a.b, k)}; }
+static inline Fq2 mul_xi(const Fq2 &a) {  // (a0 + a1 u)(9 + u) = 9 a0 - a1 + (a0 + 9 a1) u
+  Fq a8 = dbl(dbl(dbl(a.a))), b8 = dbl(dbl(dbl(a.b)));
+  return Fq2{sub(add(a8, a.a), a.b), add(add(b8, a.b), a.a)};
+}
+
+struct Fq6 {
+  Fq2 c0, c1, c2;
+  static Fq6 zero() { return Fq6{Fq2::zero(), Fq2::zero(), Fq2::zero()}; }
+  static Fq6 one() { return Fq6{Fq2::one(), Fq2::zero(), Fq2::zero()}; }
+  bool operator==(const Fq6 &o) const { return c0 == o.c0 && c1 == o.c1 && c2 == o.c2; }
+};
+static inline Fq6 add(const Fq6 &a, const Fq6 &b) { return Fq6{add(a.c0, b.c0), add(a.c1, b.c1), add(a.c2, b.c2)}; }
+static inline Fq6 sub(const Fq6 &a, const Fq6 &b) { return Fq6{sub(a.c0, b.c0), sub(a.c1, b.c1), sub(a.c2, b.c2)}; }
+static inline Fq6 neg(const Fq6 &a) { return Fq6{neg(a.c0), neg(a.c1), neg(a.c2)}; }
+static inline Fq6 mul(const Fq6 &a, const Fq6 &b) {
+  Fq2 t0 = mul(a.c0, b.c0), t1 = mul(a.c1, b.c1), t2 = mul(a.c2, b.c2);
+  Fq2 c0 = add(t0, mul_xi(sub(sub(mul(add(a.c1, a.c2), add(b.c1, b.c2)), t1), t2)));
+  Fq2 c1 = add(sub(sub(mul(add(a.c0, a.c1), add(b.c0, b.c1)), t0), t1), mul_xi(t2));
+  Fq2 c2 = add(sub(sub(mul(add(a.c0, a.c2), add(b.c0, b.c2)), t0), t2), t1);
+  return Fq6{c0, c1, c2};
+}
+static inline Fq6 mul_v(const Fq6 &a) { return Fq6{mul_xi(a.c2), a.c0, a.c1}; }  // (c0 + c1 v + c2 v^2) v
+static inline Fq6 inv(const Fq6 &a) {
+  Fq2 t0 = sub(sqr(a.c0), mul_xi(mul(a.c1, a.c2)));
+  Fq2 t1 = sub(mul_xi(sqr(a.c2)), mul(a.c0, a.c1));
+  Fq2 t2 = sub(sqr(a.c1), mul(a.c0, a.c2));
+  Fq2 d = inv(add(mul(a.c0, t0), mul_xi(add(mul(a.c2, t1), mul(a.c1, t2)))));
+  return Fq6{mul(t0, d), mul(t1, d), mul(t2, d)};
+}
+
+struct Fq12 {
+  Fq6 c0, c1;  // c0 + c1 w
+  static Fq12 one() { return Fq12{Fq6::one(), Fq6::zero()}; }
+  bool operator==(const Fq12 &o) const { return c0 == o.c0 && c1 == o.c1; }
+};
+static inline Fq12 mul(const Fq12 &a, const Fq12 &b) {
+  Fq6 t0 = mul(a.c0, b.c0), t1 = mul(a.c1, b.c1);
+  return Fq12{add(t0, mul_v(t1)), sub(sub(mul(add(a.c0, a.c1), add(b.c0, b.c1)), t0), t1)};
+}
+static inline Fq12 sqr(const Fq12 &a) { return mul(a, a); }
+static inline Fq12 conj(const Fq12 &a) { return Fq12{a.c0, neg(a.c1)}; }
+static inline Fq12 inv(const Fq12 &a) {
+  Fq6 d = inv(sub(mul(a.c0, a.c0), mul_v(mul(a.c1, a.c1))));
+  return Fq12{mul(a.c0, d), neg(mul(a.c1, d))};
+}
+template <int N>
+static inline Fq12 pow(const Fq12 &a, const uint32_t (&e)[N]) {
+  Fq12 r = Fq12::one();
+  bool started = false;
+  for (int i = 32 * N - 1; i >= 0; i--) {
+    if (started) r = sqr(r);
+    if ((e[i >> 5] >> (i & 31)) & 1) { r = started ? mul(r, a) : a; started = true; }
+  }
+  return r;
+}
+
+// q^2 + 1 and (q^4 - q^2 + 1) / r, little-endian u32 limbs
+static const uint32_t EXP_EASY2[16] = {0x275d69b2u, 0x3b5458a2u, 0x09eac101u, 0xa602072du, 0x6d96cadcu, 0x4a50189cu, 0x7a1242c8u, 0x04689e95u,
+                                       0x34c6b38du, 0x26edfa5cu, 0x16375606u, 0xb00b8551u, 0x0348d21cu, 0x599a6f7cu, 0x763cbf9cu, 0x0925c4b8u};
+static const uint32_t EXP_HARD[24] = {0xccdf42b1u, 0xe81bb482u, 0xf49c36d4u, 0x5abf5cc4u, 0x1da014fdu, 0xf1154e7eu, 0x87cdbacfu, 0xdcc7b44cu,
+                                      0x954bcf8au, 0xaaa441e3u, 0xd5095f23u, 0x6b887d56u, 0xf3fd90c6u, 0x79581e16u, 0xd189227du, 0x3b1b1355u,
+                                      0x61876f6bu, 0x4e529a58u, 0xd5b12278u, 0x6c0eb522u, 0x83177fafu, 0x331ec151u, 0x0b0759adu, 0x01baaa71u};
+// 6x + 2, x = 4965661367192848881 (65 bits)
+static const uint32_t ATE_LOOP[3] = {0xbe763ba8u, 0x9d797039u, 0x1u};
+// xi^((q-1)/3), xi^((q-1)/2): Frobenius on the twist (standard form limbs, converted on first use)
+static const uint32_t FROB_X0[8] = {0x176f553du, 0x99e39557u, 0xc2c3330cu, 0xb78cc310u, 0xf559b143u, 0x4c0bec3cu, 0x4f7911f7u, 0x2fb34798u};
+static const uint32_t FROB_X1[8] = {0x640fcba2u, 0x1665d51cu, 0x0b7c9dceu, 0x32ae2a1du, 0xd75a0794u, 0x4ba4cc8bu, 0x61ebae20u, 0x16c9e550u};
+static const uint32_t FROB_Y0[8] = {0x71a0135au, 0xdc540146u, 0xa9c95998u, 0xdbaae0edu, 0xb6e2f9b9u, 0xdc5ec698u, 0x489af5dcu, 0x063cf305u};
+static const uint32_t FROB_Y1[8] = {0x2623b0e3u, 0x82d37f63u, 0x8fa25bd2u, 0x21807dc9u, 0xec796f2bu, 0x0704b5a7u, 0xac41049au, 0x07c03cbcu};
+// twist constant b' = 3 / xi
+static const uint32_t TWIST_B0[8] = {0x24a138e5u, 0x3267e6dcu, 0x59dbefa3u, 0xb5b4c5e5u, 0x1be06ac3u, 0x81be1899u, 0xceb8aaaeu, 0x2b149d40u};
+static const uint32_t TWIST_B1[8] = {0x85c315d2u, 0xe4a2bd06u, 0xe52d1852u, 0xa74fa084u, 0xeed8fdf4u, 0xcd2cafadu, 0x3af0fed4u, 0x009713b0u};
+
+static inline bool g1_on_curve(const G1Affine &p) {  // y^2 = x^3 + 3 (TxVerifier.sol:24-26 generator (1, 2))
+  return sqr(p.y) == add(mul(sqr(p.x), p.x), fq_small(3));
+}
+static inline bool g2_on_curve(const G2Affine &p) {
+  Fq2 b{fq_from_limbs(TWIST_B0), fq_from_limbs(TWIST_B1)};
+  return sqr(p.y) == add(mul(sqr(p.x), p.x), b);
+}
+
+static inline G2Affine g2_frobenius(const G2Affine &p) {
+  Fq2 gx{fq_from_limbs(FROB_X0), fq_from_limbs(FROB_X1)}, gy{fq_from_limbs(FROB_Y0), fq_from_limbs(FROB_Y1)};
+  return G2Affine{mul(conj(p.x), gx), mul(conj(p.y), gy)};
+}
+
+static inline Fq12 line(const G2Affine &t, const Fq2 &lam, const G1Affine &p) {
+  Fq6 c0{Fq2{p.y, Fq::zero()}, Fq2::zero(), Fq2::zero()};
+  Fq6 c1{mul_fq(lam, neg(p.x)), sub(mul(lam, t.x), t.y), Fq2::zero()};
+  return Fq12{c0, c1};
+}
+static inline Fq12 dbl_step(G2Affine &t, const G1Affine &p) {
+  Fq2 xx = sqr(t.x);
+  Fq2 lam = mul(add(dbl(xx), xx), inv(dbl(t.y)));
+  Fq12 l = line(t, lam, p);
+  Fq2 x3 = sub(sqr(lam), dbl(t.x));
+  Fq2 y3 = sub(mul(lam, sub(t.x, x3)), t.y);
+  t = G2Affine{x3, y3};
+  return l;
+}
+static inline Fq12 add_step(G2Affine &t, const G2Affine &s, const G1Affine &p) {
+  Fq2 lam = mul(sub(s.y, t.y), inv(sub(s.x, t.x)));
+  Fq12 l = line(t, lam, p);
+  Fq2 x3 = sub(sub(sqr(lam), t.x), s.x);
+  Fq2 y3 = sub(mul(lam, sub(t.x, x3)), t.y);
+  t = G2Affine{x3, y3};
+  return l;
+}
+
+// Miller function f_{6x+2,Q}(P) with the two Frobenius correction lines; 1 when either point is infinity
+static inline Fq12 miller_loop(const G2Affine &q, const G1Affine &p) {
+  if (q.is_inf() || p.is_inf()) return Fq12::one();
+  G2Affine t = q;
+  Fq12 f = Fq12::one();
+  for (int i = 63; i >= 0; i--) {  // bits below the leading one of the 65-bit loop count
+    f = mul(sqr(f), dbl_step(t, p));
+    if ((ATE_LOOP[i >> 5] >> (i & 31)) & 1) f = mul(f, add_step(t, q, p));
+  }
+  G2Affine q1 = g2_frobenius(q);
+  G2Affine q2 = g2_frobenius(q1);
+  q2.y = neg(q2.y);
+  f = mul(f, add_step(t, q1, p));
+  f = mul(f, add_step(t, q2, p));
+  return f;
+}
+
+static inline Fq12 final_exponentiation(const Fq12 &f0) {
+  Fq12 f = mul(conj(f0), inv(f0));  // ^(q^6 - 1)
+  f = pow(f, EXP_EASY2);            // ^(q^2 + 1)
+  return pow(f, EXP_HARD);          // ^((q^4 - q^2 + 1) / r)
+}
+
+// prod_i e(P_i, Q_i) == 1  -- the bn256 pairing precompile's check (TxVerifier.sol:91-115)
+static inline bool pairing_product_is_one(const G1Affine *ps, const G2Affine *qs, int n) {
+  Fq12 f = Fq12::one();
+  for (int i = 0; i < n; i++) f = mul(f, miller_loop(qs[i], ps[i]));
+  return final_exponentiation(f) == Fq12::one();
+}
+
+}  // namespace pairing
+}  // namespace zkr

@@ -365,6 +365,29 @@ int zkr_synth_witness(unsigned log_m, unsigned n_public, uint64_t circuit_seed, 
   return 0;
 }
 
+// verifying key of a synthetic key in the vk_bin layout of zkr_verify: alfa_1, beta_2, delta_2 from the key header
+// (Montgomery there), gamma_2 and the IC points from the checker blob of zkr_synth_key
+int zkr_synth_vk(const zkr_key *key, const void *aux, size_t aux_len, void **vk_out, size_t *vk_len) {
+  if (!key || !aux || !vk_out || !vk_len) { set_error("null argument"); return ZKR_ERR_ARG; }
+  const uint8_t *ax = (const uint8_t *)aux;
+  uint64_t n64 = 0;
+  if (aux_len >= 8) memcpy(&n64, ax, 8);
+  const size_t nic = (size_t)key->h.p + 1, ic_off = 8 + 160 + 96 * (size_t)n64;
+  if (n64 != key->h.n || aux_len != ic_off + 64 * nic + 128) { set_error("aux blob does not belong to this key"); return ZKR_ERR_ARG; }
+  size_t len = 64 + 3 * 128 + 4 + 64 * nic;
+  uint8_t *o = (uint8_t *)malloc(len);
+  store_g1_std(o, load_g1(key->h.alfa1));
+  store_g2_std(o + 64, load_g2(key->h.beta2));
+  memcpy(o + 192, ax + ic_off + 64 * nic, 128);
+  store_g2_std(o + 320, load_g2(key->h.delta2));
+  uint32_t nic32 = (uint32_t)nic;
+  memcpy(o + 448, &nic32, 4);
+  memcpy(o + 452, ax + ic_off, 64 * nic);
+  *vk_out = o;
+  *vk_len = len;
+  return 0;
+}
+
 int zkr_synth_websnark(unsigned log_m, unsigned n_public, uint64_t circuit_seed, uint64_t toxic_seed, int device, void **pk_out, size_t *pk_len,
                        void **witness_out, size_t *witness_len) {
   if (!pk_out || !pk_len || !witness_out || !witness_len) { set_error("null argument"); return ZKR_ERR_ARG; }

@@ -20,6 +20,9 @@ export function genProof(provingKey: any, witness: Array<bigint | string>, opts?
 export function binarifyWitness(witness: Array<bigint | string>): ArrayBuffer;
 export function binarifyProvingKey(provingKey: any): ArrayBuffer;
 export function solidityProof(proof: Groth16Proof, publicSignals: Array<bigint | string>): { a: string[]; b: string[][]; c: string[]; inputs: string[] };
+/** snarkjs groth.isValid(vk, proof, publicSignals) on the native host verifier (no GPU needed). */
+export function isValid(verifyingKey: any, proof: Groth16Proof, publicSignals: Array<bigint | string>): boolean;
+export function binarifyVerifyingKey(verifyingKey: any): Uint8Array;
 export function proofFromBytes(proofBytes: Uint8Array): Groth16Proof;
 export function deviceCount(): number;
 export function version(): string;

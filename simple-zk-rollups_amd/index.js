@@ -136,6 +136,25 @@ async function genProof(provingKey, witness, opts) {
   return { proof, publicSignals };
 }
 
+// ---- groth.isValid(vk, proof, publicSignals) (operator/src/snarks/common.ts:30-34) on the native host verifier
+function binarifyVerifyingKey(vk) {
+  const g1 = (P) => Buffer.concat([bigintToLe32(P[0]), bigintToLe32(P[1])]);
+  const g2 = (P) => Buffer.concat([bigintToLe32(P[0][0]), bigintToLe32(P[0][1]), bigintToLe32(P[1][0]), bigintToLe32(P[1][1])]);
+  const n = Buffer.alloc(4);
+  n.writeUInt32LE(vk.IC.length, 0);
+  return Buffer.concat([g1(vk.vk_alfa_1), g2(vk.vk_beta_2), g2(vk.vk_gamma_2), g2(vk.vk_delta_2), n].concat(vk.IC.map(g1)));
+}
+
+function proofToBytes(proof) {
+  const v = [proof.pi_a[0], proof.pi_a[1], proof.pi_b[0][0], proof.pi_b[0][1], proof.pi_b[1][0], proof.pi_b[1][1], proof.pi_c[0], proof.pi_c[1]];
+  return Buffer.concat(v.map(bigintToLe32));
+}
+
+function isValid(vk, proof, publicSignals) {
+  const pub = Buffer.concat(publicSignals.map((x) => bigintToLe32(BigInt(x))).concat([Buffer.alloc(0)]));
+  return native().verify(binarifyVerifyingKey(vk), proofToBytes(proof), pub);
+}
+
 // operator/src/snarks/common.ts:43-50
 function solidityProof(proof, publicSignals) {
   return {
@@ -147,7 +166,7 @@ function solidityProof(proof, publicSignals) {
 }
 
 module.exports = {
-  buildBn128, genProof, binarifyWitness, binarifyProvingKey, solidityProof, proofFromBytes,
+  buildBn128, genProof, binarifyWitness, binarifyProvingKey, solidityProof, proofFromBytes, isValid, binarifyVerifyingKey,
   deviceCount: () => { native(); return deviceCount; },
   version: () => native().version(),
 };

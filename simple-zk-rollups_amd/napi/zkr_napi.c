@@ -22,6 +22,7 @@ static struct {
   void (*key_free)(zkr_key *);
   int (*key_info)(const zkr_key *, uint64_t *);
   int (*prove)(zkr_key *, const void *, size_t, const uint8_t *, const uint8_t *, uint8_t *, void *);
+  int (*verify)(const void *, size_t, const uint8_t *, const void *, size_t, int *);
 } Z;
 
 #define NAPI_OK(call)                                                     \
@@ -57,7 +58,7 @@ static napi_value js_load(napi_env env, napi_callback_info info) {
   *(void **)(&Z.field) = dlsym(h, name);                                        \
   if (!Z.field) return throw_msg(env, "libzkr_hip.so lacks symbol " name);
     SYM(last_error, "zkr_last_error") SYM(version, "zkr_version") SYM(device_count, "zkr_device_count")
-    SYM(key_load_websnark, "zkr_key_load_websnark") SYM(key_free, "zkr_key_free") SYM(key_info, "zkr_key_info") SYM(prove, "zkr_prove")
+    SYM(key_load_websnark, "zkr_key_load_websnark") SYM(key_free, "zkr_key_free") SYM(key_info, "zkr_key_info") SYM(prove, "zkr_prove") SYM(verify, "zkr_verify")
     Z.handle = h;
   }
   napi_value out;
@@ -194,11 +195,30 @@ static napi_value js_prove(napi_env env, napi_callback_info info) {
   return promise;
 }
 
+/* verify(vkBin, proofBytes256, publicBytes) -> boolean: the Groth16 pairing check on the host (zkr_verify; groth.isValid,
+ * operator/src/snarks/common.ts:30-34).  Synchronous: a few milliseconds, no GPU. */
+static napi_value js_verify(napi_env env, napi_callback_info info) {
+  size_t argc = 3;
+  napi_value argv[3];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  if (!Z.handle) return throw_msg(env, "libzkr_hip.so not loaded");
+  const uint8_t *vk, *proof, *pub;
+  size_t vk_len, proof_len, pub_len;
+  if (argc < 3 || !get_bytes(env, argv[0], &vk, &vk_len) || !get_bytes(env, argv[1], &proof, &proof_len) || !get_bytes(env, argv[2], &pub, &pub_len))
+    return throw_msg(env, "verify(vkBin, proofBytes, publicBytes): three byte buffers expected");
+  if (proof_len != 256 || pub_len % 32) return throw_msg(env, "verify: proof must be 256 bytes and the inputs a multiple of 32 bytes");
+  int ok = 0;
+  if (Z.verify(vk, vk_len, proof, pub, pub_len / 32, &ok)) return throw_msg(env, Z.last_error());
+  napi_value out;
+  NAPI_OK(napi_get_boolean(env, ok != 0, &out));
+  return out;
+}
+
 static napi_value init(napi_env env, napi_value exports) {
   napi_property_descriptor props[] = {
       {"load", NULL, js_load, NULL, NULL, NULL, napi_default, NULL},       {"version", NULL, js_version, NULL, NULL, NULL, napi_default, NULL},
       {"keyLoad", NULL, js_key_load, NULL, NULL, NULL, napi_default, NULL}, {"keyInfo", NULL, js_key_info, NULL, NULL, NULL, napi_default, NULL},
-      {"prove", NULL, js_prove, NULL, NULL, NULL, napi_default, NULL},
+      {"prove", NULL, js_prove, NULL, NULL, NULL, napi_default, NULL},     {"verify", NULL, js_verify, NULL, NULL, NULL, napi_default, NULL},
   };
   napi_define_properties(env, exports, sizeof(props) / sizeof(props[0]), props);
   return exports;

@@ -43,6 +43,7 @@ def lib():
     L.zkr_prove_device.argtypes = [vp, vp, u8p, u8p, u8p, vp]
     L.zkr_prove_submit.argtypes = [vp, vp, u8p, u8p, vp, c.POINTER(i)]
     L.zkr_prove_collect.argtypes = [vp, i, u8p]
+    L.zkr_verify.argtypes = [u8p, sz, u8p, u8p, sz, c.POINTER(i)]
     L.zkr_ntt.argtypes = [u8p, c.c_uint, i, i]
     L.zkr_msm_g1.argtypes = [u8p, u8p, sz, u8p, c.POINTER(i), i]
     L.zkr_msm_g2.argtypes = [u8p, u8p, sz, u8p, c.POINTER(i), i]
@@ -55,6 +56,7 @@ def lib():
     L.zkr_synth_websnark.argtypes = [c.c_uint, c.c_uint, c.c_uint64, c.c_uint64, i, c.POINTER(vp), c.POINTER(sz),
                                      c.POINTER(vp), c.POINTER(sz)]
     L.zkr_synth_witness.argtypes = [c.c_uint, c.c_uint, c.c_uint64, c.c_uint64, c.POINTER(vp), c.POINTER(sz)]
+    L.zkr_synth_vk.argtypes = [vp, u8p, sz, c.POINTER(vp), c.POINTER(sz)]
     L.zkr_synth_set_shape.argtypes = [c.c_uint]
     L.zkr_free.argtypes = [vp]
     L.zkr_free.restype = None
@@ -160,6 +162,15 @@ class ProvingKey:
         _check(lib().zkr_prove_device(self._h, ctypes.c_void_p(d_witness_ptr), rb, sb, out, ctypes.c_void_p(stream or 0)))
         return out.raw
 
+    def synth_vk(self, aux: bytes) -> bytes:
+        """vk_bin (zkr_verify layout) of a key made by ProvingKey.synth, from its checker blob."""
+        out, n = ctypes.c_void_p(), ctypes.c_size_t()
+        _check(lib().zkr_synth_vk(self._h, bytes(aux), len(aux), ctypes.byref(out), ctypes.byref(n)))
+        try:
+            return ctypes.string_at(out, n.value)
+        finally:
+            lib().zkr_free(out)
+
     def windows(self):
         """{table: (window bits c, windows K)} for A, B1, B2, C, H."""
         cs, ks = (ctypes.c_uint32 * 5)(), (ctypes.c_uint32 * 5)()
@@ -218,6 +229,14 @@ class ProvingKey:
             _check(lib().zkr_prof_get(self._h, st.encode(), ctypes.byref(ms), ctypes.byref(n)))
             out[st] = (ms.value, n.value)
         return out
+
+
+def verify(vk_bin: bytes, proof: bytes, public_signals) -> bool:
+    """zkr_verify: the Groth16 pairing check on the host (groth.isValid, common.ts:30-38).  public_signals: ints."""
+    pub = b"".join(int(x).to_bytes(32, "little") for x in public_signals)
+    ok = ctypes.c_int(0)
+    _check(lib().zkr_verify(bytes(vk_bin), len(vk_bin), bytes(proof), pub, len(public_signals), ctypes.byref(ok)))
+    return bool(ok.value)
 
 
 def synth_set_shape(shape: int):

@@ -22,6 +22,29 @@ def solidity_proof(proof, public_signals):
             "c": list(proof["pi_c"][:2]), "inputs": [str(int(x) % SNARK_FIELD_SIZE) for x in public_signals]}
 
 
+def binarify_verifying_key(vk) -> bytes:
+    """snarkjs verifying-key JSON (vk_alfa_1, vk_beta_2, vk_gamma_2, vk_delta_2, IC; decimal strings or ints,
+    projective third coordinate ignored) -> the vk_bin layout of zkr_verify (include/zkr.h)."""
+    le = lambda v: int(v).to_bytes(32, "little")
+    g1 = lambda p: le(p[0]) + le(p[1])
+    g2 = lambda p: le(p[0][0]) + le(p[0][1]) + le(p[1][0]) + le(p[1][1])
+    ic = vk["IC"]
+    return g1(vk["vk_alfa_1"]) + g2(vk["vk_beta_2"]) + g2(vk["vk_gamma_2"]) + g2(vk["vk_delta_2"]) + len(ic).to_bytes(4, "little") + b"".join(g1(p) for p in ic)
+
+
+def proof_bytes_from_json(proof) -> bytes:
+    """Inverse of proof_json_from_bytes."""
+    le = lambda v: int(v).to_bytes(32, "little")
+    a, b, c = proof["pi_a"], proof["pi_b"], proof["pi_c"]
+    return le(a[0]) + le(a[1]) + le(b[0][0]) + le(b[0][1]) + le(b[1][0]) + le(b[1][1]) + le(c[0]) + le(c[1])
+
+
+def is_valid(verifying_key, proof, public_signals) -> bool:
+    """groth.isValid(vk, proof, publicSignals) (common.ts:30-34) on the native host verifier (zkr_verify)."""
+    from .binding import verify
+    return verify(binarify_verifying_key(verifying_key), proof_bytes_from_json(proof), [int(x) for x in public_signals])
+
+
 class Bn128:
     """What `await buildBn128()` returns; only groth16GenProof is used by the reference."""
 
@@ -47,10 +70,11 @@ def groth16_gen_proof(witness_bin, proving_key_bin, device=0, r=None, s=None):
     return build_bn128(device).groth16GenProof(witness_bin, proving_key_bin, r, s)
 
 
-def create_proof_generator(proving_key_bin, verifying_key, is_valid, n_public, device=0):
+def create_proof_generator(proving_key_bin, verifying_key, n_public, device=0, is_valid=is_valid):
     """common.ts:10-53 with the circuit/witness steps supplied by the caller: returns
     fn(witness: list[int]) -> {proof, solidityProof}; raises Error("Invalid proof generated")
-    (common.ts:36-38) when `is_valid(vk, proof, publicSignals)` rejects the proof."""
+    (common.ts:36-38) when `is_valid(vk, proof, publicSignals)` rejects the proof (default: the native
+    verifier; any callable with snarkjs' groth.isValid signature can be passed)."""
     bn = build_bn128(device)
 
     def gen(witness, r=None, s=None):

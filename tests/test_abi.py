@@ -91,3 +91,30 @@ def test_dense_shape_witness_generator_matches_oracle_on_cpu():
     assert g.check_r1cs(circ)
     assert wb == g.binarify_witness(circ["witness"])
     assert zkr_hip.synth_witness(7, 5, 0x5A4B0005, 0x5A4B0005) == g.binarify_witness(g.synth_circuit(128, 5, 0x5A4B0005)["witness"])
+
+
+def test_native_verifier_agrees_with_oracle_pairing_check(small_case):
+    """zkr_verify (host pairing) == the oracle's TxVerifier.sol:258-276 check: accepts the
+    closed-form proof, rejects a changed public input, a changed proof element, an input >= r, an off-curve point."""
+    import groth16 as g
+    import zkr_hip
+    c = small_case
+    proof = g.proof_from_toxic(c["circ"], c["tox"], c["w"], c["r"], c["s"])
+    pb = g.proof_bytes(proof)
+    pub = c["w"][1:8]
+    vkb = zkr_hip.binarify_verifying_key(c["vk"])
+    assert g.is_valid(c["vk"], proof, pub)
+    assert zkr_hip.verify(vkb, pb, pub) is True
+    assert zkr_hip.is_valid(c["vk"], g.proof_to_json(proof), [str(x) for x in pub]) is True
+    bad_pub = list(pub)
+    bad_pub[3] = (bad_pub[3] + 1) % g.R
+    assert not g.is_valid(c["vk"], proof, bad_pub) and zkr_hip.verify(vkb, pb, bad_pub) is False
+    assert zkr_hip.verify(vkb, pb, [pub[0] + g.R] + pub[1:]) is False          # TxVerifier.sol:265: input < r
+    other = g.proof_bytes(g.proof_from_toxic(c["circ"], c["tox"], c["w"], c["r"] + 1, c["s"]))
+    assert zkr_hip.verify(vkb, other, pub) is True                              # another valid proof of the same statement
+    assert zkr_hip.verify(vkb, pb[:192] + other[192:], pub) is False            # pi_c of one with pi_a, pi_b of the other
+    assert zkr_hip.verify(vkb, pb[:32] + (1).to_bytes(32, "little") + pb[64:], pub) is False  # pi_a off the curve
+    with pytest.raises(zkr_hip.ZkrError):
+        zkr_hip.verify(vkb, pb, pub[:-1])                                       # wrong input count (TxVerifier.sol:261)
+    with pytest.raises(zkr_hip.ZkrError):
+        zkr_hip.verify(vkb[:-1], pb, pub)

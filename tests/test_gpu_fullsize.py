@@ -26,6 +26,10 @@ def test_fullsize_proof_equals_closed_form_and_verifies(log_m):
     bad = list(pub)
     bad[3] = (bad[3] + 1) % g.R
     assert not g.is_valid(vk, _proof_points(proof), bad)  # withdrawverifier.test.ts:42-68 pattern
+    # the product's native verifier (zkr_verify) on the vk the product exports: same verdicts as the oracle's pairing
+    vk_bin = key.synth_vk(aux)
+    assert vk_bin == zkr_hip.binarify_verifying_key(vk)
+    assert zkr_hip.verify(vk_bin, proof, pub) is True and zkr_hip.verify(vk_bin, proof, bad) is False
     # a second witness of the same circuit on the same key
     wb2 = zkr_hip.synth_witness(log_m, p, 0x5A4B0001, 4242)
     proof2 = key.prove(wb2, r, s)

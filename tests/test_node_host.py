@@ -120,3 +120,22 @@ def test_js_batch_runs_concurrent_proofs_on_one_key(tmp_path, small_case):
     assert len(proofs) == 6
     for i, p in enumerate(proofs):
         assert p == g.proof_to_json(g.proof_from_toxic(c["circ"], c["tox"], c["w"], c["r"] + i, c["s"] + 2 * i))
+
+
+def test_js_is_valid_on_native_verifier(tmp_path, small_case):
+    """index.js isValid(vk, proof, publicSignals) = snarkjs groth.isValid (common.ts:30-34) on zkr_verify; CPU only."""
+    c = small_case
+    vk = _stringify({k: v for k, v in c["vk"].items()})
+    vk["IC"] = [[str(p[0]), str(p[1]), "1"] for p in c["vk"]["IC"]]
+    proof = g.proof_to_json(g.proof_from_toxic(c["circ"], c["tox"], c["w"], c["r"], c["s"]))
+    pub = [str(x) for x in c["w"][1:8]]
+    bad = list(pub)
+    bad[2] = str((int(bad[2]) + 1) % g.R)
+    path = tmp_path / "vk.json"
+    path.write_text(json.dumps(dict(vk=vk, proof=proof, pub=pub, bad=bad)))
+    out = _node("""
+      const z = require('./index.js'); const fs = require('fs');
+      const d = JSON.parse(fs.readFileSync(process.argv[1]));
+      console.log(JSON.stringify([z.isValid(d.vk, d.proof, d.pub), z.isValid(d.vk, d.proof, d.bad)]));
+    """, str(path)).stdout
+    assert json.loads(out) == [True, False]
