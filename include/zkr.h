@@ -89,7 +89,7 @@ int zkr_prove_device(zkr_key *key, const void *d_witness_std, const uint8_t *r32
 
 /* Pipelined form for batches of independent proofs (rollup batch, BASELINE config 4): zkr_prove_submit enqueues
  * the whole GPU side of one proof and returns at once with a ticket; zkr_prove_collect waits for that proof and
- * does the host assembly.  A key holds two proof workspaces, so the GPU work of proof i+1 (submitted before
+ * does the host assembly.  A key holds two proof workspaces (zkr_key_slots), so the GPU work of proof i+1 (submitted before
  * collecting proof i) covers proof i's reduction tail and host assembly.  The witness buffer must stay untouched
  * until the ticket is collected.  Submitting with both workspaces in flight fails with ZKR_ERR_ARG.
  * zkr_prove_device(...) == submit + collect. */

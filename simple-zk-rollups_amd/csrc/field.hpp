@@ -126,136 +126,75 @@ ZKR_HD Fp<PM> dbl(const Fp<PM> &a) {
   return add(a, a);
 }
 
-// 96-bit column accumulator (c2 : lo) += sum_k x_k * y_k.  On gfx950 every term is exactly two VALU
+#if defined(__HIP_DEVICE_COMPILE__)
+// 96-bit column accumulator (c2 : lo) += sum_k x_k * y_k (device only; the host uses mul_host64 below).  On gfx950 every term is exactly two VALU
 // instructions: v_mad_u64_u32 adds the 64-bit product into the low pair and leaves the carry in VCC,
 // v_addc_co_u32 folds it into the third word -- no register shuffling between multiply-adds (the
 // compiler's own lowering of the 64-bit carry chain costs ~3 v_mov + one 64-bit add per multiply-add).
 // One asm statement per column half keeps hipcc's per-statement s_nop pad off the critical path.
 // Pure VALU, no memory operands, VCC declared clobbered (cdna_hip_programming.md 5.7).
-ZKR_HD void mac96_1(uint64_t &lo, uint32_t &c2, uint32_t x0, uint32_t y0) {
-#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void mac96_1(uint64_t &lo, uint32_t &c2, uint32_t x0, uint32_t y0) {
   asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(c2) : "v"(x0), "v"(y0) : "vcc");
-#else
-  { uint64_t p = (uint64_t)x0 * y0; lo += p; c2 += lo < p; }
-#endif
 }
 template <uint32_t Y0>
-ZKR_HD void mac96c_1(uint64_t &lo, uint32_t &c2, uint32_t x0) {
-#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void mac96c_1(uint64_t &lo, uint32_t &c2, uint32_t x0) {
   asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(c2) : "v"(x0), "s"(Y0) : "vcc");
-#else
-  { uint64_t p = (uint64_t)x0 * Y0; lo += p; c2 += lo < p; }
-#endif
 }
-ZKR_HD void mac96_2(uint64_t &lo, uint32_t &c2, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1) {
-#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void mac96_2(uint64_t &lo, uint32_t &c2, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1) {
   asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(c2) : "v"(x0), "v"(y0), "v"(x1), "v"(y1) : "vcc");
-#else
-  { uint64_t p = (uint64_t)x0 * y0; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x1 * y1; lo += p; c2 += lo < p; }
-#endif
 }
 template <uint32_t Y0, uint32_t Y1>
-ZKR_HD void mac96c_2(uint64_t &lo, uint32_t &c2, uint32_t x0, uint32_t x1) {
-#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void mac96c_2(uint64_t &lo, uint32_t &c2, uint32_t x0, uint32_t x1) {
   asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(c2) : "v"(x0), "s"(Y0), "v"(x1), "s"(Y1) : "vcc");
-#else
-  { uint64_t p = (uint64_t)x0 * Y0; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x1 * Y1; lo += p; c2 += lo < p; }
-#endif
 }
-ZKR_HD void mac96_3(uint64_t &lo, uint32_t &c2, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, uint32_t x2, uint32_t y2) {
-#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void mac96_3(uint64_t &lo, uint32_t &c2, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, uint32_t x2, uint32_t y2) {
   asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %6, %7, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(c2) : "v"(x0), "v"(y0), "v"(x1), "v"(y1), "v"(x2), "v"(y2) : "vcc");
-#else
-  { uint64_t p = (uint64_t)x0 * y0; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x1 * y1; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x2 * y2; lo += p; c2 += lo < p; }
-#endif
 }
 template <uint32_t Y0, uint32_t Y1, uint32_t Y2>
-ZKR_HD void mac96c_3(uint64_t &lo, uint32_t &c2, uint32_t x0, uint32_t x1, uint32_t x2) {
-#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void mac96c_3(uint64_t &lo, uint32_t &c2, uint32_t x0, uint32_t x1, uint32_t x2) {
   asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %6, %7, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(c2) : "v"(x0), "s"(Y0), "v"(x1), "s"(Y1), "v"(x2), "s"(Y2) : "vcc");
-#else
-  { uint64_t p = (uint64_t)x0 * Y0; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x1 * Y1; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x2 * Y2; lo += p; c2 += lo < p; }
-#endif
 }
-ZKR_HD void mac96_4(uint64_t &lo, uint32_t &c2, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, uint32_t x2, uint32_t y2, uint32_t x3, uint32_t y3) {
-#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void mac96_4(uint64_t &lo, uint32_t &c2, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, uint32_t x2, uint32_t y2, uint32_t x3, uint32_t y3) {
   asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %6, %7, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %8, %9, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(c2) : "v"(x0), "v"(y0), "v"(x1), "v"(y1), "v"(x2), "v"(y2), "v"(x3), "v"(y3) : "vcc");
-#else
-  { uint64_t p = (uint64_t)x0 * y0; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x1 * y1; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x2 * y2; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x3 * y3; lo += p; c2 += lo < p; }
-#endif
 }
 template <uint32_t Y0, uint32_t Y1, uint32_t Y2, uint32_t Y3>
-ZKR_HD void mac96c_4(uint64_t &lo, uint32_t &c2, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3) {
-#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void mac96c_4(uint64_t &lo, uint32_t &c2, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3) {
   asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %6, %7, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %8, %9, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(c2) : "v"(x0), "s"(Y0), "v"(x1), "s"(Y1), "v"(x2), "s"(Y2), "v"(x3), "s"(Y3) : "vcc");
-#else
-  { uint64_t p = (uint64_t)x0 * Y0; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x1 * Y1; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x2 * Y2; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x3 * Y3; lo += p; c2 += lo < p; }
-#endif
 }
-ZKR_HD void mac96_5(uint64_t &lo, uint32_t &c2, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, uint32_t x2, uint32_t y2, uint32_t x3, uint32_t y3, uint32_t x4, uint32_t y4) {
-#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void mac96_5(uint64_t &lo, uint32_t &c2, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, uint32_t x2, uint32_t y2, uint32_t x3, uint32_t y3, uint32_t x4, uint32_t y4) {
   asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %6, %7, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %8, %9, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %10, %11, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(c2) : "v"(x0), "v"(y0), "v"(x1), "v"(y1), "v"(x2), "v"(y2), "v"(x3), "v"(y3), "v"(x4), "v"(y4) : "vcc");
-#else
-  { uint64_t p = (uint64_t)x0 * y0; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x1 * y1; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x2 * y2; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x3 * y3; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x4 * y4; lo += p; c2 += lo < p; }
-#endif
 }
 template <uint32_t Y0, uint32_t Y1, uint32_t Y2, uint32_t Y3, uint32_t Y4>
-ZKR_HD void mac96c_5(uint64_t &lo, uint32_t &c2, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t x4) {
-#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void mac96c_5(uint64_t &lo, uint32_t &c2, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t x4) {
   asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %6, %7, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %8, %9, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %10, %11, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(c2) : "v"(x0), "s"(Y0), "v"(x1), "s"(Y1), "v"(x2), "s"(Y2), "v"(x3), "s"(Y3), "v"(x4), "s"(Y4) : "vcc");
-#else
-  { uint64_t p = (uint64_t)x0 * Y0; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x1 * Y1; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x2 * Y2; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x3 * Y3; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x4 * Y4; lo += p; c2 += lo < p; }
-#endif
 }
-ZKR_HD void mac96_6(uint64_t &lo, uint32_t &c2, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, uint32_t x2, uint32_t y2, uint32_t x3, uint32_t y3, uint32_t x4, uint32_t y4, uint32_t x5, uint32_t y5) {
-#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void mac96_6(uint64_t &lo, uint32_t &c2, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, uint32_t x2, uint32_t y2, uint32_t x3, uint32_t y3, uint32_t x4, uint32_t y4, uint32_t x5, uint32_t y5) {
   asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %6, %7, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %8, %9, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %10, %11, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %12, %13, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(c2) : "v"(x0), "v"(y0), "v"(x1), "v"(y1), "v"(x2), "v"(y2), "v"(x3), "v"(y3), "v"(x4), "v"(y4), "v"(x5), "v"(y5) : "vcc");
-#else
-  { uint64_t p = (uint64_t)x0 * y0; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x1 * y1; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x2 * y2; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x3 * y3; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x4 * y4; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x5 * y5; lo += p; c2 += lo < p; }
-#endif
 }
 template <uint32_t Y0, uint32_t Y1, uint32_t Y2, uint32_t Y3, uint32_t Y4, uint32_t Y5>
-ZKR_HD void mac96c_6(uint64_t &lo, uint32_t &c2, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t x4, uint32_t x5) {
-#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void mac96c_6(uint64_t &lo, uint32_t &c2, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t x4, uint32_t x5) {
   asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %6, %7, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %8, %9, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %10, %11, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %12, %13, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(c2) : "v"(x0), "s"(Y0), "v"(x1), "s"(Y1), "v"(x2), "s"(Y2), "v"(x3), "s"(Y3), "v"(x4), "s"(Y4), "v"(x5), "s"(Y5) : "vcc");
-#else
-  { uint64_t p = (uint64_t)x0 * Y0; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x1 * Y1; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x2 * Y2; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x3 * Y3; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x4 * Y4; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x5 * Y5; lo += p; c2 += lo < p; }
-#endif
 }
-ZKR_HD void mac96_7(uint64_t &lo, uint32_t &c2, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, uint32_t x2, uint32_t y2, uint32_t x3, uint32_t y3, uint32_t x4, uint32_t y4, uint32_t x5, uint32_t y5, uint32_t x6, uint32_t y6) {
-#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void mac96_7(uint64_t &lo, uint32_t &c2, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, uint32_t x2, uint32_t y2, uint32_t x3, uint32_t y3, uint32_t x4, uint32_t y4, uint32_t x5, uint32_t y5, uint32_t x6, uint32_t y6) {
   asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %6, %7, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %8, %9, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %10, %11, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %12, %13, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %14, %15, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(c2) : "v"(x0), "v"(y0), "v"(x1), "v"(y1), "v"(x2), "v"(y2), "v"(x3), "v"(y3), "v"(x4), "v"(y4), "v"(x5), "v"(y5), "v"(x6), "v"(y6) : "vcc");
-#else
-  { uint64_t p = (uint64_t)x0 * y0; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x1 * y1; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x2 * y2; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x3 * y3; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x4 * y4; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x5 * y5; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x6 * y6; lo += p; c2 += lo < p; }
-#endif
 }
 template <uint32_t Y0, uint32_t Y1, uint32_t Y2, uint32_t Y3, uint32_t Y4, uint32_t Y5, uint32_t Y6>
-ZKR_HD void mac96c_7(uint64_t &lo, uint32_t &c2, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t x4, uint32_t x5, uint32_t x6) {
-#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void mac96c_7(uint64_t &lo, uint32_t &c2, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t x4, uint32_t x5, uint32_t x6) {
   asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %6, %7, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %8, %9, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %10, %11, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %12, %13, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %14, %15, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(c2) : "v"(x0), "s"(Y0), "v"(x1), "s"(Y1), "v"(x2), "s"(Y2), "v"(x3), "s"(Y3), "v"(x4), "s"(Y4), "v"(x5), "s"(Y5), "v"(x6), "s"(Y6) : "vcc");
-#else
-  { uint64_t p = (uint64_t)x0 * Y0; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x1 * Y1; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x2 * Y2; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x3 * Y3; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x4 * Y4; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x5 * Y5; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x6 * Y6; lo += p; c2 += lo < p; }
-#endif
 }
-ZKR_HD void mac96_8(uint64_t &lo, uint32_t &c2, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, uint32_t x2, uint32_t y2, uint32_t x3, uint32_t y3, uint32_t x4, uint32_t y4, uint32_t x5, uint32_t y5, uint32_t x6, uint32_t y6, uint32_t x7, uint32_t y7) {
-#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void mac96_8(uint64_t &lo, uint32_t &c2, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, uint32_t x2, uint32_t y2, uint32_t x3, uint32_t y3, uint32_t x4, uint32_t y4, uint32_t x5, uint32_t y5, uint32_t x6, uint32_t y6, uint32_t x7, uint32_t y7) {
   asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %6, %7, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %8, %9, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %10, %11, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %12, %13, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %14, %15, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %16, %17, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(c2) : "v"(x0), "v"(y0), "v"(x1), "v"(y1), "v"(x2), "v"(y2), "v"(x3), "v"(y3), "v"(x4), "v"(y4), "v"(x5), "v"(y5), "v"(x6), "v"(y6), "v"(x7), "v"(y7) : "vcc");
-#else
-  { uint64_t p = (uint64_t)x0 * y0; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x1 * y1; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x2 * y2; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x3 * y3; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x4 * y4; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x5 * y5; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x6 * y6; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x7 * y7; lo += p; c2 += lo < p; }
-#endif
 }
 template <uint32_t Y0, uint32_t Y1, uint32_t Y2, uint32_t Y3, uint32_t Y4, uint32_t Y5, uint32_t Y6, uint32_t Y7>
-ZKR_HD void mac96c_8(uint64_t &lo, uint32_t &c2, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t x4, uint32_t x5, uint32_t x6, uint32_t x7) {
-#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void mac96c_8(uint64_t &lo, uint32_t &c2, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t x4, uint32_t x5, uint32_t x6, uint32_t x7) {
   asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %6, %7, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %8, %9, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %10, %11, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %12, %13, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %14, %15, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %16, %17, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(c2) : "v"(x0), "s"(Y0), "v"(x1), "s"(Y1), "v"(x2), "s"(Y2), "v"(x3), "s"(Y3), "v"(x4), "s"(Y4), "v"(x5), "s"(Y5), "v"(x6), "s"(Y6), "v"(x7), "s"(Y7) : "vcc");
-#else
-  { uint64_t p = (uint64_t)x0 * Y0; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x1 * Y1; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x2 * Y2; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x3 * Y3; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x4 * Y4; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x5 * Y5; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x6 * Y6; lo += p; c2 += lo < p; } { uint64_t p = (uint64_t)x7 * Y7; lo += p; c2 += lo < p; }
-#endif
 }
 
 // Montgomery product a*b/2^256 mod p by product scanning (FIPS): columns k = 0..14 of a*b + m*p are
 // summed in a 96-bit accumulator; m[k] = column_k * (-p^-1) mod 2^32 zeroes the low word of each of the
 // first eight columns.  136 multiply-adds, 2 VALU instructions each.
+#endif  // __HIP_DEVICE_COMPILE__
+
 #if !defined(__HIP_DEVICE_COMPILE__)
 // Host build of the same product (proof assembly, key build, CPU unit tests): 4 x 64-bit limbs, CIOS with
 // unsigned __int128 -- about 3x faster on x86-64 than the 32-bit product scanning below.  Same result bit for bit.

@@ -26,7 +26,6 @@
 namespace zkr {
 
 constexpr int MSM_THREADS = 256;
-constexpr int MSM_MAX_WINDOWS = 64;
 constexpr uint32_t BIG_CAP = 1024;  // oversized buckets tracked per MSM
 
 template <class F> struct PointBytes;

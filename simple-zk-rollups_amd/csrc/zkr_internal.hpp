@@ -60,8 +60,8 @@ struct MsmWorkspace {
   DigitLists own_dig;             // digit records when the workspace is not attached to a key (stage hooks)
   uint32_t *big_list = nullptr, *big_count = nullptr, *block_sums = nullptr;
   void *big_partials = nullptr;
-  void *buckets = nullptr, *group_out = nullptr, *task_out = nullptr, *window_out = nullptr;
-  void *h_window = nullptr;  // pinned host copy of the window sums
+  void *buckets = nullptr, *group_out = nullptr, *task_out = nullptr, *result = nullptr;
+  void *h_result = nullptr;  // pinned host copy of the MSM result point (XYZZ)
   size_t max_nb = 0, max_entries = 0;
 };
 

@@ -96,8 +96,8 @@ static int alloc_msm_ws(MsmWorkspace &ws, size_t n, const MsmPlan &pl, size_t xy
   ZKR_HIP_CHECK(hipMalloc(&ws.buckets, nb * xyzz_bytes));
   ZKR_HIP_CHECK(hipMalloc(&ws.group_out, (size_t)(pl.nbw >> pl.glog) * 2 * xyzz_bytes));
   ZKR_HIP_CHECK(hipMalloc(&ws.task_out, (size_t)(pl.c + 2) * pl.S * xyzz_bytes));
-  ZKR_HIP_CHECK(hipMalloc(&ws.window_out, MSM_MAX_WINDOWS * xyzz_bytes));
-  ZKR_HIP_CHECK(hipHostMalloc(&ws.h_window, MSM_MAX_WINDOWS * xyzz_bytes, hipHostMallocDefault));
+  ZKR_HIP_CHECK(hipMalloc(&ws.result, xyzz_bytes));
+  ZKR_HIP_CHECK(hipHostMalloc(&ws.h_result, xyzz_bytes, hipHostMallocDefault));
   ws.max_nb = nb;
   ws.max_entries = n * pl.K;
   return 0;
@@ -115,8 +115,8 @@ void digit_lists_free(DigitLists &dl) {
 int msm_ws_alloc(MsmWorkspace &ws, size_t n, const MsmPlan &pl, size_t xyzz_bytes) { return alloc_msm_ws(ws, n, pl, xyzz_bytes); }
 void msm_ws_free(MsmWorkspace &ws) {
   hipFree(ws.counts); hipFree(ws.offsets); hipFree(ws.chunk_cnt); hipFree(ws.size_hist); hipFree(ws.order); digit_lists_free(ws.own_dig); hipFree(ws.entries); hipFree(ws.big_list); hipFree(ws.big_count); hipFree(ws.block_sums); hipFree(ws.big_partials);
-  hipFree(ws.buckets); hipFree(ws.group_out); hipFree(ws.task_out); hipFree(ws.window_out);
-  if (ws.h_window) hipHostFree(ws.h_window);
+  hipFree(ws.buckets); hipFree(ws.group_out); hipFree(ws.task_out); hipFree(ws.result);
+  if (ws.h_result) hipHostFree(ws.h_result);
   ws = MsmWorkspace();
 }
 

@@ -3,9 +3,9 @@
 // Replaces `await wasmBn128.groth16GenProof(witnessBin, provingKeyBin)`
 // (/root/reference/operator/src/snarks/common.ts:29, scripts/index.js:46).  Stages:
 //   ingest -> QAP rows (SpMV) -> 6 NTTs of size m (h = upper half of A.B) -> 5 MSMs -> host assembly.
-// Everything up to the K window sums of each MSM runs on the GPU on ONE stream with no host
-// round trip; the host then does ~20 group operations per MSM (Horner over windows) and the
-// blinding arithmetic of App. B step 4 (six 254-bit scalar multiplications).
+// Everything up to the result point of each MSM runs on the GPU with no host round trip (streams and the
+// two-proof pipeline: prove_submit below); the host then does the blinding arithmetic of App. B step 4
+// (six 254-bit scalar multiplications) and the affine conversion.
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -235,7 +235,7 @@ static int msm_big_enqueue(Prof pf, hipStream_t s, const Affine<F> *pts, uint32_
   return 0;
 }
 
-// big-bucket partial sums -> buckets, bucket reduction, window sums -> ws.h_window: short launches of few,
+// big-bucket partial sums -> buckets, bucket reduction -> the MSM result in ws.h_result: short launches of few,
 // long-running wavefronts (raised wave priority), meant to run beside the next table's accumulation
 template <class F>
 static int msm_reduce_enqueue(Prof pf, hipStream_t s, uint32_t n, const MsmPlan &pl, const MsmWorkspace &srt, MsmWorkspace &ws) {
@@ -250,9 +250,9 @@ static int msm_reduce_enqueue(Prof pf, hipStream_t s, uint32_t n, const MsmPlan 
   uint32_t ntask = (uint32_t)(pl.c - 1 - pl.glog) + 2;
   msm_reduce1_kernel<F, MsmCfg<F>::RED_W><<<(ngroups + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, s>>>((const XYZZ<F> *)ws.buckets, g, (XYZZ<F> *)ws.group_out);
   msm_reduce2_kernel<F, MsmCfg<F>::RED_W><<<ntask * pl.S, MSM_THREADS, MSM_THREADS * sizeof(XYZZ<F>), s>>>((const XYZZ<F> *)ws.group_out, g, (XYZZ<F> *)ws.task_out);
-  msm_reduce3_kernel<F, MsmCfg<F>::RED_W><<<1, MSM_THREADS, MSM_THREADS * sizeof(XYZZ<F>), s>>>((const XYZZ<F> *)ws.task_out, g, (XYZZ<F> *)ws.window_out);
+  msm_reduce3_kernel<F, MsmCfg<F>::RED_W><<<1, MSM_THREADS, MSM_THREADS * sizeof(XYZZ<F>), s>>>((const XYZZ<F> *)ws.task_out, g, (XYZZ<F> *)ws.result);
   prof_end(pf, s, sp);
-  ZKR_HIP_CHECK(hipMemcpyAsync(ws.h_window, ws.window_out, sizeof(XYZZ<F>), hipMemcpyDeviceToHost, s));
+  ZKR_HIP_CHECK(hipMemcpyAsync(ws.h_result, ws.result, sizeof(XYZZ<F>), hipMemcpyDeviceToHost, s));
   ZKR_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -274,7 +274,7 @@ static int msm_enqueue(Prof pf, hipStream_t s, const Affine<F> *pts, const uint3
 template <class F>
 static XYZZ<F> msm_finish(uint32_t n, const MsmWorkspace &ws) {
   if (n == 0) return XYZZ<F>::inf();
-  return *(const XYZZ<F> *)ws.h_window;
+  return *(const XYZZ<F> *)ws.h_result;
 }
 
 static bool u256_lt(const uint32_t *a, const uint32_t *b) {
@@ -576,24 +576,24 @@ static int msm_hook(const void *points_mont, const void *scalars_std, size_t n, 
     int rc = msm_ws_alloc(ws, np, pl, sizeof(XYZZ<F>));
     if (rc) return rc;
     Affine<F> *d_pts = nullptr;
-    uint32_t *d_sidx = nullptr;
+    uint32_t *d_rank = nullptr;
     Fr *d_sc = nullptr, *d_sc2 = nullptr;
     ZKR_HIP_CHECK(hipMalloc(&d_pts, compact.size() * pl.K));  // K window levels
-    ZKR_HIP_CHECK(hipMalloc(&d_sidx, n * 4));
+    ZKR_HIP_CHECK(hipMalloc(&d_rank, n * 4));
     ZKR_HIP_CHECK(hipMalloc(&d_sc, n * 32));
     ZKR_HIP_CHECK(hipMalloc(&d_sc2, n * 32));
     ZKR_HIP_CHECK(hipMemcpy(d_pts, compact.data(), compact.size(), hipMemcpyHostToDevice));
-    ZKR_HIP_CHECK(hipMemcpy(d_sidx, rank.data(), n * 4, hipMemcpyHostToDevice));
+    ZKR_HIP_CHECK(hipMemcpy(d_rank, rank.data(), n * 4, hipMemcpyHostToDevice));
     ZKR_HIP_CHECK(hipMemcpy(d_sc, scalars_std, n * 32, hipMemcpyHostToDevice));
     if ((rc = msm_precompute(device, sizeof(F) != 32, d_pts, np, pl))) return rc;
     ingest_kernel<<<(unsigned)((n + 255) / 256), 256>>>(d_sc, d_sc2, n);
-    rc = msm_enqueue<F>(Prof{nullptr, nullptr}, nullptr, d_pts, d_sidx, d_sc2, (uint32_t)n, np, pl, ws);
+    rc = msm_enqueue<F>(Prof{nullptr, nullptr}, nullptr, d_pts, d_rank, d_sc2, (uint32_t)n, np, pl, ws);
     if (!rc) {
       hipError_t e = hipDeviceSynchronize();
       if (e != hipSuccess) { set_error("msm failed: %s", hipGetErrorString(e)); rc = ZKR_ERR_HIP; }
     }
     if (!rc) res = msm_finish<F>(np, ws);
-    hipFree(d_pts); hipFree(d_sidx); hipFree(d_sc); hipFree(d_sc2);
+    hipFree(d_pts); hipFree(d_rank); hipFree(d_sc); hipFree(d_sc2);
     msm_ws_free(ws);
     if (rc) return rc;
   }
