@@ -229,3 +229,24 @@ def test_dense_random_shape_matches_oracle_generator():
     proof = key.prove(wb, r, s)
     assert proof == coracle.prove(pkb, wb, r, s) == g.proof_bytes(g.proof_from_toxic(circ, tox, circ["witness"], r, s))
     assert key2.prove(wb, r, s) == proof
+
+
+def test_proof_facade_like_reference_tests(small_case):
+    """createProofGenerator flow of common.ts:10-53 on the product only (HIP prover + native isValid), asserted the way
+    contracts/__tests__/withdrawverifier.test.ts:24-65 does: valid proof, inputs in order, wrong key -> 'Invalid proof generated'."""
+    import zkr_hip
+    c = small_case
+    gen = zkr_hip.create_proof_generator(c["pkb"], c["vk"], n_public=7)
+    out = gen(c["w"], c["r"], c["s"])
+    assert out["proof"] == g.proof_to_json(g.proof_from_toxic(c["circ"], c["tox"], c["w"], c["r"], c["s"]))
+    sol = out["solidityProof"]
+    assert sol["inputs"] == [str(x) for x in c["w"][1:8]]                                  # withdrawverifier.test.ts:35-37
+    assert sol["b"][0] == [out["proof"]["pi_b"][0][1], out["proof"]["pi_b"][0][0]]          # common.ts:45-47 (im, re)
+    assert zkr_hip.is_valid(c["vk"], out["proof"], sol["inputs"])
+    tampered = list(sol["inputs"])
+    tampered[0] = str((int(tampered[0]) + 1) % g.R)
+    assert not zkr_hip.is_valid(c["vk"], out["proof"], tampered)                            # withdrawverifier.test.ts:56-65
+    # a verifying key of another setup must make the facade throw (common.ts:36-38)
+    _, vk2 = g.setup(c["circ"], g.toxic_from_seed(0x1234))
+    with pytest.raises(zkr_hip.ZkrError, match="Invalid proof generated"):
+        zkr_hip.create_proof_generator(c["pkb"], vk2, n_public=7)(c["w"], c["r"], c["s"])
