@@ -154,15 +154,43 @@ static __global__ void ingest_kernel(const Fr *in, Fr *out, size_t n) {
 }
 
 // QAP evaluation on the domain: out[c] = sum_k coef[k] * w[col[k]] over CSR row c.
-// coef Montgomery, w standard -> out standard.  One thread per constraint row (rows are 1-3 terms,
-// with occasional 64-term packing rows).
+// coef Montgomery, w standard -> out standard.  One thread per constraint row: rows are 1-3 terms, except for the
+// occasional wide row (64-term bit-packing rows, a handful per few thousand), which would leave 63 lanes of its
+// wavefront waiting for one; rows wider than SPMV_WIDE are left to spmv_wide_kernel (one wavefront per row).
+constexpr uint32_t SPMV_WIDE = 8;
 static __global__ void spmv_kernel(const uint32_t *row_ptr, const uint32_t *col, const Fr *coef, const Fr *w, Fr *out, uint32_t m) {
   uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= m) return;
   uint32_t k0 = row_ptr[c], k1 = row_ptr[c + 1];
+  if (k1 - k0 > SPMV_WIDE) return;
   Fr acc = Fr::zero();
   for (uint32_t k = k0; k < k1; k++) acc = add(acc, mul(load_fr(coef + k), load_fr(w + col[k])));
   store_fr(out + c, acc);
+}
+// wide[i] = index of the i-th row wider than SPMV_WIDE; one wavefront per row, terms strided over the lanes, LDS tree
+static __global__ __launch_bounds__(64) void spmv_wide_kernel(const uint32_t *row_ptr, const uint32_t *col, const Fr *coef, const Fr *w, Fr *out,
+                                                            const uint32_t *wide, uint32_t n_wide) {
+  __shared__ uint32_t sh[8 * 64];
+  if (blockIdx.x >= n_wide) return;
+  const uint32_t c = wide[blockIdx.x], lane = threadIdx.x;
+  uint32_t k0 = row_ptr[c], k1 = row_ptr[c + 1];
+  Fr acc = Fr::zero();
+  for (uint32_t k = k0 + lane; k < k1; k += 64) acc = add(acc, mul(load_fr(coef + k), load_fr(w + col[k])));
+#pragma unroll
+  for (int i = 0; i < 8; i++) sh[i * 64 + lane] = acc.v[i];
+  __syncthreads();
+  for (uint32_t s = 32; s > 0; s >>= 1) {
+    if (lane < s) {
+      Fr o;
+#pragma unroll
+      for (int i = 0; i < 8; i++) { acc.v[i] = sh[i * 64 + lane]; o.v[i] = sh[i * 64 + lane + s]; }
+      acc = add(acc, o);
+#pragma unroll
+      for (int i = 0; i < 8; i++) sh[i * 64 + lane] = acc.v[i];
+    }
+    __syncthreads();
+  }
+  if (lane == 0) store_fr(out + c, acc);
 }
 
 // h (bit-reversed order) = C1*S' - C2 * g^-i * D'   (DESIGN.md "calcH on the GPU"); S', D' are the

@@ -34,6 +34,8 @@ struct ArenaHeader {
   uint32_t tlog;       // twiddle table entries = 2^tlog (= m)
   uint64_t off_tw, off_twl;
   uint64_t off_rowptr[2], off_col[2], off_coef[2];
+  uint64_t off_wide[2];  // row indices of the QAP rows wider than SPMV_WIDE terms (spmv_wide_kernel)
+  uint32_t n_wide[2];
   uint64_t off_pts[N_TABLES], off_rank[N_TABLES];  // rank: u32 per scalar of the table's vector -> index of its point, RANK_NONE if dropped
   uint8_t alfa1[64], beta1[64], delta1[64];  // Montgomery affine, as in the websnark key header
   uint8_t beta2[128], delta2[128];
@@ -41,7 +43,7 @@ struct ArenaHeader {
   uint32_t win_c[N_TABLES];  // window bits of each table: off_pts[t] holds K = ceil(255/c) x npts[t] points, level k = 2^(ck) * base
   uint32_t share_ac;   // A and C are laid out over the union of their supports (missing points stored as infinity): one digit sort serves both
   uint32_t rank_identity[N_TABLES];  // rank[s] == s for every scalar of the table's vector: the sort skips the gather
-  uint8_t pad[16];
+
 };
 static_assert(sizeof(ArenaHeader) <= 1024, "header fits its slot");
 constexpr size_t ARENA_HEADER_BYTES = 1024;

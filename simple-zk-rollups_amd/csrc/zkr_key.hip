@@ -186,6 +186,7 @@ int key_build(int device, uint32_t n, uint32_t p, uint32_t m, const std::vector<
   h.nnzB = (uint32_t)col[1].size();
   memcpy(h.alfa1, consts448, 64); memcpy(h.beta1, consts448 + 64, 64); memcpy(h.delta1, consts448 + 128, 64);
   memcpy(h.beta2, consts448 + 192, 128); memcpy(h.delta2, consts448 + 320, 128);
+  std::vector<uint32_t> wide_rows[2];
   size_t off = ARENA_HEADER_BYTES;
   auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return (uint64_t)o; };
   h.off_tw = take((size_t)m * 32);
@@ -194,6 +195,10 @@ int key_build(int device, uint32_t n, uint32_t p, uint32_t m, const std::vector<
     h.off_rowptr[s] = take(((size_t)m + 1) * 4);
     h.off_col[s] = take(col[s].size() * 4 + 4);
     h.off_coef[s] = take(coef[s].size() + 32);
+    for (uint32_t r = 0; r < m; r++)
+      if (rowptr[s][r + 1] - rowptr[s][r] > SPMV_WIDE) wide_rows[s].push_back(r);
+    h.n_wide[s] = (uint32_t)wide_rows[s].size();
+    h.off_wide[s] = take(wide_rows[s].size() * 4 + 4);
   }
   // A and C multiply the same scalars and nearly the same signals (C lacks the public ones): when their supports
   // overlap by >= 90 % both tables are laid out over the UNION of the supports (a missing point is stored as
@@ -241,6 +246,7 @@ int key_build(int device, uint32_t n, uint32_t p, uint32_t m, const std::vector<
       ZKR_HIP_CHECK(hipMemcpy(arena + h.off_col[s], col[s].data(), col[s].size() * 4, hipMemcpyHostToDevice));
       ZKR_HIP_CHECK(hipMemcpy(arena + h.off_coef[s], coef[s].data(), coef[s].size(), hipMemcpyHostToDevice));
     }
+    if (!wide_rows[s].empty()) ZKR_HIP_CHECK(hipMemcpy(arena + h.off_wide[s], wide_rows[s].data(), wide_rows[s].size() * 4, hipMemcpyHostToDevice));
   }
   for (int t = 0; t < N_TABLES; t++) {
     size_t np = h.npts[t], pb = t == T_B2 ? 128 : 64;

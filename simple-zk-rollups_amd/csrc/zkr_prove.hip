@@ -128,9 +128,12 @@ int calc_h_device(zkr_key *k, ProofSlot &sl, hipStream_t s) {
   uint32_t m = h.m;
   int sp = prof_begin(pf, s, "spmv");
   Fr *evals[2] = {sl.va, sl.vb};
-  for (int i = 0; i < 2; i++)
-    spmv_kernel<<<(m + 255) / 256, 256, 0, s>>>((const uint32_t *)(ar + h.off_rowptr[i]), (const uint32_t *)(ar + h.off_col[i]),
-                                               (const Fr *)(ar + h.off_coef[i]), sl.d_w, evals[i], m);
+  for (int i = 0; i < 2; i++) {
+    const uint32_t *rp = (const uint32_t *)(ar + h.off_rowptr[i]), *cl = (const uint32_t *)(ar + h.off_col[i]);
+    const Fr *cf = (const Fr *)(ar + h.off_coef[i]);
+    spmv_kernel<<<(m + 255) / 256, 256, 0, s>>>(rp, cl, cf, sl.d_w, evals[i], m);
+    if (h.n_wide[i]) spmv_wide_kernel<<<h.n_wide[i], 64, 0, s>>>(rp, cl, cf, sl.d_w, evals[i], (const uint32_t *)(ar + h.off_wide[i]), h.n_wide[i]);
+  }
   prof_end(pf, s, sp);
   sp = prof_begin(pf, s, "ntt");
   int rc;
