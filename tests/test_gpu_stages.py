@@ -250,3 +250,26 @@ def test_proof_facade_like_reference_tests(small_case):
     _, vk2 = g.setup(c["circ"], g.toxic_from_seed(0x1234))
     with pytest.raises(zkr_hip.ZkrError, match="Invalid proof generated"):
         zkr_hip.create_proof_generator(c["pkb"], vk2, n_public=7)(c["w"], c["r"], c["s"])
+
+
+@pytest.mark.parametrize("kind", ["only_one", "all_max", "booleans", "small64", "zeros_mixed"])
+def test_degenerate_witnesses_match_oracle(small_case, kind):
+    """Witness shapes that stress the digit sort and the bucket paths through the whole proof (they do not satisfy the
+    circuit; prover and oracle must still compute the same group elements, as the reference algorithm would):
+    only w_0 = 1, every signal r-1, 0/1 signals (one oversized bucket), 64-bit values (most windows empty), and a
+    zero-heavy mix."""
+    import zkr_hip
+    c = small_case
+    n = len(c["w"])
+    rnd = random.Random(hash(kind) & 0xffff)
+    w = {
+        "only_one": [1] + [0] * (n - 1),
+        "all_max": [1] + [R - 1] * (n - 1),
+        "booleans": [1] + [rnd.randrange(2) for _ in range(n - 1)],
+        "small64": [1] + [rnd.randrange(1 << 64) for _ in range(n - 1)],
+        "zeros_mixed": [1] + [0 if i % 3 else rnd.randrange(R) for i in range(n - 1)],
+    }[kind]
+    wb = g.binarify_witness(w)
+    key = zkr_hip.ProvingKey.load_websnark(c["pkb"])
+    assert key.prove(wb, c["r"], c["s"]) == coracle.prove(c["pkb"], wb, c["r"], c["s"])
+    assert key.calc_h(wb) == b"".join(_le(x) for x in g.calc_h_websnark(c["pk"], w))
