@@ -394,7 +394,7 @@ static __global__ __launch_bounds__(SCAN_THREADS) void msm_order_kernel(const ui
 // bucket accumulation: thread per bucket, buckets taken in `order` (fullest first): the 64 lanes of a
 // wavefront get buckets of (almost) equal occupancy, so no lane idles while another finishes, and the long
 // buckets start first.  The next entry and its point are fetched while the current addition runs.
-template <class F, int MINW>
+template <class F, int MINW, bool PREFETCH = true>
 static __global__ __launch_bounds__(MSM_THREADS) __attribute__((amdgpu_waves_per_eu(MINW, MINW))) void msm_accum_kernel(const Affine<F> *points, const uint32_t *offsets, const uint32_t *entries,
                                                                      uint32_t nb, const uint32_t *counts, const uint32_t *order, XYZZ<F> *buckets) {
   const uint32_t t = blockIdx.x * MSM_THREADS + threadIdx.x;
@@ -403,17 +403,27 @@ static __global__ __launch_bounds__(MSM_THREADS) __attribute__((amdgpu_waves_per
   if (counts[b] == BIG_MARK) return;  // msm_big_kernel owns it
   uint32_t o0 = offsets[b], o1 = offsets[b + 1];
   XYZZ<F> acc = XYZZ<F>::inf();
-  if (o0 < o1) {
-    uint32_t e = entries[o0];
-    Affine<F> p = load_pod(points + (e >> 1));
-    for (uint32_t j = o0 + 1; j < o1; j++) {
-      uint32_t en = entries[j];
-      Affine<F> pn = load_pod(points + (en >> 1));
-      if (!p.is_inf()) acc = add_mixed(acc, p, (e & 1) != 0);  // infinity: placeholder of a shared-support table
-      e = en;
-      p = pn;
+  if (PREFETCH) {
+    if (o0 < o1) {
+      uint32_t e = entries[o0];
+      Affine<F> p = load_pod(points + (e >> 1));
+      for (uint32_t j = o0 + 1; j < o1; j++) {
+        uint32_t en = entries[j];
+        Affine<F> pn = load_pod(points + (en >> 1));
+        if (!p.is_inf()) acc = add_mixed(acc, p, (e & 1) != 0);  // infinity: placeholder of a shared-support table
+        e = en;
+        p = pn;
+      }
+      if (!p.is_inf()) acc = add_mixed(acc, p, (e & 1) != 0);
     }
-    if (!p.is_inf()) acc = add_mixed(acc, p, (e & 1) != 0);
+  } else {  // only the next entry index is fetched ahead: for wide points the second point in flight costs spills
+    uint32_t e = o0 < o1 ? entries[o0] : 0u;
+    for (uint32_t j = o0; j < o1; j++) {
+      uint32_t en = j + 1 < o1 ? entries[j + 1] : 0u;
+      Affine<F> p = load_pod(points + (e >> 1));
+      if (!p.is_inf()) acc = add_mixed(acc, p, (e & 1) != 0);
+      e = en;
+    }
   }
   store_pod(buckets + b, acc);
 }

@@ -161,8 +161,9 @@ int calc_h_device(zkr_key *k, ProofSlot &sl, hipStream_t s) {
 
 // ------------------------------------------------------------------ MSM driver
 template <class F> struct MsmCfg;
-template <> struct MsmCfg<Fq> { static constexpr int ACC_W = 2, RED_W = 2; static constexpr const char *ACC_STAGE = "msm_accum_g1"; };
-template <> struct MsmCfg<Fq2> { static constexpr int ACC_W = 2, RED_W = 1; static constexpr const char *ACC_STAGE = "msm_accum_g2"; };
+template <> struct MsmCfg<Fq> { static constexpr int ACC_W = 2, RED_W = 2; static constexpr bool ACC_PREFETCH = true; static constexpr const char *ACC_STAGE = "msm_accum_g1"; };
+template <> struct MsmCfg<Fq2> { static constexpr int ACC_W = 2, RED_W = 1; static constexpr bool ACC_PREFETCH = false;  // a second 128-byte point in flight only costs spills (same speed)
+  static constexpr const char *ACC_STAGE = "msm_accum_g2"; };
 
 // digit records of one scalar vector, split by bucket range; shared by every table over those scalars
 static int msm_digits_enqueue(Prof pf, hipStream_t s, const Fr *scalars, uint32_t n, const MsmPlan &pl, const DigitLists &dl) {
@@ -213,7 +214,7 @@ static int msm_accum_enqueue(Prof pf, hipStream_t s, const Affine<F> *pts, uint3
   static const char *acc_env = getenv(sizeof(F) == 32 ? "ZKR_ACC_W_G1" : "ZKR_ACC_W_G2");
   static const int acc_w = acc_env ? atoi(acc_env) : MsmCfg<F>::ACC_W;
   const unsigned grid = (pl.nb + MSM_THREADS - 1) / MSM_THREADS;
-#define ZKR_ACC_LAUNCH(W) msm_accum_kernel<F, W><<<grid, MSM_THREADS, 0, s>>>(pts, srt.offsets, srt.entries, pl.nb, srt.counts, srt.order, (XYZZ<F> *)ws.buckets)
+#define ZKR_ACC_LAUNCH(W) msm_accum_kernel<F, W, MsmCfg<F>::ACC_PREFETCH><<<grid, MSM_THREADS, 0, s>>>(pts, srt.offsets, srt.entries, pl.nb, srt.counts, srt.order, (XYZZ<F> *)ws.buckets)
   switch (acc_w) {
     case 1: ZKR_ACC_LAUNCH(1); break;
     case 3: ZKR_ACC_LAUNCH(3); break;
