@@ -146,6 +146,16 @@ int zkr_synth_websnark(unsigned log_m, unsigned n_public, uint64_t circuit_seed,
  * circuit_seed, free values from witness_seed (zkr_synth_key uses witness_seed = circuit_seed). */
 int zkr_synth_witness(unsigned log_m, unsigned n_public, uint64_t circuit_seed, uint64_t witness_seed, void **witness_out,
                       size_t *witness_len);
+/* Groth16 trusted setup of an arbitrary R1CS, key elements computed on the GPU: what
+ * `snarkjs setup --protocol groth -c build/tx.json --pk ... --vk ...` does in the reference's workflow
+ * (prover/package.json:34,37), producing the device key directly (no JSON, no binarifyProvingKey) and the verifying key
+ * in the vk_bin layout of zkr_verify.  r1cs_bin: u32 nVars | u32 nPublic (outputs + public inputs) | u32 nConstraints |
+ * per constraint, for each of A, B, C: u32 k, then k x (u32 signal, 32 B coefficient, standard form LE) -- the
+ * `constraints` array of circom's circuit JSON (index.js / facade.py convert it).  toxic160: t, alfa, beta, gamma,
+ * delta (5 x 32 B, non-zero, < r) for reproducible test setups, or NULL to draw them from the OS CSPRNG inside the call
+ * (they are wiped before it returns).  domainSize = smallest power of two >= nConstraints + nPublic + 1. */
+int zkr_setup_r1cs(const void *r1cs_bin, size_t r1cs_len, const uint8_t *toxic160, int device, zkr_key **key_out, void **vk_out, size_t *vk_len);
+
 /* Circuit shape drawn by the three zkr_synth_* calls above (process-wide): 0 = rollup-shaped (default; 1-3 terms
  * per row, 3 % boolean and 2 % small signals, a third of the signals absent from B), 1 = dense random (BASELINE.json
  * configs[4]: every row is (4 random signals) x (4 random signals) = new signal; no infinity points in any query). */

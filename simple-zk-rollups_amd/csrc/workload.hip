@@ -215,12 +215,9 @@ struct Generated {
   ~Generated() { for (auto p : d_tbl) if (p) hipFree(p); }
 };
 
-static int generate(unsigned log_m, unsigned n_public, uint64_t circuit_seed, uint64_t toxic_seed, int device, Generated &g) {
-  if (log_m < 2 || log_m > 26 || n_public + 2 > (1u << log_m)) { set_error("bad synthetic geometry log_m=%u nPublic=%u", log_m, n_public); return ZKR_ERR_ARG; }
+// g.circ and g.tox are in place: QAP polynomials at t, then every group element of the key on the GPU
+static int setup_from_circuit(int device, Generated &g) {
   if (zkr_device_count() <= device || device < 0) { set_error("no HIP device %d; key points are computed on the GPU (no CPU fallback)", device); return ZKR_ERR_NO_DEVICE; }
-  synth_circuit(g.circ, 1u << log_m, n_public, circuit_seed, circuit_seed);
-  SplitMix64 rng(toxic_seed);
-  g.tox.t = rng.fr(); g.tox.alfa = rng.fr(); g.tox.beta = rng.fr(); g.tox.gamma = rng.fr(); g.tox.delta = rng.fr();
   setup_scalars(g.circ, g.tox, g.sc);
   std::vector<uint8_t> bytes;
   int rc;
@@ -256,30 +253,23 @@ static int generate(unsigned log_m, unsigned n_public, uint64_t circuit_seed, ui
   return 0;
 }
 
+static int generate(unsigned log_m, unsigned n_public, uint64_t circuit_seed, uint64_t toxic_seed, int device, Generated &g) {
+  if (log_m < 2 || log_m > 26 || n_public + 2 > (1u << log_m)) { set_error("bad synthetic geometry log_m=%u nPublic=%u", log_m, n_public); return ZKR_ERR_ARG; }
+  if (zkr_device_count() <= device || device < 0) { set_error("no HIP device %d; key points are computed on the GPU (no CPU fallback)", device); return ZKR_ERR_NO_DEVICE; }
+  synth_circuit(g.circ, 1u << log_m, n_public, circuit_seed, circuit_seed);
+  SplitMix64 rng(toxic_seed);
+  g.tox.t = rng.fr(); g.tox.alfa = rng.fr(); g.tox.beta = rng.fr(); g.tox.gamma = rng.fr(); g.tox.delta = rng.fr();
+  return setup_from_circuit(device, g);
+}
+
 static uint32_t bitrev32(uint32_t x, unsigned bits) {
   uint32_t r = 0;
   for (unsigned b = 0; b < bits; b++) r |= ((x >> b) & 1) << (bits - 1 - b);
   return r;
 }
 
-}  // namespace zkr
-
-using namespace zkr;
-
-extern "C" {
-
-int zkr_synth_set_shape(unsigned shape) {
-  if (shape > 1) { set_error("unknown synthetic circuit shape %u", shape); return ZKR_ERR_ARG; }
-  g_shape = shape;
-  return 0;
-}
-
-int zkr_synth_key(unsigned log_m, unsigned n_public, uint64_t circuit_seed, uint64_t toxic_seed, int device, zkr_key **key_out,
-                  void **witness_out, size_t *witness_len, void **aux_out, size_t *aux_len) {
-  if (!key_out || !witness_out || !witness_len) { set_error("null argument"); return ZKR_ERR_ARG; }
-  Generated g;
-  int rc = generate(log_m, n_public, circuit_seed, toxic_seed, device, g);
-  if (rc) return rc;
+// CSR rows of the QAP (A gets the nPublic+1 input-consistency rows), the kept points of every table, then the arena
+static int build_key_from_generated(const Generated &g, int device, zkr_key **key_out) {
   const Circuit &c = g.circ;
   uint32_t n = c.n, p = c.p, m = c.m;
   // QAP rows in CSR (A gets the nPublic+1 input-consistency rows)
@@ -316,7 +306,8 @@ int zkr_synth_key(unsigned log_m, unsigned n_public, uint64_t circuit_seed, uint
   }
   for (uint32_t i = 0; i < n - p - 1; i++)
     if (!g.sc.cpriv[i].is_zero()) { srcidx[T_C].push_back(i); sidx[T_C].push_back(i + p + 1); }
-  unsigned logm = log_m;
+  unsigned logm = 0;
+  while ((1u << logm) < m) logm++;
   for (uint32_t j = 0; j < m; j++) {
     uint32_t i = bitrev32(j, logm);
     if (!g.sc.hx[i].is_zero()) { srcidx[T_H].push_back(i); sidx[T_H].push_back(j); }
@@ -324,8 +315,121 @@ int zkr_synth_key(unsigned log_m, unsigned n_public, uint64_t circuit_seed, uint
   const void *src[N_TABLES];
   bool on_dev[N_TABLES];
   for (int t = 0; t < N_TABLES; t++) { src[t] = g.d_tbl[t]; on_dev[t] = true; }
-  rc = key_build(device, n, p, m, rowptr, col, coef, src, on_dev, srcidx, sidx, g.consts, key_out);
+  return key_build(device, n, p, m, rowptr, col, coef, src, on_dev, srcidx, sidx, g.consts, key_out);
+}
+
+// vk_bin (zkr_verify layout) from the setup's own data
+static void vk_from_generated(const Generated &g, std::vector<uint8_t> &vk) {
+  const size_t nic = g.sc.ic.size();
+  vk.resize(64 + 3 * 128 + 4 + 64 * nic);
+  store_g1_std(vk.data(), load_g1(g.consts));
+  store_g2_std(vk.data() + 64, load_g2(g.consts + 192));
+  memcpy(vk.data() + 192, g.gamma2_std.data(), 128);
+  store_g2_std(vk.data() + 320, load_g2(g.consts + 320));
+  uint32_t nic32 = (uint32_t)nic;
+  memcpy(vk.data() + 448, &nic32, 4);
+  memcpy(vk.data() + 452, g.ic_std.data(), 64 * nic);
+}
+
+}  // namespace zkr
+
+using namespace zkr;
+
+extern "C" {
+
+// ---- Groth16 setup for an arbitrary R1CS: restates `snarkjs setup --protocol groth`
+// (/root/reference/prover/package.json:34,37; SURVEY App. B "Setup") with the key's group elements computed on the GPU
+static bool read_fr_std(const uint8_t *p, Fr &out) {
+  memcpy(out.v, p, 32);
+  for (int i = 7; i >= 0; i--)
+    if (out.v[i] != FrParams::P[i]) return out.v[i] < FrParams::P[i];
+  return false;
+}
+static int draw_fr(FILE *f, Fr &out) {
+  for (;;) {
+    uint8_t b[32];
+    if (fread(b, 1, 32, f) != 32) return 1;
+    b[31] &= 0x3f;
+    if (read_fr_std(b, out) && !out.is_zero()) return 0;
+  }
+}
+
+int zkr_setup_r1cs(const void *r1cs_bin, size_t r1cs_len, const uint8_t *toxic160, int device, zkr_key **key_out, void **vk_out, size_t *vk_len) {
+  if (!r1cs_bin || !key_out || !vk_out || !vk_len) { set_error("null argument"); return ZKR_ERR_ARG; }
+  const uint8_t *b = (const uint8_t *)r1cs_bin, *end = b + r1cs_len;
+  if (r1cs_len < 12) { set_error("R1CS shorter than its header"); return ZKR_ERR_ARG; }
+  Generated g;
+  Circuit &c = g.circ;
+  memcpy(&c.n, b, 4); memcpy(&c.p, b + 4, 4); memcpy(&c.nC, b + 8, 4);
+  b += 12;
+  if (c.n < 1 || c.p + 1 > c.n || c.nC < 1 || (uint64_t)c.nC + c.p + 1 > (1ull << 26)) { set_error("bad R1CS geometry nVars=%u nPublic=%u nConstraints=%u", c.n, c.p, c.nC); return ZKR_ERR_ARG; }
+  c.m = 2;
+  while (c.m < c.nC + c.p + 1) c.m <<= 1;  // snarkjs: domainBits = floor(log2(nC + nPublic)) + 1
+  std::vector<uint32_t> *rows[3] = {&c.rowA, &c.rowB, &c.rowC};
+  std::vector<Term> *terms[3] = {&c.tA, &c.tB, &c.tC};
+  for (auto r : rows) r->push_back(0);
+  for (uint32_t row = 0; row < c.nC; row++) {
+    for (int s = 0; s < 3; s++) {
+      if (b + 4 > end) { set_error("R1CS truncated in constraint %u", row); return ZKR_ERR_ARG; }
+      uint32_t k;
+      memcpy(&k, b, 4);
+      b += 4;
+      if ((uint64_t)k * 36 > (uint64_t)(end - b)) { set_error("R1CS truncated in constraint %u", row); return ZKR_ERR_ARG; }
+      for (uint32_t e = 0; e < k; e++, b += 36) {
+        Term t;
+        memcpy(&t.sig, b, 4);
+        Fr cf;
+        if (t.sig >= c.n || !read_fr_std(b + 4, cf)) { set_error("constraint %u: signal %u out of range or coefficient >= r", row, t.sig); return ZKR_ERR_ARG; }
+        t.coef = to_mont(cf);
+        terms[s]->push_back(t);
+      }
+      rows[s]->push_back((uint32_t)terms[s]->size());
+    }
+  }
+  if (b != end) { set_error("R1CS has %zu trailing bytes", (size_t)(end - b)); return ZKR_ERR_ARG; }
+  Fr *tox[5] = {&g.tox.t, &g.tox.alfa, &g.tox.beta, &g.tox.gamma, &g.tox.delta};
+  if (toxic160) {
+    for (int i = 0; i < 5; i++) {
+      Fr v;
+      if (!read_fr_std(toxic160 + 32 * i, v) || v.is_zero()) { set_error("toxic scalar %d is zero or >= r", i); return ZKR_ERR_ARG; }
+      *tox[i] = to_mont(v);
+    }
+  } else {  // fresh toxic waste from the OS CSPRNG; it never leaves this call
+    FILE *f = fopen("/dev/urandom", "rb");
+    if (!f) { set_error("cannot open /dev/urandom"); return ZKR_ERR_ARG; }
+    int bad = 0;
+    for (int i = 0; i < 5 && !bad; i++) { Fr v; bad = draw_fr(f, v); *tox[i] = to_mont(v); }
+    fclose(f);
+    if (bad) { set_error("short read from /dev/urandom"); return ZKR_ERR_ARG; }
+  }
+  int rc = setup_from_circuit(device, g);
+  if (!rc) rc = build_key_from_generated(g, device, key_out);
+  memset((void *)&g.tox, 0, sizeof(g.tox));
   if (rc) return rc;
+  std::vector<uint8_t> vk;
+  vk_from_generated(g, vk);
+  *vk_out = malloc(vk.size());
+  memcpy(*vk_out, vk.data(), vk.size());
+  *vk_len = vk.size();
+  return 0;
+}
+
+int zkr_synth_set_shape(unsigned shape) {
+  if (shape > 1) { set_error("unknown synthetic circuit shape %u", shape); return ZKR_ERR_ARG; }
+  g_shape = shape;
+  return 0;
+}
+
+int zkr_synth_key(unsigned log_m, unsigned n_public, uint64_t circuit_seed, uint64_t toxic_seed, int device, zkr_key **key_out,
+                  void **witness_out, size_t *witness_len, void **aux_out, size_t *aux_len) {
+  if (!key_out || !witness_out || !witness_len) { set_error("null argument"); return ZKR_ERR_ARG; }
+  Generated g;
+  int rc = generate(log_m, n_public, circuit_seed, toxic_seed, device, g);
+  if (rc) return rc;
+  rc = build_key_from_generated(g, device, key_out);
+  if (rc) return rc;
+  const Circuit &c = g.circ;
+  uint32_t n = c.n;
   std::vector<uint8_t> wb;
   to_std_bytes(c.w, wb);
   *witness_out = malloc(wb.size());

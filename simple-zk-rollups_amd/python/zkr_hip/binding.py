@@ -56,6 +56,7 @@ def lib():
     L.zkr_synth_websnark.argtypes = [c.c_uint, c.c_uint, c.c_uint64, c.c_uint64, i, c.POINTER(vp), c.POINTER(sz),
                                      c.POINTER(vp), c.POINTER(sz)]
     L.zkr_synth_witness.argtypes = [c.c_uint, c.c_uint, c.c_uint64, c.c_uint64, c.POINTER(vp), c.POINTER(sz)]
+    L.zkr_setup_r1cs.argtypes = [u8p, sz, u8p, i, c.POINTER(vp), c.POINTER(vp), c.POINTER(sz)]
     L.zkr_synth_vk.argtypes = [vp, u8p, sz, c.POINTER(vp), c.POINTER(sz)]
     L.zkr_synth_set_shape.argtypes = [c.c_uint]
     L.zkr_free.argtypes = [vp]
@@ -115,6 +116,18 @@ class ProvingKey:
         h = ctypes.c_void_p()
         _check(lib().zkr_key_adopt_arena(ctypes.c_void_p(dev_ptr), length, device, ctypes.byref(h)))
         return cls(h, device, keepalive)
+
+    @classmethod
+    def setup_r1cs(cls, r1cs_bin: bytes, toxic=None, device=0):
+        """Groth16 setup of an R1CS on the GPU (zkr_setup_r1cs; `snarkjs setup --protocol groth`).  toxic: None (OS
+        CSPRNG) or five ints (t, alfa, beta, gamma, delta) for reproducible tests.  Returns (key, vk_bin)."""
+        tb = None if toxic is None else b"".join(int(x).to_bytes(32, "little") for x in toxic)
+        h, vk, n = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_size_t()
+        _check(lib().zkr_setup_r1cs(bytes(r1cs_bin), len(r1cs_bin), tb, device, ctypes.byref(h), ctypes.byref(vk), ctypes.byref(n)))
+        try:
+            return cls(h, device), ctypes.string_at(vk, n.value)
+        finally:
+            lib().zkr_free(vk)
 
     @classmethod
     def load_file(cls, path, device=0):

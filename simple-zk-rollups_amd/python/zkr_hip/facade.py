@@ -32,6 +32,33 @@ def binarify_verifying_key(vk) -> bytes:
     return g1(vk["vk_alfa_1"]) + g2(vk["vk_beta_2"]) + g2(vk["vk_gamma_2"]) + g2(vk["vk_delta_2"]) + len(ic).to_bytes(4, "little") + b"".join(g1(p) for p in ic)
 
 
+def binarify_r1cs(circuit_def) -> bytes:
+    """circom 0.0.35 circuit JSON (what `compiler(...)` returns at common.ts:12-14 and `circom -o build/tx.json`
+    writes: nVars, nPubInputs, nOutputs, constraints = [[A, B, C], ...] with {signal: coefficient} maps) -> the
+    r1cs_bin layout of zkr_setup_r1cs (include/zkr.h).  Also accepts nPublic directly and (signal, coef) pair lists."""
+    p = circuit_def["nPublic"] if "nPublic" in circuit_def else circuit_def["nPubInputs"] + circuit_def["nOutputs"]
+    cons = circuit_def["constraints"]
+    out = [int(circuit_def["nVars"]).to_bytes(4, "little"), int(p).to_bytes(4, "little"), len(cons).to_bytes(4, "little")]
+    for row in cons:
+        for lc in row:
+            items = list(lc.items()) if isinstance(lc, dict) else list(lc)
+            out.append(len(items).to_bytes(4, "little"))
+            for sig, cf in items:
+                out.append(int(sig).to_bytes(4, "little") + (int(cf) % SNARK_FIELD_SIZE).to_bytes(32, "little"))
+    return b"".join(out)
+
+
+def verifying_key_from_bytes(vk_bin: bytes):
+    """vk_bin (zkr_verify layout) -> the snarkjs verifying-key JSON fields that layout carries (decimal strings,
+    projective third coordinates added), e.g. to feed `snarkjs generateverifier` (prover/package.json:35,38)."""
+    rd = lambda o: str(int.from_bytes(vk_bin[o:o + 32], "little"))
+    g1 = lambda o: [rd(o), rd(o + 32), "1"]
+    g2 = lambda o: [[rd(o), rd(o + 32)], [rd(o + 64), rd(o + 96)], ["1", "0"]]
+    nic = int.from_bytes(vk_bin[448:452], "little")
+    return {"protocol": "groth", "nPublic": nic - 1, "vk_alfa_1": g1(0), "vk_beta_2": g2(64), "vk_gamma_2": g2(192), "vk_delta_2": g2(320),
+            "IC": [g1(452 + 64 * i) for i in range(nic)]}
+
+
 def proof_bytes_from_json(proof) -> bytes:
     """Inverse of proof_json_from_bytes."""
     le = lambda v: int(v).to_bytes(32, "little")

@@ -273,3 +273,35 @@ def test_degenerate_witnesses_match_oracle(small_case, kind):
     key = zkr_hip.ProvingKey.load_websnark(c["pkb"])
     assert key.prove(wb, c["r"], c["s"]) == coracle.prove(c["pkb"], wb, c["r"], c["s"])
     assert key.calc_h(wb) == b"".join(_le(x) for x in g.calc_h_websnark(c["pk"], w))
+
+
+def test_setup_of_an_r1cs_on_the_gpu_matches_oracle_setup(small_case):
+    """zkr_setup_r1cs (`snarkjs setup --protocol groth`, prover/package.json:34,37): same toxic waste ->
+    the verifying key equals the oracle's setup and proofs equal the closed form; fresh CSPRNG toxic waste -> proofs
+    verify under the returned key and differ from the seeded setup's."""
+    import zkr_hip
+    c = small_case
+    circ, tox = c["circ"], c["tox"]
+    cdef = dict(nVars=circ["nVars"], nPubInputs=5, nOutputs=2,
+                constraints=[[{str(s): str(cf) for s, cf in lc} for lc in row] for row in circ["rows"]])
+    r1cs = zkr_hip.binarify_r1cs(cdef)
+    key, vk_bin = zkr_hip.ProvingKey.setup_r1cs(r1cs, toxic=[tox[k] for k in ("t", "alfa", "beta", "gamma", "delta")])
+    assert vk_bin == zkr_hip.binarify_verifying_key(c["vk"])
+    assert key.info()["domainSize"] == 128 and key.info()["nVars"] == circ["nVars"]
+    proof = key.prove(c["wb"], c["r"], c["s"])
+    assert proof == g.proof_bytes(g.proof_from_toxic(circ, tox, c["w"], c["r"], c["s"]))
+    pub = c["w"][1:8]
+    assert zkr_hip.verify(vk_bin, proof, pub)
+    vkj = zkr_hip.verifying_key_from_bytes(vk_bin)
+    assert zkr_hip.is_valid(vkj, zkr_hip.proof_json_from_bytes(proof), pub) and vkj["nPublic"] == 7
+    # a circuit that does not fill its domain: nConstraints + nPublic + 1 = 61 -> domainSize 64
+    small = dict(nVars=circ["nVars"], nPublic=7, constraints=[[list(lc) for lc in row] for row in circ["rows"][:53]])
+    key2, vk2 = zkr_hip.ProvingKey.setup_r1cs(zkr_hip.binarify_r1cs(small))      # CSPRNG toxic waste
+    assert key2.info()["domainSize"] == 64
+    p2 = key2.prove(c["wb"], c["r"], c["s"])   # the witness satisfies the first 53 constraints as well
+    assert zkr_hip.verify(vk2, p2, pub) and p2 != proof
+    bad = list(pub)
+    bad[0] = (bad[0] + 1) % R
+    assert not zkr_hip.verify(vk2, p2, bad)
+    with pytest.raises(zkr_hip.ZkrError):
+        zkr_hip.ProvingKey.setup_r1cs(r1cs[:-3])
