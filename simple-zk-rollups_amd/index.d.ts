@@ -12,6 +12,12 @@ export interface Bn128 {
   groth16GenProof(witnessBin: ArrayBuffer | Uint8Array, provingKeyBin: ArrayBuffer | Uint8Array, opts?: ProveOptions): Promise<Groth16Proof>;
   /** Independent proofs on one key, pipelined two deep on the GPU. */
   groth16GenProofBatch(witnessBins: Array<ArrayBuffer | Uint8Array>, provingKeyBin: ArrayBuffer | Uint8Array, opts?: ProveOptions[]): Promise<Groth16Proof[]>;
+  /** Groth16 setup of circom's circuit JSON on the GPU (snarkjs setup --protocol groth); returns the verifying key JSON. */
+  setup(circuitDef: any, opts?: { toxic?: Array<bigint | string> }): any;
+  saveKey(path: string): void;
+  loadKeyFile(path: string): void;
+  /** Proof with the key currently held on the device. */
+  prove(witnessBin: ArrayBuffer | Uint8Array, opts?: ProveOptions): Promise<Groth16Proof>;
   keyInfo(): { nVars: number; nPublic: number; domainSize: number; nnzA: number; nnzB: number } | null;
   terminate(): void;
 }
@@ -23,6 +29,8 @@ export function solidityProof(proof: Groth16Proof, publicSignals: Array<bigint |
 /** snarkjs groth.isValid(vk, proof, publicSignals) on the native host verifier (no GPU needed). */
 export function isValid(verifyingKey: any, proof: Groth16Proof, publicSignals: Array<bigint | string>): boolean;
 export function binarifyVerifyingKey(verifyingKey: any): Uint8Array;
+export function binarifyR1cs(circuitDef: any): Uint8Array;
+export function verifyingKeyFromBytes(vkBin: Uint8Array): any;
 export function proofFromBytes(proofBytes: Uint8Array): Groth16Proof;
 export function deviceCount(): number;
 export function version(): string;

@@ -76,6 +76,26 @@ class Bn128 {
     return [first, ...rest];
   }
 
+  // ---- a key held on the device without the websnark buffer in between (INTEGRATION.md section 5)
+  // Groth16 setup of a compiled circuit on the GPU: what `snarkjs setup --protocol groth` does (prover/package.json:34,37).
+  // circuitDef: circom's circuit JSON (common.ts:12-14).  opts.toxic: [t, alfa, beta, gamma, delta] for reproducible
+  // tests; by default fresh toxic waste is drawn from the OS CSPRNG inside the library.  Returns the verifying key JSON.
+  setup(circuitDef, opts) {
+    const tox = opts && opts.toxic ? Buffer.concat(opts.toxic.map(bigintToLe32)) : null;
+    const [key, vkBin] = native().setupR1cs(binarifyR1cs(circuitDef), tox, this.device);
+    this._key = key; this._fp = "setup";
+    return verifyingKeyFromBytes(vkBin);
+  }
+  saveKey(path) { if (!this._key) throw new Error("no key loaded"); native().keySave(this._key, path); }
+  loadKeyFile(path) { this._key = native().keyLoadFile(path, this.device); this._fp = "file:" + path; }
+  // proof with the key currently held (after setup / loadKeyFile / a groth16GenProof call)
+  async prove(witnessBin, opts) {
+    if (!this._key) throw new Error("no key loaded");
+    const r = opts && opts.r !== undefined ? bigintToLe32(opts.r) : null;
+    const s = opts && opts.s !== undefined ? bigintToLe32(opts.s) : null;
+    return proofFromBytes(await native().prove(this._key, witnessBin, r, s));
+  }
+
   keyInfo() {
     if (!this._key) return null;
     const v = native().keyInfo(this._key);
@@ -136,6 +156,32 @@ async function genProof(provingKey, witness, opts) {
   return { proof, publicSignals };
 }
 
+// circom 0.0.35 circuit JSON (nVars, nPubInputs, nOutputs, constraints = [[A, B, C], ...] of {signal: coefficient})
+// -> the r1cs_bin layout of zkr_setup_r1cs (include/zkr.h)
+function binarifyR1cs(cd) {
+  const p = cd.nPublic !== undefined ? cd.nPublic : cd.nPubInputs + cd.nOutputs;
+  const parts = [];
+  const u32 = (v) => { const b = Buffer.alloc(4); b.writeUInt32LE(Number(v), 0); parts.push(b); };
+  u32(cd.nVars); u32(p); u32(cd.constraints.length);
+  for (const row of cd.constraints)
+    for (const lc of row) {
+      const keys = Object.keys(lc);
+      u32(keys.length);
+      for (const k of keys) { u32(k); parts.push(bigintToLe32(((BigInt(lc[k]) % R) + R) % R)); }
+    }
+  return Buffer.concat(parts);
+}
+
+function verifyingKeyFromBytes(vk) {
+  const rd = (o) => leBytesToDecimal(vk, o);
+  const g1 = (o) => [rd(o), rd(o + 32), "1"];
+  const g2 = (o) => [[rd(o), rd(o + 32)], [rd(o + 64), rd(o + 96)], ["1", "0"]];
+  const nic = vk.readUInt32LE(448);
+  const IC = [];
+  for (let i = 0; i < nic; i++) IC.push(g1(452 + 64 * i));
+  return { protocol: "groth", nPublic: nic - 1, vk_alfa_1: g1(0), vk_beta_2: g2(64), vk_gamma_2: g2(192), vk_delta_2: g2(320), IC };
+}
+
 // ---- groth.isValid(vk, proof, publicSignals) (operator/src/snarks/common.ts:30-34) on the native host verifier
 function binarifyVerifyingKey(vk) {
   const g1 = (P) => Buffer.concat([bigintToLe32(P[0]), bigintToLe32(P[1])]);
@@ -167,6 +213,7 @@ function solidityProof(proof, publicSignals) {
 
 module.exports = {
   buildBn128, genProof, binarifyWitness, binarifyProvingKey, solidityProof, proofFromBytes, isValid, binarifyVerifyingKey,
+  binarifyR1cs, verifyingKeyFromBytes,
   deviceCount: () => { native(); return deviceCount; },
   version: () => native().version(),
 };

@@ -23,6 +23,10 @@ static struct {
   int (*key_info)(const zkr_key *, uint64_t *);
   int (*prove)(zkr_key *, const void *, size_t, const uint8_t *, const uint8_t *, uint8_t *, void *);
   int (*verify)(const void *, size_t, const uint8_t *, const void *, size_t, int *);
+  int (*setup_r1cs)(const void *, size_t, const uint8_t *, int, zkr_key **, void **, size_t *);
+  int (*key_save)(const zkr_key *, const char *);
+  int (*key_load_file)(const char *, int, zkr_key **);
+  void (*free_)(void *);
 } Z;
 
 #define NAPI_OK(call)                                                     \
@@ -59,6 +63,7 @@ static napi_value js_load(napi_env env, napi_callback_info info) {
   if (!Z.field) return throw_msg(env, "libzkr_hip.so lacks symbol " name);
     SYM(last_error, "zkr_last_error") SYM(version, "zkr_version") SYM(device_count, "zkr_device_count")
     SYM(key_load_websnark, "zkr_key_load_websnark") SYM(key_free, "zkr_key_free") SYM(key_info, "zkr_key_info") SYM(prove, "zkr_prove") SYM(verify, "zkr_verify")
+    SYM(setup_r1cs, "zkr_setup_r1cs") SYM(key_save, "zkr_key_save") SYM(key_load_file, "zkr_key_load_file") SYM(free_, "zkr_free")
     Z.handle = h;
   }
   napi_value out;
@@ -106,6 +111,68 @@ static napi_value js_key_load(napi_env env, napi_callback_info info) {
   zkr_key *key = NULL;
   int rc = Z.key_load_websnark(pk, len, dev, &key);
   if (rc) return throw_msg(env, Z.last_error());
+  napi_value ext;
+  NAPI_OK(napi_create_external(env, key, key_finalize, NULL, &ext));
+  return ext;
+}
+
+/* setupR1cs(r1csBin, toxic160|null, device) -> [key handle, vkBin Buffer]: Groth16 setup on the GPU (zkr_setup_r1cs;
+ * `snarkjs setup --protocol groth`, prover/package.json:34,37).  Synchronous: done once per circuit. */
+static napi_value js_setup_r1cs(napi_env env, napi_callback_info info) {
+  size_t argc = 3;
+  napi_value argv[3];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  if (!Z.handle) return throw_msg(env, "libzkr_hip.so not loaded");
+  const uint8_t *r1cs, *tox = NULL;
+  size_t len, tox_len = 0;
+  int32_t dev = 0;
+  if (argc < 1 || !get_bytes(env, argv[0], &r1cs, &len)) return throw_msg(env, "r1csBin must be an ArrayBuffer / Buffer / TypedArray");
+  napi_valuetype t = napi_null;
+  if (argc > 1) napi_typeof(env, argv[1], &t);
+  if (t != napi_null && t != napi_undefined) {
+    if (!get_bytes(env, argv[1], &tox, &tox_len) || tox_len != 160) return throw_msg(env, "toxic waste must be 5 x 32 bytes or null");
+  }
+  if (argc > 2) napi_get_value_int32(env, argv[2], &dev);
+  zkr_key *key = NULL;
+  void *vk = NULL;
+  size_t vk_len = 0;
+  if (Z.setup_r1cs(r1cs, len, tox, dev, &key, &vk, &vk_len)) return throw_msg(env, Z.last_error());
+  napi_value ext, vkb, arr;
+  void *copy;
+  NAPI_OK(napi_create_external(env, key, key_finalize, NULL, &ext));
+  NAPI_OK(napi_create_buffer_copy(env, vk_len, vk, &copy, &vkb));
+  Z.free_(vk);
+  NAPI_OK(napi_create_array_with_length(env, 2, &arr));
+  NAPI_OK(napi_set_element(env, arr, 0, ext));
+  NAPI_OK(napi_set_element(env, arr, 1, vkb));
+  return arr;
+}
+
+/* keySave(key, path) / keyLoadFile(path, device): the packed device-layout key file (zkr_key_save / zkr_key_load_file) */
+static napi_value js_key_save(napi_env env, napi_callback_info info) {
+  size_t argc = 2;
+  napi_value argv[2];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  zkr_key *key;
+  char path[4096];
+  size_t n = 0;
+  NAPI_OK(napi_get_value_external(env, argv[0], (void **)&key));
+  NAPI_OK(napi_get_value_string_utf8(env, argv[1], path, sizeof(path), &n));
+  if (Z.key_save(key, path)) return throw_msg(env, Z.last_error());
+  return NULL;
+}
+static napi_value js_key_load_file(napi_env env, napi_callback_info info) {
+  size_t argc = 2;
+  napi_value argv[2];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  if (!Z.handle) return throw_msg(env, "libzkr_hip.so not loaded");
+  char path[4096];
+  size_t n = 0;
+  int32_t dev = 0;
+  NAPI_OK(napi_get_value_string_utf8(env, argv[0], path, sizeof(path), &n));
+  if (argc > 1) napi_get_value_int32(env, argv[1], &dev);
+  zkr_key *key = NULL;
+  if (Z.key_load_file(path, dev, &key)) return throw_msg(env, Z.last_error());
   napi_value ext;
   NAPI_OK(napi_create_external(env, key, key_finalize, NULL, &ext));
   return ext;
@@ -219,6 +286,8 @@ static napi_value init(napi_env env, napi_value exports) {
       {"load", NULL, js_load, NULL, NULL, NULL, napi_default, NULL},       {"version", NULL, js_version, NULL, NULL, NULL, napi_default, NULL},
       {"keyLoad", NULL, js_key_load, NULL, NULL, NULL, napi_default, NULL}, {"keyInfo", NULL, js_key_info, NULL, NULL, NULL, napi_default, NULL},
       {"prove", NULL, js_prove, NULL, NULL, NULL, napi_default, NULL},     {"verify", NULL, js_verify, NULL, NULL, NULL, napi_default, NULL},
+      {"setupR1cs", NULL, js_setup_r1cs, NULL, NULL, NULL, napi_default, NULL}, {"keySave", NULL, js_key_save, NULL, NULL, NULL, napi_default, NULL},
+      {"keyLoadFile", NULL, js_key_load_file, NULL, NULL, NULL, napi_default, NULL},
   };
   napi_define_properties(env, exports, sizeof(props) / sizeof(props[0]), props);
   return exports;

@@ -139,3 +139,40 @@ def test_js_is_valid_on_native_verifier(tmp_path, small_case):
       console.log(JSON.stringify([z.isValid(d.vk, d.proof, d.pub), z.isValid(d.vk, d.proof, d.bad)]));
     """, str(path)).stdout
     assert json.loads(out) == [True, False]
+
+
+@pytest.mark.gpu
+def test_js_setup_prove_save_load_verify(tmp_path, small_case):
+    """The whole reference workflow on the product from Node: setup of the compiled circuit (snarkjs setup,
+    prover/package.json:34), proof, isValid (common.ts:30-34), packed key file round trip."""
+    c = small_case
+    cdef = dict(nVars=c["circ"]["nVars"], nPubInputs=5, nOutputs=2,
+                constraints=[[{str(s): str(cf) for s, cf in lc} for lc in row] for row in c["circ"]["rows"]])
+    tox = [str(c["tox"][k]) for k in ("t", "alfa", "beta", "gamma", "delta")]
+    path = tmp_path / "circ.json"
+    path.write_text(json.dumps(dict(cdef=cdef, tox=tox, witness=[str(x) for x in c["w"]], r=str(c["r"]), s=str(c["s"]),
+                                    keyfile=str(tmp_path / "tx.zkrkey"))))
+    out = _node("""
+      const z = require('./index.js'); const fs = require('fs');
+      const d = JSON.parse(fs.readFileSync(process.argv[1]));
+      (async () => {
+        const bn = await z.buildBn128();
+        const vk = bn.setup(d.cdef, {toxic: d.tox});
+        const wb = z.binarifyWitness(d.witness);
+        const p1 = await bn.prove(wb, {r: d.r, s: d.s});
+        const pub = d.witness.slice(1, 8);
+        bn.saveKey(d.keyfile);
+        const bn2 = await z.buildBn128();
+        bn2.loadKeyFile(d.keyfile);
+        const p2 = await bn2.prove(wb, {r: d.r, s: d.s});
+        const bn3 = await z.buildBn128();
+        const vk3 = bn3.setup(d.cdef);                       // fresh toxic waste
+        const p3 = await bn3.prove(wb);
+        console.log(JSON.stringify({vk, p1, p2, ok1: z.isValid(vk, p1, pub), ok3: z.isValid(vk3, p3, pub), cross: z.isValid(vk, p3, pub)}));
+      })().catch(e => { console.error(e); process.exit(1); });
+    """, str(path)).stdout
+    res = json.loads(out)
+    expect = g.proof_to_json(g.proof_from_toxic(c["circ"], c["tox"], c["w"], c["r"], c["s"]))
+    assert res["p1"] == expect and res["p2"] == expect
+    assert res["ok1"] is True and res["ok3"] is True and res["cross"] is False
+    assert res["vk"]["IC"][0][:2] == [str(c["vk"]["IC"][0][0]), str(c["vk"]["IC"][0][1])] and res["vk"]["nPublic"] == 7
