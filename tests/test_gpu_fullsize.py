@@ -67,3 +67,24 @@ def test_pipelined_batch_equals_synchronous_proofs(log_m):
     assert key.prove_collect(t2) == batch[2]
     with pytest.raises(zkr_hip.ZkrError):
         key.prove_collect(t2)
+
+
+def test_websnark_buffer_path_at_2_16():
+    """The reference's own data flow at the size of the real tx circuit's neighbourhood (2^17): a
+    60 MB provingKeyBin in the binarify.ts layout through zkr_key_load_websnark, proof == the C oracle on the same
+    buffers, accepted by the native verifier of the matching setup."""
+    import coracle
+    import zkr_hip
+    log_m, p = 16, 73
+    pkb, wb = zkr_hip.synth_websnark(log_m, p, 0x5A4B0001, 0x5A4B00FF)
+    key = zkr_hip.ProvingKey.load_websnark(pkb)
+    info = key.info()
+    assert info["domainSize"] == 1 << log_m and info["nPublic"] == p
+    rng = g.SplitMix64(1616)
+    r, s = rng.fr(), rng.fr()
+    proof = key.prove(wb, r, s)
+    assert proof == coracle.prove(pkb, wb, r, s)
+    key2, wb2, aux = zkr_hip.ProvingKey.synth(log_m, p, 0x5A4B0001, 0x5A4B00FF)
+    assert wb2 == wb and key2.prove(wb, r, s) == proof
+    pub = [int.from_bytes(wb[32 * i:32 * i + 32], "little") for i in range(1, p + 1)]
+    assert zkr_hip.verify(key2.synth_vk(aux), proof, pub)
