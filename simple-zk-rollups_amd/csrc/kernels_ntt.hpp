@@ -17,7 +17,7 @@
 
 namespace zkr {
 
-constexpr int NTT_THREADS = 256;
+constexpr int NTT_THREADS = 512;   // two butterflies per thread and stage; 256 and 1024 measured slower (1.13 / 1.07 vs 1.04 ms per calcH)
 constexpr int NTT_TILE_LOG = 11;   // 2048 elements = 64 KB of LDS per workgroup (2 workgroups / CU)
 constexpr int NTT_STRIDED_LOG = 9; // stages per strided pass
 constexpr int NTT_W_LOG = 2;       // 4 columns = 128 B contiguous per row in a strided pass
