@@ -8,8 +8,9 @@
 // Tower: Fq2 = Fq[u]/(u^2+1) (field.hpp), Fq6 = Fq2[v]/(v^3 - xi) with xi = 9 + u, Fq12 = Fq6[w]/(w^2 - v).
 // D-type twist: (x', y') -> (x' w^2, y' w^3).  A line through the twisted point T with Fq2-slope lam, evaluated at
 // P = (xP, yP) in G1, is  yP + (-lam xP) w + (lam xT - yT) w^3  =  ((yP, 0, 0), (-lam xP, lam xT - yT, 0)).
-// Affine Miller loop over 6x+2 with the two Frobenius correction steps, final exponentiation by plain
-// square-and-multiply -- the same route as the checker in oracle/bn254.py, kept simple on purpose.
+// Affine Miller loops over 6x+2 (all pairs in lockstep, one shared inversion per step) with the two Frobenius
+// correction steps, final exponentiation by plain square-and-multiply -- the same mathematics as the checker in
+// oracle/bn254.py, kept simple on purpose.
 #pragma once
 #include "curve.hpp"
 
@@ -119,38 +120,56 @@ static inline Fq12 line(const G2Affine &t, const Fq2 &lam, const G1Affine &p) {
   Fq6 c1{mul_fq(lam, neg(p.x)), sub(mul(lam, t.x), t.y), Fq2::zero()};
   return Fq12{c0, c1};
 }
-static inline Fq12 dbl_step(G2Affine &t, const G1Affine &p) {
-  Fq2 xx = sqr(t.x);
-  Fq2 lam = mul(add(dbl(xx), xx), inv(dbl(t.y)));
-  Fq12 l = line(t, lam, p);
-  Fq2 x3 = sub(sqr(lam), dbl(t.x));
-  Fq2 y3 = sub(mul(lam, sub(t.x, x3)), t.y);
-  t = G2Affine{x3, y3};
-  return l;
+// One step of n Miller loops in lockstep: the n slope denominators share ONE field inversion (Montgomery's trick),
+// which is where an affine Miller loop spends most of its time.
+constexpr int MAX_PAIRS = 8;
+static inline void batch_inv(Fq2 *d, int n) {
+  Fq2 pre[MAX_PAIRS];
+  Fq2 run = Fq2::one();
+  for (int i = 0; i < n; i++) { pre[i] = run; run = mul(run, d[i]); }
+  Fq2 iv = inv(run);
+  for (int i = n - 1; i >= 0; i--) { Fq2 di = mul(iv, pre[i]); iv = mul(iv, d[i]); d[i] = di; }
 }
-static inline Fq12 add_step(G2Affine &t, const G2Affine &s, const G1Affine &p) {
-  Fq2 lam = mul(sub(s.y, t.y), inv(sub(s.x, t.x)));
-  Fq12 l = line(t, lam, p);
-  Fq2 x3 = sub(sub(sqr(lam), t.x), s.x);
-  Fq2 y3 = sub(mul(lam, sub(t.x, x3)), t.y);
-  t = G2Affine{x3, y3};
-  return l;
+// doubling (s == nullptr) or addition of s[i]: t[i] <- step, f <- f * line_i for every live pair
+static inline void multi_step(G2Affine *t, const G2Affine *s, const G1Affine *p, const bool *live, int n, Fq12 &f) {
+  Fq2 num[MAX_PAIRS], den[MAX_PAIRS];
+  int idx[MAX_PAIRS], m = 0;
+  for (int i = 0; i < n; i++) {
+    if (!live[i]) continue;
+    if (s) { num[m] = sub(s[i].y, t[i].y); den[m] = sub(s[i].x, t[i].x); }
+    else { Fq2 xx = sqr(t[i].x); num[m] = add(dbl(xx), xx); den[m] = dbl(t[i].y); }
+    idx[m++] = i;
+  }
+  batch_inv(den, m);
+  for (int k = 0; k < m; k++) {
+    const int i = idx[k];
+    Fq2 lam = mul(num[k], den[k]);
+    f = mul(f, line(t[i], lam, p[i]));
+    Fq2 x3 = sub(sub(sqr(lam), t[i].x), s ? s[i].x : t[i].x);
+    Fq2 y3 = sub(mul(lam, sub(t[i].x, x3)), t[i].y);
+    t[i] = G2Affine{x3, y3};
+  }
 }
 
-// Miller function f_{6x+2,Q}(P) with the two Frobenius correction lines; 1 when either point is infinity
-static inline Fq12 miller_loop(const G2Affine &q, const G1Affine &p) {
-  if (q.is_inf() || p.is_inf()) return Fq12::one();
-  G2Affine t = q;
-  Fq12 f = Fq12::one();
-  for (int i = 63; i >= 0; i--) {  // bits below the leading one of the 65-bit loop count
-    f = mul(sqr(f), dbl_step(t, p));
-    if ((ATE_LOOP[i >> 5] >> (i & 31)) & 1) f = mul(f, add_step(t, q, p));
+// prod_i f_{6x+2,Q_i}(P_i) with the two Frobenius correction lines; pairs with a point at infinity contribute 1
+static inline Fq12 multi_miller_loop(const G1Affine *ps, const G2Affine *qs, int n) {
+  G2Affine t[MAX_PAIRS], q1[MAX_PAIRS], q2[MAX_PAIRS];
+  bool live[MAX_PAIRS];
+  for (int i = 0; i < n; i++) {
+    live[i] = !(qs[i].is_inf() || ps[i].is_inf());
+    t[i] = qs[i];
+    q1[i] = g2_frobenius(qs[i]);
+    q2[i] = g2_frobenius(q1[i]);
+    q2[i].y = neg(q2[i].y);
   }
-  G2Affine q1 = g2_frobenius(q);
-  G2Affine q2 = g2_frobenius(q1);
-  q2.y = neg(q2.y);
-  f = mul(f, add_step(t, q1, p));
-  f = mul(f, add_step(t, q2, p));
+  Fq12 f = Fq12::one();
+  for (int b = 63; b >= 0; b--) {  // bits below the leading one of the 65-bit loop count
+    f = sqr(f);
+    multi_step(t, nullptr, ps, live, n, f);
+    if ((ATE_LOOP[b >> 5] >> (b & 31)) & 1) multi_step(t, qs, ps, live, n, f);
+  }
+  multi_step(t, q1, ps, live, n, f);
+  multi_step(t, q2, ps, live, n, f);
   return f;
 }
 
@@ -162,9 +181,8 @@ static inline Fq12 final_exponentiation(const Fq12 &f0) {
 
 // prod_i e(P_i, Q_i) == 1  -- the bn256 pairing precompile's check (TxVerifier.sol:91-115)
 static inline bool pairing_product_is_one(const G1Affine *ps, const G2Affine *qs, int n) {
-  Fq12 f = Fq12::one();
-  for (int i = 0; i < n; i++) f = mul(f, miller_loop(qs[i], ps[i]));
-  return final_exponentiation(f) == Fq12::one();
+  if (n > MAX_PAIRS) return false;
+  return final_exponentiation(multi_miller_loop(ps, qs, n)) == Fq12::one();
 }
 
 }  // namespace pairing

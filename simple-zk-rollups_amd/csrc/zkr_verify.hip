@@ -5,6 +5,7 @@
 //     vk_x = IC_0 + sum_i input_i * IC_{i+1};   e(-A, B) e(alfa, beta) e(vk_x, gamma) e(C, delta) == 1.
 // SURVEY.md 8(a5) / 8(f-4).  No GPU involved (a few milliseconds of host time per proof).
 #include <string.h>
+#include <vector>
 #include "pairing.hpp"
 #include "zkr_internal.hpp"
 
@@ -58,15 +59,26 @@ extern "C" int zkr_verify(const void *vk_bin, size_t vk_len, const uint8_t proof
   G1Affine a, c;
   G2Affine b;
   if (!read_g1(proof, a) || !read_g2(proof + 64, b) || !read_g1(proof + 192, c)) return 0;
-  // vk_x = IC_0 + sum input_i IC_{i+1}; every input must be < r (TxVerifier.sol:265)
-  G1XYZZ vkx = to_xyzz(ic0);
+  // vk_x = IC_0 + sum input_i IC_{i+1}; every input must be < r (TxVerifier.sol:265).  Interleaved 4-bit windows
+  // (Straus): one shared chain of 252 doublings, one addition per input and window.
+  std::vector<G1XYZZ> tab(n_public * 15);  // tab[i * 15 + d - 1] = d * IC_{i+1}
   const uint8_t *pub = (const uint8_t *)public_std;
   for (size_t i = 0; i < n_public; i++) {
     if (!fr_lt_r(pub + 32 * i)) return 0;
     G1Affine ic;
     if (!read_g1(vk + fixed + 64 * (i + 1), ic)) { set_error("verifying key IC[%zu] is not on the curve", i + 1); return ZKR_ERR_BAD_KEY; }
-    vkx = add_full(vkx, scalar_mul(to_xyzz(ic), load_u256(pub + 32 * i)));
+    G1XYZZ base = to_xyzz(ic), cur = base;
+    for (int d = 0; d < 15; d++) { tab[i * 15 + d] = cur; cur = add_full(cur, base); }
   }
+  G1XYZZ acc = G1XYZZ::inf();
+  for (int w = 63; w >= 0; w--) {
+    if (w != 63) for (int k = 0; k < 4; k++) acc = dbl_xyzz(acc);
+    for (size_t i = 0; i < n_public; i++) {
+      unsigned d = (pub[32 * i + w / 2] >> ((w & 1) * 4)) & 15u;
+      if (d) acc = add_full(acc, tab[i * 15 + d - 1]);
+    }
+  }
+  G1XYZZ vkx = add_full(acc, to_xyzz(ic0));
   G1Affine ps[4] = {G1Affine{a.x, neg(a.y)}, alfa1, to_affine(vkx), c};
   G2Affine qs[4] = {b, beta2, gamma2, delta2};
   *valid = pairing::pairing_product_is_one(ps, qs, 4) ? 1 : 0;
