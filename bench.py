@@ -90,8 +90,8 @@ def cpu_baseline_js(sample_log_m, target_log_m):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--log-m", type=int, default=20)
     ap.add_argument("--cpu-sample-log-m", type=int, default=17)
     ap.add_argument("--shape", choices=["rollup", "dense"], default="rollup",
