@@ -211,10 +211,14 @@ def main():
         ms_total, launches = prof[st]
         avg_ms = ms_total / max(launches, 1)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-        traffic, traffic_src = None, None
+        traffic, traffic_src, proof_traffic = None, None, None
         try:  # HBM bytes per launch from the committed PMC passes (bench.py cannot collect PMCs itself)
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
-            if pmc["config"]["log_m"] == args.log_m:
+            if pmc["config"]["log_m"] == args.log_m and args.shape == "rollup":
+                # whole proof: every kernel of the proving path (not key build), per ingest_kernel launch = per proof
+                skip = ("precompute", "fixed_base", "twiddle", "gather", "fq_mul_bench", "rocclr_copy")
+                per_run = sum(v["hbm_bytes_per_launch"] * v["launches"] for k, v in pmc["kernels"].items() if not any(x in k for x in skip))
+                proof_traffic = per_run / pmc["kernels"]["ingest_kernel"]["launches"]
                 traffic = pmc["kernels"][dom.replace("<Fq>", "<Fq>")]["hbm_bytes_per_launch"]
                 traffic_src = "profiles/r1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 read correction)"
         except Exception:
@@ -246,6 +250,10 @@ def main():
             "key": {"arena_bytes": arena_bytes, "setup_s": setup_s, "bcast_s": bcast_s if world > 1 else None},
             "pcie_inclusive_proofs_per_s": pcie_rate,
             "proofs_verified": verified,
+            "hbm_whole_proof": None if proof_traffic is None else {
+                "bytes_per_proof": proof_traffic, "GBps_per_gpu": proof_traffic / (elapsed / args.steps) / 1e9,
+                "frac_of_peak": proof_traffic / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBPS,
+                "source": "sum over the proving kernels of profiles/r1_pmc_traffic.json (x2 read rule: an upper bound for the 64-byte gathers)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample_log_m, args.log_m)
