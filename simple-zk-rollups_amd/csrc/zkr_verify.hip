@@ -55,6 +55,10 @@ extern "C" int zkr_verify(const void *vk_bin, size_t vk_len, const uint8_t proof
     set_error("verifying key holds a point that is not on the curve");
     return ZKR_ERR_BAD_KEY;
   }
+  // the whole key is checked before the proof is looked at: a malformed key is an error, whatever the proof
+  std::vector<G1Affine> ics(n_public);
+  for (size_t i = 0; i < n_public; i++)
+    if (!read_g1(vk + fixed + 64 * (i + 1), ics[i])) { set_error("verifying key IC[%zu] is not on the curve", i + 1); return ZKR_ERR_BAD_KEY; }
   // proof points: off-curve or out-of-range coordinates simply do not verify
   G1Affine a, c;
   G2Affine b;
@@ -65,9 +69,7 @@ extern "C" int zkr_verify(const void *vk_bin, size_t vk_len, const uint8_t proof
   const uint8_t *pub = (const uint8_t *)public_std;
   for (size_t i = 0; i < n_public; i++) {
     if (!fr_lt_r(pub + 32 * i)) return 0;
-    G1Affine ic;
-    if (!read_g1(vk + fixed + 64 * (i + 1), ic)) { set_error("verifying key IC[%zu] is not on the curve", i + 1); return ZKR_ERR_BAD_KEY; }
-    G1XYZZ base = to_xyzz(ic), cur = base;
+    G1XYZZ base = to_xyzz(ics[i]), cur = base;
     for (int d = 0; d < 15; d++) { tab[i * 15 + d] = cur; cur = add_full(cur, base); }
   }
   G1XYZZ acc = G1XYZZ::inf();

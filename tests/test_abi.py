@@ -118,3 +118,29 @@ def test_native_verifier_agrees_with_oracle_pairing_check(small_case):
         zkr_hip.verify(vkb, pb, pub[:-1])                                       # wrong input count (TxVerifier.sol:261)
     with pytest.raises(zkr_hip.ZkrError):
         zkr_hip.verify(vkb[:-1], pb, pub)
+
+
+def test_native_verifier_accepts_the_reference_contracts_verifying_keys():
+    """Golden vectors of the reference: the verifying keys baked into contracts/contracts/TxVerifier.sol:176-257 and
+    WithdrawVerifier.sol (tests/golden/verifier_points.json; Solidity limb order [im, re]) are well-formed keys for
+    zkr_verify -- every G1 / G2 constant passes its curve check under the product's curve, twist and limb order --
+    and moving any coordinate off the curve is refused as a bad key.  (Their proving keys were never committed, so no
+    proof can be checked against them.)"""
+    import json
+    import zkr_hip
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "verifier_points.json")))
+    for name, c in fx["contracts"].items():
+        n = int(c["n_inputs"])
+        g2 = lambda k: ((int(c["g2"][k][0][1]), int(c["g2"][k][0][0])), (int(c["g2"][k][1][1]), int(c["g2"][k][1][0])))  # -> (re, im)
+        ic = [c["g1"][k] for k in c["g1"] if k != "alfa1"]
+        assert len(ic) == n + 1
+        vk = dict(vk_alfa_1=[int(v) for v in c["g1"]["alfa1"]], vk_beta_2=g2("beta2"), vk_gamma_2=g2("gamma2"), vk_delta_2=g2("delta2"),
+                  IC=[[int(x), int(y)] for x, y in ic])
+        vkb = zkr_hip.binarify_verifying_key(vk)
+        some_proof = (1).to_bytes(32, "little") + (2).to_bytes(32, "little") + bytes(192)   # pi_a = G1 generator, rest invalid
+        assert zkr_hip.verify(vkb, some_proof, [5] * n) is False          # key accepted, proof (of course) not
+        for off in (0, 64 + 32, 64 + 128, 64 + 3 * 128 + 4 + 64 * n):      # alfa1.x, beta2.x.im, gamma2.x.re, last IC x
+            bad = bytearray(vkb)
+            bad[off] ^= 1
+            with pytest.raises(zkr_hip.ZkrError):
+                zkr_hip.verify(bytes(bad), some_proof, [5] * n)
