@@ -96,7 +96,8 @@ struct ProofSlot {
   Fr *d_wraw = nullptr, *d_w = nullptr, *va = nullptr, *vb = nullptr, *ca = nullptr, *cb = nullptr, *d_h = nullptr;
   DigitLists dig_w, dig_h;  // digit records of w (shared by A, B1, B2, C) and of h
   MsmWorkspace ws[N_TABLES];
-  hipEvent_t ev_w = nullptr, ev_h = nullptr, ev_fin = nullptr;
+  hipEvent_t ev_w = nullptr, ev_h = nullptr;
+  hipEvent_t ev_red[N_TABLES] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // end of the proof's work on each reduction stream
   hipEvent_t ev_done[N_TABLES] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_sorted[N_TABLES] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   uint8_t rb[32], sb[32];  // blinding scalars of the proof in flight
@@ -115,7 +116,9 @@ struct zkr_key {
   zkr::ArenaHeader h;
   hipStream_t stream = nullptr;
   hipStream_t prep_stream = nullptr;               // digit records, digit sorts, calcH
-  hipStream_t red_stream[2] = {nullptr, nullptr};  // reduction chains of the G2 table / of the G1 tables (the same stream by default)
+  hipStream_t red_stream[zkr::N_TABLES] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // reduction chains: [0] the G2 table, the G1 tables
+                                                                                           // round-robin over [1..n_red)
+  int n_red = 1;
   zkr::ProofSlot slot[zkr::PROOF_SLOTS];
   int next_slot = 0;
   std::mutex mu;  // slot hand-out, the enqueue phase of a proof (so two host threads do not interleave launches), stage totals

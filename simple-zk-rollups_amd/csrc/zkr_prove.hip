@@ -326,15 +326,22 @@ static int prove_submit(zkr_key *k, ProofSlot &sl, const Fr *d_wsrc, const uint8
   //   s  : the five bucket accumulations back to back, B2 first (its reduction chain is the longest), B1 on the
   //        same sort (h.share_b), then A, C, H, each waiting only for its table's sort.  Every accumulation
   //        saturates the VALUs on its own;
-  //   rx : oversized-bucket and reduction chain of the G2 table;  ry : those of the four G1 tables (ry == rx
-  //        unless ZKR_FOUR_STREAMS).  Few long-running wavefronts at raised wave priority that run under the
-  //        following accumulations; the oversized buckets need only the sort and run beside the accumulation.
+  //   red[0] : oversized-bucket and reduction chain of the G2 table;  red[1] : those of the four G1 tables (more
+  //        streams with ZKR_RED_STREAMS; one stream for all five chains is the bottleneck with two proofs in
+  //        flight: ~6 ms of serialised launches per proof).  Few long-running wavefronts at raised wave priority
+  //        that run under the following accumulations; the oversized buckets need only the sort and run beside
+  //        the accumulation.
   // With two proofs in flight (zkr_prove_submit) the preparation of proof i+1 runs under the accumulations of
   // proof i, whose reduction tail and host assembly are covered by the accumulations of proof i+1.
   static const bool serial = getenv("ZKR_SERIAL") != nullptr;  // profiling aid: one stream, isolated kernel durations
   hipStream_t s = k->stream;
   hipStream_t sp = serial ? s : k->prep_stream;
-  hipStream_t rx = serial ? s : k->red_stream[0], ry = serial ? s : k->red_stream[1];
+  int g1_next = 0;
+  auto red_of = [&](int t) -> hipStream_t {  // G2 chain on [0]; G1 chains round-robin over the others
+    if (serial) return s;
+    if (t == T_B2 || k->n_red == 1) return k->red_stream[0];
+    return k->red_stream[1 + (g1_next++ % (k->n_red - 1))];
+  };
   int rc;
   ZKR_HIP_CHECK(hipEventRecord(sl.ev_w, caller));  // the witness is in place
   ZKR_HIP_CHECK(hipStreamWaitEvent(sp, sl.ev_w, 0));
@@ -385,23 +392,19 @@ static int prove_submit(zkr_key *k, ProofSlot &sl, const Fr *d_wsrc, const uint8
   if ((rc = msm_digits_enqueue(pf, sp, sl.d_h, h.m, k->plan[T_H], sl.dig_h))) return rc;
   if ((rc = sort_table(T_H))) return rc;
   // accumulations + reduction chains
-  if ((rc = accum_table(T_B2, rx))) return rc;
-  if ((rc = accum_table(T_B1, ry))) return rc;
-  if ((rc = accum_table(T_A, ry))) return rc;
-  if ((rc = accum_table(T_C, ry))) return rc;
-  if ((rc = accum_table(T_H, ry))) return rc;
-  // completion = both reduction streams done.  The accumulation stream `s` is NOT made to wait for them, so the
-  // next proof's accumulations can follow directly; callers get the proof through prove_collect.
+  const int order[N_TABLES] = {T_B2, T_B1, T_A, T_C, T_H};
+  hipStream_t last = s;
+  for (int t : order) {
+    last = red_of(t);
+    if ((rc = accum_table(t, last))) return rc;
+  }
+  // completion = every reduction stream done (prove_collect waits for the events on the host).  No stream is made
+  // to wait for another, so nothing of the next proof queues behind this one's tail.
+  prof_end(pf, last, tot);
   if (!serial) {
-    if (ry != rx) {
-      ZKR_HIP_CHECK(hipEventRecord(sl.ev_h, ry));
-      ZKR_HIP_CHECK(hipStreamWaitEvent(rx, sl.ev_h, 0));
-    }
-    prof_end(pf, rx, tot);
-    ZKR_HIP_CHECK(hipEventRecord(sl.ev_fin, rx));
+    for (int j = 0; j < k->n_red; j++) ZKR_HIP_CHECK(hipEventRecord(sl.ev_red[j], k->red_stream[j]));
   } else {
-    prof_end(pf, s, tot);
-    ZKR_HIP_CHECK(hipEventRecord(sl.ev_fin, s));
+    ZKR_HIP_CHECK(hipEventRecord(sl.ev_red[0], s));
   }
   sl.busy = true;
   return 0;
@@ -420,7 +423,8 @@ static int prove_collect(zkr_key *k, ProofSlot &sl, uint8_t proof_out[256]) {
   } release{k, sl};
   ZKR_HIP_CHECK(hipSetDevice(k->device));
   const ArenaHeader &h = k->h;
-  ZKR_HIP_CHECK(hipEventSynchronize(sl.ev_fin));
+  static const bool serial_mode = getenv("ZKR_SERIAL") != nullptr;
+  for (int j = 0; j < (serial_mode ? 1 : k->n_red); j++) ZKR_HIP_CHECK(hipEventSynchronize(sl.ev_red[j]));
   if (k->prof_on) { std::lock_guard<std::mutex> lk(k->mu); prof_collect(k, sl); }
   const uint8_t *rb = sl.rb, *sb = sl.sb;
   G1XYZZ A = msm_finish<Fq>(h.npts[T_A], sl.ws[T_A]);
