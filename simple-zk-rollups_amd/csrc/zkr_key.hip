@@ -58,7 +58,9 @@ MsmPlan msm_plan(size_t n_scalars, size_t n, int c_fixed) {
   pl.K = (255 + c - 1) / c;
   pl.nbw = 1u << (c - 1);
   pl.nb = pl.nbw;
-  pl.glog = c - 1 < 3 ? c - 1 : 3;  // bucket reduction: groups of 8 buckets (kernels_msm.hpp msm_reduce1_kernel); 4 and 16 measured slower
+  int glog = 5;  // bucket reduction: groups of 32 buckets (kernels_msm.hpp msm_reduce1_kernel): 108 / 110 / 113 / 105 proofs/s at 8 / 16 / 32 / 64
+  if (const char *e = getenv("ZKR_MSM_GLOG")) { int v = atoi(e); if (v >= 1 && v <= 6) glog = v; }
+  pl.glog = c - 1 < glog ? c - 1 : glog;
   uint64_t mean = (uint64_t)n * pl.K / pl.nbw + 1;
   pl.big_thresh = mean * 8 > 256 ? (uint32_t)(mean * 8) : 256;
   if (const char *e = getenv("ZKR_MSM_BIG")) { int v = atoi(e); if (v >= 1) pl.big_thresh = (uint32_t)v; }
