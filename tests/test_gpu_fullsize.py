@@ -88,3 +88,21 @@ def test_websnark_buffer_path_at_2_16():
     assert wb2 == wb and key2.prove(wb, r, s) == proof
     pub = [int.from_bytes(wb[32 * i:32 * i + 32], "little") for i in range(1, p + 1)]
     assert zkr_hip.verify(key2.synth_vk(aux), proof, pub)
+
+
+def test_fullsize_arena_replica_above_4_gib():
+    """The multi-GPU path's hand-off at its real size: the 4.5 GB arena (window tables included) viewed as a torch
+    tensor, copied (stands in for the RCCL broadcast) and adopted as a second key proves identically."""
+    import torch
+    import zkr_hip
+    from zkr_hip.batch import _tensor_from_ptr
+    key, wb, _ = zkr_hip.ProvingKey.synth(20, 73, 0x5A4B0001, 0x5A4B00FF, want_aux=False)
+    ptr, n = key.arena()
+    assert n > (1 << 32)
+    view = _tensor_from_ptr(ptr, n, 0)
+    replica = view.clone()
+    torch.cuda.synchronize()
+    assert replica.numel() == n and bool((replica[-4096:] == view[-4096:]).all().item())
+    key2 = zkr_hip.ProvingKey.adopt_arena(replica.data_ptr(), n, 0, keepalive=replica)
+    assert key2.info() == key.info() and key2.windows() == key.windows()
+    assert key2.prove(wb, 5, 7) == key.prove(wb, 5, 7)
