@@ -305,3 +305,28 @@ def test_setup_of_an_r1cs_on_the_gpu_matches_oracle_setup(small_case):
     assert not zkr_hip.verify(vk2, p2, bad)
     with pytest.raises(zkr_hip.ZkrError):
         zkr_hip.ProvingKey.setup_r1cs(r1cs[:-3])
+
+
+@pytest.mark.parametrize("name", ["synth_m5.json", "synth_m7.json", "synth_m10.json"])
+def test_hip_path_reproduces_committed_golden_fixtures(name):
+    """The committed fixtures (tests/golden/, written by make_golden.py from the oracle) through the product only:
+    generator + device setup give the fixture's key and witness bytes, calcH its h, the prover its proof bytes, the
+    facade its solidityProof."""
+    import hashlib
+    import json
+    import os
+    import zkr_hip
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name)))
+    pkb, wb = zkr_hip.synth_websnark(int(fx["log_m"]), int(fx["n_public"]), int(fx["circuit_seed"]), int(fx["toxic_seed"]))
+    sha = lambda b: hashlib.sha256(b).hexdigest()
+    assert (sha(pkb), len(pkb), sha(wb)) == (fx["pk_bin_sha256"], int(fx["pk_bin_len"]), fx["witness_bin_sha256"])
+    key = zkr_hip.ProvingKey.load_websnark(pkb)
+    h = key.calc_h(wb)
+    assert sha(h) == fx["h_sha256"]
+    assert [str(int.from_bytes(h[32 * i:32 * i + 32], "little")) for i in range(4)] == list(fx["h_first4"])
+    proof = key.prove(wb, int(fx["r"]), int(fx["s"]))
+    assert proof.hex() == fx["proof_bytes_hex"]
+    pj = zkr_hip.proof_json_from_bytes(proof)
+    assert pj == fx["proof"]
+    pub = [int.from_bytes(wb[32 * i:32 * i + 32], "little") for i in range(1, int(fx["n_public"]) + 1)]
+    assert zkr_hip.solidity_proof(pj, pub) == fx["solidity_proof"]
