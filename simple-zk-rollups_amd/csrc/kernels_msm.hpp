@@ -394,10 +394,14 @@ static __global__ __launch_bounds__(SCAN_THREADS) void msm_order_kernel(const ui
 // bucket accumulation: thread per bucket, buckets taken in `order` (fullest first): the 64 lanes of a
 // wavefront get buckets of (almost) equal occupancy, so no lane idles while another finishes, and the long
 // buckets start first.  The next entry and its point are fetched while the current addition runs.
+#ifndef ZKR_ACC_THREADS
+#define ZKR_ACC_THREADS 256
+#endif
+constexpr int ACC_THREADS = ZKR_ACC_THREADS;
 template <class F, int MINW, bool PREFETCH = true>
-static __global__ __launch_bounds__(MSM_THREADS) __attribute__((amdgpu_waves_per_eu(MINW, MINW))) void msm_accum_kernel(const Affine<F> *points, const uint32_t *offsets, const uint32_t *entries,
+static __global__ __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per_eu(MINW, MINW))) void msm_accum_kernel(const Affine<F> *points, const uint32_t *offsets, const uint32_t *entries,
                                                                      uint32_t nb, const uint32_t *counts, const uint32_t *order, XYZZ<F> *buckets) {
-  const uint32_t t = blockIdx.x * MSM_THREADS + threadIdx.x;
+  const uint32_t t = blockIdx.x * ACC_THREADS + threadIdx.x;
   if (t >= nb) return;
   const uint32_t b = order[t];
   if (counts[b] == BIG_MARK) return;  // msm_big_kernel owns it

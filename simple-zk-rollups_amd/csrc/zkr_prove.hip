@@ -213,8 +213,8 @@ static int msm_accum_enqueue(Prof pf, hipStream_t s, const Affine<F> *pts, uint3
   // (115 G Fq-mul/s isolated vs 112 at 3 and 103 at 4; 92 vs 88 proofs/s) and G2; ZKR_ACC_W_G1 / ZKR_ACC_W_G2 override for experiments
   static const char *acc_env = getenv(sizeof(F) == 32 ? "ZKR_ACC_W_G1" : "ZKR_ACC_W_G2");
   static const int acc_w = acc_env ? atoi(acc_env) : MsmCfg<F>::ACC_W;
-  const unsigned grid = (pl.nb + MSM_THREADS - 1) / MSM_THREADS;
-#define ZKR_ACC_LAUNCH(W) msm_accum_kernel<F, W, MsmCfg<F>::ACC_PREFETCH><<<grid, MSM_THREADS, 0, s>>>(pts, srt.offsets, srt.entries, pl.nb, srt.counts, srt.order, (XYZZ<F> *)ws.buckets)
+  const unsigned grid = (pl.nb + ACC_THREADS - 1) / ACC_THREADS;
+#define ZKR_ACC_LAUNCH(W) msm_accum_kernel<F, W, MsmCfg<F>::ACC_PREFETCH><<<grid, ACC_THREADS, 0, s>>>(pts, srt.offsets, srt.entries, pl.nb, srt.counts, srt.order, (XYZZ<F> *)ws.buckets)
   switch (acc_w) {
     case 1: ZKR_ACC_LAUNCH(1); break;
     case 3: ZKR_ACC_LAUNCH(3); break;

@@ -3,7 +3,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "csrc", "libzkr_hip.so"))
+LIB_PATH = os.environ.get("ZKR_HIP_LIB") or os.path.normpath(os.path.join(_HERE, "..", "..", "csrc", "libzkr_hip.so"))  # same override as index.js
 PROOF_BYTES = 256
 STAGES = ("ingest", "spmv", "ntt", "msm_sort", "msm_accum_g1", "msm_accum_g2", "msm_big", "msm_reduce", "total")
 _lib = None
