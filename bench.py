@@ -227,7 +227,9 @@ def main():
                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                     "avg_launch_ms": avg_ms, "launches": launches,
                     "algorithmic_bytes_per_launch": bytes_per_launch,
-                    "note": "Pippenger bucket accumulation is integer-VALU bound (v_mad_u64_u32), not HBM bound; see valu"}
+                    "note": "Pippenger bucket accumulation is integer-VALU bound (v_mad_u64_u32), not HBM bound; see valu. traffic > algorithmic bytes by design: "
+                            "the kernel gathers one precomputed 64-byte multiple per window (13 per point, 832 B) instead of re-deriving it, "
+                            "plus the 4-byte entries; the PMC figure applies the x2 read rule, an upper bound for 64-byte gathers"}
         try:
             peak_gmul = zkr_hip.bench_fq_mul(local)
             gm = fqmul_per_launch / (avg_ms * 1e-3) / 1e9
