@@ -260,7 +260,8 @@ def main():
                        "proofs_in_flight": 1 if args.no_pipeline else 2},
             "roofline": roofline,
             "stage_ms_per_proof": per_proof_ms,
-            "key": {"arena_bytes": arena_bytes, "setup_s": setup_s, "bcast_s": bcast_s if world > 1 else None},
+            "key": {"arena_bytes": arena_bytes, "setup_s": setup_s, "bcast_s": bcast_s if world > 1 else None,
+                    "bcast_GBps": (arena_bytes / bcast_s / 1e9) if world > 1 and bcast_s > 0 else None},  # one RCCL broadcast over xGMI (153 GB/s per link)
             "pcie_inclusive_proofs_per_s": pcie_rate,
             "proofs_verified": verified,
             "hbm_whole_proof": None if proof_traffic is None else {
