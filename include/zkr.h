@@ -33,7 +33,8 @@ typedef enum {
   ZKR_ERR_BAD_WITNESS = -3, /* witness length != nVars * 32 */
   ZKR_ERR_HIP = -4,         /* HIP runtime failure during a call */
   ZKR_ERR_ARG = -5,         /* null pointer / out-of-range argument */
-  ZKR_ERR_DEGENERATE = -6   /* a proof element is the point at infinity (cannot be serialised) */
+  ZKR_ERR_DEGENERATE = -6,  /* a proof element is the point at infinity (cannot be serialised) */
+  ZKR_ERR_UNSATISFIED = -7  /* circuit inputs violate a constraint (where Circuit.calculateWitness throws) */
 } zkr_status;
 
 typedef struct zkr_key zkr_key; /* device-resident proving key (one contiguous HBM arena + workspace) */
@@ -161,6 +162,31 @@ int zkr_setup_r1cs(const void *r1cs_bin, size_t r1cs_len, const uint8_t *toxic16
  * configs[4]: every row is (4 random signals) x (4 random signals) = new signal; no infinity points in any query). */
 int zkr_synth_set_shape(unsigned shape);
 void zkr_free(void *p);
+
+/* ---- the reference's rollup circuit without circom / snarkjs (host only) ---- */
+/* Witness-side crypto of operator/src/utils/crypto.ts.  Field elements are 32 B little-endian, standard form.
+ * zkr_mimcsponge_multihash = multiHash (crypto.ts:28-30; MiMCSponge-220, key 0, one output; operands taken mod r);
+ * zkr_babyjub_pubkey = genPublicKey (crypto.ts:78-84, including formatPrivKeyForBabyJub :58-76), pub = x | y;
+ * zkr_eddsa_sign = sign (crypto.ts:143-168) over n message elements, sig = R8x | R8y | S;
+ * zkr_eddsa_verify = verify (crypto.ts:170-177), *valid = 0 / 1. */
+int zkr_mimcsponge_multihash(const uint8_t *in, size_t n, uint8_t out[32]);
+int zkr_babyjub_pubkey(const uint8_t priv[32], uint8_t pub[64]);
+int zkr_eddsa_sign(const uint8_t priv[32], const uint8_t *msg, size_t n, uint8_t sig[96]);
+int zkr_eddsa_verify(const uint8_t *msg, size_t n, const uint8_t sig[96], const uint8_t pub[64], int *valid);
+/* BatchProcessTx(batch, depth) (prover/circuits/batchprocesstx.circom:3-75; `tx.circom` = (2, 6)) as a rank-1
+ * constraint system in the r1cs_bin layout of zkr_setup_r1cs, and its witness builder -- the counterpart of
+ * `compiler(tx.circom)` + `Circuit.calculateWitness` (operator/src/snarks/common.ts:12-17).  Public signals keep
+ * circom's order: newBalanceTreeRoot, then balanceTreeRoot[batch], txData[batch][8], txSenderPublicKey[batch][2],
+ * txSenderBalance[batch], txSenderNonce[batch], txSenderPathElements[batch][depth], txRecipientPublicKey[batch][2],
+ * txRecipientBalance[batch], txRecipientNonce[batch], txRecipientPathElements[batch][depth],
+ * intermediateBalanceTreeRoot[batch], intermediateBalanceTreePathElements[batch][depth]  (73 for (2, 6)).
+ * zkr_rollup_witness takes the n_public - 1 inputs in that order (32 B each) and returns the full witness
+ * (nVars x 32 B, the buffer binarifyWitness would produce; free with zkr_free); inputs that violate the circuit fail
+ * with ZKR_ERR_UNSATISFIED and a message naming the first violated statement.  The constraint system is this build's
+ * own formulation of the circuit (see csrc/rollup.cpp): its keys come from zkr_setup_r1cs, not from a circom build. */
+int zkr_rollup_info(uint32_t batch, uint32_t depth, uint32_t *n_vars, uint32_t *n_public, uint32_t *n_constraints);
+int zkr_rollup_r1cs(uint32_t batch, uint32_t depth, void **r1cs_bin, size_t *r1cs_len);
+int zkr_rollup_witness(uint32_t batch, uint32_t depth, const uint8_t *inputs, size_t n_inputs, void **witness_bin, size_t *witness_len);
 
 /* Integer-ALU microbenchmark: sustained Fq Montgomery multiplications per second on `device`
  * (each = 136 32x32 multiply-adds); used for the secondary (VALU) roofline. */

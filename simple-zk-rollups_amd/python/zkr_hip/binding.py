@@ -62,6 +62,13 @@ def lib():
     L.zkr_free.argtypes = [vp]
     L.zkr_free.restype = None
     L.zkr_bench_fq_mul.argtypes = [i, c.POINTER(c.c_double)]
+    L.zkr_mimcsponge_multihash.argtypes = [u8p, sz, u8p]
+    L.zkr_babyjub_pubkey.argtypes = [u8p, u8p]
+    L.zkr_eddsa_sign.argtypes = [u8p, u8p, sz, u8p]
+    L.zkr_eddsa_verify.argtypes = [u8p, sz, u8p, u8p, c.POINTER(i)]
+    L.zkr_rollup_info.argtypes = [c.c_uint32, c.c_uint32, c.POINTER(c.c_uint32), c.POINTER(c.c_uint32), c.POINTER(c.c_uint32)]
+    L.zkr_rollup_r1cs.argtypes = [c.c_uint32, c.c_uint32, c.POINTER(vp), c.POINTER(sz)]
+    L.zkr_rollup_witness.argtypes = [c.c_uint32, c.c_uint32, u8p, sz, c.POINTER(vp), c.POINTER(sz)]
     _lib = L
     return L
 

@@ -1,0 +1,108 @@
+"""Host side of the reference's rollup circuit without circom / snarkjs, over the C ABI.
+
+Mirrors /root/reference/operator/src/utils/crypto.ts (multiHash :28-30, genPublicKey :78-84, sign :143-168,
+verify :170-177) and the `compiler(tx.circom)` + `Circuit.calculateWitness` steps of
+operator/src/snarks/common.ts:12-21 for `BatchProcessTx(batch, depth)`
+(prover/circuits/batchprocesstx.circom:3-75).  All arithmetic is native (csrc/rollup.cpp).
+"""
+import ctypes
+
+from .binding import ZkrError, _check, _take, lib
+
+SNARK_FIELD_SIZE = 21888242871839275222246405745257275088548364400416034343698204186575808495617  # crypto.ts:16-18
+TX_INPUT_FIELDS = ("balanceTreeRoot", "txData", "txSenderPublicKey", "txSenderBalance", "txSenderNonce", "txSenderPathElements",
+                   "txRecipientPublicKey", "txRecipientBalance", "txRecipientNonce", "txRecipientPathElements",
+                   "intermediateBalanceTreeRoot", "intermediateBalanceTreePathElements")   # batchprocesstx.circom:13-36
+
+
+def _le(v):
+    return int(v).to_bytes(32, "little")
+
+
+def _ints(b):
+    return [int.from_bytes(b[i:i + 32], "little") for i in range(0, len(b), 32)]
+
+
+def multi_hash(values) -> int:
+    """multiHash(d) (crypto.ts:28-30); operands of any size are taken mod r as the reference's field operations do."""
+    buf = b"".join(_le(int(v) % (1 << 256)) for v in values)
+    assert all(0 <= int(v) < (1 << 256) for v in values)
+    out = ctypes.create_string_buffer(32)
+    _check(lib().zkr_mimcsponge_multihash(buf, len(values), out))
+    return int.from_bytes(out.raw, "little")
+
+
+def hash_left_right(left, right) -> int:   # crypto.ts:36-38
+    return multi_hash([left, right])
+
+
+def gen_public_key(priv):
+    """genPublicKey(privKey) (crypto.ts:78-84) -> (x, y)."""
+    out = ctypes.create_string_buffer(64)
+    _check(lib().zkr_babyjub_pubkey(_le(priv), out))
+    return tuple(_ints(out.raw))
+
+
+def sign(priv, msg):
+    """sign(prv, msg) (crypto.ts:143-168) -> {"R8": (x, y), "S": s}."""
+    buf = b"".join(_le(v) for v in msg)
+    out = ctypes.create_string_buffer(96)
+    _check(lib().zkr_eddsa_sign(_le(priv), buf, len(msg), out))
+    v = _ints(out.raw)
+    return {"R8": (v[0], v[1]), "S": v[2]}
+
+
+def verify(msg, sig, pub) -> bool:
+    """verify(msg, sig, pubKey) (crypto.ts:170-177)."""
+    buf = b"".join(_le(v) for v in msg)
+    sb = _le(sig["R8"][0]) + _le(sig["R8"][1]) + _le(sig["S"])
+    pb = _le(pub[0]) + _le(pub[1])
+    ok = ctypes.c_int()
+    _check(lib().zkr_eddsa_verify(buf, len(msg), sb,
+                                  pb, ctypes.byref(ok)))
+    return bool(ok.value)
+
+
+class RollupCircuit:
+    """BatchProcessTx(batch, depth): what `new Circuit(await compiler("tx.circom"))` is to the reference
+    (common.ts:12-15).  `r1cs()` feeds ProvingKey.setup_r1cs; `calculate_witness(inputs)` returns the witness as
+    binarifyWitness would lay it out (nVars x 32 B) and raises ZkrError(-7) where calculateWitness would throw."""
+
+    def __init__(self, batch=2, depth=6):   # tx.circom:3
+        self.batch, self.depth = batch, depth
+        nv, npub, nc = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32()
+        _check(lib().zkr_rollup_info(batch, depth, ctypes.byref(nv), ctypes.byref(npub), ctypes.byref(nc)))
+        self.n_vars, self.n_public, self.n_constraints = nv.value, npub.value, nc.value
+
+    def r1cs(self) -> bytes:
+        p, n = ctypes.c_void_p(), ctypes.c_size_t()
+        _check(lib().zkr_rollup_r1cs(self.batch, self.depth, ctypes.byref(p), ctypes.byref(n)))
+        return _take(p, n.value)
+
+    def flatten_inputs(self, inputs):
+        """The circuitInputs object of the reference (one entry per input signal of BatchProcessTx, arrays over the
+        batch; batchprocesstx.test.ts builds it) -> the flat list in signal order."""
+        flat = []
+
+        def walk(v):
+            if isinstance(v, (list, tuple)):
+                for x in v:
+                    walk(x)
+            else:
+                flat.append(int(v) % SNARK_FIELD_SIZE)
+        for f in TX_INPUT_FIELDS:
+            walk(inputs[f])
+        if len(flat) != self.n_public - 1:
+            raise ZkrError(-5, "circuit inputs have %d values, BatchProcessTx(%d, %d) takes %d" % (len(flat), self.batch, self.depth, self.n_public - 1))
+        return flat
+
+    def calculate_witness(self, inputs) -> bytes:
+        flat = self.flatten_inputs(inputs) if isinstance(inputs, dict) else [int(v) for v in inputs]
+        buf = b"".join(_le(v) for v in flat)
+        p, n = ctypes.c_void_p(), ctypes.c_size_t()
+        _check(lib().zkr_rollup_witness(self.batch, self.depth, buf, len(flat), ctypes.byref(p), ctypes.byref(n)))
+        return _take(p, n.value)
+
+    def public_signals(self, witness_bin: bytes):
+        """witness.slice(1, nPubInputs + nOutputs + 1) (common.ts:18-21)."""
+        return _ints(witness_bin[32:32 * (self.n_public + 1)])

@@ -1,0 +1,64 @@
+"""GPU: SURVEY 8(f-3) end to end -- the reference's tx circuit (tx.circom:3 = BatchProcessTx(2, 6)) set up, proved and
+verified without circom / snarkjs: native constraint system -> zkr_setup_r1cs -> native witness -> HIP prover ->
+native verifier, with the proof bit-identical to the oracle's closed form for fixed (toxic waste, r, s)."""
+import pytest
+
+import groth16 as g
+import rollup as o
+from test_rollup import as_inputs, ints, parse_r1cs, scenario
+
+pytestmark = pytest.mark.gpu
+
+
+def _circ_dict(c, cons):
+    return dict(nVars=c.n_vars, nPublic=c.n_public, nConstraints=c.n_constraints, domainSize=g.domain_size(c.n_constraints, c.n_public), rows=cons)
+
+
+def test_tx_circuit_proof_matches_closed_form_and_verifies():
+    import zkr_hip
+    from zkr_hip import rollup as n
+    c = n.RollupCircuit()                                   # tx.circom:3
+    r1cs = c.r1cs()
+    tox = g.toxic_from_seed(0x5A4B00F3)
+    key, vk_bin = zkr_hip.ProvingKey.setup_r1cs(r1cs, toxic=[tox[k] for k in ("t", "alfa", "beta", "gamma", "delta")])
+    info = key.info()
+    assert info["domainSize"] == 1 << 17 and info["nVars"] == c.n_vars and info["nPublic"] == 73
+    txs, tree, _ = scenario(2, 6, 41, n_accounts=5)
+    wb = c.calculate_witness(as_inputs(txs))
+    pub = c.public_signals(wb)
+    assert pub == o.batch_public_signals(txs) and pub[0] == tree.root
+    rng = g.SplitMix64(99)
+    r, s = rng.fr(), rng.fr()
+    proof = key.prove(wb, r, s)
+    # the operator's checks (operator/src/snarks/common.ts:30-38, withdrawverifier.test.ts:27-37,56-65)
+    assert zkr_hip.verify(vk_bin, proof, pub) is True
+    bad = list(pub)
+    bad[0] = (bad[0] + 1) % o.R                             # another new root
+    assert zkr_hip.verify(vk_bin, proof, bad) is False
+    sp = zkr_hip.solidity_proof(zkr_hip.proof_json_from_bytes(proof), pub)
+    assert sp["inputs"] == [str(v) for v in pub] and len(sp["inputs"]) == 73      # TxVerifier.sol:281 uint[73]
+    # bit-exact: the closed form from the toxic waste over the same constraint system and witness
+    _, _, cons = parse_r1cs(r1cs)
+    w = ints(wb)
+    assert proof == g.proof_bytes(g.proof_from_toxic(_circ_dict(c, cons), tox, w, r, s))
+    # a second batch on the same key (the operator proves batch after batch against one key)
+    txs2, tree2, _ = scenario(2, 6, 42, self_send=True, n_accounts=3)
+    wb2 = c.calculate_witness(as_inputs(txs2))
+    p2 = key.prove(wb2)
+    assert zkr_hip.verify(vk_bin, p2, c.public_signals(wb2)) and not zkr_hip.verify(vk_bin, p2, pub)
+
+
+def test_batch_of_four_depth_five_like_the_reference_test():
+    """prover/__tests__/batchprocesstx.test.ts:247-253 runs BatchProcessTx(4, 5); here with a proof on top
+    (fresh toxic waste from the OS CSPRNG)."""
+    import zkr_hip
+    from zkr_hip import rollup as n
+    c = n.RollupCircuit(4, 5)
+    key, vk_bin = zkr_hip.ProvingKey.setup_r1cs(c.r1cs())
+    txs, tree, _ = scenario(4, 5, 43, n_accounts=6)
+    wb = c.calculate_witness(as_inputs(txs))
+    pub = c.public_signals(wb)
+    assert pub[0] == tree.root
+    proof = key.prove(wb)
+    assert zkr_hip.verify(vk_bin, proof, pub)
+    assert not zkr_hip.verify(vk_bin, proof, [pub[0]] + [pub[2], pub[1]] + pub[3:])

@@ -1,0 +1,261 @@
+"""CPU: SURVEY 8(f-3) -- the reference's rollup circuit without circom / snarkjs.
+
+Oracle (oracle/rollup.py) pinned against the reference's own vectors, the native host crypto (csrc/rollup.cpp through
+the C ABI) against the oracle, and the native constraint system + witness builder against the equalities the
+reference's circuit tests assert (prover/__tests__/hasher.test.ts:24-26,45-47, eddsa.test.ts:22-37,
+merkletree.test.ts:88,118-129, processtx.test.ts:132-138,240-246, batchprocesstx.test.ts:247-253)."""
+import json
+import os
+import random
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _kat():
+    return json.load(open(os.path.join(ROOT, "tests", "golden", "rollup_kat.json")))
+
+
+def parse_r1cs(b):
+    nv, npub, nc = (int.from_bytes(b[i:i + 4], "little") for i in (0, 4, 8))
+    off, cons = 12, []
+    for _ in range(nc):
+        row = []
+        for _s in range(3):
+            k = int.from_bytes(b[off:off + 4], "little")
+            off += 4
+            row.append([(int.from_bytes(b[off + 36 * e:off + 36 * e + 4], "little"), int.from_bytes(b[off + 36 * e + 4:off + 36 * e + 36], "little")) for e in range(k)])
+            off += 36 * k
+        cons.append(row)
+    assert off == len(b)
+    return nv, npub, cons
+
+
+def first_violated(cons, w, R):
+    ev = lambda lc: sum(c * w[s] for s, c in lc) % R
+    for i, (a, b, c) in enumerate(cons):
+        if ev(a) * ev(b) % R != ev(c):
+            return i
+    return -1
+
+
+def scenario(batch, depth, seed, self_send=False, n_accounts=4):
+    """Accounts + `batch` chained transactions against an oracle balance tree: the flow of processtx.test.ts:24-130."""
+    import rollup as o
+    rnd = random.Random(seed)
+    privs = [rnd.randrange(o.R) for _ in range(n_accounts)]
+    accounts = {i: [*o.gen_public_key(privs[i]), 50 * 10 ** 18 + i, i] for i in range(n_accounts)}
+    tree = o.Tree(depth)
+    for i in range(n_accounts):
+        tree.update(i, o.leaf_hash(accounts[i][:2], accounts[i][2], accounts[i][3]))
+    txs = []
+    for t in range(batch):
+        f = rnd.randrange(n_accounts)
+        to = f if self_send else (f + 1 + rnd.randrange(n_accounts - 1)) % n_accounts
+        txs.append(o.process_tx_inputs(tree, accounts, f, to, 10 ** 18 * (t + 1), 5 * 10 ** 17, privs[f]))
+    return txs, tree, privs
+
+
+def as_inputs(txs):
+    from zkr_hip import rollup as n
+    return {f: [t[f] for t in txs] for f in n.TX_INPUT_FIELDS}
+
+
+def ints(b):
+    return [int.from_bytes(b[i:i + 32], "little") for i in range(0, len(b), 32)]
+
+
+# ------------------------------------------------------------------ oracle vs the reference's own vectors
+def test_oracle_round_constants_are_the_deployed_contract_constants():
+    """CircomLib.json bytecode (generated MiMCSponge-220): PUSH32 #0 is r, then one unreduced constant per round 1..218."""
+    import rollup as o
+    push = [int(x, 16) for x in _kat()["mimcsponge_push32"]]
+    cts = o.mimc_constants()
+    assert push[0] == o.R and len(push) == 219
+    assert [p % o.R for p in push[1:]] == cts[1:-1] and cts[0] == 0 and cts[-1] == 0
+
+
+def test_oracle_reproduces_the_reference_key_pairs():
+    """scripts/index.js:108-118: pins the hash, formatPrivKeyForBabyJub and BabyJub scalar multiplication end to end."""
+    import rollup as o
+    for kp in _kat()["keypairs"]:
+        assert o.gen_public_key(int(kp["priv"])) == tuple(int(v) for v in kp["pub"])
+        assert o.bj_on_curve(tuple(int(v) for v in kp["pub"]))
+    assert o.bj_on_curve(o.BASE8) and o.bj_mul(o.BASE8, o.SUBORDER) == (0, 1)
+    assert o.keccak256(b"").hex() == "c5d2460186f7233c927e7db2dcc703c0e500b653ca82273b7bfad8045d85a470"
+
+
+# ------------------------------------------------------------------ native host crypto vs oracle
+def test_native_hash_keys_and_signatures_match_the_oracle():
+    import rollup as o
+    from zkr_hip import rollup as n
+    rnd = random.Random(7)
+    for k in (1, 2, 3, 5, 8):
+        v = [rnd.randrange(o.R) for _ in range(k)]
+        assert n.multi_hash(v) == o.multi_hash(v)
+    assert n.multi_hash([32767]) == o.multi_hash([32767])                      # hasher.test.ts:15-26
+    assert n.hash_left_right(12345, 45678) == o.multi_hash([12345, 45678])     # hasher.test.ts:36-47
+    assert n.multi_hash([o.R + 5, (1 << 256) - 1]) == o.multi_hash([5, ((1 << 256) - 1) % o.R])   # operands mod r
+    for kp in _kat()["keypairs"]:
+        assert n.gen_public_key(int(kp["priv"])) == tuple(int(v) for v in kp["pub"])
+    for t in range(6):
+        priv = rnd.randrange(o.R) if t else 0
+        msg = [rnd.randrange(o.R) for _ in range(1 + t)]
+        so, sn = o.sign(priv, msg), n.sign(priv, msg)
+        assert (sn["R8"][0], sn["R8"][1], sn["S"]) == so
+        pub = n.gen_public_key(priv)
+        assert pub == o.gen_public_key(priv)
+        assert n.verify(msg, sn, pub) and o.verify(msg, so, pub)               # eddsa.test.ts:22-37
+        bad = list(msg)
+        bad[0] = (bad[0] + 1) % o.R
+        assert not n.verify(bad, sn, pub)
+        assert not n.verify(msg, {"R8": sn["R8"], "S": sn["S"] + o.SUBORDER}, pub)      # S >= subgroup order
+        assert not n.verify(msg, {"R8": (sn["R8"][0], sn["R8"][1] + 1), "S": sn["S"]}, pub)  # R8 off the curve
+        assert not n.verify(msg, sn, (pub[0], o.R))                                    # not a field element
+
+
+def test_native_crypto_rejects_bad_arguments():
+    import zkr_hip
+    from zkr_hip import rollup as n
+    with pytest.raises(zkr_hip.ZkrError):
+        n.gen_public_key(n.SNARK_FIELD_SIZE)        # crypto.ts:79 assert(privKey < SNARK_FIELD_SIZE)
+    with pytest.raises(zkr_hip.ZkrError):
+        n.sign(5, [n.SNARK_FIELD_SIZE])
+    with pytest.raises(zkr_hip.ZkrError):
+        n.RollupCircuit(0, 6)
+    with pytest.raises(zkr_hip.ZkrError):
+        n.RollupCircuit(2, 33)
+
+
+# ------------------------------------------------------------------ constraint system + witness builder
+def test_tx_circuit_geometry():
+    """tx.circom:3 = BatchProcessTx(2, 6): 73 public signals (TxVerifier.sol:281 takes uint[73]) and a 2^17 domain."""
+    from zkr_hip import rollup as n
+    c = n.RollupCircuit()
+    assert (c.batch, c.depth, c.n_public) == (2, 6, 73)
+    assert 1 << 16 < c.n_constraints + c.n_public + 1 <= 1 << 17
+    b = c.r1cs()
+    assert [int.from_bytes(b[i:i + 4], "little") for i in (0, 4, 8)] == [c.n_vars, 73, c.n_constraints]
+
+
+@pytest.fixture(scope="module")
+def circuit_2x4():
+    from zkr_hip import rollup as n
+    c = n.RollupCircuit(2, 4)
+    nv, npub, cons = parse_r1cs(c.r1cs())
+    assert (nv, npub, len(cons)) == (c.n_vars, c.n_public, c.n_constraints)
+    return c, cons
+
+
+def test_witness_satisfies_the_system_and_outputs_the_new_root(circuit_2x4):
+    """processtx.test.ts:132-138 / batchprocesstx.test.ts:247-253: main.newBalanceTreeRoot == the root of the tree the
+    operator computed; plus: every constraint holds and the public signals are the circuit inputs in circom's order."""
+    import rollup as o
+    c, cons = circuit_2x4
+    for seed, self_send in ((1, False), (2, False), (3, True)):     # self-send: processtx.test.ts:141-246
+        txs, tree, _ = scenario(2, 4, seed, self_send)
+        wb = c.calculate_witness(as_inputs(txs))
+        w = ints(wb)
+        assert len(w) == c.n_vars and w[0] == 1
+        assert first_violated(cons, w, o.R) == -1
+        assert w[1] == tree.root == txs[-1]["newBalanceTreeRoot"]
+        assert c.public_signals(wb) == o.batch_public_signals(txs)
+        assert c.calculate_witness(c.flatten_inputs(as_inputs(txs))) == wb
+
+
+def test_every_private_signal_is_constrained(circuit_2x4):
+    """No free signals: changing any one witness value breaks some constraint (sampled)."""
+    import rollup as o
+    c, cons = circuit_2x4
+    txs, _, _ = scenario(2, 4, 5)
+    w = ints(c.calculate_witness(as_inputs(txs)))
+    used = {}
+    for i, row in enumerate(cons):
+        for lc in row:
+            for s, _c in lc:
+                used.setdefault(s, []).append(i)
+    assert set(range(1, c.n_vars)) <= set(used)
+    rnd = random.Random(11)
+    for s in [1, 2, c.n_public] + [rnd.randrange(1, c.n_vars) for _ in range(200)]:
+        w2 = list(w)
+        w2[s] = (w2[s] + 1 + rnd.randrange(o.R - 1)) % o.R
+        ev = lambda lc: sum(cf * w2[x] for x, cf in lc) % o.R
+        assert any(ev(cons[i][0]) * ev(cons[i][1]) % o.R != ev(cons[i][2]) for i in used[s]), s
+
+
+@pytest.mark.parametrize("what,needle", [
+    ("signature", "signature"), ("message", "signature"), ("nonce", "nonce"), ("balance", "balance"), ("zero_amount", "amount"),
+    ("sender_path", "sender leaf"), ("recipient_leaf", "recipient leaf"), ("intermediate_root", "intermediate root"),
+    ("chain", "previous one"), ("huge_amount", "250 bits"), ("big_s", "subgroup order"), ("index", "fits the tree")])
+def test_inputs_that_violate_the_circuit_are_refused(what, needle):
+    """Where Circuit.calculateWitness throws (merkletree.test.ts:118-129; the `===` lines of processtx.circom:83-101,
+    127-136,185, batchprocesstx.circom:67-69): ZKR_ERR_UNSATISFIED naming the statement."""
+    import rollup as o
+    import zkr_hip
+    from zkr_hip import rollup as n
+    c = n.RollupCircuit(2, 3)
+    txs, _, privs = scenario(2, 3, 21)
+    t = txs[1]
+    if what == "signature":
+        t["txData"][7] = (t["txData"][7] + 1) % o.SUBORDER
+    elif what == "message":
+        t["txData"][3] += 1                                  # fee changed after signing
+    elif what == "nonce":
+        t["txSenderNonce"] += 1
+    elif what == "balance":                                  # amount + fee == balance is not enough (strictly greater)
+        bal = t["txSenderBalance"]
+        txs, _, _ = scenario_with_amount(bal)
+        t = txs[0]
+        c = n.RollupCircuit(1, 3)
+    elif what == "zero_amount":
+        txs, _, _ = scenario_with_amount(None, amount=0)
+        c = n.RollupCircuit(1, 3)
+    elif what == "sender_path":
+        t["txSenderPathElements"][1] += 1
+    elif what == "recipient_leaf":
+        t["txRecipientBalance"] += 1
+    elif what == "intermediate_root":
+        t["intermediateBalanceTreeRoot"] += 1
+    elif what == "chain":
+        txs = [txs[0], dict(txs[0])]                         # each valid alone, but the second ignores the first's update
+    elif what == "huge_amount":
+        txs, _, _ = scenario_with_amount(None, amount=1 << 250)
+        c = n.RollupCircuit(1, 3)
+    elif what == "big_s":
+        t["txData"][7] += o.SUBORDER
+    elif what == "index":
+        t["txData"][0] += 8
+    with pytest.raises(zkr_hip.ZkrError) as e:
+        c.calculate_witness(as_inputs(txs))
+    assert e.value.code == -7 and needle in str(e.value), str(e.value)
+
+
+def scenario_with_amount(balance_total, amount=None, depth=3):
+    """One transaction whose amount + fee equals the sender's whole balance (or with the given amount)."""
+    import rollup as o
+    rnd = random.Random(33)
+    privs = [rnd.randrange(o.R) for _ in range(2)]
+    accounts = {i: [*o.gen_public_key(privs[i]), 10 ** 18, 0] for i in range(2)}
+    tree = o.Tree(depth)
+    for i in range(2):
+        tree.update(i, o.leaf_hash(accounts[i][:2], accounts[i][2], accounts[i][3]))
+    fee = 10 ** 17
+    amt = amount if amount is not None else accounts[0][2] - fee
+    return [o.process_tx_inputs(tree, accounts, 0, 1, amt, fee, privs[0])], tree, privs
+
+
+def test_balance_edge_is_exact():
+    """balance == amount + fee + 1 passes, balance == amount + fee does not (processtx.circom:98-101, strict >)."""
+    import rollup as o
+    from zkr_hip import rollup as n
+    c = n.RollupCircuit(1, 3)
+    rnd = random.Random(34)
+    privs = [rnd.randrange(o.R) for _ in range(2)]
+    accounts = {i: [*o.gen_public_key(privs[i]), 10 ** 18, 0] for i in range(2)}
+    tree = o.Tree(3)
+    for i in range(2):
+        tree.update(i, o.leaf_hash(accounts[i][:2], accounts[i][2], accounts[i][3]))
+    tx = o.process_tx_inputs(tree, accounts, 0, 1, 10 ** 18 - 10 ** 17 - 1, 10 ** 17, privs[0])
+    w = ints(c.calculate_witness(as_inputs([tx])))
+    assert w[1] == tree.root
