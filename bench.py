@@ -87,6 +87,47 @@ def cpu_baseline_js(sample_log_m, target_log_m):
                          sec["h"], sec["msm"], target_log_m - sample_log_m)}
 
 
+def tx_circuit_leg(local, steps):
+    """the reference's own tx circuit (tx.circom:3 = BatchProcessTx(2, 6), m = 2^17) end to end on this
+    GPU -- native constraint system, Groth16 setup on the device, native witness builder (timed on the host), proofs
+    pipelined two deep, every proof checked by the native verifier.  Reported beside the headline line, never as
+    `value` (the metric is quoted on the 2^20 configuration)."""
+    import torch
+    import zkr_hip
+    from zkr_hip import rollup
+    t0 = time.time()
+    circ = rollup.RollupCircuit()
+    key, vk_bin = zkr_hip.ProvingKey.setup_r1cs(circ.r1cs(), device=local)
+    setup_s = time.time() - t0
+    privs = [0x5A4B1000 + 7919 * i for i in range(8)]
+    state = rollup.RollupState(circ.depth)
+    for i, pv in enumerate(privs):
+        state.deposit(i, rollup.gen_public_key(pv), 10 ** 20, 0)
+    n_wit, wits, pubs, wit_ms = 4, [], [], []
+    for b in range(n_wit):
+        txs = [state.transfer((2 * b + j) % 8, (2 * b + j + 3) % 8, 10 ** 17 * (j + 1), 10 ** 15, privs[(2 * b + j) % 8]) for j in range(circ.batch)]
+        flat = circ.flatten_inputs(state.batch_inputs(txs))
+        t1 = time.perf_counter()
+        wb = circ.calculate_witness(flat)
+        wit_ms.append(1e3 * (time.perf_counter() - t1))
+        pubs.append(circ.public_signals(wb))
+        wits.append(torch.frombuffer(bytearray(wb), dtype=torch.uint8).cuda(local))
+    stream = torch.cuda.current_stream().cuda_stream
+    ptrs = [wits[i % n_wit].data_ptr() for i in range(steps)]
+    key.prove_batch_device(ptrs[:4], stream=stream)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    proofs = key.prove_batch_device(ptrs, stream=stream)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t1
+    ok = sum(1 for i in range(min(steps, n_wit)) if zkr_hip.verify(vk_bin, proofs[i], pubs[i]))
+    assert ok == min(steps, n_wit), "a proof of the tx circuit failed the pairing check"
+    return {"circuit": "BatchProcessTx(%d, %d) (tx.circom)" % (circ.batch, circ.depth), "nVars": circ.n_vars, "nPublic": circ.n_public,
+            "nConstraints": circ.n_constraints, "domainSize": key.info()["domainSize"], "setup_s": setup_s,
+            "witness_ms_host": sum(wit_ms) / len(wit_ms), "proofs": steps, "proofs_per_s": steps / el, "ms_per_proof": 1e3 * el / steps,
+            "proofs_verified": ok}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -100,6 +141,7 @@ def main():
     ap.add_argument("--js-sample-log-m", type=int, default=10)
     ap.add_argument("--no-js-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="synchronous proofs, one at a time (latency)")
+    ap.add_argument("--no-tx-circuit", action="store_true", help="skip the BatchProcessTx(2, 6) leg (SURVEY 8(f-3))")
     args = ap.parse_args()
 
     import torch
@@ -269,6 +311,8 @@ def main():
                 "frac_of_peak": proof_traffic / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBPS,
                 "source": "sum over the proving kernels of profiles/r1_pmc_traffic.json (x2 read rule: an upper bound for the 64-byte gathers)"},
         }
+        if world == 1 and not args.no_tx_circuit:
+            out["tx_circuit"] = tx_circuit_leg(local, max(args.steps, 4))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample_log_m, args.log_m)
             out["cpu_baseline"]["host_cores_available"] = os.cpu_count()

@@ -21,7 +21,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -355,6 +358,9 @@ struct LC {
   Fr v;  // value (Montgomery)
 };
 
+// Linear combinations carry their terms only while constraints are being serialised; a witness-only pass moves values.
+static thread_local bool g_terms = true;
+
 struct Builder {
   bool emit;    // serialise the constraints
   bool check;   // inputs are real: a violated constraint is an error
@@ -363,16 +369,24 @@ struct Builder {
   uint32_t n_constraints = 0;
   std::string err;
 
-  Builder(bool emit_, bool check_) : emit(emit_), check(check_) { w.push_back(Fr::one()); }
+  Builder(bool emit_, bool check_) : emit(emit_), check(check_) {
+    w.push_back(Fr::one());
+    g_terms = emit_;
+  }
 
   uint32_t alloc(const Fr &val) {
     w.push_back(val);
     return (uint32_t)w.size() - 1;
   }
-  LC sig(uint32_t s) const { return LC{{Term{s, Fr::one()}}, w[s]}; }
+  LC sig(uint32_t s) const {
+    LC r;
+    if (g_terms) r.t.push_back(Term{s, Fr::one()});
+    r.v = w[s];
+    return r;
+  }
   static LC cst(const Fr &k) {
     LC r;
-    if (!k.is_zero()) r.t.push_back(Term{0, k});
+    if (g_terms && !k.is_zero()) r.t.push_back(Term{0, k});
     r.v = k;
     return r;
   }
@@ -408,9 +422,7 @@ struct Builder {
   }
   void enforce(const LC &a, const LC &b, const LC &c, const char *what) {
     if (check && err.empty() && !(mul(a.v, b.v) == c.v)) {
-      char buf[160];
-      snprintf(buf, sizeof buf, "constraint %u does not hold: %s", n_constraints, what);
-      err = buf;
+      err = what;
     }
     if (emit) {
       put_lc(a);
@@ -420,29 +432,51 @@ struct Builder {
     n_constraints++;
   }
   // new signal = a * b
-  LC mul_sig(const LC &a, const LC &b, const char *what) {
+  // a constraint whose right-hand side was just computed from its left-hand side: nothing to check
+  void define(const LC &a, const LC &b, const LC &c) {
+    if (emit) {
+      put_lc(a);
+      put_lc(b);
+      put_lc(c);
+    }
+    n_constraints++;
+  }
+  LC mul_sig(const LC &a, const LC &b, const char *) {
     LC s = sig(alloc(mul(a.v, b.v)));
-    enforce(a, b, s, what);
+    define(a, b, s);
     return s;
   }
 };
 
 static LC operator+(const LC &a, const LC &b) {
   LC r;
-  r.t.reserve(a.t.size() + b.t.size());
-  r.t = a.t;
-  r.t.insert(r.t.end(), b.t.begin(), b.t.end());
+  if (g_terms) {
+    r.t.reserve(a.t.size() + b.t.size());
+    r.t = a.t;
+    r.t.insert(r.t.end(), b.t.begin(), b.t.end());
+  }
   r.v = add(a.v, b.v);
   return r;
 }
 static LC operator*(const LC &a, const Fr &k) {
   LC r;
-  r.t.reserve(a.t.size());
-  for (const Term &x : a.t) r.t.push_back(Term{x.sig, mul(x.c, k)});
+  if (g_terms) {
+    r.t.reserve(a.t.size());
+    for (const Term &x : a.t) r.t.push_back(Term{x.sig, mul(x.c, k)});
+  }
   r.v = mul(a.v, k);
   return r;
 }
-static LC operator-(const LC &a, const LC &b) { return a + b * neg(Fr::one()); }
+static LC operator-(const LC &a, const LC &b) {
+  LC r;
+  if (g_terms) {
+    r.t.reserve(a.t.size() + b.t.size());
+    r.t = a.t;
+    for (const Term &x : b.t) r.t.push_back(Term{x.sig, neg(x.c)});
+  }
+  r.v = sub(a.v, b.v);
+  return r;
+}
 
 // ---- MiMCSponge gadget (circomlib MiMCFeistel: t2 = t*t, t4 = t2*t2, x' = x_r + t4*t; 3 constraints per round)
 static void feistel_gadget(Builder &B, LC &xl, LC &xr) {
@@ -452,7 +486,7 @@ static void feistel_gadget(Builder &B, LC &xl, LC &xr) {
     LC t2 = B.mul_sig(t, t, "MiMC t^2");
     LC t4 = B.mul_sig(t2, t2, "MiMC t^4");
     LC nx = B.sig(B.alloc(add(xr.v, mul(t4.v, t.v))));
-    B.enforce(t4, t, nx - xr, "MiMC round");
+    B.define(t4, t, nx - xr);
     if (i < NROUNDS - 1) {
       xr = xl;
       xl = nx;
@@ -512,7 +546,34 @@ static LC bits_gt_const(Builder &B, const std::vector<LC> &bits, const uint32_t 
 struct PtL {
   LC x, y;
 };
-static PtL edwards_add(Builder &B, const PtL &p, const PtL &q) {  // the complete addition law, 6 constraints
+// 1/z for every element (0 for a zero element), one field inversion in all
+static void batch_inverse(std::vector<Fr> &z) {
+  std::vector<Fr> pre(z.size());
+  Fr acc = Fr::one();
+  for (size_t i = 0; i < z.size(); i++) {
+    pre[i] = acc;
+    if (!z[i].is_zero()) acc = mul(acc, z[i]);
+  }
+  Fr ia = inv(acc);
+  for (size_t i = z.size(); i-- > 0;) {
+    if (z[i].is_zero()) continue;
+    Fr zi = mul(ia, pre[i]);
+    ia = mul(ia, z[i]);
+    z[i] = zi;
+  }
+}
+// affine coordinates of a list of projective points (x0, y0, x1, y1, ...)
+static std::vector<Fr> affine_all(const std::vector<PtP> &pts) {
+  std::vector<Fr> z(pts.size());
+  for (size_t i = 0; i < pts.size(); i++) z[i] = pts[i].z;
+  batch_inverse(z);
+  std::vector<Fr> out(2 * pts.size());
+  for (size_t i = 0; i < pts.size(); i++) out[2 * i] = mul(pts[i].x, z[i]), out[2 * i + 1] = mul(pts[i].y, z[i]);
+  return out;
+}
+
+// the complete addition law, 6 constraints; `known` = the sum's affine coordinates when a caller has them already
+static PtL edwards_add(Builder &B, const PtL &p, const PtL &q, const Fr *known = nullptr) {
   const Bj &k = bj();
   LC beta = B.mul_sig(p.x, q.y, "edwards beta");
   LC gamma = B.mul_sig(p.y, q.x, "edwards gamma");
@@ -520,21 +581,41 @@ static PtL edwards_add(Builder &B, const PtL &p, const PtL &q) {  // the complet
   LC tau = B.mul_sig(beta, gamma, "edwards tau");
   LC dt = tau * k.d;
   LC dx = Builder::one() + dt, dy = Builder::one() - dt;
-  Fr di = inv(mul(dx.v, dy.v));
   LC nx = beta + gamma, ny = delta + beta * k.a - gamma;
-  LC xo = B.sig(B.alloc(mul(nx.v, mul(di, dy.v))));
-  LC yo = B.sig(B.alloc(mul(ny.v, mul(di, dx.v))));
+  Fr xv, yv;
+  if (known) {
+    xv = known[0], yv = known[1];
+  } else {
+    Fr di = inv(mul(dx.v, dy.v));
+    xv = mul(nx.v, mul(di, dy.v)), yv = mul(ny.v, mul(di, dx.v));
+  }
+  LC xo = B.sig(B.alloc(xv));
+  LC yo = B.sig(B.alloc(yv));
   B.enforce(dx, xo, nx, "edwards x");
   B.enforce(dy, yo, ny, "edwards y");
   return PtL{xo, yo};
 }
 // sum_i e_i 2^i P for a variable point: per bit a selected addition (2 + 6) and a doubling (6)
 static PtL scalar_mul_any(Builder &B, const std::vector<LC> &e, PtL q) {
+  // values first, in projective coordinates, so that the whole chain costs one field inversion
+  const size_t n = e.size();
+  std::vector<PtP> pts;  // acc_1, q_1, acc_2, q_2, ...
+  pts.reserve(2 * n);
+  {
+    PtP qq{q.x.v, q.y.v, Fr::one()}, acc = e[0].v.is_zero() ? pt_identity() : qq;
+    for (size_t i = 1; i < n; i++) {
+      qq = pt_add(qq, qq);
+      if (!e[i].v.is_zero()) acc = pt_add(acc, qq);
+      pts.push_back(acc);
+      pts.push_back(qq);
+    }
+  }
+  std::vector<Fr> aff = affine_all(pts);
   PtL acc;
-  for (size_t i = 0; i < e.size(); i++) {
+  for (size_t i = 0; i < n; i++) {
     PtL sel{B.mul_sig(e[i], q.x, "select x"), B.mul_sig(e[i], q.y - Builder::one(), "select y") + Builder::one()};
-    acc = i == 0 ? sel : edwards_add(B, acc, sel);
-    if (i + 1 < e.size()) q = edwards_add(B, q, q);
+    acc = i == 0 ? sel : edwards_add(B, acc, sel, &aff[4 * (i - 1)]);
+    if (i + 1 < n) q = edwards_add(B, q, q, &aff[4 * i + 2]);
   }
   return acc;
 }
@@ -555,10 +636,20 @@ struct Base8Table {
 };
 static PtL scalar_mul_base8(Builder &B, const std::vector<LC> &e) {
   static const Base8Table tab;
+  std::vector<PtP> pts;
+  pts.reserve(e.size());
+  {
+    PtP acc = e[0].v.is_zero() ? pt_identity() : PtP{tab.x[0], tab.y[0], Fr::one()};
+    for (size_t i = 1; i < e.size(); i++) {
+      if (!e[i].v.is_zero()) acc = pt_add(acc, PtP{tab.x[i], tab.y[i], Fr::one()});
+      pts.push_back(acc);
+    }
+  }
+  std::vector<Fr> aff = affine_all(pts);
   PtL acc;
   for (size_t i = 0; i < e.size(); i++) {
     PtL sel{e[i] * tab.x[i], e[i] * sub(tab.y[i], Fr::one()) + Builder::one()};
-    acc = i == 0 ? sel : edwards_add(B, acc, sel);
+    acc = i == 0 ? sel : edwards_add(B, acc, sel, &aff[2 * (i - 1)]);
   }
   return acc;
 }
@@ -653,38 +744,103 @@ constexpr uint32_t PER_TX = 8 + 2 + 1 + 1 + 2 + 1 + 1 + 1 + 1;  // scalars + fix
 
 static uint32_t n_public_of(uint32_t batch, uint32_t depth) { return 1 + batch * (PER_TX + 3 * depth); }
 
-// BatchProcessTx(batch, depth) (batchprocesstx.circom:3-75).  `inputs` (n_public - 1 field elements, Montgomery) or
-// nullptr for the structure only.
-static void batch_gadget(Builder &B, uint32_t batch, uint32_t depth, const Fr *inputs) {
+struct Layout {  // circom's order: the output, then every input array in declaration order, each flattened over the batch
+  uint32_t o_root, o_tx, o_spk, o_sbal, o_snonce, o_spath, o_rpk, o_rbal, o_rnonce, o_rpath, o_iroot, o_ipath;
+  Layout(uint32_t batch, uint32_t depth) {
+    uint32_t at = 2;
+    auto take = [&](uint32_t count) {
+      uint32_t first = at;
+      at += batch * count;
+      return first;
+    };
+    o_root = take(1), o_tx = take(8), o_spk = take(2), o_sbal = take(1), o_snonce = take(1), o_spath = take(depth), o_rpk = take(2);
+    o_rbal = take(1), o_rnonce = take(1), o_rpath = take(depth), o_iroot = take(1), o_ipath = take(depth);
+  }
+};
+static TxIn tx_inputs(const Builder &B, const Layout &L, uint32_t i, uint32_t depth) {
+  TxIn in;
+  in.root = B.sig(L.o_root + i);
+  for (int j = 0; j < 8; j++) in.tx[j] = B.sig(L.o_tx + 8 * i + j);
+  for (int j = 0; j < 2; j++) in.spk[j] = B.sig(L.o_spk + 2 * i + j), in.rpk[j] = B.sig(L.o_rpk + 2 * i + j);
+  in.sbal = B.sig(L.o_sbal + i), in.snonce = B.sig(L.o_snonce + i), in.rbal = B.sig(L.o_rbal + i), in.rnonce = B.sig(L.o_rnonce + i);
+  in.iroot = B.sig(L.o_iroot + i);
+  for (uint32_t j = 0; j < depth; j++) {
+    in.spath.push_back(B.sig(L.o_spath + depth * i + j));
+    in.rpath.push_back(B.sig(L.o_rpath + depth * i + j));
+    in.ipath.push_back(B.sig(L.o_ipath + depth * i + j));
+  }
+  return in;
+}
+
+// BatchProcessTx(batch, depth) (batchprocesstx.circom:3-75), structure pass: signals and constraints in order.
+static void batch_gadget(Builder &B, uint32_t batch, uint32_t depth) {
   const uint32_t p = n_public_of(batch, depth);
-  for (uint32_t i = 1; i <= p; i++) B.alloc(i >= 2 && inputs ? inputs[i - 2] : Fr::zero());
-  // circom's order: the output, then every input array in declaration order, each flattened over the batch
-  uint32_t at = 2;
-  auto take = [&](uint32_t count) {
-    uint32_t first = at;
-    at += batch * count;
-    return first;
-  };
-  const uint32_t o_root = take(1), o_tx = take(8), o_spk = take(2), o_sbal = take(1), o_snonce = take(1), o_spath = take(depth), o_rpk = take(2),
-                 o_rbal = take(1), o_rnonce = take(1), o_rpath = take(depth), o_iroot = take(1), o_ipath = take(depth);
+  for (uint32_t i = 1; i <= p; i++) B.alloc(Fr::zero());
+  const Layout L(batch, depth);
   LC prev;
   for (uint32_t i = 0; i < batch; i++) {
-    TxIn in;
-    in.root = B.sig(o_root + i);
-    for (int j = 0; j < 8; j++) in.tx[j] = B.sig(o_tx + 8 * i + j);
-    for (int j = 0; j < 2; j++) in.spk[j] = B.sig(o_spk + 2 * i + j), in.rpk[j] = B.sig(o_rpk + 2 * i + j);
-    in.sbal = B.sig(o_sbal + i), in.snonce = B.sig(o_snonce + i), in.rbal = B.sig(o_rbal + i), in.rnonce = B.sig(o_rnonce + i);
-    in.iroot = B.sig(o_iroot + i);
-    for (uint32_t j = 0; j < depth; j++) {
-      in.spath.push_back(B.sig(o_spath + depth * i + j));
-      in.rpath.push_back(B.sig(o_rpath + depth * i + j));
-      in.ipath.push_back(B.sig(o_ipath + depth * i + j));
-    }
+    TxIn in = tx_inputs(B, L, i, depth);
     if (i > 0) B.enforce(prev, Builder::one(), in.root, "a transaction starts from the root the previous one produced");  // :67-69
     prev = process_tx_gadget(B, in, depth);
   }
   B.w[1] = prev.v;  // newBalanceTreeRoot (:72)
   B.enforce(prev, Builder::one(), B.sig(1), "newBalanceTreeRoot");
+}
+
+// Witness pass: the transactions of a batch only meet in the root chain, so each one is built on its own thread
+// (same gadget code, same signal order; private signals are concatenated in transaction order afterwards).
+// Returns the witness as binarifyWitness lays it out (32 B standard form per signal).
+static bool batch_witness(uint32_t batch, uint32_t depth, const Fr *inputs, std::vector<uint8_t> &out, std::string &err) {
+  const uint32_t p = n_public_of(batch, depth);
+  const Layout L(batch, depth);
+  std::vector<Fr> pub(p + 1, Fr::zero());
+  pub[0] = Fr::one();
+  for (uint32_t i = 2; i <= p; i++) pub[i] = inputs[i - 2];
+  std::vector<std::vector<uint8_t>> priv(batch);
+  std::vector<Fr> roots(batch);
+  std::vector<std::string> errs(batch);
+  auto one_tx = [&](uint32_t i) {
+    Builder B(false, true);
+    B.w = pub;
+    roots[i] = process_tx_gadget(B, tx_inputs(B, L, i, depth), depth).v;
+    errs[i] = B.err;
+    priv[i].resize(32 * (B.w.size() - p - 1));
+    for (size_t k = p + 1; k < B.w.size(); k++) fr_write_std(&priv[i][32 * (k - p - 1)], B.w[k]);
+  };
+  unsigned hw = std::thread::hardware_concurrency();
+  const uint32_t nthreads = std::min<uint32_t>(batch, hw ? hw : 1);
+  if (nthreads <= 1) {
+    for (uint32_t i = 0; i < batch; i++) one_tx(i);
+  } else {
+    std::vector<std::thread> th;
+    std::atomic<uint32_t> next{0};
+    for (uint32_t t = 0; t < nthreads; t++)
+      th.emplace_back([&] {
+        for (uint32_t i; (i = next.fetch_add(1)) < batch;) one_tx(i);
+      });
+    for (auto &t : th) t.join();
+  }
+  for (uint32_t i = 0; i < batch; i++) {  // first violated statement in circuit order
+    if (i > 0 && !(roots[i - 1] == pub[L.o_root + i])) {
+      err = "transaction " + std::to_string(i) + " violates: a transaction starts from the root the previous one produced";
+      return false;
+    }
+    if (!errs[i].empty()) {
+      err = "transaction " + std::to_string(i) + " violates: " + errs[i];
+      return false;
+    }
+  }
+  pub[1] = roots[batch - 1];  // newBalanceTreeRoot (:72)
+  size_t total = 32 * (size_t)(p + 1);
+  for (uint32_t i = 0; i < batch; i++) total += priv[i].size();
+  out.resize(total);
+  for (uint32_t k = 0; k <= p; k++) fr_write_std(&out[32 * k], pub[k]);
+  size_t at = 32 * (size_t)(p + 1);
+  for (uint32_t i = 0; i < batch; i++) {
+    memcpy(&out[at], priv[i].data(), priv[i].size());
+    at += priv[i].size();
+  }
+  return true;
 }
 
 static int check_geometry(uint32_t batch, uint32_t depth) {
@@ -761,7 +917,7 @@ int zkr_rollup_info(uint32_t batch, uint32_t depth, uint32_t *n_vars, uint32_t *
   int rc = check_geometry(batch, depth);
   if (rc) return rc;
   Builder B(false, false);
-  batch_gadget(B, batch, depth, nullptr);
+  batch_gadget(B, batch, depth);
   if (n_vars) *n_vars = (uint32_t)B.w.size();
   if (n_public) *n_public = n_public_of(batch, depth);
   if (n_constraints) *n_constraints = B.n_constraints;
@@ -774,7 +930,7 @@ int zkr_rollup_r1cs(uint32_t batch, uint32_t depth, void **r1cs_bin, size_t *r1c
   if (rc) return rc;
   Builder B(true, false);
   B.out.resize(12);
-  batch_gadget(B, batch, depth, nullptr);
+  batch_gadget(B, batch, depth);
   uint32_t hdr[3] = {(uint32_t)B.w.size(), n_public_of(batch, depth), B.n_constraints};
   memcpy(B.out.data(), hdr, 12);
   *r1cs_bin = dup_bytes(B.out.data(), B.out.size());
@@ -792,11 +948,9 @@ int zkr_rollup_witness(uint32_t batch, uint32_t depth, const uint8_t *inputs, si
   std::vector<Fr> in(n_inputs);
   for (size_t i = 0; i < n_inputs; i++)
     if (!fr_read_std(inputs + 32 * i, in[i])) { set_error("input %zu >= r", i); return ZKR_ERR_ARG; }
-  Builder B(false, true);
-  batch_gadget(B, batch, depth, in.data());
-  if (!B.err.empty()) { set_error("%s", B.err.c_str()); return ZKR_ERR_UNSATISFIED; }
-  std::vector<uint8_t> out(32 * B.w.size());
-  for (size_t i = 0; i < B.w.size(); i++) fr_write_std(&out[32 * i], B.w[i]);
+  std::vector<uint8_t> out;
+  std::string err;
+  if (!batch_witness(batch, depth, in.data(), out, err)) { set_error("%s", err.c_str()); return ZKR_ERR_UNSATISFIED; }
   *witness_bin = dup_bytes(out.data(), out.size());
   *witness_len = out.size();
   if (!*witness_bin) { set_error("out of memory"); return ZKR_ERR_ARG; }

@@ -14,6 +14,8 @@ export interface Bn128 {
   groth16GenProofBatch(witnessBins: Array<ArrayBuffer | Uint8Array>, provingKeyBin: ArrayBuffer | Uint8Array, opts?: ProveOptions[]): Promise<Groth16Proof[]>;
   /** Groth16 setup of circom's circuit JSON on the GPU (snarkjs setup --protocol groth); returns the verifying key JSON. */
   setup(circuitDef: any, opts?: { toxic?: Array<bigint | string> }): any;
+  /** The same for a constraint system in the r1cs_bin layout (RollupCircuit.r1cs()). */
+  setupR1cs(r1csBin: Uint8Array, opts?: { toxic?: Array<bigint | string> }): any;
   saveKey(path: string): void;
   loadKeyFile(path: string): void;
   /** Proof with the key currently held on the device. */
@@ -34,3 +36,20 @@ export function verifyingKeyFromBytes(vkBin: Uint8Array): any;
 export function proofFromBytes(proofBytes: Uint8Array): Groth16Proof;
 export function deviceCount(): number;
 export function version(): string;
+
+// ---- the rollup circuit without circom / snarkjs (operator/src/utils/crypto.ts, prover/circuits/batchprocesstx.circom)
+export interface Signature { R8: [bigint, bigint]; S: bigint; }
+export function multiHash(values: Array<bigint | string | number>): bigint;
+export function hashLeftRight(left: bigint, right: bigint): bigint;
+export function genPublicKey(privKey: bigint): [bigint, bigint];
+export function sign(privKey: bigint, msg: Array<bigint | string | number>): Signature;
+export function verify(msg: Array<bigint | string | number>, sig: Signature, pubKey: [bigint, bigint]): boolean;
+/** BatchProcessTx(batch, depth) (tx.circom = (2, 6)) as constraint system + witness builder. */
+export class RollupCircuit {
+  constructor(batch?: number, depth?: number);
+  readonly batch: number; readonly depth: number; readonly nVars: number; readonly nPublic: number; readonly nConstraints: number;
+  r1cs(): Uint8Array;
+  /** circuitInputs as the reference builds them (one array per input signal over the batch); throws where Circuit.calculateWitness would. */
+  calculateWitness(circuitInputs: { [signal: string]: any } | Array<bigint | string>): ArrayBuffer;
+  publicSignals(witnessBin: ArrayBuffer): bigint[];
+}

@@ -86,6 +86,13 @@ class Bn128 {
     this._key = key; this._fp = "setup";
     return verifyingKeyFromBytes(vkBin);
   }
+  // the same for a constraint system already in the r1cs_bin layout (RollupCircuit.r1cs())
+  setupR1cs(r1csBin, opts) {
+    const tox = opts && opts.toxic ? Buffer.concat(opts.toxic.map(bigintToLe32)) : null;
+    const [key, vkBin] = native().setupR1cs(r1csBin, tox, this.device);
+    this._key = key; this._fp = "setup";
+    return verifyingKeyFromBytes(vkBin);
+  }
   saveKey(path) { if (!this._key) throw new Error("no key loaded"); native().keySave(this._key, path); }
   loadKeyFile(path) { this._key = native().keyLoadFile(path, this.device); this._fp = "file:" + path; }
   // proof with the key currently held (after setup / loadKeyFile / a groth16GenProof call)
@@ -211,9 +218,57 @@ function solidityProof(proof, publicSignals) {
   };
 }
 
+// ---- the rollup circuit without circom / snarkjs (SURVEY 8(f-3)): operator/src/utils/crypto.ts natively, and
+// BatchProcessTx(batch, depth) (prover/circuits/batchprocesstx.circom:3-75) as constraint system + witness builder
+const concatLe = (values) => Buffer.concat(values.map((v) => bigintToLe32(BigInt(v))).concat([Buffer.alloc(0)]));
+const leToBigInts = (buf) => { const out = []; for (let o = 0; o < buf.length; o += 32) out.push(BigInt(leBytesToDecimal(buf, o))); return out; };
+// multiHash(d) (crypto.ts:28-30); hash / hashLeftRight (:32-38)
+function multiHash(values) { return leToBigInts(native().rollupCrypto(0, concatLe(values.map((v) => BigInt(v) % R))))[0]; }
+const hashLeftRight = (l, r) => multiHash([l, r]);
+// genPublicKey(privKey) (crypto.ts:78-84)
+function genPublicKey(priv) { return leToBigInts(native().rollupCrypto(1, bigintToLe32(priv))); }
+// sign(prv, msg) -> { R8: [x, y], S } (crypto.ts:143-168); verify(msg, sig, pubKey) (:170-177)
+function sign(priv, msg) {
+  const v = leToBigInts(native().rollupCrypto(2, bigintToLe32(priv), concatLe(msg)));
+  return { R8: [v[0], v[1]], S: v[2] };
+}
+function verify(msg, sig, pub) {
+  if ([sig.R8[0], sig.R8[1], sig.S, pub[0], pub[1]].some((v) => BigInt(v) < 0n || BigInt(v) >= MONT)) return false;
+  return native().rollupCrypto(3, concatLe(msg), concatLe([sig.R8[0], sig.R8[1], sig.S]), concatLe(pub));
+}
+
+const TX_INPUT_FIELDS = ["balanceTreeRoot", "txData", "txSenderPublicKey", "txSenderBalance", "txSenderNonce", "txSenderPathElements",
+  "txRecipientPublicKey", "txRecipientBalance", "txRecipientNonce", "txRecipientPathElements",
+  "intermediateBalanceTreeRoot", "intermediateBalanceTreePathElements"];  // batchprocesstx.circom:13-36
+
+// What `new Circuit(await compiler("tx.circom"))` is to the reference (common.ts:12-15), for BatchProcessTx(batch, depth):
+// r1cs() feeds Bn128.setupCircuit; calculateWitness(circuitInputs) returns the witnessBin ArrayBuffer groth16GenProof /
+// prove take (binarifyWitness layout) and throws where Circuit.calculateWitness would.
+class RollupCircuit {
+  constructor(batch, depth) {
+    this.batch = batch === undefined ? 2 : Number(batch);   // tx.circom:3
+    this.depth = depth === undefined ? 6 : Number(depth);
+    const [nVars, nPublic, nConstraints, r1cs] = native().rollupCircuit(this.batch, this.depth, null);
+    Object.assign(this, { nVars, nPublic, nConstraints });
+    this._r1cs = r1cs;
+  }
+  r1cs() { return this._r1cs; }
+  calculateWitness(circuitInputs) {
+    const flat = [];
+    const walk = (v) => { if (Array.isArray(v)) v.forEach(walk); else flat.push(((BigInt(v) % R) + R) % R); };
+    if (Array.isArray(circuitInputs)) walk(circuitInputs); else TX_INPUT_FIELDS.forEach((f) => walk(circuitInputs[f]));
+    if (flat.length !== this.nPublic - 1) throw new Error(`BatchProcessTx(${this.batch}, ${this.depth}) takes ${this.nPublic - 1} input values, got ${flat.length}`);
+    const w = native().rollupCircuit(this.batch, this.depth, concatLe(flat));
+    return w.buffer.slice(w.byteOffset, w.byteOffset + w.byteLength);
+  }
+  // witness.slice(1, nPubInputs + nOutputs + 1) (common.ts:18-21)
+  publicSignals(witnessBin) { return leToBigInts(Buffer.from(witnessBin, 32, 32 * this.nPublic)); }
+}
+
 module.exports = {
   buildBn128, genProof, binarifyWitness, binarifyProvingKey, solidityProof, proofFromBytes, isValid, binarifyVerifyingKey,
   binarifyR1cs, verifyingKeyFromBytes,
+  multiHash, hashLeftRight, genPublicKey, sign, verify, RollupCircuit,
   deviceCount: () => { native(); return deviceCount; },
   version: () => native().version(),
 };

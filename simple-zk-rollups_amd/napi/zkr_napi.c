@@ -27,6 +27,13 @@ static struct {
   int (*key_save)(const zkr_key *, const char *);
   int (*key_load_file)(const char *, int, zkr_key **);
   void (*free_)(void *);
+  int (*multihash)(const uint8_t *, size_t, uint8_t *);
+  int (*pubkey)(const uint8_t *, uint8_t *);
+  int (*eddsa_sign)(const uint8_t *, const uint8_t *, size_t, uint8_t *);
+  int (*eddsa_verify)(const uint8_t *, size_t, const uint8_t *, const uint8_t *, int *);
+  int (*rollup_info)(uint32_t, uint32_t, uint32_t *, uint32_t *, uint32_t *);
+  int (*rollup_r1cs)(uint32_t, uint32_t, void **, size_t *);
+  int (*rollup_witness)(uint32_t, uint32_t, const uint8_t *, size_t, void **, size_t *);
 } Z;
 
 #define NAPI_OK(call)                                                     \
@@ -64,6 +71,8 @@ static napi_value js_load(napi_env env, napi_callback_info info) {
     SYM(last_error, "zkr_last_error") SYM(version, "zkr_version") SYM(device_count, "zkr_device_count")
     SYM(key_load_websnark, "zkr_key_load_websnark") SYM(key_free, "zkr_key_free") SYM(key_info, "zkr_key_info") SYM(prove, "zkr_prove") SYM(verify, "zkr_verify")
     SYM(setup_r1cs, "zkr_setup_r1cs") SYM(key_save, "zkr_key_save") SYM(key_load_file, "zkr_key_load_file") SYM(free_, "zkr_free")
+    SYM(multihash, "zkr_mimcsponge_multihash") SYM(pubkey, "zkr_babyjub_pubkey") SYM(eddsa_sign, "zkr_eddsa_sign") SYM(eddsa_verify, "zkr_eddsa_verify")
+    SYM(rollup_info, "zkr_rollup_info") SYM(rollup_r1cs, "zkr_rollup_r1cs") SYM(rollup_witness, "zkr_rollup_witness")
     Z.handle = h;
   }
   napi_value out;
@@ -281,6 +290,93 @@ static napi_value js_verify(napi_env env, napi_callback_info info) {
   return out;
 }
 
+/* ---- the rollup circuit without circom / snarkjs (include/zkr.h); all synchronous host work ---- */
+/* rollupCrypto(op, a, b, c): op 0 multiHash(values) -> 32 B; 1 pubKey(priv32) -> 64 B; 2 sign(priv32, msg) -> 96 B;
+ * 3 verify(msg, sig96, pub64) -> boolean.  Field elements are 32 B little-endian (operator/src/utils/crypto.ts). */
+static napi_value js_rollup_crypto(napi_env env, napi_callback_info info) {
+  size_t argc = 4;
+  napi_value argv[4];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  if (!Z.handle) return throw_msg(env, "libzkr_hip.so not loaded");
+  int32_t op = -1;
+  const uint8_t *a = NULL, *b = NULL, *c = NULL;
+  size_t al = 0, bl = 0, cl = 0;
+  if (argc < 2 || napi_get_value_int32(env, argv[0], &op) != napi_ok || !get_bytes(env, argv[1], &a, &al)) return throw_msg(env, "rollupCrypto(op, bytes, ...)");
+  if (argc > 2 && !get_bytes(env, argv[2], &b, &bl)) return throw_msg(env, "rollupCrypto: byte buffer expected");
+  if (argc > 3 && !get_bytes(env, argv[3], &c, &cl)) return throw_msg(env, "rollupCrypto: byte buffer expected");
+  uint8_t out[96];
+  size_t out_len = 0;
+  int rc, ok = 0;
+  napi_value res;
+  switch (op) {
+    case 0:
+      if (al % 32) return throw_msg(env, "multiHash: values are 32 bytes each");
+      rc = Z.multihash(a, al / 32, out), out_len = 32;
+      break;
+    case 1:
+      if (al != 32) return throw_msg(env, "genPublicKey: the private key is 32 bytes");
+      rc = Z.pubkey(a, out), out_len = 64;
+      break;
+    case 2:
+      if (al != 32 || bl % 32) return throw_msg(env, "sign: 32-byte private key, 32 bytes per message element");
+      rc = Z.eddsa_sign(a, b, bl / 32, out), out_len = 96;
+      break;
+    case 3:
+      if (al % 32 || bl != 96 || cl != 64) return throw_msg(env, "verify: message elements of 32 bytes, 96-byte signature, 64-byte public key");
+      rc = Z.eddsa_verify(a, al / 32, b, c, &ok);
+      if (rc) return throw_msg(env, Z.last_error());
+      NAPI_OK(napi_get_boolean(env, ok != 0, &res));
+      return res;
+    default:
+      return throw_msg(env, "rollupCrypto: unknown operation");
+  }
+  if (rc) return throw_msg(env, Z.last_error());
+  void *copy;
+  NAPI_OK(napi_create_buffer_copy(env, out_len, out, &copy, &res));
+  return res;
+}
+
+/* rollupCircuit(batch, depth, inputs|null): inputs == null -> [nVars, nPublic, nConstraints, r1csBin Buffer];
+ * inputs = (nPublic - 1) x 32 B -> the witness as binarifyWitness lays it out (Buffer); throws where
+ * Circuit.calculateWitness would (operator/src/snarks/common.ts:15-17). */
+static napi_value js_rollup_circuit(napi_env env, napi_callback_info info) {
+  size_t argc = 3;
+  napi_value argv[3];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  if (!Z.handle) return throw_msg(env, "libzkr_hip.so not loaded");
+  uint32_t batch = 0, depth = 0;
+  if (argc < 2 || napi_get_value_uint32(env, argv[0], &batch) != napi_ok || napi_get_value_uint32(env, argv[1], &depth) != napi_ok)
+    return throw_msg(env, "rollupCircuit(batch, depth, inputs|null)");
+  napi_valuetype t = napi_null;
+  if (argc > 2) napi_typeof(env, argv[2], &t);
+  void *blob = NULL, *copy;
+  size_t len = 0;
+  napi_value res, buf;
+  if (t == napi_null || t == napi_undefined) {
+    uint32_t v[3];
+    if (Z.rollup_info(batch, depth, &v[0], &v[1], &v[2]) || Z.rollup_r1cs(batch, depth, &blob, &len)) return throw_msg(env, Z.last_error());
+    NAPI_OK(napi_create_array_with_length(env, 4, &res));
+    for (int i = 0; i < 3; i++) {
+      napi_value n;
+      NAPI_OK(napi_create_uint32(env, v[i], &n));
+      NAPI_OK(napi_set_element(env, res, i, n));
+    }
+    napi_status st = napi_create_buffer_copy(env, len, blob, &copy, &buf);
+    Z.free_(blob);
+    if (st != napi_ok) return throw_msg(env, "zkr_napi: cannot allocate the R1CS buffer");
+    NAPI_OK(napi_set_element(env, res, 3, buf));
+    return res;
+  }
+  const uint8_t *in;
+  size_t in_len;
+  if (!get_bytes(env, argv[2], &in, &in_len) || in_len % 32) return throw_msg(env, "rollupCircuit: inputs are 32 bytes each");
+  if (Z.rollup_witness(batch, depth, in, in_len / 32, &blob, &len)) return throw_msg(env, Z.last_error());
+  napi_status st = napi_create_buffer_copy(env, len, blob, &copy, &buf);
+  Z.free_(blob);
+  if (st != napi_ok) return throw_msg(env, "zkr_napi: cannot allocate the witness buffer");
+  return buf;
+}
+
 static napi_value init(napi_env env, napi_value exports) {
   napi_property_descriptor props[] = {
       {"load", NULL, js_load, NULL, NULL, NULL, napi_default, NULL},       {"version", NULL, js_version, NULL, NULL, NULL, napi_default, NULL},
@@ -288,6 +384,7 @@ static napi_value init(napi_env env, napi_value exports) {
       {"prove", NULL, js_prove, NULL, NULL, NULL, napi_default, NULL},     {"verify", NULL, js_verify, NULL, NULL, NULL, napi_default, NULL},
       {"setupR1cs", NULL, js_setup_r1cs, NULL, NULL, NULL, napi_default, NULL}, {"keySave", NULL, js_key_save, NULL, NULL, NULL, napi_default, NULL},
       {"keyLoadFile", NULL, js_key_load_file, NULL, NULL, NULL, napi_default, NULL},
+      {"rollupCrypto", NULL, js_rollup_crypto, NULL, NULL, NULL, napi_default, NULL}, {"rollupCircuit", NULL, js_rollup_circuit, NULL, NULL, NULL, napi_default, NULL},
   };
   napi_define_properties(env, exports, sizeof(props) / sizeof(props[0]), props);
   return exports;

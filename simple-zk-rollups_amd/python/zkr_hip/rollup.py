@@ -106,3 +106,67 @@ class RollupCircuit:
     def public_signals(self, witness_bin: bytes):
         """witness.slice(1, nPubInputs + nOutputs + 1) (common.ts:18-21)."""
         return _ints(witness_bin[32:32 * (self.n_public + 1)])
+
+
+class BalanceTree:
+    """operator/src/utils/merkletree.ts:14-83 as a full binary tree over the native hash: `depth` levels,
+    2^depth leaves, empty leaf = zero value; `path(i)` = getUpdatePath(i).pathElements."""
+
+    def __init__(self, depth, zero=0):
+        self.depth = depth
+        self.levels = [[zero] * (1 << depth)]
+        z = zero
+        for _ in range(depth):                       # an empty tree needs one hash per level
+            z = hash_left_right(z, z)
+            self.levels.append([z] * (len(self.levels[-1]) // 2))
+
+    @property
+    def root(self):
+        return self.levels[-1][0]
+
+    def update(self, idx, leaf):
+        self.levels[0][idx] = leaf
+        for l in range(self.depth):
+            idx >>= 1
+            self.levels[l + 1][idx] = hash_left_right(self.levels[l][2 * idx], self.levels[l][2 * idx + 1])
+
+    def path(self, idx):
+        out = []
+        for l in range(self.depth):
+            out.append(self.levels[l][idx ^ 1])
+            idx >>= 1
+        return out
+
+
+class RollupState:
+    """The operator's side of a batch (the flow of operator/__tests__/operatorLogic.test.ts:100-222 and
+    prover/__tests__/processtx.test.ts:24-130): accounts in a balance tree; `transfer` signs one transaction, applies
+    it and returns its ProcessTx inputs; `batch_inputs` stacks them into the circuitInputs of BatchProcessTx."""
+
+    def __init__(self, depth=6):
+        self.tree = BalanceTree(depth)
+        self.accounts = {}
+
+    def deposit(self, index, pub, balance, nonce=0):
+        self.accounts[index] = [int(pub[0]), int(pub[1]), int(balance), int(nonce)]
+        self.tree.update(index, multi_hash(self.accounts[index]))       # hashBalanceTreeLeaf, helpers.ts:80-82
+
+    def transfer(self, frm, to, amount, fee, priv):
+        sa, ra, tree = self.accounts[frm], self.accounts[to], self.tree
+        nonce = sa[3] + 1
+        sig = sign(priv, [frm, to, amount, fee, nonce])                 # formatTx, helpers.ts:59-73
+        inp = dict(balanceTreeRoot=tree.root, txData=[frm, to, amount, fee, nonce, sig["R8"][0], sig["R8"][1], sig["S"]],
+                   txSenderPublicKey=sa[:2], txSenderBalance=sa[2], txSenderNonce=sa[3], txSenderPathElements=tree.path(frm),
+                   txRecipientPublicKey=ra[:2], txRecipientBalance=ra[2], txRecipientNonce=ra[3], txRecipientPathElements=tree.path(to))
+        sa[2] -= amount + fee
+        sa[3] = nonce
+        tree.update(frm, multi_hash(sa))
+        inp["intermediateBalanceTreeRoot"] = tree.root
+        inp["intermediateBalanceTreePathElements"] = tree.path(to)
+        ra[2] += amount                                                 # the same record when frm == to (processtx.circom:141-159)
+        tree.update(to, multi_hash(ra))
+        return inp
+
+    @staticmethod
+    def batch_inputs(txs):
+        return {f: [t[f] for t in txs] for f in TX_INPUT_FIELDS}

@@ -176,3 +176,76 @@ def test_js_setup_prove_save_load_verify(tmp_path, small_case):
     assert res["p1"] == expect and res["p2"] == expect
     assert res["ok1"] is True and res["ok3"] is True and res["cross"] is False
     assert res["vk"]["IC"][0][:2] == [str(c["vk"]["IC"][0][0]), str(c["vk"]["IC"][0][1])] and res["vk"]["nPublic"] == 7
+
+
+# ---------------------------------------------------------------- the rollup circuit from JavaScript
+def _rollup_case(tmp_path, batch, depth, seed):
+    from test_rollup import as_inputs, scenario
+    txs, tree, privs = scenario(batch, depth, seed)
+    p = tmp_path / "rollup.json"
+    p.write_text(json.dumps(_stringify(dict(inputs=as_inputs(txs), root=tree.root, batch=batch, depth=depth, priv=privs[0],
+                                            msg=txs[0]["txData"][:5]))))
+    return str(p), txs, tree, privs
+
+
+def test_js_rollup_crypto_and_witness_match_the_oracle(tmp_path):
+    """index.js multiHash / genPublicKey / sign / verify == operator/src/utils/crypto.ts as restated by oracle/rollup.py
+    (pinned on the reference's key pairs); RollupCircuit.calculateWitness outputs the operator's new root
+    (processtx.test.ts:132-138) and refuses a tampered transaction as Circuit.calculateWitness does."""
+    import rollup as o
+    path, txs, tree, privs = _rollup_case(tmp_path, 2, 3, 61)
+    kat = json.load(open(os.path.join(ROOT, "tests", "golden", "rollup_kat.json")))["keypairs"][0]
+    out = _node("""
+      const z = require('./index.js'); const fs = require('fs');
+      const d = JSON.parse(fs.readFileSync(process.argv[1]));
+      const priv = BigInt(d.priv), msg = d.msg.map(BigInt);
+      const sig = z.sign(priv, msg), pub = z.genPublicKey(priv);
+      const c = new z.RollupCircuit(d.batch, d.depth);
+      const w = c.calculateWitness(d.inputs);
+      let thrown = null;
+      const bad = JSON.parse(JSON.stringify(d.inputs)); bad.txData[1][3] = (BigInt(bad.txData[1][3]) + 1n).toString();
+      try { c.calculateWitness(bad); } catch (e) { thrown = e.message; }
+      console.log(JSON.stringify({
+        h: z.multiHash([32767n]).toString(), lr: z.hashLeftRight(12345n, 45678n).toString(),
+        kat: z.genPublicKey(BigInt(process.argv[2])).map(String), pub: pub.map(String),
+        sig: [sig.R8[0], sig.R8[1], sig.S].map(String), ok: z.verify(msg, sig, pub), notok: z.verify(msg.map((v) => v + 1n), sig, pub),
+        geom: [c.nVars, c.nPublic, c.nConstraints, c.r1cs().length], wlen: w.byteLength,
+        pubsig: c.publicSignals(w).map(String), thrown }));
+    """, path, kat["priv"]).stdout
+    res = json.loads(out)
+    assert int(res["h"]) == o.multi_hash([32767]) and int(res["lr"]) == o.multi_hash([12345, 45678])
+    assert res["kat"] == kat["pub"]                                                  # scripts/index.js:108-112
+    assert tuple(int(v) for v in res["pub"]) == o.gen_public_key(privs[0])
+    assert tuple(int(v) for v in res["sig"]) == o.sign(privs[0], txs[0]["txData"][:5])
+    assert res["ok"] is True and res["notok"] is False
+    assert res["geom"][1] == 1 + 2 * (18 + 3 * 3) and res["wlen"] == 32 * res["geom"][0]
+    assert [int(v) for v in res["pubsig"]] == o.batch_public_signals(txs) and int(res["pubsig"][0]) == tree.root
+    assert res["thrown"] and "signature" in res["thrown"]
+
+
+@pytest.mark.gpu
+def test_js_operator_flow_on_the_tx_circuit(tmp_path):
+    """createProofGenerator (operator/src/snarks/common.ts:10-53) for the tx circuit with every step native: circuit ->
+    setup -> calculateWitness -> proof on the GPU -> isValid -> solidityProof; a changed public signal is refused."""
+    path, txs, tree, _ = _rollup_case(tmp_path, 2, 6, 62)
+    out = _node("""
+      const z = require('./index.js'); const fs = require('fs');
+      const d = JSON.parse(fs.readFileSync(process.argv[1]));
+      (async () => {
+        const circuit = new z.RollupCircuit();                       // tx.circom:3
+        const bn = await z.buildBn128();
+        const vk = bn.setupR1cs(circuit.r1cs());
+        const witnessBin = circuit.calculateWitness(d.inputs);
+        const publicSignals = circuit.publicSignals(witnessBin);
+        const proof = await bn.prove(witnessBin);
+        const valid = z.isValid(vk, proof, publicSignals);
+        const bad = publicSignals.slice(); bad[0] += 1n;
+        const sp = z.solidityProof(proof, publicSignals);
+        console.log(JSON.stringify({valid, invalid: z.isValid(vk, proof, bad), root: publicSignals[0].toString(), nInputs: sp.inputs.length,
+                                    info: bn.keyInfo(), nPublic: vk.nPublic}));
+      })().catch((e) => { console.error(e); process.exit(1); });
+    """, path).stdout
+    res = json.loads(out)
+    assert res["valid"] is True and res["invalid"] is False
+    assert int(res["root"]) == tree.root and res["nInputs"] == 73 and res["nPublic"] == 73
+    assert res["info"]["domainSize"] == 1 << 17

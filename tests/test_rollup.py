@@ -259,3 +259,29 @@ def test_balance_edge_is_exact():
     tx = o.process_tx_inputs(tree, accounts, 0, 1, 10 ** 18 - 10 ** 17 - 1, 10 ** 17, privs[0])
     w = ints(c.calculate_witness(as_inputs([tx])))
     assert w[1] == tree.root
+
+
+def test_product_side_operator_state_matches_the_oracle():
+    """zkr_hip.rollup.RollupState (native hash / signatures) builds the same circuit inputs and roots as the oracle's
+    state machine, including a transfer to oneself."""
+    import rollup as o
+    from zkr_hip import rollup as n
+    rnd = random.Random(71)
+    privs = [rnd.randrange(o.R) for _ in range(3)]
+    st, tree, accounts = n.RollupState(4), o.Tree(4), {}
+    for i, pv in enumerate(privs):
+        pub = o.gen_public_key(pv)
+        st.deposit(i, pub, 10 ** 19 + i, i)
+        accounts[i] = [*pub, 10 ** 19 + i, i]
+        tree.update(i, o.leaf_hash(pub, 10 ** 19 + i, i))
+    assert st.tree.root == tree.root and n.BalanceTree(4).root == o.Tree(4).root
+    txs_n, txs_o = [], []
+    for frm, to in ((0, 1), (1, 1), (2, 0), (0, 2)):
+        txs_n.append(st.transfer(frm, to, 10 ** 17 * (frm + 1), 10 ** 15, privs[frm]))
+        txs_o.append(o.process_tx_inputs(tree, accounts, frm, to, 10 ** 17 * (frm + 1), 10 ** 15, privs[frm]))
+        want = dict(txs_o[-1])
+        assert want.pop("newBalanceTreeRoot") == st.tree.root == tree.root
+        assert txs_n[-1] == want
+    c = n.RollupCircuit(4, 4)
+    wb = c.calculate_witness(st.batch_inputs(txs_n))
+    assert c.public_signals(wb) == o.batch_public_signals(txs_o)
