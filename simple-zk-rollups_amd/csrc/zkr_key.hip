@@ -58,7 +58,11 @@ MsmPlan msm_plan(size_t n_scalars, size_t n, int c_fixed) {
   pl.K = (255 + c - 1) / c;
   pl.nbw = 1u << (c - 1);
   pl.nb = pl.nbw;
-  int glog = 5;  // bucket reduction: groups of 32 buckets (kernels_msm.hpp msm_reduce1_kernel): 108 / 110 / 113 / 105 proofs/s at 8 / 16 / 32 / 64
+  // bucket reduction in groups of 2^glog buckets (kernels_msm.hpp msm_reduce1_kernel: a chain of 2 * 2^glog - 2 additions
+  // per thread).  At 2^19 buckets groups of 32 measured best (108 / 110 / 113 / 105 proofs/s at 8 / 16 / 32 / 64); with
+  // fewer buckets the chip is not filled and the chain length is what counts: keep about 2^14 groups
+  // (tx circuit, 2^16 buckets: 233 / 320 / 349 / 351 / 322 proofs/s at 32 / 16 / 8 / 4 / 2)
+  int glog = c - 1 - 14 < 2 ? 2 : c - 1 - 14 > 5 ? 5 : c - 1 - 14;
   if (const char *e = getenv("ZKR_MSM_GLOG")) { int v = atoi(e); if (v >= 1 && v <= 6) glog = v; }
   pl.glog = c - 1 < glog ? c - 1 : glog;
   uint64_t mean = (uint64_t)n * pl.K / pl.nbw + 1;
