@@ -184,6 +184,12 @@ int zkr_eddsa_verify(const uint8_t *msg, size_t n, const uint8_t sig[96], const 
  * (nVars x 32 B, the buffer binarifyWitness would produce; free with zkr_free); inputs that violate the circuit fail
  * with ZKR_ERR_UNSATISFIED and a message naming the first violated statement.  The constraint system is this build's
  * own formulation of the circuit (see csrc/rollup.cpp): its keys come from zkr_setup_r1cs, not from a circom build. */
+/* Withdraw() (prover/circuits/withdraw.circom:4-25): public signals publicKey[0], publicKey[1], nullifier; the private
+ * input is the FORMATTED key, zkr_babyjub_format_privkey = formatPrivKeyForBabyJub (crypto.ts:58-76), as in
+ * prover/__tests__/withdraw.test.ts:22-25.  Same conventions as the two calls below. */
+int zkr_babyjub_format_privkey(const uint8_t priv[32], uint8_t out[32]);
+int zkr_withdraw_r1cs(void **r1cs_bin, size_t *r1cs_len);
+int zkr_withdraw_witness(const uint8_t private_key[32], const uint8_t nullifier[32], void **witness_bin, size_t *witness_len);
 int zkr_rollup_info(uint32_t batch, uint32_t depth, uint32_t *n_vars, uint32_t *n_public, uint32_t *n_constraints);
 int zkr_rollup_r1cs(uint32_t batch, uint32_t depth, void **r1cs_bin, size_t *r1cs_len);
 int zkr_rollup_witness(uint32_t batch, uint32_t depth, const uint8_t *inputs, size_t n_inputs, void **witness_bin, size_t *witness_len);

@@ -4,7 +4,7 @@
 //     `formatPrivKeyForBabyJub` / `genPublicKey` (:58-84), EdDSA-MiMCSponge `sign` / `verify` (:143-177);
 //   * a constraint system + witness builder for `BatchProcessTx(batch, depth)`
 //     (/root/reference/prover/circuits/batchprocesstx.circom:3-75 over processtx.circom:10-193, eddsa.circom:12-139,
-//     merkletree.circom:5-84, hasher.circom:3-30): one pass of the gadget program below allocates the signals, emits
+//     merkletree.circom:5-84, hasher.circom:3-30) and for `Withdraw()` (withdraw.circom:4-25): one pass of the gadget program below allocates the signals, emits
 //     the rank-1 constraints in the r1cs_bin layout of zkr_setup_r1cs (include/zkr.h) and computes the witness, checking
 //     every constraint as it goes -- what `Circuit.calculateWitness` (operator/src/snarks/common.ts:15-17) does for the
 //     circom build.  Public signals keep circom's order (output, then the inputs in declaration order; 73 for (2, 6)).
@@ -843,6 +843,20 @@ static bool batch_witness(uint32_t batch, uint32_t depth, const Fr *inputs, std:
   return true;
 }
 
+// Withdraw() (withdraw.circom:4-25 over publickeyderivation.circom:5-27): signals 1, 2 = publicKey (outputs),
+// 3 = nullifier (public input), 4 = privateKey (private input: the formatted key, crypto.ts:58-76).
+static void withdraw_gadget(Builder &B, const Fr &priv, const Fr &nullifier) {
+  B.alloc(Fr::zero());
+  B.alloc(Fr::zero());
+  LC nul = B.sig(B.alloc(nullifier)), key = B.sig(B.alloc(priv));
+  std::vector<LC> bits = num2bits(B, key, 253, "private key fits 253 bits");  // publickeyderivation.circom:12-13
+  PtL pk = scalar_mul_base8(B, bits);                                          // :20-23
+  multihash_gadget(B, {pk.x, pk.y, nul});                                      // withdraw.circom:15-19 (binds the nullifier)
+  B.w[1] = pk.x.v, B.w[2] = pk.y.v;
+  B.enforce(pk.x, Builder::one(), B.sig(1), "publicKey[0]");                   // :21-22
+  B.enforce(pk.y, Builder::one(), B.sig(2), "publicKey[1]");
+}
+
 static int check_geometry(uint32_t batch, uint32_t depth) {
   if (batch < 1 || batch > 4096 || depth < 1 || depth > 32) {
     set_error("rollup circuit: batch %u / depth %u out of range (1..4096, 1..32)", batch, depth);
@@ -910,6 +924,45 @@ int zkr_eddsa_verify(const uint8_t *msg, size_t n, const uint8_t sig[96], const 
   for (int i = 0; i < 2; i++)
     if (!fr_read_std(pub + 32 * i, a[i])) return ZKR_OK;
   *valid = verify_host(multihash_host(m.data(), n), s[0], s[1], s[2], a[0], a[1]) ? 1 : 0;
+  return ZKR_OK;
+}
+
+int zkr_babyjub_format_privkey(const uint8_t priv[32], uint8_t out[32]) {
+  Fr k;
+  if (!priv || !out) { set_error("null argument"); return ZKR_ERR_ARG; }
+  if (!fr_read_std(priv, k)) { set_error("private key >= r"); return ZKR_ERR_ARG; }
+  uint32_t s[8];
+  pruned_secret(hex_text(multihash_host(&k, 1)), s);
+  shr3(s);
+  memcpy(out, s, 32);
+  return ZKR_OK;
+}
+
+int zkr_withdraw_r1cs(void **r1cs_bin, size_t *r1cs_len) {
+  if (!r1cs_bin || !r1cs_len) { set_error("null argument"); return ZKR_ERR_ARG; }
+  Builder B(true, false);
+  B.out.resize(12);
+  withdraw_gadget(B, Fr::zero(), Fr::zero());
+  uint32_t hdr[3] = {(uint32_t)B.w.size(), 3, B.n_constraints};
+  memcpy(B.out.data(), hdr, 12);
+  *r1cs_bin = dup_bytes(B.out.data(), B.out.size());
+  *r1cs_len = B.out.size();
+  if (!*r1cs_bin) { set_error("out of memory"); return ZKR_ERR_ARG; }
+  return ZKR_OK;
+}
+
+int zkr_withdraw_witness(const uint8_t private_key[32], const uint8_t nullifier[32], void **witness_bin, size_t *witness_len) {
+  if (!private_key || !nullifier || !witness_bin || !witness_len) { set_error("null argument"); return ZKR_ERR_ARG; }
+  Fr k, nul;
+  if (!fr_read_std(private_key, k) || !fr_read_std(nullifier, nul)) { set_error("input >= r"); return ZKR_ERR_ARG; }
+  Builder B(false, true);
+  withdraw_gadget(B, k, nul);
+  if (!B.err.empty()) { set_error("withdraw circuit violates: %s", B.err.c_str()); return ZKR_ERR_UNSATISFIED; }
+  std::vector<uint8_t> out(32 * B.w.size());
+  for (size_t i = 0; i < B.w.size(); i++) fr_write_std(&out[32 * i], B.w[i]);
+  *witness_bin = dup_bytes(out.data(), out.size());
+  *witness_len = out.size();
+  if (!*witness_bin) { set_error("out of memory"); return ZKR_ERR_ARG; }
   return ZKR_OK;
 }
 

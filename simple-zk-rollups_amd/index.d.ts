@@ -42,6 +42,7 @@ export interface Signature { R8: [bigint, bigint]; S: bigint; }
 export function multiHash(values: Array<bigint | string | number>): bigint;
 export function hashLeftRight(left: bigint, right: bigint): bigint;
 export function genPublicKey(privKey: bigint): [bigint, bigint];
+export function formatPrivKeyForBabyJub(privKey: bigint): bigint;
 export function sign(privKey: bigint, msg: Array<bigint | string | number>): Signature;
 export function verify(msg: Array<bigint | string | number>, sig: Signature, pubKey: [bigint, bigint]): boolean;
 /** BatchProcessTx(batch, depth) (tx.circom = (2, 6)) as constraint system + witness builder. */
@@ -51,5 +52,12 @@ export class RollupCircuit {
   r1cs(): Uint8Array;
   /** circuitInputs as the reference builds them (one array per input signal over the batch); throws where Circuit.calculateWitness would. */
   calculateWitness(circuitInputs: { [signal: string]: any } | Array<bigint | string>): ArrayBuffer;
+  publicSignals(witnessBin: ArrayBuffer): bigint[];
+}
+/** Withdraw() (withdraw.circom): public signals publicKey[0], publicKey[1], nullifier. */
+export class WithdrawCircuit {
+  readonly nPublic: number;
+  r1cs(): Uint8Array;
+  calculateWitness(circuitInputs: { privateKey: bigint | string; nullifier: bigint | string }): ArrayBuffer;
   publicSignals(witnessBin: ArrayBuffer): bigint[];
 }

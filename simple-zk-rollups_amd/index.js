@@ -227,6 +227,8 @@ function multiHash(values) { return leToBigInts(native().rollupCrypto(0, concatL
 const hashLeftRight = (l, r) => multiHash([l, r]);
 // genPublicKey(privKey) (crypto.ts:78-84)
 function genPublicKey(priv) { return leToBigInts(native().rollupCrypto(1, bigintToLe32(priv))); }
+// formatPrivKeyForBabyJub(privKey) (crypto.ts:58-76): the scalar the circuits take as `privateKey`
+function formatPrivKeyForBabyJub(priv) { return leToBigInts(native().rollupCrypto(4, bigintToLe32(priv)))[0]; }
 // sign(prv, msg) -> { R8: [x, y], S } (crypto.ts:143-168); verify(msg, sig, pubKey) (:170-177)
 function sign(priv, msg) {
   const v = leToBigInts(native().rollupCrypto(2, bigintToLe32(priv), concatLe(msg)));
@@ -265,10 +267,22 @@ class RollupCircuit {
   publicSignals(witnessBin) { return leToBigInts(Buffer.from(witnessBin, 32, 32 * this.nPublic)); }
 }
 
+// Withdraw() (prover/circuits/withdraw.circom:4-25): public signals publicKey[0], publicKey[1], nullifier
+class WithdrawCircuit {
+  constructor() { this.nPublic = 3; }
+  r1cs() { return native().withdrawCircuit(null); }
+  // circuitInputs = { privateKey: formatPrivKeyForBabyJub(priv), nullifier }  (withdraw.test.ts:22-25)
+  calculateWitness(circuitInputs) {
+    const w = native().withdrawCircuit(bigintToLe32(BigInt(circuitInputs.privateKey)), bigintToLe32(BigInt(circuitInputs.nullifier) % R));
+    return w.buffer.slice(w.byteOffset, w.byteOffset + w.byteLength);
+  }
+  publicSignals(witnessBin) { return leToBigInts(Buffer.from(witnessBin, 32, 96)); }
+}
+
 module.exports = {
   buildBn128, genProof, binarifyWitness, binarifyProvingKey, solidityProof, proofFromBytes, isValid, binarifyVerifyingKey,
   binarifyR1cs, verifyingKeyFromBytes,
-  multiHash, hashLeftRight, genPublicKey, sign, verify, RollupCircuit,
+  multiHash, hashLeftRight, genPublicKey, formatPrivKeyForBabyJub, sign, verify, RollupCircuit, WithdrawCircuit,
   deviceCount: () => { native(); return deviceCount; },
   version: () => native().version(),
 };

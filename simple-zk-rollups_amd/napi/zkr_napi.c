@@ -31,6 +31,9 @@ static struct {
   int (*pubkey)(const uint8_t *, uint8_t *);
   int (*eddsa_sign)(const uint8_t *, const uint8_t *, size_t, uint8_t *);
   int (*eddsa_verify)(const uint8_t *, size_t, const uint8_t *, const uint8_t *, int *);
+  int (*format_privkey)(const uint8_t *, uint8_t *);
+  int (*withdraw_r1cs)(void **, size_t *);
+  int (*withdraw_witness)(const uint8_t *, const uint8_t *, void **, size_t *);
   int (*rollup_info)(uint32_t, uint32_t, uint32_t *, uint32_t *, uint32_t *);
   int (*rollup_r1cs)(uint32_t, uint32_t, void **, size_t *);
   int (*rollup_witness)(uint32_t, uint32_t, const uint8_t *, size_t, void **, size_t *);
@@ -72,6 +75,7 @@ static napi_value js_load(napi_env env, napi_callback_info info) {
     SYM(key_load_websnark, "zkr_key_load_websnark") SYM(key_free, "zkr_key_free") SYM(key_info, "zkr_key_info") SYM(prove, "zkr_prove") SYM(verify, "zkr_verify")
     SYM(setup_r1cs, "zkr_setup_r1cs") SYM(key_save, "zkr_key_save") SYM(key_load_file, "zkr_key_load_file") SYM(free_, "zkr_free")
     SYM(multihash, "zkr_mimcsponge_multihash") SYM(pubkey, "zkr_babyjub_pubkey") SYM(eddsa_sign, "zkr_eddsa_sign") SYM(eddsa_verify, "zkr_eddsa_verify")
+    SYM(format_privkey, "zkr_babyjub_format_privkey") SYM(withdraw_r1cs, "zkr_withdraw_r1cs") SYM(withdraw_witness, "zkr_withdraw_witness")
     SYM(rollup_info, "zkr_rollup_info") SYM(rollup_r1cs, "zkr_rollup_r1cs") SYM(rollup_witness, "zkr_rollup_witness")
     Z.handle = h;
   }
@@ -292,7 +296,7 @@ static napi_value js_verify(napi_env env, napi_callback_info info) {
 
 /* ---- the rollup circuit without circom / snarkjs (include/zkr.h); all synchronous host work ---- */
 /* rollupCrypto(op, a, b, c): op 0 multiHash(values) -> 32 B; 1 pubKey(priv32) -> 64 B; 2 sign(priv32, msg) -> 96 B;
- * 3 verify(msg, sig96, pub64) -> boolean.  Field elements are 32 B little-endian (operator/src/utils/crypto.ts). */
+ * 3 verify(msg, sig96, pub64) -> boolean; 4 formatPrivKeyForBabyJub(priv32) -> 32 B.  Field elements are 32 B little-endian (operator/src/utils/crypto.ts). */
 static napi_value js_rollup_crypto(napi_env env, napi_callback_info info) {
   size_t argc = 4;
   napi_value argv[4];
@@ -327,6 +331,10 @@ static napi_value js_rollup_crypto(napi_env env, napi_callback_info info) {
       if (rc) return throw_msg(env, Z.last_error());
       NAPI_OK(napi_get_boolean(env, ok != 0, &res));
       return res;
+    case 4:
+      if (al != 32) return throw_msg(env, "formatPrivKeyForBabyJub: the private key is 32 bytes");
+      rc = Z.format_privkey(a, out), out_len = 32;
+      break;
     default:
       return throw_msg(env, "rollupCrypto: unknown operation");
   }
@@ -377,6 +385,33 @@ static napi_value js_rollup_circuit(napi_env env, napi_callback_info info) {
   return buf;
 }
 
+/* withdrawCircuit(privateKey32|null, nullifier32): null -> r1csBin Buffer; else the witness (Buffer) of Withdraw()
+ * (prover/circuits/withdraw.circom:4-25). */
+static napi_value js_withdraw_circuit(napi_env env, napi_callback_info info) {
+  size_t argc = 2;
+  napi_value argv[2];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  if (!Z.handle) return throw_msg(env, "libzkr_hip.so not loaded");
+  napi_valuetype t = napi_null;
+  if (argc > 0) napi_typeof(env, argv[0], &t);
+  void *blob = NULL, *copy;
+  size_t len = 0;
+  napi_value buf;
+  if (t == napi_null || t == napi_undefined) {
+    if (Z.withdraw_r1cs(&blob, &len)) return throw_msg(env, Z.last_error());
+  } else {
+    const uint8_t *k, *nul;
+    size_t kl, nl;
+    if (argc < 2 || !get_bytes(env, argv[0], &k, &kl) || !get_bytes(env, argv[1], &nul, &nl) || kl != 32 || nl != 32)
+      return throw_msg(env, "withdrawCircuit(privateKey32, nullifier32)");
+    if (Z.withdraw_witness(k, nul, &blob, &len)) return throw_msg(env, Z.last_error());
+  }
+  napi_status st = napi_create_buffer_copy(env, len, blob, &copy, &buf);
+  Z.free_(blob);
+  if (st != napi_ok) return throw_msg(env, "zkr_napi: cannot allocate the result buffer");
+  return buf;
+}
+
 static napi_value init(napi_env env, napi_value exports) {
   napi_property_descriptor props[] = {
       {"load", NULL, js_load, NULL, NULL, NULL, napi_default, NULL},       {"version", NULL, js_version, NULL, NULL, NULL, napi_default, NULL},
@@ -385,6 +420,7 @@ static napi_value init(napi_env env, napi_value exports) {
       {"setupR1cs", NULL, js_setup_r1cs, NULL, NULL, NULL, napi_default, NULL}, {"keySave", NULL, js_key_save, NULL, NULL, NULL, napi_default, NULL},
       {"keyLoadFile", NULL, js_key_load_file, NULL, NULL, NULL, napi_default, NULL},
       {"rollupCrypto", NULL, js_rollup_crypto, NULL, NULL, NULL, napi_default, NULL}, {"rollupCircuit", NULL, js_rollup_circuit, NULL, NULL, NULL, napi_default, NULL},
+      {"withdrawCircuit", NULL, js_withdraw_circuit, NULL, NULL, NULL, napi_default, NULL},
   };
   napi_define_properties(env, exports, sizeof(props) / sizeof(props[0]), props);
   return exports;

@@ -66,6 +66,9 @@ def lib():
     L.zkr_babyjub_pubkey.argtypes = [u8p, u8p]
     L.zkr_eddsa_sign.argtypes = [u8p, u8p, sz, u8p]
     L.zkr_eddsa_verify.argtypes = [u8p, sz, u8p, u8p, c.POINTER(i)]
+    L.zkr_babyjub_format_privkey.argtypes = [u8p, u8p]
+    L.zkr_withdraw_r1cs.argtypes = [c.POINTER(vp), c.POINTER(sz)]
+    L.zkr_withdraw_witness.argtypes = [u8p, u8p, c.POINTER(vp), c.POINTER(sz)]
     L.zkr_rollup_info.argtypes = [c.c_uint32, c.c_uint32, c.POINTER(c.c_uint32), c.POINTER(c.c_uint32), c.POINTER(c.c_uint32)]
     L.zkr_rollup_r1cs.argtypes = [c.c_uint32, c.c_uint32, c.POINTER(vp), c.POINTER(sz)]
     L.zkr_rollup_witness.argtypes = [c.c_uint32, c.c_uint32, u8p, sz, c.POINTER(vp), c.POINTER(sz)]

@@ -43,6 +43,13 @@ def gen_public_key(priv):
     return tuple(_ints(out.raw))
 
 
+def format_priv_key(priv) -> int:
+    """formatPrivKeyForBabyJub(privKey) (crypto.ts:58-76): the scalar the circuits take as `privateKey`."""
+    out = ctypes.create_string_buffer(32)
+    _check(lib().zkr_babyjub_format_privkey(_le(priv), out))
+    return int.from_bytes(out.raw, "little")
+
+
 def sign(priv, msg):
     """sign(prv, msg) (crypto.ts:143-168) -> {"R8": (x, y), "S": s}."""
     buf = b"".join(_le(v) for v in msg)
@@ -106,6 +113,25 @@ class RollupCircuit:
     def public_signals(self, witness_bin: bytes):
         """witness.slice(1, nPubInputs + nOutputs + 1) (common.ts:18-21)."""
         return _ints(witness_bin[32:32 * (self.n_public + 1)])
+
+
+class WithdrawCircuit:
+    """Withdraw() (prover/circuits/withdraw.circom:4-25): public signals publicKey[0], publicKey[1], nullifier."""
+    n_public = 3
+
+    def r1cs(self) -> bytes:
+        p, n = ctypes.c_void_p(), ctypes.c_size_t()
+        _check(lib().zkr_withdraw_r1cs(ctypes.byref(p), ctypes.byref(n)))
+        return _take(p, n.value)
+
+    def calculate_witness(self, inputs) -> bytes:
+        """inputs = {"privateKey": formatted key, "nullifier": ...} (withdraw.test.ts:22-25)."""
+        p, n = ctypes.c_void_p(), ctypes.c_size_t()
+        _check(lib().zkr_withdraw_witness(_le(int(inputs["privateKey"])), _le(int(inputs["nullifier"]) % SNARK_FIELD_SIZE), ctypes.byref(p), ctypes.byref(n)))
+        return _take(p, n.value)
+
+    def public_signals(self, witness_bin: bytes):
+        return _ints(witness_bin[32:128])
 
 
 class BalanceTree:

@@ -62,3 +62,27 @@ def test_batch_of_four_depth_five_like_the_reference_test():
     proof = key.prove(wb)
     assert zkr_hip.verify(vk_bin, proof, pub)
     assert not zkr_hip.verify(vk_bin, proof, [pub[0]] + [pub[2], pub[1]] + pub[3:])
+
+
+def test_withdraw_circuit_proof_matches_closed_form_and_verifies():
+    """genWithdrawVerifierProof (operator/src/snarks/withdraw.ts:6-10; contracts/__tests__/withdrawverifier.test.ts:24-65)
+    with every step native: the proof verifies, its public signals are (publicKey, nullifier), a changed one fails."""
+    import zkr_hip
+    from zkr_hip import rollup as n
+    c = n.WithdrawCircuit()
+    r1cs = c.r1cs()
+    tox = g.toxic_from_seed(0x5A4B00F4)
+    key, vk_bin = zkr_hip.ProvingKey.setup_r1cs(r1cs, toxic=[tox[k] for k in ("t", "alfa", "beta", "gamma", "delta")])
+    priv = 4884893312420666846728788329068334659645814268254376926932808574485660215402      # scripts/index.js:108
+    wb = c.calculate_witness({"privateKey": n.format_priv_key(priv), "nullifier": 123456789})
+    pub = c.public_signals(wb)
+    assert pub == [1503249839729450699258568253188655641897688629727284476088280559686550009373,
+                   5002035132060692260001110027450125171390191669020671174899856008595079807949, 123456789]   # index.js:109-112
+    rng = g.SplitMix64(5)
+    r, s = rng.fr(), rng.fr()
+    proof = key.prove(wb, r, s)
+    assert zkr_hip.verify(vk_bin, proof, pub)
+    assert not zkr_hip.verify(vk_bin, proof, pub[:2] + [pub[2] + 1])            # withdrawverifier.test.ts:56-65
+    nv, npub, cons = parse_r1cs(r1cs)
+    circ = dict(nVars=nv, nPublic=npub, nConstraints=len(cons), domainSize=g.domain_size(len(cons), npub), rows=cons)
+    assert proof == g.proof_bytes(g.proof_from_toxic(circ, tox, ints(wb), r, s))

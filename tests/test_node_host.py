@@ -210,7 +210,9 @@ def test_js_rollup_crypto_and_witness_match_the_oracle(tmp_path):
         kat: z.genPublicKey(BigInt(process.argv[2])).map(String), pub: pub.map(String),
         sig: [sig.R8[0], sig.R8[1], sig.S].map(String), ok: z.verify(msg, sig, pub), notok: z.verify(msg.map((v) => v + 1n), sig, pub),
         geom: [c.nVars, c.nPublic, c.nConstraints, c.r1cs().length], wlen: w.byteLength,
-        pubsig: c.publicSignals(w).map(String), thrown }));
+        pubsig: c.publicSignals(w).map(String), thrown,
+        fmt: z.formatPrivKeyForBabyJub(priv).toString(),
+        wd: (() => { const wc = new z.WithdrawCircuit(); return wc.publicSignals(wc.calculateWitness({privateKey: z.formatPrivKeyForBabyJub(priv), nullifier: 77n})).map(String); })() }));
     """, path, kat["priv"]).stdout
     res = json.loads(out)
     assert int(res["h"]) == o.multi_hash([32767]) and int(res["lr"]) == o.multi_hash([12345, 45678])
@@ -221,6 +223,8 @@ def test_js_rollup_crypto_and_witness_match_the_oracle(tmp_path):
     assert res["geom"][1] == 1 + 2 * (18 + 3 * 3) and res["wlen"] == 32 * res["geom"][0]
     assert [int(v) for v in res["pubsig"]] == o.batch_public_signals(txs) and int(res["pubsig"][0]) == tree.root
     assert res["thrown"] and "signature" in res["thrown"]
+    assert int(res["fmt"]) == o.format_priv_key(privs[0])
+    assert [int(v) for v in res["wd"]] == [*o.gen_public_key(privs[0]), 77]                  # withdraw.test.ts:27-36
 
 
 @pytest.mark.gpu

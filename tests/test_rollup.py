@@ -285,3 +285,29 @@ def test_product_side_operator_state_matches_the_oracle():
     c = n.RollupCircuit(4, 4)
     wb = c.calculate_witness(st.batch_inputs(txs_n))
     assert c.public_signals(wb) == o.batch_public_signals(txs_o)
+
+
+def test_withdraw_circuit_derives_the_public_key():
+    """prover/__tests__/withdraw.test.ts:27-36 / publickeyderivation.test.ts:26-34: main.publicKey == genPublicKey(priv)
+    for privateKey = formatPrivKeyForBabyJub(priv); here also on the reference's fixed key pairs."""
+    import rollup as o
+    import zkr_hip
+    from zkr_hip import rollup as n
+    c = n.WithdrawCircuit()
+    nv, npub, cons = parse_r1cs(c.r1cs())
+    assert npub == 3
+    rnd = random.Random(81)
+    cases = [(int(kp["priv"]), tuple(int(v) for v in kp["pub"])) for kp in _kat()["keypairs"]] + [(pv, o.gen_public_key(pv)) for pv in (rnd.randrange(o.R), 0)]
+    for priv, pub in cases:
+        fk = n.format_priv_key(priv)
+        assert fk == o.format_priv_key(priv) and fk < 1 << 253
+        nul = rnd.randrange(o.R)
+        wb = c.calculate_witness({"privateKey": fk, "nullifier": nul})
+        w = ints(wb)
+        assert len(w) == nv and first_violated(cons, w, o.R) == -1
+        assert c.public_signals(wb) == [pub[0], pub[1], nul]
+    used = {s for row in cons for lc in row for s, _c in lc}
+    assert set(range(1, nv)) <= used
+    with pytest.raises(zkr_hip.ZkrError) as e:
+        c.calculate_witness({"privateKey": 1 << 253, "nullifier": 1})     # Num2Bits(253), publickeyderivation.circom:12-13
+    assert e.value.code == -7
