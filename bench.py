@@ -225,7 +225,7 @@ def main():
             verified += 1
 
     # host-buffer boundary (zkr_prove: pageable witness over PCIe inside the call) -- reported, never `value`
-    pcie_rate = None
+    pcie_rate = pcie_rate_conc = None
     if rank == 0 and world == 1:
         hw = bytes(wits[0].cpu().numpy().tobytes())
         key.prove(hw, 5, 7)
@@ -233,6 +233,17 @@ def main():
         for i in range(3):
             key.prove(hw, 11 + i, 13 + i)
         pcie_rate = 3.0 / (time.perf_counter() - t1)
+        # the same boundary as concurrent callers use it (libuv workers behind Promise.all in index.js: every call
+        # brings its pageable host witness; the library keeps two proofs in flight per key)
+        import threading
+        n_thr, per_thr = 3, 8
+        ths = [threading.Thread(target=lambda j=j: [key.prove(hw, 100 + 10 * j + i, 200 + 10 * j + i) for i in range(per_thr)]) for j in range(n_thr)]
+        t1 = time.perf_counter()
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        pcie_rate_conc = n_thr * per_thr / (time.perf_counter() - t1)
 
     if rank == 0:
         total_proofs = args.steps * world
@@ -305,6 +316,7 @@ def main():
             "key": {"arena_bytes": arena_bytes, "setup_s": setup_s, "bcast_s": bcast_s if world > 1 else None,
                     "bcast_GBps": (arena_bytes / bcast_s / 1e9) if world > 1 and bcast_s > 0 else None},  # one RCCL broadcast over xGMI (153 GB/s per link)
             "pcie_inclusive_proofs_per_s": pcie_rate,
+            "pcie_inclusive_concurrent_callers_proofs_per_s": pcie_rate_conc,
             "proofs_verified": verified,
             "hbm_whole_proof": None if proof_traffic is None else {
                 "bytes_per_proof": proof_traffic, "GBps_per_gpu": proof_traffic / (elapsed / args.steps) / 1e9,
