@@ -10,16 +10,21 @@ def shard_indices(count, rank, world):
     return list(range(rank, count, world))
 
 
-def broadcast_arena(arena, rank, dist, device):
+ARENA_CHUNK = 1 << 30
+
+
+def broadcast_arena(arena, rank, dist, device, chunk=ARENA_CHUNK):
     """Broadcast a uint8 tensor (the key arena) from rank 0; other ranks pass None and get a new tensor
-    on `device`.  Two collectives: the length, then the bytes."""
+    on `device`.  The length, then the bytes in 1 GiB pieces (arenas reach 78 GB at 2^24: every collective stays far
+    below any 32-bit element count)."""
     n = torch.zeros(1, dtype=torch.int64, device=device)
     if rank == 0:
         n[0] = arena.numel()
     dist.broadcast(n, src=0)
     if rank != 0:
         arena = torch.empty(int(n.item()), dtype=torch.uint8, device=device)
-    dist.broadcast(arena, src=0)
+    for off in range(0, arena.numel(), chunk):
+        dist.broadcast(arena[off:off + chunk], src=0)
     return arena
 
 

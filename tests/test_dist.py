@@ -37,7 +37,7 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     g = torch.Generator().manual_seed(1234)
     arena = torch.randint(0, 256, (100_003,), dtype=torch.uint8, generator=g) if rank == 0 else None
-    arena = zkr_hip.broadcast_arena(arena, rank, dist, torch.device("cpu"))
+    arena = zkr_hip.broadcast_arena(arena, rank, dist, torch.device("cpu"), chunk=30_000)   # four pieces, the last one short
     key = _FakeKey(arena)
     count = 9
     witnesses = [bytes([i]) * 64 for i in range(count)]
