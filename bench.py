@@ -17,6 +17,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "simple-zk-rollups_amd", "python"))
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# Group additions in units of one Fq Montgomery multiplication (136 32x32 multiply-adds).  The Y coordinate of an
+# addition is a difference of two products computed with ONE reduction (csrc/field_fused.hpp: 200 multiply-adds for an
+# Fq pair, 2 x 328 for an Fq2 pair), an Fq2 product is two such sums (400), an Fq2 square two products (272):
+MADD_G1 = (8 * 136 + 200) / 136.0                 # XYZZ += affine, 8M + 2S                    -> 9.47
+MADD_G2 = (6 * 400 + 2 * 272 + 656) / 136.0       # the same over Fq2                          -> 26.47
+ADD_G1 = (12 * 136 + 200) / 136.0                 # XYZZ += XYZZ, 12M + 2S                     -> 13.47
+ADD_G2 = (10 * 400 + 2 * 272 + 656) / 136.0       # the same over Fq2                          -> 38.24
 CIRCUIT_SEED, TOXIC_SEED, N_PUBLIC = 0x5A4B0001, 0x5A4B00FF, 73
 
 
@@ -253,8 +260,8 @@ def main():
         g1_pts = info["ptsA"] + info["ptsB1"] + info["ptsC"] + info["ptsH"]
         win = key.windows()  # K mixed additions per point (one per window level of the key table)
         cands = {
-            "msm_accum_kernel<Fq>": ("msm_accum_g1", 96.0 * g1_pts / 4.0, 10.0 * g1_pts / 4.0 * win["A"][1]),
-            "msm_accum_kernel<Fq2>": ("msm_accum_g2", 160.0 * info["ptsB2"], 28.0 * info["ptsB2"] * win["B2"][1]),
+            "msm_accum_kernel<Fq>": ("msm_accum_g1", 96.0 * g1_pts / 4.0, MADD_G1 * g1_pts / 4.0 * win["A"][1]),
+            "msm_accum_kernel<Fq2>": ("msm_accum_g2", 160.0 * info["ptsB2"], MADD_G2 * info["ptsB2"] * win["B2"][1]),
         }
         dom, best = None, -1.0
         for name, (st, _, _) in cands.items():
@@ -290,13 +297,13 @@ def main():
                                 "achieved_fq_mul_per_s_G": gm, "frac": gm / peak_gmul,
                                 "window_bits": win["A"][0], "additions_per_point": win["A"][1]}
             # whole proof: every field multiplication of the path (Fq and Fr cost the same) over the time per proof.
-            # mixed addition 10 (G1) / 28 (G2) per table entry; NTT: 6 transforms of (m/2) log2 m butterflies + 5m
-            # element-wise products; QAP rows: one per non-zero; bucket reduction: 2 full additions (14 / 40) per
+            # mixed addition MADD_G1 / MADD_G2 per table entry (in 136-mad32 units, see the constants at the top); NTT: 6 transforms of (m/2) log2 m butterflies + 5m
+            # element-wise products; QAP rows: one per non-zero; bucket reduction: 2 full additions (ADD_G1 / ADD_G2) per
             # bucket + the group sums (about 8 per group of 32 buckets)
             m, lg = info["domainSize"], info["domainSize"].bit_length() - 1
             nb = 1 << (win["A"][0] - 1)
-            red = (2 * nb + 8 * (nb >> 5)) * (14 * 4 + 40)
-            total_mul = (10.0 * g1_pts * win["A"][1] + 28.0 * info["ptsB2"] * win["B2"][1] + 6 * (m // 2) * lg + 5 * m
+            red = (2 * nb + 8 * (nb >> 5)) * (ADD_G1 * 4 + ADD_G2)
+            total_mul = (MADD_G1 * g1_pts * win["A"][1] + MADD_G2 * info["ptsB2"] * win["B2"][1] + 6 * (m // 2) * lg + 5 * m
                          + info["nnzA"] + info["nnzB"] + red)
             gw = total_mul / (elapsed / args.steps) / 1e9
             roofline["valu"]["whole_proof"] = {"fq_mul_per_proof": total_mul, "achieved_fq_mul_per_s_G": gw, "frac": gw / peak_gmul}

@@ -41,7 +41,7 @@ ZKR_HD XYZZ<F> dbl_affine(const Affine<F> &p) {
   F xx = sqr(p.x);
   F m = add(dbl(xx), xx);
   F x3 = sub(sqr(m), dbl(s));
-  F y3 = sub(mul(m, sub(s, x3)), mul(w, p.y));
+  F y3 = mul_sub(m, sub(s, x3), w, p.y);
   return XYZZ<F>{x3, y3, v, w};
 }
 
@@ -55,7 +55,7 @@ ZKR_HD XYZZ<F> dbl_xyzz_inl(const XYZZ<F> &p) {
   F xx = sqr(p.x);
   F m = add(dbl(xx), xx);
   F x3 = sub(sqr(m), dbl(s));
-  F y3 = sub(mul(m, sub(s, x3)), mul(w, p.y));
+  F y3 = mul_sub(m, sub(s, x3), w, p.y);
   return XYZZ<F>{x3, y3, mul(v, p.zz), mul(w, p.zzz)};
 }
 
@@ -82,7 +82,7 @@ ZKR_HD XYZZ<F> add_mixed(const XYZZ<F> &acc, const Affine<F> &q_in, bool neg_q =
   F ppp = mul(p, pp);
   F qq = mul(acc.x, pp);
   F x3 = sub(sub(sqr(r), ppp), dbl(qq));
-  F y3 = sub(mul(r, sub(qq, x3)), mul(acc.y, ppp));
+  F y3 = mul_sub(r, sub(qq, x3), acc.y, ppp);
   return XYZZ<F>{x3, y3, mul(acc.zz, pp), mul(acc.zzz, ppp)};
 }
 
@@ -105,7 +105,7 @@ ZKR_HD XYZZ<F> add_full_inl(const XYZZ<F> &a, const XYZZ<F> &b) {
   F ppp = mul(p, pp);
   F qq = mul(u1, pp);
   F x3 = sub(sub(sqr(r), ppp), dbl(qq));
-  F y3 = sub(mul(r, sub(qq, x3)), mul(s1, ppp));
+  F y3 = mul_sub(r, sub(qq, x3), s1, ppp);
   return XYZZ<F>{x3, y3, mul(mul(a.zz, b.zz), pp), mul(mul(a.zzz, b.zzz), ppp)};
 }
 
