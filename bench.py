@@ -331,6 +331,7 @@ def main():
                 "source": "sum over the proving kernels of profiles/r1_pmc_traffic.json (x2 read rule: an upper bound for the 64-byte gathers)"},
         }
         if world == 1 and not args.no_tx_circuit:
+            key.close()  # its four streams would share the hardware queues with the streams of the tx-circuit key
             out["tx_circuit"] = tx_circuit_leg(local, max(args.steps, 4))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample_log_m, args.log_m)

@@ -432,6 +432,40 @@ static __global__ __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per
   store_pod(buckets + b, acc);
 }
 
+// The same for small bucket sets (circuits of 2^17 constraints and below: fewer buckets than the chip has lanes):
+// SPLIT neighbouring lanes share one bucket, each adds every SPLIT-th entry, the partial sums meet in a butterfly of
+// lane exchanges.  log2(SPLIT) full additions extra per bucket buy SPLIT times the wavefronts and chains 1/SPLIT as long.
+template <class F>
+__device__ __forceinline__ XYZZ<F> lane_xor_xyzz(const XYZZ<F> &v, int mask) {
+  static_assert(sizeof(XYZZ<F>) % 4 == 0, "XYZZ is made of 32-bit words");
+  XYZZ<F> r;
+  const uint32_t *src = reinterpret_cast<const uint32_t *>(&v);
+  uint32_t *dst = reinterpret_cast<uint32_t *>(&r);
+#pragma unroll
+  for (unsigned i = 0; i < sizeof(XYZZ<F>) / 4; i++) dst[i] = (uint32_t)__shfl_xor((int)src[i], mask);
+  return r;
+}
+template <class F, int MINW, int SPLIT>
+static __global__ __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per_eu(MINW, MINW))) void msm_accum_split_kernel(const Affine<F> *points, const uint32_t *offsets, const uint32_t *entries,
+                                                                     uint32_t nb, const uint32_t *counts, const uint32_t *order, XYZZ<F> *buckets) {
+  const uint32_t t = blockIdx.x * ACC_THREADS + threadIdx.x;
+  const uint32_t slot = t / SPLIT, sub = t % SPLIT;
+  if (slot >= nb) return;  // uniform over the SPLIT lanes of a bucket
+  const uint32_t b = order[slot];
+  if (counts[b] == BIG_MARK) return;
+  const uint32_t o0 = offsets[b], o1 = offsets[b + 1];
+  XYZZ<F> acc = XYZZ<F>::inf();
+  uint32_t e = o0 + sub < o1 ? entries[o0 + sub] : 0u;
+  for (uint32_t j = o0 + sub; j < o1; j += SPLIT) {
+    uint32_t en = j + SPLIT < o1 ? entries[j + SPLIT] : 0u;
+    Affine<F> p = load_pod(points + (e >> 1));
+    if (!p.is_inf()) acc = add_mixed(acc, p, (e & 1) != 0);
+    e = en;
+  }
+  for (int m = 1; m < SPLIT; m <<= 1) acc = add_full_inl(acc, lane_xor_xyzz(acc, m));
+  if (sub == 0) store_pod(buckets + b, acc);
+}
+
 // oversized buckets (0/1-heavy witnesses): BIG_SPLIT workgroups share one bucket, each does a strided
 // accumulation and an LDS tree; msm_big_finish_kernel adds the BIG_SPLIT partial sums.
 constexpr int BIG_SPLIT = 8;

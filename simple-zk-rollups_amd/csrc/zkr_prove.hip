@@ -213,6 +213,22 @@ static int msm_accum_enqueue(Prof pf, hipStream_t s, const Affine<F> *pts, uint3
   // (115 G Fq-mul/s isolated vs 112 at 3 and 103 at 4; 92 vs 88 proofs/s) and G2; ZKR_ACC_W_G1 / ZKR_ACC_W_G2 override for experiments
   static const char *acc_env = getenv(sizeof(F) == 32 ? "ZKR_ACC_W_G1" : "ZKR_ACC_W_G2");
   static const int acc_w = acc_env ? atoi(acc_env) : MsmCfg<F>::ACC_W;
+  // small bucket sets: several lanes per bucket (kernels_msm.hpp msm_accum_split_kernel)
+  static const char *split_env = getenv("ZKR_ACC_SPLIT");
+  const int split = split_env ? atoi(split_env) : pl.nb <= (1u << 17) ? 4 : 1;  // tx circuit (2^16 buckets): 379 / 455 / 458 / 393 proofs/s at 1 / 2 / 4 / 8
+  if (split > 1) {
+    const unsigned sgrid = (unsigned)(((size_t)pl.nb * split + ACC_THREADS - 1) / ACC_THREADS);
+#define ZKR_ACC_SPLIT_LAUNCH(SP) msm_accum_split_kernel<F, MsmCfg<F>::ACC_W, SP><<<sgrid, ACC_THREADS, 0, s>>>(pts, srt.offsets, srt.entries, pl.nb, srt.counts, srt.order, (XYZZ<F> *)ws.buckets)
+    switch (split) {
+      case 2: ZKR_ACC_SPLIT_LAUNCH(2); break;
+      case 8: ZKR_ACC_SPLIT_LAUNCH(8); break;
+      default: ZKR_ACC_SPLIT_LAUNCH(4); break;
+    }
+#undef ZKR_ACC_SPLIT_LAUNCH
+    prof_end(pf, s, sp);
+    ZKR_HIP_CHECK(hipGetLastError());
+    return 0;
+  }
   const unsigned grid = (pl.nb + ACC_THREADS - 1) / ACC_THREADS;
 #define ZKR_ACC_LAUNCH(W) msm_accum_kernel<F, W, MsmCfg<F>::ACC_PREFETCH><<<grid, ACC_THREADS, 0, s>>>(pts, srt.offsets, srt.entries, pl.nb, srt.counts, srt.order, (XYZZ<F> *)ws.buckets)
   switch (acc_w) {
