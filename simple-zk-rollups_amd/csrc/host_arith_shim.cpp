@@ -2,6 +2,7 @@
 // tiny C ABI so tests/test_host_arith.py can check them against the oracle without a GPU.
 // Not part of the product path (the product is libzkr_hip.so).
 #include "hostops.hpp"
+#include "pairing.hpp"
 using namespace zkr;
 
 extern "C" {
@@ -62,5 +63,25 @@ int zkt_g1_lincomb(const uint8_t *p_mont, uint32_t a, uint32_t b, int negate_b, 
   if (r.is_inf()) return 1;
   store_g1_std(out, to_affine(r));
   return 0;
+}
+// The verifier's structured final exponentiation (Frobenius maps + three powers by x) against plain square-and-multiply
+// over (q^12 - 1)/r, and the Frobenius maps against powers by q, on `count` pseudo-random Fq12 elements (xorshift from
+// `seed`).  Returns the number of elements on which everything agrees.
+int zkt_final_exp_check(uint64_t seed, int count) {
+  using namespace zkr::pairing;
+  uint64_t st = seed ? seed : 88172645463325252ull;
+  auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return (uint32_t)(st >> 16); };
+  auto rfq = [&]() { Fq a; for (int i = 0; i < 8; i++) a.v[i] = rnd(); a.v[7] &= 0x0fffffffu; return to_mont(a); };
+  auto rfq2 = [&]() { Fq2 r; r.a = rfq(); r.b = rfq(); return r; };
+  auto rfq6 = [&]() { Fq6 r; r.c0 = rfq2(); r.c1 = rfq2(); r.c2 = rfq2(); return r; };
+  uint32_t q[8];
+  for (int i = 0; i < 8; i++) q[i] = FqParams::P[i];
+  int ok = 0;
+  for (int it = 0; it < count; it++) {
+    Fq12 f{rfq6(), rfq6()};
+    Fq12 fq = pow(f, q);
+    ok += (fq == frobenius(f)) && (pow(fq, q) == frobenius2(f)) && (final_exponentiation_plain(f) == final_exponentiation(f));
+  }
+  return ok;
 }
 }

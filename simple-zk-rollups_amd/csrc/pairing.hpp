@@ -173,10 +173,82 @@ static inline Fq12 multi_miller_loop(const G1Affine *ps, const G2Affine *qs, int
   return f;
 }
 
-static inline Fq12 final_exponentiation(const Fq12 &f0) {
+// f^((q^12 - 1) / r) by plain square-and-multiply over the 1270 exponent bits: the reference form the fast one below is
+// tested against (tests/test_host_arith.py through the host shim)
+static inline Fq12 final_exponentiation_plain(const Fq12 &f0) {
   Fq12 f = mul(conj(f0), inv(f0));  // ^(q^6 - 1)
   f = pow(f, EXP_EASY2);            // ^(q^2 + 1)
   return pow(f, EXP_HARD);          // ^((q^4 - q^2 + 1) / r)
+}
+
+// Frobenius maps on Fq12 = Fq2[w]/(w^6 - xi): (sum a_i w^i)^q = sum conj(a_i) g1[i] w^i with g1[i] = xi^(i (q-1)/6),
+// (..)^(q^2) = sum a_i g2[i] w^i with g2[i] = g1[i] conj(g1[i]) in Fq.  Constants derived once from xi.
+struct FrobConst {
+  Fq2 g1[6];
+  Fq g2[6];
+  FrobConst() {
+    // e = (q - 1) / 6 by long division of the limbs
+    uint32_t e[8];
+    uint64_t rem = 0;
+    uint32_t qm1[8];
+    for (int i = 0; i < 8; i++) qm1[i] = FqParams::P[i];
+    qm1[0] -= 1;
+    for (int i = 7; i >= 0; i--) {
+      uint64_t cur = (rem << 32) | qm1[i];
+      e[i] = (uint32_t)(cur / 6);
+      rem = cur % 6;
+    }
+    Fq2 xi{fq_small(9), fq_small(1)}, r = Fq2::one(), b = xi;
+    for (int i = 0; i < 256; i++) {
+      if ((e[i >> 5] >> (i & 31)) & 1) r = mul(r, b);
+      b = sqr(b);
+    }
+    g1[0] = Fq2::one();
+    for (int i = 1; i < 6; i++) g1[i] = mul(g1[i - 1], r);
+    for (int i = 0; i < 6; i++) g2[i] = sub(mul(g1[i].a, g1[i].a), neg(mul(g1[i].b, g1[i].b)));  // norm a^2 + b^2
+  }
+};
+static inline const FrobConst &frob_const() {
+  static const FrobConst k;
+  return k;
+}
+// coefficient of w^i: i = 0, 2, 4 -> c0.{c0, c1, c2}; i = 1, 3, 5 -> c1.{c0, c1, c2}   (v = w^2)
+static inline Fq12 frobenius(const Fq12 &a) {
+  const FrobConst &k = frob_const();
+  return Fq12{Fq6{conj(a.c0.c0), mul(conj(a.c0.c1), k.g1[2]), mul(conj(a.c0.c2), k.g1[4])},
+              Fq6{mul(conj(a.c1.c0), k.g1[1]), mul(conj(a.c1.c1), k.g1[3]), mul(conj(a.c1.c2), k.g1[5])}};
+}
+static inline Fq12 frobenius2(const Fq12 &a) {
+  const FrobConst &k = frob_const();
+  return Fq12{Fq6{a.c0.c0, mul_fq(a.c0.c1, k.g2[2]), mul_fq(a.c0.c2, k.g2[4])},
+              Fq6{mul_fq(a.c1.c0, k.g2[1]), mul_fq(a.c1.c1, k.g2[3]), mul_fq(a.c1.c2, k.g2[5])}};
+}
+// the curve parameter x = 4965661367192848881 (ATE_LOOP = 6x + 2)
+static const uint32_t BN_X[2] = {0x4a6909f1u, 0x44e992b4u};
+
+// The same value with the structure of the exponent: q^6 - 1 by conjugation and one inversion, q^2 + 1 by a Frobenius
+// map, the hard part (q^4 - q^2 + 1)/r as lambda_3 q^3 + lambda_2 q^2 + lambda_1 q + lambda_0 with the lambda_i
+// polynomials in x (Scott, Benger, Charlemagne, Dominguez Perez, Kachisa: three powers by x, Frobenius maps and the
+// addition chain y0 y1^2 y2^6 y3^12 y4^18 y5^30 y6^36; inverses are conjugates after the easy part).
+static inline Fq12 final_exponentiation(const Fq12 &f0) {
+  Fq12 f = mul(conj(f0), inv(f0));  // ^(q^6 - 1)
+  f = mul(frobenius2(f), f);        // ^(q^2 + 1)
+  Fq12 fx = pow(f, BN_X), fx2 = pow(fx, BN_X), fx3 = pow(fx2, BN_X);
+  Fq12 fp = frobenius(f), fp2 = frobenius2(f), fp3 = frobenius(fp2);
+  Fq12 y0 = mul(mul(fp, fp2), fp3);
+  Fq12 y1 = conj(f);
+  Fq12 y2 = frobenius2(fx2);
+  Fq12 y3 = conj(frobenius(fx));
+  Fq12 y4 = conj(mul(fx, frobenius(fx2)));
+  Fq12 y5 = conj(fx2);
+  Fq12 y6 = conj(mul(fx3, frobenius(fx3)));
+  Fq12 t0 = mul(mul(sqr(y6), y4), y5);
+  Fq12 t1 = mul(mul(y3, y5), t0);
+  t0 = mul(t0, y2);
+  t1 = sqr(mul(sqr(t1), t0));
+  t0 = mul(t1, y1);
+  t1 = mul(t1, y0);
+  return mul(sqr(t0), t1);
 }
 
 // prod_i e(P_i, Q_i) == 1  -- the bn256 pairing precompile's check (TxVerifier.sol:91-115)

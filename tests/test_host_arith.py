@@ -82,3 +82,11 @@ def test_group_law_including_corner_cases(L):
         inf = L.zkt_g1_lincomb(mq(P5[0]) + mq(P5[1]), a, b, ng, o)
         got = None if inf else (int.from_bytes(o.raw[:32], "little"), int.from_bytes(o.raw[32:], "little"))
         assert got == bn.g1_mul(P5, (a + (-b if ng else b)) % R), (a, b, ng)
+
+
+def test_structured_final_exponentiation_equals_plain_power(L):
+    """zkr_verify's final exponentiation (csrc/pairing.hpp: Frobenius maps, three powers by the curve parameter, the
+    Scott et al. addition chain) == f^((q^12 - 1)/r) by square-and-multiply, and its Frobenius maps == powers by q."""
+    import ctypes
+    L.zkt_final_exp_check.argtypes = [ctypes.c_uint64, ctypes.c_int]
+    assert L.zkt_final_exp_check(0x5A4B0777, 4) == 4
