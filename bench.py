@@ -159,11 +159,20 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
+    # rehearsal of the N > 1 path on a one-GPU box: ZKR_BENCH_ONE_GPU=1 puts every rank on cuda:0 and
+    # ZKR_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one device); never used for reported numbers
+    one_gpu = os.environ.get("ZKR_BENCH_ONE_GPU") == "1"
+    backend = os.environ.get("ZKR_BENCH_BACKEND", "nccl")
+    if one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     zkr_hip.synth_set_shape(1 if args.shape == "dense" else 0)
     # ---- key: generated on rank 0 (points computed on the GPU), replicated by one broadcast of the arena
@@ -316,7 +325,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "u32x8 Montgomery (254-bit integer)", "data": "synthetic",
             "config": {"workload": "2^%d-constraint synthetic %s, 1 proof per step per GPU" % (args.log_m, "rollup circuit" if args.shape == "rollup" else "dense random R1CS"),
                        "log_m": args.log_m, "n_public": N_PUBLIC, "nVars": info["nVars"], "nnzA": info["nnzA"], "nnzB": info["nnzB"],
-                       "parallelism": "proof-sharded x%d (key arena broadcast once over RCCL)" % world,
+                       "parallelism": "proof-sharded x%d (key arena broadcast once over %s)" % (world, "RCCL" if backend == "nccl" else backend + ", rehearsal on one GPU" if one_gpu else backend),
                        "proofs_in_flight": 1 if args.no_pipeline else 2},
             "roofline": roofline,
             "stage_ms_per_proof": per_proof_ms,

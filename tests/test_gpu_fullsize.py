@@ -106,3 +106,29 @@ def test_fullsize_arena_replica_above_4_gib():
     key2 = zkr_hip.ProvingKey.adopt_arena(replica.data_ptr(), n, 0, keepalive=replica)
     assert key2.info() == key.info() and key2.windows() == key.windows()
     assert key2.prove(wb, 5, 7) == key.prove(wb, 5, 7)
+
+
+def test_bench_two_rank_path_rehearsal_on_one_gpu():
+    """The N > 1 flow of bench.py end to end on this one-GPU box: two ranks on cuda:0, gloo instead of RCCL (which
+    refuses two ranks per device): key built on rank 0, arena broadcast, adopted by rank 1, both shards proved,
+    max-over-ranks timing, one JSON line from rank 0 with the whole-job rate."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, ZKR_BENCH_BACKEND="gloo", ZKR_BENCH_ONE_GPU="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "1", "--log-m", "14"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                   # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "weak" and d["value"] > 0
+    assert abs(d["value"] - 2 * 6 / (d["ms_per_step"] * 6e-3)) < 1e-6 * d["value"]      # whole-job rate: all ranks' proofs / max time
+    assert d["key"]["bcast_s"] is not None and d["proofs_verified"] >= 1
