@@ -84,4 +84,20 @@ int zkt_final_exp_check(uint64_t seed, int count) {
   }
   return ok;
 }
+// proof-assembly helpers (hostops.hpp) against plain double-and-add: fixed-base window table, joint double
+// multiplication; scalars a, b standard 32 B.  Returns 1 when both agree.
+int zkt_assembly_muls(const uint8_t *p_mont, const uint8_t *q_mont, const uint8_t *a32, const uint8_t *b32) {
+  G1Affine p = load_g1(p_mont), q = load_g1(q_mont);
+  U256 a = load_u256(a32), b = load_u256(b32);
+  G1XYZZ want_fixed = scalar_mul(to_xyzz(p), a);
+  G1XYZZ got_fixed = fixed_base_mul(fixed_base_table(p), a);
+  G1XYZZ want_joint = add_full(scalar_mul(to_xyzz(p), a), scalar_mul(to_xyzz(q), b));
+  G1XYZZ got_joint = double_scalar_mul(to_xyzz(p), a, to_xyzz(q), b);
+  auto same = [](const G1XYZZ &x, const G1XYZZ &y) {
+    if (x.is_inf() || y.is_inf()) return x.is_inf() == y.is_inf();
+    G1Affine u = to_affine(x), v = to_affine(y);
+    return u.x == v.x && u.y == v.y;
+  };
+  return same(want_fixed, got_fixed) && same(want_joint, got_joint);
+}
 }

@@ -124,6 +124,10 @@ struct zkr_key {
   std::mutex mu;  // slot hand-out, the enqueue phase of a proof (so two host threads do not interleave launches), stage totals
   std::condition_variable slot_freed;
   zkr::MsmPlan plan[zkr::N_TABLES];
+  // proof assembly on the host: 4-bit window tables of delta_1 / delta_2 (built on first use)
+  std::once_flag delta_once;
+  std::vector<zkr::G1Affine> delta1_tab;
+  std::vector<zkr::G2Affine> delta2_tab;
   // profiling
   bool prof_on = false;
   std::vector<zkr::ProfStage> stages;

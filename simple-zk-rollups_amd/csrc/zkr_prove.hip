@@ -448,20 +448,25 @@ static int prove_collect(zkr_key *k, ProofSlot &sl, uint8_t proof_out[256]) {
   G2XYZZ B2 = msm_finish<Fq2>(h.npts[T_B2], sl.ws[T_B2]);
   G1XYZZ C = msm_finish<Fq>(h.npts[T_C], sl.ws[T_C]);
   G1XYZZ H = msm_finish<Fq>(h.npts[T_H], sl.ws[T_H]);
-  G1XYZZ alfa1 = to_xyzz(load_g1(h.alfa1)), beta1 = to_xyzz(load_g1(h.beta1)), delta1 = to_xyzz(load_g1(h.delta1));
-  G2XYZZ beta2 = to_xyzz(load_g2(h.beta2)), delta2 = to_xyzz(load_g2(h.delta2));
+  // pi_a = A + alfa + r delta;  pi_b = B2 + beta + s delta;  pi_c = C + H + s pi_a + r (B1 + beta + s delta) - r s delta
+  //      = C + H + s (A + alfa) + r (B1 + beta) + r s delta: three multiples of the key's delta (window tables) and one
+  // double multiplication of the two MSM results with shared doublings
+  std::call_once(k->delta_once, [&] {
+    k->delta1_tab = fixed_base_table(load_g1(h.delta1));
+    k->delta2_tab = fixed_base_table(load_g2(h.delta2));
+  });
+  G1XYZZ alfa1 = to_xyzz(load_g1(h.alfa1)), beta1 = to_xyzz(load_g1(h.beta1));
+  G2XYZZ beta2 = to_xyzz(load_g2(h.beta2));
   U256 r = load_u256(rb), sc = load_u256(sb);
-  G1XYZZ pia = add_full(add_full(A, alfa1), scalar_mul(delta1, r));
-  G2XYZZ pib = add_full(add_full(B2, beta2), scalar_mul(delta2, sc));
-  G1XYZZ pib1 = add_full(add_full(B1, beta1), scalar_mul(delta1, sc));
-  G1XYZZ pic = add_full(C, H);
-  pic = add_full(pic, scalar_mul(pia, sc));
-  pic = add_full(pic, scalar_mul(pib1, r));
-  Fr rs = neg(mul(to_mont(load_fp<FrParams>(rb)), to_mont(load_fp<FrParams>(sb))));
+  G1XYZZ a_alfa = add_full(A, alfa1), b_beta = add_full(B1, beta1);
+  G1XYZZ pia = add_full(a_alfa, fixed_base_mul(k->delta1_tab, r));
+  G2XYZZ pib = add_full(add_full(B2, beta2), fixed_base_mul(k->delta2_tab, sc));
+  Fr rs = mul(to_mont(load_fp<FrParams>(rb)), to_mont(load_fp<FrParams>(sb)));
   Fr rs_std = from_mont(rs);
   U256 rsu;
   memcpy(rsu.v, rs_std.v, 32);
-  pic = add_full(pic, scalar_mul(delta1, rsu));
+  G1XYZZ pic = add_full(add_full(C, H), double_scalar_mul(a_alfa, sc, b_beta, r));
+  pic = add_full(pic, fixed_base_mul(k->delta1_tab, rsu));
   if (pia.is_inf() || pib.is_inf() || pic.is_inf()) { set_error("degenerate proof element (point at infinity)"); return ZKR_ERR_DEGENERATE; }
   store_g1_std(proof_out, to_affine(pia));
   store_g2_std(proof_out + 64, to_affine(pib));
