@@ -173,6 +173,12 @@ int zkr_mimcsponge_multihash(const uint8_t *in, size_t n, uint8_t out[32]);
 int zkr_babyjub_pubkey(const uint8_t priv[32], uint8_t pub[64]);
 int zkr_eddsa_sign(const uint8_t priv[32], const uint8_t *msg, size_t n, uint8_t sig[96]);
 int zkr_eddsa_verify(const uint8_t *msg, size_t n, const uint8_t sig[96], const uint8_t pub[64], int *valid);
+/* The same hash batch-parallel on the GPU (one thread per hash): out[t] = multiHash(inputs[t * arity .. + arity)), host
+ * buffers, standard form; and the reference's balance tree (operator/src/utils/merkletree.ts:44-83, hashLeftRight of
+ * adjacent pairs) built level by level on the device: leaves = 2^depth x 32 B, levels_out = all levels concatenated,
+ * leaves first, root last ((2^(depth+1) - 1) x 32 B).  No CPU fallback (ZKR_ERR_NO_DEVICE). */
+int zkr_mimcsponge_multihash_batch(const void *inputs_std, size_t count, unsigned arity, void *out_std, int device);
+int zkr_balance_tree_build(const void *leaves_std, unsigned depth, void *levels_out, int device);
 /* BatchProcessTx(batch, depth) (prover/circuits/batchprocesstx.circom:3-75; `tx.circom` = (2, 6)) as a rank-1
  * constraint system in the r1cs_bin layout of zkr_setup_r1cs, and its witness builder -- the counterpart of
  * `compiler(tx.circom)` + `Circuit.calculateWitness` (operator/src/snarks/common.ts:12-17).  Public signals keep

@@ -873,6 +873,11 @@ static void *dup_bytes(const void *p, size_t n) {
 
 }  // namespace
 
+namespace zkr {
+// the 220 round constants (Montgomery form) for the device kernels of rollup_gpu.hip
+const Fr *mimc_round_constants() { return mimc().c; }
+}  // namespace zkr
+
 extern "C" {
 
 int zkr_mimcsponge_multihash(const uint8_t *in, size_t n, uint8_t out[32]) {

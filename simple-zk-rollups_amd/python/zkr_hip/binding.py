@@ -66,6 +66,8 @@ def lib():
     L.zkr_babyjub_pubkey.argtypes = [u8p, u8p]
     L.zkr_eddsa_sign.argtypes = [u8p, u8p, sz, u8p]
     L.zkr_eddsa_verify.argtypes = [u8p, sz, u8p, u8p, c.POINTER(i)]
+    L.zkr_mimcsponge_multihash_batch.argtypes = [u8p, sz, c.c_uint, u8p, i]
+    L.zkr_balance_tree_build.argtypes = [u8p, c.c_uint, u8p, i]
     L.zkr_babyjub_format_privkey.argtypes = [u8p, u8p]
     L.zkr_withdraw_r1cs.argtypes = [c.POINTER(vp), c.POINTER(sz)]
     L.zkr_withdraw_witness.argtypes = [u8p, u8p, c.POINTER(vp), c.POINTER(sz)]

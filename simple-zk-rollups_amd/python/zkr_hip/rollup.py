@@ -32,6 +32,19 @@ def multi_hash(values) -> int:
     return int.from_bytes(out.raw, "little")
 
 
+def multi_hash_batch(rows, device=0):
+    """multiHash of every row (equal lengths) on the GPU, one thread per hash (zkr_mimcsponge_multihash_batch)."""
+    rows = [list(r) for r in rows]
+    if not rows:
+        return []
+    arity = len(rows[0])
+    assert all(len(r) == arity for r in rows)
+    buf = b"".join(_le(int(v) % (1 << 256)) for r in rows for v in r)
+    out = ctypes.create_string_buffer(32 * len(rows))
+    _check(lib().zkr_mimcsponge_multihash_batch(buf, len(rows), arity, out, device))
+    return _ints(out.raw)
+
+
 def hash_left_right(left, right) -> int:   # crypto.ts:36-38
     return multi_hash([left, right])
 
@@ -145,6 +158,21 @@ class BalanceTree:
         for _ in range(depth):                       # an empty tree needs one hash per level
             z = hash_left_right(z, z)
             self.levels.append([z] * (len(self.levels[-1]) // 2))
+
+    @classmethod
+    def from_leaves(cls, depth, leaves, zero=0, device=0):
+        """The tree over `leaves` (padded with the zero value) built on the GPU (zkr_balance_tree_build)."""
+        t = cls.__new__(cls)
+        t.depth = depth
+        n = 1 << depth
+        full = [int(v) for v in leaves] + [zero] * (n - len(leaves))
+        out = ctypes.create_string_buffer(32 * (2 * n - 1))
+        _check(lib().zkr_balance_tree_build(b"".join(_le(v) for v in full), depth, out, device))
+        vals, t.levels, off = _ints(out.raw), [], 0
+        for l in range(depth + 1):
+            t.levels.append(vals[off:off + (n >> l)])
+            off += n >> l
+        return t
 
     @property
     def root(self):

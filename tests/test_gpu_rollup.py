@@ -86,3 +86,33 @@ def test_withdraw_circuit_proof_matches_closed_form_and_verifies():
     nv, npub, cons = parse_r1cs(r1cs)
     circ = dict(nVars=nv, nPublic=npub, nConstraints=len(cons), domainSize=g.domain_size(len(cons), npub), rows=cons)
     assert proof == g.proof_bytes(g.proof_from_toxic(circ, tox, ints(wb), r, s))
+
+
+def test_gpu_batch_hash_and_tree_match_the_oracle():
+    """zkr_mimcsponge_multihash_batch / zkr_balance_tree_build (csrc/rollup_gpu.hip, one thread per hash) == the pinned
+    oracle's multiHash and balance tree, leaf for leaf and level for level; operands >= r are taken mod r."""
+    import random
+    import time
+    from zkr_hip import rollup as n
+    rnd = random.Random(91)
+    for arity in (1, 2, 4, 5):
+        rows = [[rnd.randrange(o.R) for _ in range(arity)] for _ in range(37)]
+        rows[3][0] = (1 << 256) - 1
+        rows[5][arity - 1] = o.R + 11
+        assert n.multi_hash_batch(rows) == [o.multi_hash(r) for r in rows]
+    assert n.multi_hash_batch([[32767]]) == [o.multi_hash([32767])]                      # hasher.test.ts:15-26
+    depth = 5
+    leaves = [rnd.randrange(o.R) for _ in range(19)]
+    t = n.BalanceTree.from_leaves(depth, leaves)
+    ref = o.Tree(depth)
+    for i, v in enumerate(leaves):
+        ref.update(i, v)
+    assert t.levels == ref.levels and t.root == ref.root
+    assert t.path(7) == ref.path(7)
+    t.update(3, 12345)
+    ref.update(3, 12345)
+    assert t.root == ref.root                                                           # native host hash continues the GPU-built tree
+    # a 2^16-account tree: idempotence-style property at size -- the root equals the fold of the GPU-hashed level below
+    big = n.BalanceTree.from_leaves(16, [rnd.randrange(o.R) for _ in range(1 << 16)])
+    assert big.root == o.hash_left_right(big.levels[15][0], big.levels[15][1])
+    assert big.levels[1][:4] == n.multi_hash_batch([big.levels[0][2 * i:2 * i + 2] for i in range(4)])
