@@ -41,6 +41,10 @@ export function version(): string;
 export interface Signature { R8: [bigint, bigint]; S: bigint; }
 export function multiHash(values: Array<bigint | string | number>): bigint;
 export function hashLeftRight(left: bigint, right: bigint): bigint;
+/** multiHash of every row on the GPU (one thread per hash). */
+export function multiHashBatch(rows: Array<Array<bigint | string | number>>, device?: number): bigint[];
+/** The reference's balance tree over the leaves (padded to 2^depth), hashed on the GPU. */
+export function buildBalanceTree(depth: number, leaves: Array<bigint | string>, zeroValue?: bigint, device?: number): { depth: number; levels: bigint[][]; root: bigint; path(i: number): bigint[] };
 export function genPublicKey(privKey: bigint): [bigint, bigint];
 export function formatPrivKeyForBabyJub(privKey: bigint): bigint;
 export function sign(privKey: bigint, msg: Array<bigint | string | number>): Signature;

@@ -225,6 +225,23 @@ const leToBigInts = (buf) => { const out = []; for (let o = 0; o < buf.length; o
 // multiHash(d) (crypto.ts:28-30); hash / hashLeftRight (:32-38)
 function multiHash(values) { return leToBigInts(native().rollupCrypto(0, concatLe(values.map((v) => BigInt(v) % R))))[0]; }
 const hashLeftRight = (l, r) => multiHash([l, r]);
+// the same on the GPU, one thread per hash: rows of equal length -> one hash per row
+function multiHashBatch(rows, device) {
+  if (rows.length === 0) return [];
+  const flat = [];
+  rows.forEach((r) => { if (r.length !== rows[0].length) throw new Error("multiHashBatch: rows of unequal length"); r.forEach((v) => flat.push(BigInt(v) % MONT)); });
+  return leToBigInts(native().rollupGpuHash(concatLe(flat), rows[0].length, device || 0));
+}
+// the balance tree of operator/src/utils/merkletree.ts:44-83 over `leaves` (padded with zeroValue to 2^depth), hashed level
+// by level on the GPU: { root, levels[l][i], path(i) = getUpdatePath(i).pathElements }
+function buildBalanceTree(depth, leaves, zeroValue, device) {
+  const n = 1 << depth;
+  const full = leaves.map(BigInt).concat(new Array(n - leaves.length).fill(BigInt(zeroValue || 0)));
+  const all = leToBigInts(native().rollupGpuHash(concatLe(full), 0, device || 0));
+  const levels = [];
+  for (let l = 0, off = 0; l <= depth; off += n >> l, l++) levels.push(all.slice(off, off + (n >> l)));
+  return { depth, levels, root: levels[depth][0], path: (i) => levels.slice(0, depth).map((lv, l) => lv[(i >> l) ^ 1]) };
+}
 // genPublicKey(privKey) (crypto.ts:78-84)
 function genPublicKey(priv) { return leToBigInts(native().rollupCrypto(1, bigintToLe32(priv))); }
 // formatPrivKeyForBabyJub(privKey) (crypto.ts:58-76): the scalar the circuits take as `privateKey`
@@ -282,7 +299,7 @@ class WithdrawCircuit {
 module.exports = {
   buildBn128, genProof, binarifyWitness, binarifyProvingKey, solidityProof, proofFromBytes, isValid, binarifyVerifyingKey,
   binarifyR1cs, verifyingKeyFromBytes,
-  multiHash, hashLeftRight, genPublicKey, formatPrivKeyForBabyJub, sign, verify, RollupCircuit, WithdrawCircuit,
+  multiHash, multiHashBatch, buildBalanceTree, hashLeftRight, genPublicKey, formatPrivKeyForBabyJub, sign, verify, RollupCircuit, WithdrawCircuit,
   deviceCount: () => { native(); return deviceCount; },
   version: () => native().version(),
 };

@@ -32,6 +32,8 @@ static struct {
   int (*eddsa_sign)(const uint8_t *, const uint8_t *, size_t, uint8_t *);
   int (*eddsa_verify)(const uint8_t *, size_t, const uint8_t *, const uint8_t *, int *);
   int (*format_privkey)(const uint8_t *, uint8_t *);
+  int (*multihash_batch)(const void *, size_t, unsigned, void *, int);
+  int (*tree_build)(const void *, unsigned, void *, int);
   int (*withdraw_r1cs)(void **, size_t *);
   int (*withdraw_witness)(const uint8_t *, const uint8_t *, void **, size_t *);
   int (*rollup_info)(uint32_t, uint32_t, uint32_t *, uint32_t *, uint32_t *);
@@ -75,6 +77,7 @@ static napi_value js_load(napi_env env, napi_callback_info info) {
     SYM(key_load_websnark, "zkr_key_load_websnark") SYM(key_free, "zkr_key_free") SYM(key_info, "zkr_key_info") SYM(prove, "zkr_prove") SYM(verify, "zkr_verify")
     SYM(setup_r1cs, "zkr_setup_r1cs") SYM(key_save, "zkr_key_save") SYM(key_load_file, "zkr_key_load_file") SYM(free_, "zkr_free")
     SYM(multihash, "zkr_mimcsponge_multihash") SYM(pubkey, "zkr_babyjub_pubkey") SYM(eddsa_sign, "zkr_eddsa_sign") SYM(eddsa_verify, "zkr_eddsa_verify")
+    SYM(multihash_batch, "zkr_mimcsponge_multihash_batch") SYM(tree_build, "zkr_balance_tree_build")
     SYM(format_privkey, "zkr_babyjub_format_privkey") SYM(withdraw_r1cs, "zkr_withdraw_r1cs") SYM(withdraw_witness, "zkr_withdraw_witness")
     SYM(rollup_info, "zkr_rollup_info") SYM(rollup_r1cs, "zkr_rollup_r1cs") SYM(rollup_witness, "zkr_rollup_witness")
     Z.handle = h;
@@ -385,6 +388,39 @@ static napi_value js_rollup_circuit(napi_env env, napi_callback_info info) {
   return buf;
 }
 
+/* rollupGpuHash(values, arity, device) -> Buffer of one 32-byte hash per `arity` values (zkr_mimcsponge_multihash_batch);
+ * arity 0: `values` are the 2^depth leaves of a balance tree, the result is every level, leaves first, root last
+ * (zkr_balance_tree_build).  Synchronous; runs on the GPU. */
+static napi_value js_rollup_gpu_hash(napi_env env, napi_callback_info info) {
+  size_t argc = 3;
+  napi_value argv[3];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  if (!Z.handle) return throw_msg(env, "libzkr_hip.so not loaded");
+  const uint8_t *in;
+  size_t len;
+  uint32_t arity = 0;
+  int32_t dev = 0;
+  if (argc < 2 || !get_bytes(env, argv[0], &in, &len) || len % 32 || napi_get_value_uint32(env, argv[1], &arity) != napi_ok)
+    return throw_msg(env, "rollupGpuHash(values, arity, device)");
+  if (argc > 2) napi_get_value_int32(env, argv[2], &dev);
+  size_t n = len / 32, out_len;
+  unsigned depth = 0;
+  if (arity == 0) {
+    while (((size_t)1 << depth) < n) depth++;
+    if (n < 2 || ((size_t)1 << depth) != n) return throw_msg(env, "balance tree: the number of leaves must be a power of two");
+    out_len = 32 * (2 * n - 1);
+  } else {
+    if (n % arity) return throw_msg(env, "multiHashBatch: rows of unequal length");
+    out_len = 32 * (n / arity);
+  }
+  void *out = NULL;
+  napi_value buf;
+  NAPI_OK(napi_create_buffer(env, out_len, &out, &buf));
+  int rc = arity == 0 ? Z.tree_build(in, depth, out, dev) : Z.multihash_batch(in, n / arity, arity, out, dev);
+  if (rc) return throw_msg(env, Z.last_error());
+  return buf;
+}
+
 /* withdrawCircuit(privateKey32|null, nullifier32): null -> r1csBin Buffer; else the witness (Buffer) of Withdraw()
  * (prover/circuits/withdraw.circom:4-25). */
 static napi_value js_withdraw_circuit(napi_env env, napi_callback_info info) {
@@ -421,6 +457,7 @@ static napi_value init(napi_env env, napi_value exports) {
       {"keyLoadFile", NULL, js_key_load_file, NULL, NULL, NULL, napi_default, NULL},
       {"rollupCrypto", NULL, js_rollup_crypto, NULL, NULL, NULL, napi_default, NULL}, {"rollupCircuit", NULL, js_rollup_circuit, NULL, NULL, NULL, napi_default, NULL},
       {"withdrawCircuit", NULL, js_withdraw_circuit, NULL, NULL, NULL, napi_default, NULL},
+      {"rollupGpuHash", NULL, js_rollup_gpu_hash, NULL, NULL, NULL, napi_default, NULL},
   };
   napi_define_properties(env, exports, sizeof(props) / sizeof(props[0]), props);
   return exports;

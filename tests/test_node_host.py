@@ -245,11 +245,15 @@ def test_js_operator_flow_on_the_tx_circuit(tmp_path):
         const valid = z.isValid(vk, proof, publicSignals);
         const bad = publicSignals.slice(); bad[0] += 1n;
         const sp = z.solidityProof(proof, publicSignals);
+        const tree = z.buildBalanceTree(4, [11n, 22n, 33n]);
+        const okTree = tree.root === z.hashLeftRight(tree.levels[3][0], tree.levels[3][1]) && tree.levels[1][0] === z.hashLeftRight(11n, 22n)
+          && tree.path(2)[0] === 0n && tree.path(2)[1] === tree.levels[1][0] && z.multiHashBatch([[1n, 2n], [3n, 4n]])[1] === z.multiHash([3n, 4n]);
         console.log(JSON.stringify({valid, invalid: z.isValid(vk, proof, bad), root: publicSignals[0].toString(), nInputs: sp.inputs.length,
-                                    info: bn.keyInfo(), nPublic: vk.nPublic}));
+                                    info: bn.keyInfo(), nPublic: vk.nPublic, okTree}));
       })().catch((e) => { console.error(e); process.exit(1); });
     """, path).stdout
     res = json.loads(out)
     assert res["valid"] is True and res["invalid"] is False
     assert int(res["root"]) == tree.root and res["nInputs"] == 73 and res["nPublic"] == 73
     assert res["info"]["domainSize"] == 1 << 17
+    assert res["okTree"] is True                             # GPU batch hash / balance tree from JavaScript
