@@ -96,6 +96,12 @@ int zkr_prove_device(zkr_key *key, const void *d_witness_std, const uint8_t *r32
  * zkr_prove_device(...) == submit + collect. */
 int zkr_prove_submit(zkr_key *key, const void *d_witness_std, const uint8_t *r32, const uint8_t *s32, void *stream, int *ticket);
 int zkr_prove_collect(zkr_key *key, int ticket, uint8_t proof_out[256]);
+/* A whole batch from host buffers (the rollup operator's case: `count` independent witnesses against one key, e.g. the
+ * proofs of BASELINE config 4 assigned to this GPU): uploads and proofs pipelined over the key's workspaces.
+ * witnesses_std: `count` host pointers to witness_len bytes each; r32s / s32s: count x 32 B blinding scalars or NULL
+ * (drawn per proof); proofs_out: count x 256 B.  Stops at the first failing proof (its status is returned). */
+int zkr_prove_batch(zkr_key *key, const void *const *witnesses_std, size_t witness_len, size_t count, const uint8_t *r32s, const uint8_t *s32s,
+                    uint8_t *proofs_out);
 /* Number of proof workspaces of the key = proofs that can be in flight. */
 int zkr_key_slots(const zkr_key *key);
 

@@ -511,6 +511,38 @@ int zkr_prove_collect(zkr_key *key, int ticket, uint8_t proof_out[256]) {
   return prove_collect(key, key->slot[ticket], proof_out);
 }
 
+int zkr_prove_batch(zkr_key *key, const void *const *witnesses_std, size_t witness_len, size_t count, const uint8_t *r32s, const uint8_t *s32s,
+                    uint8_t *proofs_out) {
+  if (!key || (!witnesses_std && count) || !proofs_out) { set_error("null argument"); return ZKR_ERR_ARG; }
+  if (witness_len != (size_t)key->h.n * 32) { set_error("witness is %zu bytes, key expects nVars*32 = %zu", witness_len, (size_t)key->h.n * 32); return ZKR_ERR_BAD_WITNESS; }
+  int tickets[PROOF_SLOTS];
+  size_t index[PROOF_SLOTS];
+  int in_flight = 0, rc = 0;
+  auto collect_oldest = [&]() {
+    int r = prove_collect(key, key->slot[tickets[0]], proofs_out + 256 * index[0]);
+    for (int j = 1; j < in_flight; j++) { tickets[j - 1] = tickets[j]; index[j - 1] = index[j]; }
+    in_flight--;
+    return r;
+  };
+  for (size_t i = 0; i < count && !rc; i++) {
+    if (!witnesses_std[i]) { set_error("witness %zu is null", i); rc = ZKR_ERR_ARG; break; }
+    if (in_flight == PROOF_SLOTS) rc = collect_oldest();
+    if (rc) break;
+    int t = -1;
+    rc = with_free_slot(key, true, &t, [&](ProofSlot &sl) -> int {
+      ZKR_HIP_CHECK(hipSetDevice(key->device));
+      ZKR_HIP_CHECK(hipMemcpyAsync(sl.d_wraw, witnesses_std[i], witness_len, hipMemcpyHostToDevice, key->prep_stream));
+      return prove_submit(key, sl, sl.d_wraw, r32s ? r32s + 32 * i : nullptr, s32s ? s32s + 32 * i : nullptr, key->prep_stream);
+    });
+    if (!rc) { tickets[in_flight] = t; index[in_flight] = i; in_flight++; }
+  }
+  while (in_flight > 0) {  // drain, also after an error: a submitted proof must be collected to free its slot
+    int r = collect_oldest();
+    if (!rc) rc = r;
+  }
+  return rc;
+}
+
 int zkr_prove_device(zkr_key *key, const void *d_witness_std, const uint8_t *r32, const uint8_t *s32, uint8_t proof_out[256], void *stream) {
   if (!key || !d_witness_std || !proof_out) { set_error("null argument"); return ZKR_ERR_ARG; }
   int t = -1;

@@ -43,6 +43,7 @@ def lib():
     L.zkr_prove_device.argtypes = [vp, vp, u8p, u8p, u8p, vp]
     L.zkr_prove_submit.argtypes = [vp, vp, u8p, u8p, vp, c.POINTER(i)]
     L.zkr_prove_collect.argtypes = [vp, i, u8p]
+    L.zkr_prove_batch.argtypes = [vp, c.POINTER(c.c_char_p), sz, sz, u8p, u8p, u8p]
     L.zkr_verify.argtypes = [u8p, sz, u8p, u8p, sz, c.POINTER(i)]
     L.zkr_ntt.argtypes = [u8p, c.c_uint, i, i]
     L.zkr_msm_g1.argtypes = [u8p, u8p, sz, u8p, c.POINTER(i), i]
@@ -229,6 +230,18 @@ class ProvingKey:
         while pending:
             out.append(self.prove_collect(pending.popleft()))
         return out
+
+    def prove_batch(self, witnesses, rs=None, ss=None):
+        """zkr_prove_batch: host witnesses (bytes, equal length) -> list of 256-byte proofs, uploads and proofs pipelined."""
+        n = len(witnesses)
+        if n == 0:
+            return []
+        arr = (ctypes.c_char_p * n)(*[bytes(w) for w in witnesses])
+        rb = None if rs is None else b"".join(int(x).to_bytes(32, "little") for x in rs)
+        sb = None if ss is None else b"".join(int(x).to_bytes(32, "little") for x in ss)
+        out = ctypes.create_string_buffer(256 * n)
+        _check(lib().zkr_prove_batch(self._h, arr, len(witnesses[0]), n, rb, sb, out))
+        return [out.raw[256 * i:256 * i + 256] for i in range(n)]
 
     def slots(self):
         """Proofs the key can hold in flight (zkr_prove_submit before zkr_prove_collect)."""

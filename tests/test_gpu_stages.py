@@ -330,3 +330,26 @@ def test_hip_path_reproduces_committed_golden_fixtures(name):
     assert pj == fx["proof"]
     pub = [int.from_bytes(wb[32 * i:32 * i + 32], "little") for i in range(1, int(fx["n_public"]) + 1)]
     assert zkr_hip.solidity_proof(pj, pub) == fx["solidity_proof"]
+
+
+def test_prove_batch_from_host_buffers_equals_single_proofs(small_case):
+    """zkr_prove_batch (host witnesses, uploads and proofs pipelined over the key's workspaces) == zkr_prove one by one ==
+    the oracle; a witness of the wrong length is refused before anything is enqueued."""
+    import zkr_hip
+    c = small_case
+    key = zkr_hip.ProvingKey.load_websnark(c["pkb"])
+    wits, rs, ss = [], [], []
+    for i in range(5):
+        wb = c["wb"] if i % 2 == 0 else zkr_hip.synth_witness(7, 7, 0x5A4B0001, 900 + i)
+        wits.append(wb)
+        rs.append(1000 + i)
+        ss.append(2000 + i)
+    proofs = key.prove_batch(wits, rs, ss)
+    assert len(proofs) == 5
+    for i in range(5):
+        assert proofs[i] == key.prove(wits[i], rs[i], ss[i]) == coracle.prove(c["pkb"], wits[i], rs[i], ss[i])
+    assert key.prove_batch([]) == []
+    with pytest.raises(zkr_hip.ZkrError) as e:
+        key.prove_batch([wits[0][:-32]])
+    assert e.value.code == -3
+    assert key.prove(wits[1], 5, 6) == coracle.prove(c["pkb"], wits[1], 5, 6)      # the key is still usable
