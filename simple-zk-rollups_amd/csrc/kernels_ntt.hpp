@@ -9,6 +9,7 @@
 //   inside LDS on a tile of 2^(hi-lo) rows x W columns (W consecutive elements -> 32*W contiguous
 //   bytes per row in HBM).  DIF passes run top-down (natural in -> bit-reversed out), DIT passes
 //   bottom-up (bit-reversed in -> natural out), so no explicit permutation is ever done.
+//   Inside a pass the stages run in pairs on four elements held in registers (one barrier per two stages).
 //   LDS tile is limb-major (SoA): lane l touches bank (l mod 32) for every ds_read_b32 -> conflict free.
 //   Twiddles w_{2s}^x come from one table per key (w_{2m}^k, k<m, serves all spans up to m and the
 //   coset factors) plus a 32 KB table w_2048^k shared by every contiguous pass (L1/L2 resident).
@@ -89,35 +90,82 @@ static __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArg
   }
   __syncthreads();
 
-  const uint32_t nbf = tile >> 1;
-  for (int jj = 0; jj < nb; jj++) {
-    const int j = DIF ? nb - 1 - jj : jj;
+  // Stages run in PAIRS on four elements held in registers (one LDS round trip and one barrier per two stages; index
+  // math modelled in tests/test_ntt_plan.py `double`); an odd stage count starts with one single stage.
+  auto twiddle = [&](int slog, uint32_t imods) {
+    return slog <= TWL_LOG ? tw_lookup(a.twl, TWL_LOG, slog, imods, a.inverse != 0) : tw_lookup(a.tw, a.tlog, slog, imods, a.inverse != 0);
+  };
+  auto lds_get = [&](uint32_t e) {
+    Fr x;
+#pragma unroll
+    for (int k = 0; k < 8; k++) x.v[k] = lds[k * tile + e];
+    return x;
+  };
+  auto lds_put = [&](uint32_t e, const Fr &x) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) lds[k * tile + e] = x.v[k];
+  };
+  auto butterfly = [&](Fr &u, Fr &v, const Fr &w) {
+    if (DIF) {
+      Fr d = sub(u, v);
+      u = add(u, v);
+      v = mul(d, w);
+    } else {
+      Fr t = mul(v, w);
+      v = sub(u, t);
+      u = add(u, t);
+    }
+  };
+  auto single_stage = [&](int j) {
     const uint32_t sl = 1u << j;
-    const int slog = j + a.lo;  // log2 of the global span
-    const Fr *table = slog <= TWL_LOG ? a.twl : a.tw;
-    const int tlog = slog <= TWL_LOG ? TWL_LOG : a.tlog;
-    for (uint32_t b = threadIdx.x; b < nbf; b += NTT_THREADS) {
+    for (uint32_t b = threadIdx.x; b < (tile >> 1); b += NTT_THREADS) {
       uint32_t c = b & (W - 1), kk = b >> a.wlog;
       uint32_t r0 = ((kk >> j) << (j + 1)) | (kk & (sl - 1));
       uint32_t e0 = (r0 << a.wlog) + c, e1 = e0 + (sl << a.wlog);
-      uint32_t imods = ((kk & (sl - 1)) << a.lo) + l0 + c;  // i mod s
-      Fr w = tw_lookup(table, tlog, slog, imods, a.inverse != 0);
-      Fr u, v;
-#pragma unroll
-      for (int k = 0; k < 8; k++) { u.v[k] = lds[k * tile + e0]; v.v[k] = lds[k * tile + e1]; }
-      Fr x0, x1;
-      if (DIF) {
-        x0 = add(u, v);
-        x1 = mul(sub(u, v), w);
-      } else {
-        v = mul(v, w);
-        x0 = add(u, v);
-        x1 = sub(u, v);
-      }
-#pragma unroll
-      for (int k = 0; k < 8; k++) { lds[k * tile + e0] = x0.v[k]; lds[k * tile + e1] = x1.v[k]; }
+      Fr w = twiddle(j + a.lo, ((kk & (sl - 1)) << a.lo) + l0 + c);
+      Fr u = lds_get(e0), v = lds_get(e1);
+      butterfly(u, v, w);
+      lds_put(e0, u);
+      lds_put(e1, v);
     }
     __syncthreads();
+  };
+  auto double_stage = [&](int j) {  // stages j and j + 1
+    const uint32_t sl = 1u << j;
+    for (uint32_t t = threadIdx.x; t < (tile >> 2); t += NTT_THREADS) {
+      uint32_t c = t & (W - 1), kq = t >> a.wlog;
+      uint32_t xlow = kq & (sl - 1);
+      uint32_t r00 = ((kq >> j) << (j + 2)) | xlow;
+      uint32_t e00 = (r00 << a.wlog) + c, e01 = e00 + (sl << a.wlog), e10 = e00 + (sl << (a.wlog + 1)), e11 = e10 + (sl << a.wlog);
+      uint32_t im = (xlow << a.lo) + l0 + c;
+      Fr wa = twiddle(j + a.lo, im), wb0 = twiddle(j + 1 + a.lo, im), wb1 = twiddle(j + 1 + a.lo, im + (sl << a.lo));
+      Fr x00 = lds_get(e00), x01 = lds_get(e01), x10 = lds_get(e10), x11 = lds_get(e11);
+      if (DIF) {  // stage j + 1 first
+        butterfly(x00, x10, wb0);
+        butterfly(x01, x11, wb1);
+        butterfly(x00, x01, wa);
+        butterfly(x10, x11, wa);
+      } else {    // stage j first
+        butterfly(x00, x01, wa);
+        butterfly(x10, x11, wa);
+        butterfly(x00, x10, wb0);
+        butterfly(x01, x11, wb1);
+      }
+      lds_put(e00, x00);
+      lds_put(e01, x01);
+      lds_put(e10, x10);
+      lds_put(e11, x11);
+    }
+    __syncthreads();
+  };
+  if (DIF) {
+    int j = nb - 1;
+    if (nb & 1) { single_stage(j); j--; }
+    for (; j >= 1; j -= 2) double_stage(j - 1);
+  } else {
+    int j = 0;
+    if (nb & 1) { single_stage(0); j = 1; }
+    for (; j + 1 < nb; j += 2) double_stage(j);
   }
 
   for (uint32_t e = threadIdx.x; e < tile; e += NTT_THREADS) {

@@ -42,7 +42,7 @@ def ntt_plan(L, tile_log, strided_log):
     return v
 
 
-def ntt_pass(x, L, lo, hi, wlog, dif, inverse, tw, tlog, twl, twl_log):
+def ntt_pass(x, L, lo, hi, wlog, dif, inverse, tw, tlog, twl, twl_log, fused=True):
     nb, W = hi - lo, 1 << wlog
     rows = 1 << nb
     tile = rows << wlog
@@ -51,33 +51,78 @@ def ntt_pass(x, L, lo, hi, wlog, dif, inverse, tw, tlog, twl, twl_log):
         q, l0 = blk // lb, (blk % lb) << wlog
         base = (q << hi) + l0
         lds = [x[base + ((e >> wlog) << lo) + (e & (W - 1))] for e in range(tile)]
-        for jj in range(nb):
-            j = nb - 1 - jj if dif else jj
-            sl, slog = 1 << j, j + lo
+        def twiddle(slog, imods):
             table, tl = (twl, twl_log) if slog <= twl_log else (tw, tlog)
+            return tw_lookup(table, tl, slog, imods, inverse)
+
+        def bf(u, v, w):
+            if dif:
+                return (u + v) % R, (u - v) * w % R
+            v = v * w % R
+            return (u + v) % R, (u - v) % R
+
+        def single(j):
+            sl = 1 << j
             for b in range(tile >> 1):
                 c, kk = b & (W - 1), b >> wlog
                 r0 = ((kk >> j) << (j + 1)) | (kk & (sl - 1))
                 e0 = (r0 << wlog) + c
                 e1 = e0 + (sl << wlog)
-                imods = ((kk & (sl - 1)) << lo) + l0 + c
-                w = tw_lookup(table, tl, slog, imods, inverse)
-                u, v = lds[e0], lds[e1]
-                if dif:
-                    lds[e0], lds[e1] = (u + v) % R, (u - v) * w % R
-                else:
-                    v = v * w % R
-                    lds[e0], lds[e1] = (u + v) % R, (u - v) % R
+                w = twiddle(j + lo, ((kk & (sl - 1)) << lo) + l0 + c)
+                lds[e0], lds[e1] = bf(lds[e0], lds[e1], w)
+
+        def double(j):  # stages j and j+1 on four elements held in registers (one LDS round trip, one barrier)
+            sl = 1 << j
+            for t in range(tile >> 2):
+                c, kq = t & (W - 1), t >> wlog
+                xlow = kq & (sl - 1)
+                r00 = ((kq >> j) << (j + 2)) | xlow
+                e = [((r00 + a * sl + b * 2 * sl) << wlog) + c for b in (0, 1) for a in (0, 1)]   # e00, e01, e10, e11
+                wa = twiddle(j + lo, (xlow << lo) + l0 + c)
+                wb0 = twiddle(j + 1 + lo, (xlow << lo) + l0 + c)
+                wb1 = twiddle(j + 1 + lo, ((xlow + sl) << lo) + l0 + c)
+                x00, x01, x10, x11 = (lds[i] for i in e)
+                if dif:     # stage j+1 first
+                    a0, a2 = bf(x00, x10, wb0)
+                    a1, a3 = bf(x01, x11, wb1)
+                    y00, y01 = bf(a0, a1, wa)
+                    y10, y11 = bf(a2, a3, wa)
+                else:       # stage j first
+                    a0, a1 = bf(x00, x01, wa)
+                    a2, a3 = bf(x10, x11, wa)
+                    y00, y10 = bf(a0, a2, wb0)
+                    y01, y11 = bf(a1, a3, wb1)
+                lds[e[0]], lds[e[1]], lds[e[2]], lds[e[3]] = y00, y01, y10, y11
+
+        if not fused:
+            for jj in range(nb):
+                single(nb - 1 - jj if dif else jj)
+        elif dif:
+            j = nb - 1
+            if nb & 1:
+                single(j)
+                j -= 1
+            while j >= 1:
+                double(j - 1)
+                j -= 2
+        else:
+            j = 0
+            if nb & 1:
+                single(0)
+                j = 1
+            while j + 1 < nb:
+                double(j)
+                j += 2
         for e in range(tile):
             x[base + ((e >> wlog) << lo) + (e & (W - 1))] = lds[e]
 
 
-def run_ntt(x, L, dif, inverse, tw, tlog, twl, twl_log, tile_log=4, strided_log=3):
+def run_ntt(x, L, dif, inverse, tw, tlog, twl, twl_log, tile_log=4, strided_log=3, fused=True):
     plan = ntt_plan(L, tile_log, strided_log)
     if not dif:
         plan = plan[::-1]
     for lo, hi, wlog in plan:
-        ntt_pass(x, L, lo, hi, wlog, dif, inverse, tw, tlog, twl, twl_log)
+        ntt_pass(x, L, lo, hi, wlog, dif, inverse, tw, tlog, twl, twl_log, fused)
 
 
 def test_pass_structure_matches_oracle_ntt():
@@ -90,12 +135,19 @@ def test_pass_structure_matches_oracle_ntt():
         v = [rnd.randrange(R) for _ in range(m)]
         ref = g.ntt(v)
         x = list(v)
-        run_ntt(x, L, True, False, tw, L, twl, twl_log)
-        assert [x[bitrev(i, L)] for i in range(m)] == ref, L
-        y = [ref[bitrev(i, L)] for i in range(m)]
-        run_ntt(y, L, False, True, tw, L, twl, twl_log)
-        minv = pow(m, R - 2, R)
-        assert [a * minv % R for a in y] == v, L
+        for fused in (True, False):       # the device kernel fuses pairs of stages; the plain form is the same network
+            x = list(v)
+            run_ntt(x, L, True, False, tw, L, twl, twl_log, fused=fused)
+            assert [x[bitrev(i, L)] for i in range(m)] == ref, L
+            y = [ref[bitrev(i, L)] for i in range(m)]
+            run_ntt(y, L, False, True, tw, L, twl, twl_log, fused=fused)
+            minv = pow(m, R - 2, R)
+            assert [a * minv % R for a in y] == v, L
+        # tile / strided geometries with odd and even stage counts per pass
+        for tile_log, strided_log in ((5, 3), (3, 2), (6, 4)):
+            x = list(v)
+            run_ntt(x, L, True, False, tw, L, twl, twl_log, tile_log, strided_log)
+            assert [x[bitrev(i, L)] for i in range(m)] == ref, (L, tile_log)
 
 
 def test_device_plan_shapes():
