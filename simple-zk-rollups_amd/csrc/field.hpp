@@ -190,6 +190,32 @@ __device__ __forceinline__ void mac96c_8(uint64_t &lo, uint32_t &c2, uint32_t x0
   asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %6, %7, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %8, %9, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %10, %11, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %12, %13, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %14, %15, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %16, %17, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(c2) : "v"(x0), "s"(Y0), "v"(x1), "s"(Y1), "v"(x2), "s"(Y2), "v"(x3), "s"(Y3), "v"(x4), "s"(Y4), "v"(x5), "s"(Y5), "v"(x6), "s"(Y6), "v"(x7), "s"(Y7) : "vcc");
 }
 
+// first multiply-adds of a column: the carry word starts from the carry itself (no separate clearing of c2)
+__device__ __forceinline__ void mac96f_1(uint64_t &lo, uint32_t &c2, uint32_t x0, uint32_t y0) {
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32_e64 %1, vcc, 0, 0, vcc" : "+v"(lo), "=&v"(c2) : "v"(x0), "v"(y0) : "vcc");
+}
+__device__ __forceinline__ void mac96f_2(uint64_t &lo, uint32_t &c2, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1) {
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32_e64 %1, vcc, 0, 0, vcc\n\tv_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "=&v"(c2) : "v"(x0), "v"(y0), "v"(x1), "v"(y1) : "vcc");
+}
+__device__ __forceinline__ void mac96f_3(uint64_t &lo, uint32_t &c2, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, uint32_t x2, uint32_t y2) {
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32_e64 %1, vcc, 0, 0, vcc\n\tv_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %6, %7, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "=&v"(c2) : "v"(x0), "v"(y0), "v"(x1), "v"(y1), "v"(x2), "v"(y2) : "vcc");
+}
+__device__ __forceinline__ void mac96f_4(uint64_t &lo, uint32_t &c2, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, uint32_t x2, uint32_t y2, uint32_t x3, uint32_t y3) {
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32_e64 %1, vcc, 0, 0, vcc\n\tv_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %6, %7, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %8, %9, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "=&v"(c2) : "v"(x0), "v"(y0), "v"(x1), "v"(y1), "v"(x2), "v"(y2), "v"(x3), "v"(y3) : "vcc");
+}
+__device__ __forceinline__ void mac96f_5(uint64_t &lo, uint32_t &c2, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, uint32_t x2, uint32_t y2, uint32_t x3, uint32_t y3, uint32_t x4, uint32_t y4) {
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32_e64 %1, vcc, 0, 0, vcc\n\tv_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %6, %7, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %8, %9, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %10, %11, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "=&v"(c2) : "v"(x0), "v"(y0), "v"(x1), "v"(y1), "v"(x2), "v"(y2), "v"(x3), "v"(y3), "v"(x4), "v"(y4) : "vcc");
+}
+__device__ __forceinline__ void mac96f_6(uint64_t &lo, uint32_t &c2, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, uint32_t x2, uint32_t y2, uint32_t x3, uint32_t y3, uint32_t x4, uint32_t y4, uint32_t x5, uint32_t y5) {
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32_e64 %1, vcc, 0, 0, vcc\n\tv_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %6, %7, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %8, %9, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %10, %11, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %12, %13, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "=&v"(c2) : "v"(x0), "v"(y0), "v"(x1), "v"(y1), "v"(x2), "v"(y2), "v"(x3), "v"(y3), "v"(x4), "v"(y4), "v"(x5), "v"(y5) : "vcc");
+}
+__device__ __forceinline__ void mac96f_7(uint64_t &lo, uint32_t &c2, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, uint32_t x2, uint32_t y2, uint32_t x3, uint32_t y3, uint32_t x4, uint32_t y4, uint32_t x5, uint32_t y5, uint32_t x6, uint32_t y6) {
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32_e64 %1, vcc, 0, 0, vcc\n\tv_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %6, %7, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %8, %9, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %10, %11, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %12, %13, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %14, %15, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "=&v"(c2) : "v"(x0), "v"(y0), "v"(x1), "v"(y1), "v"(x2), "v"(y2), "v"(x3), "v"(y3), "v"(x4), "v"(y4), "v"(x5), "v"(y5), "v"(x6), "v"(y6) : "vcc");
+}
+__device__ __forceinline__ void mac96f_8(uint64_t &lo, uint32_t &c2, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, uint32_t x2, uint32_t y2, uint32_t x3, uint32_t y3, uint32_t x4, uint32_t y4, uint32_t x5, uint32_t y5, uint32_t x6, uint32_t y6, uint32_t x7, uint32_t y7) {
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32_e64 %1, vcc, 0, 0, vcc\n\tv_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %6, %7, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %8, %9, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %10, %11, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %12, %13, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %14, %15, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %16, %17, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "=&v"(c2) : "v"(x0), "v"(y0), "v"(x1), "v"(y1), "v"(x2), "v"(y2), "v"(x3), "v"(y3), "v"(x4), "v"(y4), "v"(x5), "v"(y5), "v"(x6), "v"(y6), "v"(x7), "v"(y7) : "vcc");
+}
+
 // Montgomery product a*b/2^256 mod p by product scanning (FIPS): columns k = 0..14 of a*b + m*p are
 // summed in a 96-bit accumulator; m[k] = column_k * (-p^-1) mod 2^32 zeroes the low word of each of the
 // first eight columns.  136 multiply-adds, 2 VALU instructions each.
@@ -236,50 +262,50 @@ ZKR_HD Fp<PM> mul(const Fp<PM> &a, const Fp<PM> &b) {
   uint32_t m[8], t[8];
   uint64_t lo = 0;
   uint32_t c2 = 0;
-#define ZKR_NEXT_COL lo = (lo >> 32) | ((uint64_t)c2 << 32); c2 = 0;
+#define ZKR_NEXT_COL lo = (lo >> 32) | ((uint64_t)c2 << 32);
 #define ZKR_FIN_LOW(K) m[K] = (uint32_t)lo * PM::INV; mac96c_1<P[0]>(lo, c2, m[K]); ZKR_NEXT_COL
-  mac96_1(lo, c2, x[0], y[0]);
+  mac96f_1(lo, c2, x[0], y[0]);
   ZKR_FIN_LOW(0)
-  mac96_2(lo, c2, x[0], y[1], x[1], y[0]);
+  mac96f_2(lo, c2, x[0], y[1], x[1], y[0]);
   mac96c_1<P[1]>(lo, c2, m[0]);
   ZKR_FIN_LOW(1)
-  mac96_3(lo, c2, x[0], y[2], x[1], y[1], x[2], y[0]);
+  mac96f_3(lo, c2, x[0], y[2], x[1], y[1], x[2], y[0]);
   mac96c_2<P[2], P[1]>(lo, c2, m[0], m[1]);
   ZKR_FIN_LOW(2)
-  mac96_4(lo, c2, x[0], y[3], x[1], y[2], x[2], y[1], x[3], y[0]);
+  mac96f_4(lo, c2, x[0], y[3], x[1], y[2], x[2], y[1], x[3], y[0]);
   mac96c_3<P[3], P[2], P[1]>(lo, c2, m[0], m[1], m[2]);
   ZKR_FIN_LOW(3)
-  mac96_5(lo, c2, x[0], y[4], x[1], y[3], x[2], y[2], x[3], y[1], x[4], y[0]);
+  mac96f_5(lo, c2, x[0], y[4], x[1], y[3], x[2], y[2], x[3], y[1], x[4], y[0]);
   mac96c_4<P[4], P[3], P[2], P[1]>(lo, c2, m[0], m[1], m[2], m[3]);
   ZKR_FIN_LOW(4)
-  mac96_6(lo, c2, x[0], y[5], x[1], y[4], x[2], y[3], x[3], y[2], x[4], y[1], x[5], y[0]);
+  mac96f_6(lo, c2, x[0], y[5], x[1], y[4], x[2], y[3], x[3], y[2], x[4], y[1], x[5], y[0]);
   mac96c_5<P[5], P[4], P[3], P[2], P[1]>(lo, c2, m[0], m[1], m[2], m[3], m[4]);
   ZKR_FIN_LOW(5)
-  mac96_7(lo, c2, x[0], y[6], x[1], y[5], x[2], y[4], x[3], y[3], x[4], y[2], x[5], y[1], x[6], y[0]);
+  mac96f_7(lo, c2, x[0], y[6], x[1], y[5], x[2], y[4], x[3], y[3], x[4], y[2], x[5], y[1], x[6], y[0]);
   mac96c_6<P[6], P[5], P[4], P[3], P[2], P[1]>(lo, c2, m[0], m[1], m[2], m[3], m[4], m[5]);
   ZKR_FIN_LOW(6)
-  mac96_8(lo, c2, x[0], y[7], x[1], y[6], x[2], y[5], x[3], y[4], x[4], y[3], x[5], y[2], x[6], y[1], x[7], y[0]);
+  mac96f_8(lo, c2, x[0], y[7], x[1], y[6], x[2], y[5], x[3], y[4], x[4], y[3], x[5], y[2], x[6], y[1], x[7], y[0]);
   mac96c_7<P[7], P[6], P[5], P[4], P[3], P[2], P[1]>(lo, c2, m[0], m[1], m[2], m[3], m[4], m[5], m[6]);
   ZKR_FIN_LOW(7)
-  mac96_7(lo, c2, x[1], y[7], x[2], y[6], x[3], y[5], x[4], y[4], x[5], y[3], x[6], y[2], x[7], y[1]);
+  mac96f_7(lo, c2, x[1], y[7], x[2], y[6], x[3], y[5], x[4], y[4], x[5], y[3], x[6], y[2], x[7], y[1]);
   mac96c_7<P[7], P[6], P[5], P[4], P[3], P[2], P[1]>(lo, c2, m[1], m[2], m[3], m[4], m[5], m[6], m[7]);
   t[0] = (uint32_t)lo; ZKR_NEXT_COL
-  mac96_6(lo, c2, x[2], y[7], x[3], y[6], x[4], y[5], x[5], y[4], x[6], y[3], x[7], y[2]);
+  mac96f_6(lo, c2, x[2], y[7], x[3], y[6], x[4], y[5], x[5], y[4], x[6], y[3], x[7], y[2]);
   mac96c_6<P[7], P[6], P[5], P[4], P[3], P[2]>(lo, c2, m[2], m[3], m[4], m[5], m[6], m[7]);
   t[1] = (uint32_t)lo; ZKR_NEXT_COL
-  mac96_5(lo, c2, x[3], y[7], x[4], y[6], x[5], y[5], x[6], y[4], x[7], y[3]);
+  mac96f_5(lo, c2, x[3], y[7], x[4], y[6], x[5], y[5], x[6], y[4], x[7], y[3]);
   mac96c_5<P[7], P[6], P[5], P[4], P[3]>(lo, c2, m[3], m[4], m[5], m[6], m[7]);
   t[2] = (uint32_t)lo; ZKR_NEXT_COL
-  mac96_4(lo, c2, x[4], y[7], x[5], y[6], x[6], y[5], x[7], y[4]);
+  mac96f_4(lo, c2, x[4], y[7], x[5], y[6], x[6], y[5], x[7], y[4]);
   mac96c_4<P[7], P[6], P[5], P[4]>(lo, c2, m[4], m[5], m[6], m[7]);
   t[3] = (uint32_t)lo; ZKR_NEXT_COL
-  mac96_3(lo, c2, x[5], y[7], x[6], y[6], x[7], y[5]);
+  mac96f_3(lo, c2, x[5], y[7], x[6], y[6], x[7], y[5]);
   mac96c_3<P[7], P[6], P[5]>(lo, c2, m[5], m[6], m[7]);
   t[4] = (uint32_t)lo; ZKR_NEXT_COL
-  mac96_2(lo, c2, x[6], y[7], x[7], y[6]);
+  mac96f_2(lo, c2, x[6], y[7], x[7], y[6]);
   mac96c_2<P[7], P[6]>(lo, c2, m[6], m[7]);
   t[5] = (uint32_t)lo; ZKR_NEXT_COL
-  mac96_1(lo, c2, x[7], y[7]);
+  mac96f_1(lo, c2, x[7], y[7]);
   mac96c_1<P[7]>(lo, c2, m[7]);
   t[6] = (uint32_t)lo; ZKR_NEXT_COL
   t[7] = (uint32_t)lo;  // column 15 is empty and (a*b + m*p)/2^256 < 2p < 2^255
