@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-O=gpurun_out/r10; mkdir -p $O
-python -m pytest tests -x -q -m gpu 2>&1 | tail -3
+O=gpurun_out/r11; mkdir -p $O
+
 python bench.py > $O/bench.json 2>$O/bench.err
 python bench.py --no-pipeline --no-cpu-baseline --no-tx-circuit > $O/bench_sync.json 2>/dev/null
 python bench.py --log-m 22 --steps 20 --no-cpu-baseline --no-tx-circuit > $O/bench_2_22.json 2>/dev/null
