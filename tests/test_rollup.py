@@ -311,3 +311,23 @@ def test_withdraw_circuit_derives_the_public_key():
     with pytest.raises(zkr_hip.ZkrError) as e:
         c.calculate_witness({"privateKey": 1 << 253, "nullifier": 1})     # Num2Bits(253), publickeyderivation.circom:12-13
     assert e.value.code == -7
+
+
+def test_ragged_or_out_of_field_circuit_inputs_are_refused():
+    """A path one element short, an extra transaction, or a value >= r passed as a flat list never reaches the builder."""
+    import zkr_hip
+    from zkr_hip import rollup as n
+    c = n.RollupCircuit(2, 3)
+    txs, _, _ = scenario(2, 3, 23)
+    inp = as_inputs(txs)
+    short = dict(inp, txSenderPathElements=[inp["txSenderPathElements"][0], inp["txSenderPathElements"][1][:-1]])
+    with pytest.raises(zkr_hip.ZkrError) as e:
+        c.calculate_witness(short)
+    assert e.value.code == -5
+    with pytest.raises(zkr_hip.ZkrError):
+        c.calculate_witness(dict(inp, balanceTreeRoot=inp["balanceTreeRoot"] + [1]))
+    flat = c.flatten_inputs(inp)
+    with pytest.raises(zkr_hip.ZkrError) as e:
+        c.calculate_witness(flat[:5] + [n.SNARK_FIELD_SIZE] + flat[6:])       # the C ABI takes canonical field elements only
+    assert e.value.code == -5 and ">= r" in str(e.value)
+    assert c.calculate_witness(dict(inp, txData=[[v + n.SNARK_FIELD_SIZE for v in t] for t in inp["txData"]])) == c.calculate_witness(inp)  # dict inputs are reduced like circom's
