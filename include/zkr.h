@@ -115,6 +115,11 @@ int zkr_key_slots(const zkr_key *key);
  * inputs, 32 B each.  *valid = 1 / 0; inputs >= r (TxVerifier.sol:265) and off-curve proof points give 0.
  * Returns an error only for a malformed key or a wrong input count. */
 int zkr_verify(const void *vk_bin, size_t vk_len, const uint8_t proof[256], const void *public_std, size_t n_public, int *valid);
+/* n_proofs proofs (n_proofs x 256 B) with their public signals (n_proofs x n_public x 32 B) under one key, merged by a
+ * random linear combination (128-bit coefficients from the OS CSPRNG) into ONE product of n_proofs + 3 pairings with one
+ * final exponentiation: *all_valid = 1 iff every proof verifies (an invalid one slips through with
+ * probability 2^-128); about 0.5 ms per proof instead of 3.7.  Use zkr_verify to locate a failing proof. */
+int zkr_verify_batch(const void *vk_bin, size_t vk_len, const uint8_t *proofs, const void *publics_std, size_t n_proofs, size_t n_public, int *all_valid);
 
 /* ---- stage hooks (tests, profiling) ----------------------------------------------------------- */
 /* In-place NTT of n = 2^logn standard-form elements in host memory; natural order in and out. */

@@ -4,7 +4,9 @@
 // (/root/reference/contracts/contracts/TxVerifier.sol:258-276):
 //     vk_x = IC_0 + sum_i input_i * IC_{i+1};   e(-A, B) e(alfa, beta) e(vk_x, gamma) e(C, delta) == 1.
 // SURVEY.md 8(a5) / 8(f-4).  No GPU involved (a few milliseconds of host time per proof).
+#include <stdio.h>
 #include <string.h>
+#include <algorithm>
 #include <vector>
 #include "pairing.hpp"
 #include "zkr_internal.hpp"
@@ -39,9 +41,14 @@ static bool read_g2(const uint8_t *p, G2Affine &out) {
   return !out.is_inf() && pairing::g2_on_curve(out);
 }
 
-extern "C" int zkr_verify(const void *vk_bin, size_t vk_len, const uint8_t proof[256], const void *public_std, size_t n_public, int *valid) {
-  if (!vk_bin || !proof || !valid || (n_public && !public_std)) { set_error("null argument"); return ZKR_ERR_ARG; }
-  *valid = 0;
+namespace {
+struct ParsedVk {
+  G1Affine alfa1, ic0;
+  G2Affine beta2, gamma2, delta2;
+  std::vector<G1Affine> ics;  // IC_1 .. IC_nPublic
+};
+// the whole key is checked before any proof is looked at: a malformed key is an error, whatever the proofs
+int parse_vk(const void *vk_bin, size_t vk_len, size_t n_public, ParsedVk &k) {
   const uint8_t *vk = (const uint8_t *)vk_bin;
   const size_t fixed = 64 + 3 * 128 + 4;
   if (vk_len < fixed) { set_error("verifying key shorter than its fixed part (%zu bytes)", fixed); return ZKR_ERR_BAD_KEY; }
@@ -49,40 +56,120 @@ extern "C" int zkr_verify(const void *vk_bin, size_t vk_len, const uint8_t proof
   memcpy(&n_ic, vk + 64 + 3 * 128, 4);
   if (vk_len != fixed + 64ull * n_ic) { set_error("verifying key length %zu does not match %u IC points", vk_len, n_ic); return ZKR_ERR_BAD_KEY; }
   if (n_ic != n_public + 1) { set_error("%zu public signals for a key with %u IC points (needs nPublic + 1, TxVerifier.sol:261)", n_public, n_ic); return ZKR_ERR_ARG; }
-  G1Affine alfa1, ic0;
-  G2Affine beta2, gamma2, delta2;
-  if (!read_g1(vk, alfa1) || !read_g2(vk + 64, beta2) || !read_g2(vk + 192, gamma2) || !read_g2(vk + 320, delta2) || !read_g1(vk + fixed, ic0)) {
+  if (!read_g1(vk, k.alfa1) || !read_g2(vk + 64, k.beta2) || !read_g2(vk + 192, k.gamma2) || !read_g2(vk + 320, k.delta2) || !read_g1(vk + fixed, k.ic0)) {
     set_error("verifying key holds a point that is not on the curve");
     return ZKR_ERR_BAD_KEY;
   }
-  // the whole key is checked before the proof is looked at: a malformed key is an error, whatever the proof
-  std::vector<G1Affine> ics(n_public);
+  k.ics.resize(n_public);
   for (size_t i = 0; i < n_public; i++)
-    if (!read_g1(vk + fixed + 64 * (i + 1), ics[i])) { set_error("verifying key IC[%zu] is not on the curve", i + 1); return ZKR_ERR_BAD_KEY; }
-  // proof points: off-curve or out-of-range coordinates simply do not verify
-  G1Affine a, c;
-  G2Affine b;
-  if (!read_g1(proof, a) || !read_g2(proof + 64, b) || !read_g1(proof + 192, c)) return 0;
-  // vk_x = IC_0 + sum input_i IC_{i+1}; every input must be < r (TxVerifier.sol:265).  Interleaved 4-bit windows
-  // (Straus): one shared chain of 252 doublings, one addition per input and window.
-  std::vector<G1XYZZ> tab(n_public * 15);  // tab[i * 15 + d - 1] = d * IC_{i+1}
-  const uint8_t *pub = (const uint8_t *)public_std;
-  for (size_t i = 0; i < n_public; i++) {
-    if (!fr_lt_r(pub + 32 * i)) return 0;
-    G1XYZZ base = to_xyzz(ics[i]), cur = base;
+    if (!read_g1(vk + fixed + 64 * (i + 1), k.ics[i])) { set_error("verifying key IC[%zu] is not on the curve", i + 1); return ZKR_ERR_BAD_KEY; }
+  return 0;
+}
+// sum_i scalar_i * IC_{i+1}, scalars standard 32 B each: interleaved 4-bit windows (Straus), one shared chain of 252
+// doublings, one addition per scalar and window
+G1XYZZ ic_combination(const ParsedVk &k, const uint8_t *scalars) {
+  const size_t n = k.ics.size();
+  std::vector<G1XYZZ> tab(n * 15);  // tab[i * 15 + d - 1] = d * IC_{i+1}
+  for (size_t i = 0; i < n; i++) {
+    G1XYZZ base = to_xyzz(k.ics[i]), cur = base;
     for (int d = 0; d < 15; d++) { tab[i * 15 + d] = cur; cur = add_full(cur, base); }
   }
   G1XYZZ acc = G1XYZZ::inf();
   for (int w = 63; w >= 0; w--) {
-    if (w != 63) for (int k = 0; k < 4; k++) acc = dbl_xyzz(acc);
-    for (size_t i = 0; i < n_public; i++) {
-      unsigned d = (pub[32 * i + w / 2] >> ((w & 1) * 4)) & 15u;
+    if (w != 63) for (int j = 0; j < 4; j++) acc = dbl_xyzz(acc);
+    for (size_t i = 0; i < n; i++) {
+      unsigned d = (scalars[32 * i + w / 2] >> ((w & 1) * 4)) & 15u;
       if (d) acc = add_full(acc, tab[i * 15 + d - 1]);
     }
   }
-  G1XYZZ vkx = add_full(acc, to_xyzz(ic0));
-  G1Affine ps[4] = {G1Affine{a.x, neg(a.y)}, alfa1, to_affine(vkx), c};
-  G2Affine qs[4] = {b, beta2, gamma2, delta2};
+  return acc;
+}
+}  // namespace
+
+extern "C" int zkr_verify(const void *vk_bin, size_t vk_len, const uint8_t proof[256], const void *public_std, size_t n_public, int *valid) {
+  if (!vk_bin || !proof || !valid || (n_public && !public_std)) { set_error("null argument"); return ZKR_ERR_ARG; }
+  *valid = 0;
+  ParsedVk k;
+  int rc = parse_vk(vk_bin, vk_len, n_public, k);
+  if (rc) return rc;
+  // proof points: off-curve or out-of-range coordinates simply do not verify
+  G1Affine a, c;
+  G2Affine b;
+  if (!read_g1(proof, a) || !read_g2(proof + 64, b) || !read_g1(proof + 192, c)) return 0;
+  // vk_x = IC_0 + sum input_i IC_{i+1}; every input must be < r (TxVerifier.sol:265)
+  const uint8_t *pub = (const uint8_t *)public_std;
+  for (size_t i = 0; i < n_public; i++)
+    if (!fr_lt_r(pub + 32 * i)) return 0;
+  G1XYZZ vkx = add_full(ic_combination(k, pub), to_xyzz(k.ic0));
+  G1Affine ps[4] = {G1Affine{a.x, neg(a.y)}, k.alfa1, to_affine(vkx), c};
+  G2Affine qs[4] = {b, k.beta2, k.gamma2, k.delta2};
   *valid = pairing::pairing_product_is_one(ps, qs, 4) ? 1 : 0;
+  return 0;
+}
+
+// Many proofs under one key with ONE final exponentiation: each proof's equation is raised to a random 128-bit z_i
+// (z_0 = 1; OS CSPRNG) and the products are merged,
+//     prod_i e(-z_i A_i, B_i) * e((sum z_i) alfa, beta) * e(sum_i z_i vk_x_i, gamma) * e(sum_i z_i C_i, delta) == 1,
+// where sum_i z_i vk_x_i = (sum z_i) IC_0 + sum_j (sum_i z_i input_ij mod r) IC_{j+1} is one combination of the IC points.
+// n + 3 Miller loops instead of 4 n; a batch with an invalid proof passes with probability 2^-128.
+extern "C" int zkr_verify_batch(const void *vk_bin, size_t vk_len, const uint8_t *proofs, const void *publics_std, size_t n_proofs, size_t n_public, int *all_valid) {
+  if (!vk_bin || !all_valid || (n_proofs && (!proofs || (n_public && !publics_std)))) { set_error("null argument"); return ZKR_ERR_ARG; }
+  *all_valid = 0;
+  ParsedVk k;
+  int rc = parse_vk(vk_bin, vk_len, n_public, k);
+  if (rc) return rc;
+  if (n_proofs == 0) { *all_valid = 1; return 0; }
+  const uint8_t *pub = (const uint8_t *)publics_std;
+  std::vector<uint8_t> z(32 * n_proofs, 0);
+  {
+    FILE *f = fopen("/dev/urandom", "rb");
+    if (!f) { set_error("cannot open /dev/urandom"); return ZKR_ERR_ARG; }
+    bool bad = false;
+    for (size_t i = 1; i < n_proofs && !bad; i++) bad = fread(&z[32 * i], 1, 16, f) != 16;
+    fclose(f);
+    if (bad) { set_error("short read from /dev/urandom"); return ZKR_ERR_ARG; }
+    z[0] = 1;
+  }
+  std::vector<G1Affine> ps;
+  std::vector<G2Affine> qs;
+  std::vector<Fr> comb(n_public, Fr::zero());  // sum_i z_i input_ij (Montgomery)
+  Fr zsum = Fr::zero();
+  G1XYZZ csum = G1XYZZ::inf();
+  for (size_t i = 0; i < n_proofs; i++) {
+    const uint8_t *pr = proofs + 256 * i;
+    G1Affine a, c;
+    G2Affine b;
+    if (!read_g1(pr, a) || !read_g2(pr + 64, b) || !read_g1(pr + 192, c)) return 0;
+    U256 zi = load_u256(&z[32 * i]);
+    Fr zm = to_mont(load_fp<FrParams>(&z[32 * i]));
+    zsum = add(zsum, zm);
+    for (size_t j = 0; j < n_public; j++) {
+      const uint8_t *v = pub + 32 * (i * n_public + j);
+      if (!fr_lt_r(v)) return 0;
+      comb[j] = add(comb[j], mul(zm, to_mont(load_fp<FrParams>(v))));
+    }
+    G1XYZZ za = scalar_mul(to_xyzz(G1Affine{a.x, neg(a.y)}), zi);  // 128-bit scalars: the loop skips the leading zero bits cheaply
+    csum = add_full(csum, scalar_mul(to_xyzz(c), zi));
+    ps.push_back(to_affine(za));
+    qs.push_back(b);
+  }
+  std::vector<uint8_t> comb_std(32 * n_public);
+  for (size_t j = 0; j < n_public; j++) store_fp(&comb_std[32 * j], from_mont(comb[j]));
+  Fr zs_std = from_mont(zsum);
+  U256 zs;
+  memcpy(zs.v, zs_std.v, 32);
+  G1XYZZ vkx = add_full(ic_combination(k, comb_std.data()), scalar_mul(to_xyzz(k.ic0), zs));
+  ps.push_back(to_affine(scalar_mul(to_xyzz(k.alfa1), zs)));
+  qs.push_back(k.beta2);
+  ps.push_back(to_affine(vkx));
+  qs.push_back(k.gamma2);
+  ps.push_back(to_affine(csum));
+  qs.push_back(k.delta2);
+  pairing::Fq12 f = pairing::Fq12::one();
+  for (size_t at = 0; at < ps.size(); at += pairing::MAX_PAIRS) {
+    int m = (int)std::min<size_t>(pairing::MAX_PAIRS, ps.size() - at);
+    f = pairing::mul(f, pairing::multi_miller_loop(&ps[at], &qs[at], m));
+  }
+  *all_valid = pairing::final_exponentiation(f) == pairing::Fq12::one() ? 1 : 0;
   return 0;
 }

@@ -30,6 +30,8 @@ export function binarifyProvingKey(provingKey: any): ArrayBuffer;
 export function solidityProof(proof: Groth16Proof, publicSignals: Array<bigint | string>): { a: string[]; b: string[][]; c: string[]; inputs: string[] };
 /** snarkjs groth.isValid(vk, proof, publicSignals) on the native host verifier (no GPU needed). */
 export function isValid(verifyingKey: any, proof: Groth16Proof, publicSignals: Array<bigint | string>): boolean;
+/** All proofs of a batch under one key with one merged pairing product (random linear combination). */
+export function isValidBatch(verifyingKey: any, proofs: Groth16Proof[], publicSignalsList: Array<Array<bigint | string>>): boolean;
 export function binarifyVerifyingKey(verifyingKey: any): Uint8Array;
 export function binarifyR1cs(circuitDef: any): Uint8Array;
 export function verifyingKeyFromBytes(vkBin: Uint8Array): any;

@@ -208,6 +208,13 @@ function isValid(vk, proof, publicSignals) {
   return native().verify(binarifyVerifyingKey(vk), proofToBytes(proof), pub);
 }
 
+// every proof of a batch under one key, merged into one pairing product (zkr_verify_batch): true iff all verify
+function isValidBatch(vk, proofs, publicSignalsList) {
+  if (proofs.length === 0) return true;
+  const pub = Buffer.concat(publicSignalsList.map((ps) => Buffer.concat(ps.map((x) => bigintToLe32(BigInt(x))).concat([Buffer.alloc(0)]))));
+  return native().verifyBatch(binarifyVerifyingKey(vk), Buffer.concat(proofs.map(proofToBytes)), pub, proofs.length);
+}
+
 // operator/src/snarks/common.ts:43-50
 function solidityProof(proof, publicSignals) {
   return {
@@ -297,7 +304,7 @@ class WithdrawCircuit {
 }
 
 module.exports = {
-  buildBn128, genProof, binarifyWitness, binarifyProvingKey, solidityProof, proofFromBytes, isValid, binarifyVerifyingKey,
+  buildBn128, genProof, binarifyWitness, binarifyProvingKey, solidityProof, proofFromBytes, isValid, isValidBatch, binarifyVerifyingKey,
   binarifyR1cs, verifyingKeyFromBytes,
   multiHash, multiHashBatch, buildBalanceTree, hashLeftRight, genPublicKey, formatPrivKeyForBabyJub, sign, verify, RollupCircuit, WithdrawCircuit,
   deviceCount: () => { native(); return deviceCount; },

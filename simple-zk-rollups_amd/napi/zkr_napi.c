@@ -23,6 +23,7 @@ static struct {
   int (*key_info)(const zkr_key *, uint64_t *);
   int (*prove)(zkr_key *, const void *, size_t, const uint8_t *, const uint8_t *, uint8_t *, void *);
   int (*verify)(const void *, size_t, const uint8_t *, const void *, size_t, int *);
+  int (*verify_batch)(const void *, size_t, const uint8_t *, const void *, size_t, size_t, int *);
   int (*setup_r1cs)(const void *, size_t, const uint8_t *, int, zkr_key **, void **, size_t *);
   int (*key_save)(const zkr_key *, const char *);
   int (*key_load_file)(const char *, int, zkr_key **);
@@ -74,7 +75,7 @@ static napi_value js_load(napi_env env, napi_callback_info info) {
   *(void **)(&Z.field) = dlsym(h, name);                                        \
   if (!Z.field) return throw_msg(env, "libzkr_hip.so lacks symbol " name);
     SYM(last_error, "zkr_last_error") SYM(version, "zkr_version") SYM(device_count, "zkr_device_count")
-    SYM(key_load_websnark, "zkr_key_load_websnark") SYM(key_free, "zkr_key_free") SYM(key_info, "zkr_key_info") SYM(prove, "zkr_prove") SYM(verify, "zkr_verify")
+    SYM(key_load_websnark, "zkr_key_load_websnark") SYM(key_free, "zkr_key_free") SYM(key_info, "zkr_key_info") SYM(prove, "zkr_prove") SYM(verify, "zkr_verify") SYM(verify_batch, "zkr_verify_batch")
     SYM(setup_r1cs, "zkr_setup_r1cs") SYM(key_save, "zkr_key_save") SYM(key_load_file, "zkr_key_load_file") SYM(free_, "zkr_free")
     SYM(multihash, "zkr_mimcsponge_multihash") SYM(pubkey, "zkr_babyjub_pubkey") SYM(eddsa_sign, "zkr_eddsa_sign") SYM(eddsa_verify, "zkr_eddsa_verify")
     SYM(multihash_batch, "zkr_mimcsponge_multihash_batch") SYM(tree_build, "zkr_balance_tree_build")
@@ -448,6 +449,26 @@ static napi_value js_withdraw_circuit(napi_env env, napi_callback_info info) {
   return buf;
 }
 
+/* verifyBatch(vkBin, proofs (n x 256 B), publics (n x nPublic x 32 B), n) -> boolean: every proof verifies (zkr_verify_batch) */
+static napi_value js_verify_batch(napi_env env, napi_callback_info info) {
+  size_t argc = 4;
+  napi_value argv[4];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  if (!Z.handle) return throw_msg(env, "libzkr_hip.so not loaded");
+  const uint8_t *vk, *proofs, *pub;
+  size_t vk_len, proofs_len, pub_len;
+  uint32_t n = 0;
+  if (argc < 4 || !get_bytes(env, argv[0], &vk, &vk_len) || !get_bytes(env, argv[1], &proofs, &proofs_len) || !get_bytes(env, argv[2], &pub, &pub_len) ||
+      napi_get_value_uint32(env, argv[3], &n) != napi_ok)
+    return throw_msg(env, "verifyBatch(vkBin, proofs, publics, n)");
+  if (n == 0 || proofs_len != 256 * (size_t)n || pub_len % (32 * (size_t)n)) return throw_msg(env, "verifyBatch: n proofs of 256 bytes and n equal rows of 32-byte inputs expected");
+  int ok = 0;
+  if (Z.verify_batch(vk, vk_len, proofs, pub, n, pub_len / 32 / n, &ok)) return throw_msg(env, Z.last_error());
+  napi_value out;
+  NAPI_OK(napi_get_boolean(env, ok != 0, &out));
+  return out;
+}
+
 static napi_value init(napi_env env, napi_value exports) {
   napi_property_descriptor props[] = {
       {"load", NULL, js_load, NULL, NULL, NULL, napi_default, NULL},       {"version", NULL, js_version, NULL, NULL, NULL, napi_default, NULL},
@@ -458,6 +479,7 @@ static napi_value init(napi_env env, napi_value exports) {
       {"rollupCrypto", NULL, js_rollup_crypto, NULL, NULL, NULL, napi_default, NULL}, {"rollupCircuit", NULL, js_rollup_circuit, NULL, NULL, NULL, napi_default, NULL},
       {"withdrawCircuit", NULL, js_withdraw_circuit, NULL, NULL, NULL, napi_default, NULL},
       {"rollupGpuHash", NULL, js_rollup_gpu_hash, NULL, NULL, NULL, napi_default, NULL},
+      {"verifyBatch", NULL, js_verify_batch, NULL, NULL, NULL, napi_default, NULL},
   };
   napi_define_properties(env, exports, sizeof(props) / sizeof(props[0]), props);
   return exports;

@@ -45,6 +45,7 @@ def lib():
     L.zkr_prove_collect.argtypes = [vp, i, u8p]
     L.zkr_prove_batch.argtypes = [vp, c.POINTER(c.c_char_p), sz, sz, u8p, u8p, u8p]
     L.zkr_verify.argtypes = [u8p, sz, u8p, u8p, sz, c.POINTER(i)]
+    L.zkr_verify_batch.argtypes = [u8p, sz, u8p, u8p, sz, sz, c.POINTER(i)]
     L.zkr_ntt.argtypes = [u8p, c.c_uint, i, i]
     L.zkr_msm_g1.argtypes = [u8p, u8p, sz, u8p, c.POINTER(i), i]
     L.zkr_msm_g2.argtypes = [u8p, u8p, sz, u8p, c.POINTER(i), i]
@@ -274,6 +275,21 @@ def verify(vk_bin: bytes, proof: bytes, public_signals) -> bool:
     pub = b"".join(int(x).to_bytes(32, "little") for x in public_signals)
     ok = ctypes.c_int(0)
     _check(lib().zkr_verify(bytes(vk_bin), len(vk_bin), bytes(proof), pub, len(public_signals), ctypes.byref(ok)))
+    return bool(ok.value)
+
+
+def verify_batch(vk_bin: bytes, proofs, public_signals) -> bool:
+    """zkr_verify_batch: True iff every proof verifies under the key (one merged pairing product, host only).
+    proofs: list of 256-byte proofs; public_signals: one list of ints per proof."""
+    n = len(proofs)
+    if n == 0:
+        return True
+    n_pub = len(public_signals[0])
+    assert len(public_signals) == n and all(len(p) == n_pub for p in public_signals)
+    pb = b"".join(bytes(p) for p in proofs)
+    sb = b"".join(int(v).to_bytes(32, "little") for p in public_signals for v in p)
+    ok = ctypes.c_int()
+    _check(lib().zkr_verify_batch(bytes(vk_bin), len(vk_bin), pb, sb, n, n_pub, ctypes.byref(ok)))
     return bool(ok.value)
 
 

@@ -144,3 +144,34 @@ def test_native_verifier_accepts_the_reference_contracts_verifying_keys():
             bad[off] ^= 1
             with pytest.raises(zkr_hip.ZkrError):
                 zkr_hip.verify(bytes(bad), some_proof, [5] * n)
+
+
+def test_batch_verifier_merges_proofs_into_one_pairing_product(small_case):
+    """zkr_verify_batch (random linear combination, one final exponentiation) accepts a batch exactly when
+    zkr_verify accepts every member: valid proofs of different witnesses pass together, one tampered proof, one wrong
+    public signal or one input >= r fails the batch; more pairs than one lock-step Miller loop holds (8) are chunked."""
+    import groth16 as g
+    import zkr_hip
+    c = small_case
+    vkb = zkr_hip.binarify_verifying_key(c["vk"])
+    proofs, pubs = [], []
+    for i in range(7):                                        # 7 + 3 pairs: two Miller-loop chunks
+        w = c["w"] if i == 0 else g.synth_circuit(128, 7, 0x5A4B0001, witness_seed=300 + i)["witness"]
+        proofs.append(g.proof_bytes(g.proof_from_toxic(c["circ"], c["tox"], w, 11 + i, 23 + i)))
+        pubs.append([x % g.R for x in w[1:8]])
+    assert all(zkr_hip.verify(vkb, p, s) for p, s in zip(proofs, pubs))
+    assert zkr_hip.verify_batch(vkb, proofs, pubs) is True
+    assert zkr_hip.verify_batch(vkb, proofs[:1], pubs[:1]) is True and zkr_hip.verify_batch(vkb, [], []) is True
+    swapped = [proofs[1], proofs[0]] + proofs[2:]             # every proof valid, but for another statement
+    assert zkr_hip.verify_batch(vkb, swapped, pubs) is False
+    bad_pub = [list(p) for p in pubs]
+    bad_pub[4][2] = (bad_pub[4][2] + 1) % g.R
+    assert zkr_hip.verify_batch(vkb, proofs, bad_pub) is False
+    big = [list(p) for p in pubs]
+    big[3][0] += g.R
+    assert zkr_hip.verify_batch(vkb, proofs, big) is False
+    off = list(proofs)
+    off[5] = off[5][:32] + (1).to_bytes(32, "little") + off[5][64:]
+    assert zkr_hip.verify_batch(vkb, off, pubs) is False
+    with pytest.raises(zkr_hip.ZkrError):
+        zkr_hip.verify_batch(vkb[:-1], proofs, pubs)

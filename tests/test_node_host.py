@@ -136,9 +136,11 @@ def test_js_is_valid_on_native_verifier(tmp_path, small_case):
     out = _node("""
       const z = require('./index.js'); const fs = require('fs');
       const d = JSON.parse(fs.readFileSync(process.argv[1]));
-      console.log(JSON.stringify([z.isValid(d.vk, d.proof, d.pub), z.isValid(d.vk, d.proof, d.bad)]));
+      console.log(JSON.stringify([z.isValid(d.vk, d.proof, d.pub), z.isValid(d.vk, d.proof, d.bad),
+                                  z.isValidBatch(d.vk, [d.proof, d.proof, d.proof], [d.pub, d.pub, d.pub]),
+                                  z.isValidBatch(d.vk, [d.proof, d.proof], [d.pub, d.bad]), z.isValidBatch(d.vk, [], [])]));
     """, str(path)).stdout
-    assert json.loads(out) == [True, False]
+    assert json.loads(out) == [True, False, True, False, True]
 
 
 @pytest.mark.gpu
