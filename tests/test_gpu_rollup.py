@@ -116,3 +116,29 @@ def test_gpu_batch_hash_and_tree_match_the_oracle():
     big = n.BalanceTree.from_leaves(16, [rnd.randrange(o.R) for _ in range(1 << 16)])
     assert big.root == o.hash_left_right(big.levels[15][0], big.levels[15][1])
     assert big.levels[1][:4] == n.multi_hash_batch([big.levels[0][2 * i:2 * i + 2] for i in range(4)])
+
+
+def test_real_circuit_at_the_headline_size():
+    """BatchProcessTx(18, 6): the reference's template filled to 1 008 108 constraints (2^20 domain, 649 public signals) --
+    set up on the GPU, witness built natively for 18 chained transactions, proved, and accepted by the native verifier
+    (single and batch form); the new root is the operator's."""
+    import zkr_hip
+    from zkr_hip import rollup as n
+    c = n.RollupCircuit(18, 6)
+    assert c.n_constraints + c.n_public + 1 <= 1 << 20 < 2 * (c.n_constraints + c.n_public + 1)
+    key, vk_bin = zkr_hip.ProvingKey.setup_r1cs(c.r1cs())
+    assert key.info()["domainSize"] == 1 << 20
+    privs = [0x5A4B2000 + 31 * i for i in range(6)]
+    st = n.RollupState(6)
+    for i, pv in enumerate(privs):
+        st.deposit(i, n.gen_public_key(pv), 10 ** 20, 0)
+    txs = [st.transfer(j % 6, (j + 1 + j // 6) % 6, 10 ** 17 + j, 10 ** 15, privs[j % 6]) for j in range(18)]
+    wb = c.calculate_witness(st.batch_inputs(txs))
+    pub = c.public_signals(wb)
+    assert pub[0] == st.tree.root and len(pub) == 649
+    proofs = key.prove_batch([wb, wb], rs=[3, 4], ss=[5, 6])
+    assert proofs[0] != proofs[1]
+    assert zkr_hip.verify(vk_bin, proofs[0], pub) and zkr_hip.verify_batch(vk_bin, proofs, [pub, pub])
+    bad = list(pub)
+    bad[640] = (bad[640] + 1) % o.R
+    assert not zkr_hip.verify(vk_bin, proofs[0], bad) and not zkr_hip.verify_batch(vk_bin, proofs, [pub, bad])
