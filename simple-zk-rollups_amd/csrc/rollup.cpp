@@ -23,6 +23,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <utility>
@@ -787,25 +788,44 @@ static void batch_gadget(Builder &B, uint32_t batch, uint32_t depth) {
   B.enforce(prev, Builder::one(), B.sig(1), "newBalanceTreeRoot");
 }
 
+// private signals of one ProcessTx(depth) (the structure does not depend on the inputs); cached per depth
+static uint32_t tx_private_count(uint32_t depth) {
+  static std::mutex mu;
+  static uint32_t cache[33] = {0};
+  std::lock_guard<std::mutex> lk(mu);
+  if (!cache[depth]) {
+    Builder B(false, false);
+    const uint32_t p = n_public_of(1, depth);
+    for (uint32_t i = 1; i <= p; i++) B.alloc(Fr::zero());
+    process_tx_gadget(B, tx_inputs(B, Layout(1, depth), 0, depth), depth);
+    cache[depth] = (uint32_t)B.w.size() - p - 1;
+  }
+  return cache[depth];
+}
+
 // Witness pass: the transactions of a batch only meet in the root chain, so each one is built on its own thread
-// (same gadget code, same signal order; private signals are concatenated in transaction order afterwards).
-// Returns the witness as binarifyWitness lays it out (32 B standard form per signal).
-static bool batch_witness(uint32_t batch, uint32_t depth, const Fr *inputs, std::vector<uint8_t> &out, std::string &err) {
-  const uint32_t p = n_public_of(batch, depth);
+// (same gadget code, same signal order) and writes its private signals straight into its slice of the result, laid out
+// as binarifyWitness does (32 B standard form per signal; malloc'ed, the caller frees).
+static bool batch_witness(uint32_t batch, uint32_t depth, const Fr *inputs, uint8_t **out_buf, size_t *out_len, std::string &err) {
+  const uint32_t p = n_public_of(batch, depth), K = tx_private_count(depth);
   const Layout L(batch, depth);
   std::vector<Fr> pub(p + 1, Fr::zero());
   pub[0] = Fr::one();
   for (uint32_t i = 2; i <= p; i++) pub[i] = inputs[i - 2];
-  std::vector<std::vector<uint8_t>> priv(batch);
+  const size_t total = 32 * ((size_t)p + 1 + (size_t)batch * K);
+  uint8_t *out = (uint8_t *)malloc(total);
+  if (!out) { err = "out of memory"; return false; }
   std::vector<Fr> roots(batch);
   std::vector<std::string> errs(batch);
   auto one_tx = [&](uint32_t i) {
     Builder B(false, true);
+    B.w.reserve(p + 1 + K);
     B.w = pub;
     roots[i] = process_tx_gadget(B, tx_inputs(B, L, i, depth), depth).v;
     errs[i] = B.err;
-    priv[i].resize(32 * (B.w.size() - p - 1));
-    for (size_t k = p + 1; k < B.w.size(); k++) fr_write_std(&priv[i][32 * (k - p - 1)], B.w[k]);
+    if (B.w.size() != (size_t)p + 1 + K) { errs[i] = "internal: private signal count differs from the structure pass"; return; }
+    uint8_t *dst = out + 32 * ((size_t)p + 1 + (size_t)i * K);
+    for (size_t k = 0; k < K; k++) fr_write_std(dst + 32 * k, B.w[p + 1 + k]);
   };
   unsigned hw = std::thread::hardware_concurrency();
   const uint32_t nthreads = std::min<uint32_t>(batch, hw ? hw : 1);
@@ -821,25 +841,14 @@ static bool batch_witness(uint32_t batch, uint32_t depth, const Fr *inputs, std:
     for (auto &t : th) t.join();
   }
   for (uint32_t i = 0; i < batch; i++) {  // first violated statement in circuit order
-    if (i > 0 && !(roots[i - 1] == pub[L.o_root + i])) {
-      err = "transaction " + std::to_string(i) + " violates: a transaction starts from the root the previous one produced";
-      return false;
-    }
-    if (!errs[i].empty()) {
-      err = "transaction " + std::to_string(i) + " violates: " + errs[i];
-      return false;
-    }
+    if (i > 0 && !(roots[i - 1] == pub[L.o_root + i])) err = "transaction " + std::to_string(i) + " violates: a transaction starts from the root the previous one produced";
+    else if (!errs[i].empty()) err = "transaction " + std::to_string(i) + " violates: " + errs[i];
+    if (!err.empty()) { free(out); return false; }
   }
   pub[1] = roots[batch - 1];  // newBalanceTreeRoot (:72)
-  size_t total = 32 * (size_t)(p + 1);
-  for (uint32_t i = 0; i < batch; i++) total += priv[i].size();
-  out.resize(total);
-  for (uint32_t k = 0; k <= p; k++) fr_write_std(&out[32 * k], pub[k]);
-  size_t at = 32 * (size_t)(p + 1);
-  for (uint32_t i = 0; i < batch; i++) {
-    memcpy(&out[at], priv[i].data(), priv[i].size());
-    at += priv[i].size();
-  }
+  for (uint32_t k = 0; k <= p; k++) fr_write_std(out + 32 * k, pub[k]);
+  *out_buf = out;
+  *out_len = total;
   return true;
 }
 
@@ -1006,12 +1015,12 @@ int zkr_rollup_witness(uint32_t batch, uint32_t depth, const uint8_t *inputs, si
   std::vector<Fr> in(n_inputs);
   for (size_t i = 0; i < n_inputs; i++)
     if (!fr_read_std(inputs + 32 * i, in[i])) { set_error("input %zu >= r", i); return ZKR_ERR_ARG; }
-  std::vector<uint8_t> out;
   std::string err;
-  if (!batch_witness(batch, depth, in.data(), out, err)) { set_error("%s", err.c_str()); return ZKR_ERR_UNSATISFIED; }
-  *witness_bin = dup_bytes(out.data(), out.size());
-  *witness_len = out.size();
-  if (!*witness_bin) { set_error("out of memory"); return ZKR_ERR_ARG; }
+  uint8_t *out = nullptr;
+  size_t out_len = 0;
+  if (!batch_witness(batch, depth, in.data(), &out, &out_len, err)) { set_error("%s", err.c_str()); return err == "out of memory" ? ZKR_ERR_ARG : ZKR_ERR_UNSATISFIED; }
+  *witness_bin = out;
+  *witness_len = out_len;
   return ZKR_OK;
 }
 
