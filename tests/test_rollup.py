@@ -331,3 +331,26 @@ def test_ragged_or_out_of_field_circuit_inputs_are_refused():
         c.calculate_witness(flat[:5] + [n.SNARK_FIELD_SIZE] + flat[6:])       # the C ABI takes canonical field elements only
     assert e.value.code == -5 and ">= r" in str(e.value)
     assert c.calculate_witness(dict(inp, txData=[[v + n.SNARK_FIELD_SIZE for v in t] for t in inp["txData"]])) == c.calculate_witness(inp)  # dict inputs are reduced like circom's
+
+
+def test_product_alone_reproduces_the_committed_rollup_fixture():
+    """tests/golden/rollup_tx.json (written by the pinned oracle, make_rollup_golden.py): the native library alone --
+    no oracle import on this path -- derives the same keys, signs the same transactions, builds the same tree and the
+    same public signals."""
+    from zkr_hip import rollup as n
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "rollup_tx.json")))
+    privs = [int(v) for v in fx["privs"]]
+    assert [[str(c) for c in n.gen_public_key(p)] for p in privs] == fx["pubs"]
+    assert [str(n.format_priv_key(p)) for p in privs] == fx["formatted"]
+    assert str(n.multi_hash([32767])) == fx["hash_1"] and str(n.hash_left_right(12345, 45678)) == fx["hash_lr"]
+    st = n.RollupState(fx["depth"])
+    for i, p in enumerate(privs):
+        st.deposit(i, n.gen_public_key(p), 7 * 10 ** 18 + i, i)
+    assert str(st.tree.root) == fx["root_before"]
+    txs = [st.transfer(0, 1, 3 * 10 ** 17, 10 ** 15, privs[0]), st.transfer(2, 2, 5 * 10 ** 17, 2 * 10 ** 15, privs[2])]
+    strs = lambda x: [strs(v) for v in x] if isinstance(x, (list, tuple)) else str(x)
+    assert {f: strs(v) for f, v in st.batch_inputs(txs).items()} == fx["inputs"]
+    assert str(st.tree.root) == fx["root_after"]
+    c = n.RollupCircuit(fx["batch"], fx["depth"])
+    wb = c.calculate_witness(fx["inputs"])                      # decimal strings, as the reference passes them
+    assert [str(v) for v in c.public_signals(wb)] == fx["public_signals"]
