@@ -8,6 +8,7 @@
 #include <string.h>
 #include "kernels_msm.hpp"
 #include "kernels_ntt.hpp"
+#include "hostops.hpp"
 #include "zkr_internal.hpp"
 
 namespace zkr {
@@ -162,6 +163,11 @@ int key_alloc_workspace(zkr_key *k) {
     if (!rc) rc = digit_lists_alloc(sl.dig_h, h.m, k->plan[T_H]);
     if (rc) return rc;
   }
+  // host-side window tables of delta_1 / delta_2 for the proof assembly (a few milliseconds; kept out of the first proof)
+  std::call_once(k->delta_once, [&] {
+    k->delta1_tab = fixed_base_table(load_g1(h.delta1));
+    k->delta2_tab = fixed_base_table(load_g2(h.delta2));
+  });
   return 0;
 }
 
