@@ -110,6 +110,19 @@ static inline bool g2_on_curve(const G2Affine &p) {
   return sqr(p.y) == add(mul(sqr(p.x), p.x), b);
 }
 
+// Q is in the order-r subgroup G2 of the twist: [r]Q == infinity.  The twist's group order is r (2q - r) and the
+// cofactor 2q - r has small prime factors (10069, ...), so an on-curve point need not be in G2; the bn256 pairing
+// precompile the contracts call (TxVerifier.sol:91-115) rejects such points, and so must this verifier.
+static inline bool g2_in_subgroup(const G2Affine &p) {
+  if (p.is_inf()) return true;
+  G2XYZZ base = to_xyzz(p), acc = G2XYZZ::inf();
+  for (int i = 253; i >= 0; i--) {  // r < 2^254
+    acc = dbl_xyzz(acc);
+    if ((FrParams::P[i >> 5] >> (i & 31)) & 1) acc = add_full(acc, base);
+  }
+  return acc.is_inf();
+}
+
 static inline G2Affine g2_frobenius(const G2Affine &p) {
   Fq2 gx{fq_from_limbs(FROB_X0), fq_from_limbs(FROB_X1)}, gy{fq_from_limbs(FROB_Y0), fq_from_limbs(FROB_Y1)};
   return G2Affine{mul(conj(p.x), gx), mul(conj(p.y), gy)};
@@ -123,15 +136,23 @@ static inline Fq12 line(const G2Affine &t, const Fq2 &lam, const G1Affine &p) {
 // One step of n Miller loops in lockstep: the n slope denominators share ONE field inversion (Montgomery's trick),
 // which is where an affine Miller loop spends most of its time.
 constexpr int MAX_PAIRS = 8;
-static inline void batch_inv(Fq2 *d, int n) {
+// false when a denominator is zero (the shared product would be zero and every inverse of the step with it)
+static inline bool batch_inv(Fq2 *d, int n) {
   Fq2 pre[MAX_PAIRS];
   Fq2 run = Fq2::one();
-  for (int i = 0; i < n; i++) { pre[i] = run; run = mul(run, d[i]); }
+  for (int i = 0; i < n; i++) {
+    if (d[i].is_zero()) return false;
+    pre[i] = run;
+    run = mul(run, d[i]);
+  }
   Fq2 iv = inv(run);
   for (int i = n - 1; i >= 0; i--) { Fq2 di = mul(iv, pre[i]); iv = mul(iv, d[i]); d[i] = di; }
+  return true;
 }
-// doubling (s == nullptr) or addition of s[i]: t[i] <- step, f <- f * line_i for every live pair
-static inline void multi_step(G2Affine *t, const G2Affine *s, const G1Affine *p, const bool *live, int n, Fq12 &f) {
+// doubling (s == nullptr) or addition of s[i]: t[i] <- step, f <- f * line_i for every live pair.  Returns false when
+// a slope is undefined (T == +-S or 2T == infinity): that cannot happen for points of the order-r subgroup, which the
+// callers check (g2_in_subgroup), so it is reported as "not a valid pairing input" instead of inverting zero.
+static inline bool multi_step(G2Affine *t, const G2Affine *s, const G1Affine *p, const bool *live, int n, Fq12 &f) {
   Fq2 num[MAX_PAIRS], den[MAX_PAIRS];
   int idx[MAX_PAIRS], m = 0;
   for (int i = 0; i < n; i++) {
@@ -140,7 +161,7 @@ static inline void multi_step(G2Affine *t, const G2Affine *s, const G1Affine *p,
     else { Fq2 xx = sqr(t[i].x); num[m] = add(dbl(xx), xx); den[m] = dbl(t[i].y); }
     idx[m++] = i;
   }
-  batch_inv(den, m);
+  if (!batch_inv(den, m)) return false;
   for (int k = 0; k < m; k++) {
     const int i = idx[k];
     Fq2 lam = mul(num[k], den[k]);
@@ -149,10 +170,13 @@ static inline void multi_step(G2Affine *t, const G2Affine *s, const G1Affine *p,
     Fq2 y3 = sub(mul(lam, sub(t[i].x, x3)), t[i].y);
     t[i] = G2Affine{x3, y3};
   }
+  return true;
 }
 
-// prod_i f_{6x+2,Q_i}(P_i) with the two Frobenius correction lines; pairs with a point at infinity contribute 1
-static inline Fq12 multi_miller_loop(const G1Affine *ps, const G2Affine *qs, int n) {
+// prod_i f_{6x+2,Q_i}(P_i) with the two Frobenius correction lines; pairs with a point at infinity contribute 1.
+// *ok (optional) is cleared when a step met an undefined slope (a Q outside the order-r subgroup): the value is
+// then meaningless and the caller must treat the input as not valid.
+static inline Fq12 multi_miller_loop(const G1Affine *ps, const G2Affine *qs, int n, bool *ok = nullptr) {
   G2Affine t[MAX_PAIRS], q1[MAX_PAIRS], q2[MAX_PAIRS];
   bool live[MAX_PAIRS];
   for (int i = 0; i < n; i++) {
@@ -163,14 +187,16 @@ static inline Fq12 multi_miller_loop(const G1Affine *ps, const G2Affine *qs, int
     q2[i].y = neg(q2[i].y);
   }
   Fq12 f = Fq12::one();
-  for (int b = 63; b >= 0; b--) {  // bits below the leading one of the 65-bit loop count
+  bool good = true;
+  for (int b = 63; b >= 0 && good; b--) {  // bits below the leading one of the 65-bit loop count
     f = sqr(f);
-    multi_step(t, nullptr, ps, live, n, f);
-    if ((ATE_LOOP[b >> 5] >> (b & 31)) & 1) multi_step(t, qs, ps, live, n, f);
+    good = multi_step(t, nullptr, ps, live, n, f);
+    if (good && ((ATE_LOOP[b >> 5] >> (b & 31)) & 1)) good = multi_step(t, qs, ps, live, n, f);
   }
-  multi_step(t, q1, ps, live, n, f);
-  multi_step(t, q2, ps, live, n, f);
-  return f;
+  good = good && multi_step(t, q1, ps, live, n, f);
+  good = good && multi_step(t, q2, ps, live, n, f);
+  if (ok) *ok = good;
+  return good ? f : Fq12::one();
 }
 
 // f^((q^12 - 1) / r) by plain square-and-multiply over the 1270 exponent bits: the reference form the fast one below is
@@ -254,7 +280,9 @@ static inline Fq12 final_exponentiation(const Fq12 &f0) {
 // prod_i e(P_i, Q_i) == 1  -- the bn256 pairing precompile's check (TxVerifier.sol:91-115)
 static inline bool pairing_product_is_one(const G1Affine *ps, const G2Affine *qs, int n) {
   if (n > MAX_PAIRS) return false;
-  return final_exponentiation(multi_miller_loop(ps, qs, n)) == Fq12::one();
+  bool ok = true;
+  Fq12 f = multi_miller_loop(ps, qs, n, &ok);
+  return ok && final_exponentiation(f) == Fq12::one();
 }
 
 }  // namespace pairing

@@ -159,7 +159,8 @@ struct SetupScalars {
 
 Fr host_root_of_unity(unsigned k);
 
-static void setup_scalars(const Circuit &c, const Toxic &tx, SetupScalars &sc) {
+template <class T> static void wipe_vector(std::vector<T> &v);
+static void setup_scalars(const Circuit &c, const Toxic &tx, SetupScalars &sc, bool secret) {
   uint32_t m = c.m, n = c.n, p = c.p;
   unsigned logm = 0;
   while ((1u << logm) < m) logm++;
@@ -198,6 +199,7 @@ static void setup_scalars(const Circuit &c, const Toxic &tx, SetupScalars &sc) {
   sc.hx.resize(m);
   Fr ti = mul(z, dinv);
   for (uint32_t i = 0; i < m; i++) { sc.hx[i] = ti; ti = mul(ti, tx.t); }
+  if (secret) { wipe_vector(den); wipe_vector(pref); wipe_vector(L); }  // t - w^c, their products, L_c(t): each reveals t
 }
 
 static void to_std_bytes(const std::vector<Fr> &v, std::vector<uint8_t> &out) {
@@ -205,36 +207,57 @@ static void to_std_bytes(const std::vector<Fr> &v, std::vector<uint8_t> &out) {
   for (size_t i = 0; i < v.size(); i++) { Fr s = from_mont(v[i]); memcpy(&out[i * 32], s.v, 32); }
 }
 
+template <class T>
+static void wipe_vector(std::vector<T> &v) {
+  if (!v.empty()) explicit_bzero((void *)v.data(), v.size() * sizeof(T));
+}
+
 struct Generated {
   Circuit circ;
   Toxic tox;
   SetupScalars sc;
+  bool secret = false;  // fresh toxic waste (zkr_setup_r1cs without injected scalars): everything derived from it is wiped
   void *d_tbl[N_TABLES] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   uint8_t consts[448];
   std::vector<uint8_t> ic_std, gamma2_std;
-  ~Generated() { for (auto p : d_tbl) if (p) hipFree(p); }
+  ~Generated() {
+    for (auto p : d_tbl) if (p) hipFree(p);
+    if (secret) {  // t, alfa, beta, gamma, delta and the per-signal / per-power scalars (a_s, b_s, c_s, K_s/delta, K_s/gamma, t^i Z/delta):
+                   // any of them lets its holder forge proofs for the generated key
+      explicit_bzero((void *)&tox, sizeof(tox));
+      wipe_vector(sc.a); wipe_vector(sc.b); wipe_vector(sc.c); wipe_vector(sc.cpriv); wipe_vector(sc.ic); wipe_vector(sc.hx);
+    }
+  }
 };
 
 // g.circ and g.tox are in place: QAP polynomials at t, then every group element of the key on the GPU
 static int setup_from_circuit(int device, Generated &g) {
   if (zkr_device_count() <= device || device < 0) { set_error("no HIP device %d; key points are computed on the GPU (no CPU fallback)", device); return ZKR_ERR_NO_DEVICE; }
-  setup_scalars(g.circ, g.tox, g.sc);
-  std::vector<uint8_t> bytes;
+  setup_scalars(g.circ, g.tox, g.sc, g.secret);
+  struct Staging {  // standard-form copies of the scalars on their way to the device: wiped with the rest
+    std::vector<uint8_t> v;
+    bool secret;
+    ~Staging() { if (secret) wipe_vector(v); }
+  } stage{{}, g.secret};
+  std::vector<uint8_t> &bytes = stage.v;
   int rc;
   const std::vector<Fr> *src[N_TABLES] = {&g.sc.a, &g.sc.b, &g.sc.b, &g.sc.cpriv, &g.sc.hx};
   for (int t = 0; t < N_TABLES; t++) {
+    if (g.secret) wipe_vector(bytes);
     to_std_bytes(*src[t], bytes);
-    if ((rc = fixed_base_points(device, t == T_B2, bytes.data(), src[t]->size(), &g.d_tbl[t]))) return rc;
+    if ((rc = fixed_base_points(device, t == T_B2, bytes.data(), src[t]->size(), &g.d_tbl[t], g.secret))) return rc;
   }
   // vk_alfa_1, vk_beta_1, vk_delta_1 | vk_beta_2, vk_delta_2  (header layout binarify.ts:163-167)
   std::vector<Fr> g1s = {g.tox.alfa, g.tox.beta, g.tox.delta}, g2s = {g.tox.beta, g.tox.delta, g.tox.gamma};
   void *d = nullptr;
+  if (g.secret) wipe_vector(bytes);
   to_std_bytes(g1s, bytes);
-  if ((rc = fixed_base_points(device, false, bytes.data(), 3, &d))) return rc;
+  if ((rc = fixed_base_points(device, false, bytes.data(), 3, &d, g.secret))) return rc;
   ZKR_HIP_CHECK(hipMemcpy(g.consts, d, 192, hipMemcpyDeviceToHost));
   hipFree(d);
   to_std_bytes(g2s, bytes);
-  if ((rc = fixed_base_points(device, true, bytes.data(), 3, &d))) return rc;
+  if ((rc = fixed_base_points(device, true, bytes.data(), 3, &d, g.secret))) return rc;
+  if (g.secret) { wipe_vector(g1s); wipe_vector(g2s); }
   uint8_t g2pts[384];
   ZKR_HIP_CHECK(hipMemcpy(g2pts, d, 384, hipMemcpyDeviceToHost));
   hipFree(d);
@@ -243,8 +266,9 @@ static int setup_from_circuit(int device, Generated &g) {
   g.gamma2_std.resize(128);
   store_g2_std(g.gamma2_std.data(), gm);
   // IC points for the checker
+  if (g.secret) wipe_vector(bytes);
   to_std_bytes(g.sc.ic, bytes);
-  if ((rc = fixed_base_points(device, false, bytes.data(), g.sc.ic.size(), &d))) return rc;
+  if ((rc = fixed_base_points(device, false, bytes.data(), g.sc.ic.size(), &d, g.secret))) return rc;
   std::vector<uint8_t> icm(g.sc.ic.size() * 64);
   ZKR_HIP_CHECK(hipMemcpy(icm.data(), d, icm.size(), hipMemcpyDeviceToHost));
   hipFree(d);
@@ -394,7 +418,9 @@ int zkr_setup_r1cs(const void *r1cs_bin, size_t r1cs_len, const uint8_t *toxic16
       if (!read_fr_std(toxic160 + 32 * i, v) || v.is_zero()) { set_error("toxic scalar %d is zero or >= r", i); return ZKR_ERR_ARG; }
       *tox[i] = to_mont(v);
     }
-  } else {  // fresh toxic waste from the OS CSPRNG; it never leaves this call
+  } else {  // fresh toxic waste from the OS CSPRNG; it never leaves this call (Generated::~Generated wipes it and
+            // everything derived from it, host and device copies)
+    g.secret = true;
     FILE *f = fopen("/dev/urandom", "rb");
     if (!f) { set_error("cannot open /dev/urandom"); return ZKR_ERR_ARG; }
     int bad = 0;
@@ -404,7 +430,6 @@ int zkr_setup_r1cs(const void *r1cs_bin, size_t r1cs_len, const uint8_t *toxic16
   }
   int rc = setup_from_circuit(device, g);
   if (!rc) rc = build_key_from_generated(g, device, key_out);
-  memset((void *)&g.tox, 0, sizeof(g.tox));
   if (rc) return rc;
   std::vector<uint8_t> vk;
   vk_from_generated(g, vk);

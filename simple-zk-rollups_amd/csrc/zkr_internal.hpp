@@ -140,7 +140,7 @@ int key_build(int device, uint32_t n, uint32_t p, uint32_t m, const std::vector<
               const std::vector<uint32_t> tbl_srcidx[N_TABLES], const std::vector<uint32_t> tbl_sidx[N_TABLES], const uint8_t *consts448,
               zkr_key **out);
 int key_alloc_workspace(zkr_key *k);
-int fixed_base_points(int device, bool g2, const uint8_t *scalars_std, size_t n, void **d_out);  // device array of affine Montgomery points
+int fixed_base_points(int device, bool g2, const uint8_t *scalars_std, size_t n, void **d_out, bool wipe_scalars = false);  // device array of affine Montgomery points
 // zkr_prove.hip
 struct Prof {  // where a launch helper records its timing spans (null key: stage hooks, no timing)
   zkr_key *k;

@@ -316,9 +316,10 @@ int key_build(int device, uint32_t n, uint32_t p, uint32_t m, const std::vector<
   return 0;
 }
 
-// scalars (host, std form) * generator -> device array of affine Montgomery points (caller hipFree's)
+// scalars (host, std form) * generator -> device array of affine Montgomery points (caller hipFree's).  wipe: the
+// scalars are secret (setup with fresh toxic waste): their device copy is zeroed before it is freed, on every path.
 template <class F>
-static int fixed_base_impl(int device, const Affine<F> &gen, const uint8_t *scalars_std, size_t n, void **d_out) {
+static int fixed_base_impl(int device, const Affine<F> &gen, const uint8_t *scalars_std, size_t n, void **d_out, bool wipe) {
   ZKR_HIP_CHECK(hipSetDevice(device));
   // T[j][d] = d * 2^(8j) * G on the host (8160 group operations, once per generator)
   std::vector<Affine<F>> table(32 * 256);
@@ -332,27 +333,40 @@ static int fixed_base_impl(int device, const Affine<F> &gen, const uint8_t *scal
     table[j * 256] = Affine<F>{F::zero(), F::one()};
     for (int b = 0; b < 8; b++) base = dbl_xyzz(base);
   }
-  Affine<F> *d_table = nullptr, *d_pts = nullptr;
-  Fr *d_sc = nullptr;
-  ZKR_HIP_CHECK(hipMalloc(&d_table, table.size() * sizeof(Affine<F>)));
-  ZKR_HIP_CHECK(hipMalloc(&d_pts, (n + 1) * sizeof(Affine<F>)));
-  ZKR_HIP_CHECK(hipMalloc(&d_sc, (n + 1) * 32));
-  ZKR_HIP_CHECK(hipMemcpy(d_table, table.data(), table.size() * sizeof(Affine<F>), hipMemcpyHostToDevice));
-  ZKR_HIP_CHECK(hipMemcpy(d_sc, scalars_std, n * 32, hipMemcpyHostToDevice));
+  struct DevBufs {  // freed (and the scalars cleared) however the function is left
+    Affine<F> *table = nullptr, *pts = nullptr;
+    Fr *sc = nullptr;
+    size_t sc_bytes = 0;
+    bool wipe = false;
+    ~DevBufs() {
+      if (sc) {
+        if (wipe) { hipMemset(sc, 0, sc_bytes); hipDeviceSynchronize(); }
+        hipFree(sc);
+      }
+      if (table) hipFree(table);
+      if (pts) hipFree(pts);
+    }
+  } d;
+  d.wipe = wipe;
+  d.sc_bytes = (n + 1) * 32;
+  ZKR_HIP_CHECK(hipMalloc(&d.table, table.size() * sizeof(Affine<F>)));
+  ZKR_HIP_CHECK(hipMalloc(&d.pts, (n + 1) * sizeof(Affine<F>)));
+  ZKR_HIP_CHECK(hipMalloc(&d.sc, d.sc_bytes));
+  ZKR_HIP_CHECK(hipMemcpy(d.table, table.data(), table.size() * sizeof(Affine<F>), hipMemcpyHostToDevice));
+  ZKR_HIP_CHECK(hipMemcpy(d.sc, scalars_std, n * 32, hipMemcpyHostToDevice));
   constexpr int MINW = sizeof(F) == 32 ? 2 : 1;
-  fixed_base_kernel<F, MINW><<<(unsigned)((n + 255) / 256), 256>>>(d_table, d_sc, n, d_pts);
+  fixed_base_kernel<F, MINW><<<(unsigned)((n + 255) / 256), 256>>>(d.table, d.sc, n, d.pts);
   ZKR_HIP_CHECK(hipGetLastError());
   ZKR_HIP_CHECK(hipDeviceSynchronize());
-  hipFree(d_table);
-  hipFree(d_sc);
-  *d_out = d_pts;
+  *d_out = d.pts;
+  d.pts = nullptr;  // handed to the caller
   return 0;
 }
 
-int fixed_base_points(int device, bool g2, const uint8_t *scalars_std, size_t n, void **d_out) {
+int fixed_base_points(int device, bool g2, const uint8_t *scalars_std, size_t n, void **d_out, bool wipe_scalars) {
   if (!g2) {
     G1Affine g{Fq::one(), add(Fq::one(), Fq::one())};  // (1, 2), TxVerifier.sol:24-26
-    return fixed_base_impl<Fq>(device, g, scalars_std, n, d_out);
+    return fixed_base_impl<Fq>(device, g, scalars_std, n, d_out, wipe_scalars);
   }
   // G2 generator, snarkjs order [re, im] (TxVerifier.sol:30-35 lists [im, re])
   static const uint32_t GX0[8] = {0xd992f6edu, 0x46debd5cu, 0xf75edaddu, 0x674322d4u, 0x5e5c4479u, 0x426a0066u, 0x121f1e76u, 0x1800deefu};
@@ -362,7 +376,7 @@ int fixed_base_points(int device, bool g2, const uint8_t *scalars_std, size_t n,
   G2Affine g;
   memcpy(g.x.a.v, GX0, 32); memcpy(g.x.b.v, GX1, 32); memcpy(g.y.a.v, GY0, 32); memcpy(g.y.b.v, GY1, 32);
   g.x.a = to_mont(g.x.a); g.x.b = to_mont(g.x.b); g.y.a = to_mont(g.y.a); g.y.b = to_mont(g.y.b);
-  return fixed_base_impl<Fq2>(device, g, scalars_std, n, d_out);
+  return fixed_base_impl<Fq2>(device, g, scalars_std, n, d_out, wipe_scalars);
 }
 
 }  // namespace zkr
@@ -391,8 +405,13 @@ int zkr_key_load_websnark(const void *pk_bin, size_t pk_len, int device, zkr_key
   uint32_t n = rd32(pk), p = rd32(pk + 4), m = rd32(pk + 8);
   uint32_t ptr[7];
   for (int i = 0; i < 7; i++) ptr[i] = rd32(pk + 12 + 4 * i);
-  if (n == 0 || p + 1 > n || m < 2 || (m & (m - 1))) { set_error("bad key geometry nVars=%u nPublic=%u domainSize=%u", n, p, m); return ZKR_ERR_BAD_KEY; }
+  if (n == 0 || (uint64_t)p + 1 > n || m < 2 || (m & (m - 1))) { set_error("bad key geometry nVars=%u nPublic=%u domainSize=%u", n, p, m); return ZKR_ERR_BAD_KEY; }
   if (ptr[0] != 488) { set_error("polsA pointer %u != 488", ptr[0]); return ZKR_ERR_BAD_KEY; }
+  // the two pols sections are scanned before anything else: their bounds must lie inside the caller's buffer
+  if ((uint64_t)ptr[1] < 488 || (uint64_t)ptr[1] > (uint64_t)ptr[2] || (uint64_t)ptr[2] > (uint64_t)pk_len) {
+    set_error("pols pointers out of order or past the buffer (polsB %u, pointsA %u, length %zu)", ptr[1], ptr[2], pk_len);
+    return ZKR_ERR_BAD_KEY;
+  }
   // point sections have fixed sizes (binarify.ts:129-138)
   uint64_t expect_end = (uint64_t)ptr[2] + 64ull * n + 64ull * n + 128ull * n + 64ull * (n - p - 1) + 64ull * m;
   if (ptr[3] != ptr[2] + 64ull * n || ptr[4] != ptr[3] + 64ull * n || ptr[5] != ptr[4] + 128ull * n || ptr[6] != ptr[5] + 64ull * (n - p - 1) ||

@@ -26,10 +26,10 @@ static int stage_index(const char *name) {
     if (!strcmp(STAGES[i], name)) return i;
   return -1;
 }
-static hipEvent_t next_event(ProofSlot &sl) {
+static hipEvent_t next_event(ProofSlot &sl) {  // nullptr when the runtime cannot create another event
   if (sl.event_next == sl.event_pool.size()) {
-    hipEvent_t e;
-    hipEventCreate(&e);
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
     sl.event_pool.push_back(e);
   }
   return sl.event_pool[sl.event_next++];
@@ -39,7 +39,8 @@ int prof_begin(Prof pf, hipStream_t s, const char *stage) {
   ProfSpan sp;
   sp.stage = stage_index(stage);
   sp.e0 = next_event(*pf.sl);
-  sp.e1 = next_event(*pf.sl);
+  sp.e1 = sp.e0 ? next_event(*pf.sl) : nullptr;
+  if (!sp.e0 || !sp.e1) return -1;  // no timing for this span; the launch itself is unaffected
   hipEventRecord(sp.e0, s);
   pf.sl->spans.push_back(sp);
   return (int)pf.sl->spans.size() - 1;
@@ -317,8 +318,24 @@ static int draw_blinding(uint8_t out[32]) {
   return 0;
 }
 
-// Enqueue the whole GPU side of one proof on the slot's buffers; returns without waiting.
+static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *d_wsrc, const uint8_t *r32, const uint8_t *s32, hipStream_t caller);
+
+// Enqueue the whole GPU side of one proof on the slot's buffers; returns without waiting.  If the enqueue fails part
+// way, kernels already launched still use the slot's buffers while the slot stays marked free: the key's streams are
+// drained before the error is returned, so the next submit (possibly from another host thread) cannot race with them.
 static int prove_submit(zkr_key *k, ProofSlot &sl, const Fr *d_wsrc, const uint8_t *r32, const uint8_t *s32, hipStream_t caller) {
+  int rc = prove_submit_enqueue(k, sl, d_wsrc, r32, s32, caller);
+  if (rc && rc != ZKR_ERR_ARG) {  // ZKR_ERR_ARG: refused before the first launch
+    hipStreamSynchronize(k->stream);
+    hipStreamSynchronize(k->prep_stream);
+    for (int j = 0; j < k->n_red; j++) hipStreamSynchronize(k->red_stream[j]);
+    sl.spans.clear();
+    sl.event_next = 0;
+  }
+  return rc;
+}
+
+static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *d_wsrc, const uint8_t *r32, const uint8_t *s32, hipStream_t caller) {
   ZKR_HIP_CHECK(hipSetDevice(k->device));
   const ArenaHeader &h = k->h;
   const unsigned char *ar = k->arena;

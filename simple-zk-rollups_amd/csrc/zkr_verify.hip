@@ -38,7 +38,8 @@ static bool read_g2(const uint8_t *p, G2Affine &out) {
     if (!fq_lt_q(p + 32 * i)) return false;
   out = G2Affine{Fq2{to_mont(load_fp<FqParams>(p)), to_mont(load_fp<FqParams>(p + 32))},
                  Fq2{to_mont(load_fp<FqParams>(p + 64)), to_mont(load_fp<FqParams>(p + 96))}};
-  return !out.is_inf() && pairing::g2_on_curve(out);
+  // on the twist AND in the order-r subgroup (the twist has cofactor 2q - r): what precompile 8 accepts
+  return !out.is_inf() && pairing::g2_on_curve(out) && pairing::g2_in_subgroup(out);
 }
 
 namespace {
@@ -57,7 +58,7 @@ int parse_vk(const void *vk_bin, size_t vk_len, size_t n_public, ParsedVk &k) {
   if (vk_len != fixed + 64ull * n_ic) { set_error("verifying key length %zu does not match %u IC points", vk_len, n_ic); return ZKR_ERR_BAD_KEY; }
   if (n_ic != n_public + 1) { set_error("%zu public signals for a key with %u IC points (needs nPublic + 1, TxVerifier.sol:261)", n_public, n_ic); return ZKR_ERR_ARG; }
   if (!read_g1(vk, k.alfa1) || !read_g2(vk + 64, k.beta2) || !read_g2(vk + 192, k.gamma2) || !read_g2(vk + 320, k.delta2) || !read_g1(vk + fixed, k.ic0)) {
-    set_error("verifying key holds a point that is not on the curve");
+    set_error("verifying key holds a point that is not on the curve (or a G2 point outside the order-r subgroup)");
     return ZKR_ERR_BAD_KEY;
   }
   k.ics.resize(n_public);
@@ -168,7 +169,9 @@ extern "C" int zkr_verify_batch(const void *vk_bin, size_t vk_len, const uint8_t
   pairing::Fq12 f = pairing::Fq12::one();
   for (size_t at = 0; at < ps.size(); at += pairing::MAX_PAIRS) {
     int m = (int)std::min<size_t>(pairing::MAX_PAIRS, ps.size() - at);
-    f = pairing::mul(f, pairing::multi_miller_loop(&ps[at], &qs[at], m));
+    bool ok = true;
+    f = pairing::mul(f, pairing::multi_miller_loop(&ps[at], &qs[at], m, &ok));
+    if (!ok) return 0;  // undefined slope: cannot happen for subgroup points (read_g2 checks), never "valid"
   }
   *all_valid = pairing::final_exponentiation(f) == pairing::Fq12::one() ? 1 : 0;
   return 0;

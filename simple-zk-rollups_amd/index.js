@@ -33,12 +33,18 @@ function proofFromBytes(pb) {
   return { pi_a: [s[0], s[1], "1"], pi_b: [[s[2], s[3]], [s[4], s[5]], ["1", "0"]], pi_c: [s[6], s[7], "1"] };
 }
 
+// 32-byte little-endian encoding of 0 <= v < 2^256; anything else is a caller error (big-integer's shift loop in
+// binarify.ts:18-26 would silently keep the low 256 bits: a value x + k 2^256 must not pass for x)
 function bigintToLe32(v) {
   const out = Buffer.alloc(32);
   let x = BigInt(v);
+  if (x < 0n || x >= MONT) throw new RangeError("value does not fit 256 bits (or is negative): " + (x < 0n ? "-" : "") + "0x" + (x < 0n ? -x : x).toString(16).slice(0, 24) + "...");
   for (let i = 0; i < 32; i++) { out[i] = Number(x & 0xffn); x >>= 8n; }
   return out;
 }
+// public signals as the verifier takes them: out of [0, r) never verifies (TxVerifier.sol:265 `require(input[i] < r)`;
+// snarkjs would reduce mod r, the chain refuses: the facade sides with the chain)
+const signalsInRange = (ps) => ps.every((x) => { const v = BigInt(x); return v >= 0n && v < R; });
 
 function keyFingerprint(buf) {
   // cheap identity for the per-instance key cache: length + FNV-1a of the header and the tail
@@ -204,15 +210,21 @@ function proofToBytes(proof) {
 }
 
 function isValid(vk, proof, publicSignals) {
+  if (!signalsInRange(publicSignals)) return false;
   const pub = Buffer.concat(publicSignals.map((x) => bigintToLe32(BigInt(x))).concat([Buffer.alloc(0)]));
-  return native().verify(binarifyVerifyingKey(vk), proofToBytes(proof), pub);
+  let pb;
+  try { pb = proofToBytes(proof); } catch (e) { if (e instanceof RangeError) return false; throw e; }  // a coordinate >= 2^256 is not a field element
+  return native().verify(binarifyVerifyingKey(vk), pb, pub);
 }
 
 // every proof of a batch under one key, merged into one pairing product (zkr_verify_batch): true iff all verify
 function isValidBatch(vk, proofs, publicSignalsList) {
   if (proofs.length === 0) return true;
+  if (!publicSignalsList.every(signalsInRange)) return false;
   const pub = Buffer.concat(publicSignalsList.map((ps) => Buffer.concat(ps.map((x) => bigintToLe32(BigInt(x))).concat([Buffer.alloc(0)]))));
-  return native().verifyBatch(binarifyVerifyingKey(vk), Buffer.concat(proofs.map(proofToBytes)), pub, proofs.length);
+  let pbs;
+  try { pbs = Buffer.concat(proofs.map(proofToBytes)); } catch (e) { if (e instanceof RangeError) return false; throw e; }
+  return native().verifyBatch(binarifyVerifyingKey(vk), pbs, pub, proofs.length);
 }
 
 // operator/src/snarks/common.ts:43-50

@@ -69,7 +69,14 @@ def proof_bytes_from_json(proof) -> bytes:
 def is_valid(verifying_key, proof, public_signals) -> bool:
     """groth.isValid(vk, proof, publicSignals) (common.ts:30-34) on the native host verifier (zkr_verify)."""
     from .binding import verify
-    return verify(binarify_verifying_key(verifying_key), proof_bytes_from_json(proof), [int(x) for x in public_signals])
+    signals = [int(x) for x in public_signals]
+    if any(v < 0 or v >= SNARK_FIELD_SIZE for v in signals):
+        return False  # TxVerifier.sol:265 `require(input[i] < r)`: the chain refuses what snarkjs would reduce mod r
+    try:
+        pb = proof_bytes_from_json(proof)
+    except OverflowError:
+        return False  # a coordinate that does not fit 256 bits is not a field element
+    return verify(binarify_verifying_key(verifying_key), pb, signals)
 
 
 class Bn128:

@@ -175,3 +175,64 @@ def test_batch_verifier_merges_proofs_into_one_pairing_product(small_case):
     assert zkr_hip.verify_batch(vkb, off, pubs) is False
     with pytest.raises(zkr_hip.ZkrError):
         zkr_hip.verify_batch(vkb[:-1], proofs, pubs)
+
+
+def _twist_point_outside_g2():
+    """A point on the twist y^2 = x^3 + 3/(9+u) that is NOT in the order-r subgroup, and its multiple by r (a point
+    whose order divides the cofactor 2q - r).  Square root in Fq2 by the norm method (q = 3 mod 4)."""
+    import bn254 as b
+    def sqrt_fq(a):
+        s = pow(a, (b.Q + 1) // 4, b.Q)
+        return s if s * s % b.Q == a % b.Q else None
+    def sqrt_fq2(a):
+        a0, a1 = a
+        s = sqrt_fq((a0 * a0 + a1 * a1) % b.Q)
+        if s is None:
+            return None
+        for sg in (s, -s):
+            x0 = sqrt_fq((a0 + sg) * b.inv(2) % b.Q)
+            if x0:
+                x1 = a1 * b.inv(2 * x0) % b.Q
+                if b.f2sqr((x0, x1)) == (a0 % b.Q, a1 % b.Q):
+                    return (x0, x1)
+        return None
+    k = 1
+    while True:
+        x = (k, 1)
+        y = sqrt_fq2(b.f2add(b.f2mul(b.f2sqr(x), x), b.B2))
+        k += 1
+        if y is None:
+            continue
+        P = (x, y)
+        assert b.g2_is_on_curve(P)
+        Pc = b.g2_mul(P, b.R, reduce=False)
+        if Pc is not None:          # [r]P != infinity: P is outside G2 (true for all but a 1/cofactor fraction of points)
+            return P, Pc
+
+
+def test_native_verifier_rejects_twist_points_outside_the_r_torsion(small_case):
+    """a G2 point on the twist but outside the order-r subgroup (the twist's cofactor 2q - r has small
+    factors) must be refused like the bn256 pairing precompile refuses it (TxVerifier.sol:91-115): as proof.B the
+    verdict is False (single and batch), inside a verifying key it is a bad key."""
+    import bn254 as b
+    import groth16 as g
+    import zkr_hip
+    c = small_case
+    P, Pc = _twist_point_outside_g2()
+    assert b.g2_is_on_curve(Pc) and b.g2_mul(Pc, 2 * b.Q - b.R, reduce=False) is None   # order divides the cofactor
+    proof = g.proof_from_toxic(c["circ"], c["tox"], c["w"], c["r"], c["s"])
+    pb = g.proof_bytes(proof)
+    pub = c["w"][1:8]
+    vkb = zkr_hip.binarify_verifying_key(c["vk"])
+    assert zkr_hip.verify(vkb, pb, pub) is True
+    le = lambda v: int(v).to_bytes(32, "little")
+    for bad in (P, Pc):
+        enc = le(bad[0][0]) + le(bad[0][1]) + le(bad[1][0]) + le(bad[1][1])
+        forged = pb[:64] + enc + pb[192:]
+        assert zkr_hip.verify(vkb, forged, pub) is False
+        assert zkr_hip.verify_batch(vkb, [pb, forged], [pub, pub]) is False
+        for off in (64, 192, 320):                            # beta2, gamma2, delta2 of the key
+            with pytest.raises(zkr_hip.ZkrError):
+                zkr_hip.verify(vkb[:off] + enc + vkb[off + 128:], pb, pub)
+    # the subgroup's own points still pass: the key's gamma2 used as proof.B is on the twist AND in G2 (verdict False, no error)
+    assert zkr_hip.verify(vkb, pb[:64] + vkb[192:320] + pb[192:], pub) is False

@@ -132,15 +132,30 @@ def test_js_is_valid_on_native_verifier(tmp_path, small_case):
     bad = list(pub)
     bad[2] = str((int(bad[2]) + 1) % g.R)
     path = tmp_path / "vk.json"
-    path.write_text(json.dumps(dict(vk=vk, proof=proof, pub=pub, bad=bad)))
+    # a signal x + k 2^256 (or x + r, or negative) must not verify as x -- TxVerifier.sol:265 refuses inputs >= r
+    wrap = [str(int(pub[0]) + (1 << 256))] + pub[1:]
+    plus_r = [str(int(pub[0]) + g.R)] + pub[1:]
+    negative = [str(int(pub[0]) - g.R)] + pub[1:]
+    huge_proof = json.loads(json.dumps(proof))
+    huge_proof["pi_a"][0] = str(int(proof["pi_a"][0]) + (1 << 256))
+    path.write_text(json.dumps(dict(vk=vk, proof=proof, pub=pub, bad=bad, wrap=wrap, plus_r=plus_r, negative=negative, huge_proof=huge_proof)))
     out = _node("""
       const z = require('./index.js'); const fs = require('fs');
       const d = JSON.parse(fs.readFileSync(process.argv[1]));
+      let threw = false;
+      try { z.binarifyWitness([d.wrap[0]]); } catch (e) { threw = e instanceof RangeError; }
       console.log(JSON.stringify([z.isValid(d.vk, d.proof, d.pub), z.isValid(d.vk, d.proof, d.bad),
                                   z.isValidBatch(d.vk, [d.proof, d.proof, d.proof], [d.pub, d.pub, d.pub]),
-                                  z.isValidBatch(d.vk, [d.proof, d.proof], [d.pub, d.bad]), z.isValidBatch(d.vk, [], [])]));
+                                  z.isValidBatch(d.vk, [d.proof, d.proof], [d.pub, d.bad]), z.isValidBatch(d.vk, [], []),
+                                  z.isValid(d.vk, d.proof, d.wrap), z.isValid(d.vk, d.proof, d.plus_r), z.isValid(d.vk, d.proof, d.negative),
+                                  z.isValidBatch(d.vk, [d.proof, d.proof], [d.pub, d.wrap]), z.isValid(d.vk, d.huge_proof, d.pub), threw]));
     """, str(path)).stdout
-    assert json.loads(out) == [True, False, True, False, True]
+    assert json.loads(out) == [True, False, True, False, True, False, False, False, False, False, True]
+    import zkr_hip
+    assert zkr_hip.is_valid(c["vk"], proof, pub) is True
+    for sig in (wrap, plus_r, negative):
+        assert zkr_hip.is_valid(c["vk"], proof, sig) is False
+    assert zkr_hip.is_valid(c["vk"], huge_proof, pub) is False
 
 
 @pytest.mark.gpu
