@@ -72,6 +72,13 @@ int zkr_key_windows(const zkr_key *key, uint32_t c_out[5], uint32_t k_out[5]);
  *          the caller keeps ownership of that memory and must keep it alive until zkr_key_free). */
 int zkr_key_arena(const zkr_key *key, void **dev_ptr, size_t *len);
 int zkr_key_adopt_arena(void *dev_ptr, size_t len, int device, zkr_key **out);
+/* The same replication with 1/10 of the bytes on the wire: zkr_key_base_arena gives a compact device buffer (owned by
+ * the key, valid until zkr_key_free) holding the QAP rows, the BASE points of every table and the rank maps, without
+ * the precomputed window levels and twiddles; zkr_key_adopt_base_arena copies it into a full arena on `device` and
+ * rebuilds those levels there (about 0.25 s at 2^20).  The caller's buffer may be released as soon as the call returns;
+ * the rebuilt arena is byte-identical to the sender's. */
+int zkr_key_base_arena(zkr_key *key, void **dev_ptr, size_t *len);
+int zkr_key_adopt_base_arena(const void *dev_ptr, size_t len, int device, zkr_key **out);
 
 /* ---- the hot path --------------------------------------------------------------------------- */
 /* One Groth16 proof.  witness_std: nVars x 32 B standard form (binarifyWitness layout, host memory).
@@ -167,6 +174,11 @@ int zkr_synth_witness(unsigned log_m, unsigned n_public, uint64_t circuit_seed, 
  * delta (5 x 32 B, non-zero, < r) for reproducible test setups, or NULL to draw them from the OS CSPRNG inside the call
  * (they are wiped before it returns).  domainSize = smallest power of two >= nConstraints + nPublic + 1. */
 int zkr_setup_r1cs(const void *r1cs_bin, size_t r1cs_len, const uint8_t *toxic160, int device, zkr_key **key_out, void **vk_out, size_t *vk_len);
+/* The same setup, delivering the proving key as the bytes `binarifyProvingKey(provingKey)` produces from snarkjs' JSON key
+ * (binarify.ts:143-206; malloc'ed, free with zkr_free; at most 4 GiB, the format's u32 offsets) instead of a device key:
+ * the provingKeyBin an UNCHANGED reference caller passes to groth16GenProof on every call (common.ts:28-29). */
+int zkr_setup_r1cs_websnark(const void *r1cs_bin, size_t r1cs_len, const uint8_t *toxic160, int device, void **pk_out, size_t *pk_len, void **vk_out,
+                            size_t *vk_len);
 
 /* Circuit shape drawn by the three zkr_synth_* calls above (process-wide): 0 = rollup-shaped (default; 1-3 terms
  * per row, 3 % boolean and 2 % small signals, a third of the signals absent from B), 1 = dense random (BASELINE.json

@@ -24,6 +24,11 @@ def lib():
         L.zo_prove.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p,
                                ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double)]
         L.zo_prove.restype = ctypes.c_int
+        L.zo_prove_mt.argtypes = L.zo_prove.argtypes + [ctypes.c_int]
+        L.zo_prove_mt.restype = ctypes.c_int
+        L.zo_max_threads.restype = ctypes.c_int
+        L.zo_fr_dot.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p]
+        L.zo_fr_dot.restype = None
         for f in (L.zo_fq_mul_std, L.zo_fr_mul_std):
             f.argtypes = [ctypes.c_char_p] * 3
             f.restype = None
@@ -70,3 +75,26 @@ def prove(pk: bytes, witness: bytes, r: int, s: int, want_timings=False):
     if rc:
         raise RuntimeError("zo_prove failed: %d" % rc)
     return (out.raw, list(tm)) if want_timings else out.raw
+
+
+def prove_mt(pk: bytes, witness: bytes, r: int, s: int, threads=0, want_timings=False):
+    """zo_prove on all host threads (OpenMP; threads = 0: every hardware thread): same bytes as prove().
+    timings = [calc_h s, msm s, total s, threads used]."""
+    out = ctypes.create_string_buffer(256)
+    tm = (ctypes.c_double * 4)()
+    rc = lib().zo_prove_mt(pk, len(pk), witness, len(witness) // 32, r.to_bytes(32, "little"), s.to_bytes(32, "little"), out, tm, threads)
+    if rc:
+        raise RuntimeError("zo_prove_mt failed: %d" % rc)
+    return (out.raw, list(tm)) if want_timings else out.raw
+
+
+def max_threads() -> int:
+    return lib().zo_max_threads()
+
+
+def fr_dot(a: bytes, b: bytes) -> int:
+    """sum_i a_i b_i mod r over two arrays of 32-byte LE standard-form elements."""
+    assert len(a) == len(b) and len(a) % 32 == 0
+    out = ctypes.create_string_buffer(32)
+    lib().zo_fr_dot(a, b, len(a) // 32, out)
+    return int.from_bytes(out.raw, "little")

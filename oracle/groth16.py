@@ -613,27 +613,50 @@ def parse_synth_aux(aux: bytes):
     return dict(n=n, tox=tox, a=a, b=b, c=c, ic=ic, gamma2=((gv[0], gv[1]), (gv[2], gv[3])))
 
 
-def proof_from_aux(aux, witness_bytes, n_public, r, s):
+def proof_from_aux(aux, witness_bytes, n_public, r, s, dot=None):
     """Toxic-waste closed form of the proof (satisfying witness) and the verifying key, for keys whose
-    group elements were computed on the GPU: no MSM, no NTT -- field dot products + 3 scalar muls."""
-    ax = parse_synth_aux(aux)
-    n, tox = ax["n"], ax["tox"]
-    w = [int.from_bytes(witness_bytes[32 * i:32 * i + 32], "little") for i in range(n)]
-    At = sum(x * y for x, y in zip(w, ax["a"])) % R
-    Bt = sum(x * y for x, y in zip(w, ax["b"])) % R
-    Ct = sum(x * y for x, y in zip(w, ax["c"])) % R
+    group elements were computed on the GPU: no MSM, no NTT -- field dot products + 3 scalar muls.
+    dot(a_bytes, b_bytes) -> sum a_i b_i mod r over 32-byte LE arrays: pass coracle.fr_dot at sizes where a Python
+    loop over big integers takes minutes (2^24: BASELINE configs[4]); default: the plain Python sums."""
+    p = n_public
+    if dot is None:
+        ax = parse_synth_aux(aux)
+        n, tox = ax["n"], ax["tox"]
+        w = [int.from_bytes(witness_bytes[32 * i:32 * i + 32], "little") for i in range(n)]
+        At = sum(x * y for x, y in zip(w, ax["a"])) % R
+        Bt = sum(x * y for x, y in zip(w, ax["b"])) % R
+        Ct = sum(x * y for x, y in zip(w, ax["c"])) % R
+        head = (ax["a"][:p + 1], ax["b"][:p + 1], ax["c"][:p + 1])
+        ic, gamma2 = ax["ic"], ax["gamma2"]
+    else:  # the same sums over the byte arrays as they lie in the blob
+        n = int.from_bytes(aux[:8], "little")
+        rd = lambda o: int.from_bytes(aux[o:o + 32], "little")
+        tox = dict(t=rd(8), alfa=rd(40), beta=rd(72), gamma=rd(104), delta=rd(136))
+        o = 168
+        wb = bytes(witness_bytes[:32 * n])
+        sums, head = [], []
+        for _ in range(3):
+            sums.append(dot(wb, bytes(aux[o:o + 32 * n])))
+            head.append([rd(o + 32 * i) for i in range(p + 1)])
+            o += 32 * n
+        At, Bt, Ct = sums
+        w = [int.from_bytes(witness_bytes[32 * i:32 * i + 32], "little") for i in range(p + 1)]
+        rest = aux[o:]
+        n_ic = (len(rest) - 128) // 64
+        ic = [(int.from_bytes(rest[64 * i:64 * i + 32], "little"), int.from_bytes(rest[64 * i + 32:64 * i + 64], "little")) for i in range(n_ic)]
+        gv = [int.from_bytes(rest[64 * n_ic + 32 * i:64 * n_ic + 32 * i + 32], "little") for i in range(4)]
+        gamma2 = ((gv[0], gv[1]), (gv[2], gv[3]))
     d = tox["delta"]
     dinv = inv(d, R)
     a_log = (tox["alfa"] + At + r * d) % R
     b_log = (tox["beta"] + Bt + s * d) % R
-    p = n_public
-    pub = sum(w[i] * ((tox["beta"] * ax["a"][i] + tox["alfa"] * ax["b"][i] + ax["c"][i]) % R) for i in range(p + 1)) % R
+    pub = sum(w[i] * ((tox["beta"] * head[0][i] + tox["alfa"] * head[1][i] + head[2][i]) % R) for i in range(p + 1)) % R
     allk = (tox["beta"] * At + tox["alfa"] * Bt + Ct) % R
     cpriv = (allk - pub) * dinv % R
     c_log = (cpriv + (At * Bt - Ct) * dinv + s * a_log + r * b_log - r * s % R * d) % R
     fb1, fb2 = _fb()
     proof = dict(pi_a=fb1.mul(a_log), pi_b=fb2.mul(b_log), pi_c=fb1.mul(c_log))
-    vk = dict(nPublic=p, IC=ax["ic"], vk_alfa_1=fb1.mul(tox["alfa"]), vk_beta_2=fb2.mul(tox["beta"]),
-              vk_gamma_2=ax["gamma2"], vk_delta_2=fb2.mul(d))
+    vk = dict(nPublic=p, IC=ic, vk_alfa_1=fb1.mul(tox["alfa"]), vk_beta_2=fb2.mul(tox["beta"]),
+              vk_gamma_2=gamma2, vk_delta_2=fb2.mul(d))
     assert vk["vk_gamma_2"] == fb2.mul(tox["gamma"])
     return proof, vk, w[1:p + 1]

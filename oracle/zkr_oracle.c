@@ -14,7 +14,9 @@
  *   algorithm       SURVEY.md Appendix B (published websnark/snarkjs algorithm):
  *                   QAP evaluation -> iNTT_m x2 -> coset NTT_m x2 -> pointwise -> iNTT_2m -> upper half;
  *                   five multiexps; blinding; affine; de-Montgomery.
- * Single-threaded; 4x64-bit limbs, Montgomery form, unsigned __int128 products.
+ * 4x64-bit limbs, Montgomery form, unsigned __int128 products.  zo_prove is single-threaded; zo_prove_mt runs the
+ * same algorithm on all host threads (OpenMP: the five multiexps cut into point slices, NTT butterflies and QAP
+ * columns in parallel loops) for bench.py's all-cores CPU baseline -- same proof bytes.
  */
 #include <stdint.h>
 #include <stdlib.h>
@@ -359,6 +361,188 @@ int zo_prove(const uint8_t *pk, size_t pk_len, const uint8_t *witness, size_t n_
   free(h);
   if (timings) { timings[0] = t1 - t0; timings[1] = t2 - t1; timings[2] = now_s() - t0; }
   return 0;
+}
+
+/* ------------------------------------------------------------------ all-host-threads variant (bench.py cpu_baseline)
+ * Same mathematics as zo_prove; the group sums are associative and the result is made affine, so the bytes are equal. */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+int zo_max_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+/* in-place NTT with the butterflies of every stage split over the threads; one twiddle table w^k, k < n/2 */
+static void ntt_mont_mt(fe *a, unsigned logn, int inverse) {
+  size_t n = (size_t)1 << logn;
+  for (size_t i = 1, j = 0; i < n; i++) {
+    size_t bit = n >> 1;
+    for (; j & bit; bit >>= 1) j ^= bit;
+    j ^= bit;
+    if (i < j) { fe t = a[i]; a[i] = a[j]; a[j] = t; }
+  }
+  fe w; fr_root_of_unity(&w, logn); if (inverse) f_inv(&FR, &w, &w);
+  fe *tw = (fe *)malloc((n / 2 + 1) * sizeof(fe));
+  /* w^k by blocks: block starts from a short serial chain, the blocks in parallel */
+  const size_t half_n = n / 2 ? n / 2 : 1, BL = 4096;
+  size_t nblk = (half_n + BL - 1) / BL;
+  fe wb = FR.r1; { fe t = w; size_t e = BL; fe acc = FR.r1; while (e) { if (e & 1) f_mul(&FR, &acc, &acc, &t); f_sqr(&FR, &t, &t); e >>= 1; } wb = acc; }
+  fe *start = (fe *)malloc(nblk * sizeof(fe));
+  start[0] = FR.r1; for (size_t b = 1; b < nblk; b++) f_mul(&FR, &start[b], &start[b - 1], &wb);
+#pragma omp parallel for schedule(static)
+  for (long b = 0; b < (long)nblk; b++) {
+    size_t lo = (size_t)b * BL, hi = lo + BL < half_n ? lo + BL : half_n;
+    tw[lo] = start[b];
+    for (size_t k = lo + 1; k < hi; k++) f_mul(&FR, &tw[k], &tw[k - 1], &w);
+  }
+  free(start);
+  for (unsigned s = 1; s <= logn; s++) {
+    size_t half = (size_t)1 << (s - 1), stride = (n / 2) >> (s - 1);
+#pragma omp parallel for schedule(static)
+    for (long q = 0; q < (long)(n / 2); q++) {
+      size_t k = (size_t)q & (half - 1), i = (((size_t)q >> (s - 1)) << s) + k;
+      fe u = a[i], v; f_mul(&FR, &v, &a[i + half], &tw[k * stride]);
+      f_add(&FR, &a[i], &u, &v); f_sub(&FR, &a[i + half], &u, &v);
+    }
+  }
+  free(tw);
+  if (inverse) {
+    fe ni = {{n, 0, 0, 0}}; f_to_mont(&FR, &ni, &ni); f_inv(&FR, &ni, &ni);
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < (long)n; i++) f_mul(&FR, &a[i], &a[i], &ni);
+  }
+}
+
+static int calc_h_mt(const uint8_t *pk, size_t pk_len, const uint8_t *witness, size_t n_w, uint8_t *h_out) {
+  if (pk_len < 488) return -1;
+  size_t n = rd32(pk), m = rd32(pk + 8);
+  if (n_w != n || (m & (m - 1))) return -2;
+  unsigned logm = 0; while (((size_t)1 << logm) < m) logm++;
+  fe *w = (fe *)malloc(n * sizeof(fe));
+#pragma omp parallel for schedule(static)
+  for (long i = 0; i < (long)n; i++) { memcpy(&w[i], witness + 32 * i, 32); f_to_mont(&FR, &w[i], &w[i]); }
+  fe *a = (fe *)malloc(m * sizeof(fe)), *b = (fe *)malloc(m * sizeof(fe));
+  fe *ac = (fe *)malloc(m * sizeof(fe)), *bc = (fe *)malloc(m * sizeof(fe));
+  fe *ev = (fe *)malloc(2 * m * sizeof(fe));
+#pragma omp parallel sections
+  {
+#pragma omp section
+    qap_eval(a, m, pk + rd32(pk + 12), n, w);   /* column-major scatter: one thread per matrix */
+#pragma omp section
+    qap_eval(b, m, pk + rd32(pk + 16), n, w);
+  }
+  memcpy(ac, a, m * sizeof(fe)); memcpy(bc, b, m * sizeof(fe));
+  ntt_mont_mt(ac, logm, 1); ntt_mont_mt(bc, logm, 1);
+  fe g; fr_root_of_unity(&g, logm + 1);
+  {  /* coset shift g^i: blocks in parallel */
+    const size_t BL = 4096; size_t nblk = (m + BL - 1) / BL;
+    fe gb = FR.r1, t = g; size_t e = BL; while (e) { if (e & 1) f_mul(&FR, &gb, &gb, &t); f_sqr(&FR, &t, &t); e >>= 1; }
+    fe *start = (fe *)malloc(nblk * sizeof(fe));
+    start[0] = FR.r1; for (size_t k = 1; k < nblk; k++) f_mul(&FR, &start[k], &start[k - 1], &gb);
+#pragma omp parallel for schedule(static)
+    for (long q = 0; q < (long)nblk; q++) {
+      size_t lo = (size_t)q * BL, hi = lo + BL < m ? lo + BL : m;
+      fe gi = start[q];
+      for (size_t i = lo; i < hi; i++) { f_mul(&FR, &ac[i], &ac[i], &gi); f_mul(&FR, &bc[i], &bc[i], &gi); f_mul(&FR, &gi, &gi, &g); }
+    }
+    free(start);
+  }
+  ntt_mont_mt(ac, logm, 0); ntt_mont_mt(bc, logm, 0);
+#pragma omp parallel for schedule(static)
+  for (long c = 0; c < (long)m; c++) { f_mul(&FR, &ev[2 * c], &a[c], &b[c]); f_mul(&FR, &ev[2 * c + 1], &ac[c], &bc[c]); }
+  ntt_mont_mt(ev, logm + 1, 1);
+#pragma omp parallel for schedule(static)
+  for (long i = 0; i < (long)m; i++) { fe t; f_from_mont(&FR, &t, &ev[m + i]); memcpy(h_out + 32 * i, &t, 32); }
+  free(w); free(a); free(b); free(ac); free(bc); free(ev);
+  return 0;
+}
+
+/* one multiexp as `slices` independent Pippenger runs over point ranges (each picks its own window size) */
+typedef struct { int g2; const uint8_t *pts, *scal; size_t n; void *out; } msm_task;
+int zo_prove_mt(const uint8_t *pk, size_t pk_len, const uint8_t *witness, size_t n_w, const uint8_t *r32, const uint8_t *s32,
+                uint8_t out[256], double *timings, int threads) {
+  double t0 = now_s();
+#ifdef _OPENMP
+  if (threads > 0) omp_set_num_threads(threads);
+  int T = omp_get_max_threads();
+#else
+  int T = 1; (void)threads;
+#endif
+  if (pk_len < 488) return -1;
+  size_t n = rd32(pk), p = rd32(pk + 4), m = rd32(pk + 8);
+  if (n_w != n) return -2;
+  uint8_t *h = (uint8_t *)malloc(32 * m);
+  int rc = calc_h_mt(pk, pk_len, witness, n_w, h); if (rc) { free(h); return rc; }
+  double t1 = now_s();
+  const uint8_t *pA = pk + rd32(pk + 20), *pB1 = pk + rd32(pk + 24), *pB2 = pk + rd32(pk + 28), *pC = pk + rd32(pk + 32), *pH = pk + rd32(pk + 36);
+  /* tasks: [A, B1, C, H] x S slices of G1 work, B2 x 3S slices (a G2 addition costs about three G1 additions) */
+  int S = T < 1 ? 1 : T;
+  while ((size_t)S * 1024 > n && S > 1) S /= 2;  /* keep slices above ~1000 points */
+  struct { int g2; const uint8_t *pts, *scal; size_t cnt; int slices; } ms[5] = {
+    {0, pA, witness, n, S}, {0, pB1, witness, n, S}, {1, pB2, witness, n, 3 * S}, {0, pC, witness + 32 * (p + 1), n - p - 1, S}, {0, pH, h, m, S}};
+  int ntask = 0, first[6];
+  for (int i = 0; i < 5; i++) { first[i] = ntask; ntask += ms[i].slices; }
+  first[5] = ntask;
+  g1_jac *r1 = (g1_jac *)calloc(ntask, sizeof(g1_jac));
+  g2_jac *r2 = (g2_jac *)calloc(ntask, sizeof(g2_jac));
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int t = 0; t < ntask; t++) {
+    int i = 0; while (t >= first[i + 1]) i++;
+    int q = t - first[i];
+    size_t lo = ms[i].cnt * (size_t)q / ms[i].slices, hi = ms[i].cnt * (size_t)(q + 1) / ms[i].slices;
+    if (ms[i].g2) g2_msm_core(&r2[t], ms[i].pts + 128 * lo, ms[i].scal + 32 * lo, hi - lo);
+    else g1_msm_core(&r1[t], ms[i].pts + 64 * lo, ms[i].scal + 32 * lo, hi - lo);
+  }
+  g1_jac A, B1, C, H; g2_jac B2;
+  g1_jac *dst[5] = {&A, &B1, NULL, &C, &H};
+  for (int i = 0; i < 5; i++) {
+    if (ms[i].g2) { g2_set_inf(&B2); for (int t = first[i]; t < first[i + 1]; t++) g2_add(&B2, &B2, &r2[t]); }
+    else { g1_set_inf(dst[i]); for (int t = first[i]; t < first[i + 1]; t++) g1_add(dst[i], dst[i], &r1[t]); }
+  }
+  free(r1); free(r2);
+  double t2 = now_s();
+  g1_aff alfa1, beta1, delta1; g2_aff beta2, delta2;
+  g1_load(&alfa1, pk + 40); g1_load(&beta1, pk + 104); g1_load(&delta1, pk + 168); g2_load(&beta2, pk + 232); g2_load(&delta2, pk + 360);
+  uint64_t r[4], s[4]; memcpy(r, r32, 32); memcpy(s, s32, 32);
+  g1_jac d1j = {delta1.x, delta1.y, FQ.r1}, t, pia, pib1, pic; g2_jac d2j = {delta2.x, delta2.y, *fq2_one()}, t2j, pib;
+  g1_add_mixed(&pia, &A, &alfa1, &FQ.r1); g1_scalar_mul(&t, &d1j, r); g1_add(&pia, &pia, &t);
+  g2_add_mixed(&pib, &B2, &beta2, fq2_one()); g2_scalar_mul(&t2j, &d2j, s); g2_add(&pib, &pib, &t2j);
+  g1_add_mixed(&pib1, &B1, &beta1, &FQ.r1); g1_scalar_mul(&t, &d1j, s); g1_add(&pib1, &pib1, &t);
+  g1_add(&pic, &C, &H);
+  g1_scalar_mul(&t, &pia, s); g1_add(&pic, &pic, &t);
+  g1_scalar_mul(&t, &pib1, r); g1_add(&pic, &pic, &t);
+  fe rm, sm, rs; memcpy(&rm, r, 32); memcpy(&sm, s, 32); f_to_mont(&FR, &rm, &rm); f_to_mont(&FR, &sm, &sm);
+  f_mul(&FR, &rs, &rm, &sm); f_neg(&FR, &rs, &rs); f_from_mont(&FR, &rs, &rs);
+  g1_scalar_mul(&t, &d1j, rs.v); g1_add(&pic, &pic, &t);
+  g1_aff a, c; g2_aff b; g1_to_affine(&a, &pia); g2_to_affine(&b, &pib); g1_to_affine(&c, &pic);
+  if (a.inf || b.inf || c.inf) { free(h); return -3; }
+  fe *o[8] = {&a.x, &a.y, &b.x.a, &b.x.b, &b.y.a, &b.y.b, &c.x, &c.y};
+  for (int i = 0; i < 8; i++) { f_from_mont(&FQ, o[i], o[i]); memcpy(out + 32 * i, o[i], 32); }
+  free(h);
+  if (timings) { timings[0] = t1 - t0; timings[1] = t2 - t1; timings[2] = now_s() - t0; timings[3] = (double)T; }
+  return 0;
+}
+
+/* sum_i a_i b_i mod r over standard-form 32-byte LE elements (the dot products of the toxic-waste closed form at full
+ * size, where a Python loop over 2^24 big integers takes minutes) */
+void zo_fr_dot(const uint8_t *a_std, const uint8_t *b_std, size_t n, uint8_t out[32]) {
+  fe acc = {{0, 0, 0, 0}};
+#pragma omp parallel
+  {
+    fe part = {{0, 0, 0, 0}};
+#pragma omp for schedule(static) nowait
+    for (long i = 0; i < (long)n; i++) {
+      fe x, y, t; memcpy(&x, a_std + 32 * i, 32); memcpy(&y, b_std + 32 * i, 32);
+      f_to_mont(&FR, &x, &x); f_mul(&FR, &t, &x, &y);   /* (a R)(b)/R = a b */
+      f_add(&FR, &part, &part, &t);
+    }
+#pragma omp critical
+    f_add(&FR, &acc, &acc, &part);
+  }
+  memcpy(out, &acc, 32);
 }
 
 /* field self-test hooks */

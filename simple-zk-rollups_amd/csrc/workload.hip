@@ -378,15 +378,14 @@ static int draw_fr(FILE *f, Fr &out) {
   }
 }
 
-int zkr_setup_r1cs(const void *r1cs_bin, size_t r1cs_len, const uint8_t *toxic160, int device, zkr_key **key_out, void **vk_out, size_t *vk_len) {
-  if (!r1cs_bin || !key_out || !vk_out || !vk_len) { set_error("null argument"); return ZKR_ERR_ARG; }
+// r1cs_bin (include/zkr.h) -> g.circ; toxic waste injected or drawn; QAP at t and every group element on the GPU
+static int setup_parse_and_run(const void *r1cs_bin, size_t r1cs_len, const uint8_t *toxic160, int device, Generated &g) {
   const uint8_t *b = (const uint8_t *)r1cs_bin, *end = b + r1cs_len;
   if (r1cs_len < 12) { set_error("R1CS shorter than its header"); return ZKR_ERR_ARG; }
-  Generated g;
   Circuit &c = g.circ;
   memcpy(&c.n, b, 4); memcpy(&c.p, b + 4, 4); memcpy(&c.nC, b + 8, 4);
   b += 12;
-  if (c.n < 1 || c.p + 1 > c.n || c.nC < 1 || (uint64_t)c.nC + c.p + 1 > (1ull << 26)) { set_error("bad R1CS geometry nVars=%u nPublic=%u nConstraints=%u", c.n, c.p, c.nC); return ZKR_ERR_ARG; }
+  if (c.n < 1 || (uint64_t)c.p + 1 > c.n || c.nC < 1 || (uint64_t)c.nC + c.p + 1 > (1ull << 26)) { set_error("bad R1CS geometry nVars=%u nPublic=%u nConstraints=%u", c.n, c.p, c.nC); return ZKR_ERR_ARG; }
   c.m = 2;
   while (c.m < c.nC + c.p + 1) c.m <<= 1;  // snarkjs: domainBits = floor(log2(nC + nPublic)) + 1
   std::vector<uint32_t> *rows[3] = {&c.rowA, &c.rowB, &c.rowC};
@@ -428,14 +427,36 @@ int zkr_setup_r1cs(const void *r1cs_bin, size_t r1cs_len, const uint8_t *toxic16
     fclose(f);
     if (bad) { set_error("short read from /dev/urandom"); return ZKR_ERR_ARG; }
   }
-  int rc = setup_from_circuit(device, g);
-  if (!rc) rc = build_key_from_generated(g, device, key_out);
-  if (rc) return rc;
+  return setup_from_circuit(device, g);
+}
+
+static void vk_to_malloc(const Generated &g, void **vk_out, size_t *vk_len) {
   std::vector<uint8_t> vk;
   vk_from_generated(g, vk);
   *vk_out = malloc(vk.size());
   memcpy(*vk_out, vk.data(), vk.size());
   *vk_len = vk.size();
+}
+
+int zkr_setup_r1cs(const void *r1cs_bin, size_t r1cs_len, const uint8_t *toxic160, int device, zkr_key **key_out, void **vk_out, size_t *vk_len) {
+  if (!r1cs_bin || !key_out || !vk_out || !vk_len) { set_error("null argument"); return ZKR_ERR_ARG; }
+  Generated g;
+  int rc = setup_parse_and_run(r1cs_bin, r1cs_len, toxic160, device, g);
+  if (!rc) rc = build_key_from_generated(g, device, key_out);
+  if (rc) return rc;
+  vk_to_malloc(g, vk_out, vk_len);
+  return 0;
+}
+
+static int render_websnark(const Generated &g, void **pk_out, size_t *pk_len);
+
+int zkr_setup_r1cs_websnark(const void *r1cs_bin, size_t r1cs_len, const uint8_t *toxic160, int device, void **pk_out, size_t *pk_len, void **vk_out, size_t *vk_len) {
+  if (!r1cs_bin || !pk_out || !pk_len || !vk_out || !vk_len) { set_error("null argument"); return ZKR_ERR_ARG; }
+  Generated g;
+  int rc = setup_parse_and_run(r1cs_bin, r1cs_len, toxic160, device, g);
+  if (!rc) rc = render_websnark(g, pk_out, pk_len);
+  if (rc) return rc;
+  vk_to_malloc(g, vk_out, vk_len);
   return 0;
 }
 
@@ -517,12 +538,8 @@ int zkr_synth_vk(const zkr_key *key, const void *aux, size_t aux_len, void **vk_
   return 0;
 }
 
-int zkr_synth_websnark(unsigned log_m, unsigned n_public, uint64_t circuit_seed, uint64_t toxic_seed, int device, void **pk_out, size_t *pk_len,
-                       void **witness_out, size_t *witness_len) {
-  if (!pk_out || !pk_len || !witness_out || !witness_len) { set_error("null argument"); return ZKR_ERR_ARG; }
-  Generated g;
-  int rc = generate(log_m, n_public, circuit_seed, toxic_seed, device, g);
-  if (rc) return rc;
+// the key of a finished setup in the byte layout binarifyProvingKey writes (binarify.ts:143-206)
+static int render_websnark(const Generated &g, void **pk_out, size_t *pk_len) {
   const Circuit &c = g.circ;
   uint32_t n = c.n, p = c.p, m = c.m;
   // per-signal columns, constraint index ascending (JS Object.keys order, binarify.ts:104-113)
@@ -557,15 +574,25 @@ int zkr_synth_websnark(unsigned log_m, unsigned n_public, uint64_t circuit_seed,
   for (int t = 0; t < N_TABLES; t++) {
     ptrs[2 + t] = (uint32_t)off;
     size_t bytes = counts[t] * (t == T_B2 ? 128 : 64);
-    if (bytes) ZKR_HIP_CHECK(hipMemcpy(o + off, g.d_tbl[t], bytes, hipMemcpyDeviceToHost));
+    if (bytes && hipMemcpy(o + off, g.d_tbl[t], bytes, hipMemcpyDeviceToHost) != hipSuccess) { free(o); set_error("download of key table %d failed", t); return ZKR_ERR_HIP; }
     off += bytes;
   }
   memcpy(o + ptr_at, ptrs, 28);
   if (off != size) { free(o); set_error("internal: websnark size mismatch"); return ZKR_ERR_ARG; }
   *pk_out = o;
   *pk_len = size;
+  return 0;
+}
+
+int zkr_synth_websnark(unsigned log_m, unsigned n_public, uint64_t circuit_seed, uint64_t toxic_seed, int device, void **pk_out, size_t *pk_len,
+                       void **witness_out, size_t *witness_len) {
+  if (!pk_out || !pk_len || !witness_out || !witness_len) { set_error("null argument"); return ZKR_ERR_ARG; }
+  Generated g;
+  int rc = generate(log_m, n_public, circuit_seed, toxic_seed, device, g);
+  if (!rc) rc = render_websnark(g, pk_out, pk_len);
+  if (rc) return rc;
   std::vector<uint8_t> wb;
-  to_std_bytes(c.w, wb);
+  to_std_bytes(g.circ.w, wb);
   *witness_out = malloc(wb.size());
   memcpy(*witness_out, wb.data(), wb.size());
   *witness_len = wb.size();

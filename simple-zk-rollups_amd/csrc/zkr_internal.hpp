@@ -113,6 +113,8 @@ struct zkr_key {
   unsigned char *arena = nullptr;
   size_t arena_len = 0;
   bool owns_arena = true;
+  unsigned char *base_arena = nullptr;  // compact form for replication (zkr_key_base_arena), built on first request
+  size_t base_arena_len = 0;
   zkr::ArenaHeader h;
   hipStream_t stream = nullptr;
   hipStream_t prep_stream = nullptr;               // digit records, digit sorts, calcH

@@ -499,6 +499,7 @@ void zkr_key_free(zkr_key *k) {
   for (hipStream_t st : streams)
     if (st) hipStreamDestroy(st);
   if (k->owns_arena) hipFree(k->arena);
+  if (k->base_arena) hipFree(k->base_arena);
   delete k;
 }
 
@@ -537,6 +538,135 @@ int zkr_key_adopt_arena(void *dev_ptr, size_t len, int device, zkr_key **out) {
   k->arena = (unsigned char *)dev_ptr;
   k->arena_len = len;
   k->owns_arena = false;
+  k->h = h;
+  int rc = key_alloc_workspace(k);
+  if (rc) { zkr_key_free(k); return rc; }
+  *out = k;
+  return 0;
+}
+
+// ---- compact form of the arena for replication over slow links: header + CSR rows + LEVEL 0 of every
+// point table + rank maps; the window levels 1..K-1 (12/13 of the arena) and the twiddle tables are rebuilt by the
+// receiver (msm_precompute_kernel, twiddle_table_kernel).  Same ArenaHeader with BASE_MAGIC and offsets of the compact
+// layout; win_c / npts / share flags carry over so the rebuilt arena is byte-identical to the sender's.
+constexpr uint64_t BASE_MAGIC = 0x32304245534b525aull;  // "ZRKSEB02"-ish tag: distinct from ARENA_MAGIC
+
+static void base_layout(const ArenaHeader &full, ArenaHeader &b) {
+  b = full;
+  b.magic = BASE_MAGIC;
+  size_t off = ARENA_HEADER_BYTES;
+  auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return (uint64_t)o; };
+  b.off_tw = b.off_twl = 0;
+  for (int s = 0; s < 2; s++) {
+    uint32_t nnz = s == 0 ? full.nnzA : full.nnzB;
+    b.off_rowptr[s] = take(((size_t)full.m + 1) * 4);
+    b.off_col[s] = take((size_t)nnz * 4 + 4);
+    b.off_coef[s] = take((size_t)nnz * 32 + 32);
+    b.off_wide[s] = take((size_t)full.n_wide[s] * 4 + 4);
+  }
+  for (int t = 0; t < N_TABLES; t++) {
+    size_t pb = t == T_B2 ? 128 : 64;
+    b.off_pts[t] = take((size_t)full.npts[t] * pb + pb);
+    b.off_rank[t] = take((size_t)(t == T_H ? full.m : full.n) * 4 + 4);
+  }
+  b.total_len = off;
+}
+
+int zkr_key_base_arena(zkr_key *k, void **dev_ptr, size_t *len) {
+  if (!k || !dev_ptr || !len) { set_error("null argument"); return ZKR_ERR_ARG; }
+  ZKR_HIP_CHECK(hipSetDevice(k->device));
+  std::lock_guard<std::mutex> lk(k->mu);
+  if (!k->base_arena) {
+    ArenaHeader b;
+    base_layout(k->h, b);
+    unsigned char *buf = nullptr;
+    ZKR_HIP_CHECK(hipMalloc(&buf, b.total_len));
+    auto cp = [&](uint64_t dst, uint64_t src, size_t bytes) { return bytes ? hipMemcpy(buf + dst, k->arena + src, bytes, hipMemcpyDeviceToDevice) : hipSuccess; };
+    hipError_t e = hipMemset(buf, 0, b.total_len);
+    if (e == hipSuccess) e = hipMemcpy(buf, &b, sizeof(b), hipMemcpyHostToDevice);
+    for (int s = 0; s < 2 && e == hipSuccess; s++) {
+      uint32_t nnz = s == 0 ? k->h.nnzA : k->h.nnzB;
+      e = cp(b.off_rowptr[s], k->h.off_rowptr[s], ((size_t)k->h.m + 1) * 4);
+      if (e == hipSuccess) e = cp(b.off_col[s], k->h.off_col[s], (size_t)nnz * 4);
+      if (e == hipSuccess) e = cp(b.off_coef[s], k->h.off_coef[s], (size_t)nnz * 32);
+      if (e == hipSuccess) e = cp(b.off_wide[s], k->h.off_wide[s], (size_t)k->h.n_wide[s] * 4);
+    }
+    for (int t = 0; t < N_TABLES && e == hipSuccess; t++) {
+      e = cp(b.off_pts[t], k->h.off_pts[t], (size_t)k->h.npts[t] * (t == T_B2 ? 128 : 64));
+      if (e == hipSuccess) e = cp(b.off_rank[t], k->h.off_rank[t], (size_t)(t == T_H ? k->h.m : k->h.n) * 4);
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) { hipFree(buf); set_error("building the compact arena failed: %s", hipGetErrorString(e)); return ZKR_ERR_HIP; }
+    k->base_arena = buf;
+    k->base_arena_len = b.total_len;
+  }
+  *dev_ptr = k->base_arena;
+  *len = k->base_arena_len;
+  return 0;
+}
+
+int zkr_key_adopt_base_arena(const void *dev_ptr, size_t len, int device, zkr_key **out) {
+  if (!dev_ptr || !out) { set_error("null argument"); return ZKR_ERR_ARG; }
+  if (zkr_device_count() <= device || device < 0) { set_error("no HIP device %d", device); return ZKR_ERR_NO_DEVICE; }
+  ZKR_HIP_CHECK(hipSetDevice(device));
+  if (len < ARENA_HEADER_BYTES) { set_error("compact arena too small"); return ZKR_ERR_BAD_KEY; }
+  ArenaHeader b;
+  ZKR_HIP_CHECK(hipMemcpy(&b, dev_ptr, sizeof(b), hipMemcpyDeviceToHost));
+  if (b.magic != BASE_MAGIC || b.total_len != len) { set_error("compact arena header mismatch (magic/len)"); return ZKR_ERR_BAD_KEY; }
+  // the full layout, exactly as key_build lays it out
+  ArenaHeader h = b;
+  h.magic = ARENA_MAGIC;
+  size_t off = ARENA_HEADER_BYTES;
+  auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return (uint64_t)o; };
+  h.off_tw = take((size_t)h.m * 32);
+  h.off_twl = take((size_t)(1u << TWL_LOG) * 32);
+  for (int s = 0; s < 2; s++) {
+    uint32_t nnz = s == 0 ? h.nnzA : h.nnzB;
+    h.off_rowptr[s] = take(((size_t)h.m + 1) * 4);
+    h.off_col[s] = take((size_t)nnz * 4 + 4);
+    h.off_coef[s] = take((size_t)nnz * 32 + 32);
+    h.off_wide[s] = take((size_t)h.n_wide[s] * 4 + 4);
+  }
+  MsmPlan plan[N_TABLES];
+  for (int t = 0; t < N_TABLES; t++) {
+    if (h.win_c[t] < 2 || h.win_c[t] > 26) { set_error("compact arena: bad window size"); return ZKR_ERR_BAD_KEY; }
+    plan[t] = msm_plan(t == T_H ? h.m : h.n, h.npts[t], (int)h.win_c[t]);
+    size_t pb = t == T_B2 ? 128 : 64;
+    h.off_pts[t] = take((size_t)h.npts[t] * plan[t].K * pb + pb);
+    h.off_rank[t] = take((size_t)(t == T_H ? h.m : h.n) * 4 + 4);
+  }
+  h.total_len = off;
+  unsigned char *arena = nullptr;
+  ZKR_HIP_CHECK(hipMalloc(&arena, off));
+  const unsigned char *src = (const unsigned char *)dev_ptr;
+  auto cp = [&](uint64_t dst, uint64_t from, size_t bytes) { return bytes ? hipMemcpy(arena + dst, src + from, bytes, hipMemcpyDeviceToDevice) : hipSuccess; };
+  hipError_t e = hipMemcpy(arena, &h, sizeof(h), hipMemcpyHostToDevice);
+  for (int s = 0; s < 2 && e == hipSuccess; s++) {
+    uint32_t nnz = s == 0 ? h.nnzA : h.nnzB;
+    e = cp(h.off_rowptr[s], b.off_rowptr[s], ((size_t)h.m + 1) * 4);
+    if (e == hipSuccess) e = cp(h.off_col[s], b.off_col[s], (size_t)nnz * 4);
+    if (e == hipSuccess) e = cp(h.off_coef[s], b.off_coef[s], (size_t)nnz * 32);
+    if (e == hipSuccess) e = cp(h.off_wide[s], b.off_wide[s], (size_t)h.n_wide[s] * 4);
+  }
+  for (int t = 0; t < N_TABLES && e == hipSuccess; t++) {
+    e = cp(h.off_pts[t], b.off_pts[t], (size_t)h.npts[t] * (t == T_B2 ? 128 : 64));
+    if (e == hipSuccess) e = cp(h.off_rank[t], b.off_rank[t], (size_t)(t == T_H ? h.m : h.n) * 4);
+  }
+  if (e != hipSuccess) { hipFree(arena); set_error("unpacking the compact arena failed: %s", hipGetErrorString(e)); return ZKR_ERR_HIP; }
+  for (int t = 0; t < N_TABLES; t++) {
+    int rc = msm_precompute(device, t == T_B2, arena + h.off_pts[t], h.npts[t], plan[t]);
+    if (rc) { hipFree(arena); return rc; }
+  }
+  twiddle_table_kernel<<<(h.m + 255) / 256, 256>>>((Fr *)(arena + h.off_tw), h.m, fr_root_of_unity(h.logm + 1));
+  twiddle_table_kernel<<<((1u << TWL_LOG) + 255) / 256, 256>>>((Fr *)(arena + h.off_twl), 1u << TWL_LOG, fr_root_of_unity(TWL_LOG + 1));
+  e = hipGetLastError();
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e != hipSuccess) { hipFree(arena); set_error("rebuilding the window tables failed: %s", hipGetErrorString(e)); return ZKR_ERR_HIP; }
+  zkr_key *k = new zkr_key();
+  k->device = device;
+  k->arena = arena;
+  k->arena_len = off;
+  k->owns_arena = true;
   k->h = h;
   int rc = key_alloc_workspace(k);
   if (rc) { zkr_key_free(k); return rc; }

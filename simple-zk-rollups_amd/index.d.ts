@@ -67,3 +67,12 @@ export class WithdrawCircuit {
   calculateWitness(circuitInputs: { privateKey: bigint | string; nullifier: bigint | string }): ArrayBuffer;
   publicSignals(witnessBin: ArrayBuffer): bigint[];
 }
+
+// ---- process-level key cache (the reference builds a new Bn128 per proof: common.ts:23) and verifier constants
+/** Device keys loaded / found in the cache by groth16GenProof so far in this process. */
+export function keyCacheStats(): { loads: number; hits: number; entries: number };
+export function clearKeyCache(): void;
+/** vk_bin -> the constants of the generated verifier's verifyingKey() in the contract's encoding (G2 as [im, re]). */
+export function solidityVerifyingKey(vkBin: Uint8Array): { alfa1: string[]; beta2: string[][]; gamma2: string[][]; delta2: string[][]; IC: string[][] };
+/** The Solidity statements of verifyingKey() for those constants (what `snarkjs generateverifier` emits). */
+export function solidityVerifyingKeySource(vkBin: Uint8Array, indent?: string): string;

@@ -46,26 +46,50 @@ function bigintToLe32(v) {
 // snarkjs would reduce mod r, the chain refuses: the facade sides with the chain)
 const signalsInRange = (ps) => ps.every((x) => { const v = BigInt(x); return v >= 0n && v < R; });
 
-function keyFingerprint(buf) {
-  // cheap identity for the per-instance key cache: length + FNV-1a of the header and the tail
+function keyFingerprint(device, buf) {
+  // identity of a provingKeyBin: device, length, SHA-256 of the first and last 4 KiB (the header carries alfa / beta /
+  // delta of the setup, the tail the last hExps points: two setups never share them)
   const u8 = buf instanceof ArrayBuffer ? new Uint8Array(buf) : new Uint8Array(buf.buffer, buf.byteOffset, buf.byteLength);
-  let h = 0x811c9dc5;
-  const mix = (b) => { h ^= b; h = Math.imul(h, 0x01000193) >>> 0; };
   const n = u8.length;
-  for (let i = 0; i < Math.min(n, 4096); i++) mix(u8[i]);
-  for (let i = Math.max(0, n - 4096); i < n; i++) mix(u8[i]);
-  return n + ":" + h;
+  const h = require("crypto").createHash("sha256");
+  h.update(u8.subarray(0, Math.min(n, 4096)));
+  h.update(u8.subarray(Math.max(0, n - 4096), n));
+  return device + ":" + n + ":" + h.digest("hex");
 }
+
+// Process-level cache of device keys (SURVEY.md 8(b) "Ownership").  The reference builds a NEW object for every proof
+// (`await buildBn128()` at operator/src/snarks/common.ts:23 and scripts/index.js:40) and passes it the same
+// provingKeyBin again (common.ts:28): a cache on the object would re-parse, re-upload and rebuild the window tables on
+// every call.  Least recently used of KEY_CACHE_SLOTS entries is dropped (its device memory goes with the handle).
+const KEY_CACHE_SLOTS = 2;
+const keyCache = new Map();  // fingerprint -> native key handle, in recency order
+const keyCacheStats = { loads: 0, hits: 0 };
+function cachedKey(provingKeyBin, device) {
+  const fp = keyFingerprint(device, provingKeyBin);
+  let key = keyCache.get(fp);
+  if (key !== undefined) {
+    keyCache.delete(fp);  // re-insert: most recently used last
+    keyCacheStats.hits++;
+  } else {
+    key = native().keyLoad(provingKeyBin, device);
+    keyCacheStats.loads++;
+  }
+  keyCache.set(fp, key);
+  while (keyCache.size > KEY_CACHE_SLOTS) keyCache.delete(keyCache.keys().next().value);
+  return key;
+}
+function clearKeyCache() { keyCache.clear(); }
 
 class Bn128 {
   constructor(device) { this.device = device || 0; this._fp = null; this._key = null; }
 
-  // websnark signature.  The reference re-parses the key on every call (common.ts:28-29); here the parsed,
-  // uploaded key is kept while the same buffer keeps arriving.  opts.r / opts.s (BigInt|string) fix the blinding.
+  // websnark signature.  The reference re-encodes and re-parses the key on every call (common.ts:28-29), on a fresh
+  // object (common.ts:23); here the parsed, uploaded key is looked up in the process-level cache above, so only the
+  // first proof of a key in a process pays for it.  opts.r / opts.s (BigInt|string) fix the blinding.
   async groth16GenProof(witnessBin, provingKeyBin, opts) {
     const a = native();
-    const fp = keyFingerprint(provingKeyBin);
-    if (fp !== this._fp) { this._key = a.keyLoad(provingKeyBin, this.device); this._fp = fp; }
+    this._key = cachedKey(provingKeyBin, this.device);
+    this._fp = "websnark";
     const r = opts && opts.r !== undefined ? bigintToLe32(opts.r) : null;
     const s = opts && opts.s !== undefined ? bigintToLe32(opts.s) : null;
     const pb = await a.prove(this._key, witnessBin, r, s);
@@ -183,6 +207,30 @@ function binarifyR1cs(cd) {
       for (const k of keys) { u32(k); parts.push(bigintToLe32(((BigInt(lc[k]) % R) + R) % R)); }
     }
   return Buffer.concat(parts);
+}
+
+// vk_bin -> the constants of the generated verifier's `verifyingKey()` in the contract's own encoding
+// (contracts/contracts/TxVerifier.sol:176-257): G1 as [x, y], G2 as [[x.im, x.re], [y.im, y.re]] (the EVM precompile order of
+// TxVerifier.sol:18-22, the reverse of the snarkjs JSON) -- what `snarkjs generateverifier` (prover/package.json:35,38)
+// pastes into TxVerifier.sol after a new setup (SURVEY 8(f-2)).
+function solidityVerifyingKey(vk) {
+  const rd = (o) => leBytesToDecimal(vk, o);
+  const g1 = (o) => [rd(o), rd(o + 32)];
+  const g2 = (o) => [[rd(o + 32), rd(o)], [rd(o + 96), rd(o + 64)]];
+  const nic = vk.readUInt32LE(448);
+  if (vk.length !== 452 + 64 * nic) throw new Error("vk_bin length does not match its IC count");
+  const IC = [];
+  for (let i = 0; i < nic; i++) IC.push(g1(452 + 64 * i));
+  return { alfa1: g1(0), beta2: g2(64), gamma2: g2(192), delta2: g2(320), IC };
+}
+// the statements of `function verifyingKey()` for these constants
+function solidityVerifyingKeySource(vk, indent) {
+  const k = solidityVerifyingKey(vk), ind = indent === undefined ? "        " : indent;
+  const g1 = (p) => `Pairing.G1Point(${p[0]},${p[1]})`;
+  const g2 = (p) => `Pairing.G2Point([${p[0][0]},${p[0][1]}], [${p[1][0]},${p[1][1]}])`;
+  const lines = [`vk.alfa1 = ${g1(k.alfa1)};`, `vk.beta2 = ${g2(k.beta2)};`, `vk.gamma2 = ${g2(k.gamma2)};`, `vk.delta2 = ${g2(k.delta2)};`,
+    `vk.IC = new Pairing.G1Point[](${k.IC.length});`].concat(k.IC.map((p, i) => `vk.IC[${i}] = ${g1(p)};`));
+  return lines.map((l) => ind + l + "\n").join("");
 }
 
 function verifyingKeyFromBytes(vk) {
@@ -317,7 +365,8 @@ class WithdrawCircuit {
 
 module.exports = {
   buildBn128, genProof, binarifyWitness, binarifyProvingKey, solidityProof, proofFromBytes, isValid, isValidBatch, binarifyVerifyingKey,
-  binarifyR1cs, verifyingKeyFromBytes,
+  binarifyR1cs, verifyingKeyFromBytes, solidityVerifyingKey, solidityVerifyingKeySource,
+  keyCacheStats: () => Object.assign({ entries: keyCache.size }, keyCacheStats), clearKeyCache,
   multiHash, multiHashBatch, buildBalanceTree, hashLeftRight, genPublicKey, formatPrivKeyForBabyJub, sign, verify, RollupCircuit, WithdrawCircuit,
   deviceCount: () => { native(); return deviceCount; },
   version: () => native().version(),

@@ -39,22 +39,36 @@ def _tensor_from_ptr(ptr, nbytes, device):
         return torch.as_tensor(_CudaArray(ptr, nbytes), device=torch.device("cuda", device))
 
 
-def broadcast_key(key, rank, world, device, dist=None):
-    """rank 0 holds `key`; every other rank receives the arena bytes and adopts them
-    (zkr_key_adopt_arena).  Returns a ProvingKey on every rank (rank 0: the same object)."""
+BCAST_MODES = ("full", "base")
+
+
+def broadcast_key(key, rank, world, device, dist=None, mode=None):
+    """rank 0 holds `key`; every other rank receives it over ONE broadcast and returns its own ProvingKey (rank 0: the
+    same object).  mode (default: env ZKR_BCAST_MODE or "full"):
+      "full"  the whole arena, window tables included (4.47 GB at 2^20): adopted in place (zkr_key_adopt_arena), nothing
+              is recomputed -- the right choice over xGMI (153 GB/s per link: ~30 ms);
+      "base"  the compact arena (base points + QAP rows, 0.45 GB): the receiver rebuilds the window levels and twiddles
+              (zkr_key_adopt_base_arena, ~0.25 s at 2^20) -- for links slower than ~15 GB/s (PCIe peer copies, a
+              host-staged backend) where ten times fewer bytes outweigh the rebuild."""
+    import os
     from .binding import ProvingKey
     if world == 1:
         return key
+    mode = mode or os.environ.get("ZKR_BCAST_MODE", "full")
+    if mode not in BCAST_MODES:
+        raise ValueError("unknown key broadcast mode %r (use one of %r)" % (mode, BCAST_MODES))
     if dist is None:
         import torch.distributed as dist
     dev = torch.device("cuda", device)
     if rank == 0:
-        ptr, length = key.arena()
+        ptr, length = key.arena() if mode == "full" else key.base_arena()
         broadcast_arena(_tensor_from_ptr(ptr, length, device), 0, dist, dev)
         return key
     buf = broadcast_arena(None, rank, dist, dev)
     torch.cuda.synchronize(dev)
-    return ProvingKey.adopt_arena(buf.data_ptr(), buf.numel(), device, keepalive=buf)
+    if mode == "full":
+        return ProvingKey.adopt_arena(buf.data_ptr(), buf.numel(), device, keepalive=buf)
+    return ProvingKey.adopt_base_arena(buf.data_ptr(), buf.numel(), device)
 
 
 def prove_batch(key, witnesses, blinding, rank=0, world=1):

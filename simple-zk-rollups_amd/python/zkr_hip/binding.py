@@ -39,6 +39,8 @@ def lib():
     L.zkr_key_windows.argtypes = [vp, c.POINTER(c.c_uint32), c.POINTER(c.c_uint32)]
     L.zkr_key_arena.argtypes = [vp, c.POINTER(vp), c.POINTER(sz)]
     L.zkr_key_adopt_arena.argtypes = [vp, sz, i, c.POINTER(vp)]
+    L.zkr_key_base_arena.argtypes = [vp, c.POINTER(vp), c.POINTER(sz)]
+    L.zkr_key_adopt_base_arena.argtypes = [vp, sz, i, c.POINTER(vp)]
     L.zkr_prove.argtypes = [vp, u8p, sz, u8p, u8p, u8p, vp]
     L.zkr_prove_device.argtypes = [vp, vp, u8p, u8p, u8p, vp]
     L.zkr_prove_submit.argtypes = [vp, vp, u8p, u8p, vp, c.POINTER(i)]
@@ -59,6 +61,7 @@ def lib():
                                      c.POINTER(vp), c.POINTER(sz)]
     L.zkr_synth_witness.argtypes = [c.c_uint, c.c_uint, c.c_uint64, c.c_uint64, c.POINTER(vp), c.POINTER(sz)]
     L.zkr_setup_r1cs.argtypes = [u8p, sz, u8p, i, c.POINTER(vp), c.POINTER(vp), c.POINTER(sz)]
+    L.zkr_setup_r1cs_websnark.argtypes = [u8p, sz, u8p, i, c.POINTER(vp), c.POINTER(sz), c.POINTER(vp), c.POINTER(sz)]
     L.zkr_synth_vk.argtypes = [vp, u8p, sz, c.POINTER(vp), c.POINTER(sz)]
     L.zkr_synth_set_shape.argtypes = [c.c_uint]
     L.zkr_free.argtypes = [vp]
@@ -132,6 +135,13 @@ class ProvingKey:
         return cls(h, device, keepalive)
 
     @classmethod
+    def adopt_base_arena(cls, dev_ptr, length, device):
+        """Full key rebuilt on `device` from the compact arena bytes (zkr_key_adopt_base_arena); the buffer is not kept."""
+        h = ctypes.c_void_p()
+        _check(lib().zkr_key_adopt_base_arena(ctypes.c_void_p(dev_ptr), length, device, ctypes.byref(h)))
+        return cls(h, device)
+
+    @classmethod
     def setup_r1cs(cls, r1cs_bin: bytes, toxic=None, device=0):
         """Groth16 setup of an R1CS on the GPU (zkr_setup_r1cs; `snarkjs setup --protocol groth`).  toxic: None (OS
         CSPRNG) or five ints (t, alfa, beta, gamma, delta) for reproducible tests.  Returns (key, vk_bin)."""
@@ -173,6 +183,12 @@ class ProvingKey:
     def arena(self):
         p, n = ctypes.c_void_p(), ctypes.c_size_t()
         _check(lib().zkr_key_arena(self._h, ctypes.byref(p), ctypes.byref(n)))
+        return p.value, n.value
+
+    def base_arena(self):
+        """(device pointer, length) of the compact arena: base points + QAP rows, no window levels (zkr_key_base_arena)."""
+        p, n = ctypes.c_void_p(), ctypes.c_size_t()
+        _check(lib().zkr_key_base_arena(self._h, ctypes.byref(p), ctypes.byref(n)))
         return p.value, n.value
 
     def prove(self, witness: bytes, r=None, s=None, stream=None) -> bytes:
@@ -333,6 +349,16 @@ def synth_websnark(log_m, n_public, circuit_seed, toxic_seed, device=0):
     _check(lib().zkr_synth_websnark(log_m, n_public, circuit_seed, toxic_seed, device, ctypes.byref(p), ctypes.byref(pl),
                                     ctypes.byref(w), ctypes.byref(wl)))
     return _take(p, pl.value), _take(w, wl.value)
+
+
+def setup_r1cs_websnark(r1cs_bin: bytes, toxic=None, device=0):
+    """zkr_setup_r1cs_websnark: Groth16 setup of an R1CS on the GPU, key returned as (provingKeyBin, vk_bin) -- the
+    buffer `binarifyProvingKey` would write for the reference's unchanged caller."""
+    tb = None if toxic is None else b"".join(int(x).to_bytes(32, "little") for x in toxic)
+    pk, vk = ctypes.c_void_p(), ctypes.c_void_p()
+    pl, vl = ctypes.c_size_t(), ctypes.c_size_t()
+    _check(lib().zkr_setup_r1cs_websnark(bytes(r1cs_bin), len(r1cs_bin), tb, device, ctypes.byref(pk), ctypes.byref(pl), ctypes.byref(vk), ctypes.byref(vl)))
+    return _take(pk, pl.value), _take(vk, vl.value)
 
 
 def synth_witness(log_m, n_public, circuit_seed, witness_seed):

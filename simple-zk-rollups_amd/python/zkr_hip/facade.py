@@ -5,6 +5,10 @@ websnark surface it uses (buildBn128().groth16GenProof, common.ts:23,29).  Same 
 meaning and error behaviour; circuit compilation and witness calculation (common.ts:12-21) stay
 with the caller, as the north-star leaves them unchanged.
 """
+import collections
+import hashlib
+import threading
+
 from .binding import ProvingKey, ZkrError
 
 SNARK_FIELD_SIZE = 21888242871839275222246405745257275088548364400416034343698204186575808495617
@@ -59,6 +63,32 @@ def verifying_key_from_bytes(vk_bin: bytes):
             "IC": [g1(452 + 64 * i) for i in range(nic)]}
 
 
+def solidity_verifying_key(vk_bin: bytes):
+    """vk_bin -> the constants of the generated verifier contract's `verifyingKey()` in the contract's own encoding
+    (contracts/contracts/TxVerifier.sol:176-257): G1 as [x, y]; G2 as [[x.im, x.re], [y.im, y.re]] -- the EVM precompile
+    order of TxVerifier.sol:18-22, the reverse of the snarkjs JSON -- decimal strings.  The tail of SURVEY 8(f-2): what
+    `snarkjs generateverifier` (prover/package.json:35,38) pastes into TxVerifier.sol for a new setup."""
+    rd = lambda o: str(int.from_bytes(vk_bin[o:o + 32], "little"))
+    g1 = lambda o: [rd(o), rd(o + 32)]
+    g2 = lambda o: [[rd(o + 32), rd(o)], [rd(o + 96), rd(o + 64)]]
+    nic = int.from_bytes(vk_bin[448:452], "little")
+    if len(vk_bin) != 452 + 64 * nic:
+        raise ValueError("vk_bin length does not match its IC count")
+    return {"alfa1": g1(0), "beta2": g2(64), "gamma2": g2(192), "delta2": g2(320), "IC": [g1(452 + 64 * i) for i in range(nic)]}
+
+
+def solidity_verifying_key_source(vk_bin: bytes, indent="        ") -> str:
+    """The statements of `function verifyingKey()` for these constants (assignment per constant, IC array sized
+    nPublic + 1), ready to replace TxVerifier.sol:177-255 / the same lines of WithdrawVerifier.sol after a new setup."""
+    k = solidity_verifying_key(vk_bin)
+    g1 = lambda p: "Pairing.G1Point(%s,%s)" % (p[0], p[1])
+    g2 = lambda p: "Pairing.G2Point([%s,%s], [%s,%s])" % (p[0][0], p[0][1], p[1][0], p[1][1])
+    lines = ["vk.alfa1 = %s;" % g1(k["alfa1"]), "vk.beta2 = %s;" % g2(k["beta2"]), "vk.gamma2 = %s;" % g2(k["gamma2"]),
+             "vk.delta2 = %s;" % g2(k["delta2"]), "vk.IC = new Pairing.G1Point[](%d);" % len(k["IC"])]
+    lines += ["vk.IC[%d] = %s;" % (i, g1(p)) for i, p in enumerate(k["IC"])]
+    return "".join(indent + ln + "\n" for ln in lines)
+
+
 def proof_bytes_from_json(proof) -> bytes:
     """Inverse of proof_json_from_bytes."""
     le = lambda v: int(v).to_bytes(32, "little")
@@ -79,21 +109,53 @@ def is_valid(verifying_key, proof, public_signals) -> bool:
     return verify(binarify_verifying_key(verifying_key), pb, signals)
 
 
+# Process-level cache of device keys (SURVEY.md 8(b) "Ownership").  The reference builds a NEW object for every proof
+# (`await buildBn128()` at common.ts:23, scripts/index.js:40) and hands it the same provingKeyBin again (common.ts:28),
+# so a cache on the object would re-parse, re-upload and rebuild the window tables on every call.  Keyed by
+# (device, length, digest of the first and last 4 KiB: header with alfa/beta/delta of the setup + the tail of hExps);
+# least recently used of KEY_CACHE_SLOTS entries is dropped (its device memory is freed when no proof uses it).
+KEY_CACHE_SLOTS = 2
+_key_cache = collections.OrderedDict()
+_key_cache_lock = threading.Lock()
+key_cache_stats = {"loads": 0, "hits": 0}
+
+
+def _key_fingerprint(device, buf):
+    head, tail = bytes(buf[:4096]), bytes(buf[-4096:])
+    return (device, len(buf), hashlib.blake2b(head + tail, digest_size=16).digest())
+
+
+def cached_key(proving_key_bin, device=0):
+    """The device key for this provingKeyBin: parsed and uploaded on first sight, reused afterwards by every Bn128."""
+    fp = _key_fingerprint(device, proving_key_bin)
+    with _key_cache_lock:
+        key = _key_cache.get(fp)
+        if key is not None:
+            _key_cache.move_to_end(fp)
+            key_cache_stats["hits"] += 1
+            return key
+        key = ProvingKey.load_websnark(proving_key_bin, device)
+        key_cache_stats["loads"] += 1
+        _key_cache[fp] = key
+        while len(_key_cache) > KEY_CACHE_SLOTS:
+            _key_cache.popitem(last=False)   # the ProvingKey frees its arena when the last reference goes
+        return key
+
+
+def clear_key_cache():
+    with _key_cache_lock:
+        _key_cache.clear()
+
+
 class Bn128:
     """What `await buildBn128()` returns; only groth16GenProof is used by the reference."""
 
     def __init__(self, device=0):
         self.device = device
-        self._cache = {}
 
     def groth16GenProof(self, witness_bin: bytes, proving_key_bin: bytes, r=None, s=None):
-        # the reference re-parses the key on every call (common.ts:28-29); cache the device key by buffer identity
-        ck = (len(proving_key_bin), hash(bytes(proving_key_bin[:4096])), hash(bytes(proving_key_bin[-4096:])))
-        key = self._cache.get(ck)
-        if key is None:
-            key = ProvingKey.load_websnark(proving_key_bin, self.device)
-            self._cache = {ck: key}
-        return proof_json_from_bytes(key.prove(witness_bin, r, s))
+        # the reference re-encodes and re-parses the key on every call (common.ts:28-29) on a fresh object (:23)
+        return proof_json_from_bytes(cached_key(proving_key_bin, self.device).prove(witness_bin, r, s))
 
 
 def build_bn128(device=0):

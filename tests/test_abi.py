@@ -236,3 +236,34 @@ def test_native_verifier_rejects_twist_points_outside_the_r_torsion(small_case):
                 zkr_hip.verify(vkb[:off] + enc + vkb[off + 128:], pb, pub)
     # the subgroup's own points still pass: the key's gamma2 used as proof.B is on the twist AND in G2 (verdict False, no error)
     assert zkr_hip.verify(vkb, pb[:64] + vkb[192:320] + pb[192:], pub) is False
+
+
+def test_solidity_verifier_constants_round_trip_the_reference_contracts():
+    """SURVEY 8(f-2) tail, pinned on the reference's own vectors both ways: the verifying-key constants of
+    contracts/contracts/TxVerifier.sol:177-255 and WithdrawVerifier.sol (tests/golden/verifier_points.json, Solidity limb
+    order [im, re]) -> vk_bin -> solidity_verifying_key() gives back exactly those constants, and the emitted
+    `verifyingKey()` statements parse back to them too (the regular expressions of tests/golden/make_verifier_points.py)."""
+    import json
+    import zkr_hip
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "verifier_points.json")))
+    for name, c in fx["contracts"].items():
+        n = int(c["n_inputs"])
+        to_js = lambda k: ((int(c["g2"][k][0][1]), int(c["g2"][k][0][0])), (int(c["g2"][k][1][1]), int(c["g2"][k][1][0])))  # [im, re] -> (re, im)
+        ic_names = ["IC[%d]" % i for i in range(n + 1)]
+        vk = dict(vk_alfa_1=[int(v) for v in c["g1"]["alfa1"]], vk_beta_2=to_js("beta2"), vk_gamma_2=to_js("gamma2"), vk_delta_2=to_js("delta2"),
+                  IC=[[int(v) for v in c["g1"][k]] for k in ic_names])
+        vkb = zkr_hip.binarify_verifying_key(vk)
+        sol = zkr_hip.solidity_verifying_key(vkb)
+        assert sol["alfa1"] == c["g1"]["alfa1"] and sol["IC"] == [c["g1"][k] for k in ic_names]
+        for k in ("beta2", "gamma2", "delta2"):
+            assert sol[k] == c["g2"][k], (name, k)
+        # and through the JSON form the product hands to the reference's tooling
+        assert zkr_hip.binarify_verifying_key(zkr_hip.verifying_key_from_bytes(vkb)) == vkb
+        src = zkr_hip.solidity_verifying_key_source(vkb)
+        g1 = re.findall(r"vk\.(alfa1|IC\[\d+\]) = Pairing\.G1Point\((\d+),\s*(\d+)\)", src)
+        g2 = re.findall(r"vk\.(beta2|gamma2|delta2) = Pairing\.G2Point\(\[(\d+),\s*(\d+)\], \[(\d+),\s*(\d+)\]\)", src)
+        assert {k: [x, y] for k, x, y in g1} == c["g1"]
+        assert {k: [[a, b], [cc, d]] for k, a, b, cc, d in g2} == c["g2"]
+        assert "vk.IC = new Pairing.G1Point[](%d);" % (n + 1) in src
+    with pytest.raises(ValueError):
+        zkr_hip.solidity_verifying_key(vkb[:-1])

@@ -22,6 +22,9 @@ def test_fullsize_proof_equals_closed_form_and_verifies(log_m):
     proof = key.prove(wb, r, s)
     expect, vk, pub = g.proof_from_aux(aux, wb, p, r, s)
     assert proof == g.proof_bytes(expect)
+    if log_m == 16:  # the closed form with the C dot products (used at 2^24, tests/test_gpu_configs.py) is the same function
+        import coracle
+        assert g.proof_from_aux(aux, wb, p, r, s, dot=coracle.fr_dot) == (expect, vk, pub)
     assert g.is_valid(vk, _proof_points(proof), pub)
     bad = list(pub)
     bad[3] = (bad[3] + 1) % g.R

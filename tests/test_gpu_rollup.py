@@ -48,6 +48,43 @@ def test_tx_circuit_proof_matches_closed_form_and_verifies():
     assert zkr_hip.verify(vk_bin, p2, c.public_signals(wb2)) and not zkr_hip.verify(vk_bin, p2, pub)
 
 
+def test_tx_circuit_through_the_websnark_buffer_like_the_unchanged_reference_caller():
+    """The reference's own data flow for its own circuit: setup (prover/package.json:34) -> provingKeyBin in the
+    binarify.ts:143-206 layout (zkr_setup_r1cs_websnark) -> createProofGenerator (common.ts:10-53) with a new Bn128
+    per proof -> proof == the device-key proof == the closed form, accepted by the verifier, Solidity-shaped output with
+    73 inputs (TxVerifier.sol:281)."""
+    import zkr_hip
+    from zkr_hip import rollup as n
+    c = n.RollupCircuit()
+    r1cs = c.r1cs()
+    tox = g.toxic_from_seed(0x5A4B00F3)
+    tl = [tox[k] for k in ("t", "alfa", "beta", "gamma", "delta")]
+    pkb, vk_bin = zkr_hip.setup_r1cs_websnark(r1cs, toxic=tl)
+    hdr = [int.from_bytes(pkb[4 * i:4 * i + 4], "little") for i in range(10)]
+    assert hdr[0] == c.n_vars and hdr[1] == 73 and hdr[2] == 1 << 17 and hdr[3] == 488
+    assert len(pkb) == hdr[9] + 64 * hdr[2]                                  # binarify.ts:115-141 size formula, last section
+    key, vk_bin2 = zkr_hip.ProvingKey.setup_r1cs(r1cs, toxic=tl)
+    assert vk_bin2 == vk_bin
+    txs, tree, _ = scenario(2, 6, 41, n_accounts=5)
+    wb = c.calculate_witness(as_inputs(txs))
+    w = ints(wb)
+    rng = g.SplitMix64(99)
+    r, s = rng.fr(), rng.fr()
+    zkr_hip.clear_key_cache()
+    loads0 = zkr_hip.key_cache_stats["loads"]
+    gen = zkr_hip.create_proof_generator(pkb, zkr_hip.verifying_key_from_bytes(vk_bin), n_public=73)
+    out = gen(w, r, s)
+    out2 = gen(w, r, s)                                                        # the operator proves batch after batch
+    assert zkr_hip.key_cache_stats["loads"] - loads0 == 1
+    pb = zkr_hip.proof_bytes_from_json(out["proof"])
+    assert pb == key.prove(wb, r, s) and out2 == out
+    _, _, cons = parse_r1cs(r1cs)
+    assert pb == g.proof_bytes(g.proof_from_toxic(_circ_dict(c, cons), tox, w, r, s))
+    assert out["solidityProof"]["inputs"] == [str(v) for v in c.public_signals(wb)] and len(out["solidityProof"]["inputs"]) == 73
+    assert out["solidityProof"]["b"][0] == [out["proof"]["pi_b"][0][1], out["proof"]["pi_b"][0][0]]     # (im, re), TxVerifier.sol:18-22
+    zkr_hip.clear_key_cache()
+
+
 def test_batch_of_four_depth_five_like_the_reference_test():
     """prover/__tests__/batchprocesstx.test.ts:247-253 runs BatchProcessTx(4, 5); here with a proof on top
     (fresh toxic waste from the OS CSPRNG)."""

@@ -152,6 +152,21 @@ def test_error_paths(small_case):
         key.prove(c["wb"][:-32], 1, 2)
     with pytest.raises(zkr_hip.ZkrError):
         key.prove(c["wb"], R, 2)
+    # malformed section pointers must be refused before anything is read through them
+    pk = bytearray(c["pkb"])
+    def with_u32(off, v):
+        b = bytearray(pk)
+        b[off:off + 4] = int(v).to_bytes(4, "little")
+        return bytes(b)
+    for bad in (with_u32(16, len(pk) + 4096),        # polsB pointer past the buffer (the polsA scan would run off the end)
+                with_u32(16, 0xFFFFFFF0),
+                with_u32(16, 100),                   # before the fixed header
+                with_u32(20, len(pk) + 64),          # pointsA pointer past the buffer
+                with_u32(4, 0xFFFFFFFF),             # nPublic + 1 wraps around
+                with_u32(12, 484)):                  # polsA pointer
+        with pytest.raises(zkr_hip.ZkrError) as e:
+            zkr_hip.ProvingKey.load_websnark(bad)
+        assert e.value.code == -2
 
 
 @pytest.mark.parametrize("log_m,p", [(6, 5), (10, 7), (13, 73)])
@@ -229,6 +244,31 @@ def test_dense_random_shape_matches_oracle_generator():
     proof = key.prove(wb, r, s)
     assert proof == coracle.prove(pkb, wb, r, s) == g.proof_bytes(g.proof_from_toxic(circ, tox, circ["witness"], r, s))
     assert key2.prove(wb, r, s) == proof
+
+
+def test_reference_caller_pattern_new_object_per_proof_uses_the_process_cache(small_case):
+    """operator/src/snarks/common.ts:23-29 calls `buildBn128()` and `binarifyProvingKey()` for every proof: with the
+    process-level cache (facade.cached_key) only the first call loads the key; three keys rotate through two slots."""
+    import zkr_hip
+    c = small_case
+    zkr_hip.clear_key_cache()
+    before = dict(zkr_hip.key_cache_stats)
+    expect = zkr_hip.proof_json_from_bytes(coracle.prove(c["pkb"], c["wb"], c["r"], c["s"]))
+    for _ in range(3):
+        bn = zkr_hip.build_bn128()                                            # a fresh object per proof
+        assert bn.groth16GenProof(c["wb"], bytes(c["pkb"]), c["r"], c["s"]) == expect
+    assert zkr_hip.key_cache_stats["loads"] - before["loads"] == 1 and zkr_hip.key_cache_stats["hits"] - before["hits"] == 2
+    def other(k):                                                             # swap two hExps points: another (valid) key
+        b = bytearray(c["pkb"])
+        b[-64:], b[-64 * (k + 1):-64 * k] = b[-64 * (k + 1):-64 * k], b[-64:]
+        return bytes(b)
+    zkr_hip.groth16_gen_proof(c["wb"], other(1))
+    zkr_hip.groth16_gen_proof(c["wb"], other(2))                              # evicts the first key
+    zkr_hip.groth16_gen_proof(c["wb"], other(1))
+    assert zkr_hip.key_cache_stats["loads"] - before["loads"] == 3
+    assert zkr_hip.groth16_gen_proof(c["wb"], c["pkb"], r=c["r"], s=c["s"]) == expect
+    assert zkr_hip.key_cache_stats["loads"] - before["loads"] == 4
+    zkr_hip.clear_key_cache()
 
 
 def test_proof_facade_like_reference_tests(small_case):

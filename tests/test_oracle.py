@@ -159,6 +159,23 @@ def test_c_oracle_msm_calc_h_prove(small_case):
 
 
 # ---------------------------------------------------------------- (d) golden fixtures
+def test_c_oracle_all_threads_prover_and_dot_product(small_case):
+    """bench.py's all-host-threads CPU baseline (zo_prove_mt: OpenMP slices of the five multiexps, parallel NTT loops)
+    returns the bytes of the single-thread prover for every thread count, also on the golden fixture sizes; zo_fr_dot
+    (the closed form's dot products at 2^24) equals the Python sum."""
+    c = small_case
+    want = coracle.prove(c["pkb"], c["wb"], c["r"], c["s"])
+    for threads in (1, 2, 3, 8, 0):
+        got, tm = coracle.prove_mt(c["pkb"], c["wb"], c["r"], c["s"], threads=threads, want_timings=True)
+        assert got == want and tm[3] >= 1
+    assert coracle.max_threads() >= 1
+    rng = g.SplitMix64(31)
+    a = [rng.fr() for _ in range(1000)] + [0, R - 1, 1]
+    b = [rng.fr() for _ in range(1000)] + [5, R - 1, R - 1]
+    assert coracle.fr_dot(b"".join(_le(x) for x in a), b"".join(_le(x) for x in b)) == sum(x * y for x, y in zip(a, b)) % R
+    assert coracle.fr_dot(b"", b"") == 0
+
+
 @pytest.mark.parametrize("name", ["synth_m5.json", "synth_m7.json"])
 def test_golden_fixture_reproduces(name):
     fx = json.load(open(os.path.join(GOLD, name)))
