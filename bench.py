@@ -27,22 +27,37 @@ ADD_G2 = (10 * 400 + 2 * 272 + 656) / 136.0       # the same over Fq2           
 CIRCUIT_SEED, TOXIC_SEED, N_PUBLIC = 0x5A4B0001, 0x5A4B00FF, 73
 
 
-def cpu_baseline(sample_log_m, target_log_m):
-    """The C oracle (single thread) on a bounded sample of the same workload: same generator, smaller
-    domain; proofs/s scaled linearly in m to the benchmarked size (the algorithm is O(m log m) NTT +
-    O(m * 254/c) group operations, so linear scaling slightly favours the CPU)."""
+def cpu_baseline(sample_log_m, target_log_m, gpu_key=None):
+    """The C oracle (oracle/zkr_oracle.c) on the host cores of this box, on a key of the same generator (websnark
+    buffer rendered by the product, fed to the oracle's own parser): zo_prove on ONE thread and zo_prove_mt on ALL
+    hardware threads (OpenMP), both MEASURED at m = 2^sample_log_m -- by default the benchmarked size itself, so
+    nothing is extrapolated ("1 thread and all host threads at the real config sizes").  The two CPU
+    proofs and, when the sizes agree, the GPU proof for the same blinding must be the same bytes."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import coracle
     import zkr_hip
     pkb, wb = zkr_hip.synth_websnark(sample_log_m, N_PUBLIC, CIRCUIT_SEED, TOXIC_SEED, device=0)
+    r, s = 12345, 67890
     t0 = time.time()
-    _, tm = coracle.prove(pkb, wb, 12345, 67890, want_timings=True)
+    p1, tm = coracle.prove(pkb, wb, r, s, want_timings=True)
     dt = time.time() - t0
+    t0 = time.time()
+    pm, tmm = coracle.prove_mt(pkb, wb, r, s, threads=0, want_timings=True)
+    dtm = time.time() - t0
+    same = p1 == pm
+    if gpu_key is not None and sample_log_m == target_log_m:
+        same = same and gpu_key.prove(wb, r, s) == p1
     scale = 2.0 ** (target_log_m - sample_log_m)
+    how = "measured at m=2^%d (the benchmarked size, no extrapolation)" % sample_log_m if scale == 1.0 else \
+          "measured at m=2^%d, value = 1/(t * 2^%d) i.e. linearly scaled to m=2^%d" % (sample_log_m, target_log_m - sample_log_m, target_log_m)
     return {"value": 1.0 / (dt * scale), "unit": "proofs/s", "cores": 1, "kind": "port",
-            "sample": "oracle/zkr_oracle.c zo_prove, 1 thread, m=2^%d rollup-shaped key: %.2f s/proof (calcH %.2f s, MSM %.2f s); "
-                      "value = 1/(t * 2^%d) i.e. linearly scaled to m=2^%d" % (sample_log_m, dt, tm[0], tm[1],
-                                                                              target_log_m - sample_log_m, target_log_m)}
+            "sample": "oracle/zkr_oracle.c zo_prove, 1 thread, one proof of the rollup-shaped key: %.2f s (calcH %.2f s, MSM %.2f s); %s" % (dt, tm[0], tm[1], how),
+            "seconds_per_proof": dt * scale,
+            "all_threads": {"value": 1.0 / (dtm * scale), "unit": "proofs/s", "cores": int(tmm[3]), "kind": "port",
+                            "sample": "oracle/zkr_oracle.c zo_prove_mt (OpenMP: five multiexps cut into point slices, parallel NTT butterflies), %d threads, "
+                                      "same key and witness: %.2f s (calcH %.2f s, MSM %.2f s); %s" % (int(tmm[3]), dtm, tmm[0], tmm[1], how),
+                            "seconds_per_proof": dtm * scale},
+            "cpu_proofs_identical_to_each_other_and_to_the_gpu_proof": bool(same)}
 
 
 def cpu_baseline_js(sample_log_m, target_log_m):
@@ -92,6 +107,163 @@ def cpu_baseline_js(sample_log_m, target_log_m):
                       "(calculateH %.1f s, per-signal scalar multiplications %.1f s); value = 1/(t * 2^%d)"
                       % (subprocess.run([node, "--version"], capture_output=True, text=True).stdout.strip(), sample_log_m, sec["total"],
                          sec["h"], sec["msm"], target_log_m - sample_log_m)}
+
+
+class GpuSampler:
+    """Device clock (MHz) and board power (W) sampled from sysfs while the timed region runs (the sustained
+    clock under this integer load must be a recorded number, not an inference).  Sources, first that works:
+    hwmon freq1_input / power1_average|power1_input of the amdgpu device, pp_dpm_sclk's starred level, `rocm-smi`."""
+
+    def __init__(self, index=0, period=0.05):
+        import glob
+        import threading
+        self.period, self.samples, self._stop = period, [], threading.Event()
+        self.dev = None
+        try:  # the sysfs node of THIS HIP device (a node has eight GPUs, and more DRM cards than GPUs)
+            import zkr_hip
+            pci = zkr_hip.device_pci_bus_id(index).lower()
+            cand = "/sys/bus/pci/devices/" + pci
+            if os.path.isdir(cand):
+                self.dev = cand
+            self.pci = pci
+        except Exception:
+            self.pci = None
+        if self.dev is None:
+            cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))
+            cards = [c for c in cards if glob.glob(os.path.join(c, "hwmon/hwmon*/freq1_input"))]
+            self.dev = cards[index] if index < len(cards) else (cards[0] if cards else None)
+        self.hw = (glob.glob(os.path.join(self.dev, "hwmon/hwmon*")) or [None])[0] if self.dev else None
+        self.source = None
+        self._thread = threading.Thread(target=self._run, daemon=True)
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                return f.read()
+        except Exception:
+            return None
+
+    def _one(self):
+        mhz = watts = None
+        if self.hw:
+            v = self._read(os.path.join(self.hw, "freq1_input"))
+            if v and v.strip().isdigit():
+                mhz = int(v) / 1e6
+            for name in ("power1_average", "power1_input"):
+                v = self._read(os.path.join(self.hw, name))
+                if v and v.strip().isdigit():
+                    watts = int(v) / 1e6
+                    break
+        if mhz is None and self.dev:
+            v = self._read(os.path.join(self.dev, "pp_dpm_sclk"))
+            if v:
+                for ln in v.splitlines():
+                    if ln.strip().endswith("*"):
+                        try:
+                            mhz = float(ln.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
+                        except Exception:
+                            pass
+        return mhz, watts
+
+    def _run(self):
+        while not self._stop.is_set():
+            self.samples.append(self._one())
+            self._stop.wait(self.period)
+
+    def start(self):
+        mhz, watts = self._one()
+        self.source = "sysfs %s" % self.dev if (mhz is not None or watts is not None) else None
+        if self.source:
+            self._thread.start()
+        return self
+
+    def stop(self):
+        self._stop.set()
+        if self._thread.is_alive():
+            self._thread.join(1.0)
+        out = {"source": self.source, "pci_bus_id": getattr(self, "pci", None), "samples": len(self.samples)}
+        mh = [m for m, _ in self.samples if m]
+        pw = [w for _, w in self.samples if w]
+        if mh:
+            out.update(sclk_mhz_mean=sum(mh) / len(mh), sclk_mhz_min=min(mh), sclk_mhz_max=max(mh))
+        if pw:
+            out.update(power_w_mean=sum(pw) / len(pw), power_w_max=max(pw))
+        if not self.source:  # one-shot fallback outside sysfs: rocm-smi (slow, so not sampled during the region)
+            import shutil
+            import subprocess
+            smi = shutil.which("rocm-smi")
+            if smi:
+                try:
+                    txt = subprocess.run([smi, "--showclocks", "--showpower"], capture_output=True, text=True, timeout=20).stdout
+                    out["rocm_smi_after_region"] = [ln.strip() for ln in txt.splitlines() if "sclk" in ln.lower() or "power" in ln.lower()][:6]
+                except Exception as e:
+                    out["rocm_smi_error"] = str(e)
+        return out
+
+
+def dropin_leg(local, batch=2, depth=6):
+    """The reference's UNCHANGED calling pattern on its own circuit (operator/src/snarks/common.ts:23-29): for every
+    proof a new `buildBn128()` object, the provingKeyBin buffer handed over again, a pageable host witness.  First call =
+    parse + upload + window tables + proof; steady state = process-level key cache hit + proof."""
+    import zkr_hip
+    from zkr_hip import rollup
+    circ = rollup.RollupCircuit(batch, depth)
+    pkb, vk_bin = zkr_hip.setup_r1cs_websnark(circ.r1cs(), device=local)
+    privs = [0x5A4B1000 + 7919 * i for i in range(4)]
+    state = rollup.RollupState(circ.depth)
+    for i, pv in enumerate(privs):
+        state.deposit(i, rollup.gen_public_key(pv), 10 ** 20, 0)
+    txs = [state.transfer(j % 4, (j + 1) % 4, 10 ** 17, 10 ** 15, privs[j % 4]) for j in range(circ.batch)]
+    wb = circ.calculate_witness(circ.flatten_inputs(state.batch_inputs(txs)))
+    pub = circ.public_signals(wb)
+    zkr_hip.clear_key_cache()
+    loads0 = zkr_hip.key_cache_stats["loads"]
+    times, proofs = [], []
+    for i in range(8):
+        t0 = time.perf_counter()
+        bn = zkr_hip.build_bn128(local)                       # common.ts:23, per call
+        proofs.append(bn.groth16GenProof(wb, pkb))            # common.ts:29 (random blinding, as the reference)
+        times.append(1e3 * (time.perf_counter() - t0))
+    ok = all(zkr_hip.verify(vk_bin, zkr_hip.proof_bytes_from_json(p), pub) for p in proofs)
+    loads = zkr_hip.key_cache_stats["loads"] - loads0
+    zkr_hip.clear_key_cache()
+    steady = sorted(times[1:])
+    return {"circuit": "BatchProcessTx(%d, %d) through the websnark provingKeyBin (%d MB), new Bn128 object per proof" % (batch, depth, len(pkb) >> 20),
+            "dropin_first_ms": times[0], "dropin_steady_ms": steady[len(steady) // 2], "key_loads": loads, "proofs_verified": len(proofs) if ok else 0}
+
+
+def bcast_modes_leg(key, wb, local):
+    """Both replication modes of the multi-GPU path timed on ONE GPU, a device-to-device clone standing in for the wire
+    (VERDICT r1 item 7b): "full" = whole arena adopted in place; "base" = compact arena + local rebuild of the window
+    levels.  wire_ms_at_153GBps = the bytes over one xGMI link, the per-link bound of a ring / chain broadcast."""
+    import torch
+    from zkr_hip.batch import _tensor_from_ptr
+    want = key.prove(wb, 5, 7)
+    out = {}
+    for mode in ("full", "base"):
+        ptr, n = key.arena() if mode == "full" else key.base_arena()
+        view = _tensor_from_ptr(ptr, n, local)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        replica = view.clone()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        k2 = zkr_hip_adopt(mode, replica, n, local)
+        t2 = time.perf_counter()
+        same = k2.prove(wb, 5, 7) == want
+        k2.close()
+        del replica
+        out[mode] = {"bytes": n, "clone_ms": 1e3 * (t1 - t0), "adopt_ms": 1e3 * (t2 - t1), "wire_ms_at_153GBps": n / 153e9 * 1e3,
+                     "replica_proof_identical": bool(same)}
+    return out
+
+
+def zkr_hip_adopt(mode, replica, n, local):
+    import zkr_hip
+    if mode == "full":
+        return zkr_hip.ProvingKey.adopt_arena(replica.data_ptr(), n, local, keepalive=replica)
+    return zkr_hip.ProvingKey.adopt_base_arena(replica.data_ptr(), n, local)
 
 
 def tx_circuit_leg(local, steps, batch=2, depth=6):
@@ -144,14 +316,15 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--log-m", type=int, default=20)
-    ap.add_argument("--cpu-sample-log-m", type=int, default=17)
+    ap.add_argument("--cpu-sample-log-m", type=int, default=None, help="size the CPU baseline is measured at (default: --log-m itself, capped at 2^20)")
     ap.add_argument("--shape", choices=["rollup", "dense"], default="rollup",
                     help="synthetic circuit: rollup-shaped (BASELINE configs[1..3]) or dense random (configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--js-sample-log-m", type=int, default=10)
     ap.add_argument("--no-js-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="synchronous proofs, one at a time (latency)")
-    ap.add_argument("--no-tx-circuit", action="store_true", help="skip the BatchProcessTx(2, 6) leg (SURVEY 8(f-3))")
+    ap.add_argument("--no-tx-circuit", action="store_true", help="skip the BatchProcessTx(2, 6) legs (SURVEY 8(f-3)) and the drop-in caller leg")
+    ap.add_argument("--no-bcast-modes", action="store_true", help="skip timing the two key replication modes on this GPU")
     args = ap.parse_args()
 
     import torch
@@ -214,6 +387,7 @@ def main():
     run(0, args.warmup)
     key.prof_enable(True)
     key.prof_reset()
+    sampler = GpuSampler(local).start() if rank == 0 else None
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -224,6 +398,7 @@ def main():
     if dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    device_state = sampler.stop() if sampler else None
     if dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -316,6 +491,18 @@ def main():
             roofline["valu"] = {"peak_fq_mul_per_s_G": peak_gmul, "unit": "G Fq-mul/s (136 mad32 each)",
                                 "achieved_fq_mul_per_s_G": gm, "frac": gm / peak_gmul,
                                 "window_bits": win["A"][0], "additions_per_point": win["A"][1]}
+            # the same rate against the chip's own bound, not only against this library's multiplier:
+            # a product needs 136 v_mad_u64_u32, a full-rate-16-lanes-per-clock instruction on each of the 1024 SIMDs
+            # (256 CUs x 4), so at clock f no multiplier can exceed 1024 * 16 * f / 136 -- quoted at the clock SAMPLED
+            # during the timed region and at the 2.4 GHz boost clock.  The carry word (v_addc_co_u32, 2 of every 6 issue
+            # cycles) and the reduction bookkeeping are what separates the microbenchmark from this bound.
+            mhz = (device_state or {}).get("sclk_mhz_mean")
+            bound = lambda f_mhz: 1024 * 16 * f_mhz * 1e6 / 136 / 1e9
+            roofline["valu"]["mad_only_bound"] = {
+                "sampled_sclk_mhz": mhz,
+                "bound_at_sampled_clock_G": bound(mhz) if mhz else None, "frac_at_sampled_clock": gm / bound(mhz) if mhz else None,
+                "bound_at_2400_mhz_G": bound(2400.0), "frac_at_2400_mhz": gm / bound(2400.0),
+                "microbench_over_bound_at_sampled_clock": peak_gmul / bound(mhz) if mhz else None}
             # whole proof: every field multiplication of the path (Fq and Fr cost the same) over the time per proof.
             # mixed addition MADD_G1 / MADD_G2 per table entry (in 136-mad32 units, see the constants at the top); NTT: 6 transforms of (m/2) log2 m butterflies + 5m
             # element-wise products; QAP rows: one per non-zero; bucket reduction: 2 full additions (ADD_G1 / ADD_G2) per
@@ -345,21 +532,26 @@ def main():
             "pcie_inclusive_proofs_per_s": pcie_rate,
             "pcie_inclusive_concurrent_callers_proofs_per_s": pcie_rate_conc,
             "proofs_verified": verified, "verify_ms_per_proof_host": verify_ms,
+            "device_state_during_timed_region": device_state,
             "hbm_whole_proof": None if proof_traffic is None else {
                 "bytes_per_proof": proof_traffic, "GBps_per_gpu": proof_traffic / (elapsed / args.steps) / 1e9,
                 "frac_of_peak": proof_traffic / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBPS,
                 "source": "sum over the proving kernels of profiles/r1_pmc_traffic.json (x2 read rule: an upper bound for the 64-byte gathers)"},
         }
-        if world == 1 and not args.no_tx_circuit:
-            key.close()  # its four streams would share the hardware queues with the streams of the tx-circuit key
-            out["tx_circuit"] = tx_circuit_leg(local, max(args.steps, 4))
-            # the same circuit family filled up to the headline size: 18 transactions per batch = 1 008 108 constraints, 2^20 domain
-            out["rollup_circuit_2_20"] = tx_circuit_leg(local, min(max(args.steps, 4), 20), batch=18, depth=6)
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample_log_m, args.log_m)
+        if world == 1 and not args.no_cpu_baseline:  # before the key goes: the GPU proof of the CPU leg's witness is compared with the CPU proofs
+            cpu_lm = args.cpu_sample_log_m if args.cpu_sample_log_m is not None else min(args.log_m, 20)
+            out["cpu_baseline"] = cpu_baseline(cpu_lm, args.log_m, gpu_key=key if args.shape == "rollup" else None)
             out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
             if not args.no_js_baseline:
                 out["cpu_baseline"]["snarkjs_style"] = cpu_baseline_js(args.js_sample_log_m, args.log_m)
+        if world == 1 and not args.no_bcast_modes:
+            out["key"]["replication_modes_one_gpu"] = bcast_modes_leg(key, bytes(wits[0].cpu().numpy().tobytes()), local)
+        if world == 1 and not args.no_tx_circuit:
+            key.close()  # its four streams would share the hardware queues with the streams of the tx-circuit key
+            out["dropin"] = dropin_leg(local)
+            out["tx_circuit"] = tx_circuit_leg(local, max(args.steps, 4))
+            # the same circuit family filled up to the headline size: 18 transactions per batch = 1 008 108 constraints, 2^20 domain
+            out["rollup_circuit_2_20"] = tx_circuit_leg(local, min(max(args.steps, 4), 20), batch=18, depth=6)
         print(json.dumps(out))
     if dist:
         dist.barrier()

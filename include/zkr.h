@@ -44,6 +44,9 @@ const char *zkr_last_error(void);
 const char *zkr_version(void);
 /* Number of HIP devices visible (0 when none; never fails). */
 int zkr_device_count(void);
+/* PCI address of HIP device `device` ("0000:c1:00.0"; out_len >= 16): lets a monitoring harness find the device's sysfs
+ * node (/sys/bus/pci/devices/<id>: hwmon clock and power) among the GPUs of the node. */
+int zkr_device_pci_bus_id(int device, char *out, size_t out_len);
 
 /* Parse a websnark-format proving key (the ArrayBuffer of binarifyProvingKey, binarify.ts:143-206),
  * build the device layout (CSR QAP rows, compacted Montgomery point tables, twiddles) and upload it

@@ -92,8 +92,18 @@ namespace zkr {
 // events and timing spans.  A key has PROOF_SLOTS of them so that the GPU work of the next proof is enqueued
 // (zkr_prove_submit) while the host still assembles the previous one (zkr_prove_collect).
 constexpr int PROOF_SLOTS = 2;
+// Host witnesses (zkr_prove, zkr_prove_batch: the ArrayBuffer of binarifyWitness) reach the GPU through a ring of staging
+// buffers, one more than there are proof slots: the witness of the NEXT proof is copied into pinned memory and sent over
+// PCIe while both slots compute, so a stream of host-buffer calls keeps the GPU as busy as device-resident witnesses do.
+constexpr int STAGE_BUFS = PROOF_SLOTS + 1;
+struct WitnessStage {
+  void *h_pinned = nullptr;  // hipHostMalloc'ed, nVars x 32 B (allocated with the first host witness)
+  Fr *d_w = nullptr;         // its device copy, read by ingest_kernel
+  hipEvent_t ev_up = nullptr;
+  bool busy = false;
+};
 struct ProofSlot {
-  Fr *d_wraw = nullptr, *d_w = nullptr, *va = nullptr, *vb = nullptr, *ca = nullptr, *cb = nullptr, *d_h = nullptr;
+  Fr *d_w = nullptr, *va = nullptr, *vb = nullptr, *ca = nullptr, *cb = nullptr, *d_h = nullptr;
   DigitLists dig_w, dig_h;  // digit records of w (shared by A, B1, B2, C) and of h
   MsmWorkspace ws[N_TABLES];
   hipEvent_t ev_w = nullptr, ev_h = nullptr;
@@ -117,6 +127,10 @@ struct zkr_key {
   size_t base_arena_len = 0;
   zkr::ArenaHeader h;
   hipStream_t stream = nullptr;
+  hipStream_t copy_stream = nullptr;               // witness uploads (host-buffer entry points)
+  zkr::WitnessStage stage[zkr::STAGE_BUFS];
+  std::mutex stage_mu;
+  std::condition_variable stage_freed;
   hipStream_t prep_stream = nullptr;               // digit records, digit sorts, calcH
   hipStream_t red_stream[zkr::N_TABLES] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // reduction chains: [0] the G2 table, the G1 tables
                                                                                            // round-robin over [1..n_red)

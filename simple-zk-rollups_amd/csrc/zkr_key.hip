@@ -137,6 +137,7 @@ int key_alloc_workspace(zkr_key *k) {
   if (getenv("ZKR_NO_PRIO")) prio_hi = prio_lo;
   ZKR_HIP_CHECK(hipStreamCreateWithPriority(&k->stream, hipStreamNonBlocking, prio_lo));
   ZKR_HIP_CHECK(hipStreamCreateWithPriority(&k->prep_stream, hipStreamNonBlocking, prio_hi));
+  ZKR_HIP_CHECK(hipStreamCreateWithPriority(&k->copy_stream, hipStreamNonBlocking, prio_hi));
   // reduction streams: the chains of one proof add up to ~6 ms of serialised launches, so on a single in-order
   // stream they, not the accumulations, set the pace with two proofs in flight (94 vs 106 proofs/s with two)
   k->n_red = 2;
@@ -151,7 +152,6 @@ int key_alloc_workspace(zkr_key *k) {
     ZKR_HIP_CHECK(hipEventCreateWithFlags(&sl.ev_w, hipEventDisableTiming));
     ZKR_HIP_CHECK(hipEventCreateWithFlags(&sl.ev_h, hipEventDisableTiming));
     for (int j = 0; j < k->n_red; j++) ZKR_HIP_CHECK(hipEventCreateWithFlags(&sl.ev_red[j], hipEventDisableTiming));
-    ZKR_HIP_CHECK(hipMalloc(&sl.d_wraw, (size_t)h.n * 32));
     ZKR_HIP_CHECK(hipMalloc(&sl.d_w, (size_t)h.n * 32));
     Fr **vecs[5] = {&sl.va, &sl.vb, &sl.ca, &sl.cb, &sl.d_h};
     for (auto v : vecs) ZKR_HIP_CHECK(hipMalloc(v, (size_t)h.m * 32));
@@ -394,6 +394,13 @@ int zkr_device_count(void) {
   return n;
 }
 
+int zkr_device_pci_bus_id(int device, char *out, size_t out_len) {
+  if (!out || out_len < 16) { set_error("buffer too small"); return ZKR_ERR_ARG; }
+  if (zkr_device_count() <= device || device < 0) { set_error("no HIP device %d", device); return ZKR_ERR_NO_DEVICE; }
+  ZKR_HIP_CHECK(hipDeviceGetPCIBusId(out, (int)out_len, device));
+  return 0;
+}
+
 static uint32_t rd32(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); return v; }
 static bool all_zero(const uint8_t *p, size_t n) { for (size_t i = 0; i < n; i++) if (p[i]) return false; return true; }
 
@@ -479,7 +486,7 @@ int zkr_key_load_websnark(const void *pk_bin, size_t pk_len, int device, zkr_key
 void zkr_key_free(zkr_key *k) {
   if (!k) return;
   hipSetDevice(k->device);
-  hipStream_t streams[2 + N_TABLES] = {k->stream, k->prep_stream, k->red_stream[0], k->red_stream[1], k->red_stream[2], k->red_stream[3], k->red_stream[4]};
+  hipStream_t streams[3 + N_TABLES] = {k->stream, k->prep_stream, k->copy_stream, k->red_stream[0], k->red_stream[1], k->red_stream[2], k->red_stream[3], k->red_stream[4]};
   for (hipStream_t st : streams)
     if (st) hipStreamSynchronize(st);
   for (ProofSlot &sl : k->slot) {
@@ -493,11 +500,16 @@ void zkr_key_free(zkr_key *k) {
     for (auto e : sl.ev_red)
       if (e) hipEventDestroy(e);
     digit_lists_free(sl.dig_w); digit_lists_free(sl.dig_h);
-    hipFree(sl.d_wraw); hipFree(sl.d_w); hipFree(sl.va); hipFree(sl.vb); hipFree(sl.ca); hipFree(sl.cb); hipFree(sl.d_h);
+    hipFree(sl.d_w); hipFree(sl.va); hipFree(sl.vb); hipFree(sl.ca); hipFree(sl.cb); hipFree(sl.d_h);
     for (auto e : sl.event_pool) hipEventDestroy(e);
   }
   for (hipStream_t st : streams)
     if (st) hipStreamDestroy(st);
+  for (WitnessStage &ws : k->stage) {
+    if (ws.h_pinned) hipHostFree(ws.h_pinned);
+    if (ws.d_w) hipFree(ws.d_w);
+    if (ws.ev_up) hipEventDestroy(ws.ev_up);
+  }
   if (k->owns_arena) hipFree(k->arena);
   if (k->base_arena) hipFree(k->base_arena);
   delete k;

@@ -318,13 +318,14 @@ static int draw_blinding(uint8_t out[32]) {
   return 0;
 }
 
-static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *d_wsrc, const uint8_t *r32, const uint8_t *s32, hipStream_t caller);
+static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *d_wsrc, const uint8_t *r32, const uint8_t *s32, hipStream_t caller, hipEvent_t ready);
 
 // Enqueue the whole GPU side of one proof on the slot's buffers; returns without waiting.  If the enqueue fails part
 // way, kernels already launched still use the slot's buffers while the slot stays marked free: the key's streams are
 // drained before the error is returned, so the next submit (possibly from another host thread) cannot race with them.
-static int prove_submit(zkr_key *k, ProofSlot &sl, const Fr *d_wsrc, const uint8_t *r32, const uint8_t *s32, hipStream_t caller) {
-  int rc = prove_submit_enqueue(k, sl, d_wsrc, r32, s32, caller);
+// ready: the event after which the witness is in place (a staged upload); null: whatever is enqueued on `caller` now.
+static int prove_submit(zkr_key *k, ProofSlot &sl, const Fr *d_wsrc, const uint8_t *r32, const uint8_t *s32, hipStream_t caller, hipEvent_t ready = nullptr) {
+  int rc = prove_submit_enqueue(k, sl, d_wsrc, r32, s32, caller, ready);
   if (rc && rc != ZKR_ERR_ARG) {  // ZKR_ERR_ARG: refused before the first launch
     hipStreamSynchronize(k->stream);
     hipStreamSynchronize(k->prep_stream);
@@ -335,7 +336,7 @@ static int prove_submit(zkr_key *k, ProofSlot &sl, const Fr *d_wsrc, const uint8
   return rc;
 }
 
-static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *d_wsrc, const uint8_t *r32, const uint8_t *s32, hipStream_t caller) {
+static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *d_wsrc, const uint8_t *r32, const uint8_t *s32, hipStream_t caller, hipEvent_t ready) {
   ZKR_HIP_CHECK(hipSetDevice(k->device));
   const ArenaHeader &h = k->h;
   const unsigned char *ar = k->arena;
@@ -376,8 +377,12 @@ static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *d_wsrc, con
     return k->red_stream[1 + (g1_next++ % (k->n_red - 1))];
   };
   int rc;
-  ZKR_HIP_CHECK(hipEventRecord(sl.ev_w, caller));  // the witness is in place
-  ZKR_HIP_CHECK(hipStreamWaitEvent(sp, sl.ev_w, 0));
+  if (ready) {
+    ZKR_HIP_CHECK(hipStreamWaitEvent(sp, ready, 0));  // the staged upload of this witness has landed
+  } else {
+    ZKR_HIP_CHECK(hipEventRecord(sl.ev_w, caller));   // the witness is in place
+    ZKR_HIP_CHECK(hipStreamWaitEvent(sp, sl.ev_w, 0));
+  }
   int tot = prof_begin(pf, sp, "total");
   int spn = prof_begin(pf, sp, "ingest");
   ingest_kernel<<<(h.n + 255) / 256, 256, 0, sp>>>(d_wsrc, sl.d_w, h.n);
@@ -491,6 +496,43 @@ static int prove_collect(zkr_key *k, ProofSlot &sl, uint8_t proof_out[256]) {
   return 0;
 }
 
+// ------------------------------------------------------------------ host witnesses: staging ring (zkr_internal.hpp WitnessStage)
+// Blocks until one of the STAGE_BUFS buffers is free; allocates its pinned and device memory on first use.
+static int stage_acquire(zkr_key *k, int *idx) {
+  std::unique_lock<std::mutex> lk(k->stage_mu);
+  for (;;) {
+    for (int i = 0; i < STAGE_BUFS; i++) {
+      WitnessStage &ws = k->stage[i];
+      if (ws.busy) continue;
+      if (!ws.d_w) {
+        ZKR_HIP_CHECK(hipSetDevice(k->device));
+        const size_t bytes = (size_t)k->h.n * 32;
+        ZKR_HIP_CHECK(hipMalloc(&ws.d_w, bytes));
+        ZKR_HIP_CHECK(hipEventCreateWithFlags(&ws.ev_up, hipEventDisableTiming));
+        if (hipHostMalloc(&ws.h_pinned, bytes, hipHostMallocDefault) != hipSuccess) ws.h_pinned = nullptr;  // pageable copies still work, slower
+      }
+      ws.busy = true;
+      *idx = i;
+      return 0;
+    }
+    k->stage_freed.wait(lk);
+  }
+}
+static void stage_release(zkr_key *k, int idx) {
+  { std::lock_guard<std::mutex> lk(k->stage_mu); k->stage[idx].busy = false; }
+  k->stage_freed.notify_one();
+}
+// host witness -> pinned buffer (this thread) -> HBM (DMA on the key's copy stream); ws.ev_up fires when it has landed
+static int stage_upload(zkr_key *k, int idx, const void *witness_std, size_t len) {
+  WitnessStage &ws = k->stage[idx];
+  ZKR_HIP_CHECK(hipSetDevice(k->device));
+  const void *src = witness_std;
+  if (ws.h_pinned) { memcpy(ws.h_pinned, witness_std, len); src = ws.h_pinned; }
+  ZKR_HIP_CHECK(hipMemcpyAsync(ws.d_w, src, len, hipMemcpyHostToDevice, k->copy_stream));
+  ZKR_HIP_CHECK(hipEventRecord(ws.ev_up, k->copy_stream));
+  return 0;
+}
+
 // Hand out a free proof slot and run `enqueue` on it under the key's lock (two host threads proving on one key --
 // e.g. two libuv workers behind Promise.all -- then pipeline like submit/collect does).  wait: block until a slot
 // frees instead of failing.
@@ -532,26 +574,30 @@ int zkr_prove_batch(zkr_key *key, const void *const *witnesses_std, size_t witne
                     uint8_t *proofs_out) {
   if (!key || (!witnesses_std && count) || !proofs_out) { set_error("null argument"); return ZKR_ERR_ARG; }
   if (witness_len != (size_t)key->h.n * 32) { set_error("witness is %zu bytes, key expects nVars*32 = %zu", witness_len, (size_t)key->h.n * 32); return ZKR_ERR_BAD_WITNESS; }
-  int tickets[PROOF_SLOTS];
+  // Pipeline of one host thread: the witness of proof i is staged (copy into pinned memory + DMA) BEFORE the oldest
+  // proof in flight is collected, i.e. while both proof slots compute; then the freed slot takes proof i at once.
+  int tickets[PROOF_SLOTS], stages[PROOF_SLOTS];
   size_t index[PROOF_SLOTS];
   int in_flight = 0, rc = 0;
   auto collect_oldest = [&]() {
     int r = prove_collect(key, key->slot[tickets[0]], proofs_out + 256 * index[0]);
-    for (int j = 1; j < in_flight; j++) { tickets[j - 1] = tickets[j]; index[j - 1] = index[j]; }
+    stage_release(key, stages[0]);
+    for (int j = 1; j < in_flight; j++) { tickets[j - 1] = tickets[j]; index[j - 1] = index[j]; stages[j - 1] = stages[j]; }
     in_flight--;
     return r;
   };
   for (size_t i = 0; i < count && !rc; i++) {
     if (!witnesses_std[i]) { set_error("witness %zu is null", i); rc = ZKR_ERR_ARG; break; }
-    if (in_flight == PROOF_SLOTS) rc = collect_oldest();
-    if (rc) break;
+    int st = -1;
+    if ((rc = stage_acquire(key, &st))) break;
+    rc = stage_upload(key, st, witnesses_std[i], witness_len);
+    if (!rc && in_flight == PROOF_SLOTS) rc = collect_oldest();
     int t = -1;
-    rc = with_free_slot(key, true, &t, [&](ProofSlot &sl) -> int {
-      ZKR_HIP_CHECK(hipSetDevice(key->device));
-      ZKR_HIP_CHECK(hipMemcpyAsync(sl.d_wraw, witnesses_std[i], witness_len, hipMemcpyHostToDevice, key->prep_stream));
-      return prove_submit(key, sl, sl.d_wraw, r32s ? r32s + 32 * i : nullptr, s32s ? s32s + 32 * i : nullptr, key->prep_stream);
+    if (!rc) rc = with_free_slot(key, true, &t, [&](ProofSlot &sl) -> int {
+      return prove_submit(key, sl, key->stage[st].d_w, r32s ? r32s + 32 * i : nullptr, s32s ? s32s + 32 * i : nullptr, key->copy_stream, key->stage[st].ev_up);
     });
-    if (!rc) { tickets[in_flight] = t; index[in_flight] = i; in_flight++; }
+    if (rc) { hipStreamSynchronize(key->copy_stream); stage_release(key, st); break; }
+    tickets[in_flight] = t; index[in_flight] = i; stages[in_flight] = st; in_flight++;
   }
   while (in_flight > 0) {  // drain, also after an error: a submitted proof must be collected to free its slot
     int r = collect_oldest();
@@ -571,15 +617,21 @@ int zkr_prove_device(zkr_key *key, const void *d_witness_std, const uint8_t *r32
 int zkr_prove(zkr_key *key, const void *witness_std, size_t witness_len, const uint8_t *r32, const uint8_t *s32, uint8_t proof_out[256], void *stream) {
   if (!key || !witness_std || !proof_out) { set_error("null argument"); return ZKR_ERR_ARG; }
   if (witness_len != (size_t)key->h.n * 32) { set_error("witness is %zu bytes, key expects nVars*32 = %zu", witness_len, (size_t)key->h.n * 32); return ZKR_ERR_BAD_WITNESS; }
-  int t = -1;
-  int rc = with_free_slot(key, true, &t, [&](ProofSlot &sl) -> int {
-    ZKR_HIP_CHECK(hipSetDevice(key->device));
-    hipStream_t s = stream ? (hipStream_t)stream : key->prep_stream;
-    ZKR_HIP_CHECK(hipMemcpyAsync(sl.d_wraw, witness_std, witness_len, hipMemcpyHostToDevice, s));
-    return prove_submit(key, sl, sl.d_wraw, r32, s32, s);
-  });
+  (void)stream;  // a host buffer is complete when the call is made: nothing on the caller's stream to wait for
+  // Upload first (own staging buffer, outside the key's lock: concurrent callers copy in parallel and a third caller
+  // uploads while two proofs are in flight), then take a proof slot as soon as one frees.
+  int st = -1;
+  int rc = stage_acquire(key, &st);
   if (rc) return rc;
-  return prove_collect(key, key->slot[t], proof_out);
+  rc = stage_upload(key, st, witness_std, witness_len);
+  int t = -1;
+  if (!rc) rc = with_free_slot(key, true, &t, [&](ProofSlot &sl) -> int {
+    return prove_submit(key, sl, key->stage[st].d_w, r32, s32, key->copy_stream, key->stage[st].ev_up);
+  });
+  if (rc) { hipStreamSynchronize(key->copy_stream); stage_release(key, st); return rc; }
+  rc = prove_collect(key, key->slot[t], proof_out);
+  stage_release(key, st);
+  return rc;
 }
 
 int zkr_calc_h(zkr_key *key, const void *witness_std, size_t witness_len, void *h_out) {
@@ -593,13 +645,19 @@ int zkr_calc_h(zkr_key *key, const void *witness_std, size_t witness_len, void *
   if (!slp) { set_error("all proof slots are in flight"); return ZKR_ERR_ARG; }
   ProofSlot &sl = *slp;
   hipStream_t s = key->stream;
-  ZKR_HIP_CHECK(hipMemcpyAsync(sl.d_wraw, witness_std, witness_len, hipMemcpyHostToDevice, s));
-  ingest_kernel<<<(key->h.n + 255) / 256, 256, 0, s>>>(sl.d_wraw, sl.d_w, key->h.n);
+  // the raw witness lands in sl.d_h (m x 32 B, written only by the last kernel of calcH, after ingest has read it) when
+  // it fits -- n <= m for every key this library builds -- and in a temporary otherwise
+  Fr *raw = sl.d_h;
+  Fr *tmp = nullptr;
+  if (key->h.n > key->h.m) { ZKR_HIP_CHECK(hipMalloc(&tmp, witness_len)); raw = tmp; }
+  ZKR_HIP_CHECK(hipMemcpyAsync(raw, witness_std, witness_len, hipMemcpyHostToDevice, s));
+  ingest_kernel<<<(key->h.n + 255) / 256, 256, 0, s>>>(raw, sl.d_w, key->h.n);
   int rc = calc_h_device(key, sl, s);
   if (rc) return rc;
   bitrev_copy_kernel<<<(key->h.m + 255) / 256, 256, 0, s>>>(sl.d_h, sl.ca, (int)key->h.logm);
   ZKR_HIP_CHECK(hipMemcpyAsync(h_out, sl.ca, (size_t)key->h.m * 32, hipMemcpyDeviceToHost, s));
   ZKR_HIP_CHECK(hipStreamSynchronize(s));
+  if (tmp) hipFree(tmp);
   if (key->prof_on) prof_collect(key, sl);
   return 0;
 }

@@ -29,6 +29,7 @@ def lib():
     L.zkr_last_error.restype = c.c_char_p
     L.zkr_version.restype = c.c_char_p
     L.zkr_device_count.restype = i
+    L.zkr_device_pci_bus_id.argtypes = [i, c.c_char_p, sz]
     L.zkr_key_load_websnark.argtypes = [u8p, sz, i, c.POINTER(vp)]
     L.zkr_key_free.argtypes = [vp]
     L.zkr_key_free.restype = None
@@ -90,6 +91,12 @@ def _check(rc):
 
 def device_count():
     return lib().zkr_device_count()
+
+
+def device_pci_bus_id(device=0) -> str:
+    buf = ctypes.create_string_buffer(32)
+    _check(lib().zkr_device_pci_bus_id(device, buf, 32))
+    return buf.value.decode()
 
 
 def version():
