@@ -112,8 +112,17 @@ int zkr_prove_collect(zkr_key *key, int ticket, uint8_t proof_out[256]);
  * (drawn per proof); proofs_out: count x 256 B.  Stops at the first failing proof (its status is returned). */
 int zkr_prove_batch(zkr_key *key, const void *const *witnesses_std, size_t witness_len, size_t count, const uint8_t *r32s, const uint8_t *s32s,
                     uint8_t *proofs_out);
-/* Number of proof workspaces of the key = proofs that can be in flight. */
+/* The same for witnesses already resident in HBM (count device pointers, nVars x 32 B each; `stream` as for
+ * zkr_prove_device).  Both batch calls FUSE proofs of small circuits: a key whose circuit is far below the size that fills
+ * the chip (the reference's tx circuit, 2^17 constraints) runs every kernel over up to zkr_key_fuse(key) witnesses at once
+ * (vectors end to end, one bucket set per proof and table), so a launch carries about the work of one 2^20 proof and the
+ * fixed latency tail of the bucket reduction is paid once per group; two groups are in flight.  Proofs are the same bytes as
+ * from zkr_prove_device. */
+int zkr_prove_batch_device(zkr_key *key, const void *const *d_witnesses_std, size_t count, const uint8_t *r32s, const uint8_t *s32s, void *stream,
+                           uint8_t *proofs_out);
+/* Number of proof workspaces of the key = submits that can be in flight; proofs one batch submit fuses (1 at 2^20 and above). */
 int zkr_key_slots(const zkr_key *key);
+int zkr_key_fuse(const zkr_key *key);
 
 /* ---- acceptance check (host only, no GPU) ---------------------------------------------------------
  * The pairing equation `groth.isValid(vk, proof, publicSignals)` evaluates at common.ts:30-38 and

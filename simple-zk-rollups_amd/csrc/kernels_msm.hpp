@@ -59,6 +59,7 @@ struct MsmGeom {
   uint32_t big_thresh;
   int glog;          // reduce group = 2^glog buckets
   uint32_t S;        // reduce2: workgroups per task
+  uint32_t batch;    // proofs fused into the launches (small circuits): `batch` bucket sets of nbw buckets laid end to end
 };
 
 // Signed-digit recoding state: scalar kept in 8 registers and shifted right by c each window so the
@@ -99,21 +100,25 @@ __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
 // scalar is 32 bytes and the recoding a few shifts).  Workgroups reserve their span of each list with one
 // atomic per range, so the lists are written in runs.
 constexpr int ENT_WIN_SHIFT = 17;
-constexpr uint32_t MAX_RANGES = 64;
+constexpr uint32_t MAX_RANGES = 256;  // x SORT_RANGE_MAX buckets = 2^21: window sizes up to c = 22 (2^24-point tables), or fused batches of small circuits
 
 __device__ __forceinline__ uint32_t digit_bucket(int d) { return (uint32_t)(d < 0 ? -d : d) - 1u; }
 
-static __global__ __launch_bounds__(MSM_THREADS) void msm_digits_count_kernel(const Fr *scalars, uint32_t n, int c, int K, int nbl_log, uint32_t nR, uint32_t *rng_cnt) {
+// Fused batches (small circuits, DESIGN.md 3.2 "several proofs per launch"): `scalars` holds the vectors of several proofs
+// end to end, n_per scalars each; proof p owns the bucket ranges [p * nR1, (p + 1) * nR1) -- i.e. its own bucket set --
+// so one sort / accumulation / reduction launch serves every proof of the batch.  One proof: n_per = n, nR1 = nR.
+static __global__ __launch_bounds__(MSM_THREADS) void msm_digits_count_kernel(const Fr *scalars, uint32_t n, uint32_t n_per, int c, int K, int nbl_log, uint32_t nR1, uint32_t nR, uint32_t *rng_cnt) {
   __shared__ uint32_t s_cnt[MAX_RANGES];
   if (threadIdx.x < nR) s_cnt[threadIdx.x] = 0;
   __syncthreads();
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) {
+    const uint32_t r0 = (i / n_per) * nR1;
     DigitIter it;
     it.init(scalars[i].v);
     for (int k = 0; k < K; k++) {
       int d = it.next(c);
-      if (d != 0) atomicAdd(&s_cnt[digit_bucket(d) >> nbl_log], 1u);
+      if (d != 0) atomicAdd(&s_cnt[r0 + (digit_bucket(d) >> nbl_log)], 1u);
     }
   }
   __syncthreads();
@@ -121,19 +126,20 @@ static __global__ __launch_bounds__(MSM_THREADS) void msm_digits_count_kernel(co
 }
 
 // rng_cnt complete, rng_fill zeroed.  Block 0 also publishes rng_off[0..nR] (exclusive prefix) for the table sorts.
-static __global__ __launch_bounds__(MSM_THREADS) void msm_digits_scatter_kernel(const Fr *scalars, uint32_t n, int c, int K, int nbl_log, uint32_t nR,
+static __global__ __launch_bounds__(MSM_THREADS) void msm_digits_scatter_kernel(const Fr *scalars, uint32_t n, uint32_t n_per, int c, int K, int nbl_log, uint32_t nR1, uint32_t nR,
                                                                               const uint32_t *rng_cnt, uint32_t *rng_fill, uint32_t *rng_off,
                                                                               uint32_t *ent_s, uint32_t *ent_b) {
   __shared__ uint32_t s_cnt[MAX_RANGES], s_base[MAX_RANGES];
   if (threadIdx.x < nR) s_cnt[threadIdx.x] = 0;
   __syncthreads();
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t r0 = i < n ? (i / n_per) * nR1 : 0u;
   DigitIter it;
   if (i < n) {
     it.init(scalars[i].v);
     for (int k = 0; k < K; k++) {
       int d = it.next(c);
-      if (d != 0) atomicAdd(&s_cnt[digit_bucket(d) >> nbl_log], 1u);
+      if (d != 0) atomicAdd(&s_cnt[r0 + (digit_bucket(d) >> nbl_log)], 1u);
     }
   }
   __syncthreads();
@@ -158,7 +164,7 @@ static __global__ __launch_bounds__(MSM_THREADS) void msm_digits_scatter_kernel(
     for (int k = 0; k < K; k++) {
       int d = it.next(c);
       if (d != 0) {
-        uint32_t b = digit_bucket(d), r = b >> nbl_log;
+        uint32_t b = digit_bucket(d), r = r0 + (b >> nbl_log);
         uint32_t pos = s_base[r] + atomicAdd(&s_cnt[r], 1u);
         ent_s[pos] = i;
         ent_b[pos] = ((uint32_t)k << ENT_WIN_SHIFT) | ((b & lo_mask) << 1) | (d < 0 ? 1u : 0u);
@@ -187,7 +193,7 @@ __device__ __forceinline__ void sort_chunk(const uint32_t *rng_off, uint32_t r, 
 
 // cnt[(r * J + j) * nbl + b] = occupancy of bucket r * nbl + b within chunk j
 static __global__ __launch_bounds__(SORT_THREADS) void msm_hist_kernel(const uint32_t *ent_s, const uint32_t *ent_b, const uint32_t *rng_off, const uint32_t *rank,
-                                                                     uint32_t nbl, uint32_t J, uint32_t *cnt) {
+                                                                     uint32_t n_per, uint32_t nbl, uint32_t J, uint32_t *cnt) {
   extern __shared__ __attribute__((aligned(16))) uint32_t s_bkt[];
   const uint32_t j = blockIdx.x % J, r = blockIdx.x / J;
   for (uint32_t b = threadIdx.x; b < nbl; b += SORT_THREADS) s_bkt[b] = 0;
@@ -203,7 +209,7 @@ static __global__ __launch_bounds__(SORT_THREADS) void msm_hist_kernel(const uin
       uint32_t eu = e + u * SORT_THREADS;
       bool in = eu < e1;
       b[u] = in ? ent_b[eu] : 0u;
-      idx[u] = in ? (rank ? rank[ent_s[eu]] : 0u) : RANK_NONE;  // rank == null: every scalar has its point (identity map)
+      idx[u] = in ? (rank ? rank[ent_s[eu] % n_per] : 0u) : RANK_NONE;  // rank == null: every scalar has its point (identity map); % n_per: fused batches
     }
 #pragma unroll
     for (int u = 0; u < SORT_UNROLL; u++)
@@ -232,7 +238,7 @@ static __global__ __launch_bounds__(MSM_THREADS) void msm_colscan_kernel(uint32_
 // entries[pos] = ((k * n + rank) << 1) | sign  -- index into the table's window levels and the sign of the digit --
 // grouped by bucket: LDS cursors = bucket offset + chunk prefix
 static __global__ __launch_bounds__(SORT_THREADS) void msm_scatter_kernel(const uint32_t *ent_s, const uint32_t *ent_b, const uint32_t *rng_off, const uint32_t *rank,
-                                                                        uint32_t n, uint32_t nbl, uint32_t J, const uint32_t *cnt, const uint32_t *offsets,
+                                                                        uint32_t n_per, uint32_t n, uint32_t nbl, uint32_t J, const uint32_t *cnt, const uint32_t *offsets,
                                                                         uint32_t *entries) {
   extern __shared__ __attribute__((aligned(16))) uint32_t s_bkt[];
   const uint32_t j = blockIdx.x % J, r = blockIdx.x / J;
@@ -248,7 +254,7 @@ static __global__ __launch_bounds__(SORT_THREADS) void msm_scatter_kernel(const 
       uint32_t eu = e + u * SORT_THREADS;
       bool in = eu < e1;
       b[u] = in ? ent_b[eu] : 0u;
-      idx[u] = in ? (rank ? rank[ent_s[eu]] : ent_s[eu]) : RANK_NONE;
+      idx[u] = in ? (rank ? rank[ent_s[eu] % n_per] : ent_s[eu] % n_per) : RANK_NONE;
     }
 #pragma unroll
     for (int u = 0; u < SORT_UNROLL; u++) {
@@ -524,7 +530,7 @@ template <class F, int MINW>
 static __global__ __launch_bounds__(MSM_THREADS, MINW) void msm_reduce1_kernel(const XYZZ<F> *buckets, MsmGeom g, XYZZ<F> *group_out) {
   __builtin_amdgcn_s_setprio(3);  // few long-running wavefronts on the critical path: win VALU arbitration against the bulk accumulation
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t ng = g.nbw >> g.glog, gs = 1u << g.glog;
+  const uint32_t ng = (g.nbw >> g.glog) * g.batch, gs = 1u << g.glog;  // groups of every bucket set of the batch, end to end
   if (t >= ng) return;
   const XYZZ<F> *B = buckets + (size_t)t * gs;
   XYZZ<F> run = load_pod(B + gs - 1), T = run;
@@ -543,15 +549,17 @@ static __global__ __launch_bounds__(MSM_THREADS, MINW) void msm_reduce2_kernel(c
   XYZZ<F> *sh = reinterpret_cast<XYZZ<F> *>(smem);
   const uint32_t nglog = (uint32_t)(g.c - 1 - g.glog), ng = 1u << nglog;
   const uint32_t j = blockIdx.x / g.S, q = blockIdx.x % g.S;
+  const uint32_t proof = blockIdx.y;  // bucket set of the batch (gridDim.y = g.batch)
+  const XYZZ<F> *R = group_out + (size_t)proof * ng;
   XYZZ<F> acc = XYZZ<F>::inf();
   if (j < nglog) {  // the u-th index with bit j set, u < ng/2; this split takes u in [u0, u1)
     const uint32_t half = ng / 2, u0 = (uint32_t)((uint64_t)half * q / g.S), u1 = (uint32_t)((uint64_t)half * (q + 1) / g.S);
     for (uint32_t u = u0 + threadIdx.x; u < u1; u += MSM_THREADS) {
       uint32_t t = ((u >> j) << (j + 1)) | (1u << j) | (u & ((1u << j) - 1u));
-      acc = add_full_inl(acc, load_pod(group_out + t));
+      acc = add_full_inl(acc, load_pod(R + t));
     }
   } else {
-    const XYZZ<F> *T = group_out + (size_t)ng;
+    const XYZZ<F> *T = group_out + (size_t)ng * g.batch + (size_t)proof * ng;
     const uint32_t h = j - nglog, lo = h * ng / 2, len = (h + 1) * ng / 2 - lo;
     const uint32_t t0 = lo + (uint32_t)((uint64_t)len * q / g.S), t1 = lo + (uint32_t)((uint64_t)len * (q + 1) / g.S);
     for (uint32_t t = t0 + threadIdx.x; t < t1; t += MSM_THREADS) acc = add_full_inl(acc, load_pod(T + t));
@@ -562,10 +570,10 @@ static __global__ __launch_bounds__(MSM_THREADS, MINW) void msm_reduce2_kernel(c
     if (threadIdx.x < s) sh[threadIdx.x] = add_full_inl(sh[threadIdx.x], sh[threadIdx.x + s]);
     __syncthreads();
   }
-  if (threadIdx.x == 0) store_pod(task_out + blockIdx.x, sh[0]);
+  if (threadIdx.x == 0) store_pod(task_out + (size_t)proof * gridDim.x + blockIdx.x, sh[0]);
 }
 
-// one workgroup of MSM_THREADS lanes; needs ntask * S <= MSM_THREADS (msm_plan guarantees it)
+// one workgroup of MSM_THREADS lanes per bucket set; needs ntask * S <= MSM_THREADS (msm_plan guarantees it)
 template <class F, int MINW>
 static __global__ __launch_bounds__(MSM_THREADS, MINW) void msm_reduce3_kernel(const XYZZ<F> *task_out, MsmGeom g, XYZZ<F> *result) {
   __builtin_amdgcn_s_setprio(3);
@@ -573,6 +581,8 @@ static __global__ __launch_bounds__(MSM_THREADS, MINW) void msm_reduce3_kernel(c
   XYZZ<F> *sh = reinterpret_cast<XYZZ<F> *>(smem);
   const uint32_t nglog = (uint32_t)(g.c - 1 - g.glog), ntask = nglog + 2, S = g.S;
   const uint32_t j = threadIdx.x / S, q = threadIdx.x % S;
+  task_out += (size_t)blockIdx.x * ntask * S;  // this bucket set's partial sums
+  result += blockIdx.x;
   sh[threadIdx.x] = j < ntask ? load_pod(task_out + threadIdx.x) : XYZZ<F>::inf();
   __syncthreads();
   uint32_t s = 1;

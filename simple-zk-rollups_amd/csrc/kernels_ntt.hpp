@@ -73,14 +73,14 @@ static __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArg
   const uint32_t tile = rows << a.wlog;
   const uint32_t lb = (1u << a.lo) >> a.wlog;  // tiles per q
   const uint32_t q = blockIdx.x / lb, l0 = (blockIdx.x % lb) << a.wlog;
-  const size_t base = ((size_t)q << a.hi) + l0;
+  const size_t base = ((size_t)blockIdx.y << a.L) + ((size_t)q << a.hi) + l0;  // blockIdx.y: transform of a fused batch (vectors end to end)
 
   for (uint32_t e = threadIdx.x; e < tile; e += NTT_THREADS) {
     uint32_t r = e >> a.wlog, c = e & (W - 1);
     size_t gi = base + ((size_t)r << a.lo) + c;
     Fr x = load_fr(a.in0 + gi);
     if (a.pre == PRE_COSET) {
-      uint32_t br = __brev((uint32_t)gi) >> (32 - a.L);  // coefficient index of a bit-reversed position
+      uint32_t br = __brev((uint32_t)gi << (32 - a.L));  // coefficient index of a bit-reversed position (low L bits of gi: position within its transform)
       x = mul(x, load_fr(a.tw + ((size_t)br << (a.tlog - a.L))));
     } else if (a.pre == PRE_MUL) {
       x = mul(x, load_fr(a.in1 + gi));
@@ -206,9 +206,11 @@ static __global__ void ingest_kernel(const Fr *in, Fr *out, size_t n) {
 // occasional wide row (64-term bit-packing rows, a handful per few thousand), which would leave 63 lanes of its
 // wavefront waiting for one; rows wider than SPMV_WIDE are left to spmv_wide_kernel (one wavefront per row).
 constexpr uint32_t SPMV_WIDE = 8;
-static __global__ void spmv_kernel(const uint32_t *row_ptr, const uint32_t *col, const Fr *coef, const Fr *w, Fr *out, uint32_t m) {
+static __global__ void spmv_kernel(const uint32_t *row_ptr, const uint32_t *col, const Fr *coef, const Fr *w, Fr *out, uint32_t m, uint32_t n) {
   uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= m) return;
+  w += (size_t)blockIdx.y * n;    // blockIdx.y: witness of a fused batch
+  out += (size_t)blockIdx.y * m;
   uint32_t k0 = row_ptr[c], k1 = row_ptr[c + 1];
   if (k1 - k0 > SPMV_WIDE) return;
   Fr acc = Fr::zero();
@@ -217,9 +219,11 @@ static __global__ void spmv_kernel(const uint32_t *row_ptr, const uint32_t *col,
 }
 // wide[i] = index of the i-th row wider than SPMV_WIDE; one wavefront per row, terms strided over the lanes, LDS tree
 static __global__ __launch_bounds__(64) void spmv_wide_kernel(const uint32_t *row_ptr, const uint32_t *col, const Fr *coef, const Fr *w, Fr *out,
-                                                            const uint32_t *wide, uint32_t n_wide) {
+                                                            const uint32_t *wide, uint32_t n_wide, uint32_t m, uint32_t n) {
   __shared__ uint32_t sh[8 * 64];
   if (blockIdx.x >= n_wide) return;
+  w += (size_t)blockIdx.y * n;
+  out += (size_t)blockIdx.y * m;
   const uint32_t c = wide[blockIdx.x], lane = threadIdx.x;
   uint32_t k0 = row_ptr[c], k1 = row_ptr[c + 1];
   Fr acc = Fr::zero();
@@ -246,6 +250,8 @@ static __global__ __launch_bounds__(64) void spmv_wide_kernel(const uint32_t *ro
 static __global__ void combine_h_kernel(const Fr *S, const Fr *D, Fr *h, const Fr *tw, int tlog, int L, Fr c1, Fr c2) {
   uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x;
   if (pos >= (1u << L)) return;
+  const size_t boff = (size_t)blockIdx.y << L;  // blockIdx.y: proof of a fused batch
+  S += boff; D += boff; h += boff;
   uint32_t i = __brev(pos) >> (32 - L);
   Fr ginv = tw_lookup(tw, tlog, L, i, true);  // g^-i, g = w_{2m}
   Fr s = mul(load_fr(S + pos), c1);

@@ -92,12 +92,13 @@ namespace zkr {
 // events and timing spans.  A key has PROOF_SLOTS of them so that the GPU work of the next proof is enqueued
 // (zkr_prove_submit) while the host still assembles the previous one (zkr_prove_collect).
 constexpr int PROOF_SLOTS = 2;
-// Host witnesses (zkr_prove, zkr_prove_batch: the ArrayBuffer of binarifyWitness) reach the GPU through a ring of staging
-// buffers, one more than there are proof slots: the witness of the NEXT proof is copied into pinned memory and sent over
-// PCIe while both slots compute, so a stream of host-buffer calls keeps the GPU as busy as device-resident witnesses do.
+// Host witnesses (zkr_prove, zkr_prove_batch: the ArrayBuffer of binarifyWitness) reach the GPU through a ring of device
+// staging buffers, one more than there are proof slots: the witness of the NEXT proof crosses PCIe while both slots
+// compute (and outside the key's lock), so a stream of host-buffer calls keeps the GPU as busy as device-resident
+// witnesses do.
 constexpr int STAGE_BUFS = PROOF_SLOTS + 1;
 struct WitnessStage {
-  void *h_pinned = nullptr;  // hipHostMalloc'ed, nVars x 32 B (allocated with the first host witness)
+  void *h_pinned = nullptr;  // optional pinned bounce buffer (ZKR_STAGE_PINNED), nVars x 32 B x fused capacity
   Fr *d_w = nullptr;         // its device copy, read by ingest_kernel
   hipEvent_t ev_up = nullptr;
   bool busy = false;
@@ -110,7 +111,9 @@ struct ProofSlot {
   hipEvent_t ev_red[N_TABLES] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // end of the proof's work on each reduction stream
   hipEvent_t ev_done[N_TABLES] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_sorted[N_TABLES] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-  uint8_t rb[32], sb[32];  // blinding scalars of the proof in flight
+  int cap = 1;    // proofs one submit can fuse into shared launches (small circuits; every buffer above is cap times one proof's)
+  int nbat = 0;   // proofs of the group in flight
+  std::vector<uint8_t> rb, sb;  // blinding scalars of the proofs in flight, cap x 32 B each
   bool busy = false, collecting = false;
   std::vector<ProfSpan> spans;
   std::vector<hipEvent_t> event_pool;
@@ -127,7 +130,6 @@ struct zkr_key {
   size_t base_arena_len = 0;
   zkr::ArenaHeader h;
   hipStream_t stream = nullptr;
-  hipStream_t copy_stream = nullptr;               // witness uploads (host-buffer entry points)
   zkr::WitnessStage stage[zkr::STAGE_BUFS];
   std::mutex stage_mu;
   std::condition_variable stage_freed;
@@ -165,8 +167,9 @@ struct Prof {  // where a launch helper records its timing spans (null key: stag
 int prof_begin(Prof pf, hipStream_t s, const char *stage);
 void prof_end(Prof pf, hipStream_t s, int span);
 int prof_collect(zkr_key *k, ProofSlot &sl);
-int run_ntt(hipStream_t s, const Fr *in0, const Fr *in1, Fr *out, const Fr *tw, const Fr *twl, int tlog, int L, bool dif, bool inverse, int pre);
-int calc_h_device(zkr_key *k, ProofSlot &sl, hipStream_t s);  // sl.d_w -> sl.d_h (bit-reversed)
+int run_ntt(hipStream_t s, const Fr *in0, const Fr *in1, Fr *out, const Fr *tw, const Fr *twl, int tlog, int L, bool dif, bool inverse, int pre, int nbat = 1);
+int calc_h_device(zkr_key *k, ProofSlot &sl, hipStream_t s, int nbat = 1);  // sl.d_w -> sl.d_h (bit-reversed), nbat vectors end to end
+int fused_capacity(const ArenaHeader &h, const MsmPlan plan[N_TABLES]);
 MsmPlan msm_plan(size_t n_scalars, size_t n_points, int c_fixed = 0);
 int digit_lists_alloc(DigitLists &dl, size_t n_scalars, const MsmPlan &pl);
 void digit_lists_free(DigitLists &dl);

@@ -52,8 +52,21 @@ MsmPlan msm_plan(size_t n_scalars, size_t n, int c_fixed) {
   while (((size_t)1 << lg) < n_scalars) lg++;
   int c = lg;  // 2^(c-1) buckets for ~n * 255/c entries: a few dozen entries per bucket
   if (c < 4) c = 4;
-  if (c > 20) c = 20;  // MAX_RANGES x SORT_RANGE_MAX = 2^19 buckets
-  if (const char *e = getenv("ZKR_MSM_C")) { int v = atoi(e); if (v >= 2 && v <= 20) c = v; }
+  if (c > 20) {
+    // Above 2^20 scalars the window is chosen by the work it implies -- ceil(255/c) mixed additions per point (9.47
+    // multiplications each) against two full additions (13.47) per bucket in the reduction -- over c = 20..22
+    // (MAX_RANGES x SORT_RANGE_MAX = 2^21 buckets).  2^22 points: 530 / 544 / 532 M multiplications at c = 20 / 21 / 22,
+    // i.e. nothing to gain; 2^24 points: 2078 / 2092 / 1961 M, c = 22 saves 5.6 % (a twelfth of the additions per point
+    // for four times the buckets).
+    double best = 0;
+    int best_c = 20;
+    for (int cc = 20; cc <= 22; cc++) {
+      double cost = (double)((255 + cc - 1) / cc) * (double)n_scalars * 9.47 + 2.0 * (double)(1u << (cc - 1)) * 13.47;
+      if (cc == 20 || cost < best * 0.98) { best = cost; best_c = cc; }  // ties stay with the smaller bucket set
+    }
+    c = best_c;
+  }
+  if (const char *e = getenv("ZKR_MSM_C")) { int v = atoi(e); if (v >= 2 && v <= 22) c = v; }
   if (c_fixed) c = c_fixed;
   pl.c = c;
   pl.K = (255 + c - 1) / c;
@@ -88,38 +101,54 @@ MsmPlan msm_plan(size_t n_scalars, size_t n, int c_fixed) {
   return pl;
 }
 
-static int alloc_msm_ws(MsmWorkspace &ws, size_t n, const MsmPlan &pl, size_t xyzz_bytes) {
-  size_t nb = pl.nb;
+// cap: proofs a fused batch can hold (cap bucket sets end to end; kernels_msm.hpp msm_digits_count_kernel)
+static int alloc_msm_ws(MsmWorkspace &ws, size_t n, const MsmPlan &pl, size_t xyzz_bytes, size_t cap = 1) {
+  size_t nb = pl.nb * cap;
   ZKR_HIP_CHECK(hipMalloc(&ws.counts, (nb + 1) * 4));
   ZKR_HIP_CHECK(hipMalloc(&ws.offsets, (nb + 1) * 4));
   ZKR_HIP_CHECK(hipMalloc(&ws.size_hist, 2 * SIZE_BINS * 4));
   ZKR_HIP_CHECK(hipMalloc(&ws.order, (nb + 1) * 4));
-  ZKR_HIP_CHECK(hipMalloc(&ws.chunk_cnt, (size_t)pl.J * pl.nbw * 4 + 4));
-  ZKR_HIP_CHECK(hipMalloc(&ws.entries, (n * pl.K + 1) * 4));
+  ZKR_HIP_CHECK(hipMalloc(&ws.chunk_cnt, (size_t)pl.J * nb * 4 + 4));
+  ZKR_HIP_CHECK(hipMalloc(&ws.entries, (n * pl.K * cap + 1) * 4));
   ZKR_HIP_CHECK(hipMalloc(&ws.big_list, BIG_CAP * 4));
   ZKR_HIP_CHECK(hipMalloc(&ws.big_count, 8));
   ZKR_HIP_CHECK(hipMalloc(&ws.block_sums, (nb / SCAN_BLOCK + 2) * 4));
   ZKR_HIP_CHECK(hipMalloc(&ws.big_partials, (size_t)BIG_CAP * BIG_SPLIT * xyzz_bytes));
   ZKR_HIP_CHECK(hipMalloc(&ws.buckets, nb * xyzz_bytes));
-  ZKR_HIP_CHECK(hipMalloc(&ws.group_out, (size_t)(pl.nbw >> pl.glog) * 2 * xyzz_bytes));
-  ZKR_HIP_CHECK(hipMalloc(&ws.task_out, (size_t)(pl.c + 2) * pl.S * xyzz_bytes));
-  ZKR_HIP_CHECK(hipMalloc(&ws.result, xyzz_bytes));
-  ZKR_HIP_CHECK(hipHostMalloc(&ws.h_result, xyzz_bytes, hipHostMallocDefault));
+  ZKR_HIP_CHECK(hipMalloc(&ws.group_out, (size_t)(pl.nbw >> pl.glog) * cap * 2 * xyzz_bytes));
+  ZKR_HIP_CHECK(hipMalloc(&ws.task_out, (size_t)(pl.c + 2) * pl.S * cap * xyzz_bytes));
+  ZKR_HIP_CHECK(hipMalloc(&ws.result, xyzz_bytes * cap));
+  ZKR_HIP_CHECK(hipHostMalloc(&ws.h_result, xyzz_bytes * cap, hipHostMallocDefault));
   ws.max_nb = nb;
-  ws.max_entries = n * pl.K;
+  ws.max_entries = n * pl.K * cap;
   return 0;
 }
-int digit_lists_alloc(DigitLists &dl, size_t n_scalars, const MsmPlan &pl) {
+int digit_lists_alloc(DigitLists &dl, size_t n_scalars, const MsmPlan &pl) {  // n_scalars: of the whole (fused) vector
   ZKR_HIP_CHECK(hipMalloc(&dl.rng, (3 * MAX_RANGES + 1) * 4));
   ZKR_HIP_CHECK(hipMalloc(&dl.ent_s, (size_t)pl.K * n_scalars * 4 + 4));
   ZKR_HIP_CHECK(hipMalloc(&dl.ent_b, (size_t)pl.K * n_scalars * 4 + 4));
   return 0;
 }
+// How many proofs of this key one submit fuses into shared launches: circuits far below the size that fills the chip
+// (the reference's own tx circuit: 2^17) run every kernel over `cap` witnesses at once -- vectors end to end, `cap` bucket
+// sets per table -- so each launch has about the work of one 2^20 proof and the fixed tail of the bucket reduction is
+// paid once per batch.  Bounds: the batch's bucket ranges must fit the digit sort's MAX_RANGES lists, the fused vectors
+// stay at or below 2^20 elements, at most 16.
+int fused_capacity(const ArenaHeader &h, const MsmPlan plan[N_TABLES]) {
+  if (const char *e = getenv("ZKR_FUSE")) { int v = atoi(e); if (v >= 1 && v <= 16) { uint32_t nr = 1; for (int t = 0; t < N_TABLES; t++) nr = plan[t].nR > nr ? plan[t].nR : nr; if ((uint32_t)v * nr <= MAX_RANGES) return v; } }
+  uint32_t nr = 1;
+  for (int t = 0; t < N_TABLES; t++) nr = plan[t].nR > nr ? plan[t].nR : nr;
+  uint32_t cap = MAX_RANGES / nr;
+  uint32_t by_size = h.m >= (1u << 20) ? 1u : (1u << 20) / h.m;
+  if (cap > by_size) cap = by_size;
+  if (cap > 16) cap = 16;
+  return cap < 1 ? 1 : (int)cap;
+}
 void digit_lists_free(DigitLists &dl) {
   hipFree(dl.rng); hipFree(dl.ent_s); hipFree(dl.ent_b);
   dl = DigitLists();
 }
-int msm_ws_alloc(MsmWorkspace &ws, size_t n, const MsmPlan &pl, size_t xyzz_bytes) { return alloc_msm_ws(ws, n, pl, xyzz_bytes); }
+int msm_ws_alloc(MsmWorkspace &ws, size_t n, const MsmPlan &pl, size_t xyzz_bytes) { return alloc_msm_ws(ws, n, pl, xyzz_bytes, 1); }
 void msm_ws_free(MsmWorkspace &ws) {
   hipFree(ws.counts); hipFree(ws.offsets); hipFree(ws.chunk_cnt); hipFree(ws.size_hist); hipFree(ws.order); digit_lists_free(ws.own_dig); hipFree(ws.entries); hipFree(ws.big_list); hipFree(ws.big_count); hipFree(ws.block_sums); hipFree(ws.big_partials);
   hipFree(ws.buckets); hipFree(ws.group_out); hipFree(ws.task_out); hipFree(ws.result);
@@ -137,14 +166,17 @@ int key_alloc_workspace(zkr_key *k) {
   if (getenv("ZKR_NO_PRIO")) prio_hi = prio_lo;
   ZKR_HIP_CHECK(hipStreamCreateWithPriority(&k->stream, hipStreamNonBlocking, prio_lo));
   ZKR_HIP_CHECK(hipStreamCreateWithPriority(&k->prep_stream, hipStreamNonBlocking, prio_hi));
-  ZKR_HIP_CHECK(hipStreamCreateWithPriority(&k->copy_stream, hipStreamNonBlocking, prio_hi));
   // reduction streams: the chains of one proof add up to ~6 ms of serialised launches, so on a single in-order
   // stream they, not the accumulations, set the pace with two proofs in flight (94 vs 106 proofs/s with two)
   k->n_red = 2;
   if (const char *e = getenv("ZKR_RED_STREAMS")) { int v = atoi(e); if (v >= 1 && v <= N_TABLES) k->n_red = v; }
   for (int j = 0; j < k->n_red; j++) ZKR_HIP_CHECK(hipStreamCreateWithPriority(&k->red_stream[j], hipStreamNonBlocking, prio_hi));
   for (int t = 0; t < N_TABLES; t++) k->plan[t] = msm_plan(t == T_H ? h.m : h.n, h.npts[t], (int)h.win_c[t]);
+  const size_t cap = (size_t)fused_capacity(h, k->plan);
   for (ProofSlot &sl : k->slot) {
+    sl.cap = (int)cap;
+    sl.rb.assign(32 * cap, 0);
+    sl.sb.assign(32 * cap, 0);
     for (int t = 0; t < N_TABLES; t++) {
       ZKR_HIP_CHECK(hipEventCreateWithFlags(&sl.ev_done[t], hipEventDisableTiming));
       ZKR_HIP_CHECK(hipEventCreateWithFlags(&sl.ev_sorted[t], hipEventDisableTiming));
@@ -152,15 +184,15 @@ int key_alloc_workspace(zkr_key *k) {
     ZKR_HIP_CHECK(hipEventCreateWithFlags(&sl.ev_w, hipEventDisableTiming));
     ZKR_HIP_CHECK(hipEventCreateWithFlags(&sl.ev_h, hipEventDisableTiming));
     for (int j = 0; j < k->n_red; j++) ZKR_HIP_CHECK(hipEventCreateWithFlags(&sl.ev_red[j], hipEventDisableTiming));
-    ZKR_HIP_CHECK(hipMalloc(&sl.d_w, (size_t)h.n * 32));
+    ZKR_HIP_CHECK(hipMalloc(&sl.d_w, (size_t)h.n * 32 * cap));
     Fr **vecs[5] = {&sl.va, &sl.vb, &sl.ca, &sl.cb, &sl.d_h};
-    for (auto v : vecs) ZKR_HIP_CHECK(hipMalloc(v, (size_t)h.m * 32));
+    for (auto v : vecs) ZKR_HIP_CHECK(hipMalloc(v, (size_t)h.m * 32 * cap));
     for (int t = 0; t < N_TABLES; t++) {
-      int rc = alloc_msm_ws(sl.ws[t], h.npts[t], k->plan[t], t == T_B2 ? sizeof(G2XYZZ) : sizeof(G1XYZZ));
+      int rc = alloc_msm_ws(sl.ws[t], h.npts[t], k->plan[t], t == T_B2 ? sizeof(G2XYZZ) : sizeof(G1XYZZ), cap);
       if (rc) return rc;
     }
-    int rc = digit_lists_alloc(sl.dig_w, h.n, k->plan[T_A]);
-    if (!rc) rc = digit_lists_alloc(sl.dig_h, h.m, k->plan[T_H]);
+    int rc = digit_lists_alloc(sl.dig_w, (size_t)h.n * cap, k->plan[T_A]);
+    if (!rc) rc = digit_lists_alloc(sl.dig_h, (size_t)h.m * cap, k->plan[T_H]);
     if (rc) return rc;
   }
   // host-side window tables of delta_1 / delta_2 for the proof assembly (a few milliseconds; kept out of the first proof)
@@ -486,7 +518,7 @@ int zkr_key_load_websnark(const void *pk_bin, size_t pk_len, int device, zkr_key
 void zkr_key_free(zkr_key *k) {
   if (!k) return;
   hipSetDevice(k->device);
-  hipStream_t streams[3 + N_TABLES] = {k->stream, k->prep_stream, k->copy_stream, k->red_stream[0], k->red_stream[1], k->red_stream[2], k->red_stream[3], k->red_stream[4]};
+  hipStream_t streams[2 + N_TABLES] = {k->stream, k->prep_stream, k->red_stream[0], k->red_stream[1], k->red_stream[2], k->red_stream[3], k->red_stream[4]};
   for (hipStream_t st : streams)
     if (st) hipStreamSynchronize(st);
   for (ProofSlot &sl : k->slot) {
@@ -523,6 +555,7 @@ int zkr_key_info(const zkr_key *k, uint64_t out[10]) {
 }
 
 int zkr_key_slots(const zkr_key *k) { return k ? PROOF_SLOTS : 0; }
+int zkr_key_fuse(const zkr_key *k) { return k ? k->slot[0].cap : 0; }
 
 int zkr_key_windows(const zkr_key *k, uint32_t c_out[5], uint32_t k_out[5]) {
   if (!k || !c_out || !k_out) { set_error("null argument"); return ZKR_ERR_ARG; }

@@ -88,7 +88,7 @@ static std::vector<PassSpec> ntt_plan(int L) {
   return v;
 }
 
-int run_ntt(hipStream_t s, const Fr *in0, const Fr *in1, Fr *out, const Fr *tw, const Fr *twl, int tlog, int L, bool dif, bool inverse, int pre) {
+int run_ntt(hipStream_t s, const Fr *in0, const Fr *in1, Fr *out, const Fr *tw, const Fr *twl, int tlog, int L, bool dif, bool inverse, int pre, int nbat) {
   std::vector<PassSpec> plan = ntt_plan(L);
   if (!dif) std::reverse(plan.begin(), plan.end());
   bool first = true;
@@ -104,8 +104,8 @@ int run_ntt(hipStream_t s, const Fr *in0, const Fr *in1, Fr *out, const Fr *tw, 
     uint32_t tile = 1u << (ps.hi - ps.lo + ps.wlog);
     uint32_t grid = (1u << L) / tile;
     size_t lds = (size_t)tile * 32;
-    if (dif) ntt_pass_kernel<true><<<grid, NTT_THREADS, lds, s>>>(a);
-    else ntt_pass_kernel<false><<<grid, NTT_THREADS, lds, s>>>(a);
+    if (dif) ntt_pass_kernel<true><<<dim3(grid, nbat), NTT_THREADS, lds, s>>>(a);
+    else ntt_pass_kernel<false><<<dim3(grid, nbat), NTT_THREADS, lds, s>>>(a);
     first = false;
   }
   ZKR_HIP_CHECK(hipGetLastError());
@@ -120,7 +120,7 @@ static Fr fr_from_u64(uint64_t x) {
 }
 
 // d_w (std, reduced) -> d_h (std, bit-reversed order).  See DESIGN.md "calcH on the GPU".
-int calc_h_device(zkr_key *k, ProofSlot &sl, hipStream_t s) {
+int calc_h_device(zkr_key *k, ProofSlot &sl, hipStream_t s, int nbat) {
   const Prof pf{k, &sl};
   const ArenaHeader &h = k->h;
   const unsigned char *ar = k->arena;
@@ -132,20 +132,20 @@ int calc_h_device(zkr_key *k, ProofSlot &sl, hipStream_t s) {
   for (int i = 0; i < 2; i++) {
     const uint32_t *rp = (const uint32_t *)(ar + h.off_rowptr[i]), *cl = (const uint32_t *)(ar + h.off_col[i]);
     const Fr *cf = (const Fr *)(ar + h.off_coef[i]);
-    spmv_kernel<<<(m + 255) / 256, 256, 0, s>>>(rp, cl, cf, sl.d_w, evals[i], m);
-    if (h.n_wide[i]) spmv_wide_kernel<<<h.n_wide[i], 64, 0, s>>>(rp, cl, cf, sl.d_w, evals[i], (const uint32_t *)(ar + h.off_wide[i]), h.n_wide[i]);
+    spmv_kernel<<<dim3((m + 255) / 256, nbat), 256, 0, s>>>(rp, cl, cf, sl.d_w, evals[i], m, h.n);
+    if (h.n_wide[i]) spmv_wide_kernel<<<dim3(h.n_wide[i], nbat), 64, 0, s>>>(rp, cl, cf, sl.d_w, evals[i], (const uint32_t *)(ar + h.off_wide[i]), h.n_wide[i], m, h.n);
   }
   prof_end(pf, s, sp);
   sp = prof_begin(pf, s, "ntt");
   int rc;
   // coefficients (x m, bit-reversed), then evaluations on the coset g*w^c (x m, natural)
-  if ((rc = run_ntt(s, sl.va, nullptr, sl.ca, tw, twl, tlog, L, true, true, PRE_NONE))) return rc;
-  if ((rc = run_ntt(s, sl.vb, nullptr, sl.cb, tw, twl, tlog, L, true, true, PRE_NONE))) return rc;
-  if ((rc = run_ntt(s, sl.ca, nullptr, sl.ca, tw, twl, tlog, L, false, false, PRE_COSET))) return rc;
-  if ((rc = run_ntt(s, sl.cb, nullptr, sl.cb, tw, twl, tlog, L, false, false, PRE_COSET))) return rc;
+  if ((rc = run_ntt(s, sl.va, nullptr, sl.ca, tw, twl, tlog, L, true, true, PRE_NONE, nbat))) return rc;
+  if ((rc = run_ntt(s, sl.vb, nullptr, sl.cb, tw, twl, tlog, L, true, true, PRE_NONE, nbat))) return rc;
+  if ((rc = run_ntt(s, sl.ca, nullptr, sl.ca, tw, twl, tlog, L, false, false, PRE_COSET, nbat))) return rc;
+  if ((rc = run_ntt(s, sl.cb, nullptr, sl.cb, tw, twl, tlog, L, false, false, PRE_COSET, nbat))) return rc;
   // D' = iNTT(A(gw^c).B(gw^c)) and S' = iNTT(a.b), both unscaled and bit-reversed
-  if ((rc = run_ntt(s, sl.ca, sl.cb, sl.ca, tw, twl, tlog, L, true, true, PRE_MUL))) return rc;
-  if ((rc = run_ntt(s, sl.va, sl.vb, sl.va, tw, twl, tlog, L, true, true, PRE_MUL))) return rc;
+  if ((rc = run_ntt(s, sl.ca, sl.cb, sl.ca, tw, twl, tlog, L, true, true, PRE_MUL, nbat))) return rc;
+  if ((rc = run_ntt(s, sl.va, sl.vb, sl.va, tw, twl, tlog, L, true, true, PRE_MUL, nbat))) return rc;
   // constants: S' = m S / R, D' = m^3 D g^i / R  ->  h = S'*R^2/(2m) (*1/R)  -  D' g^-i * R^2/(2 m^3) (*1/R)
   Fr r2 = Fr::r2();
   Fr minv = inv(to_mont(fr_from_u64(m)));        // Montgomery(1/m)
@@ -154,7 +154,7 @@ int calc_h_device(zkr_key *k, ProofSlot &sl, hipStream_t s) {
   // r2 is the integer R^2 mod r = Montgomery(R).  mul(r2, half) = Montgomery(R/2); times minv = Montgomery(R/(2m)).
   // We need the plain integer R^2/(2m) = Montgomery(R/(2m)) exactly, so c1v is already the constant to pass.
   Fr c2v = mul(mul(c1v, minv), minv);            // Montgomery(R/(2m^3)) = integer R^2/(2m^3)
-  combine_h_kernel<<<(m + 255) / 256, 256, 0, s>>>(sl.va, sl.ca, sl.d_h, tw, tlog, L, c1v, c2v);
+  combine_h_kernel<<<dim3((m + 255) / 256, nbat), 256, 0, s>>>(sl.va, sl.ca, sl.d_h, tw, tlog, L, c1v, c2v);
   prof_end(pf, s, sp);
   ZKR_HIP_CHECK(hipGetLastError());
   return 0;
@@ -167,38 +167,42 @@ template <> struct MsmCfg<Fq2> { static constexpr int ACC_W = 2, RED_W = 1; stat
   static constexpr const char *ACC_STAGE = "msm_accum_g2"; };
 
 // digit records of one scalar vector, split by bucket range; shared by every table over those scalars
-static int msm_digits_enqueue(Prof pf, hipStream_t s, const Fr *scalars, uint32_t n, const MsmPlan &pl, const DigitLists &dl) {
-  if (n == 0) return 0;
+// nbat vectors of n scalars end to end (fused batch; nbat = 1: one proof)
+static int msm_digits_enqueue(Prof pf, hipStream_t s, const Fr *scalars, uint32_t n_per, int nbat, const MsmPlan &pl, const DigitLists &dl) {
+  if (n_per == 0) return 0;
+  const uint32_t n = n_per * (uint32_t)nbat, nR = pl.nR * (uint32_t)nbat;
   int nbl_log = 0;
   while ((1u << nbl_log) < pl.nbl) nbl_log++;
   int sp = prof_begin(pf, s, "msm_sort");
   ZKR_HIP_CHECK(hipMemsetAsync(dl.rng, 0, 2 * MAX_RANGES * 4, s));
   unsigned grid = (n + MSM_THREADS - 1) / MSM_THREADS;
-  msm_digits_count_kernel<<<grid, MSM_THREADS, 0, s>>>(scalars, n, pl.c, pl.K, nbl_log, pl.nR, dl.rng);
-  msm_digits_scatter_kernel<<<grid, MSM_THREADS, 0, s>>>(scalars, n, pl.c, pl.K, nbl_log, pl.nR, dl.rng, dl.rng + MAX_RANGES, dl.rng + 2 * MAX_RANGES, dl.ent_s, dl.ent_b);
+  msm_digits_count_kernel<<<grid, MSM_THREADS, 0, s>>>(scalars, n, n_per, pl.c, pl.K, nbl_log, pl.nR, nR, dl.rng);
+  msm_digits_scatter_kernel<<<grid, MSM_THREADS, 0, s>>>(scalars, n, n_per, pl.c, pl.K, nbl_log, pl.nR, nR, dl.rng, dl.rng + MAX_RANGES, dl.rng + 2 * MAX_RANGES, dl.ent_s, dl.ent_b);
   prof_end(pf, s, sp);
   ZKR_HIP_CHECK(hipGetLastError());
   return 0;
 }
 
 // digit sort of one table: LDS histogram per (window, chunk) -> scans -> LDS-cursor scatter
-static int msm_sort_enqueue(Prof pf, hipStream_t s, const uint32_t *rank, const DigitLists &dl, uint32_t n, const MsmPlan &pl, MsmWorkspace &ws) {
+// n_scalars: scalars per proof (the records carry indices into the concatenated vectors of the batch); n: points of the table
+static int msm_sort_enqueue(Prof pf, hipStream_t s, const uint32_t *rank, const DigitLists &dl, uint32_t n_scalars, uint32_t n, int nbat, const MsmPlan &pl, MsmWorkspace &ws) {
   if (n == 0) return 0;
   int sp = prof_begin(pf, s, "msm_sort");
   ZKR_HIP_CHECK(hipMemsetAsync(ws.big_count, 0, 8, s));
   ZKR_HIP_CHECK(hipMemsetAsync(ws.size_hist, 0, 2 * SIZE_BINS * 4, s));
-  const unsigned sort_grid = pl.nR * pl.J;
+  const uint32_t nb = pl.nb * (uint32_t)nbat;  // the bucket sets of the batch end to end
+  const unsigned sort_grid = pl.nR * (unsigned)nbat * pl.J;
   const size_t lds = (size_t)pl.nbl * 4;
   const uint32_t *rng_off = dl.rng + 2 * MAX_RANGES;
-  msm_hist_kernel<<<sort_grid, SORT_THREADS, lds, s>>>(dl.ent_s, dl.ent_b, rng_off, rank, pl.nbl, pl.J, ws.chunk_cnt);
-  msm_colscan_kernel<<<(pl.nb + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, s>>>(ws.chunk_cnt, pl.nb, pl.nbl, pl.J, ws.counts);
-  unsigned scan_blocks = (pl.nb + SCAN_BLOCK - 1) / SCAN_BLOCK;
-  msm_scan_sums_kernel<<<scan_blocks, SCAN_THREADS, 0, s>>>(ws.counts, pl.nb, ws.block_sums);
+  msm_hist_kernel<<<sort_grid, SORT_THREADS, lds, s>>>(dl.ent_s, dl.ent_b, rng_off, rank, n_scalars, pl.nbl, pl.J, ws.chunk_cnt);
+  msm_colscan_kernel<<<(nb + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, s>>>(ws.chunk_cnt, nb, pl.nbl, pl.J, ws.counts);
+  unsigned scan_blocks = (nb + SCAN_BLOCK - 1) / SCAN_BLOCK;
+  msm_scan_sums_kernel<<<scan_blocks, SCAN_THREADS, 0, s>>>(ws.counts, nb, ws.block_sums);
   msm_scan_top_kernel<<<1, 1024, 0, s>>>(ws.block_sums, scan_blocks, ws.big_count + 1);
-  msm_scan_apply_kernel<<<scan_blocks, SCAN_THREADS, 0, s>>>(ws.counts, ws.block_sums, ws.big_count + 1, ws.offsets, pl.nb, pl.big_thresh,
+  msm_scan_apply_kernel<<<scan_blocks, SCAN_THREADS, 0, s>>>(ws.counts, ws.block_sums, ws.big_count + 1, ws.offsets, nb, pl.big_thresh,
                                                             ws.big_list, ws.big_count, BIG_CAP, ws.size_hist);
-  msm_order_kernel<<<scan_blocks, SCAN_THREADS, 0, s>>>(ws.counts, pl.nb, ws.size_hist, ws.size_hist + SIZE_BINS, ws.order);
-  msm_scatter_kernel<<<sort_grid, SORT_THREADS, lds, s>>>(dl.ent_s, dl.ent_b, rng_off, rank, n, pl.nbl, pl.J, ws.chunk_cnt, ws.offsets, ws.entries);
+  msm_order_kernel<<<scan_blocks, SCAN_THREADS, 0, s>>>(ws.counts, nb, ws.size_hist, ws.size_hist + SIZE_BINS, ws.order);
+  msm_scatter_kernel<<<sort_grid, SORT_THREADS, lds, s>>>(dl.ent_s, dl.ent_b, rng_off, rank, n_scalars, n, pl.nbl, pl.J, ws.chunk_cnt, ws.offsets, ws.entries);
   prof_end(pf, s, sp);
   ZKR_HIP_CHECK(hipGetLastError());
   return 0;
@@ -207,8 +211,9 @@ static int msm_sort_enqueue(Prof pf, hipStream_t s, const uint32_t *rank, const 
 // bucket accumulation of one point table over a finished sort (`srt` may belong to another table with the
 // same point set: B1 and B2 share one)
 template <class F>
-static int msm_accum_enqueue(Prof pf, hipStream_t s, const Affine<F> *pts, uint32_t n, const MsmPlan &pl, const MsmWorkspace &srt, MsmWorkspace &ws) {
+static int msm_accum_enqueue(Prof pf, hipStream_t s, const Affine<F> *pts, uint32_t n, int nbat, const MsmPlan &pl, const MsmWorkspace &srt, MsmWorkspace &ws) {
   if (n == 0) return 0;
+  const uint32_t nb = pl.nb * (uint32_t)nbat;
   int sp = prof_begin(pf, s, MsmCfg<F>::ACC_STAGE);
   // waves per SIMD the compiler budgets registers for (amdgpu_waves_per_eu): measured best at 2 for both G1
   // (115 G Fq-mul/s isolated vs 112 at 3 and 103 at 4; 92 vs 88 proofs/s) and G2; ZKR_ACC_W_G1 / ZKR_ACC_W_G2 override for experiments
@@ -216,10 +221,10 @@ static int msm_accum_enqueue(Prof pf, hipStream_t s, const Affine<F> *pts, uint3
   static const int acc_w = acc_env ? atoi(acc_env) : MsmCfg<F>::ACC_W;
   // small bucket sets: several lanes per bucket (kernels_msm.hpp msm_accum_split_kernel)
   static const char *split_env = getenv("ZKR_ACC_SPLIT");
-  const int split = split_env ? atoi(split_env) : pl.nb <= (1u << 17) ? 4 : 1;  // tx circuit (2^16 buckets): 379 / 455 / 458 / 393 proofs/s at 1 / 2 / 4 / 8
+  const int split = split_env ? atoi(split_env) : nb <= (1u << 17) ? 4 : 1;  // tx circuit (2^16 buckets): 379 / 455 / 458 / 393 proofs/s at 1 / 2 / 4 / 8
   if (split > 1) {
-    const unsigned sgrid = (unsigned)(((size_t)pl.nb * split + ACC_THREADS - 1) / ACC_THREADS);
-#define ZKR_ACC_SPLIT_LAUNCH(SP) msm_accum_split_kernel<F, MsmCfg<F>::ACC_W, SP><<<sgrid, ACC_THREADS, 0, s>>>(pts, srt.offsets, srt.entries, pl.nb, srt.counts, srt.order, (XYZZ<F> *)ws.buckets)
+    const unsigned sgrid = (unsigned)(((size_t)nb * split + ACC_THREADS - 1) / ACC_THREADS);
+#define ZKR_ACC_SPLIT_LAUNCH(SP) msm_accum_split_kernel<F, MsmCfg<F>::ACC_W, SP><<<sgrid, ACC_THREADS, 0, s>>>(pts, srt.offsets, srt.entries, nb, srt.counts, srt.order, (XYZZ<F> *)ws.buckets)
     switch (split) {
       case 2: ZKR_ACC_SPLIT_LAUNCH(2); break;
       case 8: ZKR_ACC_SPLIT_LAUNCH(8); break;
@@ -230,8 +235,8 @@ static int msm_accum_enqueue(Prof pf, hipStream_t s, const Affine<F> *pts, uint3
     ZKR_HIP_CHECK(hipGetLastError());
     return 0;
   }
-  const unsigned grid = (pl.nb + ACC_THREADS - 1) / ACC_THREADS;
-#define ZKR_ACC_LAUNCH(W) msm_accum_kernel<F, W, MsmCfg<F>::ACC_PREFETCH><<<grid, ACC_THREADS, 0, s>>>(pts, srt.offsets, srt.entries, pl.nb, srt.counts, srt.order, (XYZZ<F> *)ws.buckets)
+  const unsigned grid = (nb + ACC_THREADS - 1) / ACC_THREADS;
+#define ZKR_ACC_LAUNCH(W) msm_accum_kernel<F, W, MsmCfg<F>::ACC_PREFETCH><<<grid, ACC_THREADS, 0, s>>>(pts, srt.offsets, srt.entries, nb, srt.counts, srt.order, (XYZZ<F> *)ws.buckets)
   switch (acc_w) {
     case 1: ZKR_ACC_LAUNCH(1); break;
     case 3: ZKR_ACC_LAUNCH(3); break;
@@ -259,21 +264,21 @@ static int msm_big_enqueue(Prof pf, hipStream_t s, const Affine<F> *pts, uint32_
 // big-bucket partial sums -> buckets, bucket reduction -> the MSM result in ws.h_result: short launches of few,
 // long-running wavefronts (raised wave priority), meant to run beside the next table's accumulation
 template <class F>
-static int msm_reduce_enqueue(Prof pf, hipStream_t s, uint32_t n, const MsmPlan &pl, const MsmWorkspace &srt, MsmWorkspace &ws) {
+static int msm_reduce_enqueue(Prof pf, hipStream_t s, uint32_t n, int nbat, const MsmPlan &pl, const MsmWorkspace &srt, MsmWorkspace &ws) {
   if (n == 0) return 0;
   MsmGeom g;
-  g.n = n; g.c = pl.c; g.K = pl.K; g.nbw = pl.nbw; g.big_thresh = pl.big_thresh; g.glog = pl.glog; g.S = pl.S;
+  g.n = n; g.c = pl.c; g.K = pl.K; g.nbw = pl.nbw; g.big_thresh = pl.big_thresh; g.glog = pl.glog; g.S = pl.S; g.batch = (uint32_t)nbat;
   int sp = prof_begin(pf, s, "msm_big");
   msm_big_finish_kernel<F, MsmCfg<F>::RED_W><<<BIG_CAP / 64, 64, 0, s>>>((const XYZZ<F> *)ws.big_partials, srt.big_list, srt.big_count, BIG_CAP, (XYZZ<F> *)ws.buckets);
   prof_end(pf, s, sp);
   sp = prof_begin(pf, s, "msm_reduce");
-  uint32_t ngroups = pl.nbw >> pl.glog;
+  uint32_t ngroups = (pl.nbw >> pl.glog) * (uint32_t)nbat;
   uint32_t ntask = (uint32_t)(pl.c - 1 - pl.glog) + 2;
   msm_reduce1_kernel<F, MsmCfg<F>::RED_W><<<(ngroups + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, s>>>((const XYZZ<F> *)ws.buckets, g, (XYZZ<F> *)ws.group_out);
-  msm_reduce2_kernel<F, MsmCfg<F>::RED_W><<<ntask * pl.S, MSM_THREADS, MSM_THREADS * sizeof(XYZZ<F>), s>>>((const XYZZ<F> *)ws.group_out, g, (XYZZ<F> *)ws.task_out);
-  msm_reduce3_kernel<F, MsmCfg<F>::RED_W><<<1, MSM_THREADS, MSM_THREADS * sizeof(XYZZ<F>), s>>>((const XYZZ<F> *)ws.task_out, g, (XYZZ<F> *)ws.result);
+  msm_reduce2_kernel<F, MsmCfg<F>::RED_W><<<dim3(ntask * pl.S, nbat), MSM_THREADS, MSM_THREADS * sizeof(XYZZ<F>), s>>>((const XYZZ<F> *)ws.group_out, g, (XYZZ<F> *)ws.task_out);
+  msm_reduce3_kernel<F, MsmCfg<F>::RED_W><<<nbat, MSM_THREADS, MSM_THREADS * sizeof(XYZZ<F>), s>>>((const XYZZ<F> *)ws.task_out, g, (XYZZ<F> *)ws.result);
   prof_end(pf, s, sp);
-  ZKR_HIP_CHECK(hipMemcpyAsync(ws.h_result, ws.result, sizeof(XYZZ<F>), hipMemcpyDeviceToHost, s));
+  ZKR_HIP_CHECK(hipMemcpyAsync(ws.h_result, ws.result, sizeof(XYZZ<F>) * nbat, hipMemcpyDeviceToHost, s));
   ZKR_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -284,18 +289,18 @@ static int msm_enqueue(Prof pf, hipStream_t s, const Affine<F> *pts, const uint3
                        const MsmPlan &pl, MsmWorkspace &ws) {
   int rc;
   if (!ws.own_dig.rng && (rc = digit_lists_alloc(ws.own_dig, n_scalars, pl))) return rc;
-  if ((rc = msm_digits_enqueue(pf, s, scalars, n_scalars, pl, ws.own_dig))) return rc;
-  if ((rc = msm_sort_enqueue(pf, s, rank, ws.own_dig, n, pl, ws))) return rc;
+  if ((rc = msm_digits_enqueue(pf, s, scalars, n_scalars, 1, pl, ws.own_dig))) return rc;
+  if ((rc = msm_sort_enqueue(pf, s, rank, ws.own_dig, n_scalars, n, 1, pl, ws))) return rc;
   if ((rc = msm_big_enqueue<F>(pf, s, pts, n, pl, ws, ws))) return rc;
-  if ((rc = msm_accum_enqueue<F>(pf, s, pts, n, pl, ws, ws))) return rc;
-  return msm_reduce_enqueue<F>(pf, s, n, pl, ws, ws);
+  if ((rc = msm_accum_enqueue<F>(pf, s, pts, n, 1, pl, ws, ws))) return rc;
+  return msm_reduce_enqueue<F>(pf, s, n, 1, pl, ws, ws);
 }
 
 // the MSM result point as the reduction left it in the pinned host buffer
 template <class F>
-static XYZZ<F> msm_finish(uint32_t n, const MsmWorkspace &ws) {
+static XYZZ<F> msm_finish(uint32_t n, const MsmWorkspace &ws, int j = 0) {  // j: proof of a fused batch
   if (n == 0) return XYZZ<F>::inf();
-  return *(const XYZZ<F> *)ws.h_result;
+  return ((const XYZZ<F> *)ws.h_result)[j];
 }
 
 static bool u256_lt(const uint32_t *a, const uint32_t *b) {
@@ -318,14 +323,16 @@ static int draw_blinding(uint8_t out[32]) {
   return 0;
 }
 
-static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *d_wsrc, const uint8_t *r32, const uint8_t *s32, hipStream_t caller, hipEvent_t ready);
+static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *const *d_wsrcs, int nbat, const uint8_t *r32s, const uint8_t *s32s, hipStream_t caller, const hipEvent_t *readies);
 
 // Enqueue the whole GPU side of one proof on the slot's buffers; returns without waiting.  If the enqueue fails part
 // way, kernels already launched still use the slot's buffers while the slot stays marked free: the key's streams are
 // drained before the error is returned, so the next submit (possibly from another host thread) cannot race with them.
-// ready: the event after which the witness is in place (a staged upload); null: whatever is enqueued on `caller` now.
-static int prove_submit(zkr_key *k, ProofSlot &sl, const Fr *d_wsrc, const uint8_t *r32, const uint8_t *s32, hipStream_t caller, hipEvent_t ready = nullptr) {
-  int rc = prove_submit_enqueue(k, sl, d_wsrc, r32, s32, caller, ready);
+// nbat witnesses (1 <= nbat <= sl.cap: a fused batch shares every launch); r32s / s32s: nbat x 32 B or both
+// null (drawn per proof).  readies[j]: the event after which witness j is in place (a staged upload); readies == null:
+// whatever is enqueued on `caller` now.
+static int prove_submit_group(zkr_key *k, ProofSlot &sl, const Fr *const *d_wsrcs, int nbat, const uint8_t *r32s, const uint8_t *s32s, hipStream_t caller, const hipEvent_t *readies = nullptr) {
+  int rc = prove_submit_enqueue(k, sl, d_wsrcs, nbat, r32s, s32s, caller, readies);
   if (rc && rc != ZKR_ERR_ARG) {  // ZKR_ERR_ARG: refused before the first launch
     hipStreamSynchronize(k->stream);
     hipStreamSynchronize(k->prep_stream);
@@ -335,22 +342,32 @@ static int prove_submit(zkr_key *k, ProofSlot &sl, const Fr *d_wsrc, const uint8
   }
   return rc;
 }
+// one proof
+static int prove_submit(zkr_key *k, ProofSlot &sl, const Fr *d_wsrc, const uint8_t *r32, const uint8_t *s32, hipStream_t caller, hipEvent_t ready = nullptr) {
+  return prove_submit_group(k, sl, &d_wsrc, 1, r32, s32, caller, ready ? &ready : nullptr);
+}
 
-static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *d_wsrc, const uint8_t *r32, const uint8_t *s32, hipStream_t caller, hipEvent_t ready) {
+static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *const *d_wsrcs, int nbat, const uint8_t *r32s, const uint8_t *s32s, hipStream_t caller, const hipEvent_t *readies) {
   ZKR_HIP_CHECK(hipSetDevice(k->device));
   const ArenaHeader &h = k->h;
   const unsigned char *ar = k->arena;
   const Prof pf{k, &sl};
-  if (r32 && s32) {
-    memcpy(sl.rb, r32, 32);
-    memcpy(sl.sb, s32, 32);
-    uint32_t rv[8], sv[8];
-    memcpy(rv, sl.rb, 32); memcpy(sv, sl.sb, 32);
-    if (!u256_lt(rv, FrParams::P) || !u256_lt(sv, FrParams::P)) { set_error("blinding scalar >= r"); return ZKR_ERR_ARG; }
-  } else if (!r32 && !s32) {
-    int rc;
-    if ((rc = draw_blinding(sl.rb)) || (rc = draw_blinding(sl.sb))) return rc;
-  } else { set_error("pass both r and s or neither"); return ZKR_ERR_ARG; }
+  if (nbat < 1 || nbat > sl.cap) { set_error("a proof slot of this key takes 1..%d proofs at once, got %d", sl.cap, nbat); return ZKR_ERR_ARG; }
+  if ((r32s == nullptr) != (s32s == nullptr)) { set_error("pass both r and s or neither"); return ZKR_ERR_ARG; }
+  for (int j = 0; j < nbat; j++) {
+    uint8_t *rb = &sl.rb[32 * j], *sb = &sl.sb[32 * j];
+    if (r32s) {
+      memcpy(rb, r32s + 32 * j, 32);
+      memcpy(sb, s32s + 32 * j, 32);
+      uint32_t rv[8], sv[8];
+      memcpy(rv, rb, 32); memcpy(sv, sb, 32);
+      if (!u256_lt(rv, FrParams::P) || !u256_lt(sv, FrParams::P)) { set_error("blinding scalar >= r"); return ZKR_ERR_ARG; }
+    } else {
+      int rc;
+      if ((rc = draw_blinding(rb)) || (rc = draw_blinding(sb))) return rc;
+    }
+  }
+  sl.nbat = nbat;
 
   // The caller's stream only orders the witness before the proof (it may carry unrelated work, and with two
   // proofs in flight it must not chain them).  Schedule on the key's own streams (HIP multiplexes streams onto a
@@ -377,15 +394,15 @@ static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *d_wsrc, con
     return k->red_stream[1 + (g1_next++ % (k->n_red - 1))];
   };
   int rc;
-  if (ready) {
-    ZKR_HIP_CHECK(hipStreamWaitEvent(sp, ready, 0));  // the staged upload of this witness has landed
+  if (readies) {
+    for (int j = 0; j < nbat; j++) ZKR_HIP_CHECK(hipStreamWaitEvent(sp, readies[j], 0));  // the staged uploads have landed
   } else {
-    ZKR_HIP_CHECK(hipEventRecord(sl.ev_w, caller));   // the witness is in place
+    ZKR_HIP_CHECK(hipEventRecord(sl.ev_w, caller));   // the witnesses are in place
     ZKR_HIP_CHECK(hipStreamWaitEvent(sp, sl.ev_w, 0));
   }
   int tot = prof_begin(pf, sp, "total");
   int spn = prof_begin(pf, sp, "ingest");
-  ingest_kernel<<<(h.n + 255) / 256, 256, 0, sp>>>(d_wsrc, sl.d_w, h.n);
+  for (int j = 0; j < nbat; j++) ingest_kernel<<<(h.n + 255) / 256, 256, 0, sp>>>(d_wsrcs[j], sl.d_w + (size_t)j * h.n, h.n);
   prof_end(pf, sp, spn);
   const DigitLists *dig[N_TABLES] = {&sl.dig_w, &sl.dig_w, &sl.dig_w, &sl.dig_w, &sl.dig_h};
   const bool share_b = h.share_b != 0 && h.npts[T_B1] == h.npts[T_B2];
@@ -393,7 +410,7 @@ static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *d_wsrc, con
   int sort_src[N_TABLES] = {T_A, T_B1, share_b ? T_B1 : T_B2, share_ac ? T_A : T_C, T_H};
   auto sort_table = [&](int t) -> int {
     const uint32_t *rank = h.rank_identity[t] ? nullptr : (const uint32_t *)(ar + h.off_rank[t]);
-    int rc = msm_sort_enqueue(pf, sp, rank, *dig[t], h.npts[t], k->plan[t], sl.ws[t]);
+    int rc = msm_sort_enqueue(pf, sp, rank, *dig[t], t == T_H ? h.m : h.n, h.npts[t], nbat, k->plan[t], sl.ws[t]);
     if (rc) return rc;
     if (!serial) ZKR_HIP_CHECK(hipEventRecord(sl.ev_sorted[t], sp));
     return 0;
@@ -409,25 +426,25 @@ static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *d_wsrc, con
     if (t == T_B2) rc = msm_big_enqueue<Fq2>(pf, rs, (const G2Affine *)pts, h.npts[t], k->plan[t], srt, sl.ws[t]);
     else rc = msm_big_enqueue<Fq>(pf, rs, (const G1Affine *)pts, h.npts[t], k->plan[t], srt, sl.ws[t]);
     if (rc) return rc;
-    if (t == T_B2) rc = msm_accum_enqueue<Fq2>(pf, s, (const G2Affine *)pts, h.npts[t], k->plan[t], srt, sl.ws[t]);
-    else rc = msm_accum_enqueue<Fq>(pf, s, (const G1Affine *)pts, h.npts[t], k->plan[t], srt, sl.ws[t]);
+    if (t == T_B2) rc = msm_accum_enqueue<Fq2>(pf, s, (const G2Affine *)pts, h.npts[t], nbat, k->plan[t], srt, sl.ws[t]);
+    else rc = msm_accum_enqueue<Fq>(pf, s, (const G1Affine *)pts, h.npts[t], nbat, k->plan[t], srt, sl.ws[t]);
     if (rc) return rc;
     if (!serial) {
       ZKR_HIP_CHECK(hipEventRecord(sl.ev_done[t], s));
       ZKR_HIP_CHECK(hipStreamWaitEvent(rs, sl.ev_done[t], 0));
     }
-    if (t == T_B2) rc = msm_reduce_enqueue<Fq2>(pf, rs, h.npts[t], k->plan[t], srt, sl.ws[t]);
-    else rc = msm_reduce_enqueue<Fq>(pf, rs, h.npts[t], k->plan[t], srt, sl.ws[t]);
+    if (t == T_B2) rc = msm_reduce_enqueue<Fq2>(pf, rs, h.npts[t], nbat, k->plan[t], srt, sl.ws[t]);
+    else rc = msm_reduce_enqueue<Fq>(pf, rs, h.npts[t], nbat, k->plan[t], srt, sl.ws[t]);
     return rc;
   };
   // preparation chain
-  if ((rc = msm_digits_enqueue(pf, sp, sl.d_w, h.n, k->plan[T_A], sl.dig_w))) return rc;
+  if ((rc = msm_digits_enqueue(pf, sp, sl.d_w, h.n, nbat, k->plan[T_A], sl.dig_w))) return rc;
   if ((rc = sort_table(T_B1))) return rc;
   if (!share_b && (rc = sort_table(T_B2))) return rc;
   if ((rc = sort_table(T_A))) return rc;
   if (!share_ac && (rc = sort_table(T_C))) return rc;
-  if ((rc = calc_h_device(k, sl, sp))) return rc;
-  if ((rc = msm_digits_enqueue(pf, sp, sl.d_h, h.m, k->plan[T_H], sl.dig_h))) return rc;
+  if ((rc = calc_h_device(k, sl, sp, nbat))) return rc;
+  if ((rc = msm_digits_enqueue(pf, sp, sl.d_h, h.m, nbat, k->plan[T_H], sl.dig_h))) return rc;
   if ((rc = sort_table(T_H))) return rc;
   // accumulations + reduction chains
   const int order[N_TABLES] = {T_B2, T_B1, T_A, T_C, T_H};
@@ -448,8 +465,9 @@ static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *d_wsrc, con
   return 0;
 }
 
-// Wait for the slot's GPU work, then the host assembly.
-static int prove_collect(zkr_key *k, ProofSlot &sl, uint8_t proof_out[256]) {
+// Wait for the slot's GPU work, then the host assembly of each of its sl.nbat proofs
+// (proofs_out: nbat x 256 B; a degenerate proof fails the whole group with its status).
+static int prove_collect(zkr_key *k, ProofSlot &sl, uint8_t *proofs_out) {
   {
     std::lock_guard<std::mutex> lk(k->mu);
     if (!sl.busy || sl.collecting) { set_error("no proof in flight in this slot"); return ZKR_ERR_ARG; }
@@ -464,35 +482,38 @@ static int prove_collect(zkr_key *k, ProofSlot &sl, uint8_t proof_out[256]) {
   static const bool serial_mode = getenv("ZKR_SERIAL") != nullptr;
   for (int j = 0; j < (serial_mode ? 1 : k->n_red); j++) ZKR_HIP_CHECK(hipEventSynchronize(sl.ev_red[j]));
   if (k->prof_on) { std::lock_guard<std::mutex> lk(k->mu); prof_collect(k, sl); }
-  const uint8_t *rb = sl.rb, *sb = sl.sb;
-  G1XYZZ A = msm_finish<Fq>(h.npts[T_A], sl.ws[T_A]);
-  G1XYZZ B1 = msm_finish<Fq>(h.npts[T_B1], sl.ws[T_B1]);
-  G2XYZZ B2 = msm_finish<Fq2>(h.npts[T_B2], sl.ws[T_B2]);
-  G1XYZZ C = msm_finish<Fq>(h.npts[T_C], sl.ws[T_C]);
-  G1XYZZ H = msm_finish<Fq>(h.npts[T_H], sl.ws[T_H]);
-  // pi_a = A + alfa + r delta;  pi_b = B2 + beta + s delta;  pi_c = C + H + s pi_a + r (B1 + beta + s delta) - r s delta
-  //      = C + H + s (A + alfa) + r (B1 + beta) + r s delta: three multiples of the key's delta (window tables) and one
-  // double multiplication of the two MSM results with shared doublings
   std::call_once(k->delta_once, [&] {
     k->delta1_tab = fixed_base_table(load_g1(h.delta1));
     k->delta2_tab = fixed_base_table(load_g2(h.delta2));
   });
   G1XYZZ alfa1 = to_xyzz(load_g1(h.alfa1)), beta1 = to_xyzz(load_g1(h.beta1));
   G2XYZZ beta2 = to_xyzz(load_g2(h.beta2));
-  U256 r = load_u256(rb), sc = load_u256(sb);
-  G1XYZZ a_alfa = add_full(A, alfa1), b_beta = add_full(B1, beta1);
-  G1XYZZ pia = add_full(a_alfa, fixed_base_mul(k->delta1_tab, r));
-  G2XYZZ pib = add_full(add_full(B2, beta2), fixed_base_mul(k->delta2_tab, sc));
-  Fr rs = mul(to_mont(load_fp<FrParams>(rb)), to_mont(load_fp<FrParams>(sb)));
-  Fr rs_std = from_mont(rs);
-  U256 rsu;
-  memcpy(rsu.v, rs_std.v, 32);
-  G1XYZZ pic = add_full(add_full(C, H), double_scalar_mul(a_alfa, sc, b_beta, r));
-  pic = add_full(pic, fixed_base_mul(k->delta1_tab, rsu));
-  if (pia.is_inf() || pib.is_inf() || pic.is_inf()) { set_error("degenerate proof element (point at infinity)"); return ZKR_ERR_DEGENERATE; }
-  store_g1_std(proof_out, to_affine(pia));
-  store_g2_std(proof_out + 64, to_affine(pib));
-  store_g1_std(proof_out + 192, to_affine(pic));
+  for (int j = 0; j < sl.nbat; j++) {
+    const uint8_t *rb = &sl.rb[32 * j], *sb = &sl.sb[32 * j];
+    uint8_t *proof_out = proofs_out + 256 * j;
+    G1XYZZ A = msm_finish<Fq>(h.npts[T_A], sl.ws[T_A], j);
+    G1XYZZ B1 = msm_finish<Fq>(h.npts[T_B1], sl.ws[T_B1], j);
+    G2XYZZ B2 = msm_finish<Fq2>(h.npts[T_B2], sl.ws[T_B2], j);
+    G1XYZZ C = msm_finish<Fq>(h.npts[T_C], sl.ws[T_C], j);
+    G1XYZZ H = msm_finish<Fq>(h.npts[T_H], sl.ws[T_H], j);
+    // pi_a = A + alfa + r delta;  pi_b = B2 + beta + s delta;  pi_c = C + H + s pi_a + r (B1 + beta + s delta) - r s delta
+    //      = C + H + s (A + alfa) + r (B1 + beta) + r s delta: three multiples of the key's delta (window tables) and one
+    // double multiplication of the two MSM results with shared doublings
+    U256 r = load_u256(rb), sc = load_u256(sb);
+    G1XYZZ a_alfa = add_full(A, alfa1), b_beta = add_full(B1, beta1);
+    G1XYZZ pia = add_full(a_alfa, fixed_base_mul(k->delta1_tab, r));
+    G2XYZZ pib = add_full(add_full(B2, beta2), fixed_base_mul(k->delta2_tab, sc));
+    Fr rs = mul(to_mont(load_fp<FrParams>(rb)), to_mont(load_fp<FrParams>(sb)));
+    Fr rs_std = from_mont(rs);
+    U256 rsu;
+    memcpy(rsu.v, rs_std.v, 32);
+    G1XYZZ pic = add_full(add_full(C, H), double_scalar_mul(a_alfa, sc, b_beta, r));
+    pic = add_full(pic, fixed_base_mul(k->delta1_tab, rsu));
+    if (pia.is_inf() || pib.is_inf() || pic.is_inf()) { set_error("degenerate proof element (point at infinity)"); return ZKR_ERR_DEGENERATE; }
+    store_g1_std(proof_out, to_affine(pia));
+    store_g2_std(proof_out + 64, to_affine(pib));
+    store_g1_std(proof_out + 192, to_affine(pic));
+  }
   return 0;
 }
 
@@ -506,10 +527,10 @@ static int stage_acquire(zkr_key *k, int *idx) {
       if (ws.busy) continue;
       if (!ws.d_w) {
         ZKR_HIP_CHECK(hipSetDevice(k->device));
-        const size_t bytes = (size_t)k->h.n * 32;
+        const size_t bytes = (size_t)k->h.n * 32 * (size_t)k->slot[0].cap;  // one fused group of witnesses
         ZKR_HIP_CHECK(hipMalloc(&ws.d_w, bytes));
         ZKR_HIP_CHECK(hipEventCreateWithFlags(&ws.ev_up, hipEventDisableTiming));
-        if (hipHostMalloc(&ws.h_pinned, bytes, hipHostMallocDefault) != hipSuccess) ws.h_pinned = nullptr;  // pageable copies still work, slower
+        if (getenv("ZKR_STAGE_PINNED") && hipHostMalloc(&ws.h_pinned, bytes, hipHostMallocDefault) != hipSuccess) ws.h_pinned = nullptr;
       }
       ws.busy = true;
       *idx = i;
@@ -522,15 +543,30 @@ static void stage_release(zkr_key *k, int idx) {
   { std::lock_guard<std::mutex> lk(k->stage_mu); k->stage[idx].busy = false; }
   k->stage_freed.notify_one();
 }
-// host witness -> pinned buffer (this thread) -> HBM (DMA on the key's copy stream); ws.ev_up fires when it has landed
-static int stage_upload(zkr_key *k, int idx, const void *witness_std, size_t len) {
+// host witness j of a group -> HBM; with `last` set ws.ev_up is recorded: it fires when the whole group has landed.
+// The copy goes on the key's preparation stream (a fifth stream would share one of the four hardware queues with the
+// accumulation or a reduction stream and serialise with it: 448 -> 365 proofs/s on the tx circuit when tried).  Default:
+// hipMemcpyAsync straight from the caller's pageable buffer -- the runtime pins the pages and DMAs from them, about 0.5 ms
+// for 32 MB, blocking only this caller thread and, unlike round 1, outside the key's lock.  ZKR_STAGE_PINNED=1: copy into
+// the stage's own pinned buffer first (2-3 ms of memcpy per 32 MB on one thread; slower for a single caller: 79.9 vs 93.9
+// proofs/s at 2^20), kept for hosts where pinning user pages on the fly is slow.
+static int stage_upload(zkr_key *k, int idx, int j, const void *witness_std, size_t len, bool last) {
   WitnessStage &ws = k->stage[idx];
   ZKR_HIP_CHECK(hipSetDevice(k->device));
+  static const bool via_pinned = getenv("ZKR_STAGE_PINNED") != nullptr;
   const void *src = witness_std;
-  if (ws.h_pinned) { memcpy(ws.h_pinned, witness_std, len); src = ws.h_pinned; }
-  ZKR_HIP_CHECK(hipMemcpyAsync(ws.d_w, src, len, hipMemcpyHostToDevice, k->copy_stream));
-  ZKR_HIP_CHECK(hipEventRecord(ws.ev_up, k->copy_stream));
+  if (via_pinned && ws.h_pinned) { memcpy((uint8_t *)ws.h_pinned + (size_t)j * len, witness_std, len); src = (uint8_t *)ws.h_pinned + (size_t)j * len; }
+  ZKR_HIP_CHECK(hipMemcpyAsync((uint8_t *)ws.d_w + (size_t)j * len, src, len, hipMemcpyHostToDevice, k->prep_stream));
+  if (last) ZKR_HIP_CHECK(hipEventRecord(ws.ev_up, k->prep_stream));
   return 0;
+}
+// proofs per submit for a batch of `count`: full groups of the key's fused capacity; a batch below two full groups is
+// cut in two halves so that two groups are in flight (the second group's preparation runs under the first's accumulations)
+static int group_size(const zkr_key *k, size_t count) {
+  const size_t cap = (size_t)k->slot[0].cap;
+  if (cap <= 1) return 1;
+  size_t g = count >= 2 * cap ? cap : (count + 1) / 2;
+  return (int)(g < 1 ? 1 : g > cap ? cap : g);
 }
 
 // Hand out a free proof slot and run `enqueue` on it under the key's lock (two host threads proving on one key --
@@ -574,32 +610,71 @@ int zkr_prove_batch(zkr_key *key, const void *const *witnesses_std, size_t witne
                     uint8_t *proofs_out) {
   if (!key || (!witnesses_std && count) || !proofs_out) { set_error("null argument"); return ZKR_ERR_ARG; }
   if (witness_len != (size_t)key->h.n * 32) { set_error("witness is %zu bytes, key expects nVars*32 = %zu", witness_len, (size_t)key->h.n * 32); return ZKR_ERR_BAD_WITNESS; }
-  // Pipeline of one host thread: the witness of proof i is staged (copy into pinned memory + DMA) BEFORE the oldest
-  // proof in flight is collected, i.e. while both proof slots compute; then the freed slot takes proof i at once.
+  for (size_t i = 0; i < count; i++)
+    if (!witnesses_std[i]) { set_error("witness %zu is null", i); return ZKR_ERR_ARG; }
+  // Pipeline of one host thread over groups of `g` proofs (g = 1 for circuits that fill the chip alone): the witnesses of
+  // the next group are staged (copy into pinned memory + DMA) BEFORE the oldest group in flight is collected, i.e. while
+  // both proof slots compute; then the freed slot takes the group at once.
+  const int g = group_size(key, count);
   int tickets[PROOF_SLOTS], stages[PROOF_SLOTS];
-  size_t index[PROOF_SLOTS];
+  size_t first[PROOF_SLOTS];
   int in_flight = 0, rc = 0;
   auto collect_oldest = [&]() {
-    int r = prove_collect(key, key->slot[tickets[0]], proofs_out + 256 * index[0]);
+    int r = prove_collect(key, key->slot[tickets[0]], proofs_out + 256 * first[0]);
     stage_release(key, stages[0]);
-    for (int j = 1; j < in_flight; j++) { tickets[j - 1] = tickets[j]; index[j - 1] = index[j]; stages[j - 1] = stages[j]; }
+    for (int j = 1; j < in_flight; j++) { tickets[j - 1] = tickets[j]; first[j - 1] = first[j]; stages[j - 1] = stages[j]; }
     in_flight--;
     return r;
   };
-  for (size_t i = 0; i < count && !rc; i++) {
-    if (!witnesses_std[i]) { set_error("witness %zu is null", i); rc = ZKR_ERR_ARG; break; }
+  for (size_t i = 0; i < count && !rc; i += (size_t)g) {
+    const int nb = (int)(count - i < (size_t)g ? count - i : (size_t)g);
     int st = -1;
     if ((rc = stage_acquire(key, &st))) break;
-    rc = stage_upload(key, st, witnesses_std[i], witness_len);
+    for (int j = 0; j < nb && !rc; j++) rc = stage_upload(key, st, j, witnesses_std[i + j], witness_len, j == nb - 1);
     if (!rc && in_flight == PROOF_SLOTS) rc = collect_oldest();
     int t = -1;
     if (!rc) rc = with_free_slot(key, true, &t, [&](ProofSlot &sl) -> int {
-      return prove_submit(key, sl, key->stage[st].d_w, r32s ? r32s + 32 * i : nullptr, s32s ? s32s + 32 * i : nullptr, key->copy_stream, key->stage[st].ev_up);
+      const Fr *src[16];
+      hipEvent_t ready[16];
+      for (int j = 0; j < nb; j++) { src[j] = key->stage[st].d_w + (size_t)j * key->h.n; ready[j] = key->stage[st].ev_up; }
+      return prove_submit_group(key, sl, src, nb, r32s ? r32s + 32 * i : nullptr, s32s ? s32s + 32 * i : nullptr, key->prep_stream, ready);
     });
-    if (rc) { hipStreamSynchronize(key->copy_stream); stage_release(key, st); break; }
-    tickets[in_flight] = t; index[in_flight] = i; stages[in_flight] = st; in_flight++;
+    if (rc) { hipStreamSynchronize(key->prep_stream); stage_release(key, st); break; }
+    tickets[in_flight] = t; first[in_flight] = i; stages[in_flight] = st; in_flight++;
   }
-  while (in_flight > 0) {  // drain, also after an error: a submitted proof must be collected to free its slot
+  while (in_flight > 0) {  // drain, also after an error: a submitted group must be collected to free its slot
+    int r = collect_oldest();
+    if (!rc) rc = r;
+  }
+  return rc;
+}
+
+int zkr_prove_batch_device(zkr_key *key, const void *const *d_witnesses_std, size_t count, const uint8_t *r32s, const uint8_t *s32s, void *stream,
+                           uint8_t *proofs_out) {
+  if (!key || (!d_witnesses_std && count) || !proofs_out) { set_error("null argument"); return ZKR_ERR_ARG; }
+  for (size_t i = 0; i < count; i++)
+    if (!d_witnesses_std[i]) { set_error("witness %zu is null", i); return ZKR_ERR_ARG; }
+  const int g = group_size(key, count);
+  int tickets[PROOF_SLOTS];
+  size_t first[PROOF_SLOTS];
+  int in_flight = 0, rc = 0;
+  auto collect_oldest = [&]() {
+    int r = prove_collect(key, key->slot[tickets[0]], proofs_out + 256 * first[0]);
+    for (int j = 1; j < in_flight; j++) { tickets[j - 1] = tickets[j]; first[j - 1] = first[j]; }
+    in_flight--;
+    return r;
+  };
+  for (size_t i = 0; i < count && !rc; i += (size_t)g) {
+    const int nb = (int)(count - i < (size_t)g ? count - i : (size_t)g);
+    if (in_flight == PROOF_SLOTS) rc = collect_oldest();
+    if (rc) break;
+    int t = -1;
+    rc = with_free_slot(key, true, &t, [&](ProofSlot &sl) -> int {
+      return prove_submit_group(key, sl, (const Fr *const *)(d_witnesses_std + i), nb, r32s ? r32s + 32 * i : nullptr, s32s ? s32s + 32 * i : nullptr, (hipStream_t)stream);
+    });
+    if (!rc) { tickets[in_flight] = t; first[in_flight] = i; in_flight++; }
+  }
+  while (in_flight > 0) {
     int r = collect_oldest();
     if (!rc) rc = r;
   }
@@ -623,12 +698,12 @@ int zkr_prove(zkr_key *key, const void *witness_std, size_t witness_len, const u
   int st = -1;
   int rc = stage_acquire(key, &st);
   if (rc) return rc;
-  rc = stage_upload(key, st, witness_std, witness_len);
+  rc = stage_upload(key, st, 0, witness_std, witness_len, true);
   int t = -1;
   if (!rc) rc = with_free_slot(key, true, &t, [&](ProofSlot &sl) -> int {
-    return prove_submit(key, sl, key->stage[st].d_w, r32, s32, key->copy_stream, key->stage[st].ev_up);
+    return prove_submit(key, sl, key->stage[st].d_w, r32, s32, key->prep_stream, key->stage[st].ev_up);
   });
-  if (rc) { hipStreamSynchronize(key->copy_stream); stage_release(key, st); return rc; }
+  if (rc) { hipStreamSynchronize(key->prep_stream); stage_release(key, st); return rc; }
   rc = prove_collect(key, key->slot[t], proof_out);
   stage_release(key, st);
   return rc;
@@ -652,7 +727,7 @@ int zkr_calc_h(zkr_key *key, const void *witness_std, size_t witness_len, void *
   if (key->h.n > key->h.m) { ZKR_HIP_CHECK(hipMalloc(&tmp, witness_len)); raw = tmp; }
   ZKR_HIP_CHECK(hipMemcpyAsync(raw, witness_std, witness_len, hipMemcpyHostToDevice, s));
   ingest_kernel<<<(key->h.n + 255) / 256, 256, 0, s>>>(raw, sl.d_w, key->h.n);
-  int rc = calc_h_device(key, sl, s);
+  int rc = calc_h_device(key, sl, s, 1);
   if (rc) return rc;
   bitrev_copy_kernel<<<(key->h.m + 255) / 256, 256, 0, s>>>(sl.d_h, sl.ca, (int)key->h.logm);
   ZKR_HIP_CHECK(hipMemcpyAsync(h_out, sl.ca, (size_t)key->h.m * 32, hipMemcpyDeviceToHost, s));

@@ -10,8 +10,10 @@ export interface ProveOptions { r?: bigint | string; s?: bigint | string; device
 export interface Bn128 {
   /** websnark-compatible: ArrayBuffers produced by binarifyWitness / binarifyProvingKey. */
   groth16GenProof(witnessBin: ArrayBuffer | Uint8Array, provingKeyBin: ArrayBuffer | Uint8Array, opts?: ProveOptions): Promise<Groth16Proof>;
-  /** Independent proofs on one key, pipelined two deep on the GPU. */
+  /** Independent proofs on one key in one native call: pipelined two deep, proofs of small circuits fused into shared launches. */
   groth16GenProofBatch(witnessBins: Array<ArrayBuffer | Uint8Array>, provingKeyBin: ArrayBuffer | Uint8Array, opts?: ProveOptions[]): Promise<Groth16Proof[]>;
+  /** The same with the key currently held on the device. */
+  proveBatch(witnessBins: Array<ArrayBuffer | Uint8Array>, opts?: ProveOptions[]): Promise<Groth16Proof[]>;
   /** Groth16 setup of circom's circuit JSON on the GPU (snarkjs setup --protocol groth); returns the verifying key JSON. */
   setup(circuitDef: any, opts?: { toxic?: Array<bigint | string> }): any;
   /** The same for a constraint system in the r1cs_bin layout (RollupCircuit.r1cs()). */

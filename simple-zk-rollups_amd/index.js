@@ -96,14 +96,29 @@ class Bn128 {
     return proofFromBytes(pb);
   }
 
-  // Independent proofs of one rollup batch on the same key.  The calls run on libuv worker threads; the library
-  // keeps two proofs in flight per key (include/zkr.h zkr_prove_submit), so the GPU work of one proof covers the
-  // reduction tail and host assembly of the previous one.  opts[i] (optional) fixes the blinding of proof i.
+  // Independent proofs of one rollup batch on the same key: ONE native call (zkr_prove_batch on a libuv worker) that
+  // pipelines uploads and proofs over the key's two workspaces and, for circuits far below the chip's size (the
+  // reference's tx circuit, 2^17), runs several proofs in shared launches.  opts[i] (optional) fixes the blinding of
+  // proof i (all or none).
   async groth16GenProofBatch(witnessBins, provingKeyBin, opts) {
     if (witnessBins.length === 0) return [];
-    const first = await this.groth16GenProof(witnessBins[0], provingKeyBin, opts && opts[0]);  // loads / caches the key
-    const rest = await Promise.all(witnessBins.slice(1).map((w, i) => this.groth16GenProof(w, provingKeyBin, opts && opts[i + 1])));
-    return [first, ...rest];
+    const a = native();
+    this._key = cachedKey(provingKeyBin, this.device);
+    this._fp = "websnark";
+    return this.proveBatch(witnessBins, opts);
+  }
+  // the same with the key currently held (after setup / loadKeyFile / a groth16GenProof call)
+  async proveBatch(witnessBins, opts) {
+    if (!this._key) throw new Error("no key loaded");
+    if (witnessBins.length === 0) return [];
+    const fixed = opts && opts.length === witnessBins.length && opts.every((o) => o && o.r !== undefined && o.s !== undefined);
+    if (opts && opts.some((o) => o && (o.r !== undefined || o.s !== undefined)) && !fixed) throw new Error("proveBatch: fix the blinding of every proof or of none");
+    const rs = fixed ? Buffer.concat(opts.map((o) => bigintToLe32(o.r))) : null;
+    const ss = fixed ? Buffer.concat(opts.map((o) => bigintToLe32(o.s))) : null;
+    const pbs = await native().proveBatch(this._key, witnessBins, rs, ss);
+    const out = [];
+    for (let i = 0; i < witnessBins.length; i++) out.push(proofFromBytes(pbs.subarray(256 * i, 256 * i + 256)));
+    return out;
   }
 
   // ---- a key held on the device without the websnark buffer in between (INTEGRATION.md section 5)

@@ -22,6 +22,7 @@ static struct {
   void (*key_free)(zkr_key *);
   int (*key_info)(const zkr_key *, uint64_t *);
   int (*prove)(zkr_key *, const void *, size_t, const uint8_t *, const uint8_t *, uint8_t *, void *);
+  int (*prove_batch)(zkr_key *, const void *const *, size_t, size_t, const uint8_t *, const uint8_t *, uint8_t *);
   int (*verify)(const void *, size_t, const uint8_t *, const void *, size_t, int *);
   int (*verify_batch)(const void *, size_t, const uint8_t *, const void *, size_t, size_t, int *);
   int (*setup_r1cs)(const void *, size_t, const uint8_t *, int, zkr_key **, void **, size_t *);
@@ -75,7 +76,7 @@ static napi_value js_load(napi_env env, napi_callback_info info) {
   *(void **)(&Z.field) = dlsym(h, name);                                        \
   if (!Z.field) return throw_msg(env, "libzkr_hip.so lacks symbol " name);
     SYM(last_error, "zkr_last_error") SYM(version, "zkr_version") SYM(device_count, "zkr_device_count")
-    SYM(key_load_websnark, "zkr_key_load_websnark") SYM(key_free, "zkr_key_free") SYM(key_info, "zkr_key_info") SYM(prove, "zkr_prove") SYM(verify, "zkr_verify") SYM(verify_batch, "zkr_verify_batch")
+    SYM(key_load_websnark, "zkr_key_load_websnark") SYM(key_free, "zkr_key_free") SYM(key_info, "zkr_key_info") SYM(prove, "zkr_prove") SYM(prove_batch, "zkr_prove_batch") SYM(verify, "zkr_verify") SYM(verify_batch, "zkr_verify_batch")
     SYM(setup_r1cs, "zkr_setup_r1cs") SYM(key_save, "zkr_key_save") SYM(key_load_file, "zkr_key_load_file") SYM(free_, "zkr_free")
     SYM(multihash, "zkr_mimcsponge_multihash") SYM(pubkey, "zkr_babyjub_pubkey") SYM(eddsa_sign, "zkr_eddsa_sign") SYM(eddsa_verify, "zkr_eddsa_verify")
     SYM(multihash_batch, "zkr_mimcsponge_multihash_batch") SYM(tree_build, "zkr_balance_tree_build")
@@ -279,6 +280,90 @@ static napi_value js_prove(napi_env env, napi_callback_info info) {
   return promise;
 }
 
+/* proveBatch(key, [witnessBin...], rs|null, ss|null) -> Promise<Buffer(256 * count)>: zkr_prove_batch on a libuv worker --
+ * uploads and proofs pipelined over the key's two workspaces, proofs of small circuits (the reference's tx circuit) fused
+ * into shared launches.  rs / ss: count x 32 bytes of blinding scalars or both null (drawn per proof). */
+typedef struct {
+  napi_async_work work;
+  napi_deferred deferred;
+  napi_ref key_ref, wits_ref;
+  zkr_key *key;
+  const void **wits;
+  size_t count, wit_len;
+  uint8_t *rs, *ss, *proofs;
+  int rc;
+  char err[512];
+} batch_job;
+
+static void batch_free(batch_job *j) {
+  free(j->wits); free(j->rs); free(j->ss); free(j->proofs); free(j);
+}
+static void batch_execute(napi_env env, void *data) {
+  (void)env;
+  batch_job *j = (batch_job *)data;
+  j->rc = Z.prove_batch(j->key, j->wits, j->wit_len, j->count, j->rs, j->ss, j->proofs);
+  if (j->rc) { strncpy(j->err, Z.last_error(), sizeof(j->err) - 1); j->err[sizeof(j->err) - 1] = 0; }
+}
+static void batch_complete(napi_env env, napi_status status, void *data) {
+  batch_job *j = (batch_job *)data;
+  napi_value v;
+  if (status == napi_ok && j->rc == 0) {
+    void *out;
+    napi_create_buffer_copy(env, 256 * j->count, j->proofs, &out, &v);
+    napi_resolve_deferred(env, j->deferred, v);
+  } else {
+    napi_value msg;
+    napi_create_string_utf8(env, j->rc ? j->err : "proof job cancelled", NAPI_AUTO_LENGTH, &msg);
+    napi_create_error(env, NULL, msg, &v);
+    napi_reject_deferred(env, j->deferred, v);
+  }
+  napi_delete_reference(env, j->key_ref);
+  napi_delete_reference(env, j->wits_ref);
+  napi_delete_async_work(env, j->work);
+  batch_free(j);
+}
+static napi_value js_prove_batch(napi_env env, napi_callback_info info) {
+  size_t argc = 4;
+  napi_value argv[4];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  if (!Z.handle) return throw_msg(env, "libzkr_hip.so not loaded");
+  if (argc < 2) return throw_msg(env, "proveBatch(key, witnessBins, rs, ss)");
+  batch_job *j = (batch_job *)calloc(1, sizeof(batch_job));
+  uint32_t count = 0;
+  if (napi_get_value_external(env, argv[0], (void **)&j->key) != napi_ok || napi_get_array_length(env, argv[1], &count) != napi_ok || count == 0) {
+    free(j);
+    return throw_msg(env, "proveBatch: a key and a non-empty array of witness buffers expected");
+  }
+  j->count = count;
+  j->wits = (const void **)calloc(count, sizeof(void *));
+  j->proofs = (uint8_t *)malloc(256 * (size_t)count);
+  for (uint32_t i = 0; i < count; i++) {
+    napi_value w;
+    const uint8_t *p;
+    size_t n;
+    if (napi_get_element(env, argv[1], i, &w) != napi_ok || !get_bytes(env, w, &p, &n) || (i && n != j->wit_len)) {
+      batch_free(j);
+      return throw_msg(env, "proveBatch: every witness must be an ArrayBuffer / Buffer / TypedArray of the same length");
+    }
+    j->wits[i] = p;
+    j->wit_len = n;
+  }
+  const uint8_t *p; size_t n;
+  if (argc >= 4 && get_bytes(env, argv[2], &p, &n) && n == 32 * (size_t)count) {
+    j->rs = (uint8_t *)malloc(n); memcpy(j->rs, p, n);
+    if (!get_bytes(env, argv[3], &p, &n) || n != 32 * (size_t)count) { batch_free(j); return throw_msg(env, "proveBatch: rs and ss must both hold 32 bytes per proof"); }
+    j->ss = (uint8_t *)malloc(n); memcpy(j->ss, p, n);
+  }
+  napi_value promise, name;
+  NAPI_OK(napi_create_promise(env, &j->deferred, &promise));
+  NAPI_OK(napi_create_reference(env, argv[0], 1, &j->key_ref));
+  NAPI_OK(napi_create_reference(env, argv[1], 1, &j->wits_ref));   /* the array keeps its witness buffers alive */
+  NAPI_OK(napi_create_string_utf8(env, "zkr_prove_batch", NAPI_AUTO_LENGTH, &name));
+  NAPI_OK(napi_create_async_work(env, NULL, name, batch_execute, batch_complete, j, &j->work));
+  NAPI_OK(napi_queue_async_work(env, j->work));
+  return promise;
+}
+
 /* verify(vkBin, proofBytes256, publicBytes) -> boolean: the Groth16 pairing check on the host (zkr_verify; groth.isValid,
  * operator/src/snarks/common.ts:30-34).  Synchronous: a few milliseconds, no GPU. */
 static napi_value js_verify(napi_env env, napi_callback_info info) {
@@ -474,6 +559,7 @@ static napi_value init(napi_env env, napi_value exports) {
       {"load", NULL, js_load, NULL, NULL, NULL, napi_default, NULL},       {"version", NULL, js_version, NULL, NULL, NULL, napi_default, NULL},
       {"keyLoad", NULL, js_key_load, NULL, NULL, NULL, napi_default, NULL}, {"keyInfo", NULL, js_key_info, NULL, NULL, NULL, napi_default, NULL},
       {"prove", NULL, js_prove, NULL, NULL, NULL, napi_default, NULL},     {"verify", NULL, js_verify, NULL, NULL, NULL, napi_default, NULL},
+      {"proveBatch", NULL, js_prove_batch, NULL, NULL, NULL, napi_default, NULL},
       {"setupR1cs", NULL, js_setup_r1cs, NULL, NULL, NULL, napi_default, NULL}, {"keySave", NULL, js_key_save, NULL, NULL, NULL, napi_default, NULL},
       {"keyLoadFile", NULL, js_key_load_file, NULL, NULL, NULL, napi_default, NULL},
       {"rollupCrypto", NULL, js_rollup_crypto, NULL, NULL, NULL, napi_default, NULL}, {"rollupCircuit", NULL, js_rollup_circuit, NULL, NULL, NULL, napi_default, NULL},

@@ -37,6 +37,8 @@ def lib():
     L.zkr_key_save.argtypes = [vp, c.c_char_p]
     L.zkr_key_load_file.argtypes = [c.c_char_p, i, c.POINTER(vp)]
     L.zkr_key_slots.argtypes = [vp]
+    L.zkr_key_fuse.argtypes = [vp]
+    L.zkr_prove_batch_device.argtypes = [vp, c.POINTER(vp), sz, u8p, u8p, vp, u8p]
     L.zkr_key_windows.argtypes = [vp, c.POINTER(c.c_uint32), c.POINTER(c.c_uint32)]
     L.zkr_key_arena.argtypes = [vp, c.POINTER(vp), c.POINTER(sz)]
     L.zkr_key_adopt_arena.argtypes = [vp, sz, i, c.POINTER(vp)]
@@ -241,11 +243,22 @@ class ProvingKey:
         return out.raw
 
     def prove_batch_device(self, d_witness_ptrs, rs=None, ss=None, stream=None, depth=None):
-        """Independent proofs of one batch, pipelined: up to `depth` proofs (default: every proof slot of the key) are
-        submitted before the oldest is collected."""
+        """Independent proofs of one batch from witnesses resident in HBM (zkr_prove_batch_device): two submits in flight,
+        proofs of small circuits fused into shared launches (fuse() per submit).  depth (or env ZKR_PIPELINE_DEPTH) selects
+        the unfused submit / collect loop with that many single proofs in flight instead."""
         import collections
         import os
-        depth = depth or int(os.environ.get("ZKR_PIPELINE_DEPTH", "0")) or self.slots()
+        depth = depth or int(os.environ.get("ZKR_PIPELINE_DEPTH", "0"))
+        n = len(d_witness_ptrs)
+        if not depth:
+            if n == 0:
+                return []
+            arr = (ctypes.c_void_p * n)(*[ctypes.c_void_p(p) for p in d_witness_ptrs])
+            rb = None if rs is None else b"".join(int(x).to_bytes(32, "little") for x in rs)
+            sb = None if ss is None else b"".join(int(x).to_bytes(32, "little") for x in ss)
+            out = ctypes.create_string_buffer(256 * n)
+            _check(lib().zkr_prove_batch_device(self._h, arr, n, rb, sb, ctypes.c_void_p(stream or 0), out))
+            return [out.raw[256 * i:256 * i + 256] for i in range(n)]
         out, pending = [], collections.deque()
         for j, ptr in enumerate(d_witness_ptrs):
             if len(pending) == depth:
@@ -268,8 +281,12 @@ class ProvingKey:
         return [out.raw[256 * i:256 * i + 256] for i in range(n)]
 
     def slots(self):
-        """Proofs the key can hold in flight (zkr_prove_submit before zkr_prove_collect)."""
+        """Submits the key can hold in flight (zkr_prove_submit before zkr_prove_collect)."""
         return lib().zkr_key_slots(self._h)
+
+    def fuse(self):
+        """Proofs one batch submit runs in shared launches (zkr_key_fuse): 1 for circuits that fill the chip alone."""
+        return lib().zkr_key_fuse(self._h)
 
     def calc_h(self, witness: bytes) -> bytes:
         m = self.info()["domainSize"]

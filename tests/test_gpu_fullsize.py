@@ -72,6 +72,40 @@ def test_pipelined_batch_equals_synchronous_proofs(log_m):
         key.prove_collect(t2)
 
 
+@pytest.mark.parametrize("log_m,count", [(9, 1), (9, 2), (10, 7), (13, 16), (13, 37), (16, 20), (18, 9)])
+def test_fused_small_circuit_batches_equal_single_proofs(log_m, count):
+    """zkr_prove_batch_device / zkr_prove_batch on circuits far below the chip's size (the reference's tx circuit is 2^17):
+    up to fuse() proofs share every launch -- witnesses end to end, one bucket set per proof and table, the bucket
+    reductions of the group in one launch -- and every proof must still be the bytes of the one-at-a-time path and of the
+    toxic-waste closed form.  Counts cover a single proof, a batch cut in two halves, full groups plus a ragged tail."""
+    import torch
+    import zkr_hip
+    p = 73 if log_m >= 10 else 5
+    key, wb, aux = zkr_hip.ProvingKey.synth(log_m, p, 0x5A4B0001, 0x5A4B00FF)
+    cap = key.fuse()
+    assert cap == max(1, min(16, (1 << 20) >> log_m, 256 // max(1, (1 << (min(log_m, 20) - 1)) // 8192)))
+    wbs = [wb] + [zkr_hip.synth_witness(log_m, p, 0x5A4B0001, 31000 + i) for i in range(1, min(count, 5))]
+    wbs = [wbs[i % len(wbs)] for i in range(count)]
+    rng = g.SplitMix64(17 * log_m + count)
+    rs, ss = [rng.fr() for _ in range(count)], [rng.fr() for _ in range(count)]
+    dw = [torch.frombuffer(bytearray(w), dtype=torch.uint8).cuda() for w in wbs[:5]]
+    dev = key.prove_batch_device([dw[i % len(dw)].data_ptr() for i in range(count)], rs, ss)
+    host = key.prove_batch(wbs, rs, ss)
+    assert len(dev) == len(host) == count
+    closed = {}
+    for i in range(count):
+        assert dev[i] == host[i], "proof %d: device-witness batch and host-witness batch differ" % i
+        if i < 6 or i >= count - 2:                                       # the one-at-a-time path and the closed form on a sample
+            assert dev[i] == key.prove(wbs[i], rs[i], ss[i])
+            expect, _, _ = g.proof_from_aux(aux, wbs[i], p, rs[i], ss[i])
+            assert dev[i] == g.proof_bytes(expect)
+    # random blinding inside a fused batch: every proof verifies and no two are alike
+    vk_bin = key.synth_vk(aux)
+    rnd = key.prove_batch(wbs[:min(count, cap + 1)])
+    pubs = [[int.from_bytes(w[32 * j:32 * j + 32], "little") for j in range(1, p + 1)] for w in wbs[:len(rnd)]]
+    assert zkr_hip.verify_batch(vk_bin, rnd, pubs) and len(set(rnd)) == len(rnd)
+
+
 def test_websnark_buffer_path_at_2_16():
     """The reference's own data flow at the size of the real tx circuit's neighbourhood (2^17): a
     60 MB provingKeyBin in the binarify.ts layout through zkr_key_load_websnark, proof == the C oracle on the same
