@@ -27,6 +27,32 @@ ADD_G2 = (10 * 400 + 2 * 272 + 656) / 136.0       # the same over Fq2           
 CIRCUIT_SEED, TOXIC_SEED, N_PUBLIC = 0x5A4B0001, 0x5A4B00FF, 73
 
 
+def effective_host_cores():
+    """Hardware threads this process may really use: the smallest of the CPU count, the affinity mask and the cgroup CPU
+    quota (the GPU boxes of the pool show 256 hardware threads but run the job under a 16-CPU quota: 128 or 256 OpenMP
+    threads are then SLOWER than 16, profiles/r2_cpu_oracle_thread_scaling.txt)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+            break
+        except Exception:
+            continue
+    return n
+
+
 def cpu_baseline(sample_log_m, target_log_m, gpu_key=None):
     """The C oracle (oracle/zkr_oracle.c) on the host cores of this box, on a key of the same generator (websnark
     buffer rendered by the product, fed to the oracle's own parser): zo_prove on ONE thread and zo_prove_mt on ALL
@@ -42,7 +68,7 @@ def cpu_baseline(sample_log_m, target_log_m, gpu_key=None):
     p1, tm = coracle.prove(pkb, wb, r, s, want_timings=True)
     dt = time.time() - t0
     t0 = time.time()
-    pm, tmm = coracle.prove_mt(pkb, wb, r, s, threads=0, want_timings=True)
+    pm, tmm = coracle.prove_mt(pkb, wb, r, s, threads=effective_host_cores(), want_timings=True)
     dtm = time.time() - t0
     same = p1 == pm
     if gpu_key is not None and sample_log_m == target_log_m:
@@ -541,7 +567,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:  # before the key goes: the GPU proof of the CPU leg's witness is compared with the CPU proofs
             cpu_lm = args.cpu_sample_log_m if args.cpu_sample_log_m is not None else min(args.log_m, 20)
             out["cpu_baseline"] = cpu_baseline(cpu_lm, args.log_m, gpu_key=key if args.shape == "rollup" else None)
-            out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
+            out["cpu_baseline"]["host_cores_available"] = effective_host_cores()
+            out["cpu_baseline"]["host_hardware_threads"] = os.cpu_count()
             if not args.no_js_baseline:
                 out["cpu_baseline"]["snarkjs_style"] = cpu_baseline_js(args.js_sample_log_m, args.log_m)
         if world == 1 and not args.no_bcast_modes:

@@ -235,9 +235,12 @@ int zkr_rollup_info(uint32_t batch, uint32_t depth, uint32_t *n_vars, uint32_t *
 int zkr_rollup_r1cs(uint32_t batch, uint32_t depth, void **r1cs_bin, size_t *r1cs_len);
 int zkr_rollup_witness(uint32_t batch, uint32_t depth, const uint8_t *inputs, size_t n_inputs, void **witness_bin, size_t *witness_len);
 
-/* Integer-ALU microbenchmark: sustained Fq Montgomery multiplications per second on `device`
- * (each = 136 32x32 multiply-adds); used for the secondary (VALU) roofline. */
+/* Integer-ALU microbenchmark: sustained Fq Montgomery multiplications per second on `device` with the multiplier of the
+ * hot path (9 x 29-bit limbs, 162 multiply-adds without carry words, csrc/field29.hpp); used for the secondary (VALU)
+ * roofline.  _legacy: the 8 x 32-bit multiplier of csrc/field.hpp (136 multiply-adds + 136 carry additions), kept for
+ * the boundary formats and the cold kernels. */
 int zkr_bench_fq_mul(int device, double *gmuls_per_s);
+int zkr_bench_fq_mul_legacy(int device, double *gmuls_per_s);
 
 #ifdef __cplusplus
 }

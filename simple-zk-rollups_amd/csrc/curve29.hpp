@@ -1,0 +1,175 @@
+// curve29.hpp -- the XYZZ group law of curve.hpp over the lazily reduced 29-bit-limb fields of field29.hpp: what the bucket
+// accumulation and reduction kernels of the five MSMs run (call site
+// /root/reference/operator/src/snarks/common.ts:29).  Same formulas, same special cases; every intermediate carries its
+// value bound in its type, and the bounds below are checked by the compiler (a formula that could overflow R / p = 169
+// does not build).  In memory points keep the layouts of curve.hpp (8 x 32-bit words per coordinate): Affine<F> /
+// XYZZ<F> with F = Fq, Fq2 are the PACKED forms, coordinates there are x * 2^261 mod p (tables: canonical; buckets:
+// below 2 p).
+#pragma once
+#include "curve.hpp"
+#include "field29.hpp"
+
+namespace zkr {
+
+// coordinate families: G1 over Fq, G2 over Fq2
+struct G1C {
+  template <int H> using T = L29<Fq29, H>;
+  using W = Fq;  // packed form of one coordinate
+  template <int H> static ZKR_HD T<H> unpack(const Fq &w) { return unpack29<Fq29, H>(w.v); }
+  template <int H> static ZKR_HD Fq pack(const T<H> &a) { Fq r; pack29(a, r.v); return r; }
+  static ZKR_HD T<2> one() { return one29<Fq29>(); }
+  static ZKR_HD T<2> to256() { return const29<Fq29>(Fq29::TO256); }
+  static ZKR_HD T<2> to261() { return const29<Fq29>(Fq29::TO261); }
+};
+struct G2C {
+  template <int H> using T = Q29<H>;
+  using W = Fq2;
+  template <int H> static ZKR_HD T<H> unpack(const Fq2 &w) { return Q29<H>{unpack29<Fq29, H>(w.a.v), unpack29<Fq29, H>(w.b.v)}; }
+  template <int H> static ZKR_HD Fq2 pack(const T<H> &x) { Fq2 r; pack29(x.a, r.a.v); pack29(x.b, r.b.v); return r; }
+  static ZKR_HD T<2> one() { return Q29<2>{one29<Fq29>(), L29<Fq29, 2>::zero()}; }
+  static ZKR_HD T<2> to256() { return Q29<2>{const29<Fq29>(Fq29::TO256), L29<Fq29, 2>::zero()}; }
+  static ZKR_HD T<2> to261() { return Q29<2>{const29<Fq29>(Fq29::TO261), L29<Fq29, 2>::zero()}; }
+};
+template <class F> struct CoordOf;
+template <> struct CoordOf<Fq> { using C = G1C; };
+template <> struct CoordOf<Fq2> { using C = G2C; };
+
+// bounds (in half moduli) of the coordinates of a point held in registers: X comes out of two subtractions
+// (R^2 - P^3 - 2 X1 P^2), the others out of products
+constexpr int HX = 13, HY = 4;
+
+template <class C>
+struct Affine29 {
+  typename C::template T<2> x, y;  // canonical table values
+};
+template <class C>
+struct XYZZ29 {
+  typename C::template T<HX> x;
+  typename C::template T<HY> y, zz, zzz;
+  static ZKR_HD XYZZ29 inf() {
+    XYZZ29 r;
+    r.x = decltype(r.x)::zero(); r.y = decltype(r.y)::zero(); r.zz = decltype(r.zz)::zero(); r.zzz = decltype(r.zzz)::zero();
+    return r;
+  }
+  ZKR_HD bool is_inf() const { return zz.all_zero(); }  // infinity is always written as exact zeros; a finite point's ZZ is never 0 mod p
+};
+template <class C, class X, class Y, class ZZ, class ZZZ>
+ZKR_HD XYZZ29<C> make_xyzz(const X &x, const Y &y, const ZZ &zz, const ZZZ &zzz) {
+  XYZZ29<C> r;
+  r.x = x.template to<HX>(); r.y = y.template to<HY>(); r.zz = zz.template to<HY>(); r.zzz = zzz.template to<HY>();
+  return r;
+}
+
+// ---- packed <-> registers
+template <class F>
+ZKR_HD Affine29<typename CoordOf<F>::C> unpack_affine(const Affine<F> &p) {
+  using C = typename CoordOf<F>::C;
+  return Affine29<C>{C::template unpack<2>(p.x), C::template unpack<2>(p.y)};
+}
+template <class F>
+ZKR_HD XYZZ29<typename CoordOf<F>::C> unpack_xyzz(const XYZZ<F> &p) {  // stored coordinates are below 2 p (pack_xyzz)
+  using C = typename CoordOf<F>::C;
+  XYZZ29<C> r;
+  r.x = C::template unpack<HY>(p.x).template to<HX>();
+  r.y = C::template unpack<HY>(p.y); r.zz = C::template unpack<HY>(p.zz); r.zzz = C::template unpack<HY>(p.zzz);
+  return r;
+}
+template <class F>
+ZKR_HD XYZZ<F> pack_xyzz(const XYZZ29<typename CoordOf<F>::C> &p) {
+  using C = typename CoordOf<F>::C;
+  if (p.is_inf()) return XYZZ<F>::inf();
+  return XYZZ<F>{C::template pack<3>(weak(p.x)), C::template pack<HY>(p.y), C::template pack<HY>(p.zz), C::template pack<HY>(p.zzz)};
+}
+
+// 2 * (affine q), y possibly negated already
+template <class C, class QX, class QY>
+ZKR_HD XYZZ29<C> dbl_affine29(const QX &qx, const QY &qy) {
+  auto u = dbl(qy);
+  auto v = sqr(u);
+  auto w = mul(u, v);
+  auto s = mul(qx, v);
+  auto xx = sqr(qx);
+  auto m = add(dbl(xx), xx);
+  auto x3 = sub(sqr(m), dbl(s));
+  auto y3 = mul_sub(m, sub(s, x3), w, qy);
+  return make_xyzz<C>(x3, y3, v, w);
+}
+
+template <class C>
+ZKR_HD XYZZ29<C> dbl_xyzz29(const XYZZ29<C> &p) {
+  if (p.is_inf()) return p;
+  auto u = dbl(p.y);
+  auto v = sqr(u);
+  auto w = mul(u, v);
+  auto s = mul(p.x, v);
+  auto xx = sqr(p.x);
+  auto m = add(dbl(xx), xx);
+  auto x3 = sub(sqr(m), dbl(s));
+  auto y3 = mul_sub(m, sub(s, x3), w, p.y);
+  return make_xyzz<C>(x3, y3, mul(v, p.zz), mul(w, p.zzz));
+}
+
+// acc + q (q affine, not infinity: callers filter); neg_q adds -q
+template <class C>
+ZKR_HD XYZZ29<C> add_mixed29(const XYZZ29<C> &acc, const Affine29<C> &q, bool neg_q) {
+  auto qy = q.y;
+  if (neg_q) qy = neg(q.y).template to<2>();  // p - y (<= p)
+  if (acc.is_inf()) return make_xyzz<C>(q.x, qy, C::one(), C::one());
+  auto u2 = mul(q.x, acc.zz);
+  auto s2 = mul(qy, acc.zzz);
+  auto p = sub(u2, acc.x);
+  auto r = sub(s2, acc.y);
+  auto pp = sqr(p);
+  if (is_zero_mod_p(pp)) {  // same x: the same point (double it) or its negative (infinity)
+    if (is_zero_mod_p(sqr(r))) return dbl_affine29<C>(q.x, qy);
+    return XYZZ29<C>::inf();
+  }
+  auto ppp = mul(p, pp);
+  auto qq = mul(acc.x, pp);
+  auto x3 = sub_sub_dbl(sqr(r), ppp, qq);  // R^2 - P^3 - 2 Q, one carry sweep
+  auto y3 = mul_sub(r, sub(qq, x3), acc.y, ppp);
+  return make_xyzz<C>(x3, y3, mul(acc.zz, pp), mul(acc.zzz, ppp));
+}
+
+// a + b, both XYZZ
+template <class C>
+ZKR_HD XYZZ29<C> add_full29(const XYZZ29<C> &a, const XYZZ29<C> &b) {
+  if (a.is_inf()) return b;
+  if (b.is_inf()) return a;
+  auto u1 = mul(a.x, b.zz);
+  auto u2 = mul(b.x, a.zz);
+  auto s1 = mul(a.y, b.zzz);
+  auto s2 = mul(b.y, a.zzz);
+  auto p = sub(u2, u1);
+  auto r = sub(s2, s1);
+  auto pp = sqr(p);
+  if (is_zero_mod_p(pp)) {
+    if (is_zero_mod_p(sqr(r))) return dbl_xyzz29(a);
+    return XYZZ29<C>::inf();
+  }
+  auto ppp = mul(p, pp);
+  auto qq = mul(u1, pp);
+  auto x3 = sub_sub_dbl(sqr(r), ppp, qq);
+  auto y3 = mul_sub(r, sub(qq, x3), s1, ppp);
+  return make_xyzz<C>(x3, y3, mul(mul(a.zz, b.zz), pp), mul(mul(a.zzz, b.zzz), ppp));
+}
+
+// ---- change of Montgomery radix at the edges of the hot path (cold)
+// packed coordinate x 2^256 (key material, field.hpp) -> packed canonical x 2^261, and back
+template <class F>
+ZKR_HD_COLD F radix_to_261(const F &w) {
+  using C = typename CoordOf<F>::C;
+  return C::template pack<2>(canonical(mul(C::template unpack<10>(w), C::to261())));
+}
+template <class F>
+ZKR_HD_COLD F radix_to_256(const F &w) {
+  using C = typename CoordOf<F>::C;
+  return C::template pack<2>(canonical(mul(C::template unpack<10>(w), C::to256())));
+}
+template <class F>
+ZKR_HD_COLD XYZZ<F> xyzz_to_256(const XYZZ<F> &p) {  // an MSM result on its way to the host assembly (hostops.hpp, field.hpp arithmetic)
+  if (p.is_inf()) return p;
+  return XYZZ<F>{radix_to_256(p.x), radix_to_256(p.y), radix_to_256(p.zz), radix_to_256(p.zzz)};
+}
+
+}  // namespace zkr

@@ -1,0 +1,373 @@
+// field29.hpp -- BN254 Fq / Fr arithmetic on 9 x 29-bit limbs, Montgomery radix R = 2^261: the representation of the
+// DEVICE HOT PATHS (bucket accumulation and reduction of the five MSMs, NTT butterflies; call site of the path:
+// /root/reference/operator/src/snarks/common.ts:29).  field.hpp (8 x 32-bit limbs, radix 2^256 -- the radix of the key
+// material, /root/reference/operator/src/utils/binarify.ts:78-90) stays the representation of everything that crosses the
+// boundary, of the host code and of the cold kernels.
+//
+// Why.  On gfx950 v_mad_u64_u32 and v_addc_co_u32 BOTH issue at 4 cycles per wave64 (tools/valu_clock.hip, clock read on
+// the device: profiles/r2_valu_clock.txt).  With full 32-bit limbs every one of the 136 multiply-adds of a product needs
+// a carry word: 272 full-rate instructions, half of them carries.  With 29-bit limbs a column of up to 45 products
+// of 58 bits sums in a plain 64-bit accumulator, so a product is 162 multiply-adds and NO carry instructions (about 212
+// instructions with the column shifts): 1.4x fewer issue cycles, and the compiler spreads the columns over independent
+// accumulators, which removes the dependent-chain stalls of the two-wavefronts-per-SIMD accumulation kernels as well.
+// Additions and subtractions become 9 independent 32-bit operations plus one carry sweep; there is no conditional
+// subtraction anywhere: R / p = 169, so values are kept LAZILY reduced and the bound of every value is part of its type.
+//
+// L29<PM, H>: limbs normalised (v[i] < 2^29 for i < 8), value < H * p / 2.  A product accepts operands with
+// Ha * Hb <= 676 (a b / R < p) and returns H = 3 or 4; a subtraction adds the smallest multiple of p that keeps it
+// non-negative and says so in its result type.  static_asserts check every bound at compile time.
+// Plain C++ (no inline assembly): the same code runs on the host for the CPU unit tests (tests/test_host_arith.py).
+#pragma once
+#include "field.hpp"
+#include "field29_consts.hpp"
+
+namespace zkr {
+
+constexpr uint32_t M29 = (1u << 29) - 1u;
+
+template <class PM, int H>
+struct L29 {
+  static_assert(H >= 1 && H <= 48, "value bound out of the range the constants cover");
+  static constexpr int bound = H;
+  uint32_t v[9];
+  static ZKR_HD L29 zero() {
+    L29 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = 0;
+    return r;
+  }
+  // every limb zero: THE representation of the point at infinity's ZZ (a value that is only congruent to zero is not this)
+  ZKR_HD bool all_zero() const {
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) o |= v[i];
+    return o == 0;
+  }
+  // a looser bound is always true
+  template <int H2>
+  ZKR_HD L29<PM, H2> to() const {
+    static_assert(H2 >= H, "a value bound can only be relaxed");
+    L29<PM, H2> r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = v[i];
+    return r;
+  }
+};
+
+template <class PM>
+ZKR_HD L29<PM, 2> one29() {  // Montgomery 1
+  L29<PM, 2> r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.v[i] = PM::ONE[i];
+  return r;
+}
+template <class PM>
+ZKR_HD L29<PM, 2> const29(const uint32_t (&c)[9]) {
+  L29<PM, 2> r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.v[i] = c[i];
+  return r;
+}
+
+// ---- 256-bit words <-> limbs.  pack needs value < 2^256 (5.29 p): H <= 10.
+template <class PM, int H>
+ZKR_HD void pack29(const L29<PM, H> &a, uint32_t (&w)[8]) {
+  static_assert(H <= 10, "value may not fit 256 bits: reduce it first (weak())");
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const int lo = 32 * k, i = lo / 29, off = lo % 29;
+    uint64_t t = (uint64_t)(a.v[i] >> off);
+    if (i + 1 <= 8) t |= (uint64_t)a.v[i + 1] << (29 - off);
+    if (i + 2 <= 8 && 58 - off < 32) t |= (uint64_t)a.v[i + 2] << (58 - off);
+    w[k] = (uint32_t)t;
+  }
+}
+template <class PM, int H>
+ZKR_HD L29<PM, H> unpack29(const uint32_t (&w)[8]) {  // the caller states the bound the stored value satisfies
+  L29<PM, H> r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    const int lo = 29 * i, k = lo / 32, off = lo % 32;
+    uint64_t t = (uint64_t)w[k];
+    if (k + 1 <= 7) t |= (uint64_t)w[k + 1] << 32;
+    r.v[i] = (uint32_t)(t >> off) & M29;
+  }
+  return r;
+}
+
+// ---- Montgomery reduction shared by every product form: acc_k = col(k) + sum_{i} m_i P_{k-i}; the low 29 bits of the
+// first nine columns are zeroed by m_k = acc_k * (-p^-1) mod 2^29.  col(k) must stay below 2^63.5 - 9 * 2^58.
+template <class PM, class ColFn>
+ZKR_HD void mont29(uint32_t (&out)[9], ColFn col) {
+  uint32_t m[9];
+  uint64_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < 17; k++) {
+    acc += col(k);
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      const int j = k - i;
+      if (j >= 1 && j <= 8 && i < k) acc += (uint64_t)m[i] * PM::P[j];
+    }
+    if (k < 9) {
+      m[k] = ((uint32_t)acc * PM::INV) & M29;
+      acc += (uint64_t)m[k] * PM::P[0];
+      acc >>= 29;
+    } else {
+      out[k - 9] = (uint32_t)acc & M29;
+      acc >>= 29;
+    }
+  }
+  out[8] = (uint32_t)acc;
+}
+
+constexpr int mul_out_h(int q) { return q <= 338 ? 3 : 4; }  // a b / R + p with a b <= q p^2 / 4 and R / p = 169.28
+
+template <class PM, int HA, int HB>
+ZKR_HD L29<PM, mul_out_h(HA * HB)> mul(const L29<PM, HA> &a, const L29<PM, HB> &b) {
+  static_assert(HA * HB <= 676, "product of the operand bounds exceeds R / p");
+  L29<PM, mul_out_h(HA * HB)> r;
+  mont29<PM>(r.v, [&](int k) {
+    uint64_t s = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      const int j = k - i;
+      if (j >= 0 && j <= 8) s += (uint64_t)a.v[i] * b.v[j];
+    }
+    return s;
+  });
+  return r;
+}
+
+// a^2: the off-diagonal products are taken once against the doubled limbs (2 a_j < 2^30 still multiplies without
+// overflow): 45 multiply-adds instead of 81 in front of the same reduction
+template <class PM, int HA>
+ZKR_HD L29<PM, mul_out_h(HA * HA)> sqr(const L29<PM, HA> &a) {
+  static_assert(HA * HA <= 676, "square of the operand bound exceeds R / p");
+  uint32_t d[9];
+#pragma unroll
+  for (int i = 0; i < 9; i++) d[i] = a.v[i] << 1;
+  L29<PM, mul_out_h(HA * HA)> r;
+  mont29<PM>(r.v, [&](int k) {
+    uint64_t s = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      const int j = k - i;
+      if (j > i && j <= 8) s += (uint64_t)a.v[i] * d[j];
+      if (j == i) s += (uint64_t)a.v[i] * a.v[i];
+    }
+    return s;
+  });
+  return r;
+}
+
+// a b + c d with one reduction
+template <class PM, int HA, int HB, int HC, int HD>
+ZKR_HD L29<PM, mul_out_h(HA * HB + HC * HD)> mul_sum2(const L29<PM, HA> &a, const L29<PM, HB> &b, const L29<PM, HC> &c, const L29<PM, HD> &d) {
+  static_assert(HA * HB + HC * HD <= 676, "sum of the products of the operand bounds exceeds R / p");
+  L29<PM, mul_out_h(HA * HB + HC * HD)> r;
+  mont29<PM>(r.v, [&](int k) {
+    uint64_t s = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      const int j = k - i;
+      if (j >= 0 && j <= 8) { s += (uint64_t)a.v[i] * b.v[j]; s += (uint64_t)c.v[i] * d.v[j]; }
+    }
+    return s;
+  });
+  return r;
+}
+// a b + c d + e f + g h with one reduction (36 products of 58 bits and the 9 of the reduction stay below 2^63.5)
+template <class PM, int HA, int HB, int HC, int HD, int HE, int HF, int HG, int HI>
+ZKR_HD L29<PM, mul_out_h(HA * HB + HC * HD + HE * HF + HG * HI)> mul_sum4(const L29<PM, HA> &a, const L29<PM, HB> &b, const L29<PM, HC> &c, const L29<PM, HD> &d,
+                                                                         const L29<PM, HE> &e, const L29<PM, HF> &f, const L29<PM, HG> &g, const L29<PM, HI> &h) {
+  static_assert(HA * HB + HC * HD + HE * HF + HG * HI <= 676, "sum of the products of the operand bounds exceeds R / p");
+  L29<PM, mul_out_h(HA * HB + HC * HD + HE * HF + HG * HI)> r;
+  mont29<PM>(r.v, [&](int k) {
+    uint64_t s = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      const int j = k - i;
+      if (j >= 0 && j <= 8) { s += (uint64_t)a.v[i] * b.v[j]; s += (uint64_t)c.v[i] * d.v[j]; s += (uint64_t)e.v[i] * f.v[j]; s += (uint64_t)g.v[i] * h.v[j]; }
+    }
+    return s;
+  });
+  return r;
+}
+
+// a + b: limb-wise, then one carry sweep
+template <class PM, int HA, int HB>
+ZKR_HD L29<PM, HA + HB> add(const L29<PM, HA> &a, const L29<PM, HB> &b) {
+  L29<PM, HA + HB> r;
+  uint32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    uint32_t s = a.v[i] + b.v[i] + c;
+    if (i < 8) { r.v[i] = s & M29; c = s >> 29; } else r.v[i] = s;
+  }
+  return r;
+}
+template <class PM, int HA>
+ZKR_HD L29<PM, 2 * HA> dbl(const L29<PM, HA> &a) {
+  return add(a, a);
+}
+
+// a - b + K p, K = ceil(HB / 2) (the smallest multiple of p that is >= every value b can take): limb-wise with signed
+// carries, so no limb of the constant has to dominate the limb it meets
+template <class PM, int HA, int HB>
+ZKR_HD L29<PM, HA + 2 * ((HB + 1) / 2)> sub(const L29<PM, HA> &a, const L29<PM, HB> &b) {
+  constexpr int K = (HB + 1) / 2;
+  static_assert(K <= 24, "no multiple of p tabulated for this bound");
+  L29<PM, HA + 2 * K> r;
+  int32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    int32_t d = (int32_t)(a.v[i] + PM::KP[K][i]) - (int32_t)b.v[i] + c;
+    if (i < 8) { r.v[i] = (uint32_t)d & M29; c = d >> 29; } else r.v[i] = (uint32_t)d;  // the total is >= 0, so the top limb is
+  }
+  return r;
+}
+// a - b - 2 c + K p in ONE carry sweep (the X coordinate of every group addition: R^2 - P^3 - 2 X1 P^2), K = ceil((HB + 2 HC) / 2)
+template <class PM, int HA, int HB, int HC>
+ZKR_HD L29<PM, HA + 2 * ((HB + 2 * HC + 1) / 2)> sub_sub_dbl(const L29<PM, HA> &a, const L29<PM, HB> &b, const L29<PM, HC> &c) {
+  constexpr int K = (HB + 2 * HC + 1) / 2;
+  static_assert(K <= 24, "no multiple of p tabulated for this bound");
+  L29<PM, HA + 2 * K> r;
+  int32_t cy = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    int32_t d = (int32_t)(a.v[i] + PM::KP[K][i]) - (int32_t)b.v[i] - (int32_t)(c.v[i] << 1) + cy;  // > -2^31: three limbs below 2^29 subtracted
+    if (i < 8) { r.v[i] = (uint32_t)d & M29; cy = d >> 29; } else r.v[i] = (uint32_t)d;
+  }
+  return r;
+}
+// K p - b
+template <class PM, int HB>
+ZKR_HD L29<PM, 2 * ((HB + 1) / 2)> neg(const L29<PM, HB> &b) {
+  constexpr int K = (HB + 1) / 2;
+  static_assert(K <= 24, "no multiple of p tabulated for this bound");
+  L29<PM, 2 * K> r;
+  int32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    int32_t d = (int32_t)PM::KP[K][i] - (int32_t)b.v[i] + c;
+    if (i < 8) { r.v[i] = (uint32_t)d & M29; c = d >> 29; } else r.v[i] = (uint32_t)d;
+  }
+  return r;
+}
+// a b - c d with one reduction
+template <class PM, int HA, int HB, int HC, int HD>
+ZKR_HD auto mul_sub(const L29<PM, HA> &a, const L29<PM, HB> &b, const L29<PM, HC> &c, const L29<PM, HD> &d) {
+  return mul_sum2(a, b, neg(c), d);
+}
+
+// value < 1.5 p whatever it was (one product with the Montgomery 1): before a value with a wide bound is stored
+template <class PM, int HA>
+ZKR_HD L29<PM, 3> weak(const L29<PM, HA> &a) {
+  static_assert(HA * 2 <= 338, "bound too wide even for a product with one");
+  return mul(a, one29<PM>()).template to<3>();
+}
+
+// a == 0 (mod p) for a value below 2 p (every product): it is 0 or p
+template <class PM, int HA>
+ZKR_HD bool is_zero_mod_p(const L29<PM, HA> &a) {
+  static_assert(HA <= 4, "reduce first: the test compares with 0 and p only");
+  uint32_t z = 0, e = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) { z |= a.v[i]; e |= a.v[i] ^ PM::P[i]; }
+  return z == 0 || e == 0;
+}
+// the canonical residue (< p), for values that leave the device: at most HA / 2 subtractions of p
+template <class PM, int HA>
+ZKR_HD_COLD L29<PM, 2> canonical(const L29<PM, HA> &a) {
+  L29<PM, 2> r;
+  uint32_t v[9];
+#pragma unroll
+  for (int i = 0; i < 9; i++) v[i] = a.v[i];
+  for (int it = 0; it < (HA + 1) / 2; it++) {
+    int32_t c = 0;
+    uint32_t d[9];
+    for (int i = 0; i < 9; i++) {
+      int32_t t = (int32_t)v[i] - (int32_t)PM::P[i] + c;
+      if (i < 8) { d[i] = (uint32_t)t & M29; c = t >> 29; } else { d[i] = (uint32_t)t; c = t >> 31; }
+    }
+    if (c == 0)  // no borrow out of the top limb: v >= p
+      for (int i = 0; i < 9; i++) v[i] = d[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.v[i] = v[i];
+  return r;
+}
+
+// ---- between the two representations (device side of the boundary)
+// Fp (8 x 32, any radix, value < 2^256 -> bound 11 half-moduli) as limbs
+template <class PM29, class PM, int H = 2>
+ZKR_HD L29<PM29, H> limbs_of(const Fp<PM> &a) {
+  return unpack29<PM29, H>(a.v);
+}
+template <class PM, class PM29, int H>
+ZKR_HD Fp<PM> words_of(const L29<PM29, H> &a) {
+  Fp<PM> r;
+  pack29(a, r.v);
+  return r;
+}
+
+using Fq29 = Fq29Params;
+using Fr29 = Fr29Params;
+
+// ---------------------------------------------------------------- Fq2 = Fq[u]/(u^2+1) over the lazy limbs
+template <int H>
+struct Q29 {
+  L29<Fq29, H> a, b;  // a + b u
+  static ZKR_HD Q29 zero() { return Q29{L29<Fq29, H>::zero(), L29<Fq29, H>::zero()}; }
+  ZKR_HD bool all_zero() const { return a.all_zero() && b.all_zero(); }
+  template <int H2>
+  ZKR_HD Q29<H2> to() const { return Q29<H2>{a.template to<H2>(), b.template to<H2>()}; }
+};
+constexpr int neg_h(int h) { return 2 * ((h + 1) / 2); }
+template <int HA, int HB>
+ZKR_HD Q29<HA + HB> add(const Q29<HA> &x, const Q29<HB> &y) { return Q29<HA + HB>{add(x.a, y.a), add(x.b, y.b)}; }
+template <int HA>
+ZKR_HD Q29<2 * HA> dbl(const Q29<HA> &x) { return Q29<2 * HA>{dbl(x.a), dbl(x.b)}; }
+template <int HA, int HB>
+ZKR_HD Q29<HA + neg_h(HB)> sub(const Q29<HA> &x, const Q29<HB> &y) { return Q29<HA + neg_h(HB)>{sub(x.a, y.a), sub(x.b, y.b)}; }
+template <int HB>
+ZKR_HD Q29<neg_h(HB)> neg(const Q29<HB> &y) { return Q29<neg_h(HB)>{neg(y.a), neg(y.b)}; }
+template <int HA, int HB, int HC>
+ZKR_HD Q29<HA + 2 * ((HB + 2 * HC + 1) / 2)> sub_sub_dbl(const Q29<HA> &x, const Q29<HB> &y, const Q29<HC> &z) {
+  return Q29<HA + 2 * ((HB + 2 * HC + 1) / 2)>{sub_sub_dbl(x.a, y.a, z.a), sub_sub_dbl(x.b, y.b, z.b)};
+}
+constexpr int max_h(int a, int b) { return a > b ? a : b; }
+// (a0 b0 - a1 b1) + (a0 b1 + a1 b0) u: each component a sum of two products with one reduction
+template <int HA, int HB>
+ZKR_HD auto mul(const Q29<HA> &x, const Q29<HB> &y) {
+  auto re = mul_sum2(x.a, y.a, neg(x.b), y.b);
+  auto im = mul_sum2(x.a, y.b, x.b, y.a);
+  constexpr int H = max_h(decltype(re)::bound, decltype(im)::bound);
+  return Q29<H>{re.template to<H>(), im.template to<H>()};
+}
+// (a^2 - b^2) + 2 a b u
+template <int HA>
+ZKR_HD auto sqr(const Q29<HA> &x) {
+  auto re = mul_sum2(x.a, x.a, neg(x.b), x.b);
+  auto im = mul(dbl(x.a), x.b);
+  constexpr int H = max_h(decltype(re)::bound, decltype(im)::bound);
+  return Q29<H>{re.template to<H>(), im.template to<H>()};
+}
+// x y - z w: each component a sum of four products with one reduction
+template <int HX, int HY, int HZ, int HW>
+ZKR_HD auto mul_sub(const Q29<HX> &x, const Q29<HY> &y, const Q29<HZ> &z, const Q29<HW> &w) {
+  auto nza = neg(z.a);
+  auto re = mul_sum4(x.a, y.a, neg(x.b), y.b, nza, w.a, z.b, w.b);
+  auto im = mul_sum4(x.a, y.b, x.b, y.a, nza, w.b, neg(z.b), w.a);
+  constexpr int H = max_h(decltype(re)::bound, decltype(im)::bound);
+  return Q29<H>{re.template to<H>(), im.template to<H>()};
+}
+template <int HA>
+ZKR_HD Q29<3> weak(const Q29<HA> &x) { return Q29<3>{weak(x.a), weak(x.b)}; }
+template <int HA>
+ZKR_HD bool is_zero_mod_p(const Q29<HA> &x) { return is_zero_mod_p(x.a) && is_zero_mod_p(x.b); }
+template <int HA>
+ZKR_HD_COLD Q29<2> canonical(const Q29<HA> &x) { return Q29<2>{canonical(x.a), canonical(x.b)}; }
+
+}  // namespace zkr

@@ -3,9 +3,88 @@
 // Not part of the product path (the product is libzkr_hip.so).
 #include "hostops.hpp"
 #include "pairing.hpp"
+#include "curve29.hpp"
 using namespace zkr;
 
+// ---- the 29-bit-limb hot-path arithmetic (field29.hpp, curve29.hpp) compiled for the host
+namespace {
+template <class P29> L29<P29, 3> to_m261(const uint8_t *std32) {  // standard form -> x 2^261
+  uint32_t w[8];
+  memcpy(w, std32, 32);
+  return mul(unpack29<P29, 10>(w), const29<P29>(P29::R2)).template to<3>();
+}
+template <class P29, int H> void from_m261(const L29<P29, H> &x, uint8_t *std32) {  // x 2^261 (any bound a product accepts) -> canonical standard form
+  L29<P29, 2> raw_one = L29<P29, 2>::zero();
+  raw_one.v[0] = 1;
+  uint32_t w[8];
+  pack29(canonical(mul(x, raw_one)), w);
+  memcpy(std32, w, 32);
+}
+template <class P29> void f29_op(int op, const uint8_t *a32, const uint8_t *b32, uint8_t *out) {
+  auto a = to_m261<P29>(a32), b = to_m261<P29>(b32);
+  switch (op) {
+    case 0: from_m261(mul(a, b), out); break;
+    case 1: from_m261(sqr(a), out); break;
+    case 2: from_m261(add(a, b), out); break;
+    case 3: from_m261(sub(a, b), out); break;
+    case 4: from_m261(neg(a), out); break;
+    case 5: from_m261(mul_sub(a, b, b, a), out); break;                                  // 0
+    case 6: from_m261(mul_sum2(a, a, b, b), out); break;                                 // a^2 + b^2
+    case 7: {  // values at the wide end of their bounds: ((a - b) - (b - a) + 2 (a + b))^2 with lazy intermediates
+      auto t = sub(sub(a, b), sub(b, a));                 // 2 (a - b), bound 3 + 4 + 8 = 15 half moduli
+      auto u = add(t, dbl(add(a, b)));                    // + 2 (a + b): 4 a, bound 15 + 12 = 27... too wide for a square: reduce
+      from_m261(sqr(weak(u)), out);                       // 16 a^2
+      break;
+    }
+    case 8: from_m261(mul_sum4(a, b, a, a, b, b, neg(a), b), out); break;               // a b + a^2 + b^2 - a b
+    case 9: from_m261(weak(sub(sub(sub(a, b), b), b)), out); break;                      // a - 3 b through three lazy subtractions
+    default: from_m261(mul(sub(a, b).template to<17>(), sub(b, a).template to<17>()), out);  // -(a - b)^2 at the widest bound the group law uses
+  }
+}
+}  // namespace
+
+// sum_i (+-) P_i with the hot-path group law: points in the key's wire form (affine, x 2^256; 64 B G1 / 128 B G2), signs[i] != 0
+// subtracts.  The list is cut in two halves that are accumulated apart (add_mixed29) and then added (add_full29); with
+// `twice` the total is added to itself (the doubling branch of add_full29).  out: standard-form affine; returns 1 for infinity.
+template <class F> static int chain29(const uint8_t *pts, const uint8_t *signs, size_t n, int twice, uint8_t *out) {
+  using C = typename CoordOf<F>::C;
+  const size_t pb = sizeof(Affine<F>);
+  XYZZ29<C> half[2] = {XYZZ29<C>::inf(), XYZZ29<C>::inf()};
+  for (size_t i = 0; i < n; i++) {
+    Affine<F> p;
+    memcpy(&p, pts + i * pb, pb);
+    if (p.is_inf()) continue;
+    Affine<F> q{radix_to_261(p.x), radix_to_261(p.y)};
+    XYZZ29<C> &acc = half[i >= n / 2];
+    acc = add_mixed29<C>(acc, unpack_affine(q), signs[i] != 0);
+    acc = unpack_xyzz(pack_xyzz<F>(acc));   // through the packed form, as the kernels store buckets
+  }
+  XYZZ29<C> tot = add_full29<C>(half[0], half[1]);
+  if (twice) tot = add_full29<C>(tot, unpack_xyzz(pack_xyzz<F>(tot)));
+  XYZZ<F> res = xyzz_to_256(pack_xyzz<F>(tot));
+  if (res.is_inf()) return 1;
+  Affine<F> a = to_affine(res);
+  if constexpr (sizeof(F) == 32) store_g1_std(out, *reinterpret_cast<G1Affine *>(&a));
+  else store_g2_std(out, *reinterpret_cast<G2Affine *>(&a));
+  return 0;
+}
 extern "C" {
+// field 0 = Fq, 1 = Fr; ops: see f29_op above; inputs / outputs standard form
+void zkt29_fp(int field, int op, const uint8_t *a, const uint8_t *b, uint8_t *out) {
+  if (field == 0) f29_op<Fq29>(op, a, b, out); else f29_op<Fr29>(op, a, b, out);
+}
+// pack / unpack round trip and the change of radix both ways on a raw 256-bit word string (x 2^256 form in, same out)
+void zkt29_radix_roundtrip(const uint8_t *in32, uint8_t *out32, uint8_t *mid32) {
+  Fq w;
+  memcpy(w.v, in32, 32);
+  Fq m = radix_to_261(w);
+  memcpy(mid32, m.v, 32);
+  Fq back = radix_to_256(m);
+  memcpy(out32, back.v, 32);
+}
+int zkt29_g1_chain(const uint8_t *pts, const uint8_t *signs, size_t n, int twice, uint8_t *out) { return chain29<Fq>(pts, signs, n, twice, out); }
+int zkt29_g2_chain(const uint8_t *pts, const uint8_t *signs, size_t n, int twice, uint8_t *out) { return chain29<Fq2>(pts, signs, n, twice, out); }
+
 // op: 0 mul, 1 add, 2 sub, 3 inv(a), 4 neg(a), 5 sqr(a); inputs/outputs standard form
 void zkt_fp(int field, int op, const uint8_t *a, const uint8_t *b, uint8_t *out) {
   if (field == 0) {

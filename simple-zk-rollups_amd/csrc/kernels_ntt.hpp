@@ -62,12 +62,16 @@ struct NttPassArgs {
   int wlog;        // log2 columns per tile (0 when lo == 0)
   int inverse;     // use inverse twiddles
   int pre;         // NttPre
+  int prio;        // wave priority (s_setprio) of the pass: the preparation chain paces the pipeline once the accumulations are fast
 };
 
 // one pass; grid = 2^L / tile, block = NTT_THREADS, dynamic LDS = 32 * tile bytes
 template <bool DIF>
 static __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  if (a.prio == 1) __builtin_amdgcn_s_setprio(1);
+  else if (a.prio == 2) __builtin_amdgcn_s_setprio(2);
+  else if (a.prio == 3) __builtin_amdgcn_s_setprio(3);
   const int nb = a.hi - a.lo;
   const uint32_t rows = 1u << nb, W = 1u << a.wlog;
   const uint32_t tile = rows << a.wlog;

@@ -26,7 +26,7 @@ enum { T_A = 0, T_B1 = 1, T_B2 = 2, T_C = 3, T_H = 4, N_TABLES = 5 };
 // The device key is ONE position-independent arena: header + sections addressed by byte offsets,
 // so a replica on another GPU is a single broadcast of [arena, arena+len).
 struct ArenaHeader {
-  uint64_t magic;      // "ZKRKEY02"
+  uint64_t magic;      // "ZKRKEY03"
   uint64_t total_len;
   uint32_t n, p, m, logm;
   uint32_t nnzA, nnzB;
@@ -47,7 +47,7 @@ struct ArenaHeader {
 };
 static_assert(sizeof(ArenaHeader) <= 1024, "header fits its slot");
 constexpr size_t ARENA_HEADER_BYTES = 1024;
-constexpr uint64_t ARENA_MAGIC = 0x323059454b524b5aull;  // "ZKRKEY02": bump with every change of ArenaHeader or of a section layout (packed key files carry it)
+constexpr uint64_t ARENA_MAGIC = 0x333059454b524b5aull;  // "ZKRKEY03" (03: point tables in the radix-2^261 form of field29.hpp): bump with every change of ArenaHeader or of a section layout (packed key files carry it)
 
 // digit records of one scalar vector, split by bucket range (kernels_msm.hpp "digit sort", stage 1)
 struct DigitLists {
@@ -173,5 +173,6 @@ int fused_capacity(const ArenaHeader &h, const MsmPlan plan[N_TABLES]);
 MsmPlan msm_plan(size_t n_scalars, size_t n_points, int c_fixed = 0);
 int digit_lists_alloc(DigitLists &dl, size_t n_scalars, const MsmPlan &pl);
 void digit_lists_free(DigitLists &dl);
-int msm_precompute(int device, bool g2, void *d_table, uint32_t n, const MsmPlan &pl);  // fills levels 1..K-1 of a table whose level 0 is in place
+int msm_precompute(int device, bool g2, void *d_table, uint32_t n, const MsmPlan &pl);  // fills levels 1..K-1 of a table whose level 0 is in place, then converts the table to the hot path's radix
+int radix_convert(int device, bool g2, void *d_points, size_t count, bool to261);
 }  // namespace zkr

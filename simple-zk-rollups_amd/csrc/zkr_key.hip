@@ -168,7 +168,7 @@ int key_alloc_workspace(zkr_key *k) {
   ZKR_HIP_CHECK(hipStreamCreateWithPriority(&k->prep_stream, hipStreamNonBlocking, prio_hi));
   // reduction streams: the chains of one proof add up to ~6 ms of serialised launches, so on a single in-order
   // stream they, not the accumulations, set the pace with two proofs in flight (94 vs 106 proofs/s with two)
-  k->n_red = 2;
+  k->n_red = 3;  // round 2 (29-bit-limb kernels): 125.6 / 128.4 proofs/s with two / three reduction streams (round 1 measured the opposite order)
   if (const char *e = getenv("ZKR_RED_STREAMS")) { int v = atoi(e); if (v >= 1 && v <= N_TABLES) k->n_red = v; }
   for (int j = 0; j < k->n_red; j++) ZKR_HIP_CHECK(hipStreamCreateWithPriority(&k->red_stream[j], hipStreamNonBlocking, prio_hi));
   for (int t = 0; t < N_TABLES; t++) k->plan[t] = msm_plan(t == T_H ? h.m : h.n, h.npts[t], (int)h.win_c[t]);
@@ -203,15 +203,31 @@ int key_alloc_workspace(zkr_key *k) {
   return 0;
 }
 
-int msm_precompute(int device, bool g2, void *d_table, uint32_t n, const MsmPlan &pl) {
-  if (n == 0 || pl.K < 2) return 0;
+// `count` affine points between the key's Montgomery radix (2^256) and the hot path's (2^261), in place
+int radix_convert(int device, bool g2, void *d_points, size_t count, bool to261) {
+  if (count == 0) return 0;
   ZKR_HIP_CHECK(hipSetDevice(device));
-  unsigned grid = (n + MSM_THREADS - 1) / MSM_THREADS;
-  if (g2) msm_precompute_kernel<Fq2, 1><<<grid, MSM_THREADS>>>((G2Affine *)d_table, n, pl.c, pl.K);
-  else msm_precompute_kernel<Fq, 2><<<grid, MSM_THREADS>>>((G1Affine *)d_table, n, pl.c, pl.K);
+  unsigned grid = (unsigned)((count + MSM_THREADS - 1) / MSM_THREADS);
+  if (g2) radix_convert_kernel<Fq2><<<grid, MSM_THREADS>>>((G2Affine *)d_points, count, to261 ? 1 : 0);
+  else radix_convert_kernel<Fq><<<grid, MSM_THREADS>>>((G1Affine *)d_points, count, to261 ? 1 : 0);
   ZKR_HIP_CHECK(hipGetLastError());
   ZKR_HIP_CHECK(hipDeviceSynchronize());
   return 0;
+}
+
+// Level 0 of the table (n points, the key's wire form: coordinates x 2^256) is in place: fills levels 1..K-1, then takes
+// the whole table to the radix of the accumulation kernels (x 2^261, canonical; kernels_msm.hpp header).
+int msm_precompute(int device, bool g2, void *d_table, uint32_t n, const MsmPlan &pl) {
+  if (n == 0) return 0;
+  ZKR_HIP_CHECK(hipSetDevice(device));
+  if (pl.K >= 2) {
+    unsigned grid = (n + MSM_THREADS - 1) / MSM_THREADS;
+    if (g2) msm_precompute_kernel<Fq2, 1><<<grid, MSM_THREADS>>>((G2Affine *)d_table, n, pl.c, pl.K);
+    else msm_precompute_kernel<Fq, 2><<<grid, MSM_THREADS>>>((G1Affine *)d_table, n, pl.c, pl.K);
+    ZKR_HIP_CHECK(hipGetLastError());
+    ZKR_HIP_CHECK(hipDeviceSynchronize());
+  }
+  return radix_convert(device, g2, d_table, (size_t)n * pl.K, true);
 }
 
 // Builds the arena.  tbl_src[t]: full source table (host or device memory, affine Montgomery, 64/128 B
@@ -642,6 +658,12 @@ int zkr_key_base_arena(zkr_key *k, void **dev_ptr, size_t *len) {
     }
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) { hipFree(buf); set_error("building the compact arena failed: %s", hipGetErrorString(e)); return ZKR_ERR_HIP; }
+    // the compact form carries the base points in the key's own radix (2^256): the receiver rebuilds the window levels from
+    // them with msm_precompute, exactly as a key load does
+    for (int t = 0; t < N_TABLES; t++) {
+      int rc = radix_convert(k->device, t == T_B2, buf + b.off_pts[t], k->h.npts[t], false);
+      if (rc) { hipFree(buf); return rc; }
+    }
     k->base_arena = buf;
     k->base_arena_len = b.total_len;
   }

@@ -101,6 +101,11 @@ int run_ntt(hipStream_t s, const Fr *in0, const Fr *in1, Fr *out, const Fr *tw, 
     a.lo = ps.lo; a.hi = ps.hi; a.wlog = ps.wlog;
     a.inverse = inverse ? 1 : 0;
     a.pre = first ? pre : PRE_NONE;
+    // wave priority 1 for the NTT passes: with the 29-bit-limb accumulations the preparation chain (sorts + calcH) became
+    // the stream that paces two proofs in flight (its kernels starved behind the accumulation's wavefronts: 4.1 ms of NTT
+    // spans per proof at priority 0, 2.9 ms at 1; 120.9 -> 125.2 proofs/s; 2 and 3 measure the same as 1)
+    static const int ntt_prio = getenv("ZKR_NTT_PRIO") ? atoi(getenv("ZKR_NTT_PRIO")) : 1;
+    a.prio = ntt_prio;
     uint32_t tile = 1u << (ps.hi - ps.lo + ps.wlog);
     uint32_t grid = (1u << L) / tile;
     size_t lds = (size_t)tile * 32;
@@ -163,7 +168,14 @@ int calc_h_device(zkr_key *k, ProofSlot &sl, hipStream_t s, int nbat) {
 // ------------------------------------------------------------------ MSM driver
 template <class F> struct MsmCfg;
 template <> struct MsmCfg<Fq> { static constexpr int ACC_W = 2, RED_W = 2; static constexpr bool ACC_PREFETCH = true; static constexpr const char *ACC_STAGE = "msm_accum_g1"; };
-template <> struct MsmCfg<Fq2> { static constexpr int ACC_W = 2, RED_W = 1; static constexpr bool ACC_PREFETCH = false;  // a second 128-byte point in flight only costs spills (same speed)
+// RED_W = minimum wavefronts per SIMD the oversized-bucket and reduction kernels are compiled for, i.e. their register
+// ceiling (512 / RED_W): they are few long-running wavefronts that must find room on SIMDs whose register file two
+// accumulation wavefronts already fill to 2 x 156 of 512 (G1).  Unconstrained, the G2 forms take ~400 VGPRs on the
+// 29-bit-limb arithmetic and cannot co-reside: they wait for a CU to drain instead of running under the accumulation.
+#ifndef ZKR_RED_W_G2
+#define ZKR_RED_W_G2 3
+#endif
+template <> struct MsmCfg<Fq2> { static constexpr int ACC_W = 2, RED_W = ZKR_RED_W_G2; static constexpr bool ACC_PREFETCH = false;  // a second 128-byte point in flight only costs spills (same speed)
   static constexpr const char *ACC_STAGE = "msm_accum_g2"; };
 
 // digit records of one scalar vector, split by bucket range; shared by every table over those scalars
@@ -848,7 +860,7 @@ int zkr_prof_get(zkr_key *key, const char *stage, double *ms_total, uint64_t *la
   return ZKR_ERR_ARG;
 }
 
-int zkr_bench_fq_mul(int device, double *gmuls_per_s) {
+static int bench_fq_mul(int device, double *gmuls_per_s, int legacy) {
   if (!gmuls_per_s) { set_error("null argument"); return ZKR_ERR_ARG; }
   if (zkr_device_count() <= device || device < 0) { set_error("no HIP device %d", device); return ZKR_ERR_NO_DEVICE; }
   ZKR_HIP_CHECK(hipSetDevice(device));
@@ -862,9 +874,9 @@ int zkr_bench_fq_mul(int device, double *gmuls_per_s) {
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  fq_mul_bench_kernel<<<blocks, MSM_THREADS>>>(d, 16);  // warm up
+  fq_mul_bench_kernel<<<blocks, MSM_THREADS>>>(d, 16, legacy);  // warm up
   hipEventRecord(e0, nullptr);
-  fq_mul_bench_kernel<<<blocks, MSM_THREADS>>>(d, (int)iters);
+  fq_mul_bench_kernel<<<blocks, MSM_THREADS>>>(d, (int)iters, legacy);
   hipEventRecord(e1, nullptr);
   ZKR_HIP_CHECK(hipEventSynchronize(e1));
   float ms = 0;
@@ -875,5 +887,7 @@ int zkr_bench_fq_mul(int device, double *gmuls_per_s) {
   *gmuls_per_s = (double)nthreads * iters * 4 / (ms * 1e-3) / 1e9;
   return 0;
 }
+int zkr_bench_fq_mul(int device, double *gmuls_per_s) { return bench_fq_mul(device, gmuls_per_s, 0); }
+int zkr_bench_fq_mul_legacy(int device, double *gmuls_per_s) { return bench_fq_mul(device, gmuls_per_s, 1); }
 
 }  // extern "C"

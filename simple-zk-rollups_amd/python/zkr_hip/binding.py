@@ -70,6 +70,7 @@ def lib():
     L.zkr_free.argtypes = [vp]
     L.zkr_free.restype = None
     L.zkr_bench_fq_mul.argtypes = [i, c.POINTER(c.c_double)]
+    L.zkr_bench_fq_mul_legacy.argtypes = [i, c.POINTER(c.c_double)]
     L.zkr_mimcsponge_multihash.argtypes = [u8p, sz, u8p]
     L.zkr_babyjub_pubkey.argtypes = [u8p, u8p]
     L.zkr_eddsa_sign.argtypes = [u8p, u8p, sz, u8p]
@@ -392,7 +393,8 @@ def synth_witness(log_m, n_public, circuit_seed, witness_seed):
     return _take(w, wl.value)
 
 
-def bench_fq_mul(device=0) -> float:
+def bench_fq_mul(device=0, legacy=False) -> float:
+    """G Fq-mul/s of the hot path's multiplier (9 x 29-bit limbs); legacy=True: the 8 x 32-bit multiplier of field.hpp."""
     v = ctypes.c_double()
-    _check(lib().zkr_bench_fq_mul(device, ctypes.byref(v)))
+    _check((lib().zkr_bench_fq_mul_legacy if legacy else lib().zkr_bench_fq_mul)(device, ctypes.byref(v)))
     return v.value

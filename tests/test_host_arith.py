@@ -104,3 +104,92 @@ def test_proof_assembly_multiplications(L):
     for a, b in cases:
         assert L.zkt_assembly_muls(wire(P), wire(Q), _le(a), _le(b)) == 1, (a, b)
         assert L.zkt_assembly_muls(wire(P), wire(P), _le(a), _le(b)) == 1, (a, b)      # equal bases: doubling branch of the addition
+
+
+# ---------------------------------------------------------------- the 29-bit-limb hot-path arithmetic (field29.hpp, curve29.hpp)
+def _fp29(L, field, op, a, b=0):
+    o = ctypes.create_string_buffer(32)
+    L.zkt29_fp(field, op, _le(a), _le(b), o)
+    return int.from_bytes(o.raw, "little")
+
+
+def test_field29_ops_match_the_integers(L):
+    """Montgomery products, squares, fused sums of products, lazily reduced additions and subtractions on 9 x 29-bit
+    limbs (radix 2^261) against plain integer arithmetic mod q / mod r, including operands at 0, 1, p - 1 and values whose
+    limbs are all ones; results come back through the canonical reduction."""
+    rnd = random.Random(29)
+    for field, P in ((0, Q), (1, R)):
+        edge = [0, 1, 2, P - 1, P - 2, (1 << 253) - 1, (1 << 232) - 1, ((1 << 29) - 1) << 29, P >> 1, (1 << 253) + 12345]
+        vals = edge + [rnd.randrange(P) for _ in range(60)]
+        expect = {
+            0: lambda a, b: a * b % P, 1: lambda a, b: a * a % P, 2: lambda a, b: (a + b) % P, 3: lambda a, b: (a - b) % P,
+            4: lambda a, b: -a % P, 5: lambda a, b: 0, 6: lambda a, b: (a * a + b * b) % P, 7: lambda a, b: 16 * a * a % P,
+            8: lambda a, b: (a * a + b * b) % P, 9: lambda a, b: (a - 3 * b) % P, 10: lambda a, b: -(a - b) ** 2 % P,
+        }
+        for _ in range(400):
+            a, b = rnd.choice(vals), rnd.choice(vals)
+            for op, fn in expect.items():
+                assert _fp29(L, field, op, a, b) == fn(a, b), (field, op, a, b)
+
+
+def test_radix_change_roundtrip(L):
+    """x 2^256 (the key material's Montgomery radix, binarify.ts:78-90) -> x 2^261 (hot-path radix) -> back."""
+    rnd = random.Random(31)
+    for x in [0, 1, Q - 1] + [rnd.randrange(Q) for _ in range(50)]:
+        m256 = x * (1 << 256) % Q
+        out, mid = ctypes.create_string_buffer(32), ctypes.create_string_buffer(32)
+        L.zkt29_radix_roundtrip(_le(m256), out, mid)
+        assert int.from_bytes(mid.raw, "little") == x * (1 << 261) % Q
+        assert int.from_bytes(out.raw, "little") == m256
+
+
+def _wire_g1(P):
+    return _le(P[0] * (1 << 256) % Q) + _le(P[1] * (1 << 256) % Q)
+
+
+def _wire_g2(P):
+    return b"".join(_le(c * (1 << 256) % Q) for c in (P[0][0], P[0][1], P[1][0], P[1][1]))
+
+
+def test_group_law_on_29_bit_limbs_matches_the_oracle(L):
+    """add_mixed29 / add_full29 / the doubling and cancellation branches (curve29.hpp) over G1 and G2: signed sums of
+    random multiples of the generators -- with repeated points (doubling inside a chain), a point followed by its negative
+    (infinity in the middle of a chain), infinity placeholders, and the total added to itself -- equal the oracle's sums."""
+    rnd = random.Random(37)
+    for g2 in (False, True):
+        gen = bn.G2_GEN if g2 else bn.G1_GEN
+        mul_ = bn.g2_mul if g2 else bn.g1_mul
+        add_ = bn.g2_add if g2 else bn.g1_add
+        neg_ = bn.g2_neg if g2 else bn.g1_neg
+        wire = _wire_g2 if g2 else _wire_g1
+        fn = L.zkt29_g2_chain if g2 else L.zkt29_g1_chain
+        pb = 128 if g2 else 64
+        base = [mul_(gen, rnd.randrange(1, R)) for _ in range(6)]
+        cases = []
+        for n in (1, 2, 3, 8, 17):
+            pts = [rnd.choice(base) for _ in range(n)]
+            cases.append((pts, [rnd.randrange(2) for _ in range(n)]))
+        cases.append(([base[0], base[0], base[0], base[1]], [0, 0, 0, 1]))            # the same point three times: doubling inside the chain
+        cases.append(([base[2], base[2], base[3], base[3]], [0, 1, 1, 0]))            # P - P: infinity, then Q - Q... total infinity
+        cases.append(([base[4], base[4], base[5]], [0, 1, 0]))                        # infinity in the middle, then a point
+        cases.append(([base[1], base[1]], [0, 0]))                                    # halves equal: add_full29 doubles
+        for pts, signs in cases:
+            for twice in (0, 1):
+                want = None
+                for P, sg in zip(pts, signs):
+                    want = add_(want, neg_(P) if sg else P)
+                if twice:
+                    want = add_(want, want)
+                out = ctypes.create_string_buffer(pb)
+                blob = b"".join(wire(P) for P in pts)
+                inf = fn(blob, bytes(signs), len(pts), twice, out)
+                if want is None:
+                    assert inf == 1
+                else:
+                    assert inf == 0
+                    got = [int.from_bytes(out.raw[32 * i:32 * i + 32], "little") for i in range(pb // 32)]
+                    flat = [want[0][0], want[0][1], want[1][0], want[1][1]] if g2 else [want[0], want[1]]
+                    assert got == flat
+        # an all-zero (infinity) wire point inside the list is skipped
+        out = ctypes.create_string_buffer(pb)
+        assert fn(bytes(pb) + wire(base[0]), bytes([0, 0]), 2, 0, out) == 0
