@@ -17,13 +17,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "simple-zk-rollups_amd", "python"))
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-# Group additions in units of one Fq Montgomery multiplication (136 32x32 multiply-adds).  The Y coordinate of an
-# addition is a difference of two products computed with ONE reduction (csrc/field_fused.hpp: 200 multiply-adds for an
-# Fq pair, 2 x 328 for an Fq2 pair), an Fq2 product is two such sums (400), an Fq2 square two products (272):
-MADD_G1 = (8 * 136 + 200) / 136.0                 # XYZZ += affine, 8M + 2S                    -> 9.47
-MADD_G2 = (6 * 400 + 2 * 272 + 656) / 136.0       # the same over Fq2                          -> 26.47
-ADD_G1 = (12 * 136 + 200) / 136.0                 # XYZZ += XYZZ, 12M + 2S                     -> 13.47
-ADD_G2 = (10 * 400 + 2 * 272 + 656) / 136.0       # the same over Fq2                          -> 38.24
+# Group additions in units of one Fq Montgomery multiplication of the hot path (csrc/field29.hpp: 9 x 29-bit limbs, 162
+# 32x32 multiply-adds: 81 for the product, 81 for the reduction).  A square takes its off-diagonal products once (45 + 81),
+# the Y coordinate of an addition is a difference of two products with ONE reduction (2 x 81 + 81), an Fq2 product is two
+# such sums, an Fq2 square one such sum and one product, the Y coordinate over Fq2 two sums of four products (csrc/curve29.hpp):
+MUL, SQR, SUM2, SUM4 = 162.0, 126.0, 243.0, 405.0
+MADD_G1 = (6 * MUL + 2 * SQR + SUM2) / MUL                              # XYZZ += affine, 8M + 2S            ->  9.06
+MADD_G2 = (6 * 2 * SUM2 + 2 * (SUM2 + MUL) + 2 * SUM4) / MUL            # the same over Fq2                  -> 28.0
+ADD_G1 = (10 * MUL + 2 * SQR + SUM2) / MUL                              # XYZZ += XYZZ, 12M + 2S             -> 13.06
+ADD_G2 = (10 * 2 * SUM2 + 2 * (SUM2 + MUL) + 2 * SUM4) / MUL            # the same over Fq2                  -> 40.0
+MADS_PER_MUL = 162
 CIRCUIT_SEED, TOXIC_SEED, N_PUBLIC = 0x5A4B0001, 0x5A4B00FF, 73
 
 
@@ -494,14 +497,14 @@ def main():
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
         traffic, traffic_src, proof_traffic = None, None, None
         try:  # HBM bytes per launch from the committed PMC passes (bench.py cannot collect PMCs itself)
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")))
             if pmc["config"]["log_m"] == args.log_m and args.shape == "rollup":
                 # whole proof: every kernel of the proving path (not key build), per ingest_kernel launch = per proof
                 skip = ("precompute", "fixed_base", "twiddle", "gather", "fq_mul_bench", "rocclr_copy")
                 per_run = sum(v["hbm_bytes_per_launch"] * v["launches"] for k, v in pmc["kernels"].items() if not any(x in k for x in skip))
                 proof_traffic = per_run / pmc["kernels"]["ingest_kernel"]["launches"]
                 traffic = pmc["kernels"][dom.replace("<Fq>", "<Fq>")]["hbm_bytes_per_launch"]
-                traffic_src = "profiles/r1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 read correction)"
+                traffic_src = "profiles/r2_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 read correction)"
         except Exception:
             pass
         roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -510,27 +513,32 @@ def main():
                     "algorithmic_bytes_per_launch": bytes_per_launch,
                     "note": "Pippenger bucket accumulation is integer-VALU bound (v_mad_u64_u32), not HBM bound; see valu. traffic > algorithmic bytes by design: "
                             "the kernel gathers one precomputed 64-byte multiple per window (13 per point, 832 B) instead of re-deriving it, "
-                            "plus the 4-byte entries; the PMC figure applies the x2 read rule, an upper bound for 64-byte gathers"}
+                            "plus the 4-byte entries; the PMC figure applies the x2 read rule, an upper bound for 64-byte gathers. "
+                            "avg_launch_ms is measured with two proofs in flight (the kernel shares the chip with the other streams); isolated it runs 0.87 ms"}
         try:
             peak_gmul = zkr_hip.bench_fq_mul(local)
             gm = fqmul_per_launch / (avg_ms * 1e-3) / 1e9
-            roofline["valu"] = {"peak_fq_mul_per_s_G": peak_gmul, "unit": "G Fq-mul/s (136 mad32 each)",
+            roofline["valu"] = {"peak_fq_mul_per_s_G": peak_gmul, "unit": "G Fq-mul/s (162 mad32 each: 9 x 29-bit limbs, no carry words)",
+                                "peak_fq_mul_per_s_G_legacy_8x32": zkr_hip.bench_fq_mul(local, legacy=True),
                                 "achieved_fq_mul_per_s_G": gm, "frac": gm / peak_gmul,
                                 "window_bits": win["A"][0], "additions_per_point": win["A"][1]}
             # the same rate against the chip's own bound, not only against this library's multiplier:
-            # a product needs 136 v_mad_u64_u32, a full-rate-16-lanes-per-clock instruction on each of the 1024 SIMDs
-            # (256 CUs x 4), so at clock f no multiplier can exceed 1024 * 16 * f / 136 -- quoted at the clock SAMPLED
-            # during the timed region and at the 2.4 GHz boost clock.  The carry word (v_addc_co_u32, 2 of every 6 issue
-            # cycles) and the reduction bookkeeping are what separates the microbenchmark from this bound.
+            # a product needs 162 v_mad_u64_u32, an instruction that issues at 16 lanes per clock (4 cycles per wave64,
+            # tools/valu_clock.hip) on each of the 1024 SIMDs (256 CUs x 4), so at clock f no multiplier of this form can
+            # exceed 1024 * 16 * f / 162 -- quoted at the clock SAMPLED during the timed region and at the 2.4 GHz boost
+            # clock.  The column bookkeeping (shifts, masks, the m_k products: ~60 of ~222 instructions) is what
+            # separates the microbenchmark from this bound; the 8 x 32-bit form needs 136 multiply-adds but 136 carry
+            # additions at the same 4 cycles on top (its own bound would be 1024 * 16 * f / 136 = 285 G/s at 2.36 GHz,
+            # of which it reaches 0.46).
             mhz = (device_state or {}).get("sclk_mhz_mean")
-            bound = lambda f_mhz: 1024 * 16 * f_mhz * 1e6 / 136 / 1e9
+            bound = lambda f_mhz: 1024 * 16 * f_mhz * 1e6 / MADS_PER_MUL / 1e9
             roofline["valu"]["mad_only_bound"] = {
                 "sampled_sclk_mhz": mhz,
                 "bound_at_sampled_clock_G": bound(mhz) if mhz else None, "frac_at_sampled_clock": gm / bound(mhz) if mhz else None,
                 "bound_at_2400_mhz_G": bound(2400.0), "frac_at_2400_mhz": gm / bound(2400.0),
                 "microbench_over_bound_at_sampled_clock": peak_gmul / bound(mhz) if mhz else None}
             # whole proof: every field multiplication of the path (Fq and Fr cost the same) over the time per proof.
-            # mixed addition MADD_G1 / MADD_G2 per table entry (in 136-mad32 units, see the constants at the top); NTT: 6 transforms of (m/2) log2 m butterflies + 5m
+            # mixed addition MADD_G1 / MADD_G2 per table entry (in units of one hot-path multiplication, see the constants at the top; the NTT and QAP products are the 8 x 32-bit kind, counted one for one); NTT: 6 transforms of (m/2) log2 m butterflies + 5m
             # element-wise products; QAP rows: one per non-zero; bucket reduction: 2 full additions (ADD_G1 / ADD_G2) per
             # bucket + the group sums (about 8 per group of 32 buckets)
             m, lg = info["domainSize"], info["domainSize"].bit_length() - 1
@@ -546,7 +554,7 @@ def main():
         out = {
             "metric": "Groth16 proofs/sec (rollup batch circuit)", "value": value, "unit": "proofs/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u32x8 Montgomery (254-bit integer)", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "u32 limbs, 254-bit integer Montgomery (9 x 29 bits in the MSM kernels, 8 x 32 bits elsewhere)", "data": "synthetic",
             "config": {"workload": "2^%d-constraint synthetic %s, 1 proof per step per GPU" % (args.log_m, "rollup circuit" if args.shape == "rollup" else "dense random R1CS"),
                        "log_m": args.log_m, "n_public": N_PUBLIC, "nVars": info["nVars"], "nnzA": info["nnzA"], "nnzB": info["nnzB"],
                        "parallelism": "proof-sharded x%d (key arena broadcast once over %s)" % (world, "RCCL" if backend == "nccl" else backend + ", rehearsal on one GPU" if one_gpu else backend),
@@ -562,7 +570,7 @@ def main():
             "hbm_whole_proof": None if proof_traffic is None else {
                 "bytes_per_proof": proof_traffic, "GBps_per_gpu": proof_traffic / (elapsed / args.steps) / 1e9,
                 "frac_of_peak": proof_traffic / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBPS,
-                "source": "sum over the proving kernels of profiles/r1_pmc_traffic.json (x2 read rule: an upper bound for the 64-byte gathers)"},
+                "source": "sum over the proving kernels of profiles/r2_pmc_traffic.json (x2 read rule: an upper bound for the 64-byte gathers)"},
         }
         if world == 1 and not args.no_cpu_baseline:  # before the key goes: the GPU proof of the CPU leg's witness is compared with the CPU proofs
             cpu_lm = args.cpu_sample_log_m if args.cpu_sample_log_m is not None else min(args.log_m, 20)

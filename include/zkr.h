@@ -192,7 +192,7 @@ int zkr_setup_r1cs(const void *r1cs_bin, size_t r1cs_len, const uint8_t *toxic16
 int zkr_setup_r1cs_websnark(const void *r1cs_bin, size_t r1cs_len, const uint8_t *toxic160, int device, void **pk_out, size_t *pk_len, void **vk_out,
                             size_t *vk_len);
 
-/* Circuit shape drawn by the three zkr_synth_* calls above (process-wide): 0 = rollup-shaped (default; 1-3 terms
+/* Circuit shape drawn by the zkr_synth_* calls of the CALLING THREAD (thread-local, default 0): 0 = rollup-shaped (default; 1-3 terms
  * per row, 3 % boolean and 2 % small signals, a third of the signals absent from B), 1 = dense random (BASELINE.json
  * configs[4]: every row is (4 random signals) x (4 random signals) = new signal; no infinity points in any query). */
 int zkr_synth_set_shape(unsigned shape);

@@ -13,7 +13,7 @@ Restates, in plain Python integers:
 circomlib / snarkjs are un-vendored dependencies (prover/yarn.lock: circomlib 0.0.20, snarkjs 0.1.20): their
 published algorithms are restated here [DEP-KNOWLEDGE] and PINNED against the reference's own vectors:
   (i)  the 220 MiMCSponge round constants embedded as PUSH32 words in the reference's generated contract
-       contracts/build/contracts/CircomLib.json (tests/golden/mimcsponge_constants.json), and
+       contracts/build/contracts/CircomLib.json (tests/golden/rollup_kat.json, field "mimcsponge_push32"), and
   (ii) the two fixed (private key -> public key) pairs of scripts/index.js:108-118, which exercise the hash, the
        key formatting quirk (hex text as bytes, crypto.ts:20-22) and BabyJub scalar multiplication end to end.
 """

@@ -40,7 +40,7 @@ if len(sys.argv) > 3:
     import json
     out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pipeline (ZKR_SERIAL=1)",
            "correction": "KiB units; FETCH_SIZE doubled on gfx950 (MI355X_MICROARCH.md HBM section); calibration row: ingest_kernel (n*32 B read + n*32 B written)",
-           "config": {"log_m": int(sys.argv[4]), "n_public": 73}, "round": 1, "kernels": {}}
+           "config": {"log_m": int(sys.argv[4]), "n_public": 73}, "round": int(sys.argv[5]) if len(sys.argv) > 5 else 1, "kernels": {}}
     for k in fetch:
         n, f = fetch[k]
         wn, w = write.get(k, [n, 0.0])

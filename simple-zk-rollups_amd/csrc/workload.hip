@@ -60,7 +60,7 @@ static Fr dot(const std::vector<Term> &t, size_t b, size_t e, const std::vector<
 }
 
 // circuit shape of the zkr_synth_* entry points: 0 = rollup-shaped (default), 1 = dense random (BASELINE config 5)
-static unsigned g_shape = 0;
+static thread_local unsigned g_shape = 0;  // per calling thread (zkr_synth_set_shape): the library stays re-entrant
 
 // draw-for-draw mirror of oracle/groth16.py:synth_circuit
 static void synth_circuit(Circuit &c, uint32_t m, uint32_t p, uint64_t seed, uint64_t witness_seed) {

@@ -52,20 +52,13 @@ MsmPlan msm_plan(size_t n_scalars, size_t n, int c_fixed) {
   while (((size_t)1 << lg) < n_scalars) lg++;
   int c = lg;  // 2^(c-1) buckets for ~n * 255/c entries: a few dozen entries per bucket
   if (c < 4) c = 4;
-  if (c > 20) {
-    // Above 2^20 scalars the window is chosen by the work it implies -- ceil(255/c) mixed additions per point (9.47
-    // multiplications each) against two full additions (13.47) per bucket in the reduction -- over c = 20..22
-    // (MAX_RANGES x SORT_RANGE_MAX = 2^21 buckets).  2^22 points: 530 / 544 / 532 M multiplications at c = 20 / 21 / 22,
-    // i.e. nothing to gain; 2^24 points: 2078 / 2092 / 1961 M, c = 22 saves 5.6 % (a twelfth of the additions per point
-    // for four times the buckets).
-    double best = 0;
-    int best_c = 20;
-    for (int cc = 20; cc <= 22; cc++) {
-      double cost = (double)((255 + cc - 1) / cc) * (double)n_scalars * 9.47 + 2.0 * (double)(1u << (cc - 1)) * 13.47;
-      if (cc == 20 || cost < best * 0.98) { best = cost; best_c = cc; }  // ties stay with the smaller bucket set
-    }
-    c = best_c;
-  }
+  // c stays at 20 above 2^20 scalars.  The digit sort takes up to 2^21 buckets (MAX_RANGES x SORT_RANGE_MAX), and by
+  // multiplication counts c = 22 would pay at 2^24 points (12 instead of 13 additions per point for four times the
+  // buckets: 1961 vs 2078 M multiplications per G1 table), but measured on the 2^24 rollup-shaped key it loses: 8.19 /
+  // 7.50 proofs/s at c = 20 / 21, and at c = 22 the accumulation of a table takes 26.6 ms instead of 18 ms alone
+  // (2 M bucket threads with short chains gather worse) and 3.5 -> 0.37 proofs/s with two proofs in flight; at 2^22
+  // the counts already tie (530 / 544 / 532 M).  ZKR_MSM_C overrides for experiments.
+  if (c > 20) c = 20;
   if (const char *e = getenv("ZKR_MSM_C")) { int v = atoi(e); if (v >= 2 && v <= 22) c = v; }
   if (c_fixed) c = c_fixed;
   pl.c = c;
