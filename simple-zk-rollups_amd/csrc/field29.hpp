@@ -96,14 +96,16 @@ ZKR_HD L29<PM, H> unpack29(const uint32_t (&w)[8]) {  // the caller states the b
 }
 
 // ---- Montgomery reduction shared by every product form: acc_k = col(k) + sum_{i} m_i P_{k-i}; the low 29 bits of the
-// first nine columns are zeroed by m_k = acc_k * (-p^-1) mod 2^29.  col(k) must stay below 2^63.5 - 9 * 2^58.
+// first nine columns are zeroed by m_k = acc_k * (-p^-1) mod 2^29.  col(k, acc) adds the products of column k INTO the
+// running accumulator (every product is then one v_mad_u64_u32 chained on it: no separate 64-bit addition per column);
+// a column's products must stay below 2^63.5 - 9 * 2^58.
 template <class PM, class ColFn>
 ZKR_HD void mont29(uint32_t (&out)[9], ColFn col) {
   uint32_t m[9];
   uint64_t acc = 0;
 #pragma unroll
   for (int k = 0; k < 17; k++) {
-    acc += col(k);
+    col(k, acc);
 #pragma unroll
     for (int i = 0; i < 9; i++) {
       const int j = k - i;
@@ -127,14 +129,12 @@ template <class PM, int HA, int HB>
 ZKR_HD L29<PM, mul_out_h(HA * HB)> mul(const L29<PM, HA> &a, const L29<PM, HB> &b) {
   static_assert(HA * HB <= 676, "product of the operand bounds exceeds R / p");
   L29<PM, mul_out_h(HA * HB)> r;
-  mont29<PM>(r.v, [&](int k) {
-    uint64_t s = 0;
+  mont29<PM>(r.v, [&](int k, uint64_t &s) {
 #pragma unroll
     for (int i = 0; i < 9; i++) {
       const int j = k - i;
       if (j >= 0 && j <= 8) s += (uint64_t)a.v[i] * b.v[j];
     }
-    return s;
   });
   return r;
 }
@@ -148,15 +148,13 @@ ZKR_HD L29<PM, mul_out_h(HA * HA)> sqr(const L29<PM, HA> &a) {
 #pragma unroll
   for (int i = 0; i < 9; i++) d[i] = a.v[i] << 1;
   L29<PM, mul_out_h(HA * HA)> r;
-  mont29<PM>(r.v, [&](int k) {
-    uint64_t s = 0;
+  mont29<PM>(r.v, [&](int k, uint64_t &s) {
 #pragma unroll
     for (int i = 0; i < 9; i++) {
       const int j = k - i;
       if (j > i && j <= 8) s += (uint64_t)a.v[i] * d[j];
       if (j == i) s += (uint64_t)a.v[i] * a.v[i];
     }
-    return s;
   });
   return r;
 }
@@ -166,14 +164,12 @@ template <class PM, int HA, int HB, int HC, int HD>
 ZKR_HD L29<PM, mul_out_h(HA * HB + HC * HD)> mul_sum2(const L29<PM, HA> &a, const L29<PM, HB> &b, const L29<PM, HC> &c, const L29<PM, HD> &d) {
   static_assert(HA * HB + HC * HD <= 676, "sum of the products of the operand bounds exceeds R / p");
   L29<PM, mul_out_h(HA * HB + HC * HD)> r;
-  mont29<PM>(r.v, [&](int k) {
-    uint64_t s = 0;
+  mont29<PM>(r.v, [&](int k, uint64_t &s) {
 #pragma unroll
     for (int i = 0; i < 9; i++) {
       const int j = k - i;
       if (j >= 0 && j <= 8) { s += (uint64_t)a.v[i] * b.v[j]; s += (uint64_t)c.v[i] * d.v[j]; }
     }
-    return s;
   });
   return r;
 }
@@ -183,14 +179,12 @@ ZKR_HD L29<PM, mul_out_h(HA * HB + HC * HD + HE * HF + HG * HI)> mul_sum4(const 
                                                                          const L29<PM, HE> &e, const L29<PM, HF> &f, const L29<PM, HG> &g, const L29<PM, HI> &h) {
   static_assert(HA * HB + HC * HD + HE * HF + HG * HI <= 676, "sum of the products of the operand bounds exceeds R / p");
   L29<PM, mul_out_h(HA * HB + HC * HD + HE * HF + HG * HI)> r;
-  mont29<PM>(r.v, [&](int k) {
-    uint64_t s = 0;
+  mont29<PM>(r.v, [&](int k, uint64_t &s) {
 #pragma unroll
     for (int i = 0; i < 9; i++) {
       const int j = k - i;
       if (j >= 0 && j <= 8) { s += (uint64_t)a.v[i] * b.v[j]; s += (uint64_t)c.v[i] * d.v[j]; s += (uint64_t)e.v[i] * f.v[j]; s += (uint64_t)g.v[i] * h.v[j]; }
     }
-    return s;
   });
   return r;
 }

@@ -171,9 +171,11 @@ template <> struct MsmCfg<Fq> { static constexpr int ACC_W = 2, RED_W = 2; stati
 // RED_W = minimum wavefronts per SIMD the oversized-bucket and reduction kernels are compiled for, i.e. their register
 // ceiling (512 / RED_W): they are few long-running wavefronts that must find room on SIMDs whose register file two
 // accumulation wavefronts already fill to 2 x 156 of 512 (G1).  Unconstrained, the G2 forms take ~400 VGPRs on the
-// 29-bit-limb arithmetic and cannot co-reside: they wait for a CU to drain instead of running under the accumulation.
+// 29-bit-limb arithmetic and cannot co-reside: they wait for a CU to drain instead of running under the accumulation
+// (116.7 proofs/s).  Measured with the budget for 1 / 2 / 3 wavefronts per SIMD once the NTT priority was in place:
+// 132.9 / 133.1 / 129.6 proofs/s (at 3 the spills of the Fq2 running sums cost more than the co-residency buys).
 #ifndef ZKR_RED_W_G2
-#define ZKR_RED_W_G2 3
+#define ZKR_RED_W_G2 2
 #endif
 template <> struct MsmCfg<Fq2> { static constexpr int ACC_W = 2, RED_W = ZKR_RED_W_G2; static constexpr bool ACC_PREFETCH = false;  // a second 128-byte point in flight only costs spills (same speed)
   static constexpr const char *ACC_STAGE = "msm_accum_g2"; };

@@ -29,7 +29,6 @@ __global__ __launch_bounds__(256) void k(uint64_t *out, uint64_t *ticks, int ite
     else if (OP == 8) { REP64(asm volatile("v_lshl_add_u64 %0, %0, 0, %1\n v_lshl_add_u64 %1, %1, 0, %2\n v_lshl_add_u64 %2, %2, 0, %3\n v_lshl_add_u64 %3, %3, 0, %0" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));) }
     else if (OP == 9) { REP64(asm volatile("v_alignbit_b32 %0, %1, %0, 29\n v_alignbit_b32 %1, %2, %1, 29\n v_alignbit_b32 %2, %3, %2, 29\n v_alignbit_b32 %3, %0, %3, 29" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));) }
     else if (OP == 10) { REP64(asm volatile("v_and_b32 %0, %4, %0\n v_and_b32 %1, %4, %1\n v_lshrrev_b32 %2, 3, %2\n v_lshrrev_b32 %3, 3, %3" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(x));) }
-    else if (OP == 11) { REP64(asm volatile("v_mad_u64_u32 %0, vcc, %4, 0x187cfd47, %0\n v_mad_u64_u32 %1, vcc, %4, 0x10460b6, %1\n v_mad_u64_u32 %2, vcc, %4, 0x1c72a34f, %2\n v_mad_u64_u32 %3, vcc, %4, 0x2d522d0, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(x) : "vcc");) }
     else if (OP == 6) { REP64(asm volatile("v_mad_u64_u32 %0, s[20:21], %8, %9, %0\n v_mad_u64_u32 %1, s[22:23], %8, %9, %1\n v_addc_co_u32_e64 %4, s[20:21], 0, %4, s[20:21]\n v_addc_co_u32_e64 %5, s[22:23], 0, %5, s[22:23]\n v_mad_u64_u32 %2, s[20:21], %8, %9, %2\n v_mad_u64_u32 %3, s[22:23], %8, %9, %3\n v_addc_co_u32_e64 %6, s[20:21], 0, %6, s[20:21]\n v_addc_co_u32_e64 %7, s[22:23], 0, %7, s[22:23]" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(x), "v"(y) : "s20", "s21", "s22", "s23");) }
   }
   uint64_t t1 = clock64(), r1 = wall_clock64();
@@ -87,7 +86,6 @@ int main() {
     run<8>("v_lshl_add_u64", 4, W, khz);
     run<9>("v_alignbit_b32", 4, W, khz);
     run<10>("v_and_b32 / v_lshrrev_b32", 4, W, khz);
-    run<11>("v_mad_u64_u32 with a 32-bit literal", 4, W, khz);
   }
   return 0;
 }
