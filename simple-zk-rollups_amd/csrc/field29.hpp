@@ -18,6 +18,7 @@
 // non-negative and says so in its result type.  static_asserts check every bound at compile time.
 // Plain C++ (no inline assembly): the same code runs on the host for the CPU unit tests (tests/test_host_arith.py).
 #pragma once
+#include <utility>
 #include "field.hpp"
 #include "field29_consts.hpp"
 
@@ -95,33 +96,100 @@ ZKR_HD L29<PM, H> unpack29(const uint32_t (&w)[8]) {  // the caller states the b
   return r;
 }
 
-// ---- Montgomery reduction shared by every product form: acc_k = col(k) + sum_{i} m_i P_{k-i}; the low 29 bits of the
-// first nine columns are zeroed by m_k = acc_k * (-p^-1) mod 2^29.  col(k, acc) adds the products of column k INTO the
-// running accumulator (every product is then one v_mad_u64_u32 chained on it: no separate 64-bit addition per column);
-// a column's products must stay below 2^63.5 - 9 * 2^58.
-template <class PM, class ColFn>
-ZKR_HD void mont29(uint32_t (&out)[9], ColFn col) {
+// ---- Montgomery reduction shared by every product form.  Column k of the 17: acc += (the form's products of column k)
+// + sum_i m_i P_{k-i}; the low 29 bits of the first nine columns are zeroed by m_k = acc * (-p^-1) mod 2^29; then the
+// accumulator moves on by 29 bits.  A form is a policy with `column<K>(acc)`; its products of one column must stay below
+// 2^63.5 - 9 * 2^58.  On the device every chain of multiply-adds of a column is ONE asm statement (field29_mad.hpp): the
+// compiler would emit the same v_mad_u64_u32 from `acc += (uint64_t)x * y`, but it re-associates a column's sum into partial
+// chains (one extra 64-bit addition per column: 16 of ~222 instructions per product).  With the chains opaque a product is
+// 162 multiply-adds + 17 shifts + 17 masks + 9 m_k products = 205 instructions; independent products still interleave.
+// Measured (tools/mul29_test.hip, variant 3 against 1): 168.8 / 172.2 / 178.4 against 159.8 / 166.3 / 170.3 G Fq-mul/s at
+// 2 / 4 / 8 wavefronts per SIMD.  The host build is the plain C++ of the same sums.
+template <int LO, int... I>
+constexpr auto f29_range_seq(std::integer_sequence<int, I...>) { return std::integer_sequence<int, (LO + I)...>{}; }
+template <int LO, int HI>
+using f29_range = decltype(f29_range_seq<LO>(std::make_integer_sequence<int, (HI >= LO ? HI - LO + 1 : 0)>{}));
+constexpr int f29_max(int a, int b) { return a > b ? a : b; }
+constexpr int f29_min(int a, int b) { return a < b ? a : b; }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#include "field29_mad.hpp"
+#endif
+
+// acc += sum_{i in I} x[i] * y[K - i]
+template <int K, int... I>
+ZKR_HD void f29_cross(uint64_t &acc, const uint32_t (&x)[9], const uint32_t (&y)[9], std::integer_sequence<int, I...>) {
+  if constexpr (sizeof...(I) > 0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    mad_vv(acc, x[I]..., y[K - I]...);
+#else
+    ((acc += (uint64_t)x[I] * y[K - I]), ...);
+#endif
+  }
+}
+// acc += sum_{i in I} m[i] * P[K - i]
+template <class PM, int K, int... I>
+ZKR_HD void f29_reduce_terms(uint64_t &acc, const uint32_t (&m)[9], std::integer_sequence<int, I...>) {
+  if constexpr (sizeof...(I) > 0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    mad_vs(acc, m[I]..., PM::P[K - I]...);
+#else
+    ((acc += (uint64_t)m[I] * PM::P[K - I]), ...);
+#endif
+  }
+}
+template <class PM, int K, class Cols>
+ZKR_HD void mont29_from(uint32_t (&out)[9], uint32_t (&m)[9], uint64_t &acc, const Cols &cols) {
+  cols.template column<K>(acc);
+  f29_reduce_terms<PM, K>(acc, m, f29_range<f29_max(0, K - 8), f29_min(K - 1, 8)>{});
+  if constexpr (K < 9) {
+    m[K] = ((uint32_t)acc * PM::INV) & M29;
+    f29_reduce_terms<PM, K>(acc, m, std::integer_sequence<int, K>{});  // + m_K * P_0
+    acc >>= 29;
+  } else {
+    out[K - 9] = (uint32_t)acc & M29;
+    acc >>= 29;
+  }
+  if constexpr (K < 16) mont29_from<PM, K + 1>(out, m, acc, cols);
+  else out[8] = (uint32_t)acc;
+}
+template <class PM, class Cols>
+ZKR_HD void mont29(uint32_t (&out)[9], const Cols &cols) {
   uint32_t m[9];
   uint64_t acc = 0;
-#pragma unroll
-  for (int k = 0; k < 17; k++) {
-    col(k, acc);
-#pragma unroll
-    for (int i = 0; i < 9; i++) {
-      const int j = k - i;
-      if (j >= 1 && j <= 8 && i < k) acc += (uint64_t)m[i] * PM::P[j];
-    }
-    if (k < 9) {
-      m[k] = ((uint32_t)acc * PM::INV) & M29;
-      acc += (uint64_t)m[k] * PM::P[0];
-      acc >>= 29;
-    } else {
-      out[k - 9] = (uint32_t)acc & M29;
-      acc >>= 29;
-    }
-  }
-  out[8] = (uint32_t)acc;
+  mont29_from<PM, 0>(out, m, acc, cols);
 }
+
+// the product forms: x * y; the square (off-diagonal products once, against the doubled limbs); sums of 2 and of 4 products
+struct F29Mul {
+  const uint32_t (&x)[9], (&y)[9];
+  template <int K> ZKR_HD void column(uint64_t &acc) const { f29_cross<K>(acc, x, y, f29_range<f29_max(0, K - 8), f29_min(K, 8)>{}); }
+};
+struct F29Sqr {
+  const uint32_t (&x)[9], (&d)[9];  // d = 2 x
+  template <int K> ZKR_HD void column(uint64_t &acc) const {
+    f29_cross<K>(acc, x, d, f29_range<f29_max(0, K - 8), (K + 1) / 2 - 1>{});      // i < j = K - i
+    if constexpr (K % 2 == 0) f29_cross<K>(acc, x, x, std::integer_sequence<int, K / 2>{});
+  }
+};
+struct F29Sum2 {
+  const uint32_t (&a)[9], (&b)[9], (&c)[9], (&d)[9];
+  template <int K> ZKR_HD void column(uint64_t &acc) const {
+    using R = f29_range<f29_max(0, K - 8), f29_min(K, 8)>;
+    f29_cross<K>(acc, a, b, R{});
+    f29_cross<K>(acc, c, d, R{});
+  }
+};
+struct F29Sum4 {
+  const uint32_t (&a)[9], (&b)[9], (&c)[9], (&d)[9], (&e)[9], (&f)[9], (&g)[9], (&h)[9];
+  template <int K> ZKR_HD void column(uint64_t &acc) const {
+    using R = f29_range<f29_max(0, K - 8), f29_min(K, 8)>;
+    f29_cross<K>(acc, a, b, R{});
+    f29_cross<K>(acc, c, d, R{});
+    f29_cross<K>(acc, e, f, R{});
+    f29_cross<K>(acc, g, h, R{});
+  }
+};
 
 constexpr int mul_out_h(int q) { return q <= 338 ? 3 : 4; }  // a b / R + p with a b <= q p^2 / 4 and R / p = 169.28
 
@@ -129,13 +197,7 @@ template <class PM, int HA, int HB>
 ZKR_HD L29<PM, mul_out_h(HA * HB)> mul(const L29<PM, HA> &a, const L29<PM, HB> &b) {
   static_assert(HA * HB <= 676, "product of the operand bounds exceeds R / p");
   L29<PM, mul_out_h(HA * HB)> r;
-  mont29<PM>(r.v, [&](int k, uint64_t &s) {
-#pragma unroll
-    for (int i = 0; i < 9; i++) {
-      const int j = k - i;
-      if (j >= 0 && j <= 8) s += (uint64_t)a.v[i] * b.v[j];
-    }
-  });
+  mont29<PM>(r.v, F29Mul{a.v, b.v});
   return r;
 }
 
@@ -148,14 +210,7 @@ ZKR_HD L29<PM, mul_out_h(HA * HA)> sqr(const L29<PM, HA> &a) {
 #pragma unroll
   for (int i = 0; i < 9; i++) d[i] = a.v[i] << 1;
   L29<PM, mul_out_h(HA * HA)> r;
-  mont29<PM>(r.v, [&](int k, uint64_t &s) {
-#pragma unroll
-    for (int i = 0; i < 9; i++) {
-      const int j = k - i;
-      if (j > i && j <= 8) s += (uint64_t)a.v[i] * d[j];
-      if (j == i) s += (uint64_t)a.v[i] * a.v[i];
-    }
-  });
+  mont29<PM>(r.v, F29Sqr{a.v, d});
   return r;
 }
 
@@ -164,13 +219,7 @@ template <class PM, int HA, int HB, int HC, int HD>
 ZKR_HD L29<PM, mul_out_h(HA * HB + HC * HD)> mul_sum2(const L29<PM, HA> &a, const L29<PM, HB> &b, const L29<PM, HC> &c, const L29<PM, HD> &d) {
   static_assert(HA * HB + HC * HD <= 676, "sum of the products of the operand bounds exceeds R / p");
   L29<PM, mul_out_h(HA * HB + HC * HD)> r;
-  mont29<PM>(r.v, [&](int k, uint64_t &s) {
-#pragma unroll
-    for (int i = 0; i < 9; i++) {
-      const int j = k - i;
-      if (j >= 0 && j <= 8) { s += (uint64_t)a.v[i] * b.v[j]; s += (uint64_t)c.v[i] * d.v[j]; }
-    }
-  });
+  mont29<PM>(r.v, F29Sum2{a.v, b.v, c.v, d.v});
   return r;
 }
 // a b + c d + e f + g h with one reduction (36 products of 58 bits and the 9 of the reduction stay below 2^63.5)
@@ -179,13 +228,7 @@ ZKR_HD L29<PM, mul_out_h(HA * HB + HC * HD + HE * HF + HG * HI)> mul_sum4(const 
                                                                          const L29<PM, HE> &e, const L29<PM, HF> &f, const L29<PM, HG> &g, const L29<PM, HI> &h) {
   static_assert(HA * HB + HC * HD + HE * HF + HG * HI <= 676, "sum of the products of the operand bounds exceeds R / p");
   L29<PM, mul_out_h(HA * HB + HC * HD + HE * HF + HG * HI)> r;
-  mont29<PM>(r.v, [&](int k, uint64_t &s) {
-#pragma unroll
-    for (int i = 0; i < 9; i++) {
-      const int j = k - i;
-      if (j >= 0 && j <= 8) { s += (uint64_t)a.v[i] * b.v[j]; s += (uint64_t)c.v[i] * d.v[j]; s += (uint64_t)e.v[i] * f.v[j]; s += (uint64_t)g.v[i] * h.v[j]; }
-    }
-  });
+  mont29<PM>(r.v, F29Sum4{a.v, b.v, c.v, d.v, e.v, f.v, g.v, h.v});
   return r;
 }
 

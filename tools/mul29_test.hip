@@ -35,6 +35,40 @@ __device__ __forceinline__ void mulv(uint32_t (&out)[9], const uint32_t (&a)[9],
   out[8] = (uint32_t)acc;
 }
 
+// variant 3: every multiply-add an opaque instruction chained on ONE accumulator (no per-column 64-bit additions: the
+// optimiser cannot re-associate the sums into partial chains); the price is a fully serial chain inside a product
+__device__ __forceinline__ void madc(uint64_t &acc, uint32_t a, uint32_t b) {
+  asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b) : "vcc");
+}
+__device__ __forceinline__ void madk(uint64_t &acc, uint32_t a, uint32_t k) {
+  asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "s"(k) : "vcc");
+}
+__device__ __forceinline__ void mulv3(uint32_t (&out)[9], const uint32_t (&a)[9], const uint32_t (&b)[9]) {
+  using PM = Fq29;
+  uint32_t m[9];
+  uint64_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < 17; k++) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) { const int j = k - i; if (j >= 0 && j <= 8) madc(acc, a[i], b[j]); }
+#pragma unroll
+    for (int i = 0; i < 9; i++) { const int j = k - i; if (j >= 1 && j <= 8 && i < k) madk(acc, m[i], PM::P[j]); }
+    if (k < 9) { m[k] = ((uint32_t)acc * PM::INV) & M29; madk(acc, m[k], PM::P[0]); acc >>= 29; }
+    else { out[k - 9] = (uint32_t)acc & M29; acc >>= 29; }
+  }
+  out[8] = (uint32_t)acc;
+}
+template <int WAVES>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k29v3(uint32_t *io, int iters) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t a[9], b[9], c[9], d[9];
+#pragma unroll
+  for (int i = 0; i < 9; i++) { a[i] = io[t * 9 + i] & M29; b[i] = a[i] ^ 5; c[i] = a[i] ^ 9; d[i] = a[i] ^ 17; }
+  for (int it = 0; it < iters; it++) { mulv3(a, a, b); mulv3(c, c, d); mulv3(b, b, a); mulv3(d, d, c); }   // two independent pairs
+#pragma unroll
+  for (int i = 0; i < 9; i++) io[t * 9 + i] = a[i] + b[i] + c[i] + d[i];
+}
+
 template <int VAR, int WAVES>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k29(uint32_t *io, int iters) {
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -88,11 +122,12 @@ static void run(const char *name, K kern, int waves, double per_iter, int iters)
   hipFree(d);
 }
 #define RUN29(VAR, W) run("mul 9x29, variant " #VAR, [](int b, void *d, int it) { k29<VAR, W><<<b, 256>>>((uint32_t *)d, it); }, W, 4, 4000)
+#define RUN29V3(W) run("mul 9x29, variant 3 (opaque chained mads)", [](int b, void *d, int it) { k29v3<W><<<b, 256>>>((uint32_t *)d, it); }, W, 4, 4000)
 #define RUN32(W) run("mul 8x32 (field.hpp)", [](int b, void *d, int it) { k32<W><<<b, 256>>>((Fq *)d, it); }, W, 4, 4000)
 #define RUNADD(W) run("sub + add + sub on 9x29 (three carry sweeps)", [](int b, void *d, int it) { kadd29<W><<<b, 256>>>((uint32_t *)d, it); }, W, 3, 20000)
 int main() {
-  RUN32(2); RUN29(0, 2); RUN29(1, 2); RUN29(2, 2); RUNADD(2);
-  RUN32(4); RUN29(0, 4); RUN29(1, 4); RUN29(2, 4); RUNADD(4);
-  RUN32(8); RUN29(0, 8); RUN29(1, 8); RUN29(2, 8);
+  RUN32(2); RUN29(0, 2); RUN29(1, 2); RUN29(2, 2); RUN29V3(2); RUNADD(2);
+  RUN32(4); RUN29(0, 4); RUN29(1, 4); RUN29(2, 4); RUN29V3(4); RUNADD(4);
+  RUN32(8); RUN29(0, 8); RUN29(1, 8); RUN29(2, 8); RUN29V3(8);
   return 0;
 }
