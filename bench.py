@@ -456,7 +456,7 @@ def main():
         verify_ms = 1e3 * (time.perf_counter() - tv) / max(args.steps, 1)
 
     # host-buffer boundary (zkr_prove: pageable witness over PCIe inside the call) -- reported, never `value`
-    pcie_rate = pcie_rate_conc = None
+    pcie_rate = pcie_rate_conc = pcie_rate_batch = None
     if rank == 0 and world == 1:
         hw = bytes(wits[0].cpu().numpy().tobytes())
         key.prove(hw, 5, 7)
@@ -475,6 +475,14 @@ def main():
         for th in ths:
             th.join()
         pcie_rate_conc = n_thr * per_thr / (time.perf_counter() - t1)
+        # and as ONE caller hands over a whole batch of host buffers (zkr_prove_batch: the next witness crosses PCIe while
+        # two proofs compute) -- what index.js groth16GenProofBatch / zkr_hip.prove_batch do
+        hws = [bytes(w.cpu().numpy().tobytes()) for w in wits]
+        n_b = 24
+        key.prove_batch([hws[i % n_wit] for i in range(4)])
+        t1 = time.perf_counter()
+        key.prove_batch([hws[i % n_wit] for i in range(n_b)], [300 + i for i in range(n_b)], [400 + i for i in range(n_b)])
+        pcie_rate_batch = n_b / (time.perf_counter() - t1)
 
     if rank == 0:
         total_proofs = args.steps * world
@@ -565,6 +573,7 @@ def main():
                     "bcast_GBps": (arena_bytes / bcast_s / 1e9) if world > 1 and bcast_s > 0 else None},  # one RCCL broadcast over xGMI (153 GB/s per link)
             "pcie_inclusive_proofs_per_s": pcie_rate,
             "pcie_inclusive_concurrent_callers_proofs_per_s": pcie_rate_conc,
+            "pcie_inclusive_batch_call_proofs_per_s": pcie_rate_batch,
             "proofs_verified": verified, "verify_ms_per_proof_host": verify_ms,
             "device_state_during_timed_region": device_state,
             "hbm_whole_proof": None if proof_traffic is None else {

@@ -411,8 +411,11 @@ static __global__ __launch_bounds__(SCAN_THREADS) void msm_order_kernel(const ui
 constexpr int ACC_THREADS = ZKR_ACC_THREADS;
 template <class F, int MINW, bool PREFETCH = true>
 static __global__ __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per_eu(MINW, MINW))) void msm_accum_kernel(const Affine<F> *points, const uint32_t *offsets, const uint32_t *entries,
-                                                                     uint32_t nb, const uint32_t *counts, const uint32_t *order, XYZZ<F> *buckets) {
+                                                                     uint32_t nb, const uint32_t *counts, const uint32_t *order, XYZZ<F> *buckets, int prio) {
   using C = typename CoordOf<F>::C;
+  if (prio == 1) __builtin_amdgcn_s_setprio(1);
+  else if (prio == 2) __builtin_amdgcn_s_setprio(2);
+  else if (prio == 3) __builtin_amdgcn_s_setprio(3);
   const uint32_t t = blockIdx.x * ACC_THREADS + threadIdx.x;
   if (t >= nb) return;
   const uint32_t b = order[t];

@@ -250,7 +250,8 @@ static int msm_accum_enqueue(Prof pf, hipStream_t s, const Affine<F> *pts, uint3
     return 0;
   }
   const unsigned grid = (nb + ACC_THREADS - 1) / ACC_THREADS;
-#define ZKR_ACC_LAUNCH(W) msm_accum_kernel<F, W, MsmCfg<F>::ACC_PREFETCH><<<grid, ACC_THREADS, 0, s>>>(pts, srt.offsets, srt.entries, nb, srt.counts, srt.order, (XYZZ<F> *)ws.buckets)
+  static const int acc_prio = getenv("ZKR_ACC_PRIO") ? atoi(getenv("ZKR_ACC_PRIO")) : 0;
+#define ZKR_ACC_LAUNCH(W) msm_accum_kernel<F, W, MsmCfg<F>::ACC_PREFETCH><<<grid, ACC_THREADS, 0, s>>>(pts, srt.offsets, srt.entries, nb, srt.counts, srt.order, (XYZZ<F> *)ws.buckets, acc_prio)
   switch (acc_w) {
     case 1: ZKR_ACC_LAUNCH(1); break;
     case 3: ZKR_ACC_LAUNCH(3); break;
