@@ -106,6 +106,38 @@ def test_fused_small_circuit_batches_equal_single_proofs(log_m, count):
     assert zkr_hip.verify_batch(vk_bin, rnd, pubs) and len(set(rnd)) == len(rnd)
 
 
+def test_concurrent_host_buffer_callers_on_one_key():
+    """Several host threads inside zkr_prove on ONE key at once (libuv workers behind concurrent groth16GenProof calls):
+    every caller uploads its pageable witness into its own staging buffer outside the key's lock, at most two proofs
+    compute, the others wait for a slot -- and every proof is the bytes of the closed form for its witness and blinding."""
+    import threading
+    import zkr_hip
+    log_m, p = 14, 73
+    key, wb, aux = zkr_hip.ProvingKey.synth(log_m, p, 0x5A4B0001, 0x5A4B00FF)
+    wbs = [wb] + [zkr_hip.synth_witness(log_m, p, 0x5A4B0001, 5100 + i) for i in range(1, 4)]
+    n_thr, per = 5, 6
+    out, errs = {}, []
+
+    def worker(j):
+        try:
+            for i in range(per):
+                w = wbs[(j + i) % len(wbs)]
+                out[(j, i)] = key.prove(w, 1000 + 10 * j + i, 2000 + 10 * j + i)
+        except Exception as e:       # surfaced below: an exception in a thread must fail the test
+            errs.append(e)
+
+    ths = [threading.Thread(target=worker, args=(j,)) for j in range(n_thr)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs
+    assert len(out) == n_thr * per
+    for (j, i), proof in out.items():
+        expect, _, _ = g.proof_from_aux(aux, wbs[(j + i) % len(wbs)], p, 1000 + 10 * j + i, 2000 + 10 * j + i)
+        assert proof == g.proof_bytes(expect), (j, i)
+
+
 def test_websnark_buffer_path_at_2_16():
     """The reference's own data flow at the size of the real tx circuit's neighbourhood (2^17): a
     60 MB provingKeyBin in the binarify.ts layout through zkr_key_load_websnark, proof == the C oracle on the same
