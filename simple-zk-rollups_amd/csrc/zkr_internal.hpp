@@ -91,7 +91,10 @@ namespace zkr {
 // Everything one proof in flight owns: witness + calcH vectors, digit codes, the five MSM workspaces, its
 // events and timing spans.  A key has PROOF_SLOTS of them so that the GPU work of the next proof is enqueued
 // (zkr_prove_submit) while the host still assembles the previous one (zkr_prove_collect).
-constexpr int PROOF_SLOTS = 2;
+#ifndef ZKR_PROOF_SLOTS
+#define ZKR_PROOF_SLOTS 2
+#endif
+constexpr int PROOF_SLOTS = ZKR_PROOF_SLOTS;
 // Host witnesses (zkr_prove, zkr_prove_batch: the ArrayBuffer of binarifyWitness) reach the GPU through a ring of device
 // staging buffers, one more than there are proof slots: the witness of the NEXT proof crosses PCIe while both slots
 // compute (and outside the key's lock), so a stream of host-buffer calls keeps the GPU as busy as device-resident
