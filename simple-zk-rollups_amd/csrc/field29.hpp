@@ -99,12 +99,17 @@ ZKR_HD L29<PM, H> unpack29(const uint32_t (&w)[8]) {  // the caller states the b
 // ---- Montgomery reduction shared by every product form.  Column k of the 17: acc += (the form's products of column k)
 // + sum_i m_i P_{k-i}; the low 29 bits of the first nine columns are zeroed by m_k = acc * (-p^-1) mod 2^29; then the
 // accumulator moves on by 29 bits.  A form is a policy with `column<K>(acc)`; its products of one column must stay below
-// 2^63.5 - 9 * 2^58.  On the device every chain of multiply-adds of a column is ONE asm statement (field29_mad.hpp): the
-// compiler would emit the same v_mad_u64_u32 from `acc += (uint64_t)x * y`, but it re-associates a column's sum into partial
-// chains (one extra 64-bit addition per column: 16 of ~222 instructions per product).  With the chains opaque a product is
-// 162 multiply-adds + 17 shifts + 17 masks + 9 m_k products = 205 instructions; independent products still interleave.
-// Measured (tools/mul29_test.hip, variant 3 against 1): 168.8 / 172.2 / 178.4 against 159.8 / 166.3 / 170.3 G Fq-mul/s at
-// 2 / 4 / 8 wavefronts per SIMD.  The host build is the plain C++ of the same sums.
+// 2^63.5 - 9 * 2^58.  The recursion below is the definition and the HOST build (CPU unit tests).  On the device each form
+// is ONE inline-assembly statement with the same instruction sequence written out (field29_asm.hpp, generated): 162
+// multiply-adds + 17 shifts + 17 masks + 9 m_k products = 205 instructions for x * y.  Assembly not for the instructions
+// (the compiler emits the same v_mad_u64_u32 from `acc += (uint64_t)x * y`) but because (a) it re-associates a column's sum
+// into partial chains, one extra 64-bit addition per column, and (b) on gfx950 it pads the first reader of every register
+// an asm statement wrote with `s_nop 0`: with one statement per column chain (the first device form of this file) that was
+// ~50 idle issue cycles per product.  Measured, G Fq-mul/s at 2 wavefronts per SIMD: 159.8 plain C++, 168.8 chains as asm
+// statements (tools/mul29_test.hip), +3.8 % again for the whole product as one statement (zkr_bench_fq_mul 160.6 -> 166.8
+// in the same harness; 132.4 -> 138.2 proofs/s at 2^20).  A dependent chain of v_mad_u64_u32 issues as fast as independent
+// ones (tools/dep_chain.hip: 4.76 / 4.59 / 4.56 cycles per instruction for 1 / 2 / 4 chains at 2 wavefronts per SIMD), so
+// nothing is lost by the serial order inside a statement.
 template <int LO, int... I>
 constexpr auto f29_range_seq(std::integer_sequence<int, I...>) { return std::integer_sequence<int, (LO + I)...>{}; }
 template <int LO, int HI>
@@ -113,29 +118,24 @@ constexpr int f29_max(int a, int b) { return a > b ? a : b; }
 constexpr int f29_min(int a, int b) { return a < b ? a : b; }
 
 #if defined(__HIP_DEVICE_COMPILE__)
-#include "field29_mad.hpp"
+#include "field29_asm.hpp"
+#define ZKR_F29_DEVICE_ASM 1
+#else
+#define ZKR_F29_DEVICE_ASM 0
 #endif
 
 // acc += sum_{i in I} x[i] * y[K - i]
 template <int K, int... I>
 ZKR_HD void f29_cross(uint64_t &acc, const uint32_t (&x)[9], const uint32_t (&y)[9], std::integer_sequence<int, I...>) {
   if constexpr (sizeof...(I) > 0) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    mad_vv(acc, x[I]..., y[K - I]...);
-#else
     ((acc += (uint64_t)x[I] * y[K - I]), ...);
-#endif
   }
 }
 // acc += sum_{i in I} m[i] * P[K - i]
 template <class PM, int K, int... I>
 ZKR_HD void f29_reduce_terms(uint64_t &acc, const uint32_t (&m)[9], std::integer_sequence<int, I...>) {
   if constexpr (sizeof...(I) > 0) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    mad_vs(acc, m[I]..., PM::P[K - I]...);
-#else
     ((acc += (uint64_t)m[I] * PM::P[K - I]), ...);
-#endif
   }
 }
 template <class PM, int K, class Cols>
@@ -197,7 +197,11 @@ template <class PM, int HA, int HB>
 ZKR_HD L29<PM, mul_out_h(HA * HB)> mul(const L29<PM, HA> &a, const L29<PM, HB> &b) {
   static_assert(HA * HB <= 676, "product of the operand bounds exceeds R / p");
   L29<PM, mul_out_h(HA * HB)> r;
+#if ZKR_F29_DEVICE_ASM
+  mont29_asm_mul<PM>(r.v, a.v, b.v);
+#else
   mont29<PM>(r.v, F29Mul{a.v, b.v});
+#endif
   return r;
 }
 
@@ -210,7 +214,11 @@ ZKR_HD L29<PM, mul_out_h(HA * HA)> sqr(const L29<PM, HA> &a) {
 #pragma unroll
   for (int i = 0; i < 9; i++) d[i] = a.v[i] << 1;
   L29<PM, mul_out_h(HA * HA)> r;
+#if ZKR_F29_DEVICE_ASM
+  mont29_asm_sqr<PM>(r.v, a.v, d);
+#else
   mont29<PM>(r.v, F29Sqr{a.v, d});
+#endif
   return r;
 }
 
@@ -219,7 +227,11 @@ template <class PM, int HA, int HB, int HC, int HD>
 ZKR_HD L29<PM, mul_out_h(HA * HB + HC * HD)> mul_sum2(const L29<PM, HA> &a, const L29<PM, HB> &b, const L29<PM, HC> &c, const L29<PM, HD> &d) {
   static_assert(HA * HB + HC * HD <= 676, "sum of the products of the operand bounds exceeds R / p");
   L29<PM, mul_out_h(HA * HB + HC * HD)> r;
+#if ZKR_F29_DEVICE_ASM
+  mont29_asm_sum2<PM>(r.v, a.v, b.v, c.v, d.v);
+#else
   mont29<PM>(r.v, F29Sum2{a.v, b.v, c.v, d.v});
+#endif
   return r;
 }
 // a b + c d + e f + g h with one reduction (36 products of 58 bits and the 9 of the reduction stay below 2^63.5)
@@ -228,7 +240,11 @@ ZKR_HD L29<PM, mul_out_h(HA * HB + HC * HD + HE * HF + HG * HI)> mul_sum4(const 
                                                                          const L29<PM, HE> &e, const L29<PM, HF> &f, const L29<PM, HG> &g, const L29<PM, HI> &h) {
   static_assert(HA * HB + HC * HD + HE * HF + HG * HI <= 676, "sum of the products of the operand bounds exceeds R / p");
   L29<PM, mul_out_h(HA * HB + HC * HD + HE * HF + HG * HI)> r;
+#if ZKR_F29_DEVICE_ASM
+  mont29_asm_sum4<PM>(r.v, a.v, b.v, c.v, d.v, e.v, f.v, g.v, h.v);
+#else
   mont29<PM>(r.v, F29Sum4{a.v, b.v, c.v, d.v, e.v, f.v, g.v, h.v});
+#endif
   return r;
 }
 

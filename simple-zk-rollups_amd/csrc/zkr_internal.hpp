@@ -95,6 +95,7 @@ namespace zkr {
 #define ZKR_PROOF_SLOTS 2
 #endif
 constexpr int PROOF_SLOTS = ZKR_PROOF_SLOTS;
+constexpr int MAX_FUSE = 16;  // most proofs one launch set carries (zkr_key.hip fused_capacity)
 // Host witnesses (zkr_prove, zkr_prove_batch: the ArrayBuffer of binarifyWitness) reach the GPU through a ring of device
 // staging buffers, one more than there are proof slots: the witness of the NEXT proof crosses PCIe while both slots
 // compute (and outside the key's lock), so a stream of host-buffer calls keeps the GPU as busy as device-resident

@@ -128,13 +128,13 @@ int digit_lists_alloc(DigitLists &dl, size_t n_scalars, const MsmPlan &pl) {  //
 // paid once per batch.  Bounds: the batch's bucket ranges must fit the digit sort's MAX_RANGES lists, the fused vectors
 // stay at or below 2^20 elements, at most 16.
 int fused_capacity(const ArenaHeader &h, const MsmPlan plan[N_TABLES]) {
-  if (const char *e = getenv("ZKR_FUSE")) { int v = atoi(e); if (v >= 1 && v <= 16) { uint32_t nr = 1; for (int t = 0; t < N_TABLES; t++) nr = plan[t].nR > nr ? plan[t].nR : nr; if ((uint32_t)v * nr <= MAX_RANGES) return v; } }
+  if (const char *e = getenv("ZKR_FUSE")) { int v = atoi(e); if (v >= 1 && v <= MAX_FUSE) { uint32_t nr = 1; for (int t = 0; t < N_TABLES; t++) nr = plan[t].nR > nr ? plan[t].nR : nr; if ((uint32_t)v * nr <= MAX_RANGES) return v; } }
   uint32_t nr = 1;
   for (int t = 0; t < N_TABLES; t++) nr = plan[t].nR > nr ? plan[t].nR : nr;
   uint32_t cap = MAX_RANGES / nr;
   uint32_t by_size = h.m >= (1u << 20) ? 1u : (1u << 20) / h.m;
   if (cap > by_size) cap = by_size;
-  if (cap > 16) cap = 16;
+  if (cap > (uint32_t)MAX_FUSE) cap = MAX_FUSE;
   return cap < 1 ? 1 : (int)cap;
 }
 void digit_lists_free(DigitLists &dl) {

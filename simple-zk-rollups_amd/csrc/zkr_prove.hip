@@ -488,9 +488,13 @@ static int prove_collect(zkr_key *k, ProofSlot &sl, uint8_t *proofs_out) {
     if (!sl.busy || sl.collecting) { set_error("no proof in flight in this slot"); return ZKR_ERR_ARG; }
     sl.collecting = true;
   }
-  struct Release {  // the slot is free again when this scope ends, whatever the outcome
+  struct Release {  // the slot is free again when this scope ends, whatever the outcome; r and s do not outlive their proofs
     zkr_key *k; ProofSlot &sl;
-    ~Release() { { std::lock_guard<std::mutex> lk(k->mu); sl.busy = false; sl.collecting = false; } k->slot_freed.notify_one(); }
+    ~Release() {
+      explicit_bzero(sl.rb.data(), sl.rb.size()); explicit_bzero(sl.sb.data(), sl.sb.size());
+      { std::lock_guard<std::mutex> lk(k->mu); sl.busy = false; sl.collecting = false; }
+      k->slot_freed.notify_one();
+    }
   } release{k, sl};
   ZKR_HIP_CHECK(hipSetDevice(k->device));
   const ArenaHeader &h = k->h;
@@ -543,8 +547,8 @@ static int stage_acquire(zkr_key *k, int *idx) {
       if (!ws.d_w) {
         ZKR_HIP_CHECK(hipSetDevice(k->device));
         const size_t bytes = (size_t)k->h.n * 32 * (size_t)k->slot[0].cap;  // one fused group of witnesses
-        ZKR_HIP_CHECK(hipMalloc(&ws.d_w, bytes));
-        ZKR_HIP_CHECK(hipEventCreateWithFlags(&ws.ev_up, hipEventDisableTiming));
+        if (!ws.ev_up) ZKR_HIP_CHECK(hipEventCreateWithFlags(&ws.ev_up, hipEventDisableTiming));
+        ZKR_HIP_CHECK(hipMalloc(&ws.d_w, bytes));  // last: a stage with d_w set is complete
         if (getenv("ZKR_STAGE_PINNED") && hipHostMalloc(&ws.h_pinned, bytes, hipHostMallocDefault) != hipSuccess) ws.h_pinned = nullptr;
       }
       ws.busy = true;
@@ -649,8 +653,8 @@ int zkr_prove_batch(zkr_key *key, const void *const *witnesses_std, size_t witne
     if (!rc && in_flight == PROOF_SLOTS) rc = collect_oldest();
     int t = -1;
     if (!rc) rc = with_free_slot(key, true, &t, [&](ProofSlot &sl) -> int {
-      const Fr *src[16];
-      hipEvent_t ready[16];
+      const Fr *src[MAX_FUSE];
+      hipEvent_t ready[MAX_FUSE];
       for (int j = 0; j < nb; j++) { src[j] = key->stage[st].d_w + (size_t)j * key->h.n; ready[j] = key->stage[st].ev_up; }
       return prove_submit_group(key, sl, src, nb, r32s ? r32s + 32 * i : nullptr, s32s ? s32s + 32 * i : nullptr, key->prep_stream, ready);
     });
