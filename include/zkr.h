@@ -239,6 +239,12 @@ int zkr_rollup_witness(uint32_t batch, uint32_t depth, const uint8_t *inputs, si
  * hot path (9 x 29-bit limbs, 162 multiply-adds without carry words, csrc/field29.hpp); used for the secondary (VALU)
  * roofline.  _legacy: the 8 x 32-bit multiplier of csrc/field.hpp (136 multiply-adds + 136 carry additions), kept for
  * the boundary formats and the cold kernels. */
+/* Limb-level self test of the hot path's Montgomery product forms (csrc/field29.hpp: 9 x 29-bit limbs, radix 2^261) as the
+ * device runs them.  records: n x 8 operands x 9 raw limbs (a b c d e f g h; limbs below 2^29, the top limb free);
+ * out: n x 9 raw limbs of form 0: a b, 1: a^2, 2: a b + c d, 3: a b + c d + e f + g h (x 2^-261 mod the field's modulus,
+ * lazily reduced).  field 0 = Fq, 1 = Fr.  The host build of the same header (libzkr_hostarith.so zkt29_raw_forms) must
+ * give the same limbs bit for bit: tests/test_gpu_stages.py. */
+int zkr_selftest_f29_forms(int device, int field, int form, const uint32_t *records, size_t n, uint32_t *out);
 int zkr_bench_fq_mul(int device, double *gmuls_per_s);
 int zkr_bench_fq_mul_legacy(int device, double *gmuls_per_s);
 

@@ -248,6 +248,26 @@ ZKR_HD L29<PM, mul_out_h(HA * HB + HC * HD + HE * HF + HG * HI)> mul_sum4(const 
   return r;
 }
 
+// the four product forms on raw limbs, as this build runs them (device: field29_asm.hpp; host: the recursion above):
+// 0: a b   1: a^2   2: a b + c d   3: a b + c d + e f + g h.  The limb-level self test compares the two builds.
+template <class PM>
+ZKR_HD void f29_raw_form(int form, const uint32_t (&op)[8][9], uint32_t (&r)[9]) {
+  uint32_t d[9];
+#pragma unroll
+  for (int i = 0; i < 9; i++) d[i] = op[0][i] << 1;
+#if ZKR_F29_DEVICE_ASM
+  if (form == 0) mont29_asm_mul<PM>(r, op[0], op[1]);
+  else if (form == 1) mont29_asm_sqr<PM>(r, op[0], d);
+  else if (form == 2) mont29_asm_sum2<PM>(r, op[0], op[1], op[2], op[3]);
+  else mont29_asm_sum4<PM>(r, op[0], op[1], op[2], op[3], op[4], op[5], op[6], op[7]);
+#else
+  if (form == 0) mont29<PM>(r, F29Mul{op[0], op[1]});
+  else if (form == 1) mont29<PM>(r, F29Sqr{op[0], d});
+  else if (form == 2) mont29<PM>(r, F29Sum2{op[0], op[1], op[2], op[3]});
+  else mont29<PM>(r, F29Sum4{op[0], op[1], op[2], op[3], op[4], op[5], op[6], op[7]});
+#endif
+}
+
 // a + b: limb-wise, then one carry sweep
 template <class PM, int HA, int HB>
 ZKR_HD L29<PM, HA + HB> add(const L29<PM, HA> &a, const L29<PM, HB> &b) {

@@ -82,6 +82,16 @@ void zkt29_radix_roundtrip(const uint8_t *in32, uint8_t *out32, uint8_t *mid32) 
   Fq back = radix_to_256(m);
   memcpy(out32, back.v, 32);
 }
+// the four product forms on raw limbs (field29.hpp f29_raw_form, host build = the defining recursion); layout as
+// zkr_selftest_f29_forms
+void zkt29_raw_forms(int field, int form, const uint32_t *records, size_t n, uint32_t *out) {
+  for (size_t i = 0; i < n; i++) {
+    uint32_t op[8][9], r[9];
+    memcpy(op, records + i * 72, sizeof op);
+    if (field == 0) f29_raw_form<Fq29>(form, op, r); else f29_raw_form<Fr29>(form, op, r);
+    memcpy(out + i * 9, r, sizeof r);
+  }
+}
 int zkt29_g1_chain(const uint8_t *pts, const uint8_t *signs, size_t n, int twice, uint8_t *out) { return chain29<Fq>(pts, signs, n, twice, out); }
 int zkt29_g2_chain(const uint8_t *pts, const uint8_t *signs, size_t n, int twice, uint8_t *out) { return chain29<Fq2>(pts, signs, n, twice, out); }
 

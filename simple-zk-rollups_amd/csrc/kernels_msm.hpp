@@ -717,4 +717,22 @@ static __global__ __launch_bounds__(MSM_THREADS) void fq_mul_bench_kernel(Fq *io
   store_pod(io + i, r);
 }
 
+// Limb-level self test of the product forms of field29.hpp as the DEVICE runs them (one asm statement each,
+// field29_asm.hpp): record = 8 operands x 9 raw limbs (a b c d e f g h), result = 9 raw limbs of
+// form 0: a b   1: a^2   2: a b + c d   3: a b + c d + e f + g h    (x 2^-261 mod p, lazily reduced).
+// tests/test_gpu_stages.py compares it bit for bit with the C++ recursion of the same header run on the host.
+template <class PM>
+static __global__ void f29_forms_kernel(const uint32_t *in, size_t n, int form, uint32_t *out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t op[8][9], r[9];
+#pragma unroll
+  for (int k = 0; k < 8; k++)
+#pragma unroll
+    for (int j = 0; j < 9; j++) op[k][j] = in[i * 72 + k * 9 + j];
+  f29_raw_form<PM>(form, op, r);
+#pragma unroll
+  for (int j = 0; j < 9; j++) out[i * 9 + j] = r[j];
+}
+
 }  // namespace zkr

@@ -894,6 +894,28 @@ static int bench_fq_mul(int device, double *gmuls_per_s, int legacy) {
   *gmuls_per_s = (double)nthreads * iters * 4 / (ms * 1e-3) / 1e9;
   return 0;
 }
+int zkr_selftest_f29_forms(int device, int field, int form, const uint32_t *records, size_t n, uint32_t *out) {
+  if (!records || !out || form < 0 || form > 3 || (field != 0 && field != 1)) { set_error("bad argument"); return ZKR_ERR_ARG; }
+  if (zkr_device_count() <= device || device < 0) { set_error("no HIP device %d", device); return ZKR_ERR_NO_DEVICE; }
+  if (n == 0) return 0;
+  ZKR_HIP_CHECK(hipSetDevice(device));
+  uint32_t *d_in = nullptr, *d_out = nullptr;
+  ZKR_HIP_CHECK(hipMalloc(&d_in, n * 72 * 4));
+  if (hipMalloc(&d_out, n * 9 * 4) != hipSuccess) { hipFree(d_in); set_error("hipMalloc failed"); return ZKR_ERR_HIP; }
+  int rc = 0;
+  if (hipMemcpy(d_in, records, n * 72 * 4, hipMemcpyHostToDevice) != hipSuccess) rc = ZKR_ERR_HIP;
+  if (!rc) {
+    const unsigned grid = (unsigned)((n + 127) / 128);
+    if (field == 0) f29_forms_kernel<Fq29><<<grid, 128>>>(d_in, n, form, d_out);
+    else f29_forms_kernel<Fr29><<<grid, 128>>>(d_in, n, form, d_out);
+    if (hipGetLastError() != hipSuccess || hipMemcpy(out, d_out, n * 9 * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = ZKR_ERR_HIP;
+  }
+  hipFree(d_in);
+  hipFree(d_out);
+  if (rc) set_error("HIP failure in the product-form self test");
+  return rc;
+}
+
 int zkr_bench_fq_mul(int device, double *gmuls_per_s) { return bench_fq_mul(device, gmuls_per_s, 0); }
 int zkr_bench_fq_mul_legacy(int device, double *gmuls_per_s) { return bench_fq_mul(device, gmuls_per_s, 1); }
 

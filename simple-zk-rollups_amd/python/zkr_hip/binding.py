@@ -71,6 +71,7 @@ def lib():
     L.zkr_free.restype = None
     L.zkr_bench_fq_mul.argtypes = [i, c.POINTER(c.c_double)]
     L.zkr_bench_fq_mul_legacy.argtypes = [i, c.POINTER(c.c_double)]
+    L.zkr_selftest_f29_forms.argtypes = [i, i, i, c.POINTER(c.c_uint32), sz, c.POINTER(c.c_uint32)]
     L.zkr_mimcsponge_multihash.argtypes = [u8p, sz, u8p]
     L.zkr_babyjub_pubkey.argtypes = [u8p, u8p]
     L.zkr_eddsa_sign.argtypes = [u8p, u8p, sz, u8p]
@@ -391,6 +392,16 @@ def synth_witness(log_m, n_public, circuit_seed, witness_seed):
     w, wl = ctypes.c_void_p(), ctypes.c_size_t()
     _check(lib().zkr_synth_witness(log_m, n_public, circuit_seed, witness_seed, ctypes.byref(w), ctypes.byref(wl)))
     return _take(w, wl.value)
+
+
+def selftest_f29_forms(field, form, records, device=0):
+    """zkr_selftest_f29_forms: records = list of 8-tuples of 9-limb lists (raw 29-bit limbs); returns the 9 result limbs of
+    each record as the device computes the product form (0: a b, 1: a^2, 2: a b + c d, 3: a b + c d + e f + g h)."""
+    n = len(records)
+    flat = (ctypes.c_uint32 * (72 * n))(*[l for rec in records for operand in rec for l in operand])
+    out = (ctypes.c_uint32 * (9 * n))()
+    _check(lib().zkr_selftest_f29_forms(device, field, form, flat, n, out))
+    return [list(out[9 * k:9 * k + 9]) for k in range(n)]
 
 
 def bench_fq_mul(device=0, legacy=False) -> float:

@@ -27,6 +27,24 @@ def _g2_bytes(P):
     return b"".join(_le(c * MONT % Q) for c in (P[0][0], P[0][1], P[1][0], P[1][1]))
 
 
+def test_device_product_forms_equal_the_host_recursion_limb_for_limb():
+    """The hot path's Montgomery products run on the device as one hand-written instruction sequence per form
+    (csrc/field29_asm.hpp); their definition is the C++ column recursion of csrc/field29.hpp, which the host build runs
+    (and tests/test_host_arith.py checks against the integers).  Same raw limbs in, same raw limbs out, for operands with
+    every limb at 2^29 - 1, sparse limbs and random ones, both fields, all four forms."""
+    import ctypes
+    import os
+    import random
+    import zkr_hip
+    from test_host_arith import SHIM, _raw_records, raw_forms_host
+    assert os.path.exists(SHIM), "host arithmetic shim not built (run __graft_entry__.build())"
+    host = ctypes.CDLL(SHIM)
+    recs = _raw_records(random.Random(61), 3000)
+    for field in (0, 1):
+        for form in range(4):
+            assert zkr_hip.selftest_f29_forms(field, form, recs) == raw_forms_host(host, field, form, recs), (field, form)
+
+
 def test_fq_mul_microbench_runs():
     import zkr_hip
     assert zkr_hip.bench_fq_mul() > 0.1  # G mul/s

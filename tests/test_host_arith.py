@@ -132,6 +132,51 @@ def test_field29_ops_match_the_integers(L):
                 assert _fp29(L, field, op, a, b) == fn(a, b), (field, op, a, b)
 
 
+def _raw_records(rnd, n):
+    """operands as raw limbs: all-ones limbs, single hot limbs, zero, random -- every limb below 2^29"""
+    M = (1 << 29) - 1
+    pats = [[M] * 9, [0] * 9, [1] + [0] * 8, [0] * 8 + [M], [M] + [0] * 8, [M if i % 2 else 0 for i in range(9)], [M - i for i in range(9)]]
+    recs = []
+    for k in range(n):
+        rec = []
+        for _ in range(8):
+            rec.append(list(rnd.choice(pats)) if rnd.random() < 0.35 else [rnd.randrange(1 << 29) for _ in range(9)])
+        recs.append(rec)
+    recs[0] = [[M] * 9] * 8   # the largest column sums the forms can meet
+    return recs
+
+
+def _limbs_value(l):
+    return sum(int(x) << (29 * i) for i, x in enumerate(l))
+
+
+def raw_forms_host(L, field, form, recs):
+    n = len(recs)
+    flat = (ctypes.c_uint32 * (72 * n))(*[x for rec in recs for operand in rec for x in operand])
+    out = (ctypes.c_uint32 * (9 * n))()
+    L.zkt29_raw_forms(field, form, flat, ctypes.c_size_t(n), out)
+    return [list(out[9 * k:9 * k + 9]) for k in range(n)]
+
+
+def test_field29_product_forms_on_raw_limbs(L):
+    """The defining recursion of the four Montgomery product forms (field29.hpp mont29) at the limb level, operands not
+    reduced at all (every limb up to 2^29 - 1): the result is the sum of products times 2^-261 mod p, its low eight limbs
+    are normalised, and it stays below the sum of the operand products / 2^261 + p.  The device's one-statement assembly
+    forms are compared with exactly these limbs in tests/test_gpu_stages.py."""
+    rnd = random.Random(2929)
+    recs = _raw_records(rnd, 200)
+    for field, P in ((0, Q), (1, R)):
+        rinv = pow(1 << 261, -1, P)
+        for form in range(4):
+            outs = raw_forms_host(L, field, form, recs)
+            for rec, o in zip(recs, outs):
+                v = [_limbs_value(x) for x in rec]
+                t = [v[0] * v[1], v[0] * v[0], v[0] * v[1] + v[2] * v[3], v[0] * v[1] + v[2] * v[3] + v[4] * v[5] + v[6] * v[7]][form]
+                got = _limbs_value(o)
+                assert got % P == t * rinv % P, (field, form)
+                assert all(x < (1 << 29) for x in o[:8]) and got <= (t >> 261) + P, (field, form)
+
+
 def test_radix_change_roundtrip(L):
     """x 2^256 (the key material's Montgomery radix, binarify.ts:78-90) -> x 2^261 (hot-path radix) -> back."""
     rnd = random.Random(31)
