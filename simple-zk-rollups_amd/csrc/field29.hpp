@@ -106,8 +106,8 @@ ZKR_HD L29<PM, H> unpack29(const uint32_t (&w)[8]) {  // the caller states the b
 // into partial chains, one extra 64-bit addition per column, and (b) on gfx950 it pads the first reader of every register
 // an asm statement wrote with `s_nop 0`: with one statement per column chain (the first device form of this file) that was
 // ~50 idle issue cycles per product.  Measured, G Fq-mul/s at 2 wavefronts per SIMD: 159.8 plain C++, 168.8 chains as asm
-// statements (tools/mul29_test.hip), +3.8 % again for the whole product as one statement (zkr_bench_fq_mul 160.6 -> 166.8
-// in the same harness; 132.4 -> 138.2 proofs/s at 2^20).  A dependent chain of v_mad_u64_u32 issues as fast as independent
+// statements (tools/mul29_test.hip); the whole product as one statement: +2.0 % proofs/s at 2^20 in a same-box A/B of
+// the two builds (profiles/r2_07_ab_product_asm.txt).  A dependent chain of v_mad_u64_u32 issues as fast as independent
 // ones (tools/dep_chain.hip: 4.76 / 4.59 / 4.56 cycles per instruction for 1 / 2 / 4 chains at 2 wavefronts per SIMD), so
 // nothing is lost by the serial order inside a statement.
 template <int LO, int... I>

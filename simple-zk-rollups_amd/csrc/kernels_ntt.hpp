@@ -18,7 +18,15 @@
 
 namespace zkr {
 
-constexpr int NTT_THREADS = 512;   // two butterflies per thread and stage; 256 and 1024 measured slower (1.13 / 1.07 vs 1.04 ms per calcH)
+// Threads of an NTT workgroup (template parameter of the pass kernel), chosen per transform size by run_ntt (zkr_prove.hip).
+// 512 (two butterflies per thread and stage) is the fastest pass in isolation (256 / 1024: 1.13 / 1.07 against 1.04 ms per
+// calcH at 2^20), but its two wavefronts per SIMD need 2 x 128 VGPRs and do not fit beside two accumulation wavefronts
+// (2 x 176 of 512): under a running accumulation the workgroup waits for a CU to drain.  A 256-thread workgroup (one
+// wavefront per SIMD, 128 VGPRs) co-resides.  Same-box rounds: at 2^20 512 wins (136.8 against 135.0 proofs/s: accumulation
+// wavefronts are short-lived there); from 2^21 on, where a bucket's chain is longer and the preparation chain paces the
+// pipeline, 256 wins (2^21: 71.5 against 68.0; 2^22: 36.5 against 34.9; 2^24: 9.06 against 8.47 proofs/s).
+constexpr int NTT_THREADS_SMALL = 512, NTT_THREADS_LARGE = 256;
+constexpr int NTT_LARGE_LOG = 21;  // transforms of 2^21 and more take the 256-thread workgroups
 constexpr int NTT_TILE_LOG = 11;   // 2048 elements = 64 KB of LDS per workgroup (2 workgroups / CU)
 constexpr int NTT_STRIDED_LOG = 9; // stages per strided pass
 constexpr int NTT_W_LOG = 2;       // 4 columns = 128 B contiguous per row in a strided pass
@@ -66,7 +74,7 @@ struct NttPassArgs {
 };
 
 // one pass; grid = 2^L / tile, block = NTT_THREADS, dynamic LDS = 32 * tile bytes
-template <bool DIF>
+template <bool DIF, int NTT_THREADS>
 static __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   if (a.prio == 1) __builtin_amdgcn_s_setprio(1);

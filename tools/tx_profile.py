@@ -21,7 +21,7 @@ for b in range(4):
 stream = torch.cuda.current_stream().cuda_stream
 print("fuse", key.fuse(), "info", key.info())
 out = {}
-for n in (1, 2, 8, 16, 50, 64, 128, 256):
+for n in [int(x) for x in os.environ.get("TX_COUNTS", "1,2,8,16,50,64,128,256").split(",")]:
     ptrs = [wits[i % 4].data_ptr() for i in range(n)]
     key.prove_batch_device(ptrs, stream=stream)
     torch.cuda.synchronize()
