@@ -28,7 +28,7 @@ constexpr uint32_t M29 = (1u << 29) - 1u;
 
 template <class PM, int H>
 struct L29 {
-  static_assert(H >= 1 && H <= 48, "value bound out of the range the constants cover");
+  static_assert(H >= 1 && H <= 128, "value bound out of range: the top limb has to stay below 2^28 (reductions take it as a signed word)");
   static constexpr int bound = H;
   uint32_t v[9];
   static ZKR_HD L29 zero() {
@@ -339,6 +339,51 @@ template <class PM, int HA>
 ZKR_HD L29<PM, 3> weak(const L29<PM, HA> &a) {
   static_assert(HA * 2 <= 338, "bound too wide even for a product with one");
   return mul(a, one29<PM>()).template to<3>();
+}
+
+// value < 2.5 p whatever it was, WITHOUT a product: one quotient estimate from the top limb (the NTT's bound keeper, where a
+// product with one would double the cost of a butterfly).  t = v[8] = floor(V / 2^232), D = P[8] + 1 > p / 2^232,
+// q = floor(t * floor(2^32 / D) / 2^32) is floor(t / D) or one less, so 0 <= V - q p: q p <= (t / D) p < t 2^232 <= V; and
+// V - q p < (t + 1) 2^232 - (t / D - 2) p <= 2 p + 2^232 + (t / D) 2^232 < 2.001 p.  About 60 instructions.
+template <class PM, int HA>
+ZKR_HD L29<PM, 5> barrett(const L29<PM, HA> &a) {
+  constexpr uint32_t D = PM::P[8] + 1;
+  constexpr uint32_t RECIP = (uint32_t)((1ull << 32) / D);
+  const uint32_t q = (uint32_t)(((uint64_t)a.v[8] * RECIP) >> 32);  // < 2^7 for every bound the type admits
+  L29<PM, 5> r;
+  uint64_t t = 0;
+  int32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    t += (uint64_t)q * PM::P[i];
+    const uint32_t ti = i < 8 ? (uint32_t)t & M29 : (uint32_t)t;  // limb i of q p
+    t >>= 29;
+    const int32_t d = (int32_t)a.v[i] - (int32_t)ti + c;
+    if (i < 8) { r.v[i] = (uint32_t)d & M29; c = d >> 29; } else r.v[i] = (uint32_t)d;
+  }
+  return r;
+}
+// the canonical residue of a value with a small bound, inline (canonical() below is the out-of-line form for cold code)
+template <class PM, int HA>
+ZKR_HD L29<PM, 2> canonical_small(const L29<PM, HA> &a) {
+  static_assert(HA <= 6, "reduce first (barrett / weak): one conditional subtraction per half-modulus pair");
+  L29<PM, 2> r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.v[i] = a.v[i];
+#pragma unroll
+  for (int it = 0; it < (HA - 1) / 2; it++) {  // value < HA p / 2: after (HA - 1) / 2 conditional subtractions it is below p
+    int32_t c = 0;
+    uint32_t d[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      const int32_t t = (int32_t)r.v[i] - (int32_t)PM::P[i] + c;
+      if (i < 8) { d[i] = (uint32_t)t & M29; c = t >> 29; } else { d[i] = (uint32_t)t; c = t >> 31; }
+    }
+    const bool ge = c == 0;  // no borrow out of the top limb: the value was >= p
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = ge ? d[i] : r.v[i];
+  }
+  return r;
 }
 
 // a == 0 (mod p) for a value below 2 p (every product): it is 0 or p

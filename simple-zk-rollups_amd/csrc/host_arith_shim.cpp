@@ -92,6 +92,19 @@ void zkt29_raw_forms(int field, int form, const uint32_t *records, size_t n, uin
     memcpy(out + i * 9, r, sizeof r);
   }
 }
+// barrett() and canonical_small() of field29.hpp on raw limbs: in = 9 limbs (low eight below 2^29, value below 64 p),
+// out = 9 limbs of barrett(in), canon = 9 limbs of canonical_small(barrett(in))
+void zkt29_barrett(int field, const uint32_t *in, uint32_t *out, uint32_t *canon) {
+  if (field == 0) {
+    L29<Fq29, 128> a; memcpy(a.v, in, 36);
+    auto b = barrett(a); memcpy(out, b.v, 36);
+    auto c = canonical_small(b); memcpy(canon, c.v, 36);
+  } else {
+    L29<Fr29, 128> a; memcpy(a.v, in, 36);
+    auto b = barrett(a); memcpy(out, b.v, 36);
+    auto c = canonical_small(b); memcpy(canon, c.v, 36);
+  }
+}
 int zkt29_g1_chain(const uint8_t *pts, const uint8_t *signs, size_t n, int twice, uint8_t *out) { return chain29<Fq>(pts, signs, n, twice, out); }
 int zkt29_g2_chain(const uint8_t *pts, const uint8_t *signs, size_t n, int twice, uint8_t *out) { return chain29<Fq2>(pts, signs, n, twice, out); }
 

@@ -14,7 +14,9 @@
 //   Twiddles w_{2s}^x come from one table per key (w_{2m}^k, k<m, serves all spans up to m and the
 //   coset factors) plus a 32 KB table w_2048^k shared by every contiguous pass (L1/L2 resident).
 #pragma once
+#include <type_traits>
 #include "curve.hpp"
+#include "field29.hpp"
 
 namespace zkr {
 
@@ -62,21 +64,45 @@ struct NttPassArgs {
   const Fr *in0;   // input (may alias out)
   const Fr *in1;   // second operand for PRE_MUL
   Fr *out;
-  const Fr *tw;    // w_{2^(tlog+1)}^k table
-  const Fr *twl;   // w_2048^k table
+  const Fr *tw;    // w_{2^(tlog+1)}^k table, x 2^256 (the coset factors of PRE_COSET)
+  const Fr *tw29;  // the same powers x 2^261, 2^tlog + 1 entries (entry 2^tlog = -1): the butterflies' twiddles
+  const Fr *twl29; // w_2048^k x 2^261, 2^TWL_LOG + 1 entries
   int tlog;        // log2 of tw entries
   int L;           // transform size 2^L
   int lo, hi;      // stages [lo,hi)
   int wlog;        // log2 columns per tile (0 when lo == 0)
-  int inverse;     // use inverse twiddles
   int pre;         // NttPre
+  int canon;       // last pass of a transform: store canonical residues (between passes values below 3 r are stored)
   int prio;        // wave priority (s_setprio) of the pass: the preparation chain paces the pipeline once the accumulations are fast
 };
 
-// one pass; grid = 2^L / tile, block = NTT_THREADS, dynamic LDS = 32 * tile bytes
-template <bool DIF, int NTT_THREADS>
+// The butterflies run on 9 x 29-bit limbs (field29.hpp), lazily reduced: a product is 205 instructions instead of the ~300
+// of the 32-bit form with its carry words, an addition or subtraction 9 independent operations and one carry sweep, and
+// there is no conditional subtraction inside a pass (the 32-bit pass spent 539 instructions per butterfly, this one ~290).
+// Data are in STANDARD form, twiddles x 2^261: mul(data, twiddle) is the plain product.  In HBM a value stays 8 x 32-bit
+// words (32 B, below 3 r between passes, canonical after the last pass); in LDS it is 9 words, limb-major as before.
+// Value bounds (half moduli, the H of L29<., H>):
+//   DIF (u, v) -> (u + v, (u - v) w): the sum doubles the bound, the product resets it to 3.  In a pair of stages only one of
+//     the four outputs is a double sum (4 H): that one goes through barrett() (< 2.5 r).  Invariant: every LDS value <= NTT_H_DIF.
+//   DIT (u, v) -> (u + v w, u - v w): each stage adds at most 4 to the bound of either output, nothing needs reducing inside
+//     a pass: a value read at stage j is below NTT_H_IN + 4 j <= NTT_H_DIT, whatever the type of the expression that wrote it
+//     (the LDS words carry no type: a read states the bound, as unpack29 does, and this schedule is what makes it true);
+//     barrett() once per element when the pass stores.
+// An inverse twiddle is w^-x = -(w^(N - x)) (table entry N = -1 makes x = 0 regular): the butterfly takes w^(N - x) and
+// swaps the roles of its sum and difference instead of negating.
+constexpr int NTT_H_IN = 6;                                 // bound of a value loaded from HBM (below 3 r)
+constexpr int NTT_H_DIF = 6;
+constexpr int NTT_H_DIT = NTT_H_IN + 4 * NTT_TILE_LOG;      // 50
+static_assert(NTT_H_DIT + 8 <= 128 && 2 * (NTT_H_DIT + 8) <= 338, "a DIT pass of NTT_TILE_LOG stages must fit the bounds of field29.hpp");
+static_assert(NTT_STRIDED_LOG <= NTT_TILE_LOG, "a strided pass has no more stages than a contiguous one");
+using NttL = Fr29;
+
+// one pass; grid = 2^L / tile, block = NTT_THREADS, dynamic LDS = 36 * tile bytes
+template <bool DIF, bool INV, int NTT_THREADS>
 static __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  constexpr int HL = DIF ? NTT_H_DIF : NTT_H_DIT;  // what a value read from LDS is stated to be below
+  using V = L29<NttL, HL>;
   if (a.prio == 1) __builtin_amdgcn_s_setprio(1);
   else if (a.prio == 2) __builtin_amdgcn_s_setprio(2);
   else if (a.prio == 3) __builtin_amdgcn_s_setprio(3);
@@ -87,46 +113,51 @@ static __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArg
   const uint32_t q = blockIdx.x / lb, l0 = (blockIdx.x % lb) << a.wlog;
   const size_t base = ((size_t)blockIdx.y << a.L) + ((size_t)q << a.hi) + l0;  // blockIdx.y: transform of a fused batch (vectors end to end)
 
+  auto lds_get = [&](uint32_t e) {
+    V x;
+#pragma unroll
+    for (int k = 0; k < 9; k++) x.v[k] = lds[k * tile + e];
+    return x;
+  };
+  auto lds_put = [&](uint32_t e, const auto &x) {  // DIF: the type proves the invariant; DIT: the stage schedule does (see above)
+    static_assert(!DIF || std::remove_reference_t<decltype(x)>::bound <= HL, "DIF invariant broken");
+#pragma unroll
+    for (int k = 0; k < 9; k++) lds[k * tile + e] = x.v[k];
+  };
+
   for (uint32_t e = threadIdx.x; e < tile; e += NTT_THREADS) {
     uint32_t r = e >> a.wlog, c = e & (W - 1);
     size_t gi = base + ((size_t)r << a.lo) + c;
     Fr x = load_fr(a.in0 + gi);
-    if (a.pre == PRE_COSET) {
+    if (a.pre == PRE_COSET) {  // first pass of a transform: canonical input, 32-bit product with the x 2^256 table (once per element)
       uint32_t br = __brev((uint32_t)gi << (32 - a.L));  // coefficient index of a bit-reversed position (low L bits of gi: position within its transform)
       x = mul(x, load_fr(a.tw + ((size_t)br << (a.tlog - a.L))));
     } else if (a.pre == PRE_MUL) {
       x = mul(x, load_fr(a.in1 + gi));
     }
-#pragma unroll
-    for (int k = 0; k < 8; k++) lds[k * tile + e] = x.v[k];
+    lds_put(e, unpack29<NttL, DIF ? NTT_H_DIF : NTT_H_IN>(x.v));
   }
   __syncthreads();
 
+  // twiddle of span 2^slog at offset x: w_{2s}^x, or for an inverse transform w_{2s}^(s - x) = -(w_{2s}^-x)
+  auto twiddle = [&](int slog, uint32_t x) {
+    const Fr *tab = slog <= TWL_LOG ? a.twl29 : a.tw29;
+    const int tlog = slog <= TWL_LOG ? TWL_LOG : a.tlog;
+    uint32_t idx = x << (tlog - slog);
+    if (INV) idx = (1u << tlog) - idx;
+    return unpack29<NttL, 2>(load_fr(tab + idx).v);
+  };
   // Stages run in PAIRS on four elements held in registers (one LDS round trip and one barrier per two stages; index
   // math modelled in tests/test_ntt_plan.py `double`); an odd stage count starts with one single stage.
-  auto twiddle = [&](int slog, uint32_t imods) {
-    return slog <= TWL_LOG ? tw_lookup(a.twl, TWL_LOG, slog, imods, a.inverse != 0) : tw_lookup(a.tw, a.tlog, slog, imods, a.inverse != 0);
+  auto dif = [&](const auto &u, const auto &v, const L29<NttL, 2> &w, auto &sum, auto &prod) {  // (u + v, (u - v) w)
+    sum = add(u, v);
+    if constexpr (INV) prod = mul(sub(v, u), w); else prod = mul(sub(u, v), w);
   };
-  auto lds_get = [&](uint32_t e) {
-    Fr x;
-#pragma unroll
-    for (int k = 0; k < 8; k++) x.v[k] = lds[k * tile + e];
-    return x;
-  };
-  auto lds_put = [&](uint32_t e, const Fr &x) {
-#pragma unroll
-    for (int k = 0; k < 8; k++) lds[k * tile + e] = x.v[k];
-  };
-  auto butterfly = [&](Fr &u, Fr &v, const Fr &w) {
-    if (DIF) {
-      Fr d = sub(u, v);
-      u = add(u, v);
-      v = mul(d, w);
-    } else {
-      Fr t = mul(v, w);
-      v = sub(u, t);
-      u = add(u, t);
-    }
+  auto dit = [&](const auto &u, const auto &v, const L29<NttL, 2> &w, auto &hi, auto &lo_) {    // (u + v w, u - v w)
+    auto t = mul(v, w);
+    auto s = add(u, t).template to<std::remove_reference_t<decltype(hi)>::bound>();
+    auto d = sub(u, t);
+    if constexpr (INV) { hi = d; lo_ = s; } else { hi = s; lo_ = d; }
   };
   auto single_stage = [&](int j) {
     const uint32_t sl = 1u << j;
@@ -134,11 +165,20 @@ static __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArg
       uint32_t c = b & (W - 1), kk = b >> a.wlog;
       uint32_t r0 = ((kk >> j) << (j + 1)) | (kk & (sl - 1));
       uint32_t e0 = (r0 << a.wlog) + c, e1 = e0 + (sl << a.wlog);
-      Fr w = twiddle(j + a.lo, ((kk & (sl - 1)) << a.lo) + l0 + c);
-      Fr u = lds_get(e0), v = lds_get(e1);
-      butterfly(u, v, w);
-      lds_put(e0, u);
-      lds_put(e1, v);
+      auto w = twiddle(j + a.lo, ((kk & (sl - 1)) << a.lo) + l0 + c);
+      V u = lds_get(e0), v = lds_get(e1);
+      if constexpr (DIF) {
+        L29<NttL, 2 * HL> s;
+        L29<NttL, 3> p;
+        dif(u, v, w, s, p);
+        lds_put(e0, barrett(s));
+        lds_put(e1, p);
+      } else {
+        L29<NttL, HL + 4> x0, x1;
+        dit(u, v, w, x0, x1);
+        lds_put(e0, x0);
+        lds_put(e1, x1);
+      }
     }
     __syncthreads();
   };
@@ -150,23 +190,34 @@ static __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArg
       uint32_t r00 = ((kq >> j) << (j + 2)) | xlow;
       uint32_t e00 = (r00 << a.wlog) + c, e01 = e00 + (sl << a.wlog), e10 = e00 + (sl << (a.wlog + 1)), e11 = e10 + (sl << a.wlog);
       uint32_t im = (xlow << a.lo) + l0 + c;
-      Fr wa = twiddle(j + a.lo, im), wb0 = twiddle(j + 1 + a.lo, im), wb1 = twiddle(j + 1 + a.lo, im + (sl << a.lo));
-      Fr x00 = lds_get(e00), x01 = lds_get(e01), x10 = lds_get(e10), x11 = lds_get(e11);
-      if (DIF) {  // stage j + 1 first
-        butterfly(x00, x10, wb0);
-        butterfly(x01, x11, wb1);
-        butterfly(x00, x01, wa);
-        butterfly(x10, x11, wa);
-      } else {    // stage j first
-        butterfly(x00, x01, wa);
-        butterfly(x10, x11, wa);
-        butterfly(x00, x10, wb0);
-        butterfly(x01, x11, wb1);
+      auto wa = twiddle(j + a.lo, im), wb0 = twiddle(j + 1 + a.lo, im), wb1 = twiddle(j + 1 + a.lo, im + (sl << a.lo));
+      V x00 = lds_get(e00), x01 = lds_get(e01), x10 = lds_get(e10), x11 = lds_get(e11);
+      if constexpr (DIF) {  // stage j + 1 first
+        L29<NttL, 2 * HL> s0, s1;
+        L29<NttL, 3> p0, p1;
+        dif(x00, x10, wb0, s0, p0);
+        dif(x01, x11, wb1, s1, p1);
+        L29<NttL, 4 * HL> ss;
+        L29<NttL, 3> sp, pp;
+        L29<NttL, 6> ps;
+        dif(s0, s1, wa, ss, sp);
+        dif(p0, p1, wa, ps, pp);
+        lds_put(e00, barrett(ss));  // the one double sum of the four outputs
+        lds_put(e01, sp);
+        lds_put(e10, ps);
+        lds_put(e11, pp);
+      } else {              // stage j first
+        L29<NttL, HL + 4> y00, y01, y10, y11;
+        dit(x00, x01, wa, y00, y01);
+        dit(x10, x11, wa, y10, y11);
+        L29<NttL, HL + 8> z00, z10, z01, z11;
+        dit(y00, y10, wb0, z00, z10);
+        dit(y01, y11, wb1, z01, z11);
+        lds_put(e00, z00);
+        lds_put(e01, z01);
+        lds_put(e10, z10);
+        lds_put(e11, z11);
       }
-      lds_put(e00, x00);
-      lds_put(e01, x01);
-      lds_put(e10, x10);
-      lds_put(e11, x11);
     }
     __syncthreads();
   };
@@ -183,11 +234,27 @@ static __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArg
   for (uint32_t e = threadIdx.x; e < tile; e += NTT_THREADS) {
     uint32_t r = e >> a.wlog, c = e & (W - 1);
     size_t gi = base + ((size_t)r << a.lo) + c;
-    Fr x;
-#pragma unroll
-    for (int k = 0; k < 8; k++) x.v[k] = lds[k * tile + e];
-    store_fr(a.out + gi, x);
+    V x = lds_get(e);
+    Fr o;
+    if constexpr (DIF) {
+      static_assert(NTT_H_DIF <= NTT_H_IN, "what a DIF pass stores is what the next pass states on loading");
+      if (a.canon) pack29(canonical_small(x), o.v); else pack29(x, o.v);
+    } else {
+      auto y = barrett(x);  // < 2.5 r <= NTT_H_IN
+      if (a.canon) pack29(canonical_small(y), o.v); else pack29(y, o.v);
+    }
+    store_fr(a.out + gi, o);
   }
+}
+
+// the butterflies' twiddle tables from the x 2^256 ones: out[k] = T[k] x 2^5 (= w^k x 2^261), k < n; out[n] = -1 x 2^261
+static __global__ void twiddle261_kernel(const Fr *T, uint32_t n, Fr *out) {
+  uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k > n) return;
+  Fr w = k < n ? load_fr(T + k) : neg(Fr::one());
+  Fr o;
+  pack29(canonical_small(mul(unpack29<Fr29, 10>(w.v), const29<Fr29>(Fr29::TO261))), o.v);
+  store_fr(out + k, o);
 }
 
 // T[k] = g^k (Montgomery), k < n, g given in Montgomery form: thread k does square-and-multiply

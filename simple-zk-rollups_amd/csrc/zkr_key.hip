@@ -165,6 +165,10 @@ int key_alloc_workspace(zkr_key *k) {
   if (const char *e = getenv("ZKR_RED_STREAMS")) { int v = atoi(e); if (v >= 1 && v <= N_TABLES) k->n_red = v; }
   for (int j = 0; j < k->n_red; j++) ZKR_HIP_CHECK(hipStreamCreateWithPriority(&k->red_stream[j], hipStreamNonBlocking, prio_hi));
   for (int t = 0; t < N_TABLES; t++) k->plan[t] = msm_plan(t == T_H ? h.m : h.n, h.npts[t], (int)h.win_c[t]);
+  {
+    int rc = ntt_tables29_build((const Fr *)(k->arena + h.off_tw), 1u << h.tlog, (const Fr *)(k->arena + h.off_twl), 1u << TWL_LOG, nullptr, &k->tw29, &k->twl29);
+    if (rc) return rc;
+  }
   const size_t cap = (size_t)fused_capacity(h, k->plan);
   for (ProofSlot &sl : k->slot) {
     sl.cap = (int)cap;
@@ -551,6 +555,8 @@ void zkr_key_free(zkr_key *k) {
     if (ws.d_w) hipFree(ws.d_w);
     if (ws.ev_up) hipEventDestroy(ws.ev_up);
   }
+  hipFree(k->tw29);
+  hipFree(k->twl29);
   if (k->owns_arena) hipFree(k->arena);
   if (k->base_arena) hipFree(k->base_arena);
   delete k;

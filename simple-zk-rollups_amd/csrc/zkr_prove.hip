@@ -88,7 +88,18 @@ static std::vector<PassSpec> ntt_plan(int L) {
   return v;
 }
 
-int run_ntt(hipStream_t s, const Fr *in0, const Fr *in1, Fr *out, const Fr *tw, const Fr *twl, int tlog, int L, bool dif, bool inverse, int pre, int nbat) {
+// the butterflies' twiddle tables (x 2^261, one entry more than the x 2^256 tables they are made from; kernels_ntt.hpp)
+int ntt_tables29_build(const Fr *tw, uint32_t n_tw, const Fr *twl, uint32_t n_twl, hipStream_t s, Fr **tw29, Fr **twl29) {
+  *tw29 = *twl29 = nullptr;
+  ZKR_HIP_CHECK(hipMalloc(tw29, ((size_t)n_tw + 1) * 32));
+  ZKR_HIP_CHECK(hipMalloc(twl29, ((size_t)n_twl + 1) * 32));
+  twiddle261_kernel<<<(n_tw + 256) / 256, 256, 0, s>>>(tw, n_tw, *tw29);
+  twiddle261_kernel<<<(n_twl + 256) / 256, 256, 0, s>>>(twl, n_twl, *twl29);
+  ZKR_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int run_ntt(hipStream_t s, const Fr *in0, const Fr *in1, Fr *out, const NttTables &tb, int L, bool dif, bool inverse, int pre, int nbat) {
   std::vector<PassSpec> plan = ntt_plan(L);
   if (!dif) std::reverse(plan.begin(), plan.end());
   bool first = true;
@@ -97,10 +108,10 @@ int run_ntt(hipStream_t s, const Fr *in0, const Fr *in1, Fr *out, const Fr *tw, 
     a.in0 = first ? in0 : out;
     a.in1 = first ? in1 : nullptr;
     a.out = out;
-    a.tw = tw; a.twl = twl; a.tlog = tlog; a.L = L;
+    a.tw = tb.tw; a.tw29 = tb.tw29; a.twl29 = tb.twl29; a.tlog = tb.tlog; a.L = L;
     a.lo = ps.lo; a.hi = ps.hi; a.wlog = ps.wlog;
-    a.inverse = inverse ? 1 : 0;
     a.pre = first ? pre : PRE_NONE;
+    a.canon = &ps == &plan.back() ? 1 : 0;  // between passes values stay lazily reduced (below 3 r)
     // wave priority 1 for the NTT passes: with the 29-bit-limb accumulations the preparation chain (sorts + calcH) became
     // the stream that paces two proofs in flight (its kernels starved behind the accumulation's wavefronts: 4.1 ms of NTT
     // spans per proof at priority 0, 2.9 ms at 1; 120.9 -> 125.2 proofs/s; 2 and 3 measure the same as 1)
@@ -108,17 +119,16 @@ int run_ntt(hipStream_t s, const Fr *in0, const Fr *in1, Fr *out, const Fr *tw, 
     a.prio = ntt_prio;
     uint32_t tile = 1u << (ps.hi - ps.lo + ps.wlog);
     uint32_t grid = (1u << L) / tile;
-    size_t lds = (size_t)tile * 32;
+    size_t lds = (size_t)tile * 36;  // 9 limbs per element
     // workgroup size by transform size (kernels_ntt.hpp NTT_THREADS_*); ZKR_NTT_THREADS=256|512 overrides for experiments
     static const int thr_env = getenv("ZKR_NTT_THREADS") ? atoi(getenv("ZKR_NTT_THREADS")) : 0;
     const int threads = thr_env == NTT_THREADS_SMALL || thr_env == NTT_THREADS_LARGE ? thr_env : L >= NTT_LARGE_LOG ? NTT_THREADS_LARGE : NTT_THREADS_SMALL;
-    if (threads == NTT_THREADS_SMALL) {
-      if (dif) ntt_pass_kernel<true, NTT_THREADS_SMALL><<<dim3(grid, nbat), NTT_THREADS_SMALL, lds, s>>>(a);
-      else ntt_pass_kernel<false, NTT_THREADS_SMALL><<<dim3(grid, nbat), NTT_THREADS_SMALL, lds, s>>>(a);
-    } else {
-      if (dif) ntt_pass_kernel<true, NTT_THREADS_LARGE><<<dim3(grid, nbat), NTT_THREADS_LARGE, lds, s>>>(a);
-      else ntt_pass_kernel<false, NTT_THREADS_LARGE><<<dim3(grid, nbat), NTT_THREADS_LARGE, lds, s>>>(a);
-    }
+#define ZKR_NTT_LAUNCH(DIF, INV, T) ntt_pass_kernel<DIF, INV, T><<<dim3(grid, nbat), T, lds, s>>>(a)
+#define ZKR_NTT_LAUNCH_T(T) do { if (dif) { if (inverse) ZKR_NTT_LAUNCH(true, true, T); else ZKR_NTT_LAUNCH(true, false, T); } \
+                                 else { if (inverse) ZKR_NTT_LAUNCH(false, true, T); else ZKR_NTT_LAUNCH(false, false, T); } } while (0)
+    if (threads == NTT_THREADS_SMALL) ZKR_NTT_LAUNCH_T(NTT_THREADS_SMALL); else ZKR_NTT_LAUNCH_T(NTT_THREADS_LARGE);
+#undef ZKR_NTT_LAUNCH_T
+#undef ZKR_NTT_LAUNCH
     first = false;
   }
   ZKR_HIP_CHECK(hipGetLastError());
@@ -137,8 +147,9 @@ int calc_h_device(zkr_key *k, ProofSlot &sl, hipStream_t s, int nbat) {
   const Prof pf{k, &sl};
   const ArenaHeader &h = k->h;
   const unsigned char *ar = k->arena;
-  const Fr *tw = (const Fr *)(ar + h.off_tw), *twl = (const Fr *)(ar + h.off_twl);
+  const Fr *tw = (const Fr *)(ar + h.off_tw);
   int L = (int)h.logm, tlog = (int)h.tlog;
+  const NttTables tb{tw, k->tw29, k->twl29, tlog};
   uint32_t m = h.m;
   int sp = prof_begin(pf, s, "spmv");
   Fr *evals[2] = {sl.va, sl.vb};
@@ -152,13 +163,13 @@ int calc_h_device(zkr_key *k, ProofSlot &sl, hipStream_t s, int nbat) {
   sp = prof_begin(pf, s, "ntt");
   int rc;
   // coefficients (x m, bit-reversed), then evaluations on the coset g*w^c (x m, natural)
-  if ((rc = run_ntt(s, sl.va, nullptr, sl.ca, tw, twl, tlog, L, true, true, PRE_NONE, nbat))) return rc;
-  if ((rc = run_ntt(s, sl.vb, nullptr, sl.cb, tw, twl, tlog, L, true, true, PRE_NONE, nbat))) return rc;
-  if ((rc = run_ntt(s, sl.ca, nullptr, sl.ca, tw, twl, tlog, L, false, false, PRE_COSET, nbat))) return rc;
-  if ((rc = run_ntt(s, sl.cb, nullptr, sl.cb, tw, twl, tlog, L, false, false, PRE_COSET, nbat))) return rc;
+  if ((rc = run_ntt(s, sl.va, nullptr, sl.ca, tb, L, true, true, PRE_NONE, nbat))) return rc;
+  if ((rc = run_ntt(s, sl.vb, nullptr, sl.cb, tb, L, true, true, PRE_NONE, nbat))) return rc;
+  if ((rc = run_ntt(s, sl.ca, nullptr, sl.ca, tb, L, false, false, PRE_COSET, nbat))) return rc;
+  if ((rc = run_ntt(s, sl.cb, nullptr, sl.cb, tb, L, false, false, PRE_COSET, nbat))) return rc;
   // D' = iNTT(A(gw^c).B(gw^c)) and S' = iNTT(a.b), both unscaled and bit-reversed
-  if ((rc = run_ntt(s, sl.ca, sl.cb, sl.ca, tw, twl, tlog, L, true, true, PRE_MUL, nbat))) return rc;
-  if ((rc = run_ntt(s, sl.va, sl.vb, sl.va, tw, twl, tlog, L, true, true, PRE_MUL, nbat))) return rc;
+  if ((rc = run_ntt(s, sl.ca, sl.cb, sl.ca, tb, L, true, true, PRE_MUL, nbat))) return rc;
+  if ((rc = run_ntt(s, sl.va, sl.vb, sl.va, tb, L, true, true, PRE_MUL, nbat))) return rc;
   // constants: S' = m S / R, D' = m^3 D g^i / R  ->  h = S'*R^2/(2m) (*1/R)  -  D' g^-i * R^2/(2 m^3) (*1/R)
   Fr r2 = Fr::r2();
   Fr minv = inv(to_mont(fr_from_u64(m)));        // Montgomery(1/m)
@@ -778,13 +789,16 @@ int zkr_ntt(void *data_std, unsigned logn, int inverse, int device) {
   ZKR_HIP_CHECK(hipMemcpy(d, data_std, n * 32, hipMemcpyHostToDevice));
   twiddle_table_kernel<<<(unsigned)((n + 255) / 256), 256>>>(tw, (uint32_t)n, host_root_of_unity(logn + 1));
   twiddle_table_kernel<<<((1u << TWL_LOG) + 255) / 256, 256>>>(twl, 1u << TWL_LOG, host_root_of_unity(TWL_LOG + 1));
-  int rc = run_ntt(nullptr, d, nullptr, d, tw, twl, (int)logn, (int)logn, true, inverse != 0, PRE_NONE);  // natural -> bit-reversed
+  Fr *tw29 = nullptr, *twl29 = nullptr;
+  int rc = ntt_tables29_build(tw, (uint32_t)n, twl, 1u << TWL_LOG, nullptr, &tw29, &twl29);
+  if (!rc) rc = run_ntt(nullptr, d, nullptr, d, NttTables{tw, tw29, twl29, (int)logn}, (int)logn, true, inverse != 0, PRE_NONE);  // natural -> bit-reversed
   if (!rc) {
     bitrev_copy_kernel<<<(unsigned)((n + 255) / 256), 256>>>(d, d2, (int)logn);
     if (inverse) scale_kernel<<<(unsigned)((n + 255) / 256), 256>>>(d2, n, inv(to_mont(fr_from_u64(n))));
     hipError_t e = hipMemcpy(data_std, d2, n * 32, hipMemcpyDeviceToHost);
     if (e != hipSuccess) { set_error("copy back failed: %s", hipGetErrorString(e)); rc = ZKR_ERR_HIP; }
   }
+  hipFree(tw29); hipFree(twl29);
   hipFree(d); hipFree(d2); hipFree(tw); hipFree(twl);
   return rc;
 }

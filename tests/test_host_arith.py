@@ -177,6 +177,25 @@ def test_field29_product_forms_on_raw_limbs(L):
                 assert all(x < (1 << 29) for x in o[:8]) and got <= (t >> 261) + P, (field, form)
 
 
+def test_quotient_estimate_reduction_on_raw_limbs(L):
+    """barrett() (the NTT's bound keeper: one quotient estimate from the top limb, no product) and canonical_small():
+    for values anywhere below 64 p -- multiples of p and their neighbours, all-ones limbs, random -- the result is congruent,
+    non-negative, below 2.5 p, its low limbs normalised; the canonical form is the residue itself."""
+    rnd = random.Random(71)
+    for field, P in ((0, Q), (1, R)):
+        vals = [0, 1, P - 1, P, P + 1, 2 * P - 1, 2 * P, 63 * P, 64 * P - 1, (1 << 232) - 1, 1 << 232, (P >> 232) << 232]
+        vals += [k * P + d for k in (1, 2, 3, 17, 40, 63) for d in (-1, 0, 1, (1 << 232) - 1) if 0 <= k * P + d < 64 * P]
+        vals += [rnd.randrange(64 * P) for _ in range(3000)] + [rnd.randrange(4 * P) for _ in range(1000)]
+        for v in vals:
+            limbs = [(v >> (29 * i)) & ((1 << 29) - 1) for i in range(8)] + [v >> 232]
+            inp = (ctypes.c_uint32 * 9)(*limbs)
+            out, can = (ctypes.c_uint32 * 9)(), (ctypes.c_uint32 * 9)()
+            L.zkt29_barrett(field, inp, out, can)
+            got = _limbs_value(out)
+            assert got % P == v % P and 2 * got < 5 * P and all(x < (1 << 29) for x in out[:8]), (field, v)
+            assert _limbs_value(can) == v % P, (field, v)
+
+
 def test_radix_change_roundtrip(L):
     """x 2^256 (the key material's Montgomery radix, binarify.ts:78-90) -> x 2^261 (hot-path radix) -> back."""
     rnd = random.Random(31)
