@@ -522,7 +522,7 @@ def main():
                     "note": "Pippenger bucket accumulation is integer-VALU bound (v_mad_u64_u32), not HBM bound; see valu. traffic > algorithmic bytes by design: "
                             "the kernel gathers one precomputed 64-byte multiple per window (13 per point, 832 B) instead of re-deriving it, "
                             "plus the 4-byte entries; the PMC figure applies the x2 read rule, an upper bound for 64-byte gathers. "
-                            "avg_launch_ms is measured with two proofs in flight (the kernel shares the chip with the other streams); isolated it runs 0.87 ms"}
+                            "avg_launch_ms is measured with two proofs in flight (the kernel shares the chip with the other streams); isolated it runs 0.79 ms"}
         try:
             peak_gmul = zkr_hip.bench_fq_mul(local)
             gm = fqmul_per_launch / (avg_ms * 1e-3) / 1e9
