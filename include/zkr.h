@@ -141,7 +141,7 @@ int zkr_verify(const void *vk_bin, size_t vk_len, const uint8_t proof[256], cons
 int zkr_verify_batch(const void *vk_bin, size_t vk_len, const uint8_t *proofs, const void *publics_std, size_t n_proofs, size_t n_public, int *all_valid);
 
 /* ---- stage hooks (tests, profiling) ----------------------------------------------------------- */
-/* In-place NTT of n = 2^logn standard-form elements in host memory; natural order in and out. */
+/* In-place NTT of n = 2^logn standard-form elements in host memory; natural order in and out (words >= r are reduced first). */
 int zkr_ntt(void *data_std, unsigned logn, int inverse, int device);
 /* sum_i scalars[i] * points[i].  points: Montgomery affine as in the key sections (64 B G1 / 128 B G2;
  * x == 0 encodes infinity, binarify.ts:92-102); scalars: std 32 B.  out: std affine; *is_inf set when

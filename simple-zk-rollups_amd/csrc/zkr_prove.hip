@@ -787,6 +787,7 @@ int zkr_ntt(void *data_std, unsigned logn, int inverse, int device) {
   ZKR_HIP_CHECK(hipMalloc(&tw, n * 32));
   ZKR_HIP_CHECK(hipMalloc(&twl, (size_t)(1u << TWL_LOG) * 32));
   ZKR_HIP_CHECK(hipMemcpy(d, data_std, n * 32, hipMemcpyHostToDevice));
+  ingest_kernel<<<(unsigned)((n + 255) / 256), 256>>>(d, d, n);  // any 256-bit word -> below r, as the proving path does with witnesses: the passes state bounds on what they load
   twiddle_table_kernel<<<(unsigned)((n + 255) / 256), 256>>>(tw, (uint32_t)n, host_root_of_unity(logn + 1));
   twiddle_table_kernel<<<((1u << TWL_LOG) + 255) / 256, 256>>>(twl, 1u << TWL_LOG, host_root_of_unity(TWL_LOG + 1));
   Fr *tw29 = nullptr, *twl29 = nullptr;

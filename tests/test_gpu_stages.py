@@ -62,6 +62,18 @@ def test_ntt_matches_oracle(logn):
     assert zkr_hip.ntt(data, inverse=True) == coracle.ntt(data, inverse=True)
 
 
+def test_ntt_reduces_words_above_r_first():
+    """Words of 2^256 - 1, r, r + 5 are taken mod r before the transform (the passes state bounds on what they load)."""
+    import zkr_hip
+    rnd = random.Random(5)
+    n = 64
+    raw = [(1 << 256) - 1, R, R + 5, 3 * R + 1] + [rnd.randrange(1 << 256) for _ in range(n - 4)]
+    a = zkr_hip.ntt(b"".join(_le(v) for v in raw), False)
+    b = zkr_hip.ntt(b"".join(_le(v % R) for v in raw), False)
+    assert a == b
+    assert all(int.from_bytes(a[32 * i:32 * i + 32], "little") < R for i in range(n))
+
+
 def test_ntt_roundtrip_and_linearity_2_20():
     import zkr_hip
     rnd = random.Random(20)
