@@ -62,6 +62,25 @@ def test_ntt_matches_oracle(logn):
     assert zkr_hip.ntt(data, inverse=True) == coracle.ntt(data, inverse=True)
 
 
+@pytest.mark.parametrize("logn", [11, 13, 16])
+def test_ntt_extreme_inputs_match_oracle(logn):
+    """The butterflies keep lazily reduced values (kernels_ntt.hpp: sums grow by up to 4 half-moduli per stage of a DIT
+    pass, a DIF pair of stages quadruples one of its outputs before the quotient-estimate reduction): vectors whose
+    entries are all r - 1, only 0 and r - 1, and values whose 29-bit limbs are all ones drive every intermediate to the top
+    of its bound.  Sizes: one full-tile pass (2^11), a short strided pass in front of it (2^13), two long passes (2^16)."""
+    import zkr_hip
+    rnd = random.Random(1000 + logn)
+    n = 1 << logn
+    ones29 = ((1 << 253) - 1) % R
+    cases = [[R - 1] * n,
+             [(R - 1) if rnd.random() < 0.5 else 0 for _ in range(n)],
+             [rnd.choice((R - 1, R - 2, ones29, (1 << 232) - 1, 1, 0)) for _ in range(n)]]
+    for v in cases:
+        data = b"".join(_le(x) for x in v)
+        assert zkr_hip.ntt(data) == coracle.ntt(data)
+        assert zkr_hip.ntt(data, inverse=True) == coracle.ntt(data, inverse=True)
+
+
 def test_ntt_reduces_words_above_r_first():
     """Words of 2^256 - 1, r, r + 5 are taken mod r before the transform (the passes state bounds on what they load)."""
     import zkr_hip
