@@ -30,6 +30,9 @@
 
 namespace zkr {
 
+#ifndef ZKR_RED_PRIO
+#define ZKR_RED_PRIO 3  // wave priority of the oversized-bucket and reduction kernels (0..3)
+#endif
 constexpr int MSM_THREADS = 256;
 constexpr uint32_t BIG_CAP = 1024;  // oversized buckets tracked per MSM
 
@@ -113,6 +116,7 @@ __device__ __forceinline__ uint32_t digit_bucket(int d) { return (uint32_t)(d < 
 // end to end, n_per scalars each; proof p owns the bucket ranges [p * nR1, (p + 1) * nR1) -- i.e. its own bucket set --
 // so one sort / accumulation / reduction launch serves every proof of the batch.  One proof: n_per = n, nR1 = nR.
 static __global__ __launch_bounds__(MSM_THREADS) void msm_digits_count_kernel(const Fr *scalars, uint32_t n, uint32_t n_per, int c, int K, int nbl_log, uint32_t nR1, uint32_t nR, uint32_t *rng_cnt) {
+  ZKR_PREP_SETPRIO();
   __shared__ uint32_t s_cnt[MAX_RANGES];
   if (threadIdx.x < nR) s_cnt[threadIdx.x] = 0;
   __syncthreads();
@@ -134,6 +138,7 @@ static __global__ __launch_bounds__(MSM_THREADS) void msm_digits_count_kernel(co
 static __global__ __launch_bounds__(MSM_THREADS) void msm_digits_scatter_kernel(const Fr *scalars, uint32_t n, uint32_t n_per, int c, int K, int nbl_log, uint32_t nR1, uint32_t nR,
                                                                               const uint32_t *rng_cnt, uint32_t *rng_fill, uint32_t *rng_off,
                                                                               uint32_t *ent_s, uint32_t *ent_b) {
+  ZKR_PREP_SETPRIO();
   __shared__ uint32_t s_cnt[MAX_RANGES], s_base[MAX_RANGES];
   if (threadIdx.x < nR) s_cnt[threadIdx.x] = 0;
   __syncthreads();
@@ -199,6 +204,7 @@ __device__ __forceinline__ void sort_chunk(const uint32_t *rng_off, uint32_t r, 
 // cnt[(r * J + j) * nbl + b] = occupancy of bucket r * nbl + b within chunk j
 static __global__ __launch_bounds__(SORT_THREADS) void msm_hist_kernel(const uint32_t *ent_s, const uint32_t *ent_b, const uint32_t *rng_off, const uint32_t *rank,
                                                                      uint32_t n_per, uint32_t nbl, uint32_t J, uint32_t *cnt) {
+  ZKR_PREP_SETPRIO();
   extern __shared__ __attribute__((aligned(16))) uint32_t s_bkt[];
   const uint32_t j = blockIdx.x % J, r = blockIdx.x / J;
   for (uint32_t b = threadIdx.x; b < nbl; b += SORT_THREADS) s_bkt[b] = 0;
@@ -227,6 +233,7 @@ static __global__ __launch_bounds__(SORT_THREADS) void msm_hist_kernel(const uin
 
 // per bucket: exclusive prefix over the J chunks (in place) and the bucket total -> counts[]
 static __global__ __launch_bounds__(MSM_THREADS) void msm_colscan_kernel(uint32_t *cnt, uint32_t nb, uint32_t nbl, uint32_t J, uint32_t *counts) {
+  ZKR_PREP_SETPRIO();
   uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= nb) return;
   uint32_t r = g / nbl, b = g % nbl;
@@ -245,6 +252,7 @@ static __global__ __launch_bounds__(MSM_THREADS) void msm_colscan_kernel(uint32_
 static __global__ __launch_bounds__(SORT_THREADS) void msm_scatter_kernel(const uint32_t *ent_s, const uint32_t *ent_b, const uint32_t *rng_off, const uint32_t *rank,
                                                                         uint32_t n_per, uint32_t n, uint32_t nbl, uint32_t J, const uint32_t *cnt, const uint32_t *offsets,
                                                                         uint32_t *entries) {
+  ZKR_PREP_SETPRIO();
   extern __shared__ __attribute__((aligned(16))) uint32_t s_bkt[];
   const uint32_t j = blockIdx.x % J, r = blockIdx.x / J;
   const uint32_t *pre = cnt + ((size_t)r * J + j) * nbl, *off = offsets + (size_t)r * nbl;
@@ -278,6 +286,7 @@ constexpr int SCAN_PER_THREAD = 8;
 constexpr int SCAN_BLOCK = SCAN_THREADS * SCAN_PER_THREAD;
 
 static __global__ __launch_bounds__(SCAN_THREADS) void msm_scan_sums_kernel(const uint32_t *counts, uint32_t nb, uint32_t *block_sums) {
+  ZKR_PREP_SETPRIO();
   __shared__ uint32_t part[SCAN_THREADS];
   uint32_t base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_PER_THREAD;
   uint32_t s = 0;
@@ -294,6 +303,7 @@ static __global__ __launch_bounds__(SCAN_THREADS) void msm_scan_sums_kernel(cons
 
 // in-place exclusive scan of nblocks block sums by one workgroup; writes the grand total to *total
 static __global__ __launch_bounds__(1024) void msm_scan_top_kernel(uint32_t *block_sums, uint32_t nblocks, uint32_t *total) {
+  ZKR_PREP_SETPRIO();
   __shared__ uint32_t part[1024];
   uint32_t t = threadIdx.x;
   uint32_t per = (nblocks + 1023) / 1024;
@@ -319,6 +329,7 @@ constexpr uint32_t BIG_MARK = 0xffffffffu;  // counts[b] after the scan: bucket 
 static __global__ __launch_bounds__(SCAN_THREADS) void msm_scan_apply_kernel(uint32_t *counts, const uint32_t *block_sums, const uint32_t *total,
                                                                            uint32_t *offsets, uint32_t nb, uint32_t big_thresh,
                                                                            uint32_t *big_list, uint32_t *big_count, uint32_t big_cap, uint32_t *size_hist) {
+  ZKR_PREP_SETPRIO();
   __shared__ uint32_t part[SCAN_THREADS];
   __shared__ uint32_t s_hist[SIZE_BINS];
   for (uint32_t b = threadIdx.x; b < SIZE_BINS; b += SCAN_THREADS) s_hist[b] = 0;
@@ -359,6 +370,7 @@ static __global__ __launch_bounds__(SCAN_THREADS) void msm_scan_apply_kernel(uin
 // msm_big_kernel-owned and empty buckets go last).  Same 2048-bucket partition as the scan.  size_hist is
 // complete when this runs; `taken` (zeroed) hands out ranges inside each size class.
 static __global__ __launch_bounds__(SCAN_THREADS) void msm_order_kernel(const uint32_t *counts, uint32_t nb, const uint32_t *size_hist, uint32_t *taken, uint32_t *order) {
+  ZKR_PREP_SETPRIO();
   __shared__ uint32_t s_start[SIZE_BINS];  // first: global histogram -> start of each class (descending sizes)
   __shared__ uint32_t s_hist[SIZE_BINS];   // local histogram, then base of this workgroup's range in each class
   __shared__ uint32_t part[SCAN_THREADS];
@@ -497,7 +509,7 @@ template <class F, int MINW>
 static __global__ __launch_bounds__(MSM_THREADS, MINW) void msm_big_kernel(const Affine<F> *points, const uint32_t *offsets, const uint32_t *entries,
                                                                    const uint32_t *big_list, const uint32_t *big_count, uint32_t big_cap,
                                                                    XYZZ<F> *partials) {
-  __builtin_amdgcn_s_setprio(3);  // few long-running wavefronts on the critical path: win VALU arbitration against the bulk accumulation
+  __builtin_amdgcn_s_setprio(ZKR_RED_PRIO);  // few long-running wavefronts on the critical path: win VALU arbitration against the bulk accumulation
   using C = typename CoordOf<F>::C;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   XYZZ<F> *sh = reinterpret_cast<XYZZ<F> *>(smem);
@@ -526,7 +538,7 @@ static __global__ __launch_bounds__(MSM_THREADS, MINW) void msm_big_kernel(const
 template <class F, int MINW>
 static __global__ __launch_bounds__(64, MINW) void msm_big_finish_kernel(const XYZZ<F> *partials, const uint32_t *big_list, const uint32_t *big_count,
                                                                          uint32_t big_cap, XYZZ<F> *buckets) {
-  __builtin_amdgcn_s_setprio(3);  // few long-running wavefronts on the critical path: win VALU arbitration against the bulk accumulation
+  __builtin_amdgcn_s_setprio(ZKR_RED_PRIO);  // few long-running wavefronts on the critical path: win VALU arbitration against the bulk accumulation
   uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= min(*big_count, big_cap)) return;
   using C = typename CoordOf<F>::C;
@@ -546,7 +558,7 @@ static __global__ __launch_bounds__(64, MINW) void msm_big_finish_kernel(const X
 // group_out: R[ng] then T[ng];  task_out: [ntask][S] with ntask = log2(ng) + 2.
 template <class F, int MINW>
 static __global__ __launch_bounds__(MSM_THREADS, MINW) void msm_reduce1_kernel(const XYZZ<F> *buckets, MsmGeom g, XYZZ<F> *group_out) {
-  __builtin_amdgcn_s_setprio(3);  // few long-running wavefronts on the critical path: win VALU arbitration against the bulk accumulation
+  __builtin_amdgcn_s_setprio(ZKR_RED_PRIO);  // few long-running wavefronts on the critical path: win VALU arbitration against the bulk accumulation
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t ng = (g.nbw >> g.glog) * g.batch, gs = 1u << g.glog;  // groups of every bucket set of the batch, end to end
   if (t >= ng) return;
@@ -563,7 +575,7 @@ static __global__ __launch_bounds__(MSM_THREADS, MINW) void msm_reduce1_kernel(c
 
 template <class F, int MINW>
 static __global__ __launch_bounds__(MSM_THREADS, MINW) void msm_reduce2_kernel(const XYZZ<F> *group_out, MsmGeom g, XYZZ<F> *task_out) {
-  __builtin_amdgcn_s_setprio(3);
+  __builtin_amdgcn_s_setprio(ZKR_RED_PRIO);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   XYZZ<F> *sh = reinterpret_cast<XYZZ<F> *>(smem);
   const uint32_t nglog = (uint32_t)(g.c - 1 - g.glog), ng = 1u << nglog;
@@ -596,7 +608,7 @@ static __global__ __launch_bounds__(MSM_THREADS, MINW) void msm_reduce2_kernel(c
 // one workgroup of MSM_THREADS lanes per bucket set; needs ntask * S <= MSM_THREADS (msm_plan guarantees it)
 template <class F, int MINW>
 static __global__ __launch_bounds__(MSM_THREADS, MINW) void msm_reduce3_kernel(const XYZZ<F> *task_out, MsmGeom g, XYZZ<F> *result) {
-  __builtin_amdgcn_s_setprio(3);
+  __builtin_amdgcn_s_setprio(ZKR_RED_PRIO);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   XYZZ<F> *sh = reinterpret_cast<XYZZ<F> *>(smem);
   const uint32_t nglog = (uint32_t)(g.c - 1 - g.glog), ntask = nglog + 2, S = g.S;

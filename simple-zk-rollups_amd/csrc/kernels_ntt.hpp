@@ -286,6 +286,7 @@ static __global__ void ingest_kernel(const Fr *in, Fr *out, size_t n) {
 // wavefront waiting for one; rows wider than SPMV_WIDE are left to spmv_wide_kernel (one wavefront per row).
 constexpr uint32_t SPMV_WIDE = 8;
 static __global__ void spmv_kernel(const uint32_t *row_ptr, const uint32_t *col, const Fr *coef, const Fr *w, Fr *out, uint32_t m, uint32_t n) {
+  ZKR_PREP_SETPRIO();
   uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= m) return;
   w += (size_t)blockIdx.y * n;    // blockIdx.y: witness of a fused batch
@@ -299,6 +300,7 @@ static __global__ void spmv_kernel(const uint32_t *row_ptr, const uint32_t *col,
 // wide[i] = index of the i-th row wider than SPMV_WIDE; one wavefront per row, terms strided over the lanes, LDS tree
 static __global__ __launch_bounds__(64) void spmv_wide_kernel(const uint32_t *row_ptr, const uint32_t *col, const Fr *coef, const Fr *w, Fr *out,
                                                             const uint32_t *wide, uint32_t n_wide, uint32_t m, uint32_t n) {
+  ZKR_PREP_SETPRIO();
   __shared__ uint32_t sh[8 * 64];
   if (blockIdx.x >= n_wide) return;
   w += (size_t)blockIdx.y * n;
@@ -327,6 +329,7 @@ static __global__ __launch_bounds__(64) void spmv_wide_kernel(const uint32_t *ro
 // h (bit-reversed order) = C1*S' - C2 * g^-i * D'   (DESIGN.md "calcH on the GPU"); S', D' are the
 // unscaled inverse-DIF outputs of a.b and A(gw^c).B(gw^c); i = bitrev(pos).
 static __global__ void combine_h_kernel(const Fr *S, const Fr *D, Fr *h, const Fr *tw, int tlog, int L, Fr c1, Fr c2) {
+  ZKR_PREP_SETPRIO();
   uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x;
   if (pos >= (1u << L)) return;
   const size_t boff = (size_t)blockIdx.y << L;  // blockIdx.y: proof of a fused batch
