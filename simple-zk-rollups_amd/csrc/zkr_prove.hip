@@ -599,14 +599,16 @@ static int stage_upload(zkr_key *k, int idx, int j, const void *witness_std, siz
   if (last) ZKR_HIP_CHECK(hipEventRecord(ws.ev_up, k->prep_stream));
   return 0;
 }
-// proofs per submit for a batch of `count`: full groups of the key's fused capacity; a batch below two full groups is
-// cut in two halves so that two groups are in flight (the second group's preparation runs under the first's accumulations)
-static int group_size(const zkr_key *k, size_t count) {
+// Groups of a batch of `count` proofs: as few submits as the key's fused capacity allows, but at least two (the second
+// group's preparation runs under the first's accumulations), of sizes that differ by at most one -- 50 proofs at capacity 8
+// go as 8 + 7 x 6, not 6 x 8 + 2: a group of two costs almost the launches and latency chains of a group of eight.
+static size_t group_count(const zkr_key *k, size_t count) {
   const size_t cap = (size_t)k->slot[0].cap;
-  if (cap <= 1) return 1;
-  size_t g = count >= 2 * cap ? cap : (count + 1) / 2;
-  return (int)(g < 1 ? 1 : g > cap ? cap : g);
+  if (cap <= 1 || count <= 1) return count;
+  size_t ng = (count + cap - 1) / cap;
+  return ng < 2 ? 2 : ng;
 }
+static int next_group(size_t remaining, size_t groups_left) { return (int)((remaining + groups_left - 1) / groups_left); }
 
 // Hand out a free proof slot and run `enqueue` on it under the key's lock (two host threads proving on one key --
 // e.g. two libuv workers behind Promise.all -- then pipeline like submit/collect does).  wait: block until a slot
@@ -654,7 +656,7 @@ int zkr_prove_batch(zkr_key *key, const void *const *witnesses_std, size_t witne
   // Pipeline of one host thread over groups of `g` proofs (g = 1 for circuits that fill the chip alone): the witnesses of
   // the next group are staged (copy into pinned memory + DMA) BEFORE the oldest group in flight is collected, i.e. while
   // both proof slots compute; then the freed slot takes the group at once.
-  const int g = group_size(key, count);
+  size_t groups_left = group_count(key, count);
   int tickets[PROOF_SLOTS], stages[PROOF_SLOTS];
   size_t first[PROOF_SLOTS];
   int in_flight = 0, rc = 0;
@@ -665,8 +667,8 @@ int zkr_prove_batch(zkr_key *key, const void *const *witnesses_std, size_t witne
     in_flight--;
     return r;
   };
-  for (size_t i = 0; i < count && !rc; i += (size_t)g) {
-    const int nb = (int)(count - i < (size_t)g ? count - i : (size_t)g);
+  for (size_t i = 0; i < count && !rc;) {
+    const int nb = next_group(count - i, groups_left--);
     int st = -1;
     if ((rc = stage_acquire(key, &st))) break;
     for (int j = 0; j < nb && !rc; j++) rc = stage_upload(key, st, j, witnesses_std[i + j], witness_len, j == nb - 1);
@@ -680,6 +682,7 @@ int zkr_prove_batch(zkr_key *key, const void *const *witnesses_std, size_t witne
     });
     if (rc) { hipStreamSynchronize(key->prep_stream); stage_release(key, st); break; }
     tickets[in_flight] = t; first[in_flight] = i; stages[in_flight] = st; in_flight++;
+    i += (size_t)nb;
   }
   while (in_flight > 0) {  // drain, also after an error: a submitted group must be collected to free its slot
     int r = collect_oldest();
@@ -693,7 +696,7 @@ int zkr_prove_batch_device(zkr_key *key, const void *const *d_witnesses_std, siz
   if (!key || (!d_witnesses_std && count) || !proofs_out) { set_error("null argument"); return ZKR_ERR_ARG; }
   for (size_t i = 0; i < count; i++)
     if (!d_witnesses_std[i]) { set_error("witness %zu is null", i); return ZKR_ERR_ARG; }
-  const int g = group_size(key, count);
+  size_t groups_left = group_count(key, count);
   int tickets[PROOF_SLOTS];
   size_t first[PROOF_SLOTS];
   int in_flight = 0, rc = 0;
@@ -703,15 +706,15 @@ int zkr_prove_batch_device(zkr_key *key, const void *const *d_witnesses_std, siz
     in_flight--;
     return r;
   };
-  for (size_t i = 0; i < count && !rc; i += (size_t)g) {
-    const int nb = (int)(count - i < (size_t)g ? count - i : (size_t)g);
+  for (size_t i = 0; i < count && !rc;) {
+    const int nb = next_group(count - i, groups_left--);
     if (in_flight == PROOF_SLOTS) rc = collect_oldest();
     if (rc) break;
     int t = -1;
     rc = with_free_slot(key, true, &t, [&](ProofSlot &sl) -> int {
       return prove_submit_group(key, sl, (const Fr *const *)(d_witnesses_std + i), nb, r32s ? r32s + 32 * i : nullptr, s32s ? s32s + 32 * i : nullptr, (hipStream_t)stream);
     });
-    if (!rc) { tickets[in_flight] = t; first[in_flight] = i; in_flight++; }
+    if (!rc) { tickets[in_flight] = t; first[in_flight] = i; in_flight++; i += (size_t)nb; }
   }
   while (in_flight > 0) {
     int r = collect_oldest();
