@@ -154,6 +154,30 @@ ZKR_HD XYZZ29<C> add_full29(const XYZZ29<C> &a, const XYZZ29<C> &b) {
   return make_xyzz<C>(x3, y3, mul(mul(a.zz, b.zz), pp), mul(mul(a.zzz, b.zzz), ppp));
 }
 
+// ---- Jacobian doubling chain of the window-table build (key load; kernels_msm.hpp msm_precompute_kernel).  (X, Y, Z) with
+// x = X / Z^2, y = Y / Z^3: ONE denominator per point, so the 12 multiples a table stores per base point are made affine
+// with one inversion (Montgomery's trick over the levels) instead of twelve.  a = 0 (dbl-2009-l, with 4 X Y^2 as a product):
+// 3 products, 4 squares, two quotient-estimate reductions; bounds in and out: X, Y <= 5, Z <= 8 half moduli.
+constexpr int JX = 5, JY = 5, JZ = 8;
+template <class C>
+struct Jac29 {
+  typename C::template T<JX> x;
+  typename C::template T<JY> y;
+  typename C::template T<JZ> z;
+};
+template <class C>
+ZKR_HD Jac29<C> dbl_jac29(const Jac29<C> &p) {
+  auto a = sqr(p.x);                                          // X^2
+  auto b = sqr(p.y);                                          // Y^2
+  auto c8 = dbl(dbl(dbl(sqr(b))));                            // 8 Y^4
+  auto s = dbl(dbl(mul(p.x, b)));                             // 4 X Y^2
+  auto e = add(dbl(a), a);                                    // 3 X^2
+  auto x3 = barrett(sub(sqr(e), dbl(s)));                     // E^2 - 2 S
+  auto y3 = barrett(sub(mul(e, sub(s, x3)), c8));             // E (S - X3) - 8 Y^4
+  auto z3 = dbl(mul(p.y, p.z));                               // 2 Y Z
+  return Jac29<C>{x3.template to<JX>(), y3.template to<JY>(), z3.template to<JZ>()};
+}
+
 // ---- change of Montgomery radix at the edges of the hot path (cold)
 // packed coordinate x 2^256 (key material, field.hpp) -> packed canonical x 2^261, and back
 template <class F>

@@ -488,4 +488,31 @@ ZKR_HD bool is_zero_mod_p(const Q29<HA> &x) { return is_zero_mod_p(x.a) && is_ze
 template <int HA>
 ZKR_HD_COLD Q29<2> canonical(const Q29<HA> &x) { return Q29<2>{canonical(x.a), canonical(x.b)}; }
 
+template <int HA>
+ZKR_HD Q29<5> barrett(const Q29<HA> &x) { return Q29<5>{barrett(x.a), barrett(x.b)}; }
+template <int HA>
+ZKR_HD Q29<2> canonical_small(const Q29<HA> &x) { return Q29<2>{canonical_small(x.a), canonical_small(x.b)}; }
+
+// ---- inversion (key-build kernels only): a^(p-2), plain square-and-multiply over the bits of p - 2 (254 squares and one
+// product per set bit; the exponent is the same for every lane, so the branch is uniform).  0 -> 0.
+template <class PM, int HA>
+ZKR_HD L29<PM, 4> inv29(const L29<PM, HA> &a) {
+  static_assert(HA * 4 <= 676, "operand bound too wide for the chain's products");
+  static_assert(PM::P[0] >= 2, "p - 2 is taken limb-wise without a borrow");
+  L29<PM, 4> r = one29<PM>().template to<4>();
+#pragma unroll 1
+  for (int i = 253; i >= 0; i--) {  // p < 2^254
+    r = sqr(r).template to<4>();
+    const uint32_t limb = PM::P[i / 29] - (i / 29 == 0 ? 2u : 0u);
+    if ((limb >> (i % 29)) & 1u) r = mul(r, a).template to<4>();
+  }
+  return r;
+}
+// 1 / (a + b u) = (a - b u) / (a^2 + b^2)
+template <int HA>
+ZKR_HD Q29<4> inv29(const Q29<HA> &x) {
+  auto ni = inv29(mul_sum2(x.a, x.a, x.b, x.b));
+  return Q29<4>{mul(x.a, ni).template to<4>(), mul(neg(x.b), ni).template to<4>()};
+}
+
 }  // namespace zkr

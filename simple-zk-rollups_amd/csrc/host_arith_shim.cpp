@@ -68,6 +68,35 @@ template <class F> static int chain29(const uint8_t *pts, const uint8_t *signs, 
   else store_g2_std(out, *reinterpret_cast<G2Affine *>(&a));
   return 0;
 }
+// 2^(c l) P for l = 1..levels as msm_precompute_kernel computes them: Jacobian doubling chain on the 29-bit limbs, ONE
+// inversion of the product of the denominators, affine results.  p: wire form (x 2^256); out: levels x standard-form affine
+template <class F> static void jac_levels29(const uint8_t *pt, int c, int levels, uint8_t *out) {
+  using C = typename CoordOf<F>::C;
+  Affine<F> p;
+  memcpy(&p, pt, sizeof p);
+  p.x = radix_to_261(p.x); p.y = radix_to_261(p.y);
+  Jac29<C> q{C::template unpack<2>(p.x).template to<JX>(), C::template unpack<2>(p.y).template to<JY>(), C::one().template to<JZ>()};
+  std::vector<Jac29<C>> lv;
+  auto prod = C::one().template to<4>();
+  for (int l = 0; l < levels; l++) {
+    for (int b = 0; b < c; b++) q = dbl_jac29<C>(q);
+    lv.push_back(q);
+    prod = mul(prod, q.z).template to<4>();
+  }
+  auto inv = inv29(prod);
+  for (int l = levels - 1; l >= 0; l--) {
+    auto pre = C::one().template to<4>();
+    for (int j = 0; j < l; j++) pre = mul(pre, lv[j].z).template to<4>();
+    auto iz = mul(inv, pre);
+    inv = mul(inv, lv[l].z).template to<4>();
+    auto iz2 = sqr(iz);
+    auto iz3 = mul(iz2, iz);
+    Affine<F> a{radix_to_256(C::template pack<2>(canonical_small(mul(lv[l].x, iz2)))), radix_to_256(C::template pack<2>(canonical_small(mul(lv[l].y, iz3))))};
+    if constexpr (sizeof(F) == 32) store_g1_std(out + (size_t)l * 64, *reinterpret_cast<G1Affine *>(&a));
+    else store_g2_std(out + (size_t)l * 128, *reinterpret_cast<G2Affine *>(&a));
+  }
+}
+
 extern "C" {
 // field 0 = Fq, 1 = Fr; ops: see f29_op above; inputs / outputs standard form
 void zkt29_fp(int field, int op, const uint8_t *a, const uint8_t *b, uint8_t *out) {
@@ -105,6 +134,8 @@ void zkt29_barrett(int field, const uint32_t *in, uint32_t *out, uint32_t *canon
     auto c = canonical_small(b); memcpy(canon, c.v, 36);
   }
 }
+void zkt29_g1_levels(const uint8_t *pt, int c, int levels, uint8_t *out) { jac_levels29<Fq>(pt, c, levels, out); }
+void zkt29_g2_levels(const uint8_t *pt, int c, int levels, uint8_t *out) { jac_levels29<Fq2>(pt, c, levels, out); }
 int zkt29_g1_chain(const uint8_t *pts, const uint8_t *signs, size_t n, int twice, uint8_t *out) { return chain29<Fq>(pts, signs, n, twice, out); }
 int zkt29_g2_chain(const uint8_t *pts, const uint8_t *signs, size_t n, int twice, uint8_t *out) { return chain29<Fq2>(pts, signs, n, twice, out); }
 

@@ -212,19 +212,23 @@ int radix_convert(int device, bool g2, void *d_points, size_t count, bool to261)
   return 0;
 }
 
-// Level 0 of the table (n points, the key's wire form: coordinates x 2^256) is in place: fills levels 1..K-1, then takes
-// the whole table to the radix of the accumulation kernels (x 2^261, canonical; kernels_msm.hpp header).
+// Level 0 of the table (n points, the key's wire form: coordinates x 2^256) is in place: fills levels 1..K-1 and rewrites
+// level 0, all in the radix of the accumulation kernels (x 2^261, canonical; kernels_msm.hpp header).
 int msm_precompute(int device, bool g2, void *d_table, uint32_t n, const MsmPlan &pl) {
   if (n == 0) return 0;
   ZKR_HIP_CHECK(hipSetDevice(device));
-  if (pl.K >= 2) {
-    unsigned grid = (n + MSM_THREADS - 1) / MSM_THREADS;
-    if (g2) msm_precompute_kernel<Fq2, 1><<<grid, MSM_THREADS>>>((G2Affine *)d_table, n, pl.c, pl.K);
-    else msm_precompute_kernel<Fq, 2><<<grid, MSM_THREADS>>>((G1Affine *)d_table, n, pl.c, pl.K);
-    ZKR_HIP_CHECK(hipGetLastError());
-    ZKR_HIP_CHECK(hipDeviceSynchronize());
-  }
-  return radix_convert(device, g2, d_table, (size_t)n * pl.K, true);
+  if (pl.K < 2) return radix_convert(device, g2, d_table, (size_t)n, true);
+  const int levels = pl.K - 1 < PRE_LEVELS ? pl.K - 1 : PRE_LEVELS;
+  void *ztmp = nullptr;  // denominators of one chunk of levels (msm_precompute_kernel)
+  ZKR_HIP_CHECK(hipMalloc(&ztmp, (size_t)n * levels * (g2 ? sizeof(Fq2) : sizeof(Fq))));
+  unsigned grid = (n + MSM_THREADS - 1) / MSM_THREADS;
+  if (g2) msm_precompute_kernel<Fq2, 1><<<grid, MSM_THREADS>>>((G2Affine *)d_table, n, pl.c, pl.K, (Fq2 *)ztmp);
+  else msm_precompute_kernel<Fq, 2><<<grid, MSM_THREADS>>>((G1Affine *)d_table, n, pl.c, pl.K, (Fq *)ztmp);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  hipFree(ztmp);
+  if (e != hipSuccess) { set_error("window-table build failed: %s", hipGetErrorString(e)); return ZKR_ERR_HIP; }
+  return 0;
 }
 
 // Builds the arena.  tbl_src[t]: full source table (host or device memory, affine Montgomery, 64/128 B

@@ -196,6 +196,29 @@ def test_quotient_estimate_reduction_on_raw_limbs(L):
             assert _limbs_value(can) == v % P, (field, v)
 
 
+def test_window_table_levels_match_the_oracle(L):
+    """The key-load chain (curve29.hpp dbl_jac29 + field29.hpp inv29 with one inversion for all levels, as
+    msm_precompute_kernel runs it): 2^(c l) P for l = 1..levels equals the oracle's scalar multiplication, G1 and G2."""
+    M = 1 << 256
+    for k in (1, 5, 123456789):
+        P1 = bn.g1_mul(bn.G1_GEN, k)
+        wire = _le(P1[0] * M % Q_MOD) + _le(P1[1] * M % Q_MOD)
+        for c, levels in ((3, 5), (7, 12), (20, 2)):
+            out = ctypes.create_string_buffer(64 * levels)
+            L.zkt29_g1_levels(wire, c, levels, out)
+            for l in range(levels):
+                e = bn.g1_mul(P1, 1 << (c * (l + 1)))
+                assert out.raw[64 * l:64 * l + 64] == _le(e[0]) + _le(e[1]), (k, c, l)
+        P2 = bn.g2_mul(bn.G2_GEN, k)
+        wire2 = b"".join(_le(v * M % Q_MOD) for v in (P2[0][0], P2[0][1], P2[1][0], P2[1][1]))
+        for c, levels in ((4, 6), (20, 2)):
+            out = ctypes.create_string_buffer(128 * levels)
+            L.zkt29_g2_levels(wire2, c, levels, out)
+            for l in range(levels):
+                e = bn.g2_mul(P2, 1 << (c * (l + 1)))
+                assert out.raw[128 * l:128 * l + 128] == b"".join(_le(v) for v in (e[0][0], e[0][1], e[1][0], e[1][1])), (k, c, l)
+
+
 def test_radix_change_roundtrip(L):
     """x 2^256 (the key material's Montgomery radix, binarify.ts:78-90) -> x 2^261 (hot-path radix) -> back."""
     rnd = random.Random(31)
