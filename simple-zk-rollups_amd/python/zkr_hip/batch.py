@@ -48,7 +48,7 @@ def broadcast_key(key, rank, world, device, dist=None, mode=None):
       "full"  the whole arena, window tables included (4.47 GB at 2^20): adopted in place (zkr_key_adopt_arena), nothing
               is recomputed -- the right choice over xGMI (153 GB/s per link: ~30 ms);
       "base"  the compact arena (base points + QAP rows, 0.45 GB): the receiver rebuilds the window levels and twiddles
-              (zkr_key_adopt_base_arena, ~0.25 s at 2^20) -- for links slower than ~15 GB/s (PCIe peer copies, a
+              (zkr_key_adopt_base_arena, ~0.10 s at 2^20) -- for links slower than ~40 GB/s (PCIe peer copies, a
               host-staged backend) where ten times fewer bytes outweigh the rebuild."""
     import os
     from .binding import ProvingKey
