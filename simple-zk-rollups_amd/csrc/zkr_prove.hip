@@ -96,6 +96,7 @@ int ntt_tables29_build(const Fr *tw, uint32_t n_tw, const Fr *twl, uint32_t n_tw
   twiddle261_kernel<<<(n_tw + 256) / 256, 256, 0, s>>>(tw, n_tw, *tw29);
   twiddle261_kernel<<<(n_twl + 256) / 256, 256, 0, s>>>(twl, n_twl, *twl29);
   ZKR_HIP_CHECK(hipGetLastError());
+  ZKR_HIP_CHECK(hipStreamSynchronize(s));  // the proving streams are non-blocking: they do not order themselves after this one
   return 0;
 }
 
