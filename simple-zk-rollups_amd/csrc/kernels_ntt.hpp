@@ -10,8 +10,10 @@
 //   bytes per row in HBM).  DIF passes run top-down (natural in -> bit-reversed out), DIT passes
 //   bottom-up (bit-reversed in -> natural out), so no explicit permutation is ever done.
 //   Inside a pass the stages run in pairs on four elements held in registers (one barrier per two stages).
-//   LDS tile is limb-major (SoA): lane l touches bank (l mod 32) for every ds_read_b32 -> conflict free.
-//   Twiddles w_{2s}^x come from one table per key (w_{2m}^k, k<m, serves all spans up to m and the
+//   The butterflies run on 9 x 29-bit limbs, lazily reduced (field29.hpp; bounds: see NTT_H_* below); an element is 8
+//   words in HBM and 9 in LDS.  LDS tile is limb-major (SoA): lane l touches bank (l mod 32) for every ds_read_b32 ->
+//   conflict free.
+//   Twiddles w_{2s}^x come from one table per key (w_{2m}^k, k<m, serves all spans up to m; its x 2^256 form also gives the
 //   coset factors) plus a 32 KB table w_2048^k shared by every contiguous pass (L1/L2 resident).
 #pragma once
 #include <type_traits>
@@ -29,7 +31,7 @@ namespace zkr {
 // pipeline, 256 wins (2^21: 71.5 against 68.0; 2^22: 36.5 against 34.9; 2^24: 9.06 against 8.47 proofs/s).
 constexpr int NTT_THREADS_SMALL = 512, NTT_THREADS_LARGE = 256;
 constexpr int NTT_LARGE_LOG = 21;  // transforms of 2^21 and more take the 256-thread workgroups
-constexpr int NTT_TILE_LOG = 11;   // 2048 elements = 64 KB of LDS per workgroup (2 workgroups / CU)
+constexpr int NTT_TILE_LOG = 11;   // 2048 elements = 72 KB of LDS per workgroup (2 workgroups / CU)
 constexpr int NTT_STRIDED_LOG = 9; // stages per strided pass
 constexpr int NTT_W_LOG = 2;       // 4 columns = 128 B contiguous per row in a strided pass
 constexpr int TWL_LOG = 10;        // local table: w_2048^k, k < 1024
