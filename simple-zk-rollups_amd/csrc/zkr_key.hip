@@ -161,10 +161,14 @@ int key_alloc_workspace(zkr_key *k) {
   ZKR_HIP_CHECK(hipStreamCreateWithPriority(&k->prep_stream, hipStreamNonBlocking, prio_hi));
   // reduction streams: the chains of one proof add up to ~6 ms of serialised launches, so on a single in-order
   // stream they, not the accumulations, set the pace with two proofs in flight (94 vs 106 proofs/s with two)
-  k->n_red = 3;  // round 2 (29-bit-limb kernels): 125.6 / 128.4 proofs/s with two / three reduction streams (round 1 measured the opposite order)
+  for (int t = 0; t < N_TABLES; t++) k->plan[t] = msm_plan(t == T_H ? h.m : h.n, h.npts[t], (int)h.win_c[t]);
+  // three reduction streams for circuits that fill the chip alone (same-box rounds at 2^20: 136.3 against 132.1 proofs/s with
+  // two), two for keys whose proofs are fused into shared launches (fewer, fatter chains; with two the key's four streams
+  // have a hardware queue each: 2^16 1745 against 1680, 2^17 943 against 910, 2^18 514 against 492, 2^19 237 against 231,
+  // the tx circuit 988 against 957 proofs/s)
+  k->n_red = fused_capacity(h, k->plan) > 1 ? 2 : 3;
   if (const char *e = getenv("ZKR_RED_STREAMS")) { int v = atoi(e); if (v >= 1 && v <= N_TABLES) k->n_red = v; }
   for (int j = 0; j < k->n_red; j++) ZKR_HIP_CHECK(hipStreamCreateWithPriority(&k->red_stream[j], hipStreamNonBlocking, prio_hi));
-  for (int t = 0; t < N_TABLES; t++) k->plan[t] = msm_plan(t == T_H ? h.m : h.n, h.npts[t], (int)h.win_c[t]);
   {
     int rc = ntt_tables29_build((const Fr *)(k->arena + h.off_tw), 1u << h.tlog, (const Fr *)(k->arena + h.off_twl), 1u << TWL_LOG, nullptr, &k->tw29, &k->twl29);
     if (rc) return rc;
