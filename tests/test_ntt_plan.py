@@ -192,3 +192,34 @@ def test_calc_h_pipeline_constants():
             ginv_mont = MONT if i == 0 else (-tw[m - i] * MONT) % R
             h_br.append((montmul(V[pos], c1) - montmul(montmul(U[pos], ginv_mont), c2)) % R)
         assert [h_br[bitrev(i, L)] for i in range(m)] == g.calc_h_websnark(pk, w)
+
+
+def test_value_bounds_of_the_lazily_reduced_passes():
+    """Model of the bounds the 29-bit-limb butterflies keep (csrc/kernels_ntt.hpp, NTT_H_*), in half moduli.  DIT: a read at
+    stage j states NTT_H_DIT; the true bound after j stages is NTT_H_IN + 4 j (a product is below 2 r: bound 3 or 4, a
+    subtraction of it adds 2 r), so the statement holds as long as no pass has more than NTT_TILE_LOG stages, and the
+    operand of every product stays inside what field29.hpp's mul admits (Ha * Hb <= 676, twiddle bound 2).  DIF: every
+    value written back is at most NTT_H_DIF because the one double sum of a pair of stages goes through barrett() (bound 5)."""
+    H_IN, H_DIF, TILE_LOG, STRIDED_LOG = 6, 6, 11, 9
+    H_DIT = H_IN + 4 * TILE_LOG
+    for L in range(1, 28):
+        for (lo, hi, wlog) in ntt_plan(L, TILE_LOG, STRIDED_LOG):
+            nb = hi - lo
+            assert 1 <= nb <= TILE_LOG
+            h = H_IN
+            for j in range(nb):                    # DIT stages: t = v w (bound 3), u + t and u - t + 2 r
+                assert h <= H_DIT and h * 2 <= 676
+                h += 4
+            assert h <= H_DIT + 4 <= 128           # what barrett() takes at the end of the pass
+    # DIF pair of stages on four values of bound H: (s0, p0), (s1, p1) = dif(x00, x10), dif(x01, x11); then dif(s0, s1), dif(p0, p1)
+    def dif(hu, hv):
+        hsum, hdiff = hu + hv, hu + 2 * ((hv + 1) // 2)
+        assert hdiff * 2 <= 676 and (hv + 1) // 2 <= 24
+        return hsum, 3
+    s0, p0 = dif(H_DIF, H_DIF)
+    s1, p1 = dif(H_DIF, H_DIF)
+    ss, sp = dif(s0, s1)
+    ps, pp = dif(p0, p1)
+    assert ss <= 128 and max(5, sp, ps, pp) <= H_DIF   # ss goes through barrett() -> 5
+    s, p = dif(H_DIF, H_DIF)                           # a single stage
+    assert s <= 128 and max(5, p) <= H_DIF
