@@ -339,6 +339,36 @@ def tx_circuit_leg(local, steps, batch=2, depth=6):
             "proofs_verified": ok}
 
 
+def self_launch(n_gpus):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD `python -m torch.distributed.run`
+    (one process per GPU, rendezvous on 127.0.0.1 at a free port) with this command line, relay rank 0's single JSON
+    line on stdout and return the child's exit code.  Nothing in this parent touches HIP or torch.cuda -- a process
+    that has initialised the GPU must never exec or fork the ranks."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC (RCCL across processes)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    lines = []
+    for ln in child.stdout:  # stderr goes straight through; stdout is filtered down to the result line
+        if ln.startswith("{"):
+            lines.append(ln.rstrip("\n"))
+        else:
+            sys.stderr.write(ln)
+    rc = child.wait()
+    for ln in lines:
+        print(ln, flush=True)
+    if rc == 0 and len(lines) != 1:
+        sys.stderr.write("bench.py: expected one JSON line from rank 0, got %d\n" % len(lines))
+        return 1
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -356,14 +386,16 @@ def main():
     ap.add_argument("--no-bcast-modes", action="store_true", help="skip timing the two key replication modes on this GPU")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))  # plain `python bench.py --gpus N`: start the ranks as a child torchrun
+
     import torch
     import zkr_hip
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
+        raise SystemExit("bench.py --gpus %d was started with WORLD_SIZE=%d: launch one rank per GPU (or run it plainly, it starts them itself)" % (args.gpus, world))
     # rehearsal of the N > 1 path on a one-GPU box: ZKR_BENCH_ONE_GPU=1 puts every rank on cuda:0 and
     # ZKR_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one device); never used for reported numbers
     one_gpu = os.environ.get("ZKR_BENCH_ONE_GPU") == "1"
@@ -428,10 +460,14 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     device_state = sampler.stop() if sampler else None
+    per_rank = [{"rank": rank, "proofs": len(proofs), "seconds": elapsed}]
     if dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        parts = [None] * world
+        dist.all_gather_object(parts, per_rank[0])  # outside the timed region: what every rank did, for the SCALE record
+        per_rank = parts
     prof = key.prof()
     key.prof_enable(False)
 
@@ -485,7 +521,8 @@ def main():
         pcie_rate_batch = n_b / (time.perf_counter() - t1)
 
     if rank == 0:
-        total_proofs = args.steps * world
+        total_proofs = sum(p["proofs"] for p in per_rank)
+        assert total_proofs == args.steps * world
         value = total_proofs / elapsed
         # ---- roofline of the dominant kernel (DESIGN.md "Measurement"): algorithmic bytes = every base point
         # and every scalar of the MSM read once (64 B G1 / 128 B G2 point + 32 B scalar)
@@ -569,6 +606,7 @@ def main():
                        "proofs_in_flight": 1 if args.no_pipeline else 2},
             "roofline": roofline,
             "stage_ms_per_proof": per_proof_ms,
+            "per_rank": per_rank,
             "key": {"arena_bytes": arena_bytes, "setup_s": setup_s, "bcast_s": bcast_s if world > 1 else None,
                     "bcast_GBps": (arena_bytes / bcast_s / 1e9) if world > 1 and bcast_s > 0 else None},  # one RCCL broadcast over xGMI (153 GB/s per link)
             "pcie_inclusive_proofs_per_s": pcie_rate,

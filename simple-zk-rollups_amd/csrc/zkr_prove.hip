@@ -558,8 +558,10 @@ static int prove_collect(zkr_key *k, ProofSlot &sl, uint8_t *proofs_out) {
 }
 
 // ------------------------------------------------------------------ host witnesses: staging ring (zkr_internal.hpp WitnessStage)
-// Blocks until one of the STAGE_BUFS buffers is free; allocates its pinned and device memory on first use.
-static int stage_acquire(zkr_key *k, int *idx) {
+// Takes one of the STAGE_BUFS buffers; allocates its pinned and device memory on first use.  wait: block until one is free
+// -- only for callers that hold no proof slot (a caller that waits for a stage while its own groups occupy the slots
+// deadlocks with a caller that holds the last stage and waits for a slot); otherwise *idx = -1 when none is free.
+static int stage_acquire(zkr_key *k, int *idx, bool wait = true) {
   std::unique_lock<std::mutex> lk(k->stage_mu);
   for (;;) {
     for (int i = 0; i < STAGE_BUFS; i++) {
@@ -576,6 +578,7 @@ static int stage_acquire(zkr_key *k, int *idx) {
       *idx = i;
       return 0;
     }
+    if (!wait) { *idx = -1; return 0; }
     k->stage_freed.wait(lk);
   }
 }
@@ -616,8 +619,9 @@ static int next_group(size_t remaining, size_t groups_left) { return (int)((rema
 // Hand out a free proof slot and run `enqueue` on it under the key's lock (two host threads proving on one key --
 // e.g. two libuv workers behind Promise.all -- then pipeline like submit/collect does).  wait: block until a slot
 // frees instead of failing.
+constexpr int NO_FREE_SLOT = 1;  // internal: with_free_slot(wait = false, quiet) found every slot in flight
 template <class Fn>
-static int with_free_slot(zkr_key *key, bool wait, int *ticket, Fn enqueue) {
+static int with_free_slot(zkr_key *key, bool wait, int *ticket, Fn enqueue, bool quiet = false) {
   std::unique_lock<std::mutex> lk(key->mu);
   for (;;) {
     for (int i = 0; i < PROOF_SLOTS; i++) {
@@ -629,8 +633,23 @@ static int with_free_slot(zkr_key *key, bool wait, int *ticket, Fn enqueue) {
         return rc;
       }
     }
-    if (!wait) { set_error("all %d proof slots are in flight: collect one first", PROOF_SLOTS); return ZKR_ERR_ARG; }
+    if (!wait) {
+      if (quiet) return NO_FREE_SLOT;
+      set_error("all %d proof slots are in flight: collect one first", PROOF_SLOTS);
+      return ZKR_ERR_ARG;
+    }
     key->slot_freed.wait(lk);
+  }
+}
+// The batch calls' way to a slot: a caller with groups in flight never WAITS for a slot (or a staging buffer) -- it collects
+// its own oldest group, which frees one of each -- and blocks only while it holds nothing another caller could be waiting
+// for.  (Hold-and-wait on both resources deadlocked a batch call against any other host-buffer caller of the key.)
+template <class Fn, class Collect>
+static int take_slot(zkr_key *key, int &in_flight, int *ticket, Fn enqueue, Collect collect_oldest) {
+  for (;;) {
+    int rc = with_free_slot(key, in_flight == 0, ticket, enqueue, true);
+    if (rc != NO_FREE_SLOT) return rc;
+    if ((rc = collect_oldest())) return rc;
   }
 }
 
@@ -673,16 +692,20 @@ int zkr_prove_batch(zkr_key *key, const void *const *witnesses_std, size_t witne
   for (size_t i = 0; i < count && !rc;) {
     const int nb = next_group(count - i, groups_left--);
     int st = -1;
-    if ((rc = stage_acquire(key, &st))) break;
+    while (!rc && st < 0) {  // a staging buffer: without waiting while groups of this call hold slots and stages
+      if ((rc = stage_acquire(key, &st, in_flight == 0)) || st >= 0) break;
+      rc = collect_oldest();
+    }
+    if (rc) { if (st >= 0) stage_release(key, st); break; }
     for (int j = 0; j < nb && !rc; j++) rc = stage_upload(key, st, j, witnesses_std[i + j], witness_len, j == nb - 1);
     if (!rc && in_flight == PROOF_SLOTS) rc = collect_oldest();
     int t = -1;
-    if (!rc) rc = with_free_slot(key, true, &t, [&](ProofSlot &sl) -> int {
+    if (!rc) rc = take_slot(key, in_flight, &t, [&](ProofSlot &sl) -> int {
       const Fr *src[MAX_FUSE];
       hipEvent_t ready[MAX_FUSE];
       for (int j = 0; j < nb; j++) { src[j] = key->stage[st].d_w + (size_t)j * key->h.n; ready[j] = key->stage[st].ev_up; }
       return prove_submit_group(key, sl, src, nb, r32s ? r32s + 32 * i : nullptr, s32s ? s32s + 32 * i : nullptr, key->prep_stream, ready);
-    });
+    }, collect_oldest);
     if (rc) { hipStreamSynchronize(key->prep_stream); stage_release(key, st); break; }
     tickets[in_flight] = t; first[in_flight] = i; stages[in_flight] = st; in_flight++;
     i += (size_t)nb;
@@ -714,9 +737,9 @@ int zkr_prove_batch_device(zkr_key *key, const void *const *d_witnesses_std, siz
     if (in_flight == PROOF_SLOTS) rc = collect_oldest();
     if (rc) break;
     int t = -1;
-    rc = with_free_slot(key, true, &t, [&](ProofSlot &sl) -> int {
+    rc = take_slot(key, in_flight, &t, [&](ProofSlot &sl) -> int {
       return prove_submit_group(key, sl, (const Fr *const *)(d_witnesses_std + i), nb, r32s ? r32s + 32 * i : nullptr, s32s ? s32s + 32 * i : nullptr, (hipStream_t)stream);
-    });
+    }, collect_oldest);
     if (!rc) { tickets[in_flight] = t; first[in_flight] = i; in_flight++; i += (size_t)nb; }
   }
   while (in_flight > 0) {

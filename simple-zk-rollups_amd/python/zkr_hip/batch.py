@@ -13,10 +13,11 @@ def shard_indices(count, rank, world):
 ARENA_CHUNK = 1 << 30
 
 
-def broadcast_arena(arena, rank, dist, device, chunk=ARENA_CHUNK):
+def broadcast_arena(arena, rank, dist, device, chunk=None):
     """Broadcast a uint8 tensor (the key arena) from rank 0; other ranks pass None and get a new tensor
     on `device`.  The length, then the bytes in 1 GiB pieces (arenas reach 78 GB at 2^24: every collective stays far
     below any 32-bit element count)."""
+    chunk = chunk or ARENA_CHUNK
     n = torch.zeros(1, dtype=torch.int64, device=device)
     if rank == 0:
         n[0] = arena.numel()
@@ -34,7 +35,11 @@ class _CudaArray:
 
 
 def _tensor_from_ptr(ptr, nbytes, device):
-    """Zero-copy uint8 view of device memory owned by the C library."""
+    """Zero-copy uint8 view of memory owned by the key: device memory of the C library (device = HIP ordinal), or host
+    memory (device = None: the stand-in keys of the CPU tests, tests/test_dist.py)."""
+    if device is None:
+        import ctypes
+        return torch.frombuffer((ctypes.c_ubyte * nbytes).from_address(ptr), dtype=torch.uint8)
     with torch.cuda.device(device):
         return torch.as_tensor(_CudaArray(ptr, nbytes), device=torch.device("cuda", device))
 
@@ -42,16 +47,19 @@ def _tensor_from_ptr(ptr, nbytes, device):
 BCAST_MODES = ("full", "base")
 
 
-def broadcast_key(key, rank, world, device, dist=None, mode=None):
+def broadcast_key(key, rank, world, device, dist=None, mode=None, key_cls=None):
     """rank 0 holds `key`; every other rank receives it over ONE broadcast and returns its own ProvingKey (rank 0: the
     same object).  mode (default: env ZKR_BCAST_MODE or "full"):
       "full"  the whole arena, window tables included (4.47 GB at 2^20): adopted in place (zkr_key_adopt_arena), nothing
               is recomputed -- the right choice over xGMI (153 GB/s per link: ~30 ms);
       "base"  the compact arena (base points + QAP rows, 0.45 GB): the receiver rebuilds the window levels and twiddles
               (zkr_key_adopt_base_arena, ~0.10 s at 2^20) -- for links slower than ~40 GB/s (PCIe peer copies, a
-              host-staged backend) where ten times fewer bytes outweigh the rebuild."""
+              host-staged backend) where ten times fewer bytes outweigh the rebuild.
+    key_cls: the class whose adopt_arena / adopt_base_arena build the receiver's key (default: ProvingKey); device None:
+    the arenas are host memory (CPU tests drive this very function with a stand-in key class, no device needed)."""
     import os
-    from .binding import ProvingKey
+    if key_cls is None:
+        from .binding import ProvingKey as key_cls
     if world == 1:
         return key
     mode = mode or os.environ.get("ZKR_BCAST_MODE", "full")
@@ -59,16 +67,17 @@ def broadcast_key(key, rank, world, device, dist=None, mode=None):
         raise ValueError("unknown key broadcast mode %r (use one of %r)" % (mode, BCAST_MODES))
     if dist is None:
         import torch.distributed as dist
-    dev = torch.device("cuda", device)
+    dev = torch.device("cpu") if device is None else torch.device("cuda", device)
     if rank == 0:
         ptr, length = key.arena() if mode == "full" else key.base_arena()
         broadcast_arena(_tensor_from_ptr(ptr, length, device), 0, dist, dev)
         return key
     buf = broadcast_arena(None, rank, dist, dev)
-    torch.cuda.synchronize(dev)
+    if device is not None:
+        torch.cuda.synchronize(dev)
     if mode == "full":
-        return ProvingKey.adopt_arena(buf.data_ptr(), buf.numel(), device, keepalive=buf)
-    return ProvingKey.adopt_base_arena(buf.data_ptr(), buf.numel(), device)
+        return key_cls.adopt_arena(buf.data_ptr(), buf.numel(), device, keepalive=buf)
+    return key_cls.adopt_base_arena(buf.data_ptr(), buf.numel(), device)
 
 
 def prove_batch(key, witnesses, blinding, rank=0, world=1):

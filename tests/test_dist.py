@@ -13,14 +13,48 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-class _FakeKey:
-    """Stands in for ProvingKey on CPU: 'proves' by hashing (arena, witness, r, s)."""
+class _StubKey:
+    """Stands in for ProvingKey where no device exists: the same surface the multi-GPU driver uses (arena / base_arena /
+    adopt_arena / adopt_base_arena / prove), over HOST memory, so that the real broadcast_key / prove_batch / gather_proofs
+    code runs on CPU.  The "full" arena is the compact one followed by bytes derived from it (as the window levels are
+    derived from the base points); 'proves' by hashing (arena, witness, r, s)."""
+    device = None
 
-    def __init__(self, arena):
-        self.tag = hashlib.sha256(bytes(arena.numpy().tobytes())).digest()
+    def __init__(self, base):
+        import ctypes
+        derived = hashlib.sha256(base).digest() * 64
+        self._full = ctypes.create_string_buffer(base + derived, len(base) + len(derived))
+        self._nbase = len(base)
+        self.tag = hashlib.sha256(self._full.raw).digest()
+
+    def arena(self):
+        import ctypes
+        return ctypes.addressof(self._full), len(self._full.raw)
+
+    def base_arena(self):
+        import ctypes
+        return ctypes.addressof(self._full), self._nbase
+
+    @classmethod
+    def adopt_arena(cls, ptr, n, device, keepalive=None):
+        import ctypes
+        raw = ctypes.string_at(ptr, n)
+        k = cls(raw[:n - 32 * 64])
+        assert k._full.raw == raw, "the adopted arena is not a well-formed stub arena"
+        return k
+
+    @classmethod
+    def adopt_base_arena(cls, ptr, n, device):
+        import ctypes
+        return cls(ctypes.string_at(ptr, n))    # rebuilds the derived part
 
     def prove(self, witness, r, s):
         return hashlib.sha256(self.tag + witness + int(r).to_bytes(32, "little") + int(s).to_bytes(32, "little")).digest() * 8
+
+
+def _stub_base():
+    g = torch.Generator().manual_seed(1234)
+    return bytes(torch.randint(0, 256, (100_003,), dtype=torch.uint8, generator=g).numpy().tobytes())
 
 
 def _free_port():
@@ -31,17 +65,17 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, mode, q):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(root, "simple-zk-rollups_amd", "python"))
     import zkr_hip
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    g = torch.Generator().manual_seed(1234)
-    arena = torch.randint(0, 256, (100_003,), dtype=torch.uint8, generator=g) if rank == 0 else None
-    arena = zkr_hip.broadcast_arena(arena, rank, dist, torch.device("cpu"), chunk=30_000)   # four pieces, the last one short
-    key = _FakeKey(arena)
+    import zkr_hip.batch as zb
+    zb.ARENA_CHUNK = 30_000                                    # the arena goes in pieces, the last one short
+    key = _StubKey(_stub_base()) if rank == 0 else None
+    key = zkr_hip.broadcast_key(key, rank, world, None, dist, mode=mode, key_cls=_StubKey)   # the real replication code
     count = 9
     witnesses = [bytes([i]) * 64 for i in range(count)]
     blinding = [(100 + i, 200 + i) for i in range(count)]
@@ -52,15 +86,16 @@ def _worker(rank, world, port, q):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.barrier()
     dist.destroy_process_group()
-    q.put((rank, hashlib.sha256(b"".join(merged[i] for i in range(count))).hexdigest(), float(t.item()), arena.numel()))
+    q.put((rank, hashlib.sha256(b"".join(merged[i] for i in range(count))).hexdigest(), float(t.item()), key.arena()[1]))
 
 
-def test_two_rank_batch_over_gloo():
+@pytest.mark.parametrize("mode", ["full", "base"])
+def test_two_rank_batch_over_gloo(mode):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, mode, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in range(world)]
@@ -70,12 +105,11 @@ def test_two_rank_batch_over_gloo():
     res.sort()
     assert res[0][1] == res[1][1]            # both ranks hold the same full set of proofs
     assert res[0][2] == res[1][2] == 2.0     # max over ranks
-    assert res[0][3] == res[1][3] == 100_003
+    assert res[0][3] == res[1][3] == 100_003 + 32 * 64  # both ranks hold the whole arena, whichever form travelled
 
     # single-process reference: same proofs without any sharding
     import zkr_hip
-    g = torch.Generator().manual_seed(1234)
-    key = _FakeKey(torch.randint(0, 256, (100_003,), dtype=torch.uint8, generator=g))
+    key = _StubKey(_stub_base())
     allp = zkr_hip.prove_batch(key, [bytes([i]) * 64 for i in range(9)], [(100 + i, 200 + i) for i in range(9)])
     assert hashlib.sha256(b"".join(allp[i] for i in range(9))).hexdigest() == res[0][1]
 
@@ -87,6 +121,24 @@ def test_shard_indices_partition():
             seen = sorted(i for r in range(world) for i in zkr_hip.shard_indices(count, r, world))
             assert seen == list(range(count))
     assert zkr_hip.shard_indices(64, 3, 8) == [3, 11, 19, 27, 35, 43, 51, 59]  # BASELINE config 4: 8 proofs per GPU
+
+
+def test_plain_bench_invocation_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher in front: the parent starts the ranks as a child
+    torchrun and relays their exit code.  Without a device the ranks stop at the first device call -- which shows that two
+    ranks were started and that a failure is not swallowed; with a device the GPU suite runs the same call to the end
+    (tests/test_gpu_fullsize.py::test_bench_two_rank_path_rehearsal_on_one_gpu)."""
+    import subprocess
+    import sys
+    if torch.cuda.is_available():
+        pytest.skip("covered end to end by the GPU suite")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--log-m", "10"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode != 0                                   # the ranks' failure is the parent's exit code
+    assert "No HIP GPUs" in r.stderr or "no HIP device" in r.stderr, r.stderr[-1500:]
+    assert "local_rank: 1" in r.stderr or "rank      : 1" in r.stderr or "nproc" in r.stderr   # torchrun ran two ranks
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]                        # and no result line is invented
 
 
 # ---------------------------------------------------------------- GPU: the real key through the real collectives

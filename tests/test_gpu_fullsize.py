@@ -138,6 +138,60 @@ def test_concurrent_host_buffer_callers_on_one_key():
         assert proof == g.proof_bytes(expect), (j, i)
 
 
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("mix", ["batch_vs_single", "batch_vs_batch"])
+def test_batch_calls_do_not_deadlock_against_other_host_buffer_callers(mix):
+    """zkr_prove_batch used to wait for a third staging buffer while its own groups held both proof slots
+    and two staging buffers; a concurrent zkr_prove (or a second batch) holding the last buffer and waiting for a slot then
+    hung both for good.  A batch call now collects its own oldest group instead of waiting.  Batches of >= 4 groups against
+    single callers, and batch against batch, on ONE key from several threads; a hang fails by timeout, and every proof must
+    still be the closed form's bytes."""
+    import threading
+    import zkr_hip
+    log_m, p = 14, 73
+    key, wb, aux = zkr_hip.ProvingKey.synth(log_m, p, 0x5A4B0001, 0x5A4B00FF)
+    fuse = max(1, key.fuse())
+    wbs = [wb] + [zkr_hip.synth_witness(log_m, p, 0x5A4B0001, 6100 + i) for i in range(1, 3)]
+    n_batch = 6 * max(fuse, 1) + 1          # >= 4 groups whatever the key's fused capacity, ragged last group
+    out, errs = {}, []
+
+    def batch_worker(j, rounds):
+        try:
+            for q in range(rounds):
+                ws = [wbs[(j + q + i) % len(wbs)] for i in range(n_batch)]
+                rs = [3000 + 1000 * j + 100 * q + i for i in range(n_batch)]
+                ss = [7000 + 1000 * j + 100 * q + i for i in range(n_batch)]
+                for i, pr in enumerate(key.prove_batch(ws, rs, ss)):
+                    out[("b", j, q, i)] = (pr, (j + q + i) % len(wbs), rs[i], ss[i])
+        except Exception as e:
+            errs.append(e)
+
+    def single_worker(j, count):
+        try:
+            for i in range(count):
+                r, sc = 500 + 50 * j + i, 900 + 50 * j + i
+                out[("s", j, i)] = (key.prove(wbs[(j + i) % len(wbs)], r, sc), (j + i) % len(wbs), r, sc)
+        except Exception as e:
+            errs.append(e)
+
+    if mix == "batch_vs_single":
+        ths = [threading.Thread(target=batch_worker, args=(0, 3))] + [threading.Thread(target=single_worker, args=(j, 12)) for j in range(1, 4)]
+    else:
+        ths = [threading.Thread(target=batch_worker, args=(j, 3)) for j in range(3)] + [threading.Thread(target=single_worker, args=(3, 8))]
+    for t in ths:
+        t.daemon = True
+        t.start()
+    for t in ths:
+        t.join(300)
+        assert not t.is_alive(), "a caller is stuck: hold-and-wait between proof slots and staging buffers"
+    assert not errs, errs
+    sample = sorted(out)[::7]
+    for k in sample:
+        proof, wi, r, sc = out[k]
+        expect, _, _ = g.proof_from_aux(aux, wbs[wi], p, r, sc)
+        assert proof == g.proof_bytes(expect), k
+
+
 def test_websnark_buffer_path_at_2_16():
     """The reference's own data flow at the size of the real tx circuit's neighbourhood (2^17): a
     60 MB provingKeyBin in the binarify.ts layout through zkr_key_load_websnark, proof == the C oracle on the same
@@ -177,22 +231,29 @@ def test_fullsize_arena_replica_above_4_gib():
     assert key2.prove(wb, 5, 7) == key.prove(wb, 5, 7)
 
 
-def test_bench_two_rank_path_rehearsal_on_one_gpu():
+@pytest.mark.parametrize("launcher", ["plain", "torchrun"])
+def test_bench_two_rank_path_rehearsal_on_one_gpu(launcher):
     """The N > 1 flow of bench.py end to end on this one-GPU box: two ranks on cuda:0, gloo instead of RCCL (which
     refuses two ranks per device): key built on rank 0, arena broadcast, adopted by rank 1, both shards proved,
     max-over-ranks timing, one JSON line from rank 0 with the whole-job rate."""
     import json
     import os
-    import socket
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     env = dict(os.environ, ZKR_BENCH_BACKEND="gloo", ZKR_BENCH_ONE_GPU="1")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "1", "--log-m", "14"],
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    # "plain": `python bench.py --gpus 2` starts its own ranks as a child torchrun (VERDICT r2 item 1);
+    # "torchrun": the driver's launch line for N > 1
+    cmd = [sys.executable]
+    if launcher == "torchrun":
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port)]
+    r = subprocess.run(cmd + [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "1", "--log-m", "14"],
                        capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -200,4 +261,5 @@ def test_bench_two_rank_path_rehearsal_on_one_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "weak" and d["value"] > 0
     assert abs(d["value"] - 2 * 6 / (d["ms_per_step"] * 6e-3)) < 1e-6 * d["value"]      # whole-job rate: all ranks' proofs / max time
-    assert d["key"]["bcast_s"] is not None and d["proofs_verified"] >= 1
+    assert d["key"]["bcast_s"] is not None and d["key"]["bcast_GBps"] > 0 and d["proofs_verified"] >= 1
+    assert [(p["rank"], p["proofs"]) for p in d["per_rank"]] == [(0, 6), (1, 6)]
