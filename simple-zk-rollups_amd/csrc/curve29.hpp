@@ -91,7 +91,7 @@ ZKR_HD XYZZ29<C> dbl_affine29(const QX &qx, const QY &qy) {
   auto xx = sqr(qx);
   auto m = add(dbl(xx), xx);
   auto x3 = sub(sqr(m), dbl(s));
-  auto y3 = mul_sub(m, sub(s, x3), w, qy);
+  auto y3 = mul_sub(m, sub_factor(s, x3), w, qy);
   return make_xyzz<C>(x3, y3, v, w);
 }
 
@@ -105,30 +105,40 @@ ZKR_HD XYZZ29<C> dbl_xyzz29(const XYZZ29<C> &p) {
   auto xx = sqr(p.x);
   auto m = add(dbl(xx), xx);
   auto x3 = sub(sqr(m), dbl(s));
-  auto y3 = mul_sub(m, sub(s, x3), w, p.y);
+  auto y3 = mul_sub(m, sub_factor(s, x3), w, p.y);
   return make_xyzz<C>(x3, y3, mul(v, p.zz), mul(w, p.zzz));
 }
 
-// acc + q (q affine, not infinity: callers filter); neg_q adds -q
+// acc + q (q affine, not infinity: callers filter); neg_q adds -q.  The sign goes into the product Y2 ZZZ1 as a factor
+// without its carry sweep (field29.hpp U29), as do Q - X3 and -Y1 in the Y coordinate: three sweeps and a select less per
+// addition; the negated y itself is only formed on the rare paths that store it.
 template <class C>
 ZKR_HD XYZZ29<C> add_mixed29(const XYZZ29<C> &acc, const Affine29<C> &q, bool neg_q) {
-  auto qy = q.y;
-  if (neg_q) qy = neg(q.y).template to<2>();  // p - y (<= p)
-  if (acc.is_inf()) return make_xyzz<C>(q.x, qy, C::one(), C::one());
+  if (acc.is_inf()) {
+    auto qy = q.y;
+    if (neg_q) qy = neg(q.y).template to<2>();  // p - y (<= p)
+    return make_xyzz<C>(q.x, qy, C::one(), C::one());
+  }
   auto u2 = mul(q.x, acc.zz);
-  auto s2 = mul(qy, acc.zzz);
+  auto s2 = mul_cneg(q.y, neg_q, acc.zzz);
   auto p = sub(u2, acc.x);
   auto r = sub(s2, acc.y);
   auto pp = sqr(p);
-  if (is_zero_mod_p(pp)) {  // same x: the same point (double it) or its negative (infinity)
-    if (is_zero_mod_p(sqr(r))) return dbl_affine29<C>(q.x, qy);
+  if (maybe_zero_mod_p(pp) && is_zero_mod_p(pp)) {  // same x: the same point (double it) or its negative (infinity)
+    if (is_zero_mod_p(sqr(r))) {
+      auto qy = q.y;
+      if (neg_q) qy = neg(q.y).template to<2>();
+      return dbl_affine29<C>(q.x, qy);
+    }
     return XYZZ29<C>::inf();
   }
   auto ppp = mul(p, pp);
   auto qq = mul(acc.x, pp);
   auto x3 = sub_sub_dbl(sqr(r), ppp, qq);  // R^2 - P^3 - 2 Q, one carry sweep
-  auto y3 = mul_sub(r, sub(qq, x3), acc.y, ppp);
-  return make_xyzz<C>(x3, y3, mul(acc.zz, pp), mul(acc.zzz, ppp));
+  auto zz3 = mul(acc.zz, pp);
+  auto zzz3 = mul(acc.zzz, ppp);
+  auto y3 = mul_sub(r, sub_factor(qq, x3), acc.y, ppp);
+  return make_xyzz<C>(x3, y3, zz3, zzz3);
 }
 
 // a + b, both XYZZ
@@ -143,14 +153,14 @@ ZKR_HD XYZZ29<C> add_full29(const XYZZ29<C> &a, const XYZZ29<C> &b) {
   auto p = sub(u2, u1);
   auto r = sub(s2, s1);
   auto pp = sqr(p);
-  if (is_zero_mod_p(pp)) {
+  if (maybe_zero_mod_p(pp) && is_zero_mod_p(pp)) {
     if (is_zero_mod_p(sqr(r))) return dbl_xyzz29(a);
     return XYZZ29<C>::inf();
   }
   auto ppp = mul(p, pp);
   auto qq = mul(u1, pp);
   auto x3 = sub_sub_dbl(sqr(r), ppp, qq);
-  auto y3 = mul_sub(r, sub(qq, x3), s1, ppp);
+  auto y3 = mul_sub(r, sub_factor(qq, x3), s1, ppp);
   return make_xyzz<C>(x3, y3, mul(mul(a.zz, b.zz), pp), mul(mul(a.zzz, b.zzz), ppp));
 }
 

@@ -55,6 +55,29 @@ struct L29 {
   }
 };
 
+// U29<PM, H>: a value below H p / 2 whose limbs are NOT normalised -- each of the low eight is non-negative and below
+// W * 2^29 (W = 2: K p - b; W = 3: a + K p - b, limb by limb against a multiple of p whose low limbs were made >= 2^29 - 1 by
+// borrowing from the limb above) -- i.e. a subtraction WITHOUT its carry sweep (4 of its 5 instructions per limb).  Legal only
+// as one factor of a product whose other factor is normalised: the products of a column then stay below 2^64 as long as
+// 9 * (1 + sum over the form's products of Wa Wb) <= 64 (f29_column_fits; 1 = the reduction's own m_i P_j terms), which every
+// product form checks at compile time.  The square (doubled limbs) and the additions take normalised operands only.
+template <class PM, int H, int W>
+struct U29 {
+  static_assert(H >= 1 && H <= 128 && (W == 2 || W == 3), "loose operand out of range");
+  static constexpr int bound = H;
+  uint32_t v[9];
+};
+// limb weights in units of 2^29 (normalised: 1) and the column condition of a product form
+template <class T> struct f29_w;
+template <class PM, int H> struct f29_w<L29<PM, H>> { static constexpr int w = 1; using pm = PM; };
+template <class PM, int H, int W> struct f29_w<U29<PM, H, W>> { static constexpr int w = W; using pm = PM; };
+constexpr bool f29_column_fits(int sum_of_weight_products) { return 9 * (1 + sum_of_weight_products) <= 64; }
+// limb i of K p with the low limbs lifted to [2^29 - 1, 2^30): the minuend of the sweep-less subtractions
+template <class PM, int K>
+constexpr uint32_t f29_lifted(int i) {
+  return PM::KP[K][i] + (i < 8 ? (1u << 29) : 0u) - (i > 0 ? 1u : 0u);
+}
+
 template <class PM>
 ZKR_HD L29<PM, 2> one29() {  // Montgomery 1
   L29<PM, 2> r;
@@ -204,6 +227,19 @@ ZKR_HD L29<PM, mul_out_h(HA * HB)> mul(const L29<PM, HA> &a, const L29<PM, HB> &
 #endif
   return r;
 }
+// one factor without its carry sweep (U29)
+template <class PM, int HA, int HB, int WB>
+ZKR_HD L29<PM, mul_out_h(HA * HB)> mul(const L29<PM, HA> &a, const U29<PM, HB, WB> &b) {
+  static_assert(HA * HB <= 676, "product of the operand bounds exceeds R / p");
+  static_assert(f29_column_fits(WB), "column sum of the product exceeds 64 bits");
+  L29<PM, mul_out_h(HA * HB)> r;
+#if ZKR_F29_DEVICE_ASM
+  mont29_asm_mul<PM>(r.v, a.v, b.v);
+#else
+  mont29<PM>(r.v, F29Mul{a.v, b.v});
+#endif
+  return r;
+}
 
 // a^2: the off-diagonal products are taken once against the doubled limbs (2 a_j < 2^30 still multiplies without
 // overflow): 45 multiply-adds instead of 81 in front of the same reduction
@@ -222,11 +258,14 @@ ZKR_HD L29<PM, mul_out_h(HA * HA)> sqr(const L29<PM, HA> &a) {
   return r;
 }
 
-// a b + c d with one reduction
-template <class PM, int HA, int HB, int HC, int HD>
-ZKR_HD L29<PM, mul_out_h(HA * HB + HC * HD)> mul_sum2(const L29<PM, HA> &a, const L29<PM, HB> &b, const L29<PM, HC> &c, const L29<PM, HD> &d) {
-  static_assert(HA * HB + HC * HD <= 676, "sum of the products of the operand bounds exceeds R / p");
-  L29<PM, mul_out_h(HA * HB + HC * HD)> r;
+// a b + c d with one reduction.  A, B, C, D: L29 or -- at most one factor of each product -- U29
+template <class A, class B, class C, class D>
+ZKR_HD L29<typename f29_w<A>::pm, mul_out_h(A::bound * B::bound + C::bound * D::bound)> mul_sum2(const A &a, const B &b, const C &c, const D &d) {
+  using PM = typename f29_w<A>::pm;
+  static_assert(A::bound * B::bound + C::bound * D::bound <= 676, "sum of the products of the operand bounds exceeds R / p");
+  static_assert((f29_w<A>::w == 1 || f29_w<B>::w == 1) && (f29_w<C>::w == 1 || f29_w<D>::w == 1), "one factor of every product has to be normalised");
+  static_assert(f29_column_fits(f29_w<A>::w * f29_w<B>::w + f29_w<C>::w * f29_w<D>::w), "column sum of the products exceeds 64 bits");
+  L29<PM, mul_out_h(A::bound * B::bound + C::bound * D::bound)> r;
 #if ZKR_F29_DEVICE_ASM
   mont29_asm_sum2<PM>(r.v, a.v, b.v, c.v, d.v);
 #else
@@ -234,12 +273,17 @@ ZKR_HD L29<PM, mul_out_h(HA * HB + HC * HD)> mul_sum2(const L29<PM, HA> &a, cons
 #endif
   return r;
 }
-// a b + c d + e f + g h with one reduction (36 products of 58 bits and the 9 of the reduction stay below 2^63.5)
-template <class PM, int HA, int HB, int HC, int HD, int HE, int HF, int HG, int HI>
-ZKR_HD L29<PM, mul_out_h(HA * HB + HC * HD + HE * HF + HG * HI)> mul_sum4(const L29<PM, HA> &a, const L29<PM, HB> &b, const L29<PM, HC> &c, const L29<PM, HD> &d,
-                                                                         const L29<PM, HE> &e, const L29<PM, HF> &f, const L29<PM, HG> &g, const L29<PM, HI> &h) {
-  static_assert(HA * HB + HC * HD + HE * HF + HG * HI <= 676, "sum of the products of the operand bounds exceeds R / p");
-  L29<PM, mul_out_h(HA * HB + HC * HD + HE * HF + HG * HI)> r;
+// a b + c d + e f + g h with one reduction (with normalised factors: 36 products of 58 bits and the 9 of the reduction)
+template <class A, class B, class C, class D, class E, class F, class G, class I>
+ZKR_HD L29<typename f29_w<A>::pm, mul_out_h(A::bound * B::bound + C::bound * D::bound + E::bound * F::bound + G::bound * I::bound)>
+mul_sum4(const A &a, const B &b, const C &c, const D &d, const E &e, const F &f, const G &g, const I &h) {
+  using PM = typename f29_w<A>::pm;
+  constexpr int Q = A::bound * B::bound + C::bound * D::bound + E::bound * F::bound + G::bound * I::bound;
+  static_assert(Q <= 676, "sum of the products of the operand bounds exceeds R / p");
+  static_assert((f29_w<A>::w == 1 || f29_w<B>::w == 1) && (f29_w<C>::w == 1 || f29_w<D>::w == 1) && (f29_w<E>::w == 1 || f29_w<F>::w == 1) && (f29_w<G>::w == 1 || f29_w<I>::w == 1),
+                "one factor of every product has to be normalised");
+  static_assert(f29_column_fits(f29_w<A>::w * f29_w<B>::w + f29_w<C>::w * f29_w<D>::w + f29_w<E>::w * f29_w<F>::w + f29_w<G>::w * f29_w<I>::w), "column sum of the products exceeds 64 bits");
+  L29<PM, mul_out_h(Q)> r;
 #if ZKR_F29_DEVICE_ASM
   mont29_asm_sum4<PM>(r.v, a.v, b.v, c.v, d.v, e.v, f.v, g.v, h.v);
 #else
@@ -328,11 +372,52 @@ ZKR_HD L29<PM, 2 * ((HB + 1) / 2)> neg(const L29<PM, HB> &b) {
   }
   return r;
 }
-// a b - c d with one reduction
-template <class PM, int HA, int HB, int HC, int HD>
-ZKR_HD auto mul_sub(const L29<PM, HA> &a, const L29<PM, HB> &b, const L29<PM, HC> &c, const L29<PM, HD> &d) {
-  return mul_sum2(a, b, neg(c), d);
+// ---- the same differences WITHOUT the carry sweep (U29): for values that only ever become one factor of a product.
+// K' p - b with K' = ceil(HB / 2) + 1: the extra p keeps the top limb non-negative (b's top limb is at most that of
+// ceil(HB / 2) p, and one more p adds P[8] > 1 to it); the low limbs: f29_lifted - b_i in [0, 2^30)
+template <class PM, int HB>
+ZKR_HD U29<PM, 2 * ((HB + 1) / 2 + 1), 2> neg_loose(const L29<PM, HB> &b) {
+  constexpr int K = (HB + 1) / 2 + 1;
+  static_assert(K <= 24, "no multiple of p tabulated for this bound");
+  U29<PM, 2 * K, 2> r;
+  constexpr uint32_t c[9] = {f29_lifted<PM, K>(0), f29_lifted<PM, K>(1), f29_lifted<PM, K>(2), f29_lifted<PM, K>(3), f29_lifted<PM, K>(4),
+                             f29_lifted<PM, K>(5), f29_lifted<PM, K>(6), f29_lifted<PM, K>(7), f29_lifted<PM, K>(8)};
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.v[i] = c[i] - b.v[i];
+  return r;
 }
+// a + K' p - b, limbs in [0, 3 * 2^29)
+template <class PM, int HA, int HB>
+ZKR_HD U29<PM, HA + 2 * ((HB + 1) / 2 + 1), 3> sub_loose(const L29<PM, HA> &a, const L29<PM, HB> &b) {
+  constexpr int K = (HB + 1) / 2 + 1;
+  static_assert(K <= 24, "no multiple of p tabulated for this bound");
+  U29<PM, HA + 2 * K, 3> r;
+  constexpr uint32_t c[9] = {f29_lifted<PM, K>(0), f29_lifted<PM, K>(1), f29_lifted<PM, K>(2), f29_lifted<PM, K>(3), f29_lifted<PM, K>(4),
+                             f29_lifted<PM, K>(5), f29_lifted<PM, K>(6), f29_lifted<PM, K>(7), f29_lifted<PM, K>(8)};
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.v[i] = a.v[i] + c[i] - b.v[i];
+  return r;
+}
+// flip ? -b : b as a product factor: the sign of a table point folded into its y (18 instructions instead of a negation
+// with its sweep and a select)
+template <class PM, int HB>
+ZKR_HD U29<PM, 2 * ((HB + 1) / 2 + 1), 2> cneg_loose(const L29<PM, HB> &b, bool flip) {
+  auto n = neg_loose(b);
+#pragma unroll
+  for (int i = 0; i < 9; i++) n.v[i] = flip ? n.v[i] : b.v[i];
+  return n;
+}
+// a b - c d with one reduction; b may come without its sweep
+template <class A, class B, class PM, int HC, class D>
+ZKR_HD auto mul_sub(const A &a, const B &b, const L29<PM, HC> &c, const D &d) {
+  return mul_sum2(a, b, neg_loose(c), d);
+}
+
+// (flip ? -y : y) z and a - b as the factor of the Y coordinate's product sum: the forms the group law asks for, per field
+template <class PM, int HY, int HZ>
+ZKR_HD auto mul_cneg(const L29<PM, HY> &y, bool flip, const L29<PM, HZ> &z) { return mul(z, cneg_loose(y, flip)); }
+template <class PM, int HA, int HB>
+ZKR_HD auto sub_factor(const L29<PM, HA> &a, const L29<PM, HB> &b) { return sub_loose(a, b); }
 
 // value < 1.5 p whatever it was (one product with the Montgomery 1): before a value with a wide bound is stored
 template <class PM, int HA>
@@ -394,6 +479,13 @@ ZKR_HD bool is_zero_mod_p(const L29<PM, HA> &a) {
 #pragma unroll
   for (int i = 0; i < 9; i++) { z |= a.v[i]; e |= a.v[i] ^ PM::P[i]; }
   return z == 0 || e == 0;
+}
+// the cheap half of that test, for the hot loops: a value that is 0 or p has limb 0 equal to 0 or P[0]; everything else is
+// sorted out by two compares (one value in 2^28 passes by accident and then takes the full test)
+template <class PM, int HA>
+ZKR_HD bool maybe_zero_mod_p(const L29<PM, HA> &a) {
+  static_assert(HA <= 4, "reduce first: the test compares with 0 and p only");
+  return a.v[0] == 0 || a.v[0] == PM::P[0];
 }
 // the canonical residue (< p), for values that leave the device: at most HA / 2 subtractions of p
 template <class PM, int HA>
@@ -459,7 +551,7 @@ constexpr int max_h(int a, int b) { return a > b ? a : b; }
 // (a0 b0 - a1 b1) + (a0 b1 + a1 b0) u: each component a sum of two products with one reduction
 template <int HA, int HB>
 ZKR_HD auto mul(const Q29<HA> &x, const Q29<HB> &y) {
-  auto re = mul_sum2(x.a, y.a, neg(x.b), y.b);
+  auto re = mul_sum2(x.a, y.a, neg_loose(x.b), y.b);
   auto im = mul_sum2(x.a, y.b, x.b, y.a);
   constexpr int H = max_h(decltype(re)::bound, decltype(im)::bound);
   return Q29<H>{re.template to<H>(), im.template to<H>()};
@@ -467,7 +559,7 @@ ZKR_HD auto mul(const Q29<HA> &x, const Q29<HB> &y) {
 // (a^2 - b^2) + 2 a b u
 template <int HA>
 ZKR_HD auto sqr(const Q29<HA> &x) {
-  auto re = mul_sum2(x.a, x.a, neg(x.b), x.b);
+  auto re = mul_sum2(x.a, x.a, neg_loose(x.b), x.b);
   auto im = mul(dbl(x.a), x.b);
   constexpr int H = max_h(decltype(re)::bound, decltype(im)::bound);
   return Q29<H>{re.template to<H>(), im.template to<H>()};
@@ -475,16 +567,37 @@ ZKR_HD auto sqr(const Q29<HA> &x) {
 // x y - z w: each component a sum of four products with one reduction
 template <int HX, int HY, int HZ, int HW>
 ZKR_HD auto mul_sub(const Q29<HX> &x, const Q29<HY> &y, const Q29<HZ> &z, const Q29<HW> &w) {
-  auto nza = neg(z.a);
-  auto re = mul_sum4(x.a, y.a, neg(x.b), y.b, nza, w.a, z.b, w.b);
-  auto im = mul_sum4(x.a, y.b, x.b, y.a, nza, w.b, neg(z.b), w.a);
+  auto nza = neg_loose(z.a);  // the negations as product factors: no carry sweeps (U29)
+  auto re = mul_sum4(x.a, y.a, neg_loose(x.b), y.b, nza, w.a, z.b, w.b);
+  auto im = mul_sum4(x.a, y.b, x.b, y.a, nza, w.b, neg_loose(z.b), w.a);
   constexpr int H = max_h(decltype(re)::bound, decltype(im)::bound);
   return Q29<H>{re.template to<H>(), im.template to<H>()};
 }
+// (flip ? -y : y) z: both signs of y's components as sweep-less factors, selected per lane
+template <int HY, int HZ>
+ZKR_HD auto mul_cneg(const Q29<HY> &y, bool flip, const Q29<HZ> &z) {
+  auto pa = neg_loose(y.a), pb = neg_loose(y.b), nb = pb;  // pa, pb become +-y.a, +-y.b; nb the negative of pb
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    const uint32_t na = pa.v[i], nbi = pb.v[i];
+    pa.v[i] = flip ? na : y.a.v[i];
+    pb.v[i] = flip ? nbi : y.b.v[i];
+    nb.v[i] = flip ? y.b.v[i] : nbi;
+  }
+  auto re = mul_sum2(z.a, pa, z.b, nb);
+  auto im = mul_sum2(z.b, pa, z.a, pb);
+  constexpr int H = max_h(decltype(re)::bound, decltype(im)::bound);
+  return Q29<H>{re.template to<H>(), im.template to<H>()};
+}
+// over Fq2 the Y coordinate is a sum of FOUR products per component: its column budget has no room for a factor of weight 3
+template <int HA, int HB>
+ZKR_HD auto sub_factor(const Q29<HA> &x, const Q29<HB> &y) { return sub(x, y); }
 template <int HA>
 ZKR_HD Q29<3> weak(const Q29<HA> &x) { return Q29<3>{weak(x.a), weak(x.b)}; }
 template <int HA>
 ZKR_HD bool is_zero_mod_p(const Q29<HA> &x) { return is_zero_mod_p(x.a) && is_zero_mod_p(x.b); }
+template <int HA>
+ZKR_HD bool maybe_zero_mod_p(const Q29<HA> &x) { return maybe_zero_mod_p(x.a); }
 template <int HA>
 ZKR_HD_COLD Q29<2> canonical(const Q29<HA> &x) { return Q29<2>{canonical(x.a), canonical(x.b)}; }
 

@@ -38,6 +38,11 @@ template <class P29> void f29_op(int op, const uint8_t *a32, const uint8_t *b32,
     }
     case 8: from_m261(mul_sum4(a, b, a, a, b, b, neg(a), b), out); break;               // a b + a^2 + b^2 - a b
     case 9: from_m261(weak(sub(sub(sub(a, b), b), b)), out); break;                      // a - 3 b through three lazy subtractions
+    case 11: from_m261(mul(a, neg_loose(b)), out); break;                                 // -a b, the negation without its carry sweep
+    case 12: from_m261(mul(b, sub_loose(a, b)), out); break;                              // b (a - b)
+    case 13: from_m261(mul_sum2(a, sub_loose(a, b), neg_loose(b), a), out); break;        // a (a - b) - a b: the shape of the Y coordinate
+    case 14: from_m261(mul_cneg(a, true, b), out); break;                                 // -a b through the per-lane sign select
+    case 15: from_m261(mul_cneg(a, false, b), out); break;                                // a b
     default: from_m261(mul(sub(a, b).template to<17>(), sub(b, a).template to<17>()), out);  // -(a - b)^2 at the widest bound the group law uses
   }
 }
@@ -132,6 +137,19 @@ void zkt29_barrett(int field, const uint32_t *in, uint32_t *out, uint32_t *canon
     L29<Fr29, 128> a; memcpy(a.v, in, 36);
     auto b = barrett(a); memcpy(out, b.v, 36);
     auto c = canonical_small(b); memcpy(canon, c.v, 36);
+  }
+}
+// the sweep-less differences on raw limbs (a, b: 9 normalised limbs, value below 13 / 4 half moduli as the accumulator's X / Y
+// are): nl = neg_loose(b), sl = sub_loose(a, b) as limbs, for the range and value checks of tests/test_host_arith.py
+void zkt29_loose(int field, const uint32_t *a9, const uint32_t *b9, uint32_t *nl, uint32_t *sl, int *k_neg, int *k_sub) {
+  if (field == 0) {
+    L29<Fq29, 4> a; L29<Fq29, 13> b; memcpy(a.v, a9, 36); memcpy(b.v, b9, 36);
+    auto n = neg_loose(b); auto d = sub_loose(a, b);
+    memcpy(nl, n.v, 36); memcpy(sl, d.v, 36); *k_neg = decltype(n)::bound / 2; *k_sub = (decltype(d)::bound - 4) / 2;
+  } else {
+    L29<Fr29, 4> a; L29<Fr29, 13> b; memcpy(a.v, a9, 36); memcpy(b.v, b9, 36);
+    auto n = neg_loose(b); auto d = sub_loose(a, b);
+    memcpy(nl, n.v, 36); memcpy(sl, d.v, 36); *k_neg = decltype(n)::bound / 2; *k_sub = (decltype(d)::bound - 4) / 2;
   }
 }
 void zkt29_g1_levels(const uint8_t *pt, int c, int levels, uint8_t *out) { jac_levels29<Fq>(pt, c, levels, out); }

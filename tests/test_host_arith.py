@@ -125,6 +125,9 @@ def test_field29_ops_match_the_integers(L):
             0: lambda a, b: a * b % P, 1: lambda a, b: a * a % P, 2: lambda a, b: (a + b) % P, 3: lambda a, b: (a - b) % P,
             4: lambda a, b: -a % P, 5: lambda a, b: 0, 6: lambda a, b: (a * a + b * b) % P, 7: lambda a, b: 16 * a * a % P,
             8: lambda a, b: (a * a + b * b) % P, 9: lambda a, b: (a - 3 * b) % P, 10: lambda a, b: -(a - b) ** 2 % P,
+            # differences used as product factors WITHOUT their carry sweep (field29.hpp U29; round 3)
+            11: lambda a, b: -a * b % P, 12: lambda a, b: b * (a - b) % P, 13: lambda a, b: (a * (a - b) - a * b) % P,
+            14: lambda a, b: -a * b % P, 15: lambda a, b: a * b % P,
         }
         for _ in range(400):
             a, b = rnd.choice(vals), rnd.choice(vals)
@@ -175,6 +178,30 @@ def test_field29_product_forms_on_raw_limbs(L):
                 got = _limbs_value(o)
                 assert got % P == t * rinv % P, (field, form)
                 assert all(x < (1 << 29) for x in o[:8]) and got <= (t >> 261) + P, (field, form)
+
+
+def test_sweepless_differences_on_raw_limbs(L):
+    """neg_loose / sub_loose (field29.hpp U29: K p - b and a + K p - b limb by limb against a multiple of p whose low limbs
+    were lifted by borrowing, NO carry sweep): for b anywhere below its bound of 13 half moduli (the accumulator's X) and a
+    below 4 -- zero, multiples of p and their neighbours, the largest value of the bound, all-ones limbs, random -- every limb
+    is non-negative (no wrap), the low eight stay below 2^30 resp. 3 * 2^29 (what the products' column budget assumes), and
+    the limbs sum to exactly K p - b resp. a + K p - b."""
+    rnd = random.Random(303)
+    M = (1 << 29) - 1
+    L.zkt29_loose.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 4 + [ctypes.POINTER(ctypes.c_int)] * 2
+    for field, P in ((0, Q), (1, R)):
+        top_b, top_a = (13 * P) // 2 - 1, 2 * P - 1
+        bs = [0, 1, P - 1, P, P + 1, 6 * P, 6 * P + (P >> 1), top_b, top_b - 1, (top_b >> 232) << 232, ((top_b >> 232) << 232) - 1, _limbs_value([M] * 8 + [0])]
+        bs += [rnd.randrange(top_b + 1) for _ in range(1500)]
+        as_ = [0, 1, top_a, P, _limbs_value([M] * 8 + [0])] + [rnd.randrange(top_a + 1) for _ in range(20)]
+        for b in bs:
+            a = rnd.choice(as_)
+            limbs = lambda v: (ctypes.c_uint32 * 9)(*([(v >> (29 * i)) & M for i in range(8)] + [v >> 232]))
+            nl, sl = (ctypes.c_uint32 * 9)(), (ctypes.c_uint32 * 9)()
+            kn, ks = ctypes.c_int(), ctypes.c_int()
+            L.zkt29_loose(field, limbs(a), limbs(b), nl, sl, ctypes.byref(kn), ctypes.byref(ks))
+            assert _limbs_value(nl) == kn.value * P - b and _limbs_value(sl) == a + ks.value * P - b, (field, a, b)
+            assert all(x < (1 << 30) for x in nl[:8]) and all(x < 3 << 29 for x in sl[:8]) and nl[8] < (1 << 28) and sl[8] < (1 << 28), (field, a, b)
 
 
 def test_quotient_estimate_reduction_on_raw_limbs(L):
