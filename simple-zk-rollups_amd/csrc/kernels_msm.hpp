@@ -201,6 +201,23 @@ __device__ __forceinline__ void sort_chunk(const uint32_t *rng_off, uint32_t r, 
   e1 = min(e0 + chunk, hi);
 }
 
+// Workgroup -> (bucket range r, chunk j).  The scatter's 4-byte writes of ONE range land in one window of the entry array
+// (its buckets' slots, ~850 KB at 2^20) from all J chunks of that range: a 64-byte line gets its sixteen entries from
+// sixteen workgroups.  Workgroups go to the eight XCDs round robin by index, and each XCD has its own L2: with the plain
+// mapping (r = index / J) the chunks of a range sit on all eight, every L2 holds the line partially and writes it back
+// with a byte mask (522 MB of traffic for 54 MB of entries, rocprofv3 WRITE_SIZE, round 2).  xcd_map: all chunks of a
+// range on the XCD (r mod 8), whose L2 then merges the line before it leaves.
+__device__ __forceinline__ void sort_block_to_chunk(uint32_t b, uint32_t nR, uint32_t J, int xcd_map, uint32_t &r, uint32_t &j) {
+  if (xcd_map && nR % 8 == 0) {
+    const uint32_t xcd = b % 8, q = b / 8;  // q-th workgroup of this XCD
+    r = xcd + 8 * (q / J);
+    j = q % J;
+  } else {
+    r = b / J;
+    j = b % J;
+  }
+}
+
 // cnt[(r * J + j) * nbl + b] = occupancy of bucket r * nbl + b within chunk j
 static __global__ __launch_bounds__(SORT_THREADS) void msm_hist_kernel(const uint32_t *ent_s, const uint32_t *ent_b, const uint32_t *rng_off, const uint32_t *rank,
                                                                      uint32_t n_per, uint32_t nbl, uint32_t J, uint32_t *cnt) {
@@ -251,10 +268,11 @@ static __global__ __launch_bounds__(MSM_THREADS) void msm_colscan_kernel(uint32_
 // grouped by bucket: LDS cursors = bucket offset + chunk prefix
 static __global__ __launch_bounds__(SORT_THREADS) void msm_scatter_kernel(const uint32_t *ent_s, const uint32_t *ent_b, const uint32_t *rng_off, const uint32_t *rank,
                                                                         uint32_t n_per, uint32_t n, uint32_t nbl, uint32_t J, const uint32_t *cnt, const uint32_t *offsets,
-                                                                        uint32_t *entries) {
+                                                                        uint32_t *entries, int xcd_map) {
   ZKR_PREP_SETPRIO();
   extern __shared__ __attribute__((aligned(16))) uint32_t s_bkt[];
-  const uint32_t j = blockIdx.x % J, r = blockIdx.x / J;
+  uint32_t j, r;
+  sort_block_to_chunk(blockIdx.x, gridDim.x / J, J, xcd_map, r, j);
   const uint32_t *pre = cnt + ((size_t)r * J + j) * nbl, *off = offsets + (size_t)r * nbl;
   for (uint32_t b = threadIdx.x; b < nbl; b += SORT_THREADS) s_bkt[b] = off[b] + pre[b];
   __syncthreads();
@@ -423,7 +441,7 @@ static __global__ __launch_bounds__(SCAN_THREADS) void msm_order_kernel(const ui
 constexpr int ACC_THREADS = ZKR_ACC_THREADS;
 template <class F, int MINW, bool PREFETCH = true>
 static __global__ __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per_eu(MINW, MINW))) void msm_accum_kernel(const Affine<F> *points, const uint32_t *offsets, const uint32_t *entries,
-                                                                     uint32_t nb, const uint32_t *counts, const uint32_t *order, XYZZ<F> *buckets, int prio) {
+                                                                     uint32_t nb, const uint32_t *counts, const uint32_t *order, XYZZ<F> *buckets, int prio, int onto) {
   using C = typename CoordOf<F>::C;
   if (prio == 1) __builtin_amdgcn_s_setprio(1);
   else if (prio == 2) __builtin_amdgcn_s_setprio(2);
@@ -433,7 +451,9 @@ static __global__ __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per
   const uint32_t b = order[t];
   if (counts[b] == BIG_MARK) return;  // msm_big_kernel owns it
   uint32_t o0 = offsets[b], o1 = offsets[b + 1];
-  XYZZ29<C> acc = XYZZ29<C>::inf();
+  // onto: the bucket set already holds another table's sums over the same bucket geometry (C before H: only C + H is ever
+  // needed, so one bucket set and ONE reduction chain serve both tables)
+  XYZZ29<C> acc = onto ? unpack_xyzz(load_pod(buckets + b)) : XYZZ29<C>::inf();
   if (PREFETCH) {
     if (o0 < o1) {
       uint32_t e = entries[o0];
@@ -474,7 +494,7 @@ __device__ __forceinline__ T lane_xor_words(const T &v, int mask) {
 }
 template <class F, int MINW, int SPLIT>
 static __global__ __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per_eu(MINW, MINW))) void msm_accum_split_kernel(const Affine<F> *points, const uint32_t *offsets, const uint32_t *entries,
-                                                                     uint32_t nb, const uint32_t *counts, const uint32_t *order, XYZZ<F> *buckets) {
+                                                                     uint32_t nb, const uint32_t *counts, const uint32_t *order, XYZZ<F> *buckets, int onto) {
   const uint32_t t = blockIdx.x * ACC_THREADS + threadIdx.x;
   const uint32_t slot = t / SPLIT, sub = t % SPLIT;
   if (slot >= nb) return;  // uniform over the SPLIT lanes of a bucket
@@ -482,7 +502,7 @@ static __global__ __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per
   if (counts[b] == BIG_MARK) return;
   using C = typename CoordOf<F>::C;
   const uint32_t o0 = offsets[b], o1 = offsets[b + 1];
-  XYZZ29<C> acc = XYZZ29<C>::inf();
+  XYZZ29<C> acc = onto && sub == 0 ? unpack_xyzz(load_pod(buckets + b)) : XYZZ29<C>::inf();  // see msm_accum_kernel
   uint32_t e = o0 + sub < o1 ? entries[o0 + sub] : 0u;
   for (uint32_t j = o0 + sub; j < o1; j += SPLIT) {
     uint32_t en = j + SPLIT < o1 ? entries[j + SPLIT] : 0u;
@@ -537,13 +557,14 @@ static __global__ __launch_bounds__(MSM_THREADS, MINW) void msm_big_kernel(const
 
 template <class F, int MINW>
 static __global__ __launch_bounds__(64, MINW) void msm_big_finish_kernel(const XYZZ<F> *partials, const uint32_t *big_list, const uint32_t *big_count,
-                                                                         uint32_t big_cap, XYZZ<F> *buckets) {
+                                                                         uint32_t big_cap, XYZZ<F> *buckets, int onto) {
   __builtin_amdgcn_s_setprio(ZKR_RED_PRIO);  // few long-running wavefronts on the critical path: win VALU arbitration against the bulk accumulation
   uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= min(*big_count, big_cap)) return;
   using C = typename CoordOf<F>::C;
   XYZZ29<C> acc = unpack_xyzz(load_pod(partials + (size_t)w * BIG_SPLIT));
   for (int k = 1; k < BIG_SPLIT; k++) acc = add_full29<C>(acc, unpack_xyzz(load_pod(partials + (size_t)w * BIG_SPLIT + k)));
+  if (onto) acc = add_full29<C>(acc, unpack_xyzz(load_pod(buckets + big_list[w])));  // the bucket keeps the other table's sum (msm_accum_kernel skipped it)
   store_pod(buckets + big_list[w], pack_xyzz<F>(acc));
 }
 

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <time.h>
 #include <condition_variable>
 #include <mutex>
 #include <string>
@@ -115,8 +116,12 @@ struct ProofSlot {
   hipEvent_t ev_red[N_TABLES] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // end of the proof's work on each reduction stream
   hipEvent_t ev_done[N_TABLES] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_sorted[N_TABLES] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_res[N_TABLES] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // the table's result point has landed in its pinned host buffer
+  bool res_pending[N_TABLES] = {false, false, false, false, false};
   int cap = 1;    // proofs one submit can fuse into shared launches (small circuits; every buffer above is cap times one proof's)
   int nbat = 0;   // proofs of the group in flight
+  struct timespec t_submit = {0, 0};  // when the group's enqueue began (ZKR_TRACE_COLLECT)
+  bool merged_ch = false;  // this group's H was accumulated onto C's bucket set: C's workspace holds C + H
   std::vector<uint8_t> rb, sb;  // blinding scalars of the proofs in flight, cap x 32 B each
   bool busy = false, collecting = false;
   std::vector<ProfSpan> spans;

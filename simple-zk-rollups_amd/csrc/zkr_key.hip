@@ -181,6 +181,7 @@ int key_alloc_workspace(zkr_key *k) {
     for (int t = 0; t < N_TABLES; t++) {
       ZKR_HIP_CHECK(hipEventCreateWithFlags(&sl.ev_done[t], hipEventDisableTiming));
       ZKR_HIP_CHECK(hipEventCreateWithFlags(&sl.ev_sorted[t], hipEventDisableTiming));
+      ZKR_HIP_CHECK(hipEventCreateWithFlags(&sl.ev_res[t], hipEventDisableTiming));
     }
     ZKR_HIP_CHECK(hipEventCreateWithFlags(&sl.ev_w, hipEventDisableTiming));
     ZKR_HIP_CHECK(hipEventCreateWithFlags(&sl.ev_h, hipEventDisableTiming));
@@ -546,6 +547,7 @@ void zkr_key_free(zkr_key *k) {
     for (int t = 0; t < N_TABLES; t++) {
       if (sl.ev_done[t]) hipEventDestroy(sl.ev_done[t]);
       if (sl.ev_sorted[t]) hipEventDestroy(sl.ev_sorted[t]);
+      if (sl.ev_res[t]) hipEventDestroy(sl.ev_res[t]);
       msm_ws_free(sl.ws[t]);
     }
     if (sl.ev_w) hipEventDestroy(sl.ev_w);

@@ -9,6 +9,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <algorithm>
 #include "kernels_msm.hpp"
 #include "kernels_ntt.hpp"
@@ -236,7 +237,8 @@ static int msm_sort_enqueue(Prof pf, hipStream_t s, const uint32_t *rank, const 
   msm_scan_apply_kernel<<<scan_blocks, SCAN_THREADS, 0, s>>>(ws.counts, ws.block_sums, ws.big_count + 1, ws.offsets, nb, pl.big_thresh,
                                                             ws.big_list, ws.big_count, BIG_CAP, ws.size_hist);
   msm_order_kernel<<<scan_blocks, SCAN_THREADS, 0, s>>>(ws.counts, nb, ws.size_hist, ws.size_hist + SIZE_BINS, ws.order);
-  msm_scatter_kernel<<<sort_grid, SORT_THREADS, lds, s>>>(dl.ent_s, dl.ent_b, rng_off, rank, n_scalars, n, pl.nbl, pl.J, ws.chunk_cnt, ws.offsets, ws.entries);
+  static const int xcd_map = getenv("ZKR_SORT_XCD") ? atoi(getenv("ZKR_SORT_XCD")) : 1;
+  msm_scatter_kernel<<<sort_grid, SORT_THREADS, lds, s>>>(dl.ent_s, dl.ent_b, rng_off, rank, n_scalars, n, pl.nbl, pl.J, ws.chunk_cnt, ws.offsets, ws.entries, xcd_map);
   prof_end(pf, s, sp);
   ZKR_HIP_CHECK(hipGetLastError());
   return 0;
@@ -245,7 +247,7 @@ static int msm_sort_enqueue(Prof pf, hipStream_t s, const uint32_t *rank, const 
 // bucket accumulation of one point table over a finished sort (`srt` may belong to another table with the
 // same point set: B1 and B2 share one)
 template <class F>
-static int msm_accum_enqueue(Prof pf, hipStream_t s, const Affine<F> *pts, uint32_t n, int nbat, const MsmPlan &pl, const MsmWorkspace &srt, MsmWorkspace &ws) {
+static int msm_accum_enqueue(Prof pf, hipStream_t s, const Affine<F> *pts, uint32_t n, int nbat, const MsmPlan &pl, const MsmWorkspace &srt, MsmWorkspace &ws, bool onto = false) {
   if (n == 0) return 0;
   const uint32_t nb = pl.nb * (uint32_t)nbat;
   int sp = prof_begin(pf, s, MsmCfg<F>::ACC_STAGE);
@@ -259,7 +261,7 @@ static int msm_accum_enqueue(Prof pf, hipStream_t s, const Affine<F> *pts, uint3
   const int split = split_env ? atoi(split_env) : nb <= (1u << 17) ? 4 : 1;  // tx circuit (2^16 buckets): 379 / 455 / 458 / 393 proofs/s at 1 / 2 / 4 / 8
   if (split > 1) {
     const unsigned sgrid = (unsigned)(((size_t)nb * split + ACC_THREADS - 1) / ACC_THREADS);
-#define ZKR_ACC_SPLIT_LAUNCH(SP) msm_accum_split_kernel<F, MsmCfg<F>::ACC_W, SP><<<sgrid, ACC_THREADS, 0, s>>>(pts, srt.offsets, srt.entries, nb, srt.counts, srt.order, (XYZZ<F> *)ws.buckets)
+#define ZKR_ACC_SPLIT_LAUNCH(SP) msm_accum_split_kernel<F, MsmCfg<F>::ACC_W, SP><<<sgrid, ACC_THREADS, 0, s>>>(pts, srt.offsets, srt.entries, nb, srt.counts, srt.order, (XYZZ<F> *)ws.buckets, onto ? 1 : 0)
     switch (split) {
       case 2: ZKR_ACC_SPLIT_LAUNCH(2); break;
       case 8: ZKR_ACC_SPLIT_LAUNCH(8); break;
@@ -272,7 +274,7 @@ static int msm_accum_enqueue(Prof pf, hipStream_t s, const Affine<F> *pts, uint3
   }
   const unsigned grid = (nb + ACC_THREADS - 1) / ACC_THREADS;
   static const int acc_prio = getenv("ZKR_ACC_PRIO") ? atoi(getenv("ZKR_ACC_PRIO")) : 0;
-#define ZKR_ACC_LAUNCH(W) msm_accum_kernel<F, W, MsmCfg<F>::ACC_PREFETCH><<<grid, ACC_THREADS, 0, s>>>(pts, srt.offsets, srt.entries, nb, srt.counts, srt.order, (XYZZ<F> *)ws.buckets, acc_prio)
+#define ZKR_ACC_LAUNCH(W) msm_accum_kernel<F, W, MsmCfg<F>::ACC_PREFETCH><<<grid, ACC_THREADS, 0, s>>>(pts, srt.offsets, srt.entries, nb, srt.counts, srt.order, (XYZZ<F> *)ws.buckets, acc_prio, onto ? 1 : 0)
   switch (acc_w) {
     case 1: ZKR_ACC_LAUNCH(1); break;
     case 3: ZKR_ACC_LAUNCH(3); break;
@@ -297,17 +299,24 @@ static int msm_big_enqueue(Prof pf, hipStream_t s, const Affine<F> *pts, uint32_
   return 0;
 }
 
-// big-bucket partial sums -> buckets, bucket reduction -> the MSM result in ws.h_result: short launches of few,
-// long-running wavefronts (raised wave priority), meant to run beside the next table's accumulation
+// big-bucket partial sums -> buckets (onto: added to what the bucket holds, the other table of a shared bucket set)
+template <class F>
+static int msm_big_finish_enqueue(Prof pf, hipStream_t s, uint32_t n, const MsmWorkspace &srt, MsmWorkspace &ws, bool onto = false) {
+  if (n == 0) return 0;
+  int sp = prof_begin(pf, s, "msm_big");
+  msm_big_finish_kernel<F, MsmCfg<F>::RED_W><<<BIG_CAP / 64, 64, 0, s>>>((const XYZZ<F> *)ws.big_partials, srt.big_list, srt.big_count, BIG_CAP, (XYZZ<F> *)ws.buckets, onto ? 1 : 0);
+  prof_end(pf, s, sp);
+  ZKR_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+// bucket reduction -> the MSM result in ws.h_result: short launches of few, long-running wavefronts (raised wave
+// priority), meant to run beside the next table's accumulation
 template <class F>
 static int msm_reduce_enqueue(Prof pf, hipStream_t s, uint32_t n, int nbat, const MsmPlan &pl, const MsmWorkspace &srt, MsmWorkspace &ws) {
   if (n == 0) return 0;
   MsmGeom g;
   g.n = n; g.c = pl.c; g.K = pl.K; g.nbw = pl.nbw; g.big_thresh = pl.big_thresh; g.glog = pl.glog; g.S = pl.S; g.batch = (uint32_t)nbat;
-  int sp = prof_begin(pf, s, "msm_big");
-  msm_big_finish_kernel<F, MsmCfg<F>::RED_W><<<BIG_CAP / 64, 64, 0, s>>>((const XYZZ<F> *)ws.big_partials, srt.big_list, srt.big_count, BIG_CAP, (XYZZ<F> *)ws.buckets);
-  prof_end(pf, s, sp);
-  sp = prof_begin(pf, s, "msm_reduce");
+  int sp = prof_begin(pf, s, "msm_reduce");
   uint32_t ngroups = (pl.nbw >> pl.glog) * (uint32_t)nbat;
   uint32_t ntask = (uint32_t)(pl.c - 1 - pl.glog) + 2;
   msm_reduce1_kernel<F, MsmCfg<F>::RED_W><<<(ngroups + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, s>>>((const XYZZ<F> *)ws.buckets, g, (XYZZ<F> *)ws.group_out);
@@ -329,6 +338,7 @@ static int msm_enqueue(Prof pf, hipStream_t s, const Affine<F> *pts, const uint3
   if ((rc = msm_sort_enqueue(pf, s, rank, ws.own_dig, n_scalars, n, 1, pl, ws))) return rc;
   if ((rc = msm_big_enqueue<F>(pf, s, pts, n, pl, ws, ws))) return rc;
   if ((rc = msm_accum_enqueue<F>(pf, s, pts, n, 1, pl, ws, ws))) return rc;
+  if ((rc = msm_big_finish_enqueue<F>(pf, s, n, ws, ws))) return rc;
   return msm_reduce_enqueue<F>(pf, s, n, 1, pl, ws, ws);
 }
 
@@ -404,6 +414,7 @@ static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *const *d_ws
     }
   }
   sl.nbat = nbat;
+  clock_gettime(CLOCK_MONOTONIC, &sl.t_submit);
 
   // The caller's stream only orders the witness before the proof (it may carry unrelated work, and with two
   // proofs in flight it must not chain them).  Schedule on the key's own streams (HIP multiplexes streams onto a
@@ -451,44 +462,93 @@ static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *const *d_ws
     if (!serial) ZKR_HIP_CHECK(hipEventRecord(sl.ev_sorted[t], sp));
     return 0;
   };
+  // C and H are only ever needed as C + H (App. B step 4: pi_c): when their bucket geometry agrees, H is accumulated ONTO
+  // C's bucket set and one reduction chain serves both -- a bucket reduction (2 x 2^19 full additions, ~1.6 % of a proof's
+  // instructions) and one latency chain less.  C's chain then ends with its oversized buckets in place (ev_h), which H's
+  // accumulation waits for; H's own oversized buckets are added to what their buckets hold.
+  static const bool no_merge = getenv("ZKR_NO_MERGE_CH") != nullptr;
+  const MsmPlan &pc = k->plan[T_C], &ph = k->plan[T_H];
+  const bool merge_ch = !no_merge && h.npts[T_C] && h.npts[T_H] && pc.c == ph.c && pc.nbw == ph.nbw && pc.glog == ph.glog && pc.S == ph.S;
+  sl.merged_ch = merge_ch;
+  for (int t = 0; t < N_TABLES; t++) sl.res_pending[t] = false;
+  auto result_event = [&](int t, hipStream_t rs, int rc) -> int {  // after a table's reduction chain (its D2H copy is the last thing enqueued)
+    if (rc) return rc;
+    ZKR_HIP_CHECK(hipEventRecord(sl.ev_res[t], rs));
+    sl.res_pending[t] = true;
+    return 0;
+  };
+  // Schedule knobs (ZKR_SCHED, bits): 1 = hand each table's chain to its streams right after its sort is enqueued instead of
+  // after the whole preparation chain; 2 = the table's accumulation runs on its chain's stream instead of the one accumulation
+  // stream (tables then accumulate concurrently).  Defaults per key size below.
+  static const int sched_env = getenv("ZKR_SCHED") ? atoi(getenv("ZKR_SCHED")) : -1;
+  const int sched = sched_env >= 0 ? sched_env : 0;
+  const bool early = (sched & 1) != 0 && !serial, acc_on_chain = (sched & 2) != 0 && !serial;
   auto accum_table = [&](int t, hipStream_t rs) -> int {
     const MsmWorkspace &srt = sl.ws[sort_src[t]];
+    MsmWorkspace &dst = t == T_H && merge_ch ? sl.ws[T_C] : sl.ws[t];  // whose bucket set / reduction buffers the table lands in
+    const bool onto = t == T_H && merge_ch;
     const void *pts = ar + h.off_pts[t];
+    hipStream_t sa = acc_on_chain ? rs : s;
     int rc;
     if (!serial) {
       ZKR_HIP_CHECK(hipStreamWaitEvent(rs, sl.ev_sorted[sort_src[t]], 0));
-      ZKR_HIP_CHECK(hipStreamWaitEvent(s, sl.ev_sorted[sort_src[t]], 0));
+      if (sa != rs) ZKR_HIP_CHECK(hipStreamWaitEvent(sa, sl.ev_sorted[sort_src[t]], 0));
     }
+    // oversized buckets: partial sums into the table's OWN partials buffer (needs only the sort, runs beside the accumulation)
     if (t == T_B2) rc = msm_big_enqueue<Fq2>(pf, rs, (const G2Affine *)pts, h.npts[t], k->plan[t], srt, sl.ws[t]);
     else rc = msm_big_enqueue<Fq>(pf, rs, (const G1Affine *)pts, h.npts[t], k->plan[t], srt, sl.ws[t]);
     if (rc) return rc;
-    if (t == T_B2) rc = msm_accum_enqueue<Fq2>(pf, s, (const G2Affine *)pts, h.npts[t], nbat, k->plan[t], srt, sl.ws[t]);
-    else rc = msm_accum_enqueue<Fq>(pf, s, (const G1Affine *)pts, h.npts[t], nbat, k->plan[t], srt, sl.ws[t]);
-    if (rc) return rc;
-    if (!serial) {
-      ZKR_HIP_CHECK(hipEventRecord(sl.ev_done[t], s));
-      ZKR_HIP_CHECK(hipStreamWaitEvent(rs, sl.ev_done[t], 0));
+    if (t == T_C && merge_ch) {  // C's oversized buckets go in at once (the accumulation never touches them); that ends C's chain
+      if ((rc = msm_big_finish_enqueue<Fq>(pf, rs, h.npts[t], srt, sl.ws[t]))) return rc;
+      if (!serial) ZKR_HIP_CHECK(hipEventRecord(sl.ev_h, rs));
     }
-    if (t == T_B2) rc = msm_reduce_enqueue<Fq2>(pf, rs, h.npts[t], nbat, k->plan[t], srt, sl.ws[t]);
-    else rc = msm_reduce_enqueue<Fq>(pf, rs, h.npts[t], nbat, k->plan[t], srt, sl.ws[t]);
-    return rc;
+    if (onto && !serial) {
+      ZKR_HIP_CHECK(hipStreamWaitEvent(sa, sl.ev_h, 0));
+      if (acc_on_chain) ZKR_HIP_CHECK(hipStreamWaitEvent(sa, sl.ev_done[T_C], 0));  // C's accumulation ran on another stream
+    }
+    if (t == T_B2) rc = msm_accum_enqueue<Fq2>(pf, sa, (const G2Affine *)pts, h.npts[t], nbat, k->plan[t], srt, dst);
+    else rc = msm_accum_enqueue<Fq>(pf, sa, (const G1Affine *)pts, h.npts[t], nbat, k->plan[t], srt, dst, onto);
+    if (rc) return rc;
+    if (!serial) ZKR_HIP_CHECK(hipEventRecord(sl.ev_done[t], sa));
+    if (t == T_C && merge_ch) return 0;
+    if (!serial && sa != rs) ZKR_HIP_CHECK(hipStreamWaitEvent(rs, sl.ev_done[t], 0));
+    if (t == T_B2) {
+      if ((rc = msm_big_finish_enqueue<Fq2>(pf, rs, h.npts[t], srt, sl.ws[t]))) return rc;
+      return result_event(t, rs, msm_reduce_enqueue<Fq2>(pf, rs, h.npts[t], nbat, k->plan[t], srt, sl.ws[t]));
+    }
+    if (onto) {  // partial sums from H's buffer, buckets / reduction buffers / result of C's workspace
+      MsmWorkspace mix = dst;
+      mix.big_partials = sl.ws[t].big_partials;
+      if ((rc = msm_big_finish_enqueue<Fq>(pf, rs, h.npts[t], srt, mix, true))) return rc;
+      return result_event(t, rs, msm_reduce_enqueue<Fq>(pf, rs, h.npts[t], nbat, k->plan[t], srt, dst));
+    }
+    if ((rc = msm_big_finish_enqueue<Fq>(pf, rs, h.npts[t], srt, sl.ws[t]))) return rc;
+    return result_event(t, rs, msm_reduce_enqueue<Fq>(pf, rs, h.npts[t], nbat, k->plan[t], srt, sl.ws[t]));
+  };
+  hipStream_t last = s;
+  auto chains = [&](std::initializer_list<int> ts) -> int {
+    for (int t : ts) {
+      last = red_of(t);
+      int rc = accum_table(t, last);
+      if (rc) return rc;
+    }
+    return 0;
   };
   // preparation chain
   if ((rc = msm_digits_enqueue(pf, sp, sl.d_w, h.n, nbat, k->plan[T_A], sl.dig_w))) return rc;
   if ((rc = sort_table(T_B1))) return rc;
   if (!share_b && (rc = sort_table(T_B2))) return rc;
+  if (early && (rc = chains({T_B2, T_B1}))) return rc;
   if ((rc = sort_table(T_A))) return rc;
   if (!share_ac && (rc = sort_table(T_C))) return rc;
+  if (early && (rc = chains({T_A, T_C}))) return rc;
   if ((rc = calc_h_device(k, sl, sp, nbat))) return rc;
   if ((rc = msm_digits_enqueue(pf, sp, sl.d_h, h.m, nbat, k->plan[T_H], sl.dig_h))) return rc;
   if ((rc = sort_table(T_H))) return rc;
   // accumulations + reduction chains
-  const int order[N_TABLES] = {T_B2, T_B1, T_A, T_C, T_H};
-  hipStream_t last = s;
-  for (int t : order) {
-    last = red_of(t);
-    if ((rc = accum_table(t, last))) return rc;
-  }
+  if (early) rc = chains({T_H});
+  else rc = chains({T_B2, T_B1, T_A, T_C, T_H});
+  if (rc) return rc;
   // completion = every reduction stream done (prove_collect waits for the events on the host).  No stream is made
   // to wait for another, so nothing of the next proof queues behind this one's tail.
   prof_end(pf, last, tot);
@@ -520,22 +580,34 @@ static int prove_collect(zkr_key *k, ProofSlot &sl, uint8_t *proofs_out) {
   ZKR_HIP_CHECK(hipSetDevice(k->device));
   const ArenaHeader &h = k->h;
   static const bool serial_mode = getenv("ZKR_SERIAL") != nullptr;
-  for (int j = 0; j < (serial_mode ? 1 : k->n_red); j++) ZKR_HIP_CHECK(hipEventSynchronize(sl.ev_red[j]));
-  if (k->prof_on) { std::lock_guard<std::mutex> lk(k->mu); prof_collect(k, sl); }
+  // Host assembly in two phases.  Everything that needs A, B1, B2 only -- pi_a, pi_b and s (A + alfa) + r (B1 + beta) + r s delta,
+  // i.e. all the scalar multiplications -- is done while the LAST chains (C, H: H's sort only starts after calcH) still run
+  // on the GPU; when C + H lands, one addition and one inversion finish pi_c.  Single-proof latency: ~0.35 ms of host work
+  // off the critical path (with two proofs in flight it was hidden already).
+  auto wait_table = [&](int t) -> int {
+    if (sl.res_pending[t]) ZKR_HIP_CHECK(hipEventSynchronize(sl.ev_res[t]));
+    return 0;
+  };
+  int rcw;
+  static const bool trace = getenv("ZKR_TRACE_COLLECT") != nullptr;
+  struct timespec ts0, ts1, ts2, ts3, ts4;
+  if (trace) clock_gettime(CLOCK_MONOTONIC, &ts0);
+  if ((rcw = wait_table(T_A)) || (rcw = wait_table(T_B1)) || (rcw = wait_table(T_B2))) return rcw;
+  if (trace) clock_gettime(CLOCK_MONOTONIC, &ts1);
   std::call_once(k->delta_once, [&] {
     k->delta1_tab = fixed_base_table(load_g1(h.delta1));
     k->delta2_tab = fixed_base_table(load_g2(h.delta2));
   });
   G1XYZZ alfa1 = to_xyzz(load_g1(h.alfa1)), beta1 = to_xyzz(load_g1(h.beta1));
   G2XYZZ beta2 = to_xyzz(load_g2(h.beta2));
+  std::vector<G1XYZZ> pic_part((size_t)sl.nbat);
+  int status = 0;
   for (int j = 0; j < sl.nbat; j++) {
     const uint8_t *rb = &sl.rb[32 * j], *sb = &sl.sb[32 * j];
     uint8_t *proof_out = proofs_out + 256 * j;
     G1XYZZ A = msm_finish<Fq>(h.npts[T_A], sl.ws[T_A], j);
     G1XYZZ B1 = msm_finish<Fq>(h.npts[T_B1], sl.ws[T_B1], j);
     G2XYZZ B2 = msm_finish<Fq2>(h.npts[T_B2], sl.ws[T_B2], j);
-    G1XYZZ C = msm_finish<Fq>(h.npts[T_C], sl.ws[T_C], j);
-    G1XYZZ H = msm_finish<Fq>(h.npts[T_H], sl.ws[T_H], j);
     // pi_a = A + alfa + r delta;  pi_b = B2 + beta + s delta;  pi_c = C + H + s pi_a + r (B1 + beta + s delta) - r s delta
     //      = C + H + s (A + alfa) + r (B1 + beta) + r s delta: three multiples of the key's delta (window tables) and one
     // double multiplication of the two MSM results with shared doublings
@@ -547,13 +619,31 @@ static int prove_collect(zkr_key *k, ProofSlot &sl, uint8_t *proofs_out) {
     Fr rs_std = from_mont(rs);
     U256 rsu;
     memcpy(rsu.v, rs_std.v, 32);
-    G1XYZZ pic = add_full(add_full(C, H), double_scalar_mul(a_alfa, sc, b_beta, r));
-    pic = add_full(pic, fixed_base_mul(k->delta1_tab, rsu));
-    if (pia.is_inf() || pib.is_inf() || pic.is_inf()) { set_error("degenerate proof element (point at infinity)"); return ZKR_ERR_DEGENERATE; }
+    pic_part[j] = add_full(double_scalar_mul(a_alfa, sc, b_beta, r), fixed_base_mul(k->delta1_tab, rsu));
+    if (pia.is_inf() || pib.is_inf()) { status = ZKR_ERR_DEGENERATE; continue; }
     store_g1_std(proof_out, to_affine(pia));
     store_g2_std(proof_out + 64, to_affine(pib));
-    store_g1_std(proof_out + 192, to_affine(pic));
   }
+  if (trace) clock_gettime(CLOCK_MONOTONIC, &ts2);
+  if ((rcw = wait_table(T_C)) || (rcw = wait_table(T_H))) return rcw;
+  if (trace) clock_gettime(CLOCK_MONOTONIC, &ts3);
+  for (int j = 0; j < (serial_mode ? 1 : k->n_red); j++) ZKR_HIP_CHECK(hipEventSynchronize(sl.ev_red[j]));  // every stream of the slot is idle (all of it precedes the table events)
+  if (k->prof_on) { std::lock_guard<std::mutex> lk(k->mu); prof_collect(k, sl); }
+  for (int j = 0; j < sl.nbat && !status; j++) {
+    // merged bucket sets (prove_submit_enqueue): the one reduction result, C + H, sits in C's workspace
+    G1XYZZ C = msm_finish<Fq>(h.npts[T_C], sl.ws[T_C], j);
+    G1XYZZ H = sl.merged_ch ? G1XYZZ::inf() : msm_finish<Fq>(h.npts[T_H], sl.ws[T_H], j);
+    G1XYZZ pic = add_full(add_full(C, H), pic_part[j]);
+    if (pic.is_inf()) { status = ZKR_ERR_DEGENERATE; break; }
+    store_g1_std(proofs_out + 256 * j + 192, to_affine(pic));
+  }
+  if (trace) {
+    clock_gettime(CLOCK_MONOTONIC, &ts4);
+    auto us = [](const timespec &a, const timespec &b) { return (b.tv_sec - a.tv_sec) * 1e6 + (b.tv_nsec - a.tv_nsec) * 1e-3; };
+    fprintf(stderr, "collect: submit->collect %.0f us, wait A/B %.0f us, host phase 1 %.0f us, wait C/H %.0f us, host phase 2 %.0f us\n",
+            us(sl.t_submit, ts0), us(ts0, ts1), us(ts1, ts2), us(ts2, ts3), us(ts3, ts4));
+  }
+  if (status) { set_error("degenerate proof element (point at infinity)"); return status; }
   return 0;
 }
 
