@@ -552,7 +552,21 @@ def main():
                 traffic_src = "profiles/r2_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 read correction)"
         except Exception:
             pass
-        roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        # the kernels of the path that STREAM (SURVEY 8(d) regime 1), each against the HBM peak: algorithmic bytes per launch
+        # over the launch's own duration (hipEvents around every launch, two proofs in flight: the kernels share the chip
+        # with the accumulations; isolated durations are in profiles/)
+        m_, n_ = info["domainSize"], info["nVars"]
+        stream_bytes = {"ingest": ("ingest_kernel", 64.0 * n_), "spmv_a": ("spmv_kernel (A side)", 36.0 * info["nnzA"] + 32.0 * n_ + 32.0 * m_),
+                        "ntt_pass": ("ntt_pass_kernel", 64.0 * m_), "combine_h": ("combine_h_kernel", 96.0 * m_)}
+        streaming = {}
+        for st_name, (kname, nbytes) in stream_bytes.items():
+            ms_t, nl = prof.get(st_name, (0.0, 0))
+            if nl:
+                gbps = nbytes / (ms_t / nl * 1e-3) / 1e9
+                streaming[kname] = {"algorithmic_bytes_per_launch": nbytes, "avg_launch_us": 1e3 * ms_t / nl, "launches": nl,
+                                    "achieved_GBps": gbps, "frac_of_hbm_peak": gbps / HBM_PEAK_GBPS}
+        roofline = {"bound": "hbm", "binding_bound": "valu", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "streaming": streaming,
                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                     "avg_launch_ms": avg_ms, "launches": launches,
                     "algorithmic_bytes_per_launch": bytes_per_launch,
@@ -563,7 +577,7 @@ def main():
         try:
             peak_gmul = zkr_hip.bench_fq_mul(local)
             gm = fqmul_per_launch / (avg_ms * 1e-3) / 1e9
-            roofline["valu"] = {"peak_fq_mul_per_s_G": peak_gmul, "unit": "G Fq-mul/s (162 mad32 each: 9 x 29-bit limbs, no carry words)",
+            roofline["valu"] = {"bound": "valu", "peak_fq_mul_per_s_G": peak_gmul, "unit": "G Fq-mul/s (162 mad32 each: 9 x 29-bit limbs, no carry words)",
                                 "peak_fq_mul_per_s_G_legacy_8x32": zkr_hip.bench_fq_mul(local, legacy=True),
                                 "achieved_fq_mul_per_s_G": gm, "frac": gm / peak_gmul,
                                 "window_bits": win["A"][0], "additions_per_point": win["A"][1]}

@@ -22,6 +22,27 @@ void set_error(const char *fmt, ...);
     }                                                                                       \
   } while (0)
 
+// a device allocation (or a HIP event) that goes when its scope ends: the test hooks and one-off entry points return early on
+// every failed HIP call, and none of those paths may leave device memory behind
+struct DevBuf {
+  void *p = nullptr;
+  DevBuf() = default;
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  ~DevBuf() { if (p) hipFree(p); }
+  int alloc(size_t bytes) { ZKR_HIP_CHECK(hipMalloc(&p, bytes ? bytes : 1)); return 0; }
+  template <class T> T *as() const { return static_cast<T *>(p); }
+  void *release() { void *q = p; p = nullptr; return q; }
+};
+struct ScopedEvent {
+  hipEvent_t e = nullptr;
+  ScopedEvent() = default;
+  ScopedEvent(const ScopedEvent &) = delete;
+  ScopedEvent &operator=(const ScopedEvent &) = delete;
+  ~ScopedEvent() { if (e) hipEventDestroy(e); }
+  int create() { ZKR_HIP_CHECK(hipEventCreate(&e)); return 0; }
+};
+
 enum { T_A = 0, T_B1 = 1, T_B2 = 2, T_C = 3, T_H = 4, N_TABLES = 5 };
 
 // The device key is ONE position-independent arena: header + sections addressed by byte offsets,
@@ -178,8 +199,9 @@ int prof_begin(Prof pf, hipStream_t s, const char *stage);
 void prof_end(Prof pf, hipStream_t s, int span);
 int prof_collect(zkr_key *k, ProofSlot &sl);
 struct NttTables { const Fr *tw, *tw29, *twl29; int tlog; };  // x 2^256 powers of w_{2m} (coset factors); x 2^261 powers for the butterflies (kernels_ntt.hpp)
+int ntt_lds_check(int device);  // ZKR_ERR_NO_DEVICE with a clear message when the device cannot hold an NTT tile in LDS
 int ntt_tables29_build(const Fr *tw, uint32_t n_tw, const Fr *twl, uint32_t n_twl, hipStream_t s, Fr **tw29, Fr **twl29);
-int run_ntt(hipStream_t s, const Fr *in0, const Fr *in1, Fr *out, const NttTables &tb, int L, bool dif, bool inverse, int pre, int nbat = 1);
+int run_ntt(hipStream_t s, const Fr *in0, const Fr *in1, Fr *out, const NttTables &tb, int L, bool dif, bool inverse, int pre, int nbat, Prof pf);
 int calc_h_device(zkr_key *k, ProofSlot &sl, hipStream_t s, int nbat = 1);  // sl.d_w -> sl.d_h (bit-reversed), nbat vectors end to end
 int fused_capacity(const ArenaHeader &h, const MsmPlan plan[N_TABLES]);
 MsmPlan msm_plan(size_t n_scalars, size_t n_points, int c_fixed = 0);

@@ -9,6 +9,7 @@
 #include "kernels_msm.hpp"
 #include "kernels_ntt.hpp"
 #include "hostops.hpp"
+#include "pairing.hpp"  // the curve equations (g1_on_curve / g2_on_curve constants) for ZKR_CHECK_POINTS
 #include "zkr_internal.hpp"
 
 namespace zkr {
@@ -151,6 +152,7 @@ void msm_ws_free(MsmWorkspace &ws) {
 
 int key_alloc_workspace(zkr_key *k) {
   ZKR_HIP_CHECK(hipSetDevice(k->device));
+  if (int lrc = ntt_lds_check(k->device)) return lrc;
   const ArenaHeader &h = k->h;
   // The accumulation stream is the bulk; preparation and reduction chains are short dependent launches whose
   // delay stalls it (the next sort, the proof's completion), so their workgroups are dispatched first.
@@ -219,19 +221,53 @@ int radix_convert(int device, bool g2, void *d_points, size_t count, bool to261)
 
 // Level 0 of the table (n points, the key's wire form: coordinates x 2^256) is in place: fills levels 1..K-1 and rewrites
 // level 0, all in the radix of the accumulation kernels (x 2^261, canonical; kernels_msm.hpp header).
+// ZKR_CHECK_POINTS=1: every base point of a table (wire form, x 2^256) satisfies its curve's equation y^2 = x^3 + b before
+// anything is derived from it.  Off by default, as in the reference (websnark multiplies whatever the key holds): a point off
+// the curve makes the window-table build produce garbage multiples silently (its doubling chain may hit Y = 0).
+template <class F>
+static __global__ void on_curve_kernel(const Affine<F> *pts, uint32_t n, F b, uint32_t *bad) {  // bad[0] = count, bad[1] = smallest index
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Affine<F> p = load_pod(pts + i);
+  if (p.is_inf()) return;  // placeholder of a shared-support table
+  if (sqr(p.y) == add(mul(sqr(p.x), p.x), b)) return;
+  atomicAdd(&bad[0], 1u);
+  atomicMin(&bad[1], i);
+}
+static int check_points_on_curve(bool g2, const void *d_table, uint32_t n) {
+  DevBuf buf;
+  int rc = buf.alloc(8);
+  if (rc) return rc;
+  const uint32_t init[2] = {0u, 0xffffffffu};
+  ZKR_HIP_CHECK(hipMemcpy(buf.p, init, 8, hipMemcpyHostToDevice));
+  const unsigned grid = (n + 255) / 256;
+  if (g2) on_curve_kernel<Fq2><<<grid, 256>>>((const G2Affine *)d_table, n, Fq2{pairing::fq_from_limbs(pairing::TWIST_B0), pairing::fq_from_limbs(pairing::TWIST_B1)}, buf.as<uint32_t>());
+  else on_curve_kernel<Fq><<<grid, 256>>>((const G1Affine *)d_table, n, pairing::fq_small(3), buf.as<uint32_t>());
+  ZKR_HIP_CHECK(hipGetLastError());
+  uint32_t bad[2];
+  ZKR_HIP_CHECK(hipMemcpy(bad, buf.p, 8, hipMemcpyDeviceToHost));
+  if (bad[0]) {
+    set_error("%u point(s) of a %s table are not on the curve (first: kept point %u); ZKR_CHECK_POINTS=1", bad[0], g2 ? "G2" : "G1", bad[1]);
+    return ZKR_ERR_BAD_KEY;
+  }
+  return 0;
+}
+
 int msm_precompute(int device, bool g2, void *d_table, uint32_t n, const MsmPlan &pl) {
   if (n == 0) return 0;
   ZKR_HIP_CHECK(hipSetDevice(device));
+  if (const char *e = getenv("ZKR_CHECK_POINTS"); e && atoi(e) != 0)
+    if (int crc = check_points_on_curve(g2, d_table, n)) return crc;
   if (pl.K < 2) return radix_convert(device, g2, d_table, (size_t)n, true);
   const int levels = pl.K - 1 < PRE_LEVELS ? pl.K - 1 : PRE_LEVELS;
-  void *ztmp = nullptr;  // denominators of one chunk of levels (msm_precompute_kernel)
-  ZKR_HIP_CHECK(hipMalloc(&ztmp, (size_t)n * levels * (g2 ? sizeof(Fq2) : sizeof(Fq))));
+  DevBuf zbuf;  // denominators of one chunk of levels (msm_precompute_kernel)
+  if (int arc = zbuf.alloc((size_t)n * levels * (g2 ? sizeof(Fq2) : sizeof(Fq)))) return arc;
+  void *ztmp = zbuf.p;
   unsigned grid = (n + MSM_THREADS - 1) / MSM_THREADS;
   if (g2) msm_precompute_kernel<Fq2, 1><<<grid, MSM_THREADS>>>((G2Affine *)d_table, n, pl.c, pl.K, (Fq2 *)ztmp);
   else msm_precompute_kernel<Fq, 2><<<grid, MSM_THREADS>>>((G1Affine *)d_table, n, pl.c, pl.K, (Fq *)ztmp);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipDeviceSynchronize();
-  hipFree(ztmp);
   if (e != hipSuccess) { set_error("window-table build failed: %s", hipGetErrorString(e)); return ZKR_ERR_HIP; }
   return 0;
 }
@@ -307,6 +343,7 @@ int key_build(int device, uint32_t n, uint32_t p, uint32_t m, const std::vector<
 
   unsigned char *arena = nullptr;
   ZKR_HIP_CHECK(hipMalloc(&arena, off));
+  ZKR_HIP_CHECK(hipMemset(arena, 0, off));  // alignment gaps and slack bytes are part of the arena's bytes (replicas, packed key files): defined, not stale
   ZKR_HIP_CHECK(hipMemcpy(arena, &h, sizeof(h), hipMemcpyHostToDevice));
   for (int s = 0; s < 2; s++) {
     ZKR_HIP_CHECK(hipMemcpy(arena + h.off_rowptr[s], rowptr[s].data(), rowptr[s].size() * 4, hipMemcpyHostToDevice));
@@ -712,8 +749,25 @@ int zkr_key_adopt_base_arena(const void *dev_ptr, size_t len, int device, zkr_ke
     h.off_rank[t] = take((size_t)(t == T_H ? h.m : h.n) * 4 + 4);
   }
   h.total_len = off;
+  // every section of the compact form lies inside the bytes handed over (a truncated or edited header must not drive the copies)
+  {
+    if (h.logm > 27 || h.m != (1u << h.logm) || h.n == 0 || h.p >= h.n) { set_error("compact arena: inconsistent sizes"); return ZKR_ERR_BAD_KEY; }
+    auto inside = [&](uint64_t o, uint64_t bytes) { return o >= ARENA_HEADER_BYTES && o <= len && bytes <= len - o; };
+    bool ok = true;
+    for (int s = 0; s < 2 && ok; s++) {
+      const uint64_t nnz = s == 0 ? h.nnzA : h.nnzB;
+      ok = h.n_wide[s] <= h.m && inside(b.off_rowptr[s], ((uint64_t)h.m + 1) * 4) && inside(b.off_col[s], nnz * 4) && inside(b.off_coef[s], nnz * 32) &&
+           inside(b.off_wide[s], (uint64_t)h.n_wide[s] * 4);
+    }
+    for (int t = 0; t < N_TABLES && ok; t++) {
+      const uint64_t nsc = t == T_H ? h.m : h.n;
+      ok = h.npts[t] <= nsc && inside(b.off_pts[t], (uint64_t)h.npts[t] * (t == T_B2 ? 128 : 64)) && inside(b.off_rank[t], nsc * 4);
+    }
+    if (!ok) { set_error("compact arena: a section lies outside the %zu bytes handed over", len); return ZKR_ERR_BAD_KEY; }
+  }
   unsigned char *arena = nullptr;
   ZKR_HIP_CHECK(hipMalloc(&arena, off));
+  if (hipMemset(arena, 0, off) != hipSuccess) { hipFree(arena); set_error("hipMemset failed"); return ZKR_ERR_HIP; }  // as key_build: gaps and slack are defined bytes
   const unsigned char *src = (const unsigned char *)dev_ptr;
   auto cp = [&](uint64_t dst, uint64_t from, size_t bytes) { return bytes ? hipMemcpy(arena + dst, src + from, bytes, hipMemcpyDeviceToDevice) : hipSuccess; };
   hipError_t e = hipMemcpy(arena, &h, sizeof(h), hipMemcpyHostToDevice);

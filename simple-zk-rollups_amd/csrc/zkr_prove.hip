@@ -21,7 +21,8 @@ void msm_ws_free(MsmWorkspace &ws);
 Fr host_root_of_unity(unsigned k);
 
 // ------------------------------------------------------------------ profiling (hipEvents on the launch stream)
-static const char *STAGES[] = {"ingest", "spmv", "ntt", "msm_sort", "msm_accum_g1", "msm_accum_g2", "msm_big", "msm_reduce", "total"};
+static const char *STAGES[] = {"ingest", "spmv", "ntt", "msm_sort", "msm_accum_g1", "msm_accum_g2", "msm_big", "msm_reduce", "total",
+                               "spmv_a", "ntt_pass", "combine_h"};  // the streaming kernels one by one (bench.py roofline.streaming): one QAP side, one NTT pass, the h combination
 static int stage_index(const char *name) {
   for (int i = 0; i < (int)(sizeof(STAGES) / sizeof(STAGES[0])); i++)
     if (!strcmp(STAGES[i], name)) return i;
@@ -92,16 +93,33 @@ static std::vector<PassSpec> ntt_plan(int L) {
 // the butterflies' twiddle tables (x 2^261, one entry more than the x 2^256 tables they are made from; kernels_ntt.hpp)
 int ntt_tables29_build(const Fr *tw, uint32_t n_tw, const Fr *twl, uint32_t n_twl, hipStream_t s, Fr **tw29, Fr **twl29) {
   *tw29 = *twl29 = nullptr;
-  ZKR_HIP_CHECK(hipMalloc(tw29, ((size_t)n_tw + 1) * 32));
-  ZKR_HIP_CHECK(hipMalloc(twl29, ((size_t)n_twl + 1) * 32));
-  twiddle261_kernel<<<(n_tw + 256) / 256, 256, 0, s>>>(tw, n_tw, *tw29);
-  twiddle261_kernel<<<(n_twl + 256) / 256, 256, 0, s>>>(twl, n_twl, *twl29);
+  DevBuf a, b;
+  int rc;
+  if ((rc = a.alloc(((size_t)n_tw + 1) * 32)) || (rc = b.alloc(((size_t)n_twl + 1) * 32))) return rc;
+  twiddle261_kernel<<<(n_tw + 256) / 256, 256, 0, s>>>(tw, n_tw, a.as<Fr>());
+  twiddle261_kernel<<<(n_twl + 256) / 256, 256, 0, s>>>(twl, n_twl, b.as<Fr>());
   ZKR_HIP_CHECK(hipGetLastError());
   ZKR_HIP_CHECK(hipStreamSynchronize(s));  // the proving streams are non-blocking: they do not order themselves after this one
+  *tw29 = (Fr *)a.release();
+  *twl29 = (Fr *)b.release();
   return 0;
 }
 
-int run_ntt(hipStream_t s, const Fr *in0, const Fr *in1, Fr *out, const NttTables &tb, int L, bool dif, bool inverse, int pre, int nbat) {
+// An NTT pass keeps a tile of 2^NTT_TILE_LOG elements x 9 limbs in LDS: 72 KB, above the 64 KB every target before gfx950
+// offers.  Asked once per device, so that another architecture (the Makefile's ARCH can be overridden) fails at key load / in
+// zkr_ntt with this message instead of a generic launch error deep inside a proof.
+int ntt_lds_check(int device) {
+  int lds = 0;
+  ZKR_HIP_CHECK(hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device));
+  const int need = 36 << NTT_TILE_LOG;
+  if (lds < need) {
+    set_error("device %d offers %d bytes of LDS per workgroup, the NTT passes need %d (built for gfx950: 160 KB per CU)", device, lds, need);
+    return ZKR_ERR_NO_DEVICE;
+  }
+  return 0;
+}
+
+int run_ntt(hipStream_t s, const Fr *in0, const Fr *in1, Fr *out, const NttTables &tb, int L, bool dif, bool inverse, int pre, int nbat, Prof pf) {
   std::vector<PassSpec> plan = ntt_plan(L);
   if (!dif) std::reverse(plan.begin(), plan.end());
   bool first = true;
@@ -128,7 +146,9 @@ int run_ntt(hipStream_t s, const Fr *in0, const Fr *in1, Fr *out, const NttTable
 #define ZKR_NTT_LAUNCH(DIF, INV, T) ntt_pass_kernel<DIF, INV, T><<<dim3(grid, nbat), T, lds, s>>>(a)
 #define ZKR_NTT_LAUNCH_T(T) do { if (dif) { if (inverse) ZKR_NTT_LAUNCH(true, true, T); else ZKR_NTT_LAUNCH(true, false, T); } \
                                  else { if (inverse) ZKR_NTT_LAUNCH(false, true, T); else ZKR_NTT_LAUNCH(false, false, T); } } while (0)
+    const int psp = prof_begin(pf, s, "ntt_pass");
     if (threads == NTT_THREADS_SMALL) ZKR_NTT_LAUNCH_T(NTT_THREADS_SMALL); else ZKR_NTT_LAUNCH_T(NTT_THREADS_LARGE);
+    prof_end(pf, s, psp);
 #undef ZKR_NTT_LAUNCH_T
 #undef ZKR_NTT_LAUNCH
     first = false;
@@ -158,20 +178,22 @@ int calc_h_device(zkr_key *k, ProofSlot &sl, hipStream_t s, int nbat) {
   for (int i = 0; i < 2; i++) {
     const uint32_t *rp = (const uint32_t *)(ar + h.off_rowptr[i]), *cl = (const uint32_t *)(ar + h.off_col[i]);
     const Fr *cf = (const Fr *)(ar + h.off_coef[i]);
+    const int sa = i == 0 ? prof_begin(pf, s, "spmv_a") : -1;
     spmv_kernel<<<dim3((m + 255) / 256, nbat), 256, 0, s>>>(rp, cl, cf, sl.d_w, evals[i], m, h.n);
+    prof_end(pf, s, sa);
     if (h.n_wide[i]) spmv_wide_kernel<<<dim3(h.n_wide[i], nbat), 64, 0, s>>>(rp, cl, cf, sl.d_w, evals[i], (const uint32_t *)(ar + h.off_wide[i]), h.n_wide[i], m, h.n);
   }
   prof_end(pf, s, sp);
   sp = prof_begin(pf, s, "ntt");
   int rc;
   // coefficients (x m, bit-reversed), then evaluations on the coset g*w^c (x m, natural)
-  if ((rc = run_ntt(s, sl.va, nullptr, sl.ca, tb, L, true, true, PRE_NONE, nbat))) return rc;
-  if ((rc = run_ntt(s, sl.vb, nullptr, sl.cb, tb, L, true, true, PRE_NONE, nbat))) return rc;
-  if ((rc = run_ntt(s, sl.ca, nullptr, sl.ca, tb, L, false, false, PRE_COSET, nbat))) return rc;
-  if ((rc = run_ntt(s, sl.cb, nullptr, sl.cb, tb, L, false, false, PRE_COSET, nbat))) return rc;
+  if ((rc = run_ntt(s, sl.va, nullptr, sl.ca, tb, L, true, true, PRE_NONE, nbat, pf))) return rc;
+  if ((rc = run_ntt(s, sl.vb, nullptr, sl.cb, tb, L, true, true, PRE_NONE, nbat, pf))) return rc;
+  if ((rc = run_ntt(s, sl.ca, nullptr, sl.ca, tb, L, false, false, PRE_COSET, nbat, pf))) return rc;
+  if ((rc = run_ntt(s, sl.cb, nullptr, sl.cb, tb, L, false, false, PRE_COSET, nbat, pf))) return rc;
   // D' = iNTT(A(gw^c).B(gw^c)) and S' = iNTT(a.b), both unscaled and bit-reversed
-  if ((rc = run_ntt(s, sl.ca, sl.cb, sl.ca, tb, L, true, true, PRE_MUL, nbat))) return rc;
-  if ((rc = run_ntt(s, sl.va, sl.vb, sl.va, tb, L, true, true, PRE_MUL, nbat))) return rc;
+  if ((rc = run_ntt(s, sl.ca, sl.cb, sl.ca, tb, L, true, true, PRE_MUL, nbat, pf))) return rc;
+  if ((rc = run_ntt(s, sl.va, sl.vb, sl.va, tb, L, true, true, PRE_MUL, nbat, pf))) return rc;
   // constants: S' = m S / R, D' = m^3 D g^i / R  ->  h = S'*R^2/(2m) (*1/R)  -  D' g^-i * R^2/(2 m^3) (*1/R)
   Fr r2 = Fr::r2();
   Fr minv = inv(to_mont(fr_from_u64(m)));        // Montgomery(1/m)
@@ -180,7 +202,9 @@ int calc_h_device(zkr_key *k, ProofSlot &sl, hipStream_t s, int nbat) {
   // r2 is the integer R^2 mod r = Montgomery(R).  mul(r2, half) = Montgomery(R/2); times minv = Montgomery(R/(2m)).
   // We need the plain integer R^2/(2m) = Montgomery(R/(2m)) exactly, so c1v is already the constant to pass.
   Fr c2v = mul(mul(c1v, minv), minv);            // Montgomery(R/(2m^3)) = integer R^2/(2m^3)
+  const int csp = prof_begin(pf, s, "combine_h");
   combine_h_kernel<<<dim3((m + 255) / 256, nbat), 256, 0, s>>>(sl.va, sl.ca, sl.d_h, tw, tlog, L, c1v, c2v);
+  prof_end(pf, s, csp);
   prof_end(pf, s, sp);
   ZKR_HIP_CHECK(hipGetLastError());
   return 0;
@@ -881,8 +905,8 @@ int zkr_calc_h(zkr_key *key, const void *witness_std, size_t witness_len, void *
   // the raw witness lands in sl.d_h (m x 32 B, written only by the last kernel of calcH, after ingest has read it) when
   // it fits -- n <= m for every key this library builds -- and in a temporary otherwise
   Fr *raw = sl.d_h;
-  Fr *tmp = nullptr;
-  if (key->h.n > key->h.m) { ZKR_HIP_CHECK(hipMalloc(&tmp, witness_len)); raw = tmp; }
+  DevBuf tmp;
+  if (key->h.n > key->h.m) { if (int arc = tmp.alloc(witness_len)) return arc; raw = tmp.as<Fr>(); }
   ZKR_HIP_CHECK(hipMemcpyAsync(raw, witness_std, witness_len, hipMemcpyHostToDevice, s));
   ingest_kernel<<<(key->h.n + 255) / 256, 256, 0, s>>>(raw, sl.d_w, key->h.n);
   int rc = calc_h_device(key, sl, s, 1);
@@ -890,7 +914,6 @@ int zkr_calc_h(zkr_key *key, const void *witness_std, size_t witness_len, void *
   bitrev_copy_kernel<<<(key->h.m + 255) / 256, 256, 0, s>>>(sl.d_h, sl.ca, (int)key->h.logm);
   ZKR_HIP_CHECK(hipMemcpyAsync(h_out, sl.ca, (size_t)key->h.m * 32, hipMemcpyDeviceToHost, s));
   ZKR_HIP_CHECK(hipStreamSynchronize(s));
-  if (tmp) hipFree(tmp);
   if (key->prof_on) prof_collect(key, sl);
   return 0;
 }
@@ -899,27 +922,26 @@ int zkr_ntt(void *data_std, unsigned logn, int inverse, int device) {
   if (!data_std || logn < 1 || logn > 27) { set_error("bad argument"); return ZKR_ERR_ARG; }
   if (zkr_device_count() <= device || device < 0) { set_error("no HIP device %d; libzkr_hip has no CPU fallback", device); return ZKR_ERR_NO_DEVICE; }
   ZKR_HIP_CHECK(hipSetDevice(device));
+  if (int lrc = ntt_lds_check(device)) return lrc;
   size_t n = (size_t)1 << logn;
-  Fr *d = nullptr, *d2 = nullptr, *tw = nullptr, *twl = nullptr;
-  ZKR_HIP_CHECK(hipMalloc(&d, n * 32));
-  ZKR_HIP_CHECK(hipMalloc(&d2, n * 32));
-  ZKR_HIP_CHECK(hipMalloc(&tw, n * 32));
-  ZKR_HIP_CHECK(hipMalloc(&twl, (size_t)(1u << TWL_LOG) * 32));
+  DevBuf bd, bd2, btw, btwl, btw29, btwl29;
+  int rc;
+  if ((rc = bd.alloc(n * 32)) || (rc = bd2.alloc(n * 32)) || (rc = btw.alloc(n * 32)) || (rc = btwl.alloc((size_t)(1u << TWL_LOG) * 32))) return rc;
+  Fr *d = bd.as<Fr>(), *d2 = bd2.as<Fr>(), *tw = btw.as<Fr>(), *twl = btwl.as<Fr>();
   ZKR_HIP_CHECK(hipMemcpy(d, data_std, n * 32, hipMemcpyHostToDevice));
   ingest_kernel<<<(unsigned)((n + 255) / 256), 256>>>(d, d, n);  // any 256-bit word -> below r, as the proving path does with witnesses: the passes state bounds on what they load
   twiddle_table_kernel<<<(unsigned)((n + 255) / 256), 256>>>(tw, (uint32_t)n, host_root_of_unity(logn + 1));
   twiddle_table_kernel<<<((1u << TWL_LOG) + 255) / 256, 256>>>(twl, 1u << TWL_LOG, host_root_of_unity(TWL_LOG + 1));
   Fr *tw29 = nullptr, *twl29 = nullptr;
-  int rc = ntt_tables29_build(tw, (uint32_t)n, twl, 1u << TWL_LOG, nullptr, &tw29, &twl29);
-  if (!rc) rc = run_ntt(nullptr, d, nullptr, d, NttTables{tw, tw29, twl29, (int)logn}, (int)logn, true, inverse != 0, PRE_NONE);  // natural -> bit-reversed
+  rc = ntt_tables29_build(tw, (uint32_t)n, twl, 1u << TWL_LOG, nullptr, &tw29, &twl29);
+  btw29.p = tw29; btwl29.p = twl29;
+  if (!rc) rc = run_ntt(nullptr, d, nullptr, d, NttTables{tw, tw29, twl29, (int)logn}, (int)logn, true, inverse != 0, PRE_NONE, 1, Prof{nullptr, nullptr});  // natural -> bit-reversed
   if (!rc) {
     bitrev_copy_kernel<<<(unsigned)((n + 255) / 256), 256>>>(d, d2, (int)logn);
     if (inverse) scale_kernel<<<(unsigned)((n + 255) / 256), 256>>>(d2, n, inv(to_mont(fr_from_u64(n))));
     hipError_t e = hipMemcpy(data_std, d2, n * 32, hipMemcpyDeviceToHost);
     if (e != hipSuccess) { set_error("copy back failed: %s", hipGetErrorString(e)); rc = ZKR_ERR_HIP; }
   }
-  hipFree(tw29); hipFree(twl29);
-  hipFree(d); hipFree(d2); hipFree(tw); hipFree(twl);
   return rc;
 }
 
@@ -945,30 +967,28 @@ static int msm_hook(const void *points_mont, const void *scalars_std, size_t n, 
   XYZZ<F> res = XYZZ<F>::inf();
   if (np) {
     MsmPlan pl = msm_plan(n, np);
-    MsmWorkspace ws;
+    struct WsGuard {  // the sort / bucket workspace goes with the scope as well
+      MsmWorkspace ws;
+      ~WsGuard() { msm_ws_free(ws); }
+    } g;
+    MsmWorkspace &ws = g.ws;
     int rc = msm_ws_alloc(ws, np, pl, sizeof(XYZZ<F>));
     if (rc) return rc;
-    Affine<F> *d_pts = nullptr;
-    uint32_t *d_rank = nullptr;
-    Fr *d_sc = nullptr, *d_sc2 = nullptr;
-    ZKR_HIP_CHECK(hipMalloc(&d_pts, compact.size() * pl.K));  // K window levels
-    ZKR_HIP_CHECK(hipMalloc(&d_rank, n * 4));
-    ZKR_HIP_CHECK(hipMalloc(&d_sc, n * 32));
-    ZKR_HIP_CHECK(hipMalloc(&d_sc2, n * 32));
+    DevBuf bpts, brank, bsc, bsc2;
+    if ((rc = bpts.alloc(compact.size() * pl.K)) || (rc = brank.alloc(n * 4)) || (rc = bsc.alloc(n * 32)) || (rc = bsc2.alloc(n * 32))) return rc;  // K window levels
+    Affine<F> *d_pts = bpts.as<Affine<F>>();
+    uint32_t *d_rank = brank.as<uint32_t>();
+    Fr *d_sc = bsc.as<Fr>(), *d_sc2 = bsc2.as<Fr>();
     ZKR_HIP_CHECK(hipMemcpy(d_pts, compact.data(), compact.size(), hipMemcpyHostToDevice));
     ZKR_HIP_CHECK(hipMemcpy(d_rank, rank.data(), n * 4, hipMemcpyHostToDevice));
     ZKR_HIP_CHECK(hipMemcpy(d_sc, scalars_std, n * 32, hipMemcpyHostToDevice));
     if ((rc = msm_precompute(device, sizeof(F) != 32, d_pts, np, pl))) return rc;
     ingest_kernel<<<(unsigned)((n + 255) / 256), 256>>>(d_sc, d_sc2, n);
     rc = msm_enqueue<F>(Prof{nullptr, nullptr}, nullptr, d_pts, d_rank, d_sc2, (uint32_t)n, np, pl, ws);
-    if (!rc) {
-      hipError_t e = hipDeviceSynchronize();
-      if (e != hipSuccess) { set_error("msm failed: %s", hipGetErrorString(e)); rc = ZKR_ERR_HIP; }
-    }
-    if (!rc) res = msm_finish<F>(np, ws);
-    hipFree(d_pts); hipFree(d_rank); hipFree(d_sc); hipFree(d_sc2);
-    msm_ws_free(ws);
+    hipError_t e = hipDeviceSynchronize();  // also after a failed enqueue: nothing may still run on buffers that are about to go
+    if (!rc && e != hipSuccess) { set_error("msm failed: %s", hipGetErrorString(e)); rc = ZKR_ERR_HIP; }
     if (rc) return rc;
+    res = msm_finish<F>(np, ws);
   }
   *is_inf = res.is_inf() ? 1 : 0;
   memset(out, 0, pb);
@@ -1016,28 +1036,25 @@ static int bench_fq_mul(int device, double *gmuls_per_s, int legacy) {
   ZKR_HIP_CHECK(hipSetDevice(device));
   const unsigned blocks = 256 * 8, iters = 2048;
   size_t nthreads = (size_t)blocks * MSM_THREADS;
-  Fq *d = nullptr;
-  ZKR_HIP_CHECK(hipMalloc(&d, nthreads * 32));
+  DevBuf buf;
+  ScopedEvent ev0, ev1;
+  int rc;
+  if ((rc = buf.alloc(nthreads * 32)) || (rc = ev0.create()) || (rc = ev1.create())) return rc;
+  Fq *d = buf.as<Fq>();
   std::vector<uint32_t> init(nthreads * 8);
   for (size_t i = 0; i < init.size(); i++) init[i] = (uint32_t)(i * 2654435761u) & ((i & 7) == 7 ? 0x0fffffffu : 0xffffffffu);
   ZKR_HIP_CHECK(hipMemcpy(d, init.data(), nthreads * 32, hipMemcpyHostToDevice));
-  hipEvent_t e0, e1;
-  hipEventCreate(&e0);
-  hipEventCreate(&e1);
   fq_mul_bench_kernel<<<blocks, MSM_THREADS>>>(d, 256, legacy);  // warm up: brings the clock up under this load
   float ms = 0;
   for (int rep = 0; rep < 3; rep++) {  // best of three ~30 ms launches: a single short launch scatters by +-4 % with the clock ramp
-    hipEventRecord(e0, nullptr);
+    ZKR_HIP_CHECK(hipEventRecord(ev0.e, nullptr));
     fq_mul_bench_kernel<<<blocks, MSM_THREADS>>>(d, (int)iters, legacy);
-    hipEventRecord(e1, nullptr);
-    if (hipEventSynchronize(e1) != hipSuccess) { hipEventDestroy(e0); hipEventDestroy(e1); hipFree(d); set_error("HIP failure in the multiplier microbenchmark"); return ZKR_ERR_HIP; }
+    ZKR_HIP_CHECK(hipEventRecord(ev1.e, nullptr));
+    ZKR_HIP_CHECK(hipEventSynchronize(ev1.e));
     float t = 0;
-    hipEventElapsedTime(&t, e0, e1);
+    ZKR_HIP_CHECK(hipEventElapsedTime(&t, ev0.e, ev1.e));
     if (rep == 0 || t < ms) ms = t;
   }
-  hipEventDestroy(e0);
-  hipEventDestroy(e1);
-  hipFree(d);
   *gmuls_per_s = (double)nthreads * iters * 4 / (ms * 1e-3) / 1e9;
   return 0;
 }

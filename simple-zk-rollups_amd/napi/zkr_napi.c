@@ -286,17 +286,23 @@ static napi_value js_prove(napi_env env, napi_callback_info info) {
 typedef struct {
   napi_async_work work;
   napi_deferred deferred;
-  napi_ref key_ref, wits_ref;
+  napi_ref key_ref;
+  napi_ref *wit_refs;  /* one strong reference per witness buffer: the worker reads their memory, whatever the caller does to the array meanwhile */
   zkr_key *key;
   const void **wits;
-  size_t count, wit_len;
+  size_t count, wit_len, n_refs;
   uint8_t *rs, *ss, *proofs;
   int rc;
   char err[512];
 } batch_job;
 
-static void batch_free(batch_job *j) {
-  free(j->wits); free(j->rs); free(j->ss); free(j->proofs); free(j);
+/* everything a job holds, on the JS thread (references need the env); safe on a partly built job */
+static void batch_free(napi_env env, batch_job *j) {
+  if (!j) return;
+  if (j->key_ref) napi_delete_reference(env, j->key_ref);
+  for (size_t i = 0; i < j->n_refs; i++) napi_delete_reference(env, j->wit_refs[i]);
+  if (j->work) napi_delete_async_work(env, j->work);
+  free(j->wit_refs); free(j->wits); free(j->rs); free(j->ss); free(j->proofs); free(j);
 }
 static void batch_execute(napi_env env, void *data) {
   (void)env;
@@ -317,10 +323,11 @@ static void batch_complete(napi_env env, napi_status status, void *data) {
     napi_create_error(env, NULL, msg, &v);
     napi_reject_deferred(env, j->deferred, v);
   }
-  napi_delete_reference(env, j->key_ref);
-  napi_delete_reference(env, j->wits_ref);
-  napi_delete_async_work(env, j->work);
-  batch_free(j);
+  batch_free(env, j);
+}
+static int is_nullish(napi_env env, napi_value v) {
+  napi_valuetype t;
+  return napi_typeof(env, v, &t) == napi_ok && (t == napi_undefined || t == napi_null);
 }
 static napi_value js_prove_batch(napi_env env, napi_callback_info info) {
   size_t argc = 4;
@@ -329,38 +336,53 @@ static napi_value js_prove_batch(napi_env env, napi_callback_info info) {
   if (!Z.handle) return throw_msg(env, "libzkr_hip.so not loaded");
   if (argc < 2) return throw_msg(env, "proveBatch(key, witnessBins, rs, ss)");
   batch_job *j = (batch_job *)calloc(1, sizeof(batch_job));
+  if (!j) return throw_msg(env, "proveBatch: out of memory");
   uint32_t count = 0;
   if (napi_get_value_external(env, argv[0], (void **)&j->key) != napi_ok || napi_get_array_length(env, argv[1], &count) != napi_ok || count == 0) {
-    free(j);
+    batch_free(env, j);
     return throw_msg(env, "proveBatch: a key and a non-empty array of witness buffers expected");
   }
   j->count = count;
   j->wits = (const void **)calloc(count, sizeof(void *));
+  j->wit_refs = (napi_ref *)calloc(count, sizeof(napi_ref));
   j->proofs = (uint8_t *)malloc(256 * (size_t)count);
+  if (!j->wits || !j->wit_refs || !j->proofs) { batch_free(env, j); return throw_msg(env, "proveBatch: out of memory"); }
   for (uint32_t i = 0; i < count; i++) {
     napi_value w;
     const uint8_t *p;
     size_t n;
     if (napi_get_element(env, argv[1], i, &w) != napi_ok || !get_bytes(env, w, &p, &n) || (i && n != j->wit_len)) {
-      batch_free(j);
+      batch_free(env, j);
       return throw_msg(env, "proveBatch: every witness must be an ArrayBuffer / Buffer / TypedArray of the same length");
     }
+    if (napi_create_reference(env, w, 1, &j->wit_refs[i]) != napi_ok) { batch_free(env, j); return throw_msg(env, "proveBatch: cannot pin a witness buffer"); }
+    j->n_refs = i + 1;  /* pinned before its pointer is kept */
     j->wits[i] = p;
     j->wit_len = n;
   }
-  const uint8_t *p; size_t n;
-  if (argc >= 4 && get_bytes(env, argv[2], &p, &n) && n == 32 * (size_t)count) {
-    j->rs = (uint8_t *)malloc(n); memcpy(j->rs, p, n);
-    if (!get_bytes(env, argv[3], &p, &n) || n != 32 * (size_t)count) { batch_free(j); return throw_msg(env, "proveBatch: rs and ss must both hold 32 bytes per proof"); }
-    j->ss = (uint8_t *)malloc(n); memcpy(j->ss, p, n);
+  /* blinding: both rs and ss (32 bytes per proof each), or neither (null / undefined / omitted: drawn per proof).  Anything
+   * else is an error -- a buffer of the wrong length must not silently turn into random blinding. */
+  const int have_rs = argc >= 3 && !is_nullish(env, argv[2]), have_ss = argc >= 4 && !is_nullish(env, argv[3]);
+  if (have_rs || have_ss) {
+    const uint8_t *pr, *ps;
+    size_t nr, ns;
+    if (!have_rs || !have_ss || !get_bytes(env, argv[2], &pr, &nr) || !get_bytes(env, argv[3], &ps, &ns) || nr != 32 * (size_t)count || ns != 32 * (size_t)count) {
+      batch_free(env, j);
+      return throw_msg(env, "proveBatch: rs and ss must both hold 32 bytes per proof (or both be null)");
+    }
+    j->rs = (uint8_t *)malloc(nr);
+    j->ss = (uint8_t *)malloc(ns);
+    if (!j->rs || !j->ss) { batch_free(env, j); return throw_msg(env, "proveBatch: out of memory"); }
+    memcpy(j->rs, pr, nr);
+    memcpy(j->ss, ps, ns);
   }
   napi_value promise, name;
-  NAPI_OK(napi_create_promise(env, &j->deferred, &promise));
-  NAPI_OK(napi_create_reference(env, argv[0], 1, &j->key_ref));
-  NAPI_OK(napi_create_reference(env, argv[1], 1, &j->wits_ref));   /* the array keeps its witness buffers alive */
-  NAPI_OK(napi_create_string_utf8(env, "zkr_prove_batch", NAPI_AUTO_LENGTH, &name));
-  NAPI_OK(napi_create_async_work(env, NULL, name, batch_execute, batch_complete, j, &j->work));
-  NAPI_OK(napi_queue_async_work(env, j->work));
+  if (napi_create_promise(env, &j->deferred, &promise) != napi_ok || napi_create_reference(env, argv[0], 1, &j->key_ref) != napi_ok ||
+      napi_create_string_utf8(env, "zkr_prove_batch", NAPI_AUTO_LENGTH, &name) != napi_ok ||
+      napi_create_async_work(env, NULL, name, batch_execute, batch_complete, j, &j->work) != napi_ok || napi_queue_async_work(env, j->work) != napi_ok) {
+    batch_free(env, j);  /* nothing was queued: the job and its references go here */
+    return throw_msg(env, "proveBatch: could not queue the proof job");
+  }
   return promise;
 }
 

@@ -5,7 +5,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ZKR_HIP_LIB") or os.path.normpath(os.path.join(_HERE, "..", "..", "csrc", "libzkr_hip.so"))  # same override as index.js
 PROOF_BYTES = 256
-STAGES = ("ingest", "spmv", "ntt", "msm_sort", "msm_accum_g1", "msm_accum_g2", "msm_big", "msm_reduce", "total")
+STAGES = ("ingest", "spmv", "ntt", "msm_sort", "msm_accum_g1", "msm_accum_g2", "msm_big", "msm_reduce", "total",
+          "spmv_a", "ntt_pass", "combine_h")   # the last three: single streaming kernels (bench.py roofline.streaming)
 _lib = None
 
 

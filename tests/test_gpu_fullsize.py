@@ -192,6 +192,37 @@ def test_batch_calls_do_not_deadlock_against_other_host_buffer_callers(mix):
         assert proof == g.proof_bytes(expect), k
 
 
+def test_off_curve_points_are_refused_when_point_checks_are_on(monkeypatch):
+    """ZKR_CHECK_POINTS=1 runs an on-curve kernel over every table's base points at key load.  A
+    provingKeyBin with ONE coordinate of one G1 point (pointsA) or of one G2 point (pointsB2) edited is refused with the
+    table and the point named; the clean buffer loads with the check on; with the check off (the default, and what the
+    reference does: websnark multiplies whatever the key holds) the edited buffer still loads."""
+    import struct
+    import zkr_hip
+    pkb, wb = zkr_hip.synth_websnark(9, 5, 0x5A4B0001, 0x5A4B00FF)
+    ptr_a, ptr_b2 = struct.unpack_from("<I", pkb, 20)[0], struct.unpack_from("<I", pkb, 28)[0]
+
+    def edited(ptr, size):
+        b = bytearray(pkb)
+        j = next(j for j in range(2, 64) if any(b[ptr + size * j:ptr + size * j + size // 2]))   # a finite point (x != 0)
+        b[ptr + size * j + size // 2] ^= 1                                                      # lowest bit of y (y.re for G2)
+        return bytes(b), j
+
+    monkeypatch.setenv("ZKR_CHECK_POINTS", "1")
+    key = zkr_hip.ProvingKey.load_websnark(pkb)
+    want = key.prove(wb, 5, 7)
+    key.close()
+    for ptr, size, group in ((ptr_a, 64, "G1"), (ptr_b2, 128, "G2")):
+        bad, j = edited(ptr, size)
+        with pytest.raises(zkr_hip.ZkrError, match="%s table are not on the curve" % group):
+            zkr_hip.ProvingKey.load_websnark(bad)
+    monkeypatch.delenv("ZKR_CHECK_POINTS")
+    bad, _ = edited(ptr_a, 64)
+    k2 = zkr_hip.ProvingKey.load_websnark(bad)          # unchecked, as in the reference: loads, and proves something else
+    assert k2.prove(wb, 5, 7) != want
+    k2.close()
+
+
 def test_websnark_buffer_path_at_2_16():
     """The reference's own data flow at the size of the real tx circuit's neighbourhood (2^17): a
     60 MB provingKeyBin in the binarify.ts layout through zkr_key_load_websnark, proof == the C oracle on the same

@@ -11,7 +11,7 @@ from bn254 import Q, R
 Q_MOD = Q
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SHIM = os.path.join(ROOT, "simple-zk-rollups_amd", "csrc", "libzkr_hostarith.so")
+SHIM = os.environ.get("ZKR_HOSTARITH_LIB") or os.path.join(ROOT, "simple-zk-rollups_amd", "csrc", "libzkr_hostarith.so")  # the sanitizer run points it at asan/
 
 
 @pytest.fixture(scope="module")

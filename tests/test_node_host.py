@@ -113,6 +113,15 @@ def test_js_batch_runs_concurrent_proofs_on_one_key(tmp_path, small_case):
         const opts = [];
         for (let i = 0; i < 6; i++) opts.push({r: (BigInt(d.r) + BigInt(i)).toString(), s: (BigInt(d.s) + BigInt(2 * i)).toString()});
         const proofs = await bn.groth16GenProofBatch([wb, wb, wb, wb, wb, wb], pb, opts);
+        // ADVICE r2: a blinding buffer of the wrong length (or only one of the two) is an error, never silently random blinding
+        const native = require('./napi/zkr_napi.node');
+        const refused = [];
+        for (const [rs, ss] of [[Buffer.alloc(32 * 5), Buffer.alloc(32 * 6)], [Buffer.alloc(32 * 6), null], [null, Buffer.alloc(32 * 6)], [Buffer.alloc(32 * 6), Buffer.alloc(7)]]) {
+          try { await native.proveBatch(bn._key, [wb, wb, wb, wb, wb, wb], rs, ss); refused.push(false); } catch (e) { refused.push(/rs and ss/.test(e.message)); }
+        }
+        if (!refused.every((x) => x)) throw new Error("a malformed blinding buffer was accepted: " + JSON.stringify(refused));
+        const drawn = await native.proveBatch(bn._key, [wb, wb], null, undefined);      // neither: drawn per proof
+        if (drawn.length !== 512 || drawn.subarray(0, 256).equals(drawn.subarray(256, 512))) throw new Error("random blinding expected");
         console.log(JSON.stringify(proofs));
       })().catch(e => { console.error(e); process.exit(1); });
     """, path).stdout
