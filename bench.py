@@ -339,6 +339,64 @@ def tx_circuit_leg(local, steps, batch=2, depth=6):
             "proofs_verified": ok}
 
 
+def facade_pipeline_leg(local, n_batches=256, chunk=32):
+    """The whole of createProofGenerator (operator/src/snarks/common.ts:10-53) for a stream of rollup batches of the
+    reference's tx circuit, every step native and overlapped: witness (`calculateWitness`, :15-17: the host builder on a pool
+    of threads, one call per batch) -> proof (`groth16GenProof`, :29: zkr_prove_batch on pageable host witnesses, fused
+    launches) -> acceptance (`isValid`, :30-34: zkr_verify_batch, one merged pairing product per chunk).  End-to-end rate over
+    n_batches distinct batches (consecutive states of one rollup), circuit inputs prepared beforehand (the operator's side:
+    signing, tree updates)."""
+    import queue
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
+    import zkr_hip
+    from zkr_hip import rollup
+    circ = rollup.RollupCircuit(2, 6)
+    key, vk_bin = zkr_hip.ProvingKey.setup_r1cs(circ.r1cs(), device=local)
+    privs = [0x5A4B1000 + 7919 * i for i in range(8)]
+    state = rollup.RollupState(circ.depth)
+    for i, pv in enumerate(privs):
+        state.deposit(i, rollup.gen_public_key(pv), 10 ** 24, 0)
+    flats = []
+    for b in range(n_batches):
+        txs = [state.transfer((2 * b + j) % 8, (2 * b + j + 3) % 8, 10 ** 15 * (j + 1) + b, 10 ** 12, privs[(2 * b + j) % 8]) for j in range(circ.batch)]
+        flats.append(circ.flatten_inputs(state.batch_inputs(txs)))
+    workers = max(2, effective_host_cores() - 2)
+    key.prove_batch([circ.calculate_witness(flats[0])] * 4)   # warm: staging buffers, fused launch plans
+    verified = [0]
+    failures = []
+    q_verify = queue.Queue()
+
+    def verifier():
+        while True:
+            item = q_verify.get()
+            if item is None:
+                return
+            proofs, pubs = item
+            if zkr_hip.verify_batch(vk_bin, proofs, pubs):
+                verified[0] += len(proofs)
+            else:
+                failures.append(len(proofs))
+
+    t0 = time.perf_counter()
+    vt = threading.Thread(target=verifier)
+    vt.start()
+    with ThreadPoolExecutor(workers) as pool:
+        futs = [pool.submit(circ.calculate_witness, f) for f in flats]          # ctypes releases the GIL inside the builder
+        for c0 in range(0, n_batches, chunk):
+            wits = [f.result() for f in futs[c0:c0 + chunk]]
+            proofs = key.prove_batch(wits)                                        # random blinding, as the reference draws it
+            q_verify.put((proofs, [circ.public_signals(w) for w in wits]))
+    q_verify.put(None)
+    vt.join()
+    el = time.perf_counter() - t0
+    key.close()
+    return {"circuit": "BatchProcessTx(2, 6) (tx.circom)", "batches": n_batches, "chunk": chunk, "witness_threads": workers,
+            "end_to_end_proofs_per_s": n_batches / el, "ms_per_batch": 1e3 * el / n_batches, "proofs_verified": verified[0],
+            "verification_failures": len(failures),
+            "steps": "witness (host builder, thread pool) -> zkr_prove_batch (host witnesses) -> zkr_verify_batch, overlapped"}
+
+
 def self_launch(n_gpus):
     """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD `python -m torch.distributed.run`
     (one process per GPU, rendezvous on 127.0.0.1 at a free port) with this command line, relay rank 0's single JSON
@@ -648,6 +706,7 @@ def main():
             out["tx_circuit"] = tx_circuit_leg(local, max(args.steps, 4))
             # the same circuit family filled up to the headline size: 18 transactions per batch = 1 008 108 constraints, 2^20 domain
             out["rollup_circuit_2_20"] = tx_circuit_leg(local, min(max(args.steps, 4), 20), batch=18, depth=6)
+            out["facade_pipeline"] = facade_pipeline_leg(local)
         print(json.dumps(out))
     if dist:
         dist.barrier()

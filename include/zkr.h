@@ -234,6 +234,18 @@ int zkr_withdraw_witness(const uint8_t private_key[32], const uint8_t nullifier[
 int zkr_rollup_info(uint32_t batch, uint32_t depth, uint32_t *n_vars, uint32_t *n_public, uint32_t *n_constraints);
 int zkr_rollup_r1cs(uint32_t batch, uint32_t depth, void **r1cs_bin, size_t *r1cs_len);
 int zkr_rollup_witness(uint32_t batch, uint32_t depth, const uint8_t *inputs, size_t n_inputs, void **witness_bin, size_t *witness_len);
+/* The same for MANY rollup batches at once, ON THE GPU (one thread per transaction): inputs = n_batches x n_inputs x 32 B
+ * (host memory), d_witnesses = device memory for n_batches x nVars x 32 B, each witness laid out as zkr_rollup_witness returns
+ * it (byte for byte) and ready for zkr_prove_batch_device -- `Circuit.calculateWitness` (operator/src/snarks/common.ts:15-17)
+ * for a queue of batches without touching the host cores.  ZKR_ERR_UNSATISFIED names the first batch / transaction /
+ * statement that fails; ZKR_ERR_ARG an input that is not below r.  No CPU fallback (ZKR_ERR_NO_DEVICE). */
+int zkr_rollup_witness_batch_device(uint32_t batch, uint32_t depth, const uint8_t *inputs, size_t n_inputs, size_t n_batches, void *d_witnesses, int device);
+/* Test hook: the program one GPU thread runs per transaction (csrc/rollup_witness.hpp), run on the HOST for one batch --
+ * witness_out = nVars x 32 B as zkr_rollup_witness lays it out, *stmt = code of the first violated statement (0: none;
+ * zkr_rollup_statement_text gives its wording), *tx = its transaction.  Lets the CPU suite compare the GPU builder's program
+ * with the host builder signal for signal. */
+int zkr_rollup_witness_program_host(uint32_t batch, uint32_t depth, const uint8_t *inputs, size_t n_inputs, uint8_t *witness_out, uint32_t *stmt, uint32_t *tx);
+const char *zkr_rollup_statement_text(uint32_t stmt);
 
 /* Integer-ALU microbenchmark: sustained Fq Montgomery multiplications per second on `device` with the multiplier of the
  * hot path (9 x 29-bit limbs, 162 multiply-adds without carry words, csrc/field29.hpp); used for the secondary (VALU)

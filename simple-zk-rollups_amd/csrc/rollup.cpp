@@ -885,6 +885,19 @@ static void *dup_bytes(const void *p, size_t n) {
 namespace zkr {
 // the 220 round constants (Montgomery form) for the device kernels of rollup_gpu.hip
 const Fr *mimc_round_constants() { return mimc().c; }
+// what the device witness builder (rollup_gpu.hip) shares with the gadget program above: curve constants, the fixed-base
+// table of scalar_mul_base8, and the geometry of the signal vector
+void rollup_device_constants(Fr *a, Fr *d, uint32_t suborder_m1[8], Fr *b8x253, Fr *b8y253) {
+  const Bj &k = bj();
+  *a = k.a;
+  *d = k.d;
+  memcpy(suborder_m1, k.suborder_m1, 32);
+  static const Base8Table tab;
+  for (int i = 0; i < 253; i++) b8x253[i] = tab.x[i], b8y253[i] = tab.y[i];
+}
+uint32_t rollup_tx_private_count(uint32_t depth) { return tx_private_count(depth); }
+uint32_t rollup_n_public(uint32_t batch, uint32_t depth) { return n_public_of(batch, depth); }
+int rollup_check_geometry(uint32_t batch, uint32_t depth) { return check_geometry(batch, depth); }
 }  // namespace zkr
 
 extern "C" {

@@ -5,11 +5,15 @@
 // (2^21 - 1 hashes of two elements) is 2.8 * 10^9 multiplications: tens of milliseconds here, minutes in the circomlib
 // BigInt code.  Host counterpart and round constants: rollup.cpp; parity against oracle/rollup.py in tests/test_gpu_rollup.py.
 #include "zkr_internal.hpp"
+#include "rollup_witness.hpp"
 
 namespace zkr {
 const Fr *mimc_round_constants();  // rollup.cpp
+void rollup_device_constants(Fr *a, Fr *d, uint32_t suborder_m1[8], Fr *b8x253, Fr *b8y253);
+uint32_t rollup_tx_private_count(uint32_t depth);
+uint32_t rollup_n_public(uint32_t batch, uint32_t depth);
+int rollup_check_geometry(uint32_t batch, uint32_t depth);
 
-constexpr int MIMC_ROUNDS = 220;
 __constant__ uint32_t c_mimc[MIMC_ROUNDS * 8];
 
 __device__ __forceinline__ Fr mimc_const(int i) {
@@ -68,6 +72,61 @@ static int upload_constants(int device) {
   if (device < 64) done[device] = true;
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------ witnesses on the GPU
+// SURVEY 8(f-3) "batch-parallel across txs on GPU": the witness of BatchProcessTx(batch, depth) for MANY rollup batches at
+// once, one thread per transaction, left in HBM for zkr_prove_batch_device.  The program below is the value side of the
+// gadget program of rollup.cpp (processtx.circom:10-193 over eddsa.circom:12-139, merkletree.circom:5-84,
+// hasher.circom:3-30): the same statements in the same order, every allocated signal written where rollup.cpp's Builder
+// puts it, so the bytes equal zkr_rollup_witness's (tests/test_gpu_rollup.py).  A transaction is ~6 * 10^4 dependent field
+// multiplications (74 MiMC permutations, two 254-step scalar multiplications): one lane takes ~35 ms for it, and the
+// transactions of all batches run side by side -- 512 of them (256 batches of tx.circom) in the time of one, where the
+// host builder needs ~13 ms of one core per batch.  Values are Montgomery while they are computed; a second kernel lays the
+// vector out as binarifyWitness does (32 B standard form per signal, operator/src/utils/binarify.ts:10-48).
+// One thread per transaction.  inputs: per batch the n_public - 1 input signals (standard form, circom's order: rollup.cpp
+// Layout); wit: the witnesses, nv signals per batch -- a transaction writes its K private signals (Montgomery for now) into its
+// slice behind the public part; roots / errs: per transaction.
+static __global__ __launch_bounds__(64) void rollup_witness_tx_kernel(const Fr *inputs, uint32_t n_batches, uint32_t batch, uint32_t depth, uint32_t K, TxConsts k,
+                                                                      Fr *wit, Fr *workspace, Fr *roots, uint32_t *errs) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_batches * batch) return;
+  const uint32_t bi = t / batch, i = t % batch;
+  const uint32_t p = tx_layout(batch, depth).p;
+  Fr root;
+  errs[t] = tx_witness(inputs + (size_t)bi * (p - 1), batch, depth, i, K, k, wit + (size_t)bi * ((size_t)p + 1 + (size_t)batch * K) + p + 1 + (size_t)i * K,
+                       workspace + (size_t)t * 4 * WS_PTS, &root);
+  roots[t] = root;
+}
+// The vector as binarifyWitness lays it out: signal 0 = 1, signal 1 = the last transaction's root, the inputs as given, the
+// private signals converted to standard form in place.  Thread per signal of every batch; the first thread of a batch also
+// checks the root chain (batchprocesstx.circom:67-69).
+static __global__ __launch_bounds__(256) void rollup_witness_layout_kernel(const Fr *inputs, uint32_t n_batches, uint32_t batch, uint32_t depth, uint32_t K,
+                                                                          const Fr *roots, Fr *wit, uint32_t *chain_errs) {
+  const uint32_t p = 1 + batch * (8 + 2 + 1 + 1 + 2 + 1 + 1 + 1 + 1 + 3 * depth);
+  const size_t nv = (size_t)p + 1 + (size_t)batch * K;
+  const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= nv * n_batches) return;
+  const size_t bi = g / nv, s = g % nv;
+  Fr v;
+  if (s == 0) {
+    v = Fr::zero();
+    v.v[0] = 1;
+    uint32_t bad = 0;  // transaction i starts from the root transaction i - 1 produced (the inputs' root array starts at signal 2)
+    for (uint32_t i = 1; i < batch && !bad; i++) {
+      Fr want;
+      tx_read_input(inputs + bi * (p - 1) + i, want);
+      if (!(roots[bi * batch + i - 1] == want)) bad = i;
+    }
+    chain_errs[bi] = bad;
+  } else if (s == 1) {
+    v = from_mont(roots[bi * batch + batch - 1]);
+  } else if (s <= p) {
+    v = inputs[bi * (p - 1) + (s - 2)];
+  } else {
+    v = from_mont(wit[g]);
+  }
+  wit[g] = v;
+}
 }  // namespace zkr
 
 using namespace zkr;
@@ -94,6 +153,96 @@ int zkr_mimcsponge_multihash_batch(const void *inputs_std, size_t count, unsigne
   if (e != hipSuccess) { set_error("batch hash failed: %s", hipGetErrorString(e)); return ZKR_ERR_HIP; }
   return ZKR_OK;
 }
+
+int zkr_rollup_witness_batch_device(uint32_t batch, uint32_t depth, const uint8_t *inputs, size_t n_inputs, size_t n_batches, void *d_witnesses, int device) {
+  if ((!inputs && n_batches) || !d_witnesses) { set_error("null argument"); return ZKR_ERR_ARG; }
+  int rc = rollup_check_geometry(batch, depth);
+  if (rc) return rc;
+  if (zkr_device_count() <= device || device < 0) { set_error("no HIP device %d; the batch witness builder runs on the GPU (zkr_rollup_witness is the host call)", device); return ZKR_ERR_NO_DEVICE; }
+  const uint32_t p = rollup_n_public(batch, depth), K = rollup_tx_private_count(depth);
+  if (n_inputs != p - 1) { set_error("rollup circuit (%u, %u) takes %u inputs, got %zu", batch, depth, p - 1, n_inputs); return ZKR_ERR_ARG; }
+  if (n_batches == 0) return ZKR_OK;
+  if (n_batches * (size_t)batch > (1u << 22)) { set_error("too many transactions in one call (%zu batches of %u)", n_batches, batch); return ZKR_ERR_ARG; }
+  ZKR_HIP_CHECK(hipSetDevice(device));
+  if ((rc = upload_constants(device))) return rc;
+  // curve constants, the fixed-base table and the round constants, once per device
+  static std::mutex mu;
+  static Fr *d_tab[64] = {nullptr};
+  TxConsts k;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    if (device >= 64) { set_error("device index out of range"); return ZKR_ERR_ARG; }
+    std::vector<Fr> tab(2 * 253 + MIMC_ROUNDS);
+    rollup_device_constants(&k.a, &k.d, k.suborder_m1, tab.data(), tab.data() + 253);
+    memcpy(tab.data() + 506, mimc_round_constants(), MIMC_ROUNDS * 32);
+    if (!d_tab[device]) {
+      Fr *d = nullptr;
+      ZKR_HIP_CHECK(hipMalloc(&d, tab.size() * 32));
+      if (hipMemcpy(d, tab.data(), tab.size() * 32, hipMemcpyHostToDevice) != hipSuccess) { hipFree(d); set_error("upload of the witness builder's tables failed"); return ZKR_ERR_HIP; }
+      d_tab[device] = d;
+    }
+  }
+  k.b8x = d_tab[device], k.b8y = d_tab[device] + 253, k.mimc = d_tab[device] + 506;
+  const size_t n_tx = n_batches * batch, nv = (size_t)p + 1 + (size_t)batch * K;
+  DevBuf b_in, b_ws, b_roots, b_errs;
+  if ((rc = b_in.alloc(n_batches * (size_t)(p - 1) * 32)) || (rc = b_ws.alloc(n_tx * 4 * WS_PTS * 32)) || (rc = b_roots.alloc(n_tx * 32)) ||
+      (rc = b_errs.alloc((n_tx + n_batches) * 4)))
+    return rc;
+  ZKR_HIP_CHECK(hipMemcpy(b_in.p, inputs, n_batches * (size_t)(p - 1) * 32, hipMemcpyHostToDevice));
+  uint32_t *d_errs = b_errs.as<uint32_t>(), *d_chain = d_errs + n_tx;
+  rollup_witness_tx_kernel<<<(unsigned)((n_tx + 63) / 64), 64>>>(b_in.as<Fr>(), (uint32_t)n_batches, batch, depth, K, k, (Fr *)d_witnesses, b_ws.as<Fr>(), b_roots.as<Fr>(), d_errs);
+  ZKR_HIP_CHECK(hipGetLastError());
+  const size_t total = nv * n_batches;
+  rollup_witness_layout_kernel<<<(unsigned)((total + 255) / 256), 256>>>(b_in.as<Fr>(), (uint32_t)n_batches, batch, depth, K, b_roots.as<Fr>(), (Fr *)d_witnesses, d_chain);
+  ZKR_HIP_CHECK(hipGetLastError());
+  std::vector<uint32_t> errs(n_tx + n_batches);
+  ZKR_HIP_CHECK(hipMemcpy(errs.data(), d_errs, errs.size() * 4, hipMemcpyDeviceToHost));  // also waits for the kernels
+  for (size_t bi = 0; bi < n_batches; bi++) {  // first violated statement in circuit order, as zkr_rollup_witness reports it
+    for (uint32_t i = 0; i < batch; i++) {
+      const uint32_t chain = errs[n_tx + bi], e = errs[bi * batch + i];
+      if (e == ST_INPUT_RANGE) { set_error("batch %zu: an input of transaction %u is not below r", bi, i); return ZKR_ERR_ARG; }
+      if (e == ST_COUNT) { set_error("internal: private signal count differs from the structure pass"); return ZKR_ERR_HIP; }
+      if (i > 0 && chain == i) { set_error("batch %zu: transaction %u violates: %s", bi, i, TX_STMT_TEXT[ST_CHAIN]); return ZKR_ERR_UNSATISFIED; }
+      if (e) { set_error("batch %zu: transaction %u violates: %s", bi, i, TX_STMT_TEXT[e < ST_COUNT ? e : 0]); return ZKR_ERR_UNSATISFIED; }
+    }
+  }
+  return ZKR_OK;
+}
+
+// The same value program run on the HOST for one batch (test hook: no device involved): witness_out = nVars x 32 B laid out as
+// zkr_rollup_witness returns it; *stmt = the first violated statement's code (0 = none), *tx its transaction.  tests/test_rollup.py
+// compares it with the host Builder byte for byte, so the program the GPU threads run is checked where no GPU exists.
+int zkr_rollup_witness_program_host(uint32_t batch, uint32_t depth, const uint8_t *inputs, size_t n_inputs, uint8_t *witness_out, uint32_t *stmt, uint32_t *tx) {
+  if (!inputs || !witness_out || !stmt || !tx) { set_error("null argument"); return ZKR_ERR_ARG; }
+  int rc = rollup_check_geometry(batch, depth);
+  if (rc) return rc;
+  const uint32_t p = rollup_n_public(batch, depth), K = rollup_tx_private_count(depth);
+  if (n_inputs != p - 1) { set_error("rollup circuit (%u, %u) takes %u inputs, got %zu", batch, depth, p - 1, n_inputs); return ZKR_ERR_ARG; }
+  std::vector<Fr> tab(2 * 253), in(p - 1), w(K), ws(4 * WS_PTS), roots(batch);
+  TxConsts k;
+  rollup_device_constants(&k.a, &k.d, k.suborder_m1, tab.data(), tab.data() + 253);
+  k.b8x = tab.data(), k.b8y = tab.data() + 253, k.mimc = mimc_round_constants();
+  memcpy(in.data(), inputs, (size_t)(p - 1) * 32);
+  Fr *out = reinterpret_cast<Fr *>(witness_out);
+  *stmt = 0, *tx = 0;
+  for (uint32_t i = 0; i < batch; i++) {
+    uint32_t e = tx_witness(in.data(), batch, depth, i, K, k, w.data(), ws.data(), &roots[i]);
+    if (i > 0) {  // the root chain comes first in circuit order (batchprocesstx.circom:67-69), as in rollup.cpp batch_witness
+      Fr want;
+      tx_read_input(&in[i], want);
+      if (!(roots[i - 1] == want)) e = ST_CHAIN;
+    }
+    if (e && !*stmt) { *stmt = e; *tx = i; }
+    for (uint32_t s = 0; s < K; s++) out[(size_t)p + 1 + (size_t)i * K + s] = from_mont(w[s]);
+  }
+  Fr one = Fr::zero();
+  one.v[0] = 1;
+  out[0] = one;
+  out[1] = from_mont(roots[batch - 1]);
+  for (uint32_t s = 2; s <= p; s++) out[s] = in[s - 2];
+  return ZKR_OK;
+}
+const char *zkr_rollup_statement_text(uint32_t stmt) { return stmt < ST_COUNT ? TX_STMT_TEXT[stmt] : ""; }
 
 int zkr_balance_tree_build(const void *leaves_std, unsigned depth, void *levels_out, int device) {
   if (!leaves_std || !levels_out || depth < 1 || depth > 28) { set_error("bad argument"); return ZKR_ERR_ARG; }

@@ -85,6 +85,10 @@ def lib():
     L.zkr_rollup_info.argtypes = [c.c_uint32, c.c_uint32, c.POINTER(c.c_uint32), c.POINTER(c.c_uint32), c.POINTER(c.c_uint32)]
     L.zkr_rollup_r1cs.argtypes = [c.c_uint32, c.c_uint32, c.POINTER(vp), c.POINTER(sz)]
     L.zkr_rollup_witness.argtypes = [c.c_uint32, c.c_uint32, u8p, sz, c.POINTER(vp), c.POINTER(sz)]
+    L.zkr_rollup_witness_batch_device.argtypes = [c.c_uint32, c.c_uint32, u8p, sz, sz, vp, c.c_int]
+    L.zkr_rollup_witness_program_host.argtypes = [c.c_uint32, c.c_uint32, u8p, sz, vp, c.POINTER(c.c_uint32), c.POINTER(c.c_uint32)]
+    L.zkr_rollup_statement_text.argtypes = [c.c_uint32]
+    L.zkr_rollup_statement_text.restype = c.c_char_p
     _lib = L
     return L
 

@@ -127,6 +127,32 @@ class RollupCircuit:
         """witness.slice(1, nPubInputs + nOutputs + 1) (common.ts:18-21)."""
         return _ints(witness_bin[32:32 * (self.n_public + 1)])
 
+    def witness_program_host(self, inputs):
+        """The GPU builder's per-transaction program (csrc/rollup_witness.hpp) run on the host for one batch (test hook):
+        (witness bytes, statement text of the first violation or None, its transaction)."""
+        flat = self.flatten_inputs(inputs) if isinstance(inputs, dict) else [int(v) for v in inputs]
+        buf = b"".join(_le(v) for v in flat)
+        out = ctypes.create_string_buffer(self.n_vars * 32)
+        stmt, tx = ctypes.c_uint32(), ctypes.c_uint32()
+        _check(lib().zkr_rollup_witness_program_host(self.batch, self.depth, buf, len(flat), out, ctypes.byref(stmt), ctypes.byref(tx)))
+        return out.raw, (lib().zkr_rollup_statement_text(stmt.value).decode() if stmt.value else None), tx.value
+
+    def calculate_witness_batch_device(self, inputs_list, device=0):
+        """calculateWitness for MANY rollup batches on the GPU (zkr_rollup_witness_batch_device: one thread per transaction):
+        a uint8 torch tensor [len(inputs_list), nVars * 32] in HBM, row i = the bytes calculate_witness(inputs_list[i])
+        returns, ready for ProvingKey.prove_batch_device([t[i].data_ptr() ...]).  Raises ZkrError(-7) naming the first batch,
+        transaction and statement that fails."""
+        import torch
+        flats = [self.flatten_inputs(x) if isinstance(x, dict) else [int(v) for v in x] for x in inputs_list]
+        for f in flats:
+            if len(f) != self.n_public - 1:
+                raise ZkrError(-5, "circuit inputs have %d values, BatchProcessTx(%d, %d) takes %d" % (len(f), self.batch, self.depth, self.n_public - 1))
+        buf = b"".join(_le(v) for f in flats for v in f)
+        out = torch.empty((len(flats), self.n_vars * 32), dtype=torch.uint8, device=torch.device("cuda", device))
+        torch.cuda.synchronize(device)
+        _check(lib().zkr_rollup_witness_batch_device(self.batch, self.depth, buf, self.n_public - 1, len(flats), out.data_ptr(), device))
+        return out
+
 
 class WithdrawCircuit:
     """Withdraw() (prover/circuits/withdraw.circom:4-25): public signals publicKey[0], publicKey[1], nullifier."""

@@ -179,3 +179,76 @@ def test_real_circuit_at_the_headline_size():
     bad = list(pub)
     bad[640] = (bad[640] + 1) % o.R
     assert not zkr_hip.verify(vk_bin, proofs[0], bad) and not zkr_hip.verify_batch(vk_bin, proofs, [pub, bad])
+
+
+def test_gpu_witness_builder_is_byte_equal_to_the_host_builder():
+    """zkr_rollup_witness_batch_device -- the witnesses of MANY rollup batches built on the GPU, one thread
+    per transaction, left in HBM -- against zkr_rollup_witness (the host gadget program, itself checked against the emitted
+    constraint system and the pinned oracle in tests/test_rollup.py): every batch byte for byte, for tx.circom's geometry
+    (2, 6), a self-send, another geometry in the same process (4 transactions, depth 3) and the committed golden batch
+    (tests/golden/rollup_tx.json); a witness taken from HBM proves to the same bytes as the host-built one."""
+    import json
+    import os
+    import zkr_hip
+    from zkr_hip import rollup as n
+    c = n.RollupCircuit(2, 6)
+    flats = []
+    for seed, self_send in ((41, False), (42, False), (43, True), (44, False), (45, False)):
+        txs, _, _ = scenario(2, 6, seed, self_send, n_accounts=5)
+        flats.append(c.flatten_inputs(as_inputs(txs)))
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rollup_tx.json")))
+    cf = n.RollupCircuit(fx["batch"], fx["depth"])             # the committed batch (decimal strings, as the reference passes them)
+    df = cf.calculate_witness_batch_device([fx["inputs"]])
+    wf = bytes(df[0].cpu().numpy().tobytes())
+    assert wf == cf.calculate_witness(fx["inputs"]) and [str(v) for v in cf.public_signals(wf)] == fx["public_signals"]
+    dev = c.calculate_witness_batch_device(flats)
+    assert tuple(dev.shape) == (len(flats), c.n_vars * 32)
+    host = [c.calculate_witness(f) for f in flats]
+    for i, wb in enumerate(host):
+        assert bytes(dev[i].cpu().numpy().tobytes()) == wb, "batch %d differs from the host builder" % i
+    c43 = n.RollupCircuit(4, 3)
+    txs, tree, _ = scenario(4, 3, 7)
+    d43 = c43.calculate_witness_batch_device([as_inputs(txs)] * 3)
+    want = c43.calculate_witness(as_inputs(txs))
+    assert all(bytes(d43[i].cpu().numpy().tobytes()) == want for i in range(3)) and ints(want)[1] == tree.root
+    key, vk_bin = zkr_hip.ProvingKey.setup_r1cs(c.r1cs())
+    got = key.prove_batch_device([dev[i].data_ptr() for i in range(3)], [5, 6, 7], [8, 9, 10])
+    assert got == [key.prove(host[i], 5 + i, 8 + i) for i in range(3)]
+    assert zkr_hip.verify_batch(vk_bin, got, [c.public_signals(host[i]) for i in range(3)])
+
+
+@pytest.mark.parametrize("what,needle", [
+    ("signature", "signature"), ("nonce", "nonce"), ("sender_path", "sender leaf"), ("recipient_leaf", "recipient leaf"),
+    ("intermediate_root", "intermediate root"), ("chain", "previous one"), ("big_s", "subgroup order"), ("index", "fits the tree")])
+def test_gpu_witness_builder_refuses_what_the_host_builder_refuses(what, needle):
+    """Where Circuit.calculateWitness throws (operator/src/snarks/common.ts:15-17): the GPU builder names the same statement as
+    the host builder, and the batch it sits in -- here the second of three."""
+    import rollup as o
+    import zkr_hip
+    from zkr_hip import rollup as n
+    c = n.RollupCircuit(2, 3)
+    good, _, _ = scenario(2, 3, 20)
+    txs, _, _ = scenario(2, 3, 21)
+    t = txs[1]
+    if what == "signature":
+        t["txData"][7] = (t["txData"][7] + 1) % o.SUBORDER
+    elif what == "nonce":
+        t["txSenderNonce"] += 1
+    elif what == "sender_path":
+        t["txSenderPathElements"][1] += 1
+    elif what == "recipient_leaf":
+        t["txRecipientBalance"] += 1
+    elif what == "intermediate_root":
+        t["intermediateBalanceTreeRoot"] += 1
+    elif what == "chain":
+        txs = [txs[0], dict(txs[0])]
+    elif what == "big_s":
+        t["txData"][7] += o.SUBORDER
+    elif what == "index":
+        t["txData"][0] += 8
+    with pytest.raises(zkr_hip.ZkrError) as eh:
+        c.calculate_witness(as_inputs(txs))
+    with pytest.raises(zkr_hip.ZkrError) as eg:
+        c.calculate_witness_batch_device([as_inputs(good), as_inputs(txs), as_inputs(good)])
+    assert eg.value.code == eh.value.code == -7 and needle in str(eg.value) and needle in str(eh.value), (str(eg.value), str(eh.value))
+    assert "batch 1: transaction 1" in str(eg.value), str(eg.value)

@@ -354,3 +354,49 @@ def test_product_alone_reproduces_the_committed_rollup_fixture():
     c = n.RollupCircuit(fx["batch"], fx["depth"])
     wb = c.calculate_witness(fx["inputs"])                      # decimal strings, as the reference passes them
     assert [str(v) for v in c.public_signals(wb)] == fx["public_signals"]
+
+
+def test_gpu_witness_program_equals_the_host_builder_signal_for_signal():
+    """csrc/rollup_witness.hpp -- the program ONE GPU THREAD runs per transaction in zkr_rollup_witness_batch_device --
+    compiled for the host and compared with the gadget program of rollup.cpp (which the tests above hold against the emitted
+    constraint system and the pinned oracle): every signal of the witness, byte for byte, for two geometries, a self-send and
+    the committed golden batch; and where the host builder refuses inputs, the program names the same statement."""
+    import rollup as o
+    from zkr_hip import rollup as n
+    for (batch, depth, seed, self_send) in ((2, 6, 41, False), (2, 6, 43, True), (4, 3, 7, False), (1, 3, 9, False)):
+        c = n.RollupCircuit(batch, depth)
+        txs, tree, _ = scenario(batch, depth, seed, self_send, n_accounts=5 if depth > 2 else 4)
+        want = c.calculate_witness(as_inputs(txs))
+        got, stmt, _tx = c.witness_program_host(as_inputs(txs))
+        assert stmt is None and got == want, (batch, depth, seed)
+        assert ints(got)[1] == tree.root
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "rollup_tx.json")))
+    c = n.RollupCircuit(fx["batch"], fx["depth"])
+    got, stmt, _tx = c.witness_program_host(fx["inputs"])
+    assert stmt is None and got == c.calculate_witness(fx["inputs"]) and [str(v) for v in c.public_signals(got)] == fx["public_signals"]
+    c = n.RollupCircuit(2, 3)
+    for what, needle in (("signature", "signature"), ("nonce", "nonce"), ("sender_path", "sender leaf"), ("recipient_leaf", "recipient leaf"),
+                         ("intermediate_root", "intermediate root"), ("chain", "previous one"), ("big_s", "subgroup order"), ("index", "fits the tree")):
+        txs, _, _ = scenario(2, 3, 21)
+        t = txs[1]
+        if what == "signature":
+            t["txData"][7] = (t["txData"][7] + 1) % o.SUBORDER
+        elif what == "nonce":
+            t["txSenderNonce"] += 1
+        elif what == "sender_path":
+            t["txSenderPathElements"][1] += 1
+        elif what == "recipient_leaf":
+            t["txRecipientBalance"] += 1
+        elif what == "intermediate_root":
+            t["intermediateBalanceTreeRoot"] += 1
+        elif what == "chain":
+            txs = [txs[0], dict(txs[0])]
+        elif what == "big_s":
+            t["txData"][7] += o.SUBORDER
+        elif what == "index":
+            t["txData"][0] += 8
+        _w, stmt, tx = c.witness_program_host(as_inputs(txs))
+        assert stmt is not None and needle in stmt and tx == 1, (what, stmt, tx)
+        with pytest.raises(Exception) as e:
+            c.calculate_witness(as_inputs(txs))
+        assert stmt in str(e.value), (what, stmt, str(e.value))

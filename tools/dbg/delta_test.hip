@@ -1,0 +1,32 @@
+// debug: delta = (p.y - a p.x)(q.x + q.y) on device vs host for q = (0, one), q = random
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../simple-zk-rollups_amd/csrc/field.hpp"
+using namespace zkr;
+__host__ __device__ static Fr delta_of(const Fr &px, const Fr &py, const Fr &qx, const Fr &qy, const Fr &a) {
+  return mul(sub(py, mul(px, a)), add(qx, qy));
+}
+__global__ void k(const Fr *in, Fr *out, int n, Fr a) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  out[i] = delta_of(in[4 * i], in[4 * i + 1], in[4 * i + 2], in[4 * i + 3], a);
+}
+int main() {
+  const int n = 256;
+  Fr h[4 * n], o[n];
+  unsigned long long st = 88172645463325252ull;
+  auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return (uint32_t)(st >> 16); };
+  Fr a = Fr::zero(); a.v[0] = 168700; a = to_mont(a);
+  for (int i = 0; i < 4 * n; i++) { for (int j = 0; j < 8; j++) h[i].v[j] = rnd(); h[i].v[7] &= 0x0fffffffu; h[i] = to_mont(h[i]); }
+  for (int i = 0; i < n; i += 2) { h[4 * i + 2] = Fr::zero(); h[4 * i + 3] = Fr::one(); }
+  Fr *d, *dout;
+  hipMalloc(&d, sizeof h); hipMalloc(&dout, sizeof o);
+  hipMemcpy(d, h, sizeof h, hipMemcpyHostToDevice);
+  k<<<1, 256>>>(d, dout, n, a);
+  hipMemcpy(o, dout, sizeof o, hipMemcpyDeviceToHost);
+  int bad = 0;
+  for (int i = 0; i < n; i++) { Fr w = delta_of(h[4 * i], h[4 * i + 1], h[4 * i + 2], h[4 * i + 3], a); if (!(w == o[i])) { if (bad < 5) printf("mismatch at %d (q %s)\n", i, i % 2 ? "random" : "(0,1)"); bad++; } }
+  printf("bad %d of %d\n", bad, n);
+  return 0;
+}
