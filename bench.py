@@ -339,13 +339,15 @@ def tx_circuit_leg(local, steps, batch=2, depth=6):
             "proofs_verified": ok}
 
 
-def facade_pipeline_leg(local, n_batches=256, chunk=32):
+def facade_pipeline_leg(local, n_batches=256, chunk=64, witness="gpu"):
     """The whole of createProofGenerator (operator/src/snarks/common.ts:10-53) for a stream of rollup batches of the
-    reference's tx circuit, every step native and overlapped: witness (`calculateWitness`, :15-17: the host builder on a pool
-    of threads, one call per batch) -> proof (`groth16GenProof`, :29: zkr_prove_batch on pageable host witnesses, fused
-    launches) -> acceptance (`isValid`, :30-34: zkr_verify_batch, one merged pairing product per chunk).  End-to-end rate over
-    n_batches distinct batches (consecutive states of one rollup), circuit inputs prepared beforehand (the operator's side:
-    signing, tree updates)."""
+    reference's tx circuit, every step native and overlapped: witness (`calculateWitness`, :15-17) -> proof
+    (`groth16GenProof`, :29) -> acceptance (`isValid`, :30-34: zkr_verify_batch, one merged pairing product per chunk).
+    witness="gpu": zkr_rollup_witness_batch_device builds a chunk's witnesses on the GPU (one thread per transaction) and
+    leaves them in HBM for zkr_prove_batch_device, while the previous chunk is being proved; witness="host": the host
+    builder on a pool of threads and zkr_prove_batch on pageable host witnesses.  End-to-end rate over n_batches distinct
+    batches (consecutive states of one rollup), circuit inputs prepared beforehand (the operator's side: signing, tree
+    updates)."""
     import queue
     import threading
     from concurrent.futures import ThreadPoolExecutor
@@ -362,10 +364,15 @@ def facade_pipeline_leg(local, n_batches=256, chunk=32):
         txs = [state.transfer((2 * b + j) % 8, (2 * b + j + 3) % 8, 10 ** 15 * (j + 1) + b, 10 ** 12, privs[(2 * b + j) % 8]) for j in range(circ.batch)]
         flats.append(circ.flatten_inputs(state.batch_inputs(txs)))
     workers = max(2, effective_host_cores() - 2)
-    key.prove_batch([circ.calculate_witness(flats[0])] * 4)   # warm: staging buffers, fused launch plans
+    w0 = circ.calculate_witness(flats[0])
+    key.prove_batch([w0] * 4)                                   # warm: staging buffers, fused launch plans
+    if witness == "gpu":  # warm: the builder's tables, and torch's first device-to-host copy (tens of milliseconds once per process)
+        circ.calculate_witness_batch_device(flats[:2], device=local)[:, 32:64].cpu()
     verified = [0]
     failures = []
-    q_verify = queue.Queue()
+    trace = [] if os.environ.get("ZKR_PIPE_TRACE") else None
+    q_verify, q_wit = queue.Queue(), queue.Queue(maxsize=2)
+    n_pub = circ.n_public
 
     def verifier():
         while True:
@@ -373,28 +380,95 @@ def facade_pipeline_leg(local, n_batches=256, chunk=32):
             if item is None:
                 return
             proofs, pubs = item
+            ta = time.perf_counter()
             if zkr_hip.verify_batch(vk_bin, proofs, pubs):
                 verified[0] += len(proofs)
             else:
                 failures.append(len(proofs))
+            if trace is not None:
+                trace.append(("V%d" % len(proofs), ta, time.perf_counter()))
+
+    # chunk plan: the GPU builder's latency is flat (~30 ms whatever the count), so the first chunk is small (the prover starts
+    # after one builder latency), the following ones `chunk` batches each (calls of that size keep the prover's pipeline full);
+    # verification streams behind the proofs in pieces of 16 on four host threads.  (The first batches from the HOST builder
+    # while the GPU builds the second chunk was tried: 16 witnesses on the thread pool take 67 ms beside everything else, the
+    # GPU's first chunk 27 ms -- ZKR_PIPE_HOST_FIRST=16 re-runs it.)
+    host_first = min(int(os.environ.get("ZKR_PIPE_HOST_FIRST", "0")), n_batches) if witness == "gpu" else 0
+    sizes, left = [], n_batches - host_first
+    if left > 0:
+        sizes.append(min(32, chunk, left))
+        left -= sizes[-1]
+    while left > 0:
+        sizes.append(min(chunk, left))
+        left -= sizes[-1]
+
+    def gpu_witnesses():                                            # chunk i + 1 is built while chunk i is proved
+        import torch
+        torch.cuda.set_device(local)
+        c0 = host_first
+        for sz in sizes:
+            ta = time.perf_counter()
+            t = circ.calculate_witness_batch_device(flats[c0:c0 + sz], device=local)
+            if trace is not None:
+                trace.append(("W%d" % sz, ta, time.perf_counter()))
+            q_wit.put(t)
+            c0 += sz
+        q_wit.put(None)
 
     t0 = time.perf_counter()
-    vt = threading.Thread(target=verifier)
-    vt.start()
-    with ThreadPoolExecutor(workers) as pool:
-        futs = [pool.submit(circ.calculate_witness, f) for f in flats]          # ctypes releases the GIL inside the builder
-        for c0 in range(0, n_batches, chunk):
-            wits = [f.result() for f in futs[c0:c0 + chunk]]
-            proofs = key.prove_batch(wits)                                        # random blinding, as the reference draws it
-            q_verify.put((proofs, [circ.public_signals(w) for w in wits]))
-    q_verify.put(None)
-    vt.join()
+    vts = [threading.Thread(target=verifier) for _ in range(4)]     # 0.75 ms of one core per proof; pieces of 16, so the tail after the last proof is short
+    for vt in vts:
+        vt.start()
+    def to_verify(proofs, pubs):
+        for o in range(0, len(proofs), 16):
+            q_verify.put((proofs[o:o + 16], pubs[o:o + 16]))
+
+    if witness == "gpu":
+        wt = threading.Thread(target=gpu_witnesses)
+        wt.start()
+        if host_first:
+            with ThreadPoolExecutor(min(workers, host_first)) as pool:
+                wits = list(pool.map(circ.calculate_witness, flats[:host_first]))
+            ta = time.perf_counter()
+            proofs = key.prove_batch(wits)
+            if trace is not None:
+                trace.append(("Ph%d" % len(proofs), ta, time.perf_counter()))
+            to_verify(proofs, [circ.public_signals(w) for w in wits])
+        while True:
+            t = q_wit.get()
+            if t is None:
+                break
+            ta = time.perf_counter()
+            proofs = key.prove_batch_device([t[i].data_ptr() for i in range(t.shape[0])])     # random blinding, as the reference draws it
+            tb = time.perf_counter()
+            head = t[:, 32:32 * (n_pub + 1)].cpu().numpy()
+            pubs = [[int.from_bytes(row[32 * j:32 * j + 32].tobytes(), "little") for j in range(n_pub)] for row in head]
+            if trace is not None:
+                trace += [("P%d" % len(proofs), ta, tb), ("pub", tb, time.perf_counter())]
+            to_verify(proofs, pubs)
+            del t
+        wt.join()
+    else:
+        with ThreadPoolExecutor(workers) as pool:
+            futs = [pool.submit(circ.calculate_witness, f) for f in flats]          # ctypes releases the GIL inside the builder
+            for c0 in range(0, n_batches, chunk):
+                wits = [f.result() for f in futs[c0:c0 + chunk]]
+                proofs = key.prove_batch(wits)
+                to_verify(proofs, [circ.public_signals(w) for w in wits])
+    for vt in vts:
+        q_verify.put(None)
+    for vt in vts:
+        vt.join()
     el = time.perf_counter() - t0
     key.close()
-    return {"circuit": "BatchProcessTx(2, 6) (tx.circom)", "batches": n_batches, "chunk": chunk, "witness_threads": workers,
+    if trace:
+        for name, ta, tb in sorted(trace, key=lambda e: e[1]):
+            sys.stderr.write("%-6s %7.1f -> %7.1f  (%.1f ms)\n" % (name, 1e3 * (ta - t0), 1e3 * (tb - t0), 1e3 * (tb - ta)))
+    return {"circuit": "BatchProcessTx(2, 6) (tx.circom)", "batches": n_batches, "chunk": chunk, "chunks": (([["host", host_first]] if host_first else []) + sizes) if witness == "gpu" else None,
+            "witness": "GPU builder (zkr_rollup_witness_batch_device), witnesses stay in HBM" if witness == "gpu" else "host builder on %d threads" % workers,
             "end_to_end_proofs_per_s": n_batches / el, "ms_per_batch": 1e3 * el / n_batches, "proofs_verified": verified[0],
             "verification_failures": len(failures),
-            "steps": "witness (host builder, thread pool) -> zkr_prove_batch (host witnesses) -> zkr_verify_batch, overlapped"}
+            "steps": "witness -> proof -> zkr_verify_batch, overlapped (chunk i + 1's witnesses under chunk i's proofs, verification on a host thread)"}
 
 
 def self_launch(n_gpus):
@@ -706,7 +780,9 @@ def main():
             out["tx_circuit"] = tx_circuit_leg(local, max(args.steps, 4))
             # the same circuit family filled up to the headline size: 18 transactions per batch = 1 008 108 constraints, 2^20 domain
             out["rollup_circuit_2_20"] = tx_circuit_leg(local, min(max(args.steps, 4), 20), batch=18, depth=6)
-            out["facade_pipeline"] = facade_pipeline_leg(local)
+            out["facade_pipeline"] = facade_pipeline_leg(local)                         # 256 batches: VERDICT r2 item 7
+            out["facade_pipeline_1024"] = facade_pipeline_leg(local, n_batches=1024)  # a longer stream: the one-off builder latency weighs less
+            out["facade_pipeline_host_witness"] = facade_pipeline_leg(local, chunk=32, witness="host")
         print(json.dumps(out))
     if dist:
         dist.barrier()

@@ -88,14 +88,16 @@ static int upload_constants(int device) {
 // slice behind the public part; roots / errs: per transaction.
 static __global__ __launch_bounds__(64) void rollup_witness_tx_kernel(const Fr *inputs, uint32_t n_batches, uint32_t batch, uint32_t depth, uint32_t K, TxConsts k,
                                                                       Fr *wit, Fr *workspace, Fr *roots, uint32_t *errs) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n_batches * batch) return;
+  __builtin_amdgcn_s_setprio(3);  // a few wavefronts with a dependent chain of ~15 ms each: they win the issue slot against the bulk kernels of proofs in flight
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, part = blockIdx.y;  // a wavefront = one part of 64 transactions
+  const uint32_t n_tx = n_batches * batch;
+  if (t >= n_tx) return;
   const uint32_t bi = t / batch, i = t % batch;
   const uint32_t p = tx_layout(batch, depth).p;
   Fr root;
-  errs[t] = tx_witness(inputs + (size_t)bi * (p - 1), batch, depth, i, K, k, wit + (size_t)bi * ((size_t)p + 1 + (size_t)batch * K) + p + 1 + (size_t)i * K,
-                       workspace + (size_t)t * 4 * WS_PTS, &root);
-  roots[t] = root;
+  errs[(size_t)part * n_tx + t] = tx_witness(inputs + (size_t)bi * (p - 1), batch, depth, i, K, k, wit + (size_t)bi * ((size_t)p + 1 + (size_t)batch * K) + p + 1 + (size_t)i * K,
+                                             workspace + (size_t)t * 4 * WS_PTS, &root, (int)part);
+  if (part == TX_PARTS - 1) roots[t] = root;
 }
 // The vector as binarifyWitness lays it out: signal 0 = 1, signal 1 = the last transaction's root, the inputs as given, the
 // private signals converted to standard form in place.  Thread per signal of every batch; the first thread of a batch also
@@ -127,6 +129,10 @@ static __global__ __launch_bounds__(256) void rollup_witness_layout_kernel(const
   }
   wit[g] = v;
 }
+struct DevView {  // a typed look at device memory owned elsewhere
+  void *p;
+  template <class T> T *as() const { return static_cast<T *>(p); }
+};
 }  // namespace zkr
 
 using namespace zkr;
@@ -184,22 +190,50 @@ int zkr_rollup_witness_batch_device(uint32_t batch, uint32_t depth, const uint8_
   }
   k.b8x = d_tab[device], k.b8y = d_tab[device] + 253, k.mimc = d_tab[device] + 506;
   const size_t n_tx = n_batches * batch, nv = (size_t)p + 1 + (size_t)batch * K;
-  DevBuf b_in, b_ws, b_roots, b_errs;
-  if ((rc = b_in.alloc(n_batches * (size_t)(p - 1) * 32)) || (rc = b_ws.alloc(n_tx * 4 * WS_PTS * 32)) || (rc = b_roots.alloc(n_tx * 32)) ||
-      (rc = b_errs.alloc((n_tx + n_batches) * 4)))
-    return rc;
-  ZKR_HIP_CHECK(hipMemcpy(b_in.p, inputs, n_batches * (size_t)(p - 1) * 32, hipMemcpyHostToDevice));
-  uint32_t *d_errs = b_errs.as<uint32_t>(), *d_chain = d_errs + n_tx;
-  rollup_witness_tx_kernel<<<(unsigned)((n_tx + 63) / 64), 64>>>(b_in.as<Fr>(), (uint32_t)n_batches, batch, depth, K, k, (Fr *)d_witnesses, b_ws.as<Fr>(), b_roots.as<Fr>(), d_errs);
+  // Scratch kept per device and only ever grown: hipMalloc / hipFree synchronise the whole device, i.e. every call would wait
+  // for the proofs in flight on the key's streams (measured: the builder's 30 ms became the 63 ms of the prove call beside it).
+  // One call per device at a time (the lock is held to the end of the call).
+  struct Scratch { void *p = nullptr; size_t cap = 0; };
+  static Scratch scratch[64][4];
+  static std::mutex scratch_mu[64];
+  std::lock_guard<std::mutex> scratch_lock(scratch_mu[device]);
+  const size_t want[4] = {n_batches * (size_t)(p - 1) * 32, n_tx * 4 * WS_PTS * 32, n_tx * 32, (TX_PARTS * n_tx + n_batches) * 4};
+  for (int j = 0; j < 4; j++) {
+    Scratch &sc = scratch[device][j];
+    if (sc.cap >= want[j]) continue;
+    if (sc.p) hipFree(sc.p);
+    sc.p = nullptr, sc.cap = 0;
+    ZKR_HIP_CHECK(hipMalloc(&sc.p, want[j] + want[j] / 2));
+    sc.cap = want[j] + want[j] / 2;
+  }
+  const DevView b_in{scratch[device][0].p}, b_ws{scratch[device][1].p}, b_roots{scratch[device][2].p}, b_errs{scratch[device][3].p};
+  // Its own stream (non-blocking, highest priority): the builder is a handful of long-running wavefronts that must neither wait
+  // for nor hold up the proofs in flight on the key's streams; nothing here synchronises the device.
+  struct StreamGuard {
+    hipStream_t s = nullptr;
+    ~StreamGuard() { if (s) hipStreamDestroy(s); }
+  } sg;
+  int prio_lo = 0, prio_hi = 0;
+  ZKR_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+  ZKR_HIP_CHECK(hipStreamCreateWithPriority(&sg.s, hipStreamNonBlocking, prio_hi));
+  ZKR_HIP_CHECK(hipMemcpyAsync(b_in.p, inputs, n_batches * (size_t)(p - 1) * 32, hipMemcpyHostToDevice, sg.s));
+  uint32_t *d_errs = b_errs.as<uint32_t>(), *d_chain = d_errs + TX_PARTS * n_tx;
+  rollup_witness_tx_kernel<<<dim3((unsigned)((n_tx + 63) / 64), TX_PARTS), 64, 0, sg.s>>>(b_in.as<Fr>(), (uint32_t)n_batches, batch, depth, K, k, (Fr *)d_witnesses, b_ws.as<Fr>(), b_roots.as<Fr>(), d_errs);
   ZKR_HIP_CHECK(hipGetLastError());
   const size_t total = nv * n_batches;
-  rollup_witness_layout_kernel<<<(unsigned)((total + 255) / 256), 256>>>(b_in.as<Fr>(), (uint32_t)n_batches, batch, depth, K, b_roots.as<Fr>(), (Fr *)d_witnesses, d_chain);
+  rollup_witness_layout_kernel<<<(unsigned)((total + 255) / 256), 256, 0, sg.s>>>(b_in.as<Fr>(), (uint32_t)n_batches, batch, depth, K, b_roots.as<Fr>(), (Fr *)d_witnesses, d_chain);
   ZKR_HIP_CHECK(hipGetLastError());
-  std::vector<uint32_t> errs(n_tx + n_batches);
-  ZKR_HIP_CHECK(hipMemcpy(errs.data(), d_errs, errs.size() * 4, hipMemcpyDeviceToHost));  // also waits for the kernels
+  std::vector<uint32_t> errs(TX_PARTS * n_tx + n_batches);
+  ZKR_HIP_CHECK(hipMemcpyAsync(errs.data(), d_errs, errs.size() * 4, hipMemcpyDeviceToHost, sg.s));
+  ZKR_HIP_CHECK(hipStreamSynchronize(sg.s));
   for (size_t bi = 0; bi < n_batches; bi++) {  // first violated statement in circuit order, as zkr_rollup_witness reports it
     for (uint32_t i = 0; i < batch; i++) {
-      const uint32_t chain = errs[n_tx + bi], e = errs[bi * batch + i];
+      const uint32_t chain = errs[TX_PARTS * n_tx + bi];
+      uint32_t e = 0;  // the codes are in program order: the smallest one over the parts is the transaction's first violation
+      for (uint32_t part = 0; part < TX_PARTS; part++) {
+        const uint32_t ep = errs[(size_t)part * n_tx + bi * batch + i];
+        if (ep && (!e || ep < e)) e = ep;
+      }
       if (e == ST_INPUT_RANGE) { set_error("batch %zu: an input of transaction %u is not below r", bi, i); return ZKR_ERR_ARG; }
       if (e == ST_COUNT) { set_error("internal: private signal count differs from the structure pass"); return ZKR_ERR_HIP; }
       if (i > 0 && chain == i) { set_error("batch %zu: transaction %u violates: %s", bi, i, TX_STMT_TEXT[ST_CHAIN]); return ZKR_ERR_UNSATISFIED; }
@@ -226,7 +260,13 @@ int zkr_rollup_witness_program_host(uint32_t batch, uint32_t depth, const uint8_
   Fr *out = reinterpret_cast<Fr *>(witness_out);
   *stmt = 0, *tx = 0;
   for (uint32_t i = 0; i < batch; i++) {
-    uint32_t e = tx_witness(in.data(), batch, depth, i, K, k, w.data(), ws.data(), &roots[i]);
+    uint32_t e = 0;  // part by part, as the GPU builder's wavefronts run them; the smallest code is the first violation in program order
+    for (uint32_t part = 0; part < TX_PARTS; part++) {
+      Fr r;
+      const uint32_t ep = tx_witness(in.data(), batch, depth, i, K, k, w.data(), ws.data(), &r, (int)part);
+      if (ep && (!e || ep < e)) e = ep;
+      if (part == TX_PARTS - 1) roots[i] = r;
+    }
     if (i > 0) {  // the root chain comes first in circuit order (batchprocesstx.circom:67-69), as in rollup.cpp batch_witness
       Fr want;
       tx_read_input(&in[i], want);

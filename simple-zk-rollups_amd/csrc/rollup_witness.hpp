@@ -246,41 +246,74 @@ struct TxInD {
   Fr spath[TX_MAX_DEPTH], rpath[TX_MAX_DEPTH], ipath[TX_MAX_DEPTH];
 };
 // ProcessTx (process_tx_gadget): returns the new root
-ZKR_HDF Fr tx_process(TxB &b, const TxInD &in, uint32_t depth) {
+// The program in three parts that share no signal: 0 = indices, signature, range checks (the two scalar multiplications);
+// 1 = the sender's leaves and paths; 2 = the recipient's leaves and paths -- about 2 * 10^4 dependent multiplications each.
+// part < 0 runs all of them in order (host, tests); the GPU builder gives each part of 64 transactions its own wavefront
+// (rollup_gpu.hip), three times shorter than one lane doing everything.  Where a part starts is a matter of counting:
+// a leaf hash is 4 x 660 signals, a path depth x (1 + 2 x 660), the recipient selectors 4.
+constexpr uint32_t TX_PARTS = 3;
+ZKR_HDF Fr tx_process(TxB &b, const TxInD &in, uint32_t depth, int part, uint32_t K) {
+  const bool all = part < 0;
+  const uint32_t leaf = 4 * 3 * MIMC_ROUNDS, path = depth * (1 + 2 * 3 * MIMC_ROUNDS);
+  const uint32_t o_sleaf = K - (4 * leaf + 4 * path + 4), o_rleaf = o_sleaf + leaf, o_spath = o_rleaf + leaf, o_rpath = o_spath + path;
+  const uint32_t o_nsleaf = o_rpath + path, o_same = o_nsleaf + leaf, o_nrleaf = o_same + 4, o_nspath = o_nrleaf + leaf, o_nrpath = o_nspath + path;
   uint32_t sidx[8], ridx[8], tmp[8];
-  tx_num2bits(b, in.tx[0], (int)depth, ST_SIDX, sidx);
-  tx_num2bits(b, in.tx[1], (int)depth, ST_RIDX, ridx);
-  const Fr m5[5] = {in.tx[0], in.tx[1], in.tx[2], in.tx[3], in.tx[4]};
-  Fr msg = tx_multihash(b, m5, 5);
-  if (!tx_eddsa_verify(b, in.spk[0], in.spk[1], in.tx[7], in.tx[5], in.tx[6], msg)) b.fail(ST_SIGNATURE);
-  if (!(in.tx[4] == add(in.snonce, Fr::one()))) b.fail(ST_NONCE);
-  tx_num2bits(b, in.tx[2], 250, ST_AMOUNT_BITS, tmp);
-  tx_num2bits(b, in.tx[3], 250, ST_FEE_BITS, tmp);
-  tx_num2bits(b, in.sbal, 250, ST_BALANCE_BITS, tmp);
-  if (tx_is_zero(b, in.tx[2])) b.fail(ST_AMOUNT_POS);
-  if (tx_is_zero(b, in.tx[3])) b.fail(ST_FEE_POS);
-  {  // balance > amount + fee: bit 251 of balance - (amount + fee) - 1 + 2^251 (greater_than_250)
-    Fr p251 = Fr::one();
-    for (int i = 0; i < 251; i++) p251 = dbl(p251);
-    Fr v = add(sub(sub(in.sbal, add(in.tx[2], in.tx[3])), Fr::one()), p251);
-    tx_num2bits(b, v, 252, ST_CMP_BITS, tmp);
-    if (!word_bit(tmp, 251)) b.fail(ST_BALANCE_GT);
+  if (all || part == 0) {
+    tx_num2bits(b, in.tx[0], (int)depth, ST_SIDX, sidx);
+    tx_num2bits(b, in.tx[1], (int)depth, ST_RIDX, ridx);
+    const Fr m5[5] = {in.tx[0], in.tx[1], in.tx[2], in.tx[3], in.tx[4]};
+    Fr msg = tx_multihash(b, m5, 5);
+    if (!tx_eddsa_verify(b, in.spk[0], in.spk[1], in.tx[7], in.tx[5], in.tx[6], msg)) b.fail(ST_SIGNATURE);
+    if (!(in.tx[4] == add(in.snonce, Fr::one()))) b.fail(ST_NONCE);
+    tx_num2bits(b, in.tx[2], 250, ST_AMOUNT_BITS, tmp);
+    tx_num2bits(b, in.tx[3], 250, ST_FEE_BITS, tmp);
+    tx_num2bits(b, in.sbal, 250, ST_BALANCE_BITS, tmp);
+    if (tx_is_zero(b, in.tx[2])) b.fail(ST_AMOUNT_POS);
+    if (tx_is_zero(b, in.tx[3])) b.fail(ST_FEE_POS);
+    {  // balance > amount + fee: bit 251 of balance - (amount + fee) - 1 + 2^251 (greater_than_250)
+      Fr p251 = Fr::one();
+      for (int i = 0; i < 251; i++) p251 = dbl(p251);
+      Fr v = add(sub(sub(in.sbal, add(in.tx[2], in.tx[3])), Fr::one()), p251);
+      tx_num2bits(b, v, 252, ST_CMP_BITS, tmp);
+      if (!word_bit(tmp, 251)) b.fail(ST_BALANCE_GT);
+    }
+    if (!b.err && b.n != o_sleaf) b.fail(ST_COUNT);  // internal: the count above is not the structure pass's
+  } else {  // the index bits without their signals
+    Fr s0 = from_mont(in.tx[0]), s1 = from_mont(in.tx[1]);
+#pragma unroll
+    for (int i = 0; i < 8; i++) sidx[i] = s0.v[i], ridx[i] = s1.v[i];
   }
-  const Fr sl[4] = {in.spk[0], in.spk[1], in.sbal, in.snonce}, rl[4] = {in.rpk[0], in.rpk[1], in.rbal, in.rnonce};
-  Fr sleaf = tx_multihash(b, sl, 4);
-  Fr rleaf = tx_multihash(b, rl, 4);
-  if (!(tx_merkle_root(b, sleaf, in.spath, sidx, depth) == in.root)) b.fail(ST_SLEAF);
-  if (!(tx_merkle_root(b, rleaf, in.rpath, ridx, depth) == in.root)) b.fail(ST_RLEAF);
-  Fr nsbal = sub(sub(in.sbal, in.tx[2]), in.tx[3]);
-  const Fr nsl[4] = {in.spk[0], in.spk[1], nsbal, in.tx[4]};
-  Fr nsleaf = tx_multihash(b, nsl, 4);
-  const bool same = tx_is_zero(b, sub(in.tx[0], in.tx[1]));
-  Fr selbal = add(in.rbal, b.put(same ? sub(nsbal, in.rbal) : Fr::zero()));
-  Fr selnonce = add(in.rnonce, b.put(same ? sub(in.tx[4], in.rnonce) : Fr::zero()));
-  const Fr nrl[4] = {in.rpk[0], in.rpk[1], add(selbal, in.tx[2]), selnonce};
-  Fr nrleaf = tx_multihash(b, nrl, 4);
-  if (!(tx_merkle_root(b, nsleaf, in.spath, sidx, depth) == in.iroot)) b.fail(ST_IROOT);
-  return tx_merkle_root(b, nrleaf, in.ipath, ridx, depth);
+  const Fr nsbal = sub(sub(in.sbal, in.tx[2]), in.tx[3]);
+  Fr root = Fr::zero();
+  if (all || part == 1) {
+    const Fr sl[4] = {in.spk[0], in.spk[1], in.sbal, in.snonce};
+    b.n = o_sleaf;
+    Fr sleaf = tx_multihash(b, sl, 4);
+    b.n = o_spath;
+    if (!(tx_merkle_root(b, sleaf, in.spath, sidx, depth) == in.root)) b.fail(ST_SLEAF);
+    const Fr nsl[4] = {in.spk[0], in.spk[1], nsbal, in.tx[4]};
+    b.n = o_nsleaf;
+    Fr nsleaf = tx_multihash(b, nsl, 4);
+    b.n = o_nspath;
+    if (!(tx_merkle_root(b, nsleaf, in.spath, sidx, depth) == in.iroot)) b.fail(ST_IROOT);
+  }
+  if (all || part == 2) {
+    const Fr rl[4] = {in.rpk[0], in.rpk[1], in.rbal, in.rnonce};
+    b.n = o_rleaf;
+    Fr rleaf = tx_multihash(b, rl, 4);
+    b.n = o_rpath;
+    if (!(tx_merkle_root(b, rleaf, in.rpath, ridx, depth) == in.root)) b.fail(ST_RLEAF);
+    b.n = o_same;
+    const bool same = tx_is_zero(b, sub(in.tx[0], in.tx[1]));
+    Fr selbal = add(in.rbal, b.put(same ? sub(nsbal, in.rbal) : Fr::zero()));
+    Fr selnonce = add(in.rnonce, b.put(same ? sub(in.tx[4], in.rnonce) : Fr::zero()));
+    const Fr nrl[4] = {in.rpk[0], in.rpk[1], add(selbal, in.tx[2]), selnonce};
+    Fr nrleaf = tx_multihash(b, nrl, 4);
+    b.n = o_nrpath;
+    root = tx_merkle_root(b, nrleaf, in.ipath, ridx, depth);
+    if (!b.err && b.n != K) b.fail(ST_COUNT);
+  }
+  return root;
 }
 // standard-form input below r -> Montgomery; false when it is not a field element
 ZKR_HDF bool tx_read_input(const Fr *p, Fr &out) {
@@ -305,9 +338,11 @@ ZKR_HDF TxLayout tx_layout(uint32_t batch, uint32_t depth) {
   L.o_rbal = take(1), L.o_rnonce = take(1), L.o_rpath = take(depth), L.o_iroot = take(1), L.o_ipath = take(depth);
   return L;
 }
-// One transaction: inputs = the batch's n_public - 1 input signals (standard form), w = its slice of K private signals
-// (Montgomery values out), ws = 4 * WS_PTS scratch elements.  Returns the first violated statement (TxStmt); *root = its new root.
-ZKR_HDF uint32_t tx_witness(const Fr *inputs, uint32_t batch, uint32_t depth, uint32_t i, uint32_t K, const TxConsts &k, Fr *w, Fr *ws, Fr *root) {
+// One transaction (or one of its TX_PARTS parts): inputs = the batch's n_public - 1 input signals (standard form), w = its
+// slice of K private signals (Montgomery values out), ws = 4 * WS_PTS scratch elements (part 0 only).  Returns the first
+// violated statement of what it ran (TxStmt: the codes are in program order, so the smallest non-zero code over the parts
+// is the transaction's); *root = its new root (part 2).
+ZKR_HDF uint32_t tx_witness(const Fr *inputs, uint32_t batch, uint32_t depth, uint32_t i, uint32_t K, const TxConsts &k, Fr *w, Fr *ws, Fr *root, int part = -1) {
   const TxLayout L = tx_layout(batch, depth);
   const Fr *in = inputs - 2;  // in[s] = signal s of this batch (s >= 2)
   TxB b;
@@ -334,8 +369,7 @@ ZKR_HDF uint32_t tx_witness(const Fr *inputs, uint32_t batch, uint32_t depth, ui
     ok = tx_read_input(in + L.o_ipath + depth * i + j, x.ipath[j]) && ok;
   }
   if (!ok) b.fail(ST_INPUT_RANGE);
-  *root = tx_process(b, x, depth);
-  if (!b.err && b.n != K) b.err = ST_COUNT;  // internal: the signal count differs from the structure pass
+  *root = tx_process(b, x, depth, part, K);
   return b.err;
 }
 }  // namespace zkr

@@ -148,8 +148,7 @@ class RollupCircuit:
             if len(f) != self.n_public - 1:
                 raise ZkrError(-5, "circuit inputs have %d values, BatchProcessTx(%d, %d) takes %d" % (len(f), self.batch, self.depth, self.n_public - 1))
         buf = b"".join(_le(v) for f in flats for v in f)
-        out = torch.empty((len(flats), self.n_vars * 32), dtype=torch.uint8, device=torch.device("cuda", device))
-        torch.cuda.synchronize(device)
+        out = torch.empty((len(flats), self.n_vars * 32), dtype=torch.uint8, device=torch.device("cuda", device))   # an allocation: nothing to wait for
         _check(lib().zkr_rollup_witness_batch_device(self.batch, self.depth, buf, self.n_public - 1, len(flats), out.data_ptr(), device))
         return out
 
