@@ -235,6 +235,13 @@ int zkt_final_exp_check(uint64_t seed, int count) {
   }
   return ok;
 }
+// the two G2 membership tests on one twist point (128 B standard form: x.re, x.im, y.re, y.im): bit 0 = the definition
+// ([r]Q == infinity), bit 1 = the endomorphism test the verifier runs (psi(Q) == [6x^2]Q), bit 2 = the point is on the twist
+int zkt_g2_membership(const uint8_t *pt) {
+  using namespace zkr::pairing;
+  G2Affine q{Fq2{to_mont(load_fp<FqParams>(pt)), to_mont(load_fp<FqParams>(pt + 32))}, Fq2{to_mont(load_fp<FqParams>(pt + 64)), to_mont(load_fp<FqParams>(pt + 96))}};
+  return (g2_in_subgroup_plain(q) ? 1 : 0) | (g2_in_subgroup(q) ? 2 : 0) | (g2_on_curve(q) ? 4 : 0);
+}
 // proof-assembly helpers (hostops.hpp) against plain double-and-add: fixed-base window table, joint double
 // multiplication; scalars a, b standard 32 B.  Returns 1 when both agree.
 int zkt_assembly_muls(const uint8_t *p_mont, const uint8_t *q_mont, const uint8_t *a32, const uint8_t *b32) {

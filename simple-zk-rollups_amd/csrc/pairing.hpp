@@ -68,7 +68,49 @@ static inline Fq12 mul(const Fq12 &a, const Fq12 &b) {
   Fq6 t0 = mul(a.c0, b.c0), t1 = mul(a.c1, b.c1);
   return Fq12{add(t0, mul_v(t1)), sub(sub(mul(add(a.c0, a.c1), add(b.c0, b.c1)), t0), t1)};
 }
-static inline Fq12 sqr(const Fq12 &a) { return mul(a, a); }
+// (a0 + a1 w)^2 = a0^2 + v a1^2 + 2 a0 a1 w with two Fq6 products: (a0 + a1)(a0 + v a1) - a0 a1 - v a0 a1 is the first part
+static inline Fq12 sqr(const Fq12 &a) {
+  Fq6 ab = mul(a.c0, a.c1);
+  Fq6 t = mul(add(a.c0, a.c1), add(a.c0, mul_v(a.c1)));
+  return Fq12{sub(sub(t, ab), mul_v(ab)), add(ab, ab)};
+}
+// x * (b0 + b1 v): an Fq6 product whose second factor has no v^2 term (five Fq2 products instead of six)
+static inline Fq6 mul_sparse01(const Fq6 &x, const Fq2 &b0, const Fq2 &b1) {
+  Fq2 t0 = mul(x.c0, b0), t1 = mul(x.c1, b1);
+  Fq2 c1 = sub(sub(mul(add(x.c0, x.c1), add(b0, b1)), t0), t1);
+  return Fq6{add(t0, mul_xi(mul(x.c2, b1))), c1, add(t1, mul(x.c2, b0))};
+}
+// f * (a + (b0 + b1 v) w) for a in Fq: the line functions of the Miller loop (line() below builds exactly this shape): six Fq
+// and ten Fq2 products instead of the eighteen Fq2 products of a general Fq12 product
+static inline Fq12 mul_by_line(const Fq12 &f, const Fq &a, const Fq2 &b0, const Fq2 &b1) {
+  Fq6 t0{mul_fq(f.c0.c0, a), mul_fq(f.c0.c1, a), mul_fq(f.c0.c2, a)};
+  Fq6 t1 = mul_sparse01(f.c1, b0, b1);
+  Fq6 m = mul_sparse01(add(f.c0, f.c1), Fq2{add(b0.a, a), b0.b}, b1);
+  return Fq12{add(t0, mul_v(t1)), sub(sub(m, t0), t1)};
+}
+// a^2 for a in the cyclotomic subgroup (anything after the easy part of the final exponentiation): Granger-Scott, three
+// Fq4 squarings = six Fq2 products instead of twelve
+static inline Fq12 cyclotomic_sqr(const Fq12 &a) {
+  Fq2 z0 = a.c0.c0, z4 = a.c0.c1, z3 = a.c0.c2, z2 = a.c1.c0, z1 = a.c1.c1, z5 = a.c1.c2;
+  auto fq4_sqr = [](const Fq2 &x, const Fq2 &y, Fq2 &r0, Fq2 &r1) {  // (x + y s)^2 with s^2 = xi
+    Fq2 tmp = mul(x, y);
+    r0 = sub(sub(mul(add(x, y), add(x, mul_xi(y))), tmp), mul_xi(tmp));
+    r1 = add(tmp, tmp);
+  };
+  Fq2 t0, t1, t2, t3, t4, t5;
+  fq4_sqr(z0, z1, t0, t1);
+  fq4_sqr(z2, z3, t2, t3);
+  fq4_sqr(z4, z5, t4, t5);
+  auto three_minus_two = [](const Fq2 &t, const Fq2 &z) { Fq2 d = sub(t, z); return add(add(d, d), t); };  // 3 t - 2 z
+  auto three_plus_two = [](const Fq2 &t, const Fq2 &z) { Fq2 d = add(t, z); return add(add(d, d), t); };    // 3 t + 2 z
+  z0 = three_minus_two(t0, z0);
+  z1 = three_plus_two(t1, z1);
+  z2 = three_plus_two(mul_xi(t5), z2);
+  z3 = three_minus_two(t4, z3);
+  z4 = three_minus_two(t2, z4);
+  z5 = three_plus_two(t3, z5);
+  return Fq12{Fq6{z0, z4, z3}, Fq6{z2, z1, z5}};
+}
 static inline Fq12 conj(const Fq12 &a) { return Fq12{a.c0, neg(a.c1)}; }
 static inline Fq12 inv(const Fq12 &a) {
   Fq6 d = inv(sub(mul(a.c0, a.c0), mul_v(mul(a.c1, a.c1))));
@@ -80,6 +122,18 @@ static inline Fq12 pow(const Fq12 &a, const uint32_t (&e)[N]) {
   bool started = false;
   for (int i = 32 * N - 1; i >= 0; i--) {
     if (started) r = sqr(r);
+    if ((e[i >> 5] >> (i & 31)) & 1) { r = started ? mul(r, a) : a; started = true; }
+  }
+  return r;
+}
+
+// the same for an element of the cyclotomic subgroup
+template <int N>
+static inline Fq12 pow_cyclotomic(const Fq12 &a, const uint32_t (&e)[N]) {
+  Fq12 r = Fq12::one();
+  bool started = false;
+  for (int i = 32 * N - 1; i >= 0; i--) {
+    if (started) r = cyclotomic_sqr(r);
     if ((e[i >> 5] >> (i & 31)) & 1) { r = started ? mul(r, a) : a; started = true; }
   }
   return r;
@@ -113,7 +167,8 @@ static inline bool g2_on_curve(const G2Affine &p) {
 // Q is in the order-r subgroup G2 of the twist: [r]Q == infinity.  The twist's group order is r (2q - r) and the
 // cofactor 2q - r has small prime factors (10069, ...), so an on-curve point need not be in G2; the bn256 pairing
 // precompile the contracts call (TxVerifier.sol:91-115) rejects such points, and so must this verifier.
-static inline bool g2_in_subgroup(const G2Affine &p) {
+// g2_in_subgroup_plain is the definition (a 254-bit multiplication); g2_in_subgroup below is the test the verifier runs.
+static inline bool g2_in_subgroup_plain(const G2Affine &p) {
   if (p.is_inf()) return true;
   G2XYZZ base = to_xyzz(p), acc = G2XYZZ::inf();
   for (int i = 253; i >= 0; i--) {  // r < 2^254
@@ -126,6 +181,25 @@ static inline bool g2_in_subgroup(const G2Affine &p) {
 static inline G2Affine g2_frobenius(const G2Affine &p) {
   Fq2 gx{fq_from_limbs(FROB_X0), fq_from_limbs(FROB_X1)}, gy{fq_from_limbs(FROB_Y0), fq_from_limbs(FROB_Y1)};
   return G2Affine{mul(conj(p.x), gx), mul(conj(p.y), gy)};
+}
+
+// The same membership through the twist's Frobenius endomorphism psi (untwist, q-power, twist = g2_frobenius): on G2 psi acts
+// as multiplication by q = 6x^2 + 1 - ... = 6x^2 (mod r) for the BN parameter x, and for a BN curve psi(Q) == [6x^2]Q holds
+// ONLY on G2 (Scott, "A note on group membership tests for G1, G2 and GT on BLS pairing-friendly curves", and the BN case
+// as implemented in gnark-crypto's bn254 G2 IsInSubGroup): a 127-bit multiplication instead of a 254-bit one.  Compared
+// with the plain definition on subgroup points, on-curve points outside it and their sums in tests/test_host_arith.py.
+static const uint32_t SIX_X_SQ[4] = {0xe87cfd46u, 0xf83e9682u, 0xeeb859fbu, 0x6f4d8248u};  // 6 x^2 = 147946756881789318990833708069417712966 = q - r
+static inline bool g2_in_subgroup(const G2Affine &p) {
+  if (p.is_inf()) return true;
+  G2XYZZ base = to_xyzz(p), acc = G2XYZZ::inf();
+  for (int i = 126; i >= 0; i--) {  // 6 x^2 < 2^127
+    acc = dbl_xyzz(acc);
+    if ((SIX_X_SQ[i >> 5] >> (i & 31)) & 1) acc = add_full(acc, base);
+  }
+  if (acc.is_inf()) return false;
+  const G2Affine lhs = g2_frobenius(p);
+  // [6x^2]Q == psi(Q) without leaving XYZZ: X == x ZZ and Y == y ZZZ
+  return mul(lhs.x, acc.zz) == acc.x && mul(lhs.y, acc.zzz) == acc.y;
 }
 
 static inline Fq12 line(const G2Affine &t, const Fq2 &lam, const G1Affine &p) {
@@ -165,7 +239,7 @@ static inline bool multi_step(G2Affine *t, const G2Affine *s, const G1Affine *p,
   for (int k = 0; k < m; k++) {
     const int i = idx[k];
     Fq2 lam = mul(num[k], den[k]);
-    f = mul(f, line(t[i], lam, p[i]));
+    f = mul_by_line(f, p[i].y, mul_fq(lam, neg(p[i].x)), sub(mul(lam, t[i].x), t[i].y));  // = f * line(t[i], lam, p[i])
     Fq2 x3 = sub(sub(sqr(lam), t[i].x), s ? s[i].x : t[i].x);
     Fq2 y3 = sub(mul(lam, sub(t[i].x, x3)), t[i].y);
     t[i] = G2Affine{x3, y3};
@@ -259,7 +333,7 @@ static const uint32_t BN_X[2] = {0x4a6909f1u, 0x44e992b4u};
 static inline Fq12 final_exponentiation(const Fq12 &f0) {
   Fq12 f = mul(conj(f0), inv(f0));  // ^(q^6 - 1)
   f = mul(frobenius2(f), f);        // ^(q^2 + 1)
-  Fq12 fx = pow(f, BN_X), fx2 = pow(fx, BN_X), fx3 = pow(fx2, BN_X);
+  Fq12 fx = pow_cyclotomic(f, BN_X), fx2 = pow_cyclotomic(fx, BN_X), fx3 = pow_cyclotomic(fx2, BN_X);
   Fq12 fp = frobenius(f), fp2 = frobenius2(f), fp3 = frobenius(fp2);
   Fq12 y0 = mul(mul(fp, fp2), fp3);
   Fq12 y1 = conj(f);
@@ -268,13 +342,13 @@ static inline Fq12 final_exponentiation(const Fq12 &f0) {
   Fq12 y4 = conj(mul(fx, frobenius(fx2)));
   Fq12 y5 = conj(fx2);
   Fq12 y6 = conj(mul(fx3, frobenius(fx3)));
-  Fq12 t0 = mul(mul(sqr(y6), y4), y5);
+  Fq12 t0 = mul(mul(cyclotomic_sqr(y6), y4), y5);
   Fq12 t1 = mul(mul(y3, y5), t0);
   t0 = mul(t0, y2);
-  t1 = sqr(mul(sqr(t1), t0));
+  t1 = cyclotomic_sqr(mul(cyclotomic_sqr(t1), t0));
   t0 = mul(t1, y1);
   t1 = mul(t1, y0);
-  return mul(sqr(t0), t1);
+  return mul(cyclotomic_sqr(t0), t1);
 }
 
 // prod_i e(P_i, Q_i) == 1  -- the bn256 pairing precompile's check (TxVerifier.sol:91-115)

@@ -7,6 +7,9 @@
 #include <stdio.h>
 #include <string.h>
 #include <algorithm>
+#include <list>
+#include <memory>
+#include <mutex>
 #include <vector>
 #include "pairing.hpp"
 #include "zkr_internal.hpp"
@@ -85,14 +88,99 @@ G1XYZZ ic_combination(const ParsedVk &k, const uint8_t *scalars) {
   }
   return acc;
 }
+
+// ---- verifying keys seen before.  The reference checks every proof against the SAME key (operator/src/snarks/common.ts:24,30:
+// one vk per circuit), and a call spent most of its time on the key, not the proof: three G2 membership tests and nPublic + 2
+// curve checks to parse it, then a Straus combination of its IC points from tables rebuilt per call (73 inputs for tx.circom:
+// ~6 * 10^4 field multiplications, more than the four Miller loops and the final exponentiation together).  A key's bytes are
+// parsed once per process; from its second use on the IC combination runs over 8-bit window tables of AFFINE multiples
+// (d * IC_i, d < 256: 32 mixed additions per input instead of 64 full ones).  Entries are immutable once published (several
+// host threads verify at once); the least recently used of VK_CACHE_SLOTS goes.
+constexpr size_t VK_CACHE_SLOTS = 4;
+struct VkEntry {
+  std::vector<uint8_t> bytes;
+  ParsedVk k;
+  std::vector<G1Affine> win8;  // [i * 255 + d - 1] = d * IC_{i+1}; empty until the key's second use
+  int uses = 0;
+};
+std::mutex vk_mu;
+std::list<std::shared_ptr<VkEntry>> vk_cache;
+
+void build_win8(VkEntry &e) {
+  const size_t n = e.k.ics.size();
+  std::vector<G1XYZZ> pts(n * 255);
+  for (size_t i = 0; i < n; i++) {
+    G1XYZZ base = to_xyzz(e.k.ics[i]), cur = base;
+    for (int d = 0; d < 255; d++) { pts[i * 255 + d] = cur; cur = add_mixed(cur, e.k.ics[i]); }
+  }
+  // affine with ONE inversion: x = X / ZZ, y = Y / ZZZ, and 1 / ZZ = ZZ^2 / ZZZ^2 (ZZ^3 = ZZZ^2), so only the ZZZ are inverted
+  std::vector<Fq> pre(pts.size());
+  Fq run = Fq::one();
+  for (size_t j = 0; j < pts.size(); j++) {
+    pre[j] = run;
+    if (!pts[j].is_inf()) run = mul(run, pts[j].zzz);
+  }
+  Fq iv = inv(run);
+  e.win8.assign(pts.size(), G1Affine{Fq::zero(), Fq::one()});
+  for (size_t j = pts.size(); j-- > 0;) {
+    if (pts[j].is_inf()) continue;  // d * IC = infinity cannot happen for a point of prime order r > 255; kept for safety
+    Fq izzz = mul(iv, pre[j]);
+    iv = mul(iv, pts[j].zzz);
+    Fq izz = mul(sqr(pts[j].zz), sqr(izzz));
+    e.win8[j] = G1Affine{mul(pts[j].x, izz), mul(pts[j].y, izzz)};
+  }
+}
+// the parsed key for these bytes (ZKR_ERR_* through *rc when they are not a well-formed key for n_public inputs)
+std::shared_ptr<const VkEntry> cached_vk(const void *vk_bin, size_t vk_len, size_t n_public, int *rc) {
+  *rc = 0;
+  {
+    std::lock_guard<std::mutex> lk(vk_mu);
+    for (auto it = vk_cache.begin(); it != vk_cache.end(); ++it) {
+      if ((*it)->bytes.size() != vk_len || memcmp((*it)->bytes.data(), vk_bin, vk_len) != 0) continue;
+      std::shared_ptr<VkEntry> e = *it;
+      if (e->k.ics.size() != n_public) break;  // the count check below words the error
+      vk_cache.splice(vk_cache.begin(), vk_cache, it);
+      if (++e->uses == 2 && e->win8.empty()) {  // second use: worth the tables.  A new entry replaces the old one (readers keep theirs)
+        auto e2 = std::make_shared<VkEntry>(*e);
+        build_win8(*e2);
+        vk_cache.front() = e2;
+        return e2;
+      }
+      return e;
+    }
+  }
+  auto e = std::make_shared<VkEntry>();
+  if ((*rc = parse_vk(vk_bin, vk_len, n_public, e->k))) return nullptr;
+  e->bytes.assign((const uint8_t *)vk_bin, (const uint8_t *)vk_bin + vk_len);
+  e->uses = 1;
+  std::lock_guard<std::mutex> lk(vk_mu);
+  vk_cache.push_front(e);
+  while (vk_cache.size() > VK_CACHE_SLOTS) vk_cache.pop_back();
+  return e;
+}
+// sum_i scalar_i * IC_{i+1} for a cached key: the window tables when it has them, the per-call Straus tables otherwise
+G1XYZZ ic_combination(const VkEntry &e, const uint8_t *scalars) {
+  if (e.win8.empty()) return ic_combination(e.k, scalars);
+  const size_t n = e.k.ics.size();
+  G1XYZZ acc = G1XYZZ::inf();
+  for (int w = 31; w >= 0; w--) {
+    if (w != 31) for (int j = 0; j < 8; j++) acc = dbl_xyzz(acc);
+    for (size_t i = 0; i < n; i++) {
+      const unsigned d = scalars[32 * i + w];
+      if (d) acc = add_mixed(acc, e.win8[i * 255 + d - 1]);
+    }
+  }
+  return acc;
+}
 }  // namespace
 
 extern "C" int zkr_verify(const void *vk_bin, size_t vk_len, const uint8_t proof[256], const void *public_std, size_t n_public, int *valid) {
   if (!vk_bin || !proof || !valid || (n_public && !public_std)) { set_error("null argument"); return ZKR_ERR_ARG; }
   *valid = 0;
-  ParsedVk k;
-  int rc = parse_vk(vk_bin, vk_len, n_public, k);
-  if (rc) return rc;
+  int rc = 0;
+  std::shared_ptr<const VkEntry> ent = cached_vk(vk_bin, vk_len, n_public, &rc);
+  if (!ent) return rc;
+  const ParsedVk &k = ent->k;
   // proof points: off-curve or out-of-range coordinates simply do not verify
   G1Affine a, c;
   G2Affine b;
@@ -101,7 +189,7 @@ extern "C" int zkr_verify(const void *vk_bin, size_t vk_len, const uint8_t proof
   const uint8_t *pub = (const uint8_t *)public_std;
   for (size_t i = 0; i < n_public; i++)
     if (!fr_lt_r(pub + 32 * i)) return 0;
-  G1XYZZ vkx = add_full(ic_combination(k, pub), to_xyzz(k.ic0));
+  G1XYZZ vkx = add_full(ic_combination(*ent, pub), to_xyzz(k.ic0));
   G1Affine ps[4] = {G1Affine{a.x, neg(a.y)}, k.alfa1, to_affine(vkx), c};
   G2Affine qs[4] = {b, k.beta2, k.gamma2, k.delta2};
   *valid = pairing::pairing_product_is_one(ps, qs, 4) ? 1 : 0;
@@ -116,9 +204,10 @@ extern "C" int zkr_verify(const void *vk_bin, size_t vk_len, const uint8_t proof
 extern "C" int zkr_verify_batch(const void *vk_bin, size_t vk_len, const uint8_t *proofs, const void *publics_std, size_t n_proofs, size_t n_public, int *all_valid) {
   if (!vk_bin || !all_valid || (n_proofs && (!proofs || (n_public && !publics_std)))) { set_error("null argument"); return ZKR_ERR_ARG; }
   *all_valid = 0;
-  ParsedVk k;
-  int rc = parse_vk(vk_bin, vk_len, n_public, k);
-  if (rc) return rc;
+  int rc = 0;
+  std::shared_ptr<const VkEntry> ent = cached_vk(vk_bin, vk_len, n_public, &rc);
+  if (!ent) return rc;
+  const ParsedVk &k = ent->k;
   if (n_proofs == 0) { *all_valid = 1; return 0; }
   const uint8_t *pub = (const uint8_t *)publics_std;
   std::vector<uint8_t> z(32 * n_proofs, 0);
@@ -159,7 +248,7 @@ extern "C" int zkr_verify_batch(const void *vk_bin, size_t vk_len, const uint8_t
   Fr zs_std = from_mont(zsum);
   U256 zs;
   memcpy(zs.v, zs_std.v, 32);
-  G1XYZZ vkx = add_full(ic_combination(k, comb_std.data()), scalar_mul(to_xyzz(k.ic0), zs));
+  G1XYZZ vkx = add_full(ic_combination(*ent, comb_std.data()), scalar_mul(to_xyzz(k.ic0), zs));
   ps.push_back(to_affine(scalar_mul(to_xyzz(k.alfa1), zs)));
   qs.push_back(k.beta2);
   ps.push_back(to_affine(vkx));

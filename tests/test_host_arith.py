@@ -307,3 +307,21 @@ def test_group_law_on_29_bit_limbs_matches_the_oracle(L):
         # an all-zero (infinity) wire point inside the list is skipped
         out = ctypes.create_string_buffer(pb)
         assert fn(bytes(pb) + wire(base[0]), bytes([0, 0]), 2, 0, out) == 0
+
+
+def test_g2_membership_by_endomorphism_equals_the_definition(L):
+    """The verifier's G2 membership test psi(Q) == [6x^2]Q (pairing.hpp g2_in_subgroup: a 127-bit multiplication) against the
+    definition [r]Q == infinity (g2_in_subgroup_plain) on: multiples of the generator (TxVerifier.sol:30-35), points of the
+    twist outside G2, points whose order divides the cofactor 2q - r, and sums of a G2 point with such a point (on the twist,
+    outside G2) -- what the bn256 precompile (TxVerifier.sol:91-115) must refuse."""
+    import bn254 as b
+    from test_abi import _twist_point_outside_g2
+    enc = lambda P: b"".join(int(v).to_bytes(32, "little") for v in (P[0][0], P[0][1], P[1][0], P[1][1]))
+    P, Pc = _twist_point_outside_g2()
+    rnd = random.Random(6)
+    inside = [b.g2_mul(b.G2_GEN, k) for k in (1, 2, 3, 0x5A4B, rnd.randrange(b.R), b.R - 1)]
+    outside = [P, Pc, b.g2_mul(P, 2, reduce=False), b.g2_mul(P, 7, reduce=False), b.g2_add(inside[3], Pc), b.g2_add(inside[4], P)]
+    for Q in inside:
+        assert L.zkt_g2_membership(enc(Q)) == 7, Q          # on the twist, in G2 by both tests
+    for Q in outside:
+        assert b.g2_is_on_curve(Q) and L.zkt_g2_membership(enc(Q)) == 4, Q   # on the twist, refused by both tests

@@ -1,0 +1,22 @@
+"""zkr_verify / zkr_verify_batch on the host alone (no GPU): one proof of a 73-public-input statement (the tx circuit's
+count, TxVerifier.sol:281) through the oracle's setup at m = 2^8.   python tools/verify_time.py"""
+import os, sys, time
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, os.path.join(ROOT, "simple-zk-rollups_amd", "python")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import groth16 as g, zkr_hip
+circ = g.synth_circuit(256, 73, 0x5A4B0001)
+tox = g.toxic_from_seed(0x5A4B00FF)
+pk, vk = g.setup(circ, tox)
+vkb = zkr_hip.binarify_verifying_key(vk)
+w = circ["witness"]
+pub = w[1:74]
+proofs = [g.proof_bytes(g.proof_from_toxic(circ, tox, w, 11 + i, 13 + i)) for i in range(16)]
+assert zkr_hip.verify(vkb, proofs[0], pub)
+for rep in range(3):
+    t = time.perf_counter()
+    for i in range(16):
+        assert zkr_hip.verify(vkb, proofs[i], pub)
+    print("zkr_verify: %.2f ms per proof" % (1e3 * (time.perf_counter() - t) / 16))
+bad = list(pub); bad[5] = (bad[5] + 1) % g.R
+assert not zkr_hip.verify(vkb, proofs[0], bad)
+t = time.perf_counter(); ok = zkr_hip.verify_batch(vkb, proofs, [pub] * 16); print("zkr_verify_batch: %.2f ms per proof (%s)" % (1e3 * (time.perf_counter() - t) / 16, ok))
