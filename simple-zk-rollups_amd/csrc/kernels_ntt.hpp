@@ -60,6 +60,16 @@ __device__ __forceinline__ Fr tw_lookup(const Fr *table, int tlog, int slog, uin
   return neg(load_fr(table + ((1u << tlog) - idx)));  // w^(2^tlog) = -1
 }
 
+// a butterfly twiddle as the product takes it: nine 29-bit limbs, canonical, x 2^261 (36 bytes: no unpacking in the passes,
+// which load three twiddles per four butterflies)
+struct Tw29 { uint32_t v[9]; };
+__device__ __forceinline__ L29<Fr29, 2> load_tw29(const Tw29 *p) {
+  L29<Fr29, 2> r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.v[i] = p->v[i];
+  return r;
+}
+
 enum NttPre { PRE_NONE = 0, PRE_COSET = 1, PRE_MUL = 2 };
 
 struct NttPassArgs {
@@ -67,8 +77,8 @@ struct NttPassArgs {
   const Fr *in1;   // second operand for PRE_MUL
   Fr *out;
   const Fr *tw;    // w_{2^(tlog+1)}^k table, x 2^256 (the coset factors of PRE_COSET)
-  const Fr *tw29;  // the same powers x 2^261, 2^tlog + 1 entries (entry 2^tlog = -1): the butterflies' twiddles
-  const Fr *twl29; // w_2048^k x 2^261, 2^TWL_LOG + 1 entries
+  const Tw29 *tw29;  // the same powers x 2^261 as limbs, 2^tlog + 1 entries (entry 2^tlog = -1): the butterflies' twiddles
+  const Tw29 *twl29; // w_2048^k x 2^261, 2^TWL_LOG + 1 entries
   int tlog;        // log2 of tw entries
   int L;           // transform size 2^L
   int lo, hi;      // stages [lo,hi)
@@ -143,17 +153,18 @@ static __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArg
 
   // twiddle of span 2^slog at offset x: w_{2s}^x, or for an inverse transform w_{2s}^(s - x) = -(w_{2s}^-x)
   auto twiddle = [&](int slog, uint32_t x) {
-    const Fr *tab = slog <= TWL_LOG ? a.twl29 : a.tw29;
+    const Tw29 *tab = slog <= TWL_LOG ? a.twl29 : a.tw29;
     const int tlog = slog <= TWL_LOG ? TWL_LOG : a.tlog;
     uint32_t idx = x << (tlog - slog);
     if (INV) idx = (1u << tlog) - idx;
-    return unpack29<NttL, 2>(load_fr(tab + idx).v);
+    return load_tw29(tab + idx);
   };
   // Stages run in PAIRS on four elements held in registers (one LDS round trip and one barrier per two stages; index
   // math modelled in tests/test_ntt_plan.py `double`); an odd stage count starts with one single stage.
   auto dif = [&](const auto &u, const auto &v, const L29<NttL, 2> &w, auto &sum, auto &prod) {  // (u + v, (u - v) w)
     sum = add(u, v);
-    if constexpr (INV) prod = mul(sub(v, u), w); else prod = mul(sub(u, v), w);
+    // the difference only ever becomes a factor of the product with the (normalised) twiddle: no carry sweep (field29.hpp U29)
+    if constexpr (INV) prod = mul(w, sub_loose(v, u)); else prod = mul(w, sub_loose(u, v));
   };
   auto dit = [&](const auto &u, const auto &v, const L29<NttL, 2> &w, auto &hi, auto &lo_) {    // (u + v w, u - v w)
     auto t = mul(v, w);
@@ -250,13 +261,13 @@ static __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArg
 }
 
 // the butterflies' twiddle tables from the x 2^256 ones: out[k] = T[k] x 2^5 (= w^k x 2^261), k < n; out[n] = -1 x 2^261
-static __global__ void twiddle261_kernel(const Fr *T, uint32_t n, Fr *out) {
+static __global__ void twiddle261_kernel(const Fr *T, uint32_t n, Tw29 *out) {
   uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k > n) return;
   Fr w = k < n ? load_fr(T + k) : neg(Fr::one());
-  Fr o;
-  pack29(canonical_small(mul(unpack29<Fr29, 10>(w.v), const29<Fr29>(Fr29::TO261))), o.v);
-  store_fr(out + k, o);
+  auto l = canonical_small(mul(unpack29<Fr29, 10>(w.v), const29<Fr29>(Fr29::TO261)));
+#pragma unroll
+  for (int i = 0; i < 9; i++) out[k].v[i] = l.v[i];
 }
 
 // T[k] = g^k (Montgomery), k < n, g given in Montgomery form: thread k does square-and-multiply

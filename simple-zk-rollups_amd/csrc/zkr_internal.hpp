@@ -12,6 +12,7 @@
 
 namespace zkr {
 
+struct Tw29;  // kernels_ntt.hpp: a butterfly twiddle as nine 29-bit limbs
 void set_error(const char *fmt, ...);
 #define ZKR_HIP_CHECK(expr)                                                                 \
   do {                                                                                      \
@@ -173,7 +174,7 @@ struct zkr_key {
   std::condition_variable slot_freed;
   zkr::MsmPlan plan[zkr::N_TABLES];
   // proof assembly on the host: 4-bit window tables of delta_1 / delta_2 (built on first use)
-  zkr::Fr *tw29 = nullptr, *twl29 = nullptr;  // butterfly twiddles, derived from the arena's tables when the key is set up (not part of the arena)
+  zkr::Tw29 *tw29 = nullptr, *twl29 = nullptr;  // butterfly twiddles, derived from the arena's tables when the key is set up (not part of the arena)
   std::once_flag delta_once;
   std::vector<zkr::G1Affine> delta1_tab;
   std::vector<zkr::G2Affine> delta2_tab;
@@ -198,9 +199,9 @@ struct Prof {  // where a launch helper records its timing spans (null key: stag
 int prof_begin(Prof pf, hipStream_t s, const char *stage);
 void prof_end(Prof pf, hipStream_t s, int span);
 int prof_collect(zkr_key *k, ProofSlot &sl);
-struct NttTables { const Fr *tw, *tw29, *twl29; int tlog; };  // x 2^256 powers of w_{2m} (coset factors); x 2^261 powers for the butterflies (kernels_ntt.hpp)
+struct NttTables { const Fr *tw; const Tw29 *tw29, *twl29; int tlog; };  // x 2^256 powers of w_{2m} (coset factors); x 2^261 powers for the butterflies (kernels_ntt.hpp)
 int ntt_lds_check(int device);  // ZKR_ERR_NO_DEVICE with a clear message when the device cannot hold an NTT tile in LDS
-int ntt_tables29_build(const Fr *tw, uint32_t n_tw, const Fr *twl, uint32_t n_twl, hipStream_t s, Fr **tw29, Fr **twl29);
+int ntt_tables29_build(const Fr *tw, uint32_t n_tw, const Fr *twl, uint32_t n_twl, hipStream_t s, Tw29 **tw29, Tw29 **twl29);
 int run_ntt(hipStream_t s, const Fr *in0, const Fr *in1, Fr *out, const NttTables &tb, int L, bool dif, bool inverse, int pre, int nbat, Prof pf);
 int calc_h_device(zkr_key *k, ProofSlot &sl, hipStream_t s, int nbat = 1);  // sl.d_w -> sl.d_h (bit-reversed), nbat vectors end to end
 int fused_capacity(const ArenaHeader &h, const MsmPlan plan[N_TABLES]);

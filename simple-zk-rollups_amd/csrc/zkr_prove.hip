@@ -91,17 +91,17 @@ static std::vector<PassSpec> ntt_plan(int L) {
 }
 
 // the butterflies' twiddle tables (x 2^261, one entry more than the x 2^256 tables they are made from; kernels_ntt.hpp)
-int ntt_tables29_build(const Fr *tw, uint32_t n_tw, const Fr *twl, uint32_t n_twl, hipStream_t s, Fr **tw29, Fr **twl29) {
+int ntt_tables29_build(const Fr *tw, uint32_t n_tw, const Fr *twl, uint32_t n_twl, hipStream_t s, Tw29 **tw29, Tw29 **twl29) {
   *tw29 = *twl29 = nullptr;
   DevBuf a, b;
   int rc;
-  if ((rc = a.alloc(((size_t)n_tw + 1) * 32)) || (rc = b.alloc(((size_t)n_twl + 1) * 32))) return rc;
-  twiddle261_kernel<<<(n_tw + 256) / 256, 256, 0, s>>>(tw, n_tw, a.as<Fr>());
-  twiddle261_kernel<<<(n_twl + 256) / 256, 256, 0, s>>>(twl, n_twl, b.as<Fr>());
+  if ((rc = a.alloc(((size_t)n_tw + 1) * sizeof(Tw29))) || (rc = b.alloc(((size_t)n_twl + 1) * sizeof(Tw29)))) return rc;
+  twiddle261_kernel<<<(n_tw + 256) / 256, 256, 0, s>>>(tw, n_tw, a.as<Tw29>());
+  twiddle261_kernel<<<(n_twl + 256) / 256, 256, 0, s>>>(twl, n_twl, b.as<Tw29>());
   ZKR_HIP_CHECK(hipGetLastError());
   ZKR_HIP_CHECK(hipStreamSynchronize(s));  // the proving streams are non-blocking: they do not order themselves after this one
-  *tw29 = (Fr *)a.release();
-  *twl29 = (Fr *)b.release();
+  *tw29 = (Tw29 *)a.release();
+  *twl29 = (Tw29 *)b.release();
   return 0;
 }
 
@@ -932,7 +932,7 @@ int zkr_ntt(void *data_std, unsigned logn, int inverse, int device) {
   ingest_kernel<<<(unsigned)((n + 255) / 256), 256>>>(d, d, n);  // any 256-bit word -> below r, as the proving path does with witnesses: the passes state bounds on what they load
   twiddle_table_kernel<<<(unsigned)((n + 255) / 256), 256>>>(tw, (uint32_t)n, host_root_of_unity(logn + 1));
   twiddle_table_kernel<<<((1u << TWL_LOG) + 255) / 256, 256>>>(twl, 1u << TWL_LOG, host_root_of_unity(TWL_LOG + 1));
-  Fr *tw29 = nullptr, *twl29 = nullptr;
+  Tw29 *tw29 = nullptr, *twl29 = nullptr;
   rc = ntt_tables29_build(tw, (uint32_t)n, twl, 1u << TWL_LOG, nullptr, &tw29, &twl29);
   btw29.p = tw29; btwl29.p = twl29;
   if (!rc) rc = run_ntt(nullptr, d, nullptr, d, NttTables{tw, tw29, twl29, (int)logn}, (int)logn, true, inverse != 0, PRE_NONE, 1, Prof{nullptr, nullptr});  // natural -> bit-reversed

@@ -1,0 +1,53 @@
+# Round-3 measurement set on one MI355X (run through gpurun):  bash tools/profile_round3.sh <part> <tag>   -> gpurun_out/<tag>/
+#   part a: bench lines of every BASELINE size (2^20 pipelined / synchronous, 2^22, 2^24 rollup-shaped and dense)
+#   part b: kernel stats of the benchmarked command (rocprofv3 --kernel-trace --stats), isolated kernel durations (ZKR_SERIAL=1),
+#           HBM traffic (FETCH_SIZE / WRITE_SIZE in separate --pmc passes), SQ counters per kernel at 2^20
+#   part c: the counter set BASELINE configs[2] asks for at 2^22 (FETCH_SIZE, WRITE_SIZE, SQ_INSTS_VALU, SQ_WAVES, LDS bank conflicts)
+#   part d: timeline of one synchronous proof of the tx circuit (2^17) and of one 2^20 proof
+# rocprofv3 is always given the program itself after `--` (python3 ...), and --pmc passes carry --kernel-trace only.
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+PART=${1:-a}; O=gpurun_out/${2:-r3p}; mkdir -p $O
+LIGHT="--no-cpu-baseline --no-tx-circuit --no-bcast-modes"
+if [ $PART = a ]; then
+  python3 bench.py --no-pipeline $LIGHT > $O/bench_sync.json 2>/dev/null
+  python3 bench.py --log-m 22 --steps 20 $LIGHT > $O/bench_2_22.json 2>/dev/null
+  python3 bench.py --log-m 24 --steps 6 --warmup 1 $LIGHT > $O/bench_2_24_rollup.json 2>/dev/null
+  python3 bench.py --log-m 24 --shape dense --steps 6 --warmup 1 $LIGHT > $O/bench_2_24_dense.json 2>/dev/null
+  for f in bench_sync bench_2_22 bench_2_24_rollup bench_2_24_dense; do python3 -c "
+import json; d=json.load(open('$O/$f.json')); print('$f', round(d['value'],2), 'proofs/s', round(d['ms_per_step'],2), 'ms')"; done
+fi
+if [ $PART = b ]; then
+  rocprofv3 --kernel-trace --stats -d $O/trace -- python3 bench.py --steps 20 --warmup 3 $LIGHT > $O/bench_traced.json 2>$O/trace.err
+  python3 profiles/summarize_rocpd.py $(find $O/trace -name "*.db" | head -1) 0 > $O/kernel_stats.md
+  python3 profiles/occupancy_timeline.py $(find $O/trace -name "*.db" | head -1) > $O/queue_occupancy.txt; rm -rf $O/trace
+  ZKR_SERIAL=1 rocprofv3 --kernel-trace --stats -d $O/strace -- python3 bench.py --steps 4 --warmup 1 --no-pipeline $LIGHT > $O/bench_serial.json 2>$O/strace.err
+  python3 profiles/summarize_rocpd.py $(find $O/strace -name "*.db" | head -1) 0 > $O/serial_kernel_stats.md; rm -rf $O/strace
+  ZKR_SERIAL=1 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pf -- python3 bench.py --steps 2 --warmup 1 --no-pipeline $LIGHT > /dev/null 2>$O/pf.err
+  ZKR_SERIAL=1 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pw -- python3 bench.py --steps 2 --warmup 1 --no-pipeline $LIGHT > /dev/null 2>$O/pw.err
+  python3 profiles/summarize_pmc.py $(find $O/pf -name "*.db" | head -1) $(find $O/pw -name "*.db" | head -1) $O/pmc_traffic.json 20 2 > $O/pmc_traffic.md; rm -rf $O/pf $O/pw
+  for c in SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_SALU; do
+    ZKR_SERIAL=1 timeout 600 rocprofv3 --kernel-trace --pmc $c -d $O/$c -- python3 bench.py --steps 2 --warmup 1 --no-pipeline $LIGHT > /dev/null 2>$O/$c.err
+    DB=$(find $O/$c -name "*.db" | head -1)
+    if [ -n "$DB" ]; then python3 profiles/summarize_counter.py $DB $c > $O/$c.md; else tail -3 $O/$c.err; fi
+    rm -rf $O/$c
+  done
+  head -14 $O/kernel_stats.md | cut -c1-160; head -12 $O/pmc_traffic.md; head -12 $O/SQ_INSTS_VALU.md
+fi
+if [ $PART = c ]; then
+  for c in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU SQ_WAVES SQ_LDS_BANK_CONFLICT; do
+    ZKR_SERIAL=1 timeout 900 rocprofv3 --kernel-trace --pmc $c -d $O/$c -- python3 bench.py --log-m 22 --steps 2 --warmup 1 --no-pipeline $LIGHT > /dev/null 2>$O/$c.err
+    DB=$(find $O/$c -name "*.db" | head -1)
+    if [ -n "$DB" ]; then python3 profiles/summarize_counter.py $DB $c > $O/c22_$c.md; else tail -3 $O/$c.err; fi
+    rm -rf $O/$c
+  done
+  ZKR_SERIAL=1 rocprofv3 --kernel-trace --stats -d $O/st22 -- python3 bench.py --log-m 22 --steps 3 --warmup 1 --no-pipeline $LIGHT > $O/bench_2_22_serial.json 2>$O/st22.err
+  python3 profiles/summarize_rocpd.py $(find $O/st22 -name "*.db" | head -1) 0 > $O/serial_kernel_stats_2_22.md; rm -rf $O/st22
+  head -12 $O/c22_FETCH_SIZE.md; head -12 $O/c22_SQ_LDS_BANK_CONFLICT.md
+fi
+if [ $PART = d ]; then
+  rocprofv3 --kernel-trace -d $O/ttx -- python3 tools/tx_single.py 12 > $O/tx_single.txt 2>$O/ttx.err
+  python3 profiles/timeline.py $(find $O/ttx -name "*.db" | head -1) 8 > $O/timeline_one_tx_proof.txt; rm -rf $O/ttx
+  rocprofv3 --kernel-trace -d $O/t20 -- python3 bench.py --steps 6 --warmup 2 --no-pipeline $LIGHT > $O/bench_sync_traced.json 2>$O/t20.err
+  python3 profiles/timeline.py $(find $O/t20 -name "*.db" | head -1) 4 > $O/timeline_one_2_20_proof.txt; rm -rf $O/t20
+  cat $O/tx_single.txt; head -60 $O/timeline_one_tx_proof.txt
+fi
