@@ -511,7 +511,7 @@ def main():
     ap.add_argument("--shape", choices=["rollup", "dense"], default="rollup",
                     help="synthetic circuit: rollup-shaped (BASELINE configs[1..3]) or dense random (configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--js-sample-log-m", type=int, default=10)
+    ap.add_argument("--js-sample-log-m", type=int, default=12, help="size the snarkjs-shaped JS baseline is measured at (about 23 s at 2^12; scaled linearly to --log-m)")
     ap.add_argument("--no-js-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="synchronous proofs, one at a time (latency)")
     ap.add_argument("--no-tx-circuit", action="store_true", help="skip the BatchProcessTx(2, 6) legs (SURVEY 8(f-3)) and the drop-in caller leg")
@@ -674,14 +674,15 @@ def main():
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
         traffic, traffic_src, proof_traffic = None, None, None
         try:  # HBM bytes per launch from the committed PMC passes (bench.py cannot collect PMCs itself)
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")))
+            pmc_file = next(f for f in ("r3_pmc_traffic.json", "r2_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
             if pmc["config"]["log_m"] == args.log_m and args.shape == "rollup":
                 # whole proof: every kernel of the proving path (not key build), per ingest_kernel launch = per proof
                 skip = ("precompute", "fixed_base", "twiddle", "gather", "fq_mul_bench", "rocclr_copy")
                 per_run = sum(v["hbm_bytes_per_launch"] * v["launches"] for k, v in pmc["kernels"].items() if not any(x in k for x in skip))
                 proof_traffic = per_run / pmc["kernels"]["ingest_kernel"]["launches"]
                 traffic = pmc["kernels"][dom.replace("<Fq>", "<Fq>")]["hbm_bytes_per_launch"]
-                traffic_src = "profiles/r2_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 read correction)"
+                traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 read correction)" % pmc_file
         except Exception:
             pass
         # the kernels of the path that STREAM (SURVEY 8(d) regime 1), each against the HBM peak: algorithmic bytes per launch
@@ -731,10 +732,11 @@ def main():
             # whole proof: every field multiplication of the path (Fq and Fr cost the same) over the time per proof.
             # mixed addition MADD_G1 / MADD_G2 per table entry (in units of one hot-path multiplication, see the constants at the top; the NTT and QAP products are the 8 x 32-bit kind, counted one for one); NTT: 6 transforms of (m/2) log2 m butterflies + 5m
             # element-wise products; QAP rows: one per non-zero; bucket reduction: 2 full additions (ADD_G1 / ADD_G2) per
-            # bucket + the group sums (about 8 per group of 32 buckets)
+            # bucket + the group sums (about 8 per group of 32 buckets), three G1 bucket sets (C and H share one) and the G2 one
             m, lg = info["domainSize"], info["domainSize"].bit_length() - 1
             nb = 1 << (win["A"][0] - 1)
-            red = (2 * nb + 8 * (nb >> 5)) * (ADD_G1 * 4 + ADD_G2)
+            n_red_g1 = 3 if win["C"] == win["H"] else 4   # C and H share one bucket set and ONE reduction when their geometry agrees (round 3)
+            red = (2 * nb + 8 * (nb >> 5)) * (ADD_G1 * n_red_g1 + ADD_G2)
             total_mul = (MADD_G1 * g1_pts * win["A"][1] + MADD_G2 * info["ptsB2"] * win["B2"][1] + 6 * (m // 2) * lg + 5 * m
                          + info["nnzA"] + info["nnzB"] + red)
             gw = total_mul / (elapsed / args.steps) / 1e9
@@ -763,7 +765,7 @@ def main():
             "hbm_whole_proof": None if proof_traffic is None else {
                 "bytes_per_proof": proof_traffic, "GBps_per_gpu": proof_traffic / (elapsed / args.steps) / 1e9,
                 "frac_of_peak": proof_traffic / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBPS,
-                "source": "sum over the proving kernels of profiles/r2_pmc_traffic.json (x2 read rule: an upper bound for the 64-byte gathers)"},
+                "source": "sum over the proving kernels of profiles/%s (x2 read rule: an upper bound for the 64-byte gathers)" % pmc_file},
         }
         if world == 1 and not args.no_cpu_baseline:  # before the key goes: the GPU proof of the CPU leg's witness is compared with the CPU proofs
             cpu_lm = args.cpu_sample_log_m if args.cpu_sample_log_m is not None else min(args.log_m, 20)
