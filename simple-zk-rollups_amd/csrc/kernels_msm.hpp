@@ -435,6 +435,7 @@ static __global__ __launch_bounds__(SCAN_THREADS) void msm_order_kernel(const ui
 // bucket accumulation: thread per bucket, buckets taken in `order` (fullest first): the 64 lanes of a
 // wavefront get buckets of (almost) equal occupancy, so no lane idles while another finishes, and the long
 // buckets start first.  The next entry and its point are fetched while the current addition runs.
+constexpr int ACC_ONTO = 1, ACC_ZERO_BIG = 2;  // flags of the accumulation kernels' `onto` argument
 #ifndef ZKR_ACC_THREADS
 #define ZKR_ACC_THREADS 256
 #endif
@@ -449,11 +450,16 @@ static __global__ __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per
   const uint32_t t = blockIdx.x * ACC_THREADS + threadIdx.x;
   if (t >= nb) return;
   const uint32_t b = order[t];
-  if (counts[b] == BIG_MARK) return;  // msm_big_kernel owns it
+  // msm_big_kernel owns an oversized bucket.  ACC_ZERO_BIG: its slot is cleared here, because the partial sums will be ADDED
+  // to it later (the first table of a shared bucket set: see ACC_ONTO)
+  if (counts[b] == BIG_MARK) {
+    if (onto & ACC_ZERO_BIG) store_pod(buckets + b, XYZZ<F>::inf());
+    return;
+  }
   uint32_t o0 = offsets[b], o1 = offsets[b + 1];
-  // onto: the bucket set already holds another table's sums over the same bucket geometry (C before H: only C + H is ever
-  // needed, so one bucket set and ONE reduction chain serve both tables)
-  XYZZ29<C> acc = onto ? unpack_xyzz(load_pod(buckets + b)) : XYZZ29<C>::inf();
+  // ACC_ONTO: the bucket set already holds another table's sums over the same bucket geometry (C before H: only C + H is
+  // ever needed, so one bucket set and ONE reduction chain serve both tables)
+  XYZZ29<C> acc = (onto & ACC_ONTO) ? unpack_xyzz(load_pod(buckets + b)) : XYZZ29<C>::inf();
   if (PREFETCH) {
     if (o0 < o1) {
       uint32_t e = entries[o0];
@@ -499,10 +505,13 @@ static __global__ __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per
   const uint32_t slot = t / SPLIT, sub = t % SPLIT;
   if (slot >= nb) return;  // uniform over the SPLIT lanes of a bucket
   const uint32_t b = order[slot];
-  if (counts[b] == BIG_MARK) return;
+  if (counts[b] == BIG_MARK) {  // see msm_accum_kernel
+    if ((onto & ACC_ZERO_BIG) && sub == 0) store_pod(buckets + b, XYZZ<F>::inf());
+    return;
+  }
   using C = typename CoordOf<F>::C;
   const uint32_t o0 = offsets[b], o1 = offsets[b + 1];
-  XYZZ29<C> acc = onto && sub == 0 ? unpack_xyzz(load_pod(buckets + b)) : XYZZ29<C>::inf();  // see msm_accum_kernel
+  XYZZ29<C> acc = (onto & ACC_ONTO) && sub == 0 ? unpack_xyzz(load_pod(buckets + b)) : XYZZ29<C>::inf();  // see msm_accum_kernel
   uint32_t e = o0 + sub < o1 ? entries[o0 + sub] : 0u;
   for (uint32_t j = o0 + sub; j < o1; j += SPLIT) {
     uint32_t en = j + SPLIT < o1 ? entries[j + SPLIT] : 0u;

@@ -271,7 +271,7 @@ static int msm_sort_enqueue(Prof pf, hipStream_t s, const uint32_t *rank, const 
 // bucket accumulation of one point table over a finished sort (`srt` may belong to another table with the
 // same point set: B1 and B2 share one)
 template <class F>
-static int msm_accum_enqueue(Prof pf, hipStream_t s, const Affine<F> *pts, uint32_t n, int nbat, const MsmPlan &pl, const MsmWorkspace &srt, MsmWorkspace &ws, bool onto = false) {
+static int msm_accum_enqueue(Prof pf, hipStream_t s, const Affine<F> *pts, uint32_t n, int nbat, const MsmPlan &pl, const MsmWorkspace &srt, MsmWorkspace &ws, int onto = 0) {
   if (n == 0) return 0;
   const uint32_t nb = pl.nb * (uint32_t)nbat;
   int sp = prof_begin(pf, s, MsmCfg<F>::ACC_STAGE);
@@ -285,7 +285,7 @@ static int msm_accum_enqueue(Prof pf, hipStream_t s, const Affine<F> *pts, uint3
   const int split = split_env ? atoi(split_env) : nb <= (1u << 17) ? 4 : 1;  // tx circuit (2^16 buckets): 379 / 455 / 458 / 393 proofs/s at 1 / 2 / 4 / 8
   if (split > 1) {
     const unsigned sgrid = (unsigned)(((size_t)nb * split + ACC_THREADS - 1) / ACC_THREADS);
-#define ZKR_ACC_SPLIT_LAUNCH(SP) msm_accum_split_kernel<F, MsmCfg<F>::ACC_W, SP><<<sgrid, ACC_THREADS, 0, s>>>(pts, srt.offsets, srt.entries, nb, srt.counts, srt.order, (XYZZ<F> *)ws.buckets, onto ? 1 : 0)
+#define ZKR_ACC_SPLIT_LAUNCH(SP) msm_accum_split_kernel<F, MsmCfg<F>::ACC_W, SP><<<sgrid, ACC_THREADS, 0, s>>>(pts, srt.offsets, srt.entries, nb, srt.counts, srt.order, (XYZZ<F> *)ws.buckets, onto)
     switch (split) {
       case 2: ZKR_ACC_SPLIT_LAUNCH(2); break;
       case 8: ZKR_ACC_SPLIT_LAUNCH(8); break;
@@ -298,7 +298,7 @@ static int msm_accum_enqueue(Prof pf, hipStream_t s, const Affine<F> *pts, uint3
   }
   const unsigned grid = (nb + ACC_THREADS - 1) / ACC_THREADS;
   static const int acc_prio = getenv("ZKR_ACC_PRIO") ? atoi(getenv("ZKR_ACC_PRIO")) : 0;
-#define ZKR_ACC_LAUNCH(W) msm_accum_kernel<F, W, MsmCfg<F>::ACC_PREFETCH><<<grid, ACC_THREADS, 0, s>>>(pts, srt.offsets, srt.entries, nb, srt.counts, srt.order, (XYZZ<F> *)ws.buckets, acc_prio, onto ? 1 : 0)
+#define ZKR_ACC_LAUNCH(W) msm_accum_kernel<F, W, MsmCfg<F>::ACC_PREFETCH><<<grid, ACC_THREADS, 0, s>>>(pts, srt.offsets, srt.entries, nb, srt.counts, srt.order, (XYZZ<F> *)ws.buckets, acc_prio, onto)
   switch (acc_w) {
     case 1: ZKR_ACC_LAUNCH(1); break;
     case 3: ZKR_ACC_LAUNCH(3); break;
@@ -488,8 +488,8 @@ static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *const *d_ws
   };
   // C and H are only ever needed as C + H (App. B step 4: pi_c): when their bucket geometry agrees, H is accumulated ONTO
   // C's bucket set and one reduction chain serves both -- a bucket reduction (2 x 2^19 full additions, ~1.6 % of a proof's
-  // instructions) and one latency chain less.  C's chain then ends with its oversized buckets in place (ev_h), which H's
-  // accumulation waits for; H's own oversized buckets are added to what their buckets hold.
+  // instructions) and one latency chain less.  Oversized buckets of either table are ADDED to the shared set after H's
+  // accumulation (C's accumulation clears their slots), so no accumulation waits for a reduction stream.
   static const bool no_merge = getenv("ZKR_NO_MERGE_CH") != nullptr;
   const MsmPlan &pc = k->plan[T_C], &ph = k->plan[T_H];
   const bool merge_ch = !no_merge && h.npts[T_C] && h.npts[T_H] && pc.c == ph.c && pc.nbw == ph.nbw && pc.glog == ph.glog && pc.S == ph.S;
@@ -522,16 +522,13 @@ static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *const *d_ws
     if (t == T_B2) rc = msm_big_enqueue<Fq2>(pf, rs, (const G2Affine *)pts, h.npts[t], k->plan[t], srt, sl.ws[t]);
     else rc = msm_big_enqueue<Fq>(pf, rs, (const G1Affine *)pts, h.npts[t], k->plan[t], srt, sl.ws[t]);
     if (rc) return rc;
-    if (t == T_C && merge_ch) {  // C's oversized buckets go in at once (the accumulation never touches them); that ends C's chain
-      if ((rc = msm_big_finish_enqueue<Fq>(pf, rs, h.npts[t], srt, sl.ws[t]))) return rc;
-      if (!serial) ZKR_HIP_CHECK(hipEventRecord(sl.ev_h, rs));
-    }
-    if (onto && !serial) {
-      ZKR_HIP_CHECK(hipStreamWaitEvent(sa, sl.ev_h, 0));
-      if (acc_on_chain) ZKR_HIP_CHECK(hipStreamWaitEvent(sa, sl.ev_done[T_C], 0));  // C's accumulation ran on another stream
-    }
+    if (t == T_C && merge_ch && !serial) ZKR_HIP_CHECK(hipEventRecord(sl.ev_h, rs));  // C's partial sums are on their way: H's chain adds them in
+    if (onto && acc_on_chain && !serial) ZKR_HIP_CHECK(hipStreamWaitEvent(sa, sl.ev_done[T_C], 0));  // C's accumulation ran on another stream
+    // shared bucket set: C's accumulation clears the slots of ITS oversized buckets (their sums are added after H's
+    // accumulation, so H's accumulation waits for nothing but C's accumulation in front of it on the same stream)
+    const int flags = onto ? ACC_ONTO : (t == T_C && merge_ch ? ACC_ZERO_BIG : 0);
     if (t == T_B2) rc = msm_accum_enqueue<Fq2>(pf, sa, (const G2Affine *)pts, h.npts[t], nbat, k->plan[t], srt, dst);
-    else rc = msm_accum_enqueue<Fq>(pf, sa, (const G1Affine *)pts, h.npts[t], nbat, k->plan[t], srt, dst, onto);
+    else rc = msm_accum_enqueue<Fq>(pf, sa, (const G1Affine *)pts, h.npts[t], nbat, k->plan[t], srt, dst, flags);
     if (rc) return rc;
     if (!serial) ZKR_HIP_CHECK(hipEventRecord(sl.ev_done[t], sa));
     if (t == T_C && merge_ch) return 0;
@@ -540,7 +537,10 @@ static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *const *d_ws
       if ((rc = msm_big_finish_enqueue<Fq2>(pf, rs, h.npts[t], srt, sl.ws[t]))) return rc;
       return result_event(t, rs, msm_reduce_enqueue<Fq2>(pf, rs, h.npts[t], nbat, k->plan[t], srt, sl.ws[t]));
     }
-    if (onto) {  // partial sums from H's buffer, buckets / reduction buffers / result of C's workspace
+    if (onto) {  // both tables' oversized buckets are ADDED to what the shared set holds: C's partial sums (its own sort's list), then H's
+      if (!serial) ZKR_HIP_CHECK(hipStreamWaitEvent(rs, sl.ev_h, 0));
+      MsmWorkspace mixc = dst;  // C's workspace: its partials, its buckets
+      if ((rc = msm_big_finish_enqueue<Fq>(pf, rs, h.npts[T_C], sl.ws[sort_src[T_C]], mixc, true))) return rc;
       MsmWorkspace mix = dst;
       mix.big_partials = sl.ws[t].big_partials;
       if ((rc = msm_big_finish_enqueue<Fq>(pf, rs, h.npts[t], srt, mix, true))) return rc;
