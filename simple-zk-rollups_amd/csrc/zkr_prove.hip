@@ -518,11 +518,16 @@ static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *const *d_ws
       ZKR_HIP_CHECK(hipStreamWaitEvent(rs, sl.ev_sorted[sort_src[t]], 0));
       if (sa != rs) ZKR_HIP_CHECK(hipStreamWaitEvent(sa, sl.ev_sorted[sort_src[t]], 0));
     }
-    // oversized buckets: partial sums into the table's OWN partials buffer (needs only the sort, runs beside the accumulation)
-    if (t == T_B2) rc = msm_big_enqueue<Fq2>(pf, rs, (const G2Affine *)pts, h.npts[t], k->plan[t], srt, sl.ws[t]);
-    else rc = msm_big_enqueue<Fq>(pf, rs, (const G1Affine *)pts, h.npts[t], k->plan[t], srt, sl.ws[t]);
+    // oversized buckets: partial sums into the table's OWN partials buffer (needs only the sort, runs beside the accumulation).
+    // C's, when C shares H's bucket set, go to the G2 chain's stream: C has no chain of its own, and behind the other G1 chains
+    // they would start after H's accumulation has ended (a single tx proof waited 0.1 ms for them)
+    static const bool c_big_on_g2 = getenv("ZKR_C_BIG_OWN_STREAM") == nullptr;
+    hipStream_t bs = (t == T_C && merge_ch && !serial && c_big_on_g2) ? k->red_stream[0] : rs;
+    if (bs != rs) ZKR_HIP_CHECK(hipStreamWaitEvent(bs, sl.ev_sorted[sort_src[t]], 0));
+    if (t == T_B2) rc = msm_big_enqueue<Fq2>(pf, bs, (const G2Affine *)pts, h.npts[t], k->plan[t], srt, sl.ws[t]);
+    else rc = msm_big_enqueue<Fq>(pf, bs, (const G1Affine *)pts, h.npts[t], k->plan[t], srt, sl.ws[t]);
     if (rc) return rc;
-    if (t == T_C && merge_ch && !serial) ZKR_HIP_CHECK(hipEventRecord(sl.ev_h, rs));  // C's partial sums are on their way: H's chain adds them in
+    if (t == T_C && merge_ch && !serial) ZKR_HIP_CHECK(hipEventRecord(sl.ev_h, bs));  // C's partial sums are on their way: H's chain adds them in
     if (onto && acc_on_chain && !serial) ZKR_HIP_CHECK(hipStreamWaitEvent(sa, sl.ev_done[T_C], 0));  // C's accumulation ran on another stream
     // shared bucket set: C's accumulation clears the slots of ITS oversized buckets (their sums are added after H's
     // accumulation, so H's accumulation waits for nothing but C's accumulation in front of it on the same stream)
