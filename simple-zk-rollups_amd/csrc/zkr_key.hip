@@ -164,6 +164,19 @@ int key_alloc_workspace(zkr_key *k) {
   // reduction streams: the chains of one proof add up to ~6 ms of serialised launches, so on a single in-order
   // stream they, not the accumulations, set the pace with two proofs in flight (94 vs 106 proofs/s with two)
   for (int t = 0; t < N_TABLES; t++) k->plan[t] = msm_plan(t == T_H ? h.m : h.n, h.npts[t], (int)h.win_c[t]);
+  // experiment knob: reduction group size of the G2 table alone (its reduce1 chain is the longest of a proof)
+  if (const char *e = getenv("ZKR_MSM_GLOG_G2")) {
+    int v = atoi(e);
+    MsmPlan &pl = k->plan[T_B2];
+    if (v >= 1 && v <= 6 && v <= pl.c - 1) {
+      pl.glog = v;
+      uint32_t ng = pl.nbw >> pl.glog, ntask = (uint32_t)(pl.c - 1 - pl.glog) + 2;
+      uint32_t S = (ng + 2047) / 2048;
+      if (S > 16) S = 16;
+      if (S > MSM_THREADS / ntask) S = MSM_THREADS / ntask;
+      pl.S = S < 1 ? 1 : S;
+    }
+  }
   // three reduction streams for circuits that fill the chip alone (same-box rounds at 2^20: 136.3 against 132.1 proofs/s with
   // two), two for keys whose proofs are fused into shared launches (fewer, fatter chains; with two the key's four streams
   // have a hardware queue each: 2^16 1745 against 1680, 2^17 943 against 910, 2^18 514 against 492, 2^19 237 against 231,
