@@ -70,31 +70,68 @@ struct MsmGeom {
   uint32_t batch;    // proofs fused into the launches (small circuits): `batch` bucket sets of nbw buckets laid end to end
 };
 
-// Signed-digit recoding state: scalar kept in 8 registers and shifted right by c each window so the
+// Signed-digit recoding state: scalar kept in 9 registers and shifted right by c each window so the
 // digit is always the low bits (no runtime-indexed register array -> no scratch).
+//
+// Top-window spreading (round 3).  K = ceil(255 / c) windows cover c K bits, but a scalar has 254: at c = 20 the top window only
+// ever sees 14 bits, so its 2^20 digits pile onto the 12 400 lowest buckets -- 105 entries in each of them against a mean of 26,
+// and since a bucket is one thread's chain, those 194 wavefronts WERE the accumulation kernel: 825 us for a G1 table, whatever
+// its instruction count or occupancy (profiles/r3_ab_top_window_spreading.txt).  A multiple of the group order changes no
+// product: s P = (s + t r) P for a point of order r (every point of G1; the key's G2 points, which the setup makes multiples of
+// the generator).  So a scalar whose top window is in play is recoded as s + t r with t = (its index) mod tmax, tmax = the
+// largest count for which (t + 1) r still fits c K - 1 bits (42 at c = 20: no signed digit overflows): the top digits then spread
+// over the whole bucket range (13.5 / 13 of the mean at most).  Scalars below 2^(c (K - 1)) -- zeros, booleans, 64-bit values --
+// stay as they are: their top digit is zero, and as s + t r they would cost K additions instead of one.
 struct DigitIter {
-  uint32_t s[8];
+  uint32_t s[9];
   uint32_t carry;
-  __device__ __forceinline__ void init(const uint32_t *p) {
+  __device__ __forceinline__ void init(const uint32_t *p, uint32_t index = 0, uint32_t tmax = 0, int top_bit = 256) {
     const uint4 *q = reinterpret_cast<const uint4 *>(p);
     uint4 a = q[0], b = q[1];
     s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w; s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
+    s[8] = 0;
     carry = 0;
+    if (tmax > 1 && top_bit < 256) {
+      // top window in play: any bit at or above top_bit = c (K - 1)
+      const int tw = top_bit >> 5, to = top_bit & 31;
+      uint32_t hi = 0;
+#pragma unroll
+      for (int i = 0; i < 8; i++) hi |= i > tw ? s[i] : (i == tw ? s[i] >> to : 0u);
+      const uint32_t t = hi ? index % tmax : 0u;
+      uint64_t cy = 0;
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        cy += (uint64_t)s[i] + (uint64_t)t * FrParams::P[i];
+        s[i] = (uint32_t)cy;
+        cy >>= 32;
+      }
+      s[8] = (uint32_t)cy;
+    }
   }
   __device__ __forceinline__ bool is_zero() const {
-    return (s[0] | s[1] | s[2] | s[3] | s[4] | s[5] | s[6] | s[7] | carry) == 0;
+    return (s[0] | s[1] | s[2] | s[3] | s[4] | s[5] | s[6] | s[7] | s[8] | carry) == 0;
   }
   // returns signed digit in [-2^(c-1), 2^(c-1)]
   __device__ __forceinline__ int next(int c) {
     uint32_t raw = (s[0] & ((1u << c) - 1)) + carry;
 #pragma unroll
-    for (int i = 0; i < 7; i++) s[i] = (s[i] >> c) | (s[i + 1] << (32 - c));
-    s[7] >>= c;
+    for (int i = 0; i < 8; i++) s[i] = (s[i] >> c) | (s[i + 1] << (32 - c));
+    s[8] >>= c;
     int d = (int)raw;
     if (raw > (1u << (c - 1))) { d -= (1 << c); carry = 1; } else { carry = 0; }
     return d;
   }
 };
+// tmax of DigitIter::init for a window geometry: the largest t count with (t + 1) r <= 2^(c K - 1), capped (0 or 1: no spreading)
+inline uint32_t digit_spread_tmax(int c, int K) {
+  const int bits = c * K - 1;  // s + t r must stay below 2^bits so that the top signed digit does not overflow
+  if (bits <= 254) return 0;
+  if (bits - 254 >= 12) return 4096;
+  // floor(2^bits / r) for bits in [255, 265]: r = 0x30644e72e131a029... * 2^192, i.e. 2^254 / r = 1.3226...
+  const double ratio = 1.3225;  // 2^254 / r = 1.32253..., rounded DOWN
+  uint32_t t = (uint32_t)(ratio * (double)(1u << (bits - 254)));
+  return t;
+}
 
 __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
 
@@ -115,7 +152,7 @@ __device__ __forceinline__ uint32_t digit_bucket(int d) { return (uint32_t)(d < 
 // Fused batches (small circuits, DESIGN.md 3.2 "several proofs per launch"): `scalars` holds the vectors of several proofs
 // end to end, n_per scalars each; proof p owns the bucket ranges [p * nR1, (p + 1) * nR1) -- i.e. its own bucket set --
 // so one sort / accumulation / reduction launch serves every proof of the batch.  One proof: n_per = n, nR1 = nR.
-static __global__ __launch_bounds__(MSM_THREADS) void msm_digits_count_kernel(const Fr *scalars, uint32_t n, uint32_t n_per, int c, int K, int nbl_log, uint32_t nR1, uint32_t nR, uint32_t *rng_cnt) {
+static __global__ __launch_bounds__(MSM_THREADS) void msm_digits_count_kernel(const Fr *scalars, uint32_t n, uint32_t n_per, int c, int K, int nbl_log, uint32_t nR1, uint32_t nR, uint32_t *rng_cnt, uint32_t tmax) {
   ZKR_PREP_SETPRIO();
   __shared__ uint32_t s_cnt[MAX_RANGES];
   if (threadIdx.x < nR) s_cnt[threadIdx.x] = 0;
@@ -124,7 +161,7 @@ static __global__ __launch_bounds__(MSM_THREADS) void msm_digits_count_kernel(co
   if (i < n) {
     const uint32_t r0 = (i / n_per) * nR1;
     DigitIter it;
-    it.init(scalars[i].v);
+    it.init(scalars[i].v, i, tmax, c * (K - 1));
     for (int k = 0; k < K; k++) {
       int d = it.next(c);
       if (d != 0) atomicAdd(&s_cnt[r0 + (digit_bucket(d) >> nbl_log)], 1u);
@@ -137,7 +174,7 @@ static __global__ __launch_bounds__(MSM_THREADS) void msm_digits_count_kernel(co
 // rng_cnt complete, rng_fill zeroed.  Block 0 also publishes rng_off[0..nR] (exclusive prefix) for the table sorts.
 static __global__ __launch_bounds__(MSM_THREADS) void msm_digits_scatter_kernel(const Fr *scalars, uint32_t n, uint32_t n_per, int c, int K, int nbl_log, uint32_t nR1, uint32_t nR,
                                                                               const uint32_t *rng_cnt, uint32_t *rng_fill, uint32_t *rng_off,
-                                                                              uint32_t *ent_s, uint32_t *ent_b) {
+                                                                              uint32_t *ent_s, uint32_t *ent_b, uint32_t tmax) {
   ZKR_PREP_SETPRIO();
   __shared__ uint32_t s_cnt[MAX_RANGES], s_base[MAX_RANGES];
   if (threadIdx.x < nR) s_cnt[threadIdx.x] = 0;
@@ -146,7 +183,7 @@ static __global__ __launch_bounds__(MSM_THREADS) void msm_digits_scatter_kernel(
   const uint32_t r0 = i < n ? (i / n_per) * nR1 : 0u;
   DigitIter it;
   if (i < n) {
-    it.init(scalars[i].v);
+    it.init(scalars[i].v, i, tmax, c * (K - 1));
     for (int k = 0; k < K; k++) {
       int d = it.next(c);
       if (d != 0) atomicAdd(&s_cnt[r0 + (digit_bucket(d) >> nbl_log)], 1u);
@@ -169,7 +206,7 @@ static __global__ __launch_bounds__(MSM_THREADS) void msm_digits_scatter_kernel(
   }
   __syncthreads();
   if (i < n) {
-    it.init(scalars[i].v);
+    it.init(scalars[i].v, i, tmax, c * (K - 1));
     const uint32_t lo_mask = (1u << nbl_log) - 1u;
     for (int k = 0; k < K; k++) {
       int d = it.next(c);

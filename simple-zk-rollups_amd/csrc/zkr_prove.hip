@@ -235,8 +235,10 @@ static int msm_digits_enqueue(Prof pf, hipStream_t s, const Fr *scalars, uint32_
   int sp = prof_begin(pf, s, "msm_sort");
   ZKR_HIP_CHECK(hipMemsetAsync(dl.rng, 0, 2 * MAX_RANGES * 4, s));
   unsigned grid = (n + MSM_THREADS - 1) / MSM_THREADS;
-  msm_digits_count_kernel<<<grid, MSM_THREADS, 0, s>>>(scalars, n, n_per, pl.c, pl.K, nbl_log, pl.nR, nR, dl.rng);
-  msm_digits_scatter_kernel<<<grid, MSM_THREADS, 0, s>>>(scalars, n, n_per, pl.c, pl.K, nbl_log, pl.nR, nR, dl.rng, dl.rng + MAX_RANGES, dl.rng + 2 * MAX_RANGES, dl.ent_s, dl.ent_b);
+  static const bool no_spread = getenv("ZKR_NO_TOP_SPREAD") != nullptr;  // A/B: the top window as it falls (DigitIter)
+  const uint32_t tmax = no_spread ? 0u : digit_spread_tmax(pl.c, pl.K);
+  msm_digits_count_kernel<<<grid, MSM_THREADS, 0, s>>>(scalars, n, n_per, pl.c, pl.K, nbl_log, pl.nR, nR, dl.rng, tmax);
+  msm_digits_scatter_kernel<<<grid, MSM_THREADS, 0, s>>>(scalars, n, n_per, pl.c, pl.K, nbl_log, pl.nR, nR, dl.rng, dl.rng + MAX_RANGES, dl.rng + 2 * MAX_RANGES, dl.ent_s, dl.ent_b, tmax);
   prof_end(pf, s, sp);
   ZKR_HIP_CHECK(hipGetLastError());
   return 0;
