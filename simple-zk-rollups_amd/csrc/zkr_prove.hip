@@ -219,8 +219,12 @@ template <> struct MsmCfg<Fq> { static constexpr int ACC_W = 2, RED_W = 2; stati
 // 29-bit-limb arithmetic and cannot co-reside: they wait for a CU to drain instead of running under the accumulation
 // (116.7 proofs/s).  Measured with the budget for 1 / 2 / 3 wavefronts per SIMD once the NTT priority was in place:
 // 132.9 / 133.1 / 129.6 proofs/s (at 3 the spills of the Fq2 running sums cost more than the co-residency buys).
+// Round 3: 1 -- at one wavefront per SIMD the Fq2 forms keep everything in registers (arch + accumulation VGPRs: 314-394, no
+// scratch in reduce1 / reduce2 / big / big_finish, where the budget for two left 496 / 192 / 196 / 208 B per lane spilled);
+// proof rate, tx-circuit rate and single-proof latencies are the same either way in same-box runs (141.6 / 140.7 against
+// 140.6 / 141.5 proofs/s, 2.28 against 2.27 ms, 8.50 against 8.52 ms), so the variant without the scratch traffic ships.
 #ifndef ZKR_RED_W_G2
-#define ZKR_RED_W_G2 2
+#define ZKR_RED_W_G2 1
 #endif
 template <> struct MsmCfg<Fq2> { static constexpr int ACC_W = 2, RED_W = ZKR_RED_W_G2; static constexpr bool ACC_PREFETCH = false;  // a second 128-byte point in flight only costs spills (same speed)
   static constexpr const char *ACC_STAGE = "msm_accum_g2"; };
