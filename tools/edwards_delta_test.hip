@@ -1,8 +1,9 @@
-// debug: delta = (p.y - a p.x)(q.x + q.y) on device vs host for q = (0, one), q = random
+// Standalone check of the witness program's delta = (p.y - a p.x)(q.x + q.y) on the device against the host (round 3: inlined into the
+// scalar-multiplication loop of rollup_witness.hpp hipcc 7.2 miscompiled this expression; standalone it is right: bad 0 of 256).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <string.h>
-#include "../../simple-zk-rollups_amd/csrc/field.hpp"
+#include "../simple-zk-rollups_amd/csrc/field.hpp"
 using namespace zkr;
 __host__ __device__ static Fr delta_of(const Fr &px, const Fr &py, const Fr &qx, const Fr &qy, const Fr &a) {
   return mul(sub(py, mul(px, a)), add(qx, qy));
