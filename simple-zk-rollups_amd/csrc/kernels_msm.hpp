@@ -141,81 +141,142 @@ __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
 //
 // Stage 1, once per SCALAR VECTOR (w serves the A, B1, B2 and C tables, h serves H): every non-zero digit
 // becomes a record in the list of its bucket range -- ent_s = scalar index, ent_b = window << 17 | (bucket
-// within the range) << 1 | (d < 0).  Two launches: count per range, then scatter (digits are recomputed; a
-// scalar is 32 bytes and the recoding a few shifts).  Workgroups reserve their span of each list with one
-// atomic per range, so the lists are written in runs.
+// within the range) << 1 | (d < 0).  Two launches: count per list, then scatter (digits are recomputed; a
+// scalar is 32 bytes and the recoding a few shifts).
+//
+// Lists and write combining (round 3).  A range's list is the concatenation of DIGIT_XCDS sub-lists, one per XCD slot
+// (x = workgroup index mod 8, the round-robin placement of workgroups on the eight XCDs), and a workgroup reserves its span
+// of sub-list (r, x) with one atomic: neighbouring spans then belong to workgroups of the SAME XCD, whose L2 completes the
+// 64-byte lines they share before they leave.  The workgroup first groups its records by range in LDS (DIGIT_STAGE records:
+// spt x 256 scalars x K digits) and then writes every run with consecutive lanes -- with 256 lists a workgroup writing in
+// arrival order keeps 256 lines open for its whole life, a few thousand of them per XCD: more than its L2 holds, and the
+// lines left in pieces (WRITE_SIZE 469 MB for 108 MB of records; profiles/r3_ab_sort_ranges.md).  Vectors whose K is too
+// large for the stage (tiny circuits: K = 64 at c = 4) take the unstaged form of the same kernel.
+// A workgroup takes spt x 256 scalars: every workgroup ends with one global atomic per range on the same counters, and those
+// -- 262 k at 2^20 with one scalar per thread -- were the count kernel's bound (81 us against 30 at spt = 4).
 constexpr int ENT_WIN_SHIFT = 17;
+constexpr int ENT_TAG_SHIFT = 24;     // staged records carry their list's range in bits 24..31 until they are written out
+static_assert(MSM_THREADS == 256, "the digit kernels keep one range counter per thread");
 constexpr uint32_t MAX_RANGES = 256;  // x SORT_RANGE_MAX buckets = 2^21: window sizes up to c = 22 (2^24-point tables), or fused batches of small circuits
+constexpr uint32_t DIGIT_XCDS = 8;
+constexpr uint32_t DIGIT_STAGE = 2 * 256 * 13;  // records a workgroup groups in LDS (x 8 bytes = 53 KB)
+constexpr size_t DIGIT_RNG_WORDS = 2 * DIGIT_XCDS * MAX_RANGES + MAX_RANGES + 1;  // counts[r][x] | fill cursors[r][x] | range offsets[nR + 1]
 
 __device__ __forceinline__ uint32_t digit_bucket(int d) { return (uint32_t)(d < 0 ? -d : d) - 1u; }
 
 // Fused batches (small circuits, DESIGN.md 3.2 "several proofs per launch"): `scalars` holds the vectors of several proofs
 // end to end, n_per scalars each; proof p owns the bucket ranges [p * nR1, (p + 1) * nR1) -- i.e. its own bucket set --
 // so one sort / accumulation / reduction launch serves every proof of the batch.  One proof: n_per = n, nR1 = nR.
-static __global__ __launch_bounds__(MSM_THREADS) void msm_digits_count_kernel(const Fr *scalars, uint32_t n, uint32_t n_per, int c, int K, int nbl_log, uint32_t nR1, uint32_t nR, uint32_t *rng_cnt, uint32_t tmax) {
+static __global__ __launch_bounds__(MSM_THREADS) void msm_digits_count_kernel(const Fr *scalars, uint32_t n, uint32_t n_per, int c, int K, int nbl_log, uint32_t nR1, uint32_t nR, uint32_t *rng_cnt, uint32_t tmax, int spt) {
   ZKR_PREP_SETPRIO();
   __shared__ uint32_t s_cnt[MAX_RANGES];
   if (threadIdx.x < nR) s_cnt[threadIdx.x] = 0;
   __syncthreads();
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) {
-    const uint32_t r0 = (i / n_per) * nR1;
-    DigitIter it;
-    it.init(scalars[i].v, i, tmax, c * (K - 1));
-    for (int k = 0; k < K; k++) {
-      int d = it.next(c);
-      if (d != 0) atomicAdd(&s_cnt[r0 + (digit_bucket(d) >> nbl_log)], 1u);
+  for (int q = 0; q < spt; q++) {
+    uint32_t i = (blockIdx.x * spt + q) * blockDim.x + threadIdx.x;
+    if (i < n) {
+      const uint32_t r0 = (i / n_per) * nR1;
+      DigitIter it;
+      it.init(scalars[i].v, i, tmax, c * (K - 1));
+      for (int k = 0; k < K; k++) {
+        int d = it.next(c);
+        if (d != 0) atomicAdd(&s_cnt[r0 + (digit_bucket(d) >> nbl_log)], 1u);
+      }
     }
   }
   __syncthreads();
-  if (threadIdx.x < nR && s_cnt[threadIdx.x]) atomicAdd(&rng_cnt[threadIdx.x], s_cnt[threadIdx.x]);
+  if (threadIdx.x < nR && s_cnt[threadIdx.x]) atomicAdd(&rng_cnt[threadIdx.x * DIGIT_XCDS + blockIdx.x % DIGIT_XCDS], s_cnt[threadIdx.x]);
 }
 
-// rng_cnt complete, rng_fill zeroed.  Block 0 also publishes rng_off[0..nR] (exclusive prefix) for the table sorts.
+// rng_cnt complete, rng_fill zeroed; same grid and spt as the count.  Block 0 also publishes rng_off[0..nR] (exclusive prefix
+// over the ranges) for the table sorts.  STAGED: dynamic LDS of DIGIT_STAGE x 8 bytes, needs spt * 256 * K <= DIGIT_STAGE.
+template <bool STAGED>
 static __global__ __launch_bounds__(MSM_THREADS) void msm_digits_scatter_kernel(const Fr *scalars, uint32_t n, uint32_t n_per, int c, int K, int nbl_log, uint32_t nR1, uint32_t nR,
                                                                               const uint32_t *rng_cnt, uint32_t *rng_fill, uint32_t *rng_off,
-                                                                              uint32_t *ent_s, uint32_t *ent_b, uint32_t tmax) {
+                                                                              uint32_t *ent_s, uint32_t *ent_b, uint32_t tmax, int spt) {
   ZKR_PREP_SETPRIO();
-  __shared__ uint32_t s_cnt[MAX_RANGES], s_base[MAX_RANGES];
-  if (threadIdx.x < nR) s_cnt[threadIdx.x] = 0;
+  extern __shared__ __attribute__((aligned(16))) uint32_t s_stage[];  // STAGED: [DIGIT_STAGE] scalar indices, [DIGIT_STAGE] tagged records
+  __shared__ uint32_t s_cnt[MAX_RANGES], s_base[MAX_RANGES], s_loc[MAX_RANGES];
+  const uint32_t t = threadIdx.x, x = blockIdx.x % DIGIT_XCDS;
+  if (t < nR) s_cnt[t] = 0;
   __syncthreads();
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t r0 = i < n ? (i / n_per) * nR1 : 0u;
-  DigitIter it;
-  if (i < n) {
-    it.init(scalars[i].v, i, tmax, c * (K - 1));
-    for (int k = 0; k < K; k++) {
-      int d = it.next(c);
-      if (d != 0) atomicAdd(&s_cnt[r0 + (digit_bucket(d) >> nbl_log)], 1u);
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t run = 0;
-    for (uint32_t r = 0; r < nR; r++) { s_base[r] = run; run += rng_cnt[r]; }
-    if (blockIdx.x == 0) {
-      for (uint32_t r = 0; r < nR; r++) rng_off[r] = s_base[r];
-      rng_off[nR] = run;
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x < nR) {
-    uint32_t mine = s_cnt[threadIdx.x];
-    s_base[threadIdx.x] += mine ? atomicAdd(&rng_fill[threadIdx.x], mine) : 0u;
-    s_cnt[threadIdx.x] = 0;
-  }
-  __syncthreads();
-  if (i < n) {
-    it.init(scalars[i].v, i, tmax, c * (K - 1));
-    const uint32_t lo_mask = (1u << nbl_log) - 1u;
-    for (int k = 0; k < K; k++) {
-      int d = it.next(c);
-      if (d != 0) {
-        uint32_t b = digit_bucket(d), r = r0 + (b >> nbl_log);
-        uint32_t pos = s_base[r] + atomicAdd(&s_cnt[r], 1u);
-        ent_s[pos] = i;
-        ent_b[pos] = ((uint32_t)k << ENT_WIN_SHIFT) | ((b & lo_mask) << 1) | (d < 0 ? 1u : 0u);
+  for (int q = 0; q < spt; q++) {
+    uint32_t i = (blockIdx.x * spt + q) * blockDim.x + t;
+    if (i < n) {
+      const uint32_t r0 = (i / n_per) * nR1;
+      DigitIter it;
+      it.init(scalars[i].v, i, tmax, c * (K - 1));
+      for (int k = 0; k < K; k++) {
+        int d = it.next(c);
+        if (d != 0) atomicAdd(&s_cnt[r0 + (digit_bucket(d) >> nbl_log)], 1u);
       }
+    }
+  }
+  __syncthreads();
+  // range starts = exclusive prefix of the range totals (one range per thread); this workgroup's sub-list starts behind the
+  // sub-lists of the lower XCD slots.  The same scan carries the workgroup's own counts (high half) -> start of each run in the stage
+  uint32_t own = 0, before = 0;
+  if (t < nR) {
+    const uint4 *cq = reinterpret_cast<const uint4 *>(rng_cnt + t * DIGIT_XCDS);
+    const uint4 lo = cq[0], hi = cq[1];
+    const uint32_t cx[DIGIT_XCDS] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+    for (uint32_t j = 0; j < DIGIT_XCDS; j++) { own += cx[j]; before += j < x ? cx[j] : 0u; }
+  }
+  const uint32_t mine = t < nR ? s_cnt[t] : 0u;
+  s_base[t] = own;
+  s_loc[t] = mine;
+  __syncthreads();
+  for (uint32_t off = 1; off < MAX_RANGES; off <<= 1) {
+    uint32_t v = t >= off ? s_base[t - off] : 0u, w = t >= off ? s_loc[t - off] : 0u;
+    __syncthreads();
+    s_base[t] += v;
+    s_loc[t] += w;
+    __syncthreads();
+  }
+  const uint32_t start = s_base[t] - own, lstart = s_loc[t] - mine, ltotal = s_loc[MAX_RANGES - 1];
+  __syncthreads();
+  if (t < nR) {
+    if (blockIdx.x == 0) {
+      rng_off[t] = start;
+      if (t == nR - 1) rng_off[nR] = start + own;
+    }
+    s_base[t] = start + before + (mine ? atomicAdd(&rng_fill[t * DIGIT_XCDS + x], mine) : 0u);
+    s_loc[t] = lstart;
+    s_cnt[t] = 0;
+  }
+  __syncthreads();
+  const uint32_t lo_mask = (1u << nbl_log) - 1u;
+  for (int q = 0; q < spt; q++) {
+    uint32_t i = (blockIdx.x * spt + q) * blockDim.x + t;
+    if (i < n) {
+      const uint32_t r0 = (i / n_per) * nR1;
+      DigitIter it;
+      it.init(scalars[i].v, i, tmax, c * (K - 1));
+      for (int k = 0; k < K; k++) {
+        int d = it.next(c);
+        if (d != 0) {
+          const uint32_t b = digit_bucket(d), r = r0 + (b >> nbl_log);
+          const uint32_t rec = ((uint32_t)k << ENT_WIN_SHIFT) | ((b & lo_mask) << 1) | (d < 0 ? 1u : 0u);
+          const uint32_t slot = atomicAdd(&s_cnt[r], 1u);
+          if (STAGED) {
+            s_stage[s_loc[r] + slot] = i;
+            s_stage[DIGIT_STAGE + s_loc[r] + slot] = rec | (r << ENT_TAG_SHIFT);
+          } else {
+            ent_s[s_base[r] + slot] = i;
+            ent_b[s_base[r] + slot] = rec;
+          }
+        }
+      }
+    }
+  }
+  if (STAGED) {
+    __syncthreads();
+    for (uint32_t e = t; e < ltotal; e += MSM_THREADS) {  // consecutive lanes, consecutive addresses inside a run
+      const uint32_t rec = s_stage[DIGIT_STAGE + e], r = rec >> ENT_TAG_SHIFT;
+      const uint32_t pos = s_base[r] + (e - s_loc[r]);
+      ent_s[pos] = s_stage[e];
+      ent_b[pos] = rec & ((1u << ENT_TAG_SHIFT) - 1u);
     }
   }
 }
@@ -228,6 +289,8 @@ static __global__ __launch_bounds__(MSM_THREADS) void msm_digits_scatter_kernel(
 constexpr int SORT_THREADS = 256;
 constexpr uint32_t SORT_RANGE_MAX = 8192;  // bucket counters per workgroup (x 4 B of LDS): small footprint, so these
                                            // memory/LDS-bound workgroups find room on CUs busy with an accumulation
+constexpr uint32_t SORT_RANGE_DEFAULT = 2048;   // buckets per range and records per (range, chunk) workgroup that msm_plan aims
+constexpr uint32_t SORT_CHUNK_RECORDS = 3328;   // for (zkr_key.hip: the L2 footprint of the scatter decides)
 constexpr uint32_t RANK_NONE = 0xffffffffu;
 constexpr int SORT_UNROLL = 8;
 

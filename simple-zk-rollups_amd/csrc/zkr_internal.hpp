@@ -74,7 +74,7 @@ constexpr uint64_t ARENA_MAGIC = 0x333059454b524b5aull;  // "ZKRKEY03" (03: poin
 
 // digit records of one scalar vector, split by bucket range (kernels_msm.hpp "digit sort", stage 1)
 struct DigitLists {
-  uint32_t *rng = nullptr;  // [MAX_RANGES] counts | [MAX_RANGES] fill cursors | [MAX_RANGES + 1] offsets
+  uint32_t *rng = nullptr;  // counts[range][XCD slot] | fill cursors[range][XCD slot] | range offsets[nR + 1]  (kernels_msm.hpp DIGIT_RNG_WORDS)
   uint32_t *ent_s = nullptr, *ent_b = nullptr;
 };
 

@@ -76,12 +76,19 @@ MsmPlan msm_plan(size_t n_scalars, size_t n, int c_fixed) {
   uint64_t mean = (uint64_t)n * pl.K / pl.nbw + 1;
   pl.big_thresh = mean * 8 > 256 ? (uint32_t)(mean * 8) : 256;
   if (const char *e = getenv("ZKR_MSM_BIG")) { int v = atoi(e); if (v >= 1) pl.big_thresh = (uint32_t)v; }
-  // digit sort: one workgroup per (bucket range, chunk): about four per CU at full size, chunks of >= 4096 points
-  pl.nbl = pl.nbw < SORT_RANGE_MAX ? pl.nbw : SORT_RANGE_MAX;
+  // digit sort: one workgroup per (bucket range, chunk).  Ranges of 2048 buckets, chunks of ~3300 records: what counts is the
+  // window of the entry array that the workgroups resident on one XCD scatter into together -- it has to stay in that XCD's
+  // 4 MB L2 until its lines are complete (kernels_msm.hpp sort_block_to_chunk).  At 2^20 points: 256 ranges x 16 chunks, a
+  // range's window is 212 KB, ~12 ranges in flight per XCD; with ranges of 8192 buckets (round 2) the same 16 chunks per range
+  // kept 6.8 MB in flight per XCD and every line left L2 in pieces (WRITE_SIZE 386 MB per launch for 54 MB of entries, against
+  // 98 MB now; kernel 159 -> 83 us; profiles/r3_ab_sort_ranges.md).
+  uint32_t range_max = SORT_RANGE_DEFAULT;
+  if (const char *e = getenv("ZKR_SORT_NBL")) { uint32_t v = (uint32_t)atoi(e); if (v >= 64 && v <= SORT_RANGE_MAX && (v & (v - 1)) == 0) range_max = v; }
+  if (pl.nbw / range_max > MAX_RANGES) range_max = pl.nbw / MAX_RANGES;
+  pl.nbl = pl.nbw < range_max ? pl.nbw : range_max;
   pl.nR = pl.nbw / pl.nbl;
-  uint32_t J = (uint32_t)((n + 4095) / 4096);
-  uint32_t jmax = 1024 / pl.nR ? 1024 / pl.nR : 1u;
-  if (J > jmax) J = jmax;
+  uint64_t J64 = ((uint64_t)n * pl.K + (uint64_t)pl.nR * SORT_CHUNK_RECORDS - 1) / ((uint64_t)pl.nR * SORT_CHUNK_RECORDS);
+  uint32_t J = J64 > 64 ? 64u : (uint32_t)J64;
   if (J < 1) J = 1;
   if (const char *e = getenv("ZKR_MSM_J")) { int v = atoi(e); if (v >= 1 && v <= 256) J = (uint32_t)v; }
   pl.J = J;
@@ -118,7 +125,7 @@ static int alloc_msm_ws(MsmWorkspace &ws, size_t n, const MsmPlan &pl, size_t xy
   return 0;
 }
 int digit_lists_alloc(DigitLists &dl, size_t n_scalars, const MsmPlan &pl) {  // n_scalars: of the whole (fused) vector
-  ZKR_HIP_CHECK(hipMalloc(&dl.rng, (3 * MAX_RANGES + 1) * 4));
+  ZKR_HIP_CHECK(hipMalloc(&dl.rng, DIGIT_RNG_WORDS * 4));
   ZKR_HIP_CHECK(hipMalloc(&dl.ent_s, (size_t)pl.K * n_scalars * 4 + 4));
   ZKR_HIP_CHECK(hipMalloc(&dl.ent_b, (size_t)pl.K * n_scalars * 4 + 4));
   return 0;

@@ -237,12 +237,21 @@ static int msm_digits_enqueue(Prof pf, hipStream_t s, const Fr *scalars, uint32_
   int nbl_log = 0;
   while ((1u << nbl_log) < pl.nbl) nbl_log++;
   int sp = prof_begin(pf, s, "msm_sort");
-  ZKR_HIP_CHECK(hipMemsetAsync(dl.rng, 0, 2 * MAX_RANGES * 4, s));
-  unsigned grid = (n + MSM_THREADS - 1) / MSM_THREADS;
+  ZKR_HIP_CHECK(hipMemsetAsync(dl.rng, 0, 2 * DIGIT_XCDS * MAX_RANGES * 4, s));
+  // scalars per thread (kernels_msm.hpp, stage 1): four from 2^18 scalars on; the staged scatter takes what its LDS stage holds
+  static const int spt_env = getenv("ZKR_DIGITS_SPT") ? atoi(getenv("ZKR_DIGITS_SPT")) : 0;
+  static const bool no_stage = getenv("ZKR_DIGITS_NO_STAGE") != nullptr;  // A/B: records written in arrival order
+  int spt = spt_env >= 1 && spt_env <= 16 ? spt_env : n >= (1u << 18) ? 4 : n >= (1u << 17) ? 2 : 1;
+  const uint32_t per_scalar = (uint32_t)pl.K * MSM_THREADS;
+  const bool staged = !no_stage && per_scalar <= DIGIT_STAGE;
+  if (staged && (uint32_t)spt * per_scalar > DIGIT_STAGE) spt = (int)(DIGIT_STAGE / per_scalar);
+  unsigned grid = (n + MSM_THREADS * spt - 1) / (MSM_THREADS * spt);
   static const bool no_spread = getenv("ZKR_NO_TOP_SPREAD") != nullptr;  // A/B: the top window as it falls (DigitIter)
   const uint32_t tmax = no_spread ? 0u : digit_spread_tmax(pl.c, pl.K);
-  msm_digits_count_kernel<<<grid, MSM_THREADS, 0, s>>>(scalars, n, n_per, pl.c, pl.K, nbl_log, pl.nR, nR, dl.rng, tmax);
-  msm_digits_scatter_kernel<<<grid, MSM_THREADS, 0, s>>>(scalars, n, n_per, pl.c, pl.K, nbl_log, pl.nR, nR, dl.rng, dl.rng + MAX_RANGES, dl.rng + 2 * MAX_RANGES, dl.ent_s, dl.ent_b, tmax);
+  uint32_t *cnt = dl.rng, *fill = dl.rng + DIGIT_XCDS * MAX_RANGES, *off = dl.rng + 2 * DIGIT_XCDS * MAX_RANGES;
+  msm_digits_count_kernel<<<grid, MSM_THREADS, 0, s>>>(scalars, n, n_per, pl.c, pl.K, nbl_log, pl.nR, nR, cnt, tmax, spt);
+  if (staged) msm_digits_scatter_kernel<true><<<grid, MSM_THREADS, (size_t)DIGIT_STAGE * 8, s>>>(scalars, n, n_per, pl.c, pl.K, nbl_log, pl.nR, nR, cnt, fill, off, dl.ent_s, dl.ent_b, tmax, spt);
+  else msm_digits_scatter_kernel<false><<<grid, MSM_THREADS, 0, s>>>(scalars, n, n_per, pl.c, pl.K, nbl_log, pl.nR, nR, cnt, fill, off, dl.ent_s, dl.ent_b, tmax, spt);
   prof_end(pf, s, sp);
   ZKR_HIP_CHECK(hipGetLastError());
   return 0;
@@ -258,7 +267,7 @@ static int msm_sort_enqueue(Prof pf, hipStream_t s, const uint32_t *rank, const 
   const uint32_t nb = pl.nb * (uint32_t)nbat;  // the bucket sets of the batch end to end
   const unsigned sort_grid = pl.nR * (unsigned)nbat * pl.J;
   const size_t lds = (size_t)pl.nbl * 4;
-  const uint32_t *rng_off = dl.rng + 2 * MAX_RANGES;
+  const uint32_t *rng_off = dl.rng + 2 * DIGIT_XCDS * MAX_RANGES;
   msm_hist_kernel<<<sort_grid, SORT_THREADS, lds, s>>>(dl.ent_s, dl.ent_b, rng_off, rank, n_scalars, pl.nbl, pl.J, ws.chunk_cnt);
   msm_colscan_kernel<<<(nb + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, s>>>(ws.chunk_cnt, nb, pl.nbl, pl.J, ws.counts);
   unsigned scan_blocks = (nb + SCAN_BLOCK - 1) / SCAN_BLOCK;

@@ -47,7 +47,7 @@ fi
 if [ $PART = d ]; then
   rocprofv3 --kernel-trace -d $O/ttx -- python3 tools/tx_single.py 12 > $O/tx_single.txt 2>$O/ttx.err
   python3 profiles/timeline.py $(find $O/ttx -name "*.db" | head -1) 8 > $O/timeline_one_tx_proof.txt; rm -rf $O/ttx
-  rocprofv3 --kernel-trace -d $O/t20 -- python3 bench.py --steps 6 --warmup 2 --no-pipeline $LIGHT > $O/bench_sync_traced.json 2>$O/t20.err
-  python3 profiles/timeline.py $(find $O/t20 -name "*.db" | head -1) 4 > $O/timeline_one_2_20_proof.txt; rm -rf $O/t20
+  rocprofv3 --kernel-trace -d $O/t20 -- python3 tools/sync_single.py 20 8 > $O/sync_single.txt 2>$O/t20.err
+  python3 profiles/timeline.py $(find $O/t20 -name "*.db" | head -1) 3 > $O/timeline_one_2_20_proof.txt; rm -rf $O/t20
   cat $O/tx_single.txt; head -60 $O/timeline_one_tx_proof.txt
 fi
