@@ -442,3 +442,42 @@ def test_prove_batch_from_host_buffers_equals_single_proofs(small_case):
         key.prove_batch([wits[0][:-32]])
     assert e.value.code == -3
     assert key.prove(wits[1], 5, 6) == coracle.prove(c["pkb"], wits[1], 5, 6)      # the key is still usable
+
+
+_SORT_KNOB_CHILD = r"""
+import random, sys
+sys.path[:0] = %r
+import coracle, zkr_hip
+from bn254 import Q, R, G1_GEN, g1_add, g1_mul
+MONT = 1 << 256
+le = lambda v: int(v).to_bytes(32, "little")
+rnd = random.Random(77)
+pts, P = [], G1_GEN
+for i in range(300):
+    pts.append(None if i %% 7 == 3 else P)
+    P = g1_add(P, G1_GEN) if i %% 5 else g1_mul(P, 3)
+for n in (1000, 20000):
+    sc = [rnd.randrange(R) for _ in range(n)]
+    for i in range(0, n, 11):
+        sc[i] = rnd.choice([0, 1, 1, 2, R - 1, (1 << 64) - 1, 1 << 253])
+    pb = b"".join(le(0) + le(MONT %% Q) if pts[i %% 300] is None else le(pts[i %% 300][0] * MONT %% Q) + le(pts[i %% 300][1] * MONT %% Q) for i in range(n))
+    sb = b"".join(le(x) for x in sc)
+    assert zkr_hip.msm_g1(pb, sb) == coracle.msm_g1(pb, sb), n
+print("sort knobs ok")
+"""
+
+
+@pytest.mark.parametrize("knobs", [
+    {"ZKR_DIGITS_NO_STAGE": "1"},                      # records written in arrival order (the form tiny circuits take)
+    {"ZKR_DIGITS_SPT": "1"}, {"ZKR_DIGITS_SPT": "3"},  # scalars per thread of the record kernels
+    {"ZKR_SORT_NBL": "64", "ZKR_MSM_J": "5"},          # many small bucket ranges, odd chunk count
+    {"ZKR_SORT_NBL": "8192", "ZKR_MSM_J": "16"},       # round 2's geometry
+    {"ZKR_SORT_XCD": "0"},
+], ids=lambda k: ",".join("%s=%s" % kv for kv in k.items()))
+def test_digit_sort_geometry_knobs_change_no_result(knobs):
+    """The sort's tuning knobs (bucket-range size, chunks, scalars per thread, staged record lists, XCD mapping) are read when
+    the library plans a key, so each setting runs in its own process: same MSM results as the oracle under every one."""
+    import os, subprocess, sys
+    env = dict(os.environ, **knobs)
+    out = subprocess.run([sys.executable, "-c", _SORT_KNOB_CHILD % (sys.path,)], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "sort knobs ok" in out.stdout, out.stderr[-2000:]
