@@ -167,7 +167,9 @@ struct zkr_key {
   hipStream_t prep_stream = nullptr;               // digit records, digit sorts, calcH
   hipStream_t red_stream[zkr::N_TABLES] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // reduction chains: [0] the G2 table, the G1 tables
                                                                                            // round-robin over [1..n_red)
-  int n_red = 1;
+  hipStream_t aux_stream = nullptr;                // = red_stream[n_all - 1]: C's oversized-bucket partial sums when C shares H's bucket set (zkr_prove.hip c_big)
+  int n_red = 1;                                   // streams the reduction chains rotate over
+  int n_all = 1;                                   // streams in red_stream[] (n_red + the auxiliary one)
   zkr::ProofSlot slot[zkr::PROOF_SLOTS];
   int next_slot = 0;
   std::mutex mu;  // slot hand-out, the enqueue phase of a proof (so two host threads do not interleave launches), stage totals

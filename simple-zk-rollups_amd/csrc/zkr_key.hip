@@ -191,6 +191,10 @@ int key_alloc_workspace(zkr_key *k) {
   k->n_red = fused_capacity(h, k->plan) > 1 ? 2 : 3;
   if (const char *e = getenv("ZKR_RED_STREAMS")) { int v = atoi(e); if (v >= 1 && v <= N_TABLES) k->n_red = v; }
   for (int j = 0; j < k->n_red; j++) ZKR_HIP_CHECK(hipStreamCreateWithPriority(&k->red_stream[j], hipStreamNonBlocking, prio_hi));
+  // one more for C's oversized-bucket sums (and, ZKR_H_CHAIN_AUX, the proof's last chain): an entry of red_stream behind the chains' streams
+  k->n_all = k->n_red < N_TABLES ? k->n_red + 1 : k->n_red;
+  if (k->n_all > k->n_red) ZKR_HIP_CHECK(hipStreamCreateWithPriority(&k->red_stream[k->n_red], hipStreamNonBlocking, prio_hi));
+  k->aux_stream = k->red_stream[k->n_all - 1];
   {
     int rc = ntt_tables29_build((const Fr *)(k->arena + h.off_tw), 1u << h.tlog, (const Fr *)(k->arena + h.off_twl), 1u << TWL_LOG, nullptr, &k->tw29, &k->twl29);
     if (rc) return rc;
@@ -207,7 +211,7 @@ int key_alloc_workspace(zkr_key *k) {
     }
     ZKR_HIP_CHECK(hipEventCreateWithFlags(&sl.ev_w, hipEventDisableTiming));
     ZKR_HIP_CHECK(hipEventCreateWithFlags(&sl.ev_h, hipEventDisableTiming));
-    for (int j = 0; j < k->n_red; j++) ZKR_HIP_CHECK(hipEventCreateWithFlags(&sl.ev_red[j], hipEventDisableTiming));
+    for (int j = 0; j < k->n_all; j++) ZKR_HIP_CHECK(hipEventCreateWithFlags(&sl.ev_red[j], hipEventDisableTiming));
     ZKR_HIP_CHECK(hipMalloc(&sl.d_w, (size_t)h.n * 32 * cap));
     Fr **vecs[5] = {&sl.va, &sl.vb, &sl.ca, &sl.cb, &sl.d_h};
     for (auto v : vecs) ZKR_HIP_CHECK(hipMalloc(v, (size_t)h.m * 32 * cap));

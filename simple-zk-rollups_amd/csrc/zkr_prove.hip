@@ -421,7 +421,7 @@ static int prove_submit_group(zkr_key *k, ProofSlot &sl, const Fr *const *d_wsrc
   if (rc && rc != ZKR_ERR_ARG) {  // ZKR_ERR_ARG: refused before the first launch
     hipStreamSynchronize(k->stream);
     hipStreamSynchronize(k->prep_stream);
-    for (int j = 0; j < k->n_red; j++) hipStreamSynchronize(k->red_stream[j]);
+    for (int j = 0; j < k->n_all; j++) hipStreamSynchronize(k->red_stream[j]);
     sl.spans.clear();
     sl.event_next = 0;
   }
@@ -474,8 +474,11 @@ static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *const *d_ws
   hipStream_t s = k->stream;
   hipStream_t sp = serial ? s : k->prep_stream;
   int g1_next = 0;
+  static const int h_aux_env = getenv("ZKR_H_CHAIN_AUX") ? atoi(getenv("ZKR_H_CHAIN_AUX")) : 0;
+  const bool h_chain_aux = h_aux_env != 0 && !serial;
   auto red_of = [&](int t) -> hipStream_t {  // G2 chain on [0]; G1 chains round-robin over the others
     if (serial) return s;
+    if (t == T_H && h_chain_aux) return k->aux_stream;  // the proof's last chain does not queue behind the earlier G1 chains
     if (t == T_B2 || k->n_red == 1) return k->red_stream[0];
     return k->red_stream[1 + (g1_next++ % (k->n_red - 1))];
   };
@@ -522,6 +525,8 @@ static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *const *d_ws
   static const int sched_env = getenv("ZKR_SCHED") ? atoi(getenv("ZKR_SCHED")) : -1;
   const int sched = sched_env >= 0 ? sched_env : 0;
   const bool early = (sched & 1) != 0 && !serial, acc_on_chain = (sched & 2) != 0 && !serial;
+  static const int c_big_env = getenv("ZKR_C_BIG_FIRST") ? atoi(getenv("ZKR_C_BIG_FIRST")) : -1;  // 0 / 1: never / always (A/B)
+  const bool c_big_first = merge_ch && !serial && (c_big_env >= 0 ? c_big_env != 0 : (nbat == 1 && sl.cap > 1));
   auto accum_table = [&](int t, hipStream_t rs) -> int {
     const MsmWorkspace &srt = sl.ws[sort_src[t]];
     MsmWorkspace &dst = t == T_H && merge_ch ? sl.ws[T_C] : sl.ws[t];  // whose bucket set / reduction buffers the table lands in
@@ -534,15 +539,13 @@ static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *const *d_ws
       if (sa != rs) ZKR_HIP_CHECK(hipStreamWaitEvent(sa, sl.ev_sorted[sort_src[t]], 0));
     }
     // oversized buckets: partial sums into the table's OWN partials buffer (needs only the sort, runs beside the accumulation).
-    // C's, when C shares H's bucket set, go to the G2 chain's stream: C has no chain of its own, and behind the other G1 chains
-    // they would start after H's accumulation has ended (a single tx proof waited 0.1 ms for them)
-    static const bool c_big_on_g2 = getenv("ZKR_C_BIG_OWN_STREAM") == nullptr;
-    hipStream_t bs = (t == T_C && merge_ch && !serial && c_big_on_g2) ? k->red_stream[0] : rs;
-    if (bs != rs) ZKR_HIP_CHECK(hipStreamWaitEvent(bs, sl.ev_sorted[sort_src[t]], 0));
-    if (t == T_B2) rc = msm_big_enqueue<Fq2>(pf, bs, (const G2Affine *)pts, h.npts[t], k->plan[t], srt, sl.ws[t]);
-    else rc = msm_big_enqueue<Fq>(pf, bs, (const G1Affine *)pts, h.npts[t], k->plan[t], srt, sl.ws[t]);
-    if (rc) return rc;
-    if (t == T_C && merge_ch && !serial) ZKR_HIP_CHECK(hipEventRecord(sl.ev_h, bs));  // C's partial sums are on their way: H's chain adds them in
+    // C's, when C shares H's bucket set, were enqueued in front of every chain (c_big_first below)
+    if (!(t == T_C && c_big_first)) {
+      if (t == T_B2) rc = msm_big_enqueue<Fq2>(pf, rs, (const G2Affine *)pts, h.npts[t], k->plan[t], srt, sl.ws[t]);
+      else rc = msm_big_enqueue<Fq>(pf, rs, (const G1Affine *)pts, h.npts[t], k->plan[t], srt, sl.ws[t]);
+      if (rc) return rc;
+      if (t == T_C && merge_ch && !serial) ZKR_HIP_CHECK(hipEventRecord(sl.ev_h, rs));  // C's partial sums are on their way: H's chain adds them in
+    }
     if (onto && acc_on_chain && !serial) ZKR_HIP_CHECK(hipStreamWaitEvent(sa, sl.ev_done[T_C], 0));  // C's accumulation ran on another stream
     // shared bucket set: C's accumulation clears the slots of ITS oversized buckets (their sums are added after H's
     // accumulation, so H's accumulation waits for nothing but C's accumulation in front of it on the same stream)
@@ -569,6 +572,22 @@ static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *const *d_ws
     if ((rc = msm_big_finish_enqueue<Fq>(pf, rs, h.npts[t], srt, sl.ws[t]))) return rc;
     return result_event(t, rs, msm_reduce_enqueue<Fq>(pf, rs, h.npts[t], nbat, k->plan[t], srt, sl.ws[t]));
   };
+  // C shares H's bucket set and has no chain of its own: its oversized-bucket partial sums (needed by H's chain, which adds them
+  // to the shared set) normally take C's turn on a G1 chain's stream.  There they wait for the chains in front of them: in a
+  // single tx proof they ran after H's accumulation had ended, and the proof's last reduction chain started 0.2 ms late
+  // (profiles/r3_07_timeline_one_tx_proof.txt).  For ONE proof of a small circuit (a key that can fuse batches, called with a
+  // single witness: the latency case) they go to the auxiliary stream right behind C's sort: 2.12-2.16 against 2.16-2.24 ms per
+  // tx proof.  Fused batches and large circuits keep C's turn: a fifth active stream costs them 1.5 % / 0.3 % of their rate
+  // (930-943 against 947-964 tx proofs/s, 150.5 against 151.0 at 2^20: tools/ab_c_big_tx.sh).
+  auto c_big = [&]() -> int {
+    if (!c_big_first) return 0;
+    hipStream_t bs = k->aux_stream;
+    ZKR_HIP_CHECK(hipStreamWaitEvent(bs, sl.ev_sorted[sort_src[T_C]], 0));
+    int rc = msm_big_enqueue<Fq>(pf, bs, (const G1Affine *)(ar + h.off_pts[T_C]), h.npts[T_C], k->plan[T_C], sl.ws[sort_src[T_C]], sl.ws[T_C]);
+    if (rc) return rc;
+    ZKR_HIP_CHECK(hipEventRecord(sl.ev_h, bs));
+    return 0;
+  };
   hipStream_t last = s;
   auto chains = [&](std::initializer_list<int> ts) -> int {
     for (int t : ts) {
@@ -585,19 +604,19 @@ static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *const *d_ws
   if (early && (rc = chains({T_B2, T_B1}))) return rc;
   if ((rc = sort_table(T_A))) return rc;
   if (!share_ac && (rc = sort_table(T_C))) return rc;
-  if (early && (rc = chains({T_A, T_C}))) return rc;
+  if (early && ((rc = c_big()) || (rc = chains({T_A, T_C})))) return rc;
   if ((rc = calc_h_device(k, sl, sp, nbat))) return rc;
   if ((rc = msm_digits_enqueue(pf, sp, sl.d_h, h.m, nbat, k->plan[T_H], sl.dig_h))) return rc;
   if ((rc = sort_table(T_H))) return rc;
   // accumulations + reduction chains
   if (early) rc = chains({T_H});
-  else rc = chains({T_B2, T_B1, T_A, T_C, T_H});
+  else { if ((rc = c_big())) return rc; rc = chains({T_B2, T_B1, T_A, T_C, T_H}); }
   if (rc) return rc;
   // completion = every reduction stream done (prove_collect waits for the events on the host).  No stream is made
   // to wait for another, so nothing of the next proof queues behind this one's tail.
   prof_end(pf, last, tot);
   if (!serial) {
-    for (int j = 0; j < k->n_red; j++) ZKR_HIP_CHECK(hipEventRecord(sl.ev_red[j], k->red_stream[j]));
+    for (int j = 0; j < k->n_all; j++) ZKR_HIP_CHECK(hipEventRecord(sl.ev_red[j], k->red_stream[j]));
   } else {
     ZKR_HIP_CHECK(hipEventRecord(sl.ev_red[0], s));
   }
@@ -671,7 +690,7 @@ static int prove_collect(zkr_key *k, ProofSlot &sl, uint8_t *proofs_out) {
   if (trace) clock_gettime(CLOCK_MONOTONIC, &ts2);
   if ((rcw = wait_table(T_C)) || (rcw = wait_table(T_H))) return rcw;
   if (trace) clock_gettime(CLOCK_MONOTONIC, &ts3);
-  for (int j = 0; j < (serial_mode ? 1 : k->n_red); j++) ZKR_HIP_CHECK(hipEventSynchronize(sl.ev_red[j]));  // every stream of the slot is idle (all of it precedes the table events)
+  for (int j = 0; j < (serial_mode ? 1 : k->n_all); j++) ZKR_HIP_CHECK(hipEventSynchronize(sl.ev_red[j]));  // every stream of the slot is idle (all of it precedes the table events)
   if (k->prof_on) { std::lock_guard<std::mutex> lk(k->mu); prof_collect(k, sl); }
   for (int j = 0; j < sl.nbat && !status; j++) {
     // merged bucket sets (prove_submit_enqueue): the one reduction result, C + H, sits in C's workspace
