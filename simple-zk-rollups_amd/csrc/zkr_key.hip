@@ -191,9 +191,12 @@ int key_alloc_workspace(zkr_key *k) {
   k->n_red = fused_capacity(h, k->plan) > 1 ? 2 : 3;
   if (const char *e = getenv("ZKR_RED_STREAMS")) { int v = atoi(e); if (v >= 1 && v <= N_TABLES) k->n_red = v; }
   for (int j = 0; j < k->n_red; j++) ZKR_HIP_CHECK(hipStreamCreateWithPriority(&k->red_stream[j], hipStreamNonBlocking, prio_hi));
-  // one more for C's oversized-bucket sums (and, ZKR_H_CHAIN_AUX, the proof's last chain): an entry of red_stream behind the chains' streams
+  // one more for C's oversized-bucket sums (and, ZKR_H_CHAIN_AUX, the proof's last chain): an entry of red_stream behind the chains' streams.
+  // At the MIDDLE priority: the runtime multiplexes the streams of one priority over GPU_MAX_HW_QUEUES = 4 hardware queues, and a fifth
+  // high-priority stream made the next one created -- the witness builder's (rollup_gpu.hip) -- share a queue with the preparation
+  // stream: its 28 ms kernel then stalled every proof behind it (facade pipeline 623 against 840 batches/s, tools/ab_hw_queues2.sh)
   k->n_all = k->n_red < N_TABLES ? k->n_red + 1 : k->n_red;
-  if (k->n_all > k->n_red) ZKR_HIP_CHECK(hipStreamCreateWithPriority(&k->red_stream[k->n_red], hipStreamNonBlocking, prio_hi));
+  if (k->n_all > k->n_red) ZKR_HIP_CHECK(hipStreamCreateWithPriority(&k->red_stream[k->n_red], hipStreamNonBlocking, (prio_lo + prio_hi) / 2));
   k->aux_stream = k->red_stream[k->n_all - 1];
   {
     int rc = ntt_tables29_build((const Fr *)(k->arena + h.off_tw), 1u << h.tlog, (const Fr *)(k->arena + h.off_twl), 1u << TWL_LOG, nullptr, &k->tw29, &k->twl29);
