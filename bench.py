@@ -381,6 +381,9 @@ def facade_pipeline_leg(local, n_batches=256, chunk=64, witness="gpu"):
                 return
             proofs, pubs = item
             ta = time.perf_counter()
+            if not isinstance(pubs, list):                           # the witnesses' public heads, still on the device
+                head = pubs.cpu().numpy()
+                pubs = [[int.from_bytes(row[32 * j:32 * j + 32].tobytes(), "little") for j in range(n_pub)] for row in head]
             if zkr_hip.verify_batch(vk_bin, proofs, pubs):
                 verified[0] += len(proofs)
             else:
@@ -388,19 +391,19 @@ def facade_pipeline_leg(local, n_batches=256, chunk=64, witness="gpu"):
             if trace is not None:
                 trace.append(("V%d" % len(proofs), ta, time.perf_counter()))
 
-    # chunk plan: the GPU builder's latency is flat (~30 ms whatever the count), so the first chunk is small (the prover starts
-    # after one builder latency), the following ones `chunk` batches each (calls of that size keep the prover's pipeline full);
-    # verification streams behind the proofs in pieces of 16 on four host threads.  (The first batches from the HOST builder
-    # while the GPU builds the second chunk was tried: 16 witnesses on the thread pool take 67 ms beside everything else, the
-    # GPU's first chunk 27 ms -- ZKR_PIPE_HOST_FIRST=16 re-runs it.)
+    # chunk plan: the GPU builder's latency is flat (~30 ms whatever the count, ~60 ms beside a running prover), so it is called
+    # TWICE: for the first `chunk` batches (the prover starts after one builder latency) and for all the others, built while
+    # the first ones are proved (64 proofs take longer than the second call; with a second call of 64 after a first of 32 the
+    # prover waited 25 ms for it).  The prover takes the witnesses in pieces of `chunk` (calls of that size keep its pipeline
+    # full) and verification streams behind the proofs in pieces of 16 on four host threads.  ZKR_PIPE_HOST_FIRST=n: the first
+    # n batches from the HOST builder on the thread pool while the GPU builds its first chunk.
     host_first = min(int(os.environ.get("ZKR_PIPE_HOST_FIRST", "0")), n_batches) if witness == "gpu" else 0
     sizes, left = [], n_batches - host_first
     if left > 0:
-        sizes.append(min(32, chunk, left))
-        left -= sizes[-1]
-    while left > 0:
         sizes.append(min(chunk, left))
         left -= sizes[-1]
+    if left > 0:
+        sizes.append(left)
 
     def gpu_witnesses():                                            # chunk i + 1 is built while chunk i is proved
         import torch
@@ -416,12 +419,15 @@ def facade_pipeline_leg(local, n_batches=256, chunk=64, witness="gpu"):
         q_wit.put(None)
 
     t0 = time.perf_counter()
-    vts = [threading.Thread(target=verifier) for _ in range(4)]     # 0.75 ms of one core per proof; pieces of 16, so the tail after the last proof is short
+    # 0.75 ms of one core per proof; with the GPU builder the host is idle: pieces of 8 on eight threads, so the tail after the
+    # last proof is short; beside the host builder's pool four threads and pieces of 16 (eight cost it 15 %: 499 against 583)
+    n_ver, piece_ver = (8, 8) if witness == "gpu" else (4, 16)
+    vts = [threading.Thread(target=verifier) for _ in range(n_ver)]
     for vt in vts:
         vt.start()
     def to_verify(proofs, pubs):
-        for o in range(0, len(proofs), 16):
-            q_verify.put((proofs[o:o + 16], pubs[o:o + 16]))
+        for o in range(0, len(proofs), piece_ver):
+            q_verify.put((proofs[o:o + piece_ver], pubs[o:o + piece_ver]))
 
     if witness == "gpu":
         wt = threading.Thread(target=gpu_witnesses)
@@ -438,14 +444,14 @@ def facade_pipeline_leg(local, n_batches=256, chunk=64, witness="gpu"):
             t = q_wit.get()
             if t is None:
                 break
-            ta = time.perf_counter()
-            proofs = key.prove_batch_device([t[i].data_ptr() for i in range(t.shape[0])])     # random blinding, as the reference draws it
-            tb = time.perf_counter()
-            head = t[:, 32:32 * (n_pub + 1)].cpu().numpy()
-            pubs = [[int.from_bytes(row[32 * j:32 * j + 32].tobytes(), "little") for j in range(n_pub)] for row in head]
-            if trace is not None:
-                trace += [("P%d" % len(proofs), ta, tb), ("pub", tb, time.perf_counter())]
-            to_verify(proofs, pubs)
+            for o in range(0, t.shape[0], chunk):
+                ta = time.perf_counter()
+                piece = t[o:o + chunk]
+                proofs = key.prove_batch_device([piece[i].data_ptr() for i in range(piece.shape[0])])     # random blinding, as the reference draws it
+                tb = time.perf_counter()
+                if trace is not None:
+                    trace.append(("P%d" % len(proofs), ta, tb))
+                to_verify(proofs, piece[:, 32:32 * (n_pub + 1)])      # the verifier threads fetch the public signals (2.3 KB per proof)
             del t
         wt.join()
     else:
@@ -468,7 +474,7 @@ def facade_pipeline_leg(local, n_batches=256, chunk=64, witness="gpu"):
             "witness": "GPU builder (zkr_rollup_witness_batch_device), witnesses stay in HBM" if witness == "gpu" else "host builder on %d threads" % workers,
             "end_to_end_proofs_per_s": n_batches / el, "ms_per_batch": 1e3 * el / n_batches, "proofs_verified": verified[0],
             "verification_failures": len(failures),
-            "steps": "witness -> proof -> zkr_verify_batch, overlapped (chunk i + 1's witnesses under chunk i's proofs, verification on a host thread)"}
+            "steps": "witness -> proof -> zkr_verify_batch, overlapped (chunk i + 1's witnesses under chunk i's proofs, verification on host threads)"}
 
 
 def self_launch(n_gpus):
