@@ -184,11 +184,14 @@ int key_alloc_workspace(zkr_key *k) {
       pl.S = S < 1 ? 1 : S;
     }
   }
-  // three reduction streams for circuits that fill the chip alone (same-box rounds at 2^20: 136.3 against 132.1 proofs/s with
-  // two), two for keys whose proofs are fused into shared launches (fewer, fatter chains; with two the key's four streams
-  // have a hardware queue each: 2^16 1745 against 1680, 2^17 943 against 910, 2^18 514 against 492, 2^19 237 against 231,
-  // the tx circuit 988 against 957 proofs/s)
-  k->n_red = fused_capacity(h, k->plan) > 1 ? 2 : 3;
+  // Two reduction streams: the G2 chain on [0], the G1 chains one after the other on [1].  Round 2 ran circuits that fill the
+  // chip alone with three (136.3 against 132.1 proofs/s at 2^20); since C and H share one chain and the G2 reductions take a
+  // whole SIMD's registers, the third stream only adds contention for the accumulations: 152.5-153.5 against 145.9-146.6
+  // proofs/s at 2^20 (three same-box rounds), 38.5 against 37.4 at 2^22, a synchronous 2^20 proof 7.75 against 8.0 ms; one
+  // stream: 122 (tools/sweep_knobs2.sh).  Keys whose proofs are fused into shared launches always ran with two (fewer, fatter
+  // chains: 2^16 1745 against 1680, 2^17 943 against 910, 2^18 514 against 492, 2^19 237 against 231, the tx circuit 988
+  // against 957 proofs/s).
+  k->n_red = 2;
   if (const char *e = getenv("ZKR_RED_STREAMS")) { int v = atoi(e); if (v >= 1 && v <= N_TABLES) k->n_red = v; }
   for (int j = 0; j < k->n_red; j++) ZKR_HIP_CHECK(hipStreamCreateWithPriority(&k->red_stream[j], hipStreamNonBlocking, prio_hi));
   // one more for C's oversized-bucket sums (and, ZKR_H_CHAIN_AUX, the proof's last chain): an entry of red_stream behind the chains' streams.
