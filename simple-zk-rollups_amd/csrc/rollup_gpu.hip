@@ -4,6 +4,8 @@
 // per hash, 220 rounds of x -> x^5 in Fr Montgomery arithmetic (3 multiplications per round), so a tree of 2^20 accounts
 // (2^21 - 1 hashes of two elements) is 2.8 * 10^9 multiplications: tens of milliseconds here, minutes in the circomlib
 // BigInt code.  Host counterpart and round constants: rollup.cpp; parity against oracle/rollup.py in tests/test_gpu_rollup.py.
+#include <atomic>
+#include <thread>
 #include "zkr_internal.hpp"
 #include "rollup_witness.hpp"
 
@@ -133,6 +135,67 @@ struct DevView {  // a typed look at device memory owned elsewhere
   void *p;
   template <class T> T *as() const { return static_cast<T *>(p); }
 };
+}  // namespace zkr
+
+// Host fast path of zkr_rollup_witness (rollup.cpp batch_witness): the value program on host threads, one task per
+// (transaction, part) as the GPU builder's wavefronts run it, then the signals to standard form in slices.  inputs_std: the p - 1
+// circuit inputs (32 B standard form, already checked < r); out: (p + 1 + batch * K) x 32 B.  Returns true when the witness is
+// complete and every statement holds; false (nothing promised about `out`) when any statement fails -- the caller then runs the
+// gadget builder, which names the violated statement the way it always did.
+namespace zkr {
+bool rollup_witness_fast_host(uint32_t batch, uint32_t depth, const uint8_t *inputs_std, uint8_t *out_bytes) {
+  const uint32_t p = rollup_n_public(batch, depth), K = rollup_tx_private_count(depth);
+  std::vector<Fr> tab(2 * 253), in(p - 1), w((size_t)batch * K), roots(batch);
+  std::vector<uint32_t> errs((size_t)batch * TX_PARTS, 0);
+  TxConsts k;
+  rollup_device_constants(&k.a, &k.d, k.suborder_m1, tab.data(), tab.data() + 253);
+  k.b8x = tab.data(), k.b8y = tab.data() + 253, k.mimc = mimc_round_constants();
+  memcpy(in.data(), inputs_std, (size_t)(p - 1) * 32);
+  Fr *out = reinterpret_cast<Fr *>(out_bytes);
+  const uint32_t tasks = batch * TX_PARTS;
+  unsigned hw = std::thread::hardware_concurrency();
+  if (const char *e = getenv("ZKR_WITNESS_THREADS")) { int v = atoi(e); if (v >= 1) hw = (unsigned)v; }
+  const uint32_t nthreads = std::max<uint32_t>(1, std::min<uint32_t>(tasks, hw ? hw : 1));
+  const size_t total = (size_t)batch * K, slice = 4096, nslices = (total + slice - 1) / slice;
+  std::atomic<uint32_t> next_task{0}, next_slice{0}, arrived{0};
+  auto worker = [&] {
+    {
+      std::vector<Fr> ws(4 * WS_PTS);
+      for (uint32_t t; (t = next_task.fetch_add(1)) < tasks;) {
+        const uint32_t i = t / TX_PARTS, part = t % TX_PARTS;
+        Fr r;
+        errs[t] = tx_witness(in.data(), batch, depth, i, K, k, w.data() + (size_t)i * K, ws.data(), &r, (int)part);
+        if (part == TX_PARTS - 1) roots[i] = r;
+      }
+    }
+    arrived.fetch_add(1);
+    while (arrived.load() < nthreads) std::this_thread::yield();  // every signal is in place before any slice is converted
+    for (uint32_t c; (c = next_slice.fetch_add(1)) < nslices;) {
+      const size_t lo = (size_t)c * slice, hi = std::min(total, lo + slice);
+      for (size_t s = lo; s < hi; s++) out[(size_t)p + 1 + s] = from_mont(w[s]);
+    }
+  };
+  if (nthreads <= 1) {
+    worker();
+  } else {
+    std::vector<std::thread> th;
+    for (uint32_t t = 1; t < nthreads; t++) th.emplace_back(worker);
+    worker();
+    for (auto &t : th) t.join();
+  }
+  for (uint32_t t = 0; t < tasks; t++)
+    if (errs[t]) return false;
+  for (uint32_t i = 1; i < batch; i++) {  // the root chain (batchprocesstx.circom:67-69)
+    Fr want;
+    if (!tx_read_input(&in[i], want) || !(roots[i - 1] == want)) return false;
+  }
+  Fr one = Fr::zero();
+  one.v[0] = 1;
+  out[0] = one;
+  out[1] = from_mont(roots[batch - 1]);
+  for (uint32_t s = 2; s <= p; s++) out[s] = in[s - 2];
+  return true;
+}
 }  // namespace zkr
 
 using namespace zkr;
