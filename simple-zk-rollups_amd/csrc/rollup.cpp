@@ -820,7 +820,7 @@ static bool batch_witness(uint32_t batch, uint32_t depth, const Fr *inputs, cons
   // Fast path: the value program the GPU builder runs (rollup_witness.hpp), on host threads -- a task per (transaction, part)
   // instead of a thread per transaction, no linear-combination bookkeeping: 5.9 -> ~2 ms for a (2, 6) batch.  tests/test_rollup.py
   // holds the two builders equal signal for signal; whenever a statement fails the gadget builder below runs and names it.
-  static const bool no_fast = getenv("ZKR_WITNESS_GADGETS") != nullptr;
+  const bool no_fast = getenv("ZKR_WITNESS_GADGETS") != nullptr;  // read per call: the tests switch builders inside one process
   if (!no_fast && zkr::rollup_witness_fast_host(batch, depth, inputs_std, out)) {
     *out_buf = out;
     *out_len = total;

@@ -363,17 +363,26 @@ def test_gpu_witness_program_equals_the_host_builder_signal_for_signal():
     the committed golden batch; and where the host builder refuses inputs, the program names the same statement."""
     import rollup as o
     from zkr_hip import rollup as n
+
+    def gadget_witness(c, inputs):  # zkr_rollup_witness with its fast path (this very program on host threads) switched off
+        os.environ["ZKR_WITNESS_GADGETS"] = "1"
+        try:
+            return c.calculate_witness(inputs)
+        finally:
+            del os.environ["ZKR_WITNESS_GADGETS"]
+
     for (batch, depth, seed, self_send) in ((2, 6, 41, False), (2, 6, 43, True), (4, 3, 7, False), (1, 3, 9, False)):
         c = n.RollupCircuit(batch, depth)
         txs, tree, _ = scenario(batch, depth, seed, self_send, n_accounts=5 if depth > 2 else 4)
-        want = c.calculate_witness(as_inputs(txs))
+        want = gadget_witness(c, as_inputs(txs))
         got, stmt, _tx = c.witness_program_host(as_inputs(txs))
         assert stmt is None and got == want, (batch, depth, seed)
+        assert c.calculate_witness(as_inputs(txs)) == want                      # the fast path: (transaction, part) tasks on threads
         assert ints(got)[1] == tree.root
     fx = json.load(open(os.path.join(ROOT, "tests", "golden", "rollup_tx.json")))
     c = n.RollupCircuit(fx["batch"], fx["depth"])
     got, stmt, _tx = c.witness_program_host(fx["inputs"])
-    assert stmt is None and got == c.calculate_witness(fx["inputs"]) and [str(v) for v in c.public_signals(got)] == fx["public_signals"]
+    assert stmt is None and got == gadget_witness(c, fx["inputs"]) == c.calculate_witness(fx["inputs"]) and [str(v) for v in c.public_signals(got)] == fx["public_signals"]
     c = n.RollupCircuit(2, 3)
     for what, needle in (("signature", "signature"), ("nonce", "nonce"), ("sender_path", "sender leaf"), ("recipient_leaf", "recipient leaf"),
                          ("intermediate_root", "intermediate root"), ("chain", "previous one"), ("big_s", "subgroup order"), ("index", "fits the tree")):
