@@ -235,6 +235,45 @@ int zkt_final_exp_check(uint64_t seed, int count) {
   }
   return ok;
 }
+// The verifier's inversion-free Miller loop (projective steps for arbitrary second arguments, prepared lines for fixed ones)
+// against the affine loop, after the final exponentiation: `count` rounds of three pairs (a_i G1, b_i G2) with pseudo-random
+// small multiples of the generators (g1 64 B, g2 128 B standard form), every split of the pairs into "arbitrary" and "prepared",
+// one pair with a point at infinity in the last round.  Returns the number of agreeing comparisons (count * 4 expected).
+int zkt_miller_loops_agree(const uint8_t *g1, const uint8_t *g2, uint64_t seed, int count) {
+  using namespace zkr::pairing;
+  uint64_t st = seed ? seed : 88172645463325252ull;
+  auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return (uint32_t)(st >> 16); };
+  G1Affine P{to_mont(load_fp<FqParams>(g1)), to_mont(load_fp<FqParams>(g1 + 32))};
+  G2Affine Q{Fq2{to_mont(load_fp<FqParams>(g2)), to_mont(load_fp<FqParams>(g2 + 32))}, Fq2{to_mont(load_fp<FqParams>(g2 + 64)), to_mont(load_fp<FqParams>(g2 + 96))}};
+  auto g2_mul = [&](uint32_t k) {
+    G2XYZZ acc = G2XYZZ::inf();
+    for (int b = 31; b >= 0; b--) { acc = dbl_xyzz(acc); if ((k >> b) & 1) acc = add_mixed(acc, Q); }
+    return to_affine(acc);
+  };
+  int agree = 0;
+  for (int it = 0; it < count; it++) {
+    G1Affine ps[3];
+    G2Affine qs[3];
+    for (int i = 0; i < 3; i++) {
+      ps[i] = to_affine(mul_small(to_xyzz(P), (rnd() & 0xffff) + 1));
+      qs[i] = g2_mul((rnd() & 0xfffff) + 1);
+    }
+    if (it == count - 1) ps[1] = G1Affine{Fq::zero(), Fq::one()};  // infinity as the wire form has it: the pair contributes 1
+    bool ok = true;
+    const Fq12 want = final_exponentiation(multi_miller_loop(ps, qs, 3, &ok));
+    if (!ok) continue;
+    for (int nfixed = 0; nfixed <= 3; nfixed++) {  // the last nfixed pairs prepared
+      G2Prepared prep[3];
+      const G2Prepared *pp[3];
+      bool good = true;
+      for (int j = 0; j < nfixed; j++) { good = g2_prepare(qs[3 - nfixed + j], prep[j]) && good; pp[j] = &prep[j]; }
+      bool ok2 = true;
+      const Fq12 got = final_exponentiation(miller_loop_mixed(ps, qs, 3 - nfixed, ps + 3 - nfixed, pp, nfixed, &ok2));
+      agree += good && ok2 && got == want;
+    }
+  }
+  return agree;
+}
 // the two G2 membership tests on one twist point (128 B standard form: x.re, x.im, y.re, y.im): bit 0 = the definition
 // ([r]Q == infinity), bit 1 = the endomorphism test the verifier runs (psi(Q) == [6x^2]Q), bit 2 = the point is on the twist
 int zkt_g2_membership(const uint8_t *pt) {

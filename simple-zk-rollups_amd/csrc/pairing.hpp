@@ -14,6 +14,7 @@
 #pragma once
 #include "curve.hpp"
 
+#include <vector>
 namespace zkr {
 namespace pairing {
 
@@ -271,6 +272,131 @@ static inline Fq12 multi_miller_loop(const G1Affine *ps, const G2Affine *qs, int
   good = good && multi_step(t, q2, ps, live, n, f);
   if (ok) *ok = good;
   return good ? f : Fq12::one();
+}
+
+// ---- The Miller loop the verifier runs (round 3): no inversions.
+// The affine loop above pays one Fq2 inversion per step (~380 of a step's ~630 Fq products with four pairs).  Two kinds of pairs:
+//  * FIXED second arguments (beta, gamma, delta of a verifying key): the slope and intercept of every step's line do not depend on
+//    the first argument, so they are computed once per key (g2_prepare: the affine steps above, 89 lines) and a step costs two Fq
+//    products for the evaluation at P and the sparse product with f;
+//  * the proof's own B: homogeneous projective steps (Costello, Lange, Naehrig, "Faster pairing computations on curves with high-
+//    degree twists"): a line may be scaled by any element of Fq2 -- it is killed by the final exponentiation, (q^2 - 1) divides
+//    (q^12 - 1) / r -- so 2 Y Z, resp. the slope's denominator, multiplies the line instead of being inverted.
+// With T = (X, Y, Z) on y^2 = x^3 + b':
+//   doubling:  line = (2 Y Z) yP  -  (3 X^2) xP w  +  (Y^2 - 3 b' Z^2) w^3
+//              X3 = (X Y / 2)(Y^2 - 9 b' Z^2),  Y3 = ((Y^2 + 9 b' Z^2) / 2)^2 - 27 b'^2 Z^4,  Z3 = 2 Y^3 Z
+//   addition of the affine Q = (x2, y2), theta = Y - y2 Z, lam = X - x2 Z:
+//              line = lam yP  -  theta xP w  +  (theta x2 - lam y2) w^3
+//              X3 = lam H, Y3 = theta (X lam^2 - H) - lam^3 Y, Z3 = Z lam^3  with H = lam^3 + Z theta^2 - 2 X lam^2
+// Same value after the final exponentiation as multi_miller_loop (tests/test_host_arith.py: random pairs, both loops).
+struct G2Prepared {
+  std::vector<Fq2> lam, c;  // per step of the loop over 6x + 2 and the two Frobenius steps: slope, slope * x_T - y_T
+  bool inf = false;
+};
+static inline bool g2_prepare(const G2Affine &q, G2Prepared &out) {
+  out.lam.clear(), out.c.clear();
+  out.inf = q.is_inf();
+  if (out.inf) return true;
+  G2Affine t = q, q1 = g2_frobenius(q), q2 = g2_frobenius(q1);
+  q2.y = neg(q2.y);
+  auto step = [&](const G2Affine *s) -> bool {
+    Fq2 num, den;
+    if (s) { num = sub(s->y, t.y); den = sub(s->x, t.x); }
+    else { Fq2 xx = sqr(t.x); num = add(dbl(xx), xx); den = dbl(t.y); }
+    if (den.is_zero()) return false;
+    Fq2 lam = mul(num, inv(den));
+    out.lam.push_back(lam);
+    out.c.push_back(sub(mul(lam, t.x), t.y));
+    Fq2 x3 = sub(sub(sqr(lam), t.x), s ? s->x : t.x);
+    t = G2Affine{x3, sub(mul(lam, sub(t.x, x3)), t.y)};
+    return true;
+  };
+  for (int b = 63; b >= 0; b--) {
+    if (!step(nullptr)) return false;
+    if (((ATE_LOOP[b >> 5] >> (b & 31)) & 1) && !step(&q)) return false;
+  }
+  return step(&q1) && step(&q2);
+}
+// f * (a + (b0 + b1 v) w) with a in Fq2: thirteen Fq2 products
+static inline Fq12 mul_by_line2(const Fq12 &f, const Fq2 &a, const Fq2 &b0, const Fq2 &b1) {
+  Fq6 t0{mul(f.c0.c0, a), mul(f.c0.c1, a), mul(f.c0.c2, a)};
+  Fq6 t1 = mul_sparse01(f.c1, b0, b1);
+  Fq6 m = mul_sparse01(add(f.c0, f.c1), add(a, b0), b1);
+  return Fq12{add(t0, mul_v(t1)), sub(sub(m, t0), t1)};
+}
+struct G2Proj { Fq2 x, y, z; };
+static inline const Fq2 &twist_b() {
+  static const Fq2 b{fq_from_limbs(TWIST_B0), fq_from_limbs(TWIST_B1)};
+  return b;
+}
+static inline const Fq &fq_half() {
+  static const Fq h = inv(fq_small(2));
+  return h;
+}
+// T <- 2T; f <- f * line_{T,T}(P)
+static inline void proj_double_step(G2Proj &t, const G1Affine &p, Fq12 &f) {
+  const Fq2 xx = sqr(t.x), b = sqr(t.y), c = sqr(t.z);
+  const Fq2 e = mul(twist_b(), add(dbl(c), c));                 // 3 b' Z^2
+  const Fq2 f3 = add(dbl(e), e);                                // 9 b' Z^2
+  const Fq2 a = mul_fq(mul(t.x, t.y), fq_half());               // X Y / 2
+  const Fq2 g = mul_fq(add(b, f3), fq_half());                  // (Y^2 + 9 b' Z^2) / 2
+  const Fq2 h = sub(sqr(add(t.y, t.z)), add(b, c));             // 2 Y Z
+  const Fq2 e2 = sqr(e);
+  f = mul_by_line2(f, mul_fq(h, p.y), mul_fq(add(dbl(xx), xx), neg(p.x)), sub(b, e));
+  t = G2Proj{mul(a, sub(b, f3)), sub(sqr(g), add(dbl(e2), e2)), mul(b, h)};
+}
+// T <- T + Q (Q affine, T != +-Q); f <- f * line_{T,Q}(P)
+static inline void proj_add_step(G2Proj &t, const G2Affine &q, const G1Affine &p, Fq12 &f) {
+  const Fq2 theta = sub(t.y, mul(q.y, t.z)), lam = sub(t.x, mul(q.x, t.z));
+  const Fq2 c = sqr(theta), d = sqr(lam), e = mul(lam, d), ff = mul(t.z, c), g = mul(t.x, d);
+  const Fq2 h = sub(add(e, ff), dbl(g));
+  f = mul_by_line2(f, mul_fq(lam, p.y), mul_fq(theta, neg(p.x)), sub(mul(theta, q.x), mul(lam, q.y)));
+  t = G2Proj{mul(lam, h), sub(mul(theta, sub(g, h)), mul(e, t.y)), mul(t.z, e)};
+}
+// prod_i f_{6x+2,ql_i}(pl_i) * prod_j f_{6x+2,qf_j}(pf_j): nl pairs with arbitrary second arguments (projective steps), nf pairs
+// with prepared ones.  Pairs with a point at infinity contribute 1.  *ok is cleared when a projective point degenerates (Z = 0:
+// impossible for second arguments of order r, which the callers check).
+static inline Fq12 miller_loop_mixed(const G1Affine *pl, const G2Affine *ql, size_t nl, const G1Affine *pf, const G2Prepared *const *qf, size_t nf, bool *ok = nullptr) {
+  std::vector<G2Proj> t(nl);
+  std::vector<G2Affine> q1(nl), q2(nl);
+  std::vector<char> live(nl), livef(nf);
+  for (size_t i = 0; i < nl; i++) {
+    live[i] = !(ql[i].is_inf() || pl[i].is_inf());
+    t[i] = G2Proj{ql[i].x, ql[i].y, Fq2::one()};
+    q1[i] = g2_frobenius(ql[i]);
+    q2[i] = g2_frobenius(q1[i]);
+    q2[i].y = neg(q2[i].y);
+  }
+  for (size_t j = 0; j < nf; j++) livef[j] = !(qf[j]->inf || pf[j].is_inf());
+  Fq12 f = Fq12::one();
+  size_t at = 0;  // index of the step in the prepared tables
+  auto fixed_lines = [&]() {
+    for (size_t j = 0; j < nf; j++)
+      if (livef[j]) f = mul_by_line(f, pf[j].y, mul_fq(qf[j]->lam[at], neg(pf[j].x)), qf[j]->c[at]);
+    at++;
+  };
+  for (int b = 63; b >= 0; b--) {
+    f = sqr(f);
+    for (size_t i = 0; i < nl; i++)
+      if (live[i]) proj_double_step(t[i], pl[i], f);
+    fixed_lines();
+    if ((ATE_LOOP[b >> 5] >> (b & 31)) & 1) {
+      for (size_t i = 0; i < nl; i++)
+        if (live[i]) proj_add_step(t[i], ql[i], pl[i], f);
+      fixed_lines();
+    }
+  }
+  for (size_t i = 0; i < nl; i++)
+    if (live[i]) proj_add_step(t[i], q1[i], pl[i], f);
+  fixed_lines();
+  for (size_t i = 0; i < nl; i++)
+    if (live[i]) proj_add_step(t[i], q2[i], pl[i], f);
+  fixed_lines();
+  bool good = true;
+  for (size_t i = 0; i < nl; i++)
+    if (live[i] && t[i].z.is_zero()) good = false;  // the loop ends at -pi^3(Q), never at infinity, for Q of order r
+  if (ok) *ok = good;
+  return f;
 }
 
 // f^((q^12 - 1) / r) by plain square-and-multiply over the 1270 exponent bits: the reference form the fast one below is

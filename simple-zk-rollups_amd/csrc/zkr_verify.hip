@@ -101,6 +101,7 @@ struct VkEntry {
   std::vector<uint8_t> bytes;
   ParsedVk k;
   std::vector<G1Affine> win8;  // [i * 255 + d - 1] = d * IC_{i+1}; empty until the key's second use
+  pairing::G2Prepared beta, gamma, delta;  // the line coefficients of the key's fixed G2 points (pairing.hpp g2_prepare), built with the entry
   int uses = 0;
 };
 std::mutex vk_mu;
@@ -151,6 +152,11 @@ std::shared_ptr<const VkEntry> cached_vk(const void *vk_bin, size_t vk_len, size
   }
   auto e = std::make_shared<VkEntry>();
   if ((*rc = parse_vk(vk_bin, vk_len, n_public, e->k))) return nullptr;
+  if (!pairing::g2_prepare(e->k.beta2, e->beta) || !pairing::g2_prepare(e->k.gamma2, e->gamma) || !pairing::g2_prepare(e->k.delta2, e->delta)) {
+    set_error("verifying key: a G2 point is not a valid pairing input");  // an undefined slope: impossible for points of order r, which parse_vk checks
+    *rc = ZKR_ERR_BAD_KEY;
+    return nullptr;
+  }
   e->bytes.assign((const uint8_t *)vk_bin, (const uint8_t *)vk_bin + vk_len);
   e->uses = 1;
   std::lock_guard<std::mutex> lk(vk_mu);
@@ -190,9 +196,13 @@ extern "C" int zkr_verify(const void *vk_bin, size_t vk_len, const uint8_t proof
   for (size_t i = 0; i < n_public; i++)
     if (!fr_lt_r(pub + 32 * i)) return 0;
   G1XYZZ vkx = add_full(ic_combination(*ent, pub), to_xyzz(k.ic0));
-  G1Affine ps[4] = {G1Affine{a.x, neg(a.y)}, k.alfa1, to_affine(vkx), c};
-  G2Affine qs[4] = {b, k.beta2, k.gamma2, k.delta2};
-  *valid = pairing::pairing_product_is_one(ps, qs, 4) ? 1 : 0;
+  // e(-A, B) e(alfa, beta) e(vk_x, gamma) e(C, delta) == 1: B by projective steps, the key's three points through their prepared lines
+  const G1Affine pa{a.x, neg(a.y)};
+  const G1Affine pf[3] = {k.alfa1, to_affine(vkx), c};
+  const pairing::G2Prepared *qf[3] = {&ent->beta, &ent->gamma, &ent->delta};
+  bool ok = true;
+  const pairing::Fq12 f = pairing::miller_loop_mixed(&pa, &b, 1, pf, qf, 3, &ok);
+  *valid = ok && pairing::final_exponentiation(f) == pairing::Fq12::one() ? 1 : 0;
   return 0;
 }
 
@@ -249,19 +259,11 @@ extern "C" int zkr_verify_batch(const void *vk_bin, size_t vk_len, const uint8_t
   U256 zs;
   memcpy(zs.v, zs_std.v, 32);
   G1XYZZ vkx = add_full(ic_combination(*ent, comb_std.data()), scalar_mul(to_xyzz(k.ic0), zs));
-  ps.push_back(to_affine(scalar_mul(to_xyzz(k.alfa1), zs)));
-  qs.push_back(k.beta2);
-  ps.push_back(to_affine(vkx));
-  qs.push_back(k.gamma2);
-  ps.push_back(to_affine(csum));
-  qs.push_back(k.delta2);
-  pairing::Fq12 f = pairing::Fq12::one();
-  for (size_t at = 0; at < ps.size(); at += pairing::MAX_PAIRS) {
-    int m = (int)std::min<size_t>(pairing::MAX_PAIRS, ps.size() - at);
-    bool ok = true;
-    f = pairing::mul(f, pairing::multi_miller_loop(&ps[at], &qs[at], m, &ok));
-    if (!ok) return 0;  // undefined slope: cannot happen for subgroup points (read_g2 checks), never "valid"
-  }
+  const G1Affine pf[3] = {to_affine(scalar_mul(to_xyzz(k.alfa1), zs)), to_affine(vkx), to_affine(csum)};
+  const pairing::G2Prepared *qf[3] = {&ent->beta, &ent->gamma, &ent->delta};
+  bool ok = true;  // one loop over all pairs: the proofs' B_i by projective steps (one squaring of f per bit for the whole batch)
+  const pairing::Fq12 f = pairing::miller_loop_mixed(ps.data(), qs.data(), ps.size(), pf, qf, 3, &ok);
+  if (!ok) return 0;  // a degenerate step: cannot happen for subgroup points (read_g2 checks), never "valid"
   *all_valid = pairing::final_exponentiation(f) == pairing::Fq12::one() ? 1 : 0;
   return 0;
 }

@@ -325,3 +325,15 @@ def test_g2_membership_by_endomorphism_equals_the_definition(L):
         assert L.zkt_g2_membership(enc(Q)) == 7, Q          # on the twist, in G2 by both tests
     for Q in outside:
         assert b.g2_is_on_curve(Q) and L.zkt_g2_membership(enc(Q)) == 4, Q   # on the twist, refused by both tests
+
+
+def test_inversion_free_miller_loop_equals_the_affine_one(L):
+    """The Miller loop zkr_verify runs (pairing.hpp miller_loop_mixed: homogeneous projective steps for the proof's own G2 point,
+    per-key prepared line coefficients for beta / gamma / delta) against the affine loop the earlier rounds pinned to the oracle's
+    pairing (multi_miller_loop), after the final exponentiation: random multiples of the generators, every split of three pairs
+    into arbitrary and prepared second arguments, a pair with a point at infinity."""
+    import bn254 as b
+    g1 = b"".join(int(v).to_bytes(32, "little") for v in b.G1_GEN)
+    g2 = b"".join(int(v).to_bytes(32, "little") for v in (b.G2_GEN[0][0], b.G2_GEN[0][1], b.G2_GEN[1][0], b.G2_GEN[1][1]))
+    L.zkt_miller_loops_agree.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_int]
+    assert L.zkt_miller_loops_agree(g1, g2, 0x5A4B0999, 3) == 12
