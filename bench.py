@@ -323,7 +323,9 @@ def tx_circuit_leg(local, steps, batch=2, depth=6):
         wits.append(torch.frombuffer(bytearray(wb), dtype=torch.uint8).cuda(local))
     stream = torch.cuda.current_stream().cuda_stream
     ptrs = [wits[i % n_wit].data_ptr() for i in range(steps)]
-    key.prove_batch_device(ptrs[:4], stream=stream)
+    tw = time.perf_counter()                                    # warm: launch plans, and the device's clocks -- the legs before this
+    while time.perf_counter() - tw < 0.4:                       # one run on the host for a minute (CPU baselines), the GPU idles down
+        key.prove_batch_device(ptrs[:8], stream=stream)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     proofs = key.prove_batch_device(ptrs, stream=stream)
