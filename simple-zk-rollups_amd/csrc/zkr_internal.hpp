@@ -167,6 +167,9 @@ struct zkr_key {
   hipStream_t prep_stream = nullptr;               // digit records, digit sorts, calcH
   hipStream_t red_stream[zkr::N_TABLES] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // reduction chains: [0] the G2 table, the G1 tables
                                                                                            // round-robin over [1..n_red)
+  bool own_streams = false;                        // ZKR_PRIVATE_STREAMS: this key made its streams itself and destroys them
+  void *streams_owner = nullptr;                   // the DeviceStreams set (zkr_key.hip) the stream handles below come from
+  std::mutex *enqueue_mu = nullptr;                // the device's enqueue lock (shared streams: one proof's launches are enqueued without interleaving)
   hipStream_t aux_stream = nullptr;                // = red_stream[n_all - 1]: C's oversized-bucket partial sums when C shares H's bucket set (zkr_prove.hip c_big)
   int n_red = 1;                                   // streams the reduction chains rotate over
   int n_all = 1;                                   // streams in red_stream[] (n_red + the auxiliary one)

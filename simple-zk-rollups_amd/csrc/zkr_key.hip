@@ -10,6 +10,7 @@
 #include "kernels_ntt.hpp"
 #include "hostops.hpp"
 #include "pairing.hpp"  // the curve equations (g1_on_curve / g2_on_curve constants) for ZKR_CHECK_POINTS
+#include <map>
 #include "zkr_internal.hpp"
 
 namespace zkr {
@@ -157,17 +158,44 @@ void msm_ws_free(MsmWorkspace &ws) {
   ws = MsmWorkspace();
 }
 
-int key_alloc_workspace(zkr_key *k) {
-  ZKR_HIP_CHECK(hipSetDevice(k->device));
-  if (int lrc = ntt_lds_check(k->device)) return lrc;
-  const ArenaHeader &h = k->h;
+// The streams of a device, made ONCE per process and shared by every key on that device.  The HIP runtime multiplexes the streams
+// of one priority over GPU_MAX_HW_QUEUES = 4 hardware queues and hands the queues out as streams come and go: a process that had
+// created and freed a few keys (the bench's replication leg; an operator with its tx and withdraw keys and a key cache) found two
+// streams of its NEXT key on one hardware queue -- preparation and a reduction chain serialised, 10 % off every rate (tx circuit
+// 940 against 1 040 proofs/s, the real circuit at 2^20 133 against 154; with GPU_MAX_HW_QUEUES=8 they came back:
+// tools/bench_leg_interference*.sh).  One set per device never moves.  Two keys proving at the same time share the streams: the
+// launches of one proof are enqueued under the device's enqueue lock, so every cross-stream wait points at work enqueued before it
+// and the shared streams cannot wait for each other in a circle.  ZKR_PRIVATE_STREAMS=1: a set per key as before (A/B).
+namespace {
+struct DeviceStreams {
+  hipStream_t accum = nullptr, prep = nullptr, aux = nullptr, red[N_TABLES] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  std::mutex enqueue_mu;
+};
+std::mutex g_streams_mu;
+std::map<int, DeviceStreams *> g_streams;  // never freed: the streams live as long as the process
+}  // namespace
+
+static int make_streams(DeviceStreams &ds, int n_red) {
   // The accumulation stream is the bulk; preparation and reduction chains are short dependent launches whose
   // delay stalls it (the next sort, the proof's completion), so their workgroups are dispatched first.
   int prio_lo = 0, prio_hi = 0;
   ZKR_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));  // numerically lower = higher priority
   if (getenv("ZKR_NO_PRIO")) prio_hi = prio_lo;
-  ZKR_HIP_CHECK(hipStreamCreateWithPriority(&k->stream, hipStreamNonBlocking, prio_lo));
-  ZKR_HIP_CHECK(hipStreamCreateWithPriority(&k->prep_stream, hipStreamNonBlocking, prio_hi));
+  if (!ds.accum) ZKR_HIP_CHECK(hipStreamCreateWithPriority(&ds.accum, hipStreamNonBlocking, prio_lo));
+  if (!ds.prep) ZKR_HIP_CHECK(hipStreamCreateWithPriority(&ds.prep, hipStreamNonBlocking, prio_hi));
+  for (int j = 0; j < n_red; j++)
+    if (!ds.red[j]) ZKR_HIP_CHECK(hipStreamCreateWithPriority(&ds.red[j], hipStreamNonBlocking, prio_hi));
+  // one more for C's oversized-bucket sums (and, ZKR_H_CHAIN_AUX, the proof's last chain).  At the MIDDLE priority: a fifth
+  // high-priority stream made the next one created -- the witness builder's (rollup_gpu.hip) -- share a hardware queue with the
+  // preparation stream: its 28 ms kernel then stalled every proof behind it (facade pipeline 623 against 840 batches/s, tools/ab_hw_queues2.sh)
+  if (!ds.aux) ZKR_HIP_CHECK(hipStreamCreateWithPriority(&ds.aux, hipStreamNonBlocking, (prio_lo + prio_hi) / 2));
+  return 0;
+}
+
+int key_alloc_workspace(zkr_key *k) {
+  ZKR_HIP_CHECK(hipSetDevice(k->device));
+  if (int lrc = ntt_lds_check(k->device)) return lrc;
+  const ArenaHeader &h = k->h;
   // reduction streams: the chains of one proof add up to ~6 ms of serialised launches, so on a single in-order
   // stream they, not the accumulations, set the pace with two proofs in flight (94 vs 106 proofs/s with two)
   for (int t = 0; t < N_TABLES; t++) k->plan[t] = msm_plan(t == T_H ? h.m : h.n, h.npts[t], (int)h.win_c[t]);
@@ -192,15 +220,33 @@ int key_alloc_workspace(zkr_key *k) {
   // chains: 2^16 1745 against 1680, 2^17 943 against 910, 2^18 514 against 492, 2^19 237 against 231, the tx circuit 988
   // against 957 proofs/s).
   k->n_red = 2;
-  if (const char *e = getenv("ZKR_RED_STREAMS")) { int v = atoi(e); if (v >= 1 && v <= N_TABLES) k->n_red = v; }
-  for (int j = 0; j < k->n_red; j++) ZKR_HIP_CHECK(hipStreamCreateWithPriority(&k->red_stream[j], hipStreamNonBlocking, prio_hi));
-  // one more for C's oversized-bucket sums (and, ZKR_H_CHAIN_AUX, the proof's last chain): an entry of red_stream behind the chains' streams.
-  // At the MIDDLE priority: the runtime multiplexes the streams of one priority over GPU_MAX_HW_QUEUES = 4 hardware queues, and a fifth
-  // high-priority stream made the next one created -- the witness builder's (rollup_gpu.hip) -- share a queue with the preparation
-  // stream: its 28 ms kernel then stalled every proof behind it (facade pipeline 623 against 840 batches/s, tools/ab_hw_queues2.sh)
-  k->n_all = k->n_red < N_TABLES ? k->n_red + 1 : k->n_red;
-  if (k->n_all > k->n_red) ZKR_HIP_CHECK(hipStreamCreateWithPriority(&k->red_stream[k->n_red], hipStreamNonBlocking, (prio_lo + prio_hi) / 2));
-  k->aux_stream = k->red_stream[k->n_all - 1];
+  if (const char *e = getenv("ZKR_RED_STREAMS")) { int v = atoi(e); if (v >= 1 && v < N_TABLES) k->n_red = v; }
+  {
+    DeviceStreams *ds = nullptr;
+    k->own_streams = getenv("ZKR_PRIVATE_STREAMS") != nullptr;
+    if (k->own_streams) {
+      ds = new DeviceStreams();  // its mutex is this key's alone; freed with the key
+    } else {
+      std::lock_guard<std::mutex> lk(g_streams_mu);
+      DeviceStreams *&slot = g_streams[k->device];
+      if (!slot) slot = new DeviceStreams();
+      ds = slot;
+    }
+    int src = 0;
+    {
+      std::lock_guard<std::mutex> lk(g_streams_mu);  // creation of missing streams of a shared set, one key at a time
+      src = make_streams(*ds, k->n_red);
+    }
+    if (src) { if (k->own_streams) delete ds; return src; }
+    k->streams_owner = ds;
+    k->enqueue_mu = &ds->enqueue_mu;
+    k->stream = ds->accum;
+    k->prep_stream = ds->prep;
+    for (int j = 0; j < k->n_red; j++) k->red_stream[j] = ds->red[j];
+    k->red_stream[k->n_red] = ds->aux;  // an entry of red_stream behind the chains' streams
+    k->n_all = k->n_red + 1;
+    k->aux_stream = ds->aux;
+  }
   {
     int rc = ntt_tables29_build((const Fr *)(k->arena + h.off_tw), 1u << h.tlog, (const Fr *)(k->arena + h.off_twl), 1u << TWL_LOG, nullptr, &k->tw29, &k->twl29);
     if (rc) return rc;
@@ -625,8 +671,11 @@ void zkr_key_free(zkr_key *k) {
     hipFree(sl.d_w); hipFree(sl.va); hipFree(sl.vb); hipFree(sl.ca); hipFree(sl.cb); hipFree(sl.d_h);
     for (auto e : sl.event_pool) hipEventDestroy(e);
   }
-  for (hipStream_t st : streams)
-    if (st) hipStreamDestroy(st);
+  if (k->own_streams) {
+    for (hipStream_t st : streams)
+      if (st) hipStreamDestroy(st);
+    delete static_cast<DeviceStreams *>(k->streams_owner);
+  }
   for (WitnessStage &ws : k->stage) {
     if (ws.h_pinned) hipHostFree(ws.h_pinned);
     if (ws.d_w) hipFree(ws.d_w);

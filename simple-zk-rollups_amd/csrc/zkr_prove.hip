@@ -454,6 +454,9 @@ static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *const *d_ws
   }
   sl.nbat = nbat;
   clock_gettime(CLOCK_MONOTONIC, &sl.t_submit);
+  // The streams are the device's, shared by every key on it (zkr_key.hip DeviceStreams): the launches of one proof are enqueued
+  // without another key's in between, so that every cross-stream wait below points at work enqueued before it
+  std::lock_guard<std::mutex> enqueue_lock(*k->enqueue_mu);
 
   // The caller's stream only orders the witness before the proof (it may carry unrelated work, and with two
   // proofs in flight it must not chain them).  Schedule on the key's own streams (HIP multiplexes streams onto a

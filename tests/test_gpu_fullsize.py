@@ -139,6 +139,59 @@ def test_concurrent_host_buffer_callers_on_one_key():
 
 
 @pytest.mark.timeout(600)
+def test_two_keys_prove_at_once_on_the_devices_shared_streams():
+    """The streams belong to the device, not to the key (zkr_key.hip DeviceStreams): two keys of different sizes proving at the same
+    time from different threads -- single calls and batch calls, pipelined two deep each -- enqueue onto the same five streams.
+    The device's enqueue lock keeps one proof's launches together, so the cross-stream waits cannot form a circle (a hang fails by
+    timeout), and every proof is the closed form's bytes for its key, witness and blinding; a key freed in between (its free
+    synchronises the shared streams) disturbs nothing."""
+    import threading
+    import zkr_hip
+    p = 73
+    keys = {}
+    for log_m in (12, 14):
+        key, wb, aux = zkr_hip.ProvingKey.synth(log_m, p, 0x5A4B0001, 0x5A4B00FF)
+        keys[log_m] = (key, [wb, zkr_hip.synth_witness(log_m, p, 0x5A4B0001, 7100 + log_m)], aux)
+    out, errs = {}, []
+
+    def worker(log_m, j, batch):
+        key, wbs, _ = keys[log_m]
+        try:
+            for i in range(5):
+                if batch:
+                    ws = [wbs[(i + q) % 2] for q in range(5)]
+                    rs, ss = [3000 + 100 * j + 10 * i + q for q in range(5)], [4000 + 100 * j + 10 * i + q for q in range(5)]
+                    for q, pr in enumerate(key.prove_batch(ws, rs, ss)):
+                        out[(log_m, j, i, q)] = (pr, (i + q) % 2, rs[q], ss[q])
+                else:
+                    out[(log_m, j, i, 0)] = (key.prove(wbs[i % 2], 3000 + 100 * j + i, 4000 + 100 * j + i), i % 2, 3000 + 100 * j + i, 4000 + 100 * j + i)
+        except Exception as e:
+            errs.append(e)
+
+    def churn():  # a third key comes and goes while the others prove
+        try:
+            for _ in range(3):
+                k3, w3, _a = zkr_hip.ProvingKey.synth(10, p, 0x5A4B0001, 0x5A4B00FF)
+                k3.prove(w3, 5, 7)
+                k3.close()
+        except Exception as e:
+            errs.append(e)
+
+    ths = [threading.Thread(target=worker, args=(12, 0, False)), threading.Thread(target=worker, args=(14, 1, False)),
+           threading.Thread(target=worker, args=(12, 2, True)), threading.Thread(target=worker, args=(14, 3, True)), threading.Thread(target=churn)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs
+    assert len(out) == 2 * 5 + 2 * 25
+    for (log_m, j, i, q), (proof, wi, r, s_) in out.items():
+        _, wbs, aux = keys[log_m]
+        expect, _, _ = g.proof_from_aux(aux, wbs[wi], p, r, s_)
+        assert proof == g.proof_bytes(expect), (log_m, j, i, q)
+
+
+@pytest.mark.timeout(600)
 @pytest.mark.parametrize("mix", ["batch_vs_single", "batch_vs_batch"])
 def test_batch_calls_do_not_deadlock_against_other_host_buffer_callers(mix):
     """zkr_prove_batch used to wait for a third staging buffer while its own groups held both proof slots
