@@ -102,6 +102,7 @@ struct VkEntry {
   ParsedVk k;
   std::vector<G1Affine> win8;  // [i * 255 + d - 1] = d * IC_{i+1}; empty until the key's second use
   pairing::G2Prepared beta, gamma, delta;  // the line coefficients of the key's fixed G2 points (pairing.hpp g2_prepare), built with the entry
+  pairing::Fq12 f_alfa_beta;               // Miller value of (alfa, beta): both arguments belong to the key
   int uses = 0;
 };
 std::mutex vk_mu;
@@ -157,6 +158,10 @@ std::shared_ptr<const VkEntry> cached_vk(const void *vk_bin, size_t vk_len, size
     *rc = ZKR_ERR_BAD_KEY;
     return nullptr;
   }
+  {
+    const pairing::G2Prepared *qb = &e->beta;
+    e->f_alfa_beta = pairing::miller_loop_mixed(nullptr, nullptr, 0, &e->k.alfa1, &qb, 1);
+  }
   e->bytes.assign((const uint8_t *)vk_bin, (const uint8_t *)vk_bin + vk_len);
   e->uses = 1;
   std::lock_guard<std::mutex> lk(vk_mu);
@@ -196,12 +201,13 @@ extern "C" int zkr_verify(const void *vk_bin, size_t vk_len, const uint8_t proof
   for (size_t i = 0; i < n_public; i++)
     if (!fr_lt_r(pub + 32 * i)) return 0;
   G1XYZZ vkx = add_full(ic_combination(*ent, pub), to_xyzz(k.ic0));
-  // e(-A, B) e(alfa, beta) e(vk_x, gamma) e(C, delta) == 1: B by projective steps, the key's three points through their prepared lines
+  // e(-A, B) e(alfa, beta) e(vk_x, gamma) e(C, delta) == 1: B by projective steps, gamma and delta through their prepared lines,
+  // the Miller value of (alfa, beta) from the key's entry
   const G1Affine pa{a.x, neg(a.y)};
-  const G1Affine pf[3] = {k.alfa1, to_affine(vkx), c};
-  const pairing::G2Prepared *qf[3] = {&ent->beta, &ent->gamma, &ent->delta};
+  const G1Affine pf[2] = {to_affine(vkx), c};
+  const pairing::G2Prepared *qf[2] = {&ent->gamma, &ent->delta};
   bool ok = true;
-  const pairing::Fq12 f = pairing::miller_loop_mixed(&pa, &b, 1, pf, qf, 3, &ok);
+  const pairing::Fq12 f = pairing::mul(ent->f_alfa_beta, pairing::miller_loop_mixed(&pa, &b, 1, pf, qf, 2, &ok));
   *valid = ok && pairing::final_exponentiation(f) == pairing::Fq12::one() ? 1 : 0;
   return 0;
 }
