@@ -333,12 +333,30 @@ def tx_circuit_leg(local, steps, batch=2, depth=6):
     el = time.perf_counter() - t1
     assert zkr_hip.verify_batch(vk_bin, proofs, [pubs[i % n_wit] for i in range(steps)]), "a proof of the tx circuit failed the pairing check"
     ok = steps
+    # the reference's own sequence, one batch at a time (createProofGenerator, common.ts:10-53): calculateWitness -> groth16GenProof
+    # on the host witness -> isValid, nothing overlapped
+    seq = None
+    if (batch, depth) == (2, 6):
+        parts = [0.0, 0.0, 0.0]
+        n_seq = 12
+        for it in range(n_seq + 2):
+            ta = time.perf_counter()
+            wb = circ.calculate_witness(flat)
+            tb = time.perf_counter()
+            pr = key.prove(wb)
+            tc = time.perf_counter()
+            good = zkr_hip.verify(vk_bin, pr, circ.public_signals(wb))
+            td = time.perf_counter()
+            assert good
+            if it >= 2:
+                parts = [parts[0] + tb - ta, parts[1] + tc - tb, parts[2] + td - tc]
+        seq = {"witness_ms": 1e3 * parts[0] / n_seq, "proof_ms": 1e3 * parts[1] / n_seq, "is_valid_ms": 1e3 * parts[2] / n_seq, "total_ms": 1e3 * sum(parts) / n_seq, "calls": n_seq}
     domain = key.info()["domainSize"]
     key.close()
     return {"circuit": "BatchProcessTx(%d, %d)%s" % (circ.batch, circ.depth, " (tx.circom)" if (batch, depth) == (2, 6) else ""), "nVars": circ.n_vars, "nPublic": circ.n_public,
             "nConstraints": circ.n_constraints, "domainSize": domain, "setup_s": setup_s,
             "witness_ms_host": sum(wit_ms) / len(wit_ms), "proofs": steps, "proofs_per_s": steps / el, "ms_per_proof": 1e3 * el / steps,
-            "proofs_verified": ok}
+            "proofs_verified": ok, "facade_sequential": seq}
 
 
 def facade_pipeline_leg(local, n_batches=256, chunk=64, witness="gpu"):
