@@ -98,8 +98,17 @@ static __global__ __launch_bounds__(64) void rollup_witness_tx_kernel(const Fr *
   const uint32_t p = tx_layout(batch, depth).p;
   Fr root;
   errs[(size_t)part * n_tx + t] = tx_witness(inputs + (size_t)bi * (p - 1), batch, depth, i, K, k, wit + (size_t)bi * ((size_t)p + 1 + (size_t)batch * K) + p + 1 + (size_t)i * K,
-                                             workspace + (size_t)t * 4 * WS_PTS, &root, (int)part);
+                                             workspace + (size_t)t * TX_WS_ELEMS, &root, (int)part);
   if (part == TX_PARTS - 1) roots[t] = root;
+}
+// The comparison of the signature equation's two sides, which parts 0 and 1 computed apart (rollup_witness.hpp tx_finish): a thread
+// per transaction, a handful of field operations when the signature holds.
+static __global__ __launch_bounds__(64) void rollup_witness_finish_kernel(uint32_t n_batches, uint32_t batch, uint32_t depth, uint32_t K, Fr *wit, uint32_t *errs) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, n_tx = n_batches * batch;
+  if (t >= n_tx) return;
+  const uint32_t bi = t / batch, i = t % batch;
+  const uint32_t p = tx_layout(batch, depth).p;
+  errs[(size_t)TX_PARTS * n_tx + t] = tx_finish(wit + (size_t)bi * ((size_t)p + 1 + (size_t)batch * K) + p + 1 + (size_t)i * K, depth, K);
 }
 // The vector as binarifyWitness lays it out: signal 0 = 1, signal 1 = the last transaction's root, the inputs as given, the
 // private signals converted to standard form in place.  Thread per signal of every batch; the first thread of a batch also
@@ -146,7 +155,9 @@ namespace zkr {
 bool rollup_witness_fast_host(uint32_t batch, uint32_t depth, const uint8_t *inputs_std, uint8_t *out_bytes) {
   const uint32_t p = rollup_n_public(batch, depth), K = rollup_tx_private_count(depth);
   std::vector<Fr> tab(2 * 253), in(p - 1), w((size_t)batch * K), roots(batch);
-  std::vector<uint32_t> errs((size_t)batch * TX_PARTS, 0);
+  std::vector<uint32_t> errs((size_t)batch * (TX_PARTS + 1), 0);
+  std::vector<std::atomic<uint32_t>> parts_done(batch);
+  for (auto &d : parts_done) d.store(0);
   TxConsts k;
   rollup_device_constants(&k.a, &k.d, k.suborder_m1, tab.data(), tab.data() + 253);
   k.b8x = tab.data(), k.b8y = tab.data() + 253, k.mimc = mimc_round_constants();
@@ -160,12 +171,14 @@ bool rollup_witness_fast_host(uint32_t batch, uint32_t depth, const uint8_t *inp
   std::atomic<uint32_t> next_task{0}, next_slice{0}, arrived{0};
   auto worker = [&] {
     {
-      std::vector<Fr> ws(4 * WS_PTS);
+      std::vector<Fr> ws(TX_WS_ELEMS);
       for (uint32_t t; (t = next_task.fetch_add(1)) < tasks;) {
         const uint32_t i = t / TX_PARTS, part = t % TX_PARTS;
         Fr r;
         errs[t] = tx_witness(in.data(), batch, depth, i, K, k, w.data() + (size_t)i * K, ws.data(), &r, (int)part);
         if (part == TX_PARTS - 1) roots[i] = r;
+        if (parts_done[i].fetch_add(1) + 1 == TX_PARTS)  // the transaction's last part: both sides of its signature equation are in place
+          errs[(size_t)batch * TX_PARTS + i] = tx_finish(w.data() + (size_t)i * K, depth, K);
       }
     }
     arrived.fetch_add(1);
@@ -183,8 +196,8 @@ bool rollup_witness_fast_host(uint32_t batch, uint32_t depth, const uint8_t *inp
     worker();
     for (auto &t : th) t.join();
   }
-  for (uint32_t t = 0; t < tasks; t++)
-    if (errs[t]) return false;
+  for (uint32_t e : errs)
+    if (e) return false;
   for (uint32_t i = 1; i < batch; i++) {  // the root chain (batchprocesstx.circom:67-69)
     Fr want;
     if (!tx_read_input(&in[i], want) || !(roots[i - 1] == want)) return false;
@@ -260,7 +273,8 @@ int zkr_rollup_witness_batch_device(uint32_t batch, uint32_t depth, const uint8_
   static Scratch scratch[64][4];
   static std::mutex scratch_mu[64];
   std::lock_guard<std::mutex> scratch_lock(scratch_mu[device]);
-  const size_t want[4] = {n_batches * (size_t)(p - 1) * 32, n_tx * 4 * WS_PTS * 32, n_tx * 32, (TX_PARTS * n_tx + n_batches) * 4};
+  const uint32_t ROWS = TX_PARTS + 1;  // a row of statement codes per part, one for tx_finish
+  const size_t want[4] = {n_batches * (size_t)(p - 1) * 32, n_tx * (size_t)TX_WS_ELEMS * 32, n_tx * 32, (ROWS * n_tx + n_batches) * 4};
   for (int j = 0; j < 4; j++) {
     Scratch &sc = scratch[device][j];
     if (sc.cap >= want[j]) continue;
@@ -272,28 +286,33 @@ int zkr_rollup_witness_batch_device(uint32_t batch, uint32_t depth, const uint8_
   const DevView b_in{scratch[device][0].p}, b_ws{scratch[device][1].p}, b_roots{scratch[device][2].p}, b_errs{scratch[device][3].p};
   // Its own stream (non-blocking, highest priority): the builder is a handful of long-running wavefronts that must neither wait
   // for nor hold up the proofs in flight on the key's streams; nothing here synchronises the device.
-  struct StreamGuard {
-    hipStream_t s = nullptr;
-    ~StreamGuard() { if (s) hipStreamDestroy(s); }
-  } sg;
-  int prio_lo = 0, prio_hi = 0;
-  ZKR_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-  ZKR_HIP_CHECK(hipStreamCreateWithPriority(&sg.s, hipStreamNonBlocking, prio_hi));
+  // Made once per device and kept (the scratch lock above serialises the calls): streams that come and go reshuffle the
+  // runtime's hardware queues under the provers' streams (zkr_key.hip DeviceStreams).
+  struct StreamRef { hipStream_t s = nullptr; };
+  static StreamRef kept[64];
+  StreamRef &sg = kept[device];
+  if (!sg.s) {
+    int prio_lo = 0, prio_hi = 0;
+    ZKR_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+    ZKR_HIP_CHECK(hipStreamCreateWithPriority(&sg.s, hipStreamNonBlocking, prio_hi));
+  }
   ZKR_HIP_CHECK(hipMemcpyAsync(b_in.p, inputs, n_batches * (size_t)(p - 1) * 32, hipMemcpyHostToDevice, sg.s));
-  uint32_t *d_errs = b_errs.as<uint32_t>(), *d_chain = d_errs + TX_PARTS * n_tx;
+  uint32_t *d_errs = b_errs.as<uint32_t>(), *d_chain = d_errs + ROWS * n_tx;
   rollup_witness_tx_kernel<<<dim3((unsigned)((n_tx + 63) / 64), TX_PARTS), 64, 0, sg.s>>>(b_in.as<Fr>(), (uint32_t)n_batches, batch, depth, K, k, (Fr *)d_witnesses, b_ws.as<Fr>(), b_roots.as<Fr>(), d_errs);
+  ZKR_HIP_CHECK(hipGetLastError());
+  rollup_witness_finish_kernel<<<(unsigned)((n_tx + 63) / 64), 64, 0, sg.s>>>((uint32_t)n_batches, batch, depth, K, (Fr *)d_witnesses, d_errs);
   ZKR_HIP_CHECK(hipGetLastError());
   const size_t total = nv * n_batches;
   rollup_witness_layout_kernel<<<(unsigned)((total + 255) / 256), 256, 0, sg.s>>>(b_in.as<Fr>(), (uint32_t)n_batches, batch, depth, K, b_roots.as<Fr>(), (Fr *)d_witnesses, d_chain);
   ZKR_HIP_CHECK(hipGetLastError());
-  std::vector<uint32_t> errs(TX_PARTS * n_tx + n_batches);
+  std::vector<uint32_t> errs(ROWS * n_tx + n_batches);
   ZKR_HIP_CHECK(hipMemcpyAsync(errs.data(), d_errs, errs.size() * 4, hipMemcpyDeviceToHost, sg.s));
   ZKR_HIP_CHECK(hipStreamSynchronize(sg.s));
   for (size_t bi = 0; bi < n_batches; bi++) {  // first violated statement in circuit order, as zkr_rollup_witness reports it
     for (uint32_t i = 0; i < batch; i++) {
-      const uint32_t chain = errs[TX_PARTS * n_tx + bi];
+      const uint32_t chain = errs[ROWS * n_tx + bi];
       uint32_t e = 0;  // the codes are in program order: the smallest one over the parts is the transaction's first violation
-      for (uint32_t part = 0; part < TX_PARTS; part++) {
+      for (uint32_t part = 0; part < ROWS; part++) {
         const uint32_t ep = errs[(size_t)part * n_tx + bi * batch + i];
         if (ep && (!e || ep < e)) e = ep;
       }
@@ -315,7 +334,7 @@ int zkr_rollup_witness_program_host(uint32_t batch, uint32_t depth, const uint8_
   if (rc) return rc;
   const uint32_t p = rollup_n_public(batch, depth), K = rollup_tx_private_count(depth);
   if (n_inputs != p - 1) { set_error("rollup circuit (%u, %u) takes %u inputs, got %zu", batch, depth, p - 1, n_inputs); return ZKR_ERR_ARG; }
-  std::vector<Fr> tab(2 * 253), in(p - 1), w(K), ws(4 * WS_PTS), roots(batch);
+  std::vector<Fr> tab(2 * 253), in(p - 1), w(K), ws(TX_WS_ELEMS), roots(batch);
   TxConsts k;
   rollup_device_constants(&k.a, &k.d, k.suborder_m1, tab.data(), tab.data() + 253);
   k.b8x = tab.data(), k.b8y = tab.data() + 253, k.mimc = mimc_round_constants();
@@ -329,6 +348,10 @@ int zkr_rollup_witness_program_host(uint32_t batch, uint32_t depth, const uint8_
       const uint32_t ep = tx_witness(in.data(), batch, depth, i, K, k, w.data(), ws.data(), &r, (int)part);
       if (ep && (!e || ep < e)) e = ep;
       if (part == TX_PARTS - 1) roots[i] = r;
+    }
+    {
+      const uint32_t ef = tx_finish(w.data(), depth, K);
+      if (ef && (!e || ef < e)) e = ef;
     }
     if (i > 0) {  // the root chain comes first in circuit order (batchprocesstx.circom:67-69), as in rollup.cpp batch_witness
       Fr want;

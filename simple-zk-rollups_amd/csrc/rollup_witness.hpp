@@ -28,6 +28,7 @@ static const char *const TX_STMT_TEXT[ST_COUNT] = {  // rollup.cpp's wording
     "a transaction starts from the root the previous one produced"};
 
 constexpr int WS_PTS = 512;  // projective points of one scalar-multiplication chain (2 x 253 at most)
+constexpr int TX_WS_ELEMS = 8 * WS_PTS;  // scratch of one transaction: four coordinate arrays for each of the two parts with such chains
 struct TxConsts {
   Fr a, d;
   uint32_t suborder_m1[8];
@@ -204,7 +205,13 @@ ZKR_HDF bool tx_is_zero(TxB &b, const Fr &v) {  // IsZero: inverse, flag
   return z;
 }
 // EdDSAMiMCSpongeVerifierPatched (eddsa_verify_gadget): valid ? 1 : 0
-ZKR_HDF bool tx_eddsa_verify(TxB &b, const Fr &ax, const Fr &ay, const Fr &S, const Fr &r8x, const Fr &r8y, const Fr &M) {
+// signals of the fixed-base multiplication S * BASE8 (252 additions), of the three IsZero behind it, and of what ProcessTx
+// allocates after the signature (three 250-bit range checks, two IsZero, the 252-bit comparison): where the multiplication starts
+// is counted back from the first leaf hash
+constexpr uint32_t TX_BASE8_SIGNALS = 252 * 6, TX_SIGZ_SIGNALS = 6, TX_TAIL_SIGNALS = 3 * 250 + 4 + 252;
+// skip_base8: everything up to R8 + h * 8A; the multiplication S * BASE8 and the comparison of the two sides are left to another
+// part (tx_process part 1) and to tx_finish, their signals are stepped over
+ZKR_HDF bool tx_eddsa_verify(TxB &b, const Fr &ax, const Fr &ay, const Fr &S, const Fr &r8x, const Fr &r8y, const Fr &M, uint32_t o_base8, bool skip_base8) {
   uint32_t sbits[8], hbits[8];
   tx_num2bits(b, S, 253, ST_SBITS, sbits);
   if (tx_bits_gt_const(b, sbits, 253, b.k.suborder_m1)) b.fail(ST_SORDER);
@@ -223,6 +230,11 @@ ZKR_HDF bool tx_eddsa_verify(TxB &b, const Fr &ax, const Fr &ay, const Fr &S, co
   if (tx_is_zero(b, a4.x)) b.fail(ST_SMALL_ORDER);
   PtA right2 = tx_scalar_mul_any(b, hbits, 254, a8);
   PtA right = tx_edwards_add(b, PtA{r8x, r8y}, right2);
+  if (!b.err && b.n != o_base8) b.fail(ST_COUNT);  // internal: the count back from the leaf hashes is not the program's
+  if (skip_base8) {
+    b.n += TX_BASE8_SIGNALS + TX_SIGZ_SIGNALS;
+    return true;
+  }
   PtA left = tx_scalar_mul_base8(b, sbits, 253);
   const bool ex = tx_is_zero(b, sub(left.x, right.x)), ey = tx_is_zero(b, sub(left.y, right.y));
   Fr two = add(Fr::one(), Fr::one());
@@ -246,24 +258,29 @@ struct TxInD {
   Fr spath[TX_MAX_DEPTH], rpath[TX_MAX_DEPTH], ipath[TX_MAX_DEPTH];
 };
 // ProcessTx (process_tx_gadget): returns the new root
-// The program in three parts that share no signal: 0 = indices, signature, range checks (the two scalar multiplications);
-// 1 = the sender's leaves and paths; 2 = the recipient's leaves and paths -- about 2 * 10^4 dependent multiplications each.
-// part < 0 runs all of them in order (host, tests); the GPU builder gives each part of 64 transactions its own wavefront
-// (rollup_gpu.hip), three times shorter than one lane doing everything.  Where a part starts is a matter of counting:
-// a leaf hash is 4 x 660 signals, a path depth x (1 + 2 x 660), the recipient selectors 4.
-constexpr uint32_t TX_PARTS = 3;
+// The program in six parts that share no signal, each a chain of dependent multiplications:
+//   0  indices, message hash, signature up to R8 + h * 8A (two sponges and the variable-base multiplication: ~16 000), range checks
+//   1  the fixed-base multiplication S * BASE8 (~4 300)
+//   2  the sender's leaf and path        3  the sender's new leaf and path           (~10 500 each)
+//   4  the recipient's leaf and path     5  the recipient's new leaf and path = the transaction's root
+// and tx_finish, which compares the two sides of the signature equation once parts 0 and 1 are done (three IsZero, no inversion when
+// the signature holds).  part < 0 runs everything in order (tests, the gadget comparison); the GPU builder gives each part of 64
+// transactions its own wavefront (rollup_gpu.hip), the host builder's fast path a task.  Where a part starts is a matter of
+// counting: a leaf hash is 4 x 660 signals, a path depth x (1 + 2 x 660), the recipient selectors 4.
+constexpr uint32_t TX_PARTS = 6;
 ZKR_HDF Fr tx_process(TxB &b, const TxInD &in, uint32_t depth, int part, uint32_t K) {
   const bool all = part < 0;
   const uint32_t leaf = 4 * 3 * MIMC_ROUNDS, path = depth * (1 + 2 * 3 * MIMC_ROUNDS);
   const uint32_t o_sleaf = K - (4 * leaf + 4 * path + 4), o_rleaf = o_sleaf + leaf, o_spath = o_rleaf + leaf, o_rpath = o_spath + path;
   const uint32_t o_nsleaf = o_rpath + path, o_same = o_nsleaf + leaf, o_nrleaf = o_same + 4, o_nspath = o_nrleaf + leaf, o_nrpath = o_nspath + path;
+  const uint32_t o_base8 = o_sleaf - TX_TAIL_SIGNALS - TX_SIGZ_SIGNALS - TX_BASE8_SIGNALS;
   uint32_t sidx[8], ridx[8], tmp[8];
   if (all || part == 0) {
     tx_num2bits(b, in.tx[0], (int)depth, ST_SIDX, sidx);
     tx_num2bits(b, in.tx[1], (int)depth, ST_RIDX, ridx);
     const Fr m5[5] = {in.tx[0], in.tx[1], in.tx[2], in.tx[3], in.tx[4]};
     Fr msg = tx_multihash(b, m5, 5);
-    if (!tx_eddsa_verify(b, in.spk[0], in.spk[1], in.tx[7], in.tx[5], in.tx[6], msg)) b.fail(ST_SIGNATURE);
+    if (!tx_eddsa_verify(b, in.spk[0], in.spk[1], in.tx[7], in.tx[5], in.tx[6], msg, o_base8, !all)) b.fail(ST_SIGNATURE);
     if (!(in.tx[4] == add(in.snonce, Fr::one()))) b.fail(ST_NONCE);
     tx_num2bits(b, in.tx[2], 250, ST_AMOUNT_BITS, tmp);
     tx_num2bits(b, in.tx[3], 250, ST_FEE_BITS, tmp);
@@ -283,26 +300,40 @@ ZKR_HDF Fr tx_process(TxB &b, const TxInD &in, uint32_t depth, int part, uint32_
 #pragma unroll
     for (int i = 0; i < 8; i++) sidx[i] = s0.v[i], ridx[i] = s1.v[i];
   }
+  if (part == 1) {  // S's bits without their signals (part 0 allocates them and refuses an S of more than 253 bits)
+    uint32_t sbits[8];
+    Fr s = from_mont(in.tx[7]);
+#pragma unroll
+    for (int i = 0; i < 8; i++) sbits[i] = s.v[i];
+    sbits[7] &= (1u << (253 - 224)) - 1u;
+    b.n = o_base8;
+    tx_scalar_mul_base8(b, sbits, 253);
+    if (!b.err && b.n != o_base8 + TX_BASE8_SIGNALS) b.fail(ST_COUNT);
+  }
   const Fr nsbal = sub(sub(in.sbal, in.tx[2]), in.tx[3]);
   Fr root = Fr::zero();
-  if (all || part == 1) {
+  if (all || part == 2) {
     const Fr sl[4] = {in.spk[0], in.spk[1], in.sbal, in.snonce};
     b.n = o_sleaf;
     Fr sleaf = tx_multihash(b, sl, 4);
     b.n = o_spath;
     if (!(tx_merkle_root(b, sleaf, in.spath, sidx, depth) == in.root)) b.fail(ST_SLEAF);
+  }
+  if (all || part == 3) {
     const Fr nsl[4] = {in.spk[0], in.spk[1], nsbal, in.tx[4]};
     b.n = o_nsleaf;
     Fr nsleaf = tx_multihash(b, nsl, 4);
     b.n = o_nspath;
     if (!(tx_merkle_root(b, nsleaf, in.spath, sidx, depth) == in.iroot)) b.fail(ST_IROOT);
   }
-  if (all || part == 2) {
+  if (all || part == 4) {
     const Fr rl[4] = {in.rpk[0], in.rpk[1], in.rbal, in.rnonce};
     b.n = o_rleaf;
     Fr rleaf = tx_multihash(b, rl, 4);
     b.n = o_rpath;
     if (!(tx_merkle_root(b, rleaf, in.rpath, ridx, depth) == in.root)) b.fail(ST_RLEAF);
+  }
+  if (all || part == 5) {
     b.n = o_same;
     const bool same = tx_is_zero(b, sub(in.tx[0], in.tx[1]));
     Fr selbal = add(in.rbal, b.put(same ? sub(nsbal, in.rbal) : Fr::zero()));
@@ -314,6 +345,23 @@ ZKR_HDF Fr tx_process(TxB &b, const TxInD &in, uint32_t depth, int part, uint32_
     if (!b.err && b.n != K) b.fail(ST_COUNT);
   }
   return root;
+}
+// What is left of the signature check when the parts ran apart: the two sides of S * BASE8 == R8 + h * 8A are the last signals of
+// part 1's and of part 0's additions; their comparison is three IsZero (an inversion only where a difference is not zero, i.e.
+// never for a valid signature).  w: the transaction's private signals (Montgomery).  Returns ST_SIGNATURE or 0.
+ZKR_HDF uint32_t tx_finish(Fr *w, uint32_t depth, uint32_t K) {
+  const uint32_t leaf = 4 * 3 * MIMC_ROUNDS, path = depth * (1 + 2 * 3 * MIMC_ROUNDS);
+  const uint32_t o_sleaf = K - (4 * leaf + 4 * path + 4);
+  const uint32_t o_base8 = o_sleaf - TX_TAIL_SIGNALS - TX_SIGZ_SIGNALS - TX_BASE8_SIGNALS;
+  TxB b;
+  b.w = w;
+  b.n = o_base8 + TX_BASE8_SIGNALS;
+  b.err = ST_OK;
+  const Fr rx = w[o_base8 - 2], ry = w[o_base8 - 1], lx = w[b.n - 2], ly = w[b.n - 1];
+  const bool ex = tx_is_zero(b, sub(lx, rx)), ey = tx_is_zero(b, sub(ly, ry));
+  Fr two = add(Fr::one(), Fr::one());
+  Fr exy = sub(add(ex ? Fr::one() : Fr::zero(), ey ? Fr::one() : Fr::zero()), two);
+  return tx_is_zero(b, exy) ? (uint32_t)ST_OK : (uint32_t)ST_SIGNATURE;
 }
 // standard-form input below r -> Montgomery; false when it is not a field element
 ZKR_HDF bool tx_read_input(const Fr *p, Fr &out) {
@@ -339,7 +387,7 @@ ZKR_HDF TxLayout tx_layout(uint32_t batch, uint32_t depth) {
   return L;
 }
 // One transaction (or one of its TX_PARTS parts): inputs = the batch's n_public - 1 input signals (standard form), w = its
-// slice of K private signals (Montgomery values out), ws = 4 * WS_PTS scratch elements (part 0 only).  Returns the first
+// slice of K private signals (Montgomery values out), ws = TX_WS_ELEMS scratch elements (parts 0 and 1).  Returns the first
 // violated statement of what it ran (TxStmt: the codes are in program order, so the smallest non-zero code over the parts
 // is the transaction's); *root = its new root (part 2).
 ZKR_HDF uint32_t tx_witness(const Fr *inputs, uint32_t batch, uint32_t depth, uint32_t i, uint32_t K, const TxConsts &k, Fr *w, Fr *ws, Fr *root, int part = -1) {
@@ -349,6 +397,7 @@ ZKR_HDF uint32_t tx_witness(const Fr *inputs, uint32_t batch, uint32_t depth, ui
   b.w = w;
   b.n = 0;
   b.err = ST_OK;
+  if (part == 1) ws += 4 * WS_PTS;  // parts 0 and 1 both run scalar-multiplication chains, possibly at the same time
   b.wx = ws, b.wy = ws + WS_PTS, b.wz = ws + 2 * WS_PTS, b.wp = ws + 3 * WS_PTS;
   b.k = k;
   TxInD x;
