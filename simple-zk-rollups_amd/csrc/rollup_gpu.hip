@@ -5,6 +5,8 @@
 // (2^21 - 1 hashes of two elements) is 2.8 * 10^9 multiplications: tens of milliseconds here, minutes in the circomlib
 // BigInt code.  Host counterpart and round constants: rollup.cpp; parity against oracle/rollup.py in tests/test_gpu_rollup.py.
 #include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 #include "zkr_internal.hpp"
 #include "rollup_witness.hpp"
@@ -164,11 +166,20 @@ bool rollup_witness_fast_host(uint32_t batch, uint32_t depth, const uint8_t *inp
   memcpy(in.data(), inputs_std, (size_t)(p - 1) * 32);
   Fr *out = reinterpret_cast<Fr *>(out_bytes);
   const uint32_t tasks = batch * TX_PARTS;
+  // Threads of this call: at most twelve (tx.circom is twelve tasks), shared out between the calls that are inside this function
+  // at the same time -- a caller that already builds many witnesses side by side (the host-witness pipeline: fourteen callers on
+  // a sixteen-CPU quota) gets one thread per call instead of 168 that wait for each other
+  static std::atomic<int> calls_inside{0};
+  struct Inside { Inside() { calls_inside.fetch_add(1); } ~Inside() { calls_inside.fetch_sub(1); } } inside;
   unsigned hw = std::thread::hardware_concurrency();
-  if (const char *e = getenv("ZKR_WITNESS_THREADS")) { int v = atoi(e); if (v >= 1) hw = (unsigned)v; }
-  const uint32_t nthreads = std::max<uint32_t>(1, std::min<uint32_t>(tasks, hw ? hw : 1));
+  unsigned cap = 12;
+  if (const char *e = getenv("ZKR_WITNESS_THREADS")) { int v = atoi(e); if (v >= 1) hw = cap = (unsigned)v; }
+  const unsigned share = std::max(1u, std::min(hw ? hw : 1u, cap) / (unsigned)std::max(1, calls_inside.load()));
+  const uint32_t nthreads = std::max<uint32_t>(1, std::min<uint32_t>(tasks, share));
   const size_t total = (size_t)batch * K, slice = 4096, nslices = (total + slice - 1) / slice;
   std::atomic<uint32_t> next_task{0}, next_slice{0}, arrived{0};
+  std::mutex bar_mu;
+  std::condition_variable bar_cv;
   auto worker = [&] {
     {
       std::vector<Fr> ws(TX_WS_ELEMS);
@@ -181,8 +192,11 @@ bool rollup_witness_fast_host(uint32_t batch, uint32_t depth, const uint8_t *inp
           errs[(size_t)batch * TX_PARTS + i] = tx_finish(w.data() + (size_t)i * K, depth, K);
       }
     }
-    arrived.fetch_add(1);
-    while (arrived.load() < nthreads) std::this_thread::yield();  // every signal is in place before any slice is converted
+    {  // every signal is in place before any slice is converted (a blocking barrier: waiting threads do not spin)
+      std::unique_lock<std::mutex> lk(bar_mu);
+      if (arrived.fetch_add(1) + 1 == nthreads) bar_cv.notify_all();
+      else bar_cv.wait(lk, [&] { return arrived.load() >= nthreads; });
+    }
     for (uint32_t c; (c = next_slice.fetch_add(1)) < nslices;) {
       const size_t lo = (size_t)c * slice, hi = std::min(total, lo + slice);
       for (size_t s = lo; s < hi; s++) out[(size_t)p + 1 + s] = from_mont(w[s]);
