@@ -297,7 +297,10 @@ static int msm_accum_enqueue(Prof pf, hipStream_t s, const Affine<F> *pts, uint3
   static const int acc_w = acc_env ? atoi(acc_env) : MsmCfg<F>::ACC_W;
   // small bucket sets: several lanes per bucket (kernels_msm.hpp msm_accum_split_kernel)
   static const char *split_env = getenv("ZKR_ACC_SPLIT");
-  const int split = split_env ? atoi(split_env) : nb <= (1u << 17) ? 4 : 1;  // tx circuit (2^16 buckets): 379 / 455 / 458 / 393 proofs/s at 1 / 2 / 4 / 8
+  // lanes per bucket by bucket count, from single-proof latencies on the round's last tree: 2^11 / 2^13 / 2^15 buckets (circuits of
+  // 2^12 / 2^14 / 2^16): 1.52 / 1.31 / 1.33, 1.83 / 1.64 / 1.68, 1.76 / 1.69 / 2.00 ms at 2 / 4 / 8 lanes; the tx circuit's 2^16
+  // buckets: 2.30 / 2.02 / 2.15 / 2.52 ms at 1 / 2 / 4 / 8 (and 631 against 614 unfused pipelined proofs/s at 2 / 4)
+  const int split = split_env ? atoi(split_env) : nb <= (1u << 15) ? 4 : nb <= (1u << 17) ? 2 : 1;
   if (split > 1) {
     const unsigned sgrid = (unsigned)(((size_t)nb * split + ACC_THREADS - 1) / ACC_THREADS);
 #define ZKR_ACC_SPLIT_LAUNCH(SP) msm_accum_split_kernel<F, MsmCfg<F>::ACC_W, SP><<<sgrid, ACC_THREADS, 0, s>>>(pts, srt.offsets, srt.entries, nb, srt.counts, srt.order, (XYZZ<F> *)ws.buckets, onto)
