@@ -356,13 +356,34 @@ static int msm_big_finish_enqueue(Prof pf, hipStream_t s, uint32_t n, const MsmW
 template <class F>
 static int msm_reduce_enqueue(Prof pf, hipStream_t s, uint32_t n, int nbat, const MsmPlan &pl, const MsmWorkspace &srt, MsmWorkspace &ws) {
   if (n == 0) return 0;
+  // Group size of a FUSED launch: the plan's groups keep about 2^14 of them per proof, which is what a single proof of a small
+  // circuit needs to fill the chip (msm_plan); nbat proofs in one launch bring nbat times the groups, so they take larger ones --
+  // about 2^15 groups per launch -- and reduce2 / reduce3 have that much less to sum: the tx circuit in batches of eight 1 063 /
+  // 1 149 / 1 192 / 1 185 proofs/s at groups of 4 / 8 / 16 / 32 (tools/sweep_tx_fused_glog.sh).  The buffers are sized for the
+  // plan's (smaller) groups.  ZKR_MSM_GLOG_FUSED overrides.
+  int glog = pl.glog;
+  uint32_t S = pl.S;
+  if (nbat > 1) {
+    static const int fused_env = getenv("ZKR_MSM_GLOG_FUSED") ? atoi(getenv("ZKR_MSM_GLOG_FUSED")) : 0;
+    int lg = 0;
+    while (((uint64_t)1 << lg) < (uint64_t)pl.nbw * (uint64_t)nbat) lg++;
+    int want = fused_env >= 1 ? fused_env : lg - 15;
+    if (want > 5) want = 5;
+    if (want > pl.c - 1) want = pl.c - 1;
+    if (want > glog) {
+      glog = want;
+      const uint32_t ng = pl.nbw >> glog;
+      uint32_t s2 = (ng + 2047) / 2048;
+      S = s2 < 1 ? 1 : s2 > pl.S ? pl.S : s2;
+    }
+  }
   MsmGeom g;
-  g.n = n; g.c = pl.c; g.K = pl.K; g.nbw = pl.nbw; g.big_thresh = pl.big_thresh; g.glog = pl.glog; g.S = pl.S; g.batch = (uint32_t)nbat;
+  g.n = n; g.c = pl.c; g.K = pl.K; g.nbw = pl.nbw; g.big_thresh = pl.big_thresh; g.glog = glog; g.S = S; g.batch = (uint32_t)nbat;
   int sp = prof_begin(pf, s, "msm_reduce");
-  uint32_t ngroups = (pl.nbw >> pl.glog) * (uint32_t)nbat;
-  uint32_t ntask = (uint32_t)(pl.c - 1 - pl.glog) + 2;
+  uint32_t ngroups = (pl.nbw >> glog) * (uint32_t)nbat;
+  uint32_t ntask = (uint32_t)(pl.c - 1 - glog) + 2;
   msm_reduce1_kernel<F, MsmCfg<F>::RED_W><<<(ngroups + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, s>>>((const XYZZ<F> *)ws.buckets, g, (XYZZ<F> *)ws.group_out);
-  msm_reduce2_kernel<F, MsmCfg<F>::RED_W><<<dim3(ntask * pl.S, nbat), MSM_THREADS, MSM_THREADS * sizeof(XYZZ<F>), s>>>((const XYZZ<F> *)ws.group_out, g, (XYZZ<F> *)ws.task_out);
+  msm_reduce2_kernel<F, MsmCfg<F>::RED_W><<<dim3(ntask * S, nbat), MSM_THREADS, MSM_THREADS * sizeof(XYZZ<F>), s>>>((const XYZZ<F> *)ws.group_out, g, (XYZZ<F> *)ws.task_out);
   msm_reduce3_kernel<F, MsmCfg<F>::RED_W><<<nbat, MSM_THREADS, MSM_THREADS * sizeof(XYZZ<F>), s>>>((const XYZZ<F> *)ws.task_out, g, (XYZZ<F> *)ws.result);
   prof_end(pf, s, sp);
   ZKR_HIP_CHECK(hipMemcpyAsync(ws.h_result, ws.result, sizeof(XYZZ<F>) * nbat, hipMemcpyDeviceToHost, s));
