@@ -83,6 +83,21 @@ int zkr_key_adopt_arena(void *dev_ptr, size_t len, int device, zkr_key **out);
 int zkr_key_base_arena(zkr_key *key, void **dev_ptr, size_t *len);
 int zkr_key_adopt_base_arena(const void *dev_ptr, size_t len, int device, zkr_key **out);
 
+/* The same replication inside ONE process, device to device (SURVEY.md 8(b) "Threading": one host thread per GPU;
+ * 8(e)): the form a Node operator uses -- the reference's host awaits its proofs from one process
+ * (operator/src/snarks/common.ts:23-29) -- where no launcher starts a rank per GPU.  Copies `key` (on its own device)
+ * to `dst_device` and returns an independent key there (own workspaces; free both with zkr_key_free, in any order).
+ * mode FULL: the whole arena in peer copies of at most 1 GiB, adopted as is (nothing recomputed; over xGMI about
+ * 30 ms at 2^20); BASE: the compact arena (1/10 of the bytes) and a rebuild of the window levels on dst_device
+ * (about 0.1 s at 2^20) -- for device pairs without direct peer access, where the runtime stages the copy through host
+ * memory; AUTO: FULL when the devices can address each other (or are the same device), else BASE.  dst_device may be
+ * key's own device: a second replica there (two host threads, two proof pipelines on one GPU).  The replica's arena is
+ * byte-identical to the source's in every mode. */
+enum { ZKR_REPLICATE_AUTO = 0, ZKR_REPLICATE_FULL = 1, ZKR_REPLICATE_BASE = 2 };
+int zkr_key_replicate(const zkr_key *key, int dst_device, int mode, zkr_key **out);
+/* HIP ordinal of the device the key lives on. */
+int zkr_key_device(const zkr_key *key);
+
 /* ---- the hot path --------------------------------------------------------------------------- */
 /* One Groth16 proof.  witness_std: nVars x 32 B standard form (binarifyWitness layout, host memory).
  * r32/s32: blinding scalars (32 B LE, < r); pass NULL for both to draw them from the OS CSPRNG as
@@ -120,6 +135,17 @@ int zkr_prove_batch(zkr_key *key, const void *const *witnesses_std, size_t witne
  * from zkr_prove_device. */
 int zkr_prove_batch_device(zkr_key *key, const void *const *d_witnesses_std, size_t count, const uint8_t *r32s, const uint8_t *s32s, void *stream,
                            uint8_t *proofs_out);
+/* A batch over SEVERAL GPUs of the node from one process (BASELINE config 4: 64 independent proofs, 8 per GPU): keys[j] are
+ * replicas of one key on n_keys devices (zkr_key_replicate; the same device may appear through two replicas), proof i
+ * goes to keys[i mod n_keys], one host thread per key runs zkr_prove_batch / zkr_prove_batch_device on its share (uploads
+ * and proofs pipelined per device, small circuits fused), proofs_out keeps the caller's order.  No data moves between
+ * the devices.  r32s / s32s as in zkr_prove_batch.  _device: d_witnesses_std[i] is resident on the device of
+ * keys[i mod n_keys] and complete when the call is made.  The first failing share's status is returned with its
+ * message (prefixed by the key's index and device); the other shares still run to their end. */
+int zkr_prove_batch_multi(zkr_key *const *keys, size_t n_keys, const void *const *witnesses_std, size_t witness_len, size_t count, const uint8_t *r32s,
+                          const uint8_t *s32s, uint8_t *proofs_out);
+int zkr_prove_batch_multi_device(zkr_key *const *keys, size_t n_keys, const void *const *d_witnesses_std, size_t count, const uint8_t *r32s,
+                                 const uint8_t *s32s, uint8_t *proofs_out);
 /* Number of proof workspaces of the key = submits that can be in flight; proofs one batch submit fuses (1 at 2^20 and above). */
 int zkr_key_slots(const zkr_key *key);
 int zkr_key_fuse(const zkr_key *key);

@@ -7,13 +7,17 @@ export interface Groth16Proof {
   protocol?: "groth";
 }
 export interface ProveOptions { r?: bigint | string; s?: bigint | string; device?: number; }
+/** devices: HIP ordinals of the GPUs a batch is sharded over (a device may be listed twice: two proof pipelines on it). */
+export interface BatchOptions { devices?: number[]; blinding?: ProveOptions[]; }
 export interface Bn128 {
   /** websnark-compatible: ArrayBuffers produced by binarifyWitness / binarifyProvingKey. */
   groth16GenProof(witnessBin: ArrayBuffer | Uint8Array, provingKeyBin: ArrayBuffer | Uint8Array, opts?: ProveOptions): Promise<Groth16Proof>;
   /** Independent proofs on one key in one native call: pipelined two deep, proofs of small circuits fused into shared launches. */
-  groth16GenProofBatch(witnessBins: Array<ArrayBuffer | Uint8Array>, provingKeyBin: ArrayBuffer | Uint8Array, opts?: ProveOptions[]): Promise<Groth16Proof[]>;
+  /** opts: per-proof blinding (array), or { devices, blinding }: the batch is sharded over the listed GPUs of this node
+   *  (proof i on devices[i % devices.length]; the key is parsed once and copied device to device to the others). */
+  groth16GenProofBatch(witnessBins: Array<ArrayBuffer | Uint8Array>, provingKeyBin: ArrayBuffer | Uint8Array, opts?: ProveOptions[] | BatchOptions): Promise<Groth16Proof[]>;
   /** The same with the key currently held on the device. */
-  proveBatch(witnessBins: Array<ArrayBuffer | Uint8Array>, opts?: ProveOptions[]): Promise<Groth16Proof[]>;
+  proveBatch(witnessBins: Array<ArrayBuffer | Uint8Array>, opts?: ProveOptions[] | BatchOptions): Promise<Groth16Proof[]>;
   /** Groth16 setup of circom's circuit JSON on the GPU (snarkjs setup --protocol groth); returns the verifying key JSON. */
   setup(circuitDef: any, opts?: { toxic?: Array<bigint | string> }): any;
   /** The same for a constraint system in the r1cs_bin layout (RollupCircuit.r1cs()). */
@@ -72,7 +76,8 @@ export class WithdrawCircuit {
 
 // ---- process-level key cache (the reference builds a new Bn128 per proof: common.ts:23) and verifier constants
 /** Device keys loaded / found in the cache by groth16GenProof so far in this process. */
-export function keyCacheStats(): { loads: number; hits: number; entries: number };
+export function keyCacheStats(): { loads: number; hits: number; replications: number; entries: number; handles: number };
+export function keyFingerprint(provingKeyBin: ArrayBuffer | Uint8Array, full?: boolean): string;
 export function clearKeyCache(): void;
 /** vk_bin -> the constants of the generated verifier's verifyingKey() in the contract's encoding (G2 as [im, re]). */
 export function solidityVerifyingKey(vkBin: Uint8Array): { alfa1: string[]; beta2: string[][]; gamma2: string[][]; delta2: string[][]; IC: string[][] };

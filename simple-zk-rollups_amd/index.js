@@ -46,39 +46,98 @@ function bigintToLe32(v) {
 // snarkjs would reduce mod r, the chain refuses: the facade sides with the chain)
 const signalsInRange = (ps) => ps.every((x) => { const v = BigInt(x); return v >= 0n && v < R; });
 
-function keyFingerprint(device, buf) {
-  // identity of a provingKeyBin: device, length, SHA-256 of the first and last 4 KiB (the header carries alfa / beta /
-  // delta of the setup, the tail the last hExps points: two setups never share them)
+// Identity of a provingKeyBin: its length and a SHA-256 over the first 4 KiB (geometry, alfa / beta / delta of the setup), the
+// last 4 KiB (the last hExps points) and 64 blocks of 4 KiB spread evenly over everything in between.  Header and tail alone
+// would alias two circuits of equal sizes set up from the same toxic waste (seeded test setups: same header points, same
+// t^i Z / delta tail) and the cache would prove with the wrong key where the reference re-parses on every call
+// (operator/src/snarks/common.ts:28); the strided blocks reach into the QAP rows and every point section.  About 0.3 MB
+// hashed whatever the key's size (< 0.1 ms); tests/test_gpu_multi.py and tests/test_node_host.py hold the aliasing case.
+// full (default: env ZKR_KEY_FINGERPRINT === "full"): every byte is hashed -- exact, a few ms per MB -- for callers whose keys
+// may differ in a single constraint under one setup (sampling sees geometry, setup and broad content, not a lone coefficient).
+const FP_BLOCK = 4096, FP_STRIDED = 64;
+function keyFingerprint(buf, full) {
   const u8 = buf instanceof ArrayBuffer ? new Uint8Array(buf) : new Uint8Array(buf.buffer, buf.byteOffset, buf.byteLength);
   const n = u8.length;
   const h = require("crypto").createHash("sha256");
-  h.update(u8.subarray(0, Math.min(n, 4096)));
-  h.update(u8.subarray(Math.max(0, n - 4096), n));
-  return device + ":" + n + ":" + h.digest("hex");
+  if (full === undefined) full = process.env.ZKR_KEY_FINGERPRINT === "full";
+  if (full || n <= FP_BLOCK * (FP_STRIDED + 2)) h.update(u8);
+  else {
+    h.update(u8.subarray(0, FP_BLOCK));
+    const span = n - 2 * FP_BLOCK;
+    for (let i = 0; i < FP_STRIDED; i++) {
+      const o = FP_BLOCK + Math.floor((span - FP_BLOCK) * i / (FP_STRIDED - 1));
+      h.update(u8.subarray(o, o + FP_BLOCK));
+    }
+    h.update(u8.subarray(n - FP_BLOCK, n));
+  }
+  return n + ":" + h.digest("hex");
 }
 
 // Process-level cache of device keys (SURVEY.md 8(b) "Ownership").  The reference builds a NEW object for every proof
 // (`await buildBn128()` at operator/src/snarks/common.ts:23 and scripts/index.js:40) and passes it the same
 // provingKeyBin again (common.ts:28): a cache on the object would re-parse, re-upload and rebuild the window tables on
-// every call.  Least recently used of KEY_CACHE_SLOTS entries is dropped (its device memory goes with the handle).
+// every call.  An entry is one key CONTENT with its replicas, one per (device, ordinal) it has been asked for
+// (groth16GenProofBatch with opts.devices); the least recently used of KEY_CACHE_SLOTS contents is dropped with all its
+// replicas (their device memory goes with the handles).
 const KEY_CACHE_SLOTS = 2;
-const keyCache = new Map();  // fingerprint -> native key handle, in recency order
-const keyCacheStats = { loads: 0, hits: 0 };
-function cachedKey(provingKeyBin, device) {
-  const fp = keyFingerprint(device, provingKeyBin);
-  let key = keyCache.get(fp);
-  if (key !== undefined) {
-    keyCache.delete(fp);  // re-insert: most recently used last
-    keyCacheStats.hits++;
-  } else {
-    key = native().keyLoad(provingKeyBin, device);
-    keyCacheStats.loads++;
-  }
-  keyCache.set(fp, key);
+const keyCache = new Map();  // fingerprint -> Map("device#ordinal" -> native key handle), in recency order
+const keyCacheStats = { loads: 0, hits: 0, replications: 0 };
+function cacheEntry(provingKeyBin) {
+  const fp = keyFingerprint(provingKeyBin);
+  let ent = keyCache.get(fp);
+  if (ent !== undefined) keyCache.delete(fp);  // re-insert: most recently used last
+  else ent = new Map();
+  keyCache.set(fp, ent);
   while (keyCache.size > KEY_CACHE_SLOTS) keyCache.delete(keyCache.keys().next().value);
+  return ent;
+}
+function cachedKey(provingKeyBin, device) {
+  const ent = cacheEntry(provingKeyBin), slot = device + "#0";
+  let key = ent.get(slot);
+  if (key !== undefined) keyCacheStats.hits++;
+  else {
+    // another device already holds this key: copy it device to device instead of parsing the buffer again
+    const src = ent.size ? ent.values().next().value : undefined;
+    if (src !== undefined) { key = native().keyReplicate(src, device, 0); keyCacheStats.replications++; }
+    else { key = native().keyLoad(provingKeyBin, device); keyCacheStats.loads++; }
+    ent.set(slot, key);
+  }
   return key;
 }
+// one replica per entry of `devices` (a device listed twice gets two replicas: two proof pipelines on that GPU); the buffer is
+// parsed at most once, every further replica is a device-to-device copy of the first (zkr_key_replicate)
+function cachedReplicas(provingKeyBin, devices) {
+  const ent = cacheEntry(provingKeyBin), seen = new Map(), keys = [];
+  for (const d of devices) {
+    const ord = seen.get(d) || 0;
+    seen.set(d, ord + 1);
+    const slot = d + "#" + ord;
+    let key = ent.get(slot);
+    if (key !== undefined) keyCacheStats.hits++;
+    else {
+      const src = ent.size ? ent.values().next().value : undefined;
+      if (src !== undefined) { key = native().keyReplicate(src, d, 0); keyCacheStats.replications++; }
+      else { key = native().keyLoad(provingKeyBin, d); keyCacheStats.loads++; }
+      ent.set(slot, key);
+    }
+    keys.push(key);
+  }
+  return keys;
+}
 function clearKeyCache() { keyCache.clear(); }
+
+// blinding: null / undefined, or one {r, s} per proof (all or none)
+async function proveBatchOn(keys, witnessBins, blinding) {
+  const fixed = blinding && blinding.length === witnessBins.length && blinding.every((o) => o && o.r !== undefined && o.s !== undefined);
+  if (blinding && blinding.some((o) => o && (o.r !== undefined || o.s !== undefined)) && !fixed) throw new Error("proveBatch: fix the blinding of every proof or of none");
+  const rs = fixed ? Buffer.concat(blinding.map((o) => bigintToLe32(o.r))) : null;
+  const ss = fixed ? Buffer.concat(blinding.map((o) => bigintToLe32(o.s))) : null;
+  // keys.slice(): the addon references THIS array until the promise settles, so no replica is finalized under the job
+  const pbs = keys.length === 1 ? await native().proveBatch(keys[0], witnessBins, rs, ss) : await native().proveBatchMulti(keys.slice(), witnessBins, rs, ss);
+  const out = [];
+  for (let i = 0; i < witnessBins.length; i++) out.push(proofFromBytes(pbs.subarray(256 * i, 256 * i + 256)));
+  return out;
+}
 
 class Bn128 {
   constructor(device) { this.device = device || 0; this._fp = null; this._key = null; }
@@ -98,27 +157,47 @@ class Bn128 {
 
   // Independent proofs of one rollup batch on the same key: ONE native call (zkr_prove_batch on a libuv worker) that
   // pipelines uploads and proofs over the key's two workspaces and, for circuits far below the chip's size (the
-  // reference's tx circuit, 2^17), runs several proofs in shared launches.  opts[i] (optional) fixes the blinding of
-  // proof i (all or none).
+  // reference's tx circuit, 2^17), runs several proofs in shared launches.
+  // opts: an array -- opts[i] fixes the blinding {r, s} of proof i (all or none) -- or an object
+  //   { devices: [0, 1, ...], blinding: [{r, s}, ...] }
+  // devices: the GPUs of this node the batch is sharded over (BASELINE config 4: 64 proofs, 8 per GPU; SURVEY 8(e)): the key
+  // is parsed once, copied device to device to the others (zkr_key_replicate, cached like the first) and proof i runs on
+  // devices[i mod devices.length], one host thread per device inside zkr_prove_batch_multi; the result keeps the caller's order.
   async groth16GenProofBatch(witnessBins, provingKeyBin, opts) {
     if (witnessBins.length === 0) return [];
-    const a = native();
-    this._key = cachedKey(provingKeyBin, this.device);
+    native();
+    const devices = opts && !Array.isArray(opts) && opts.devices ? opts.devices.map(Number) : null;
+    const blinding = Array.isArray(opts) ? opts : opts && opts.blinding;
+    if (devices && devices.length === 0) throw new Error("groth16GenProofBatch: opts.devices is empty");
+    if (devices && devices.some((d) => !Number.isInteger(d) || d < 0 || d >= deviceCount)) throw new Error("groth16GenProofBatch: opts.devices names a GPU this node does not have (" + deviceCount + " visible)");
+    if (!devices) {
+      this._key = cachedKey(provingKeyBin, this.device);
+      this._fp = "websnark";
+      return this.proveBatch(witnessBins, blinding);
+    }
+    const keys = cachedReplicas(provingKeyBin, devices);
+    this._key = keys[0];
     this._fp = "websnark";
-    return this.proveBatch(witnessBins, opts);
+    return proveBatchOn(keys, witnessBins, blinding);
   }
-  // the same with the key currently held (after setup / loadKeyFile / a groth16GenProof call)
+  // the same with the key currently held (after setup / loadKeyFile / a groth16GenProof call); opts.devices as above: the held
+  // key is replicated to the devices it is not on yet (replicas are kept on this object)
   async proveBatch(witnessBins, opts) {
     if (!this._key) throw new Error("no key loaded");
     if (witnessBins.length === 0) return [];
-    const fixed = opts && opts.length === witnessBins.length && opts.every((o) => o && o.r !== undefined && o.s !== undefined);
-    if (opts && opts.some((o) => o && (o.r !== undefined || o.s !== undefined)) && !fixed) throw new Error("proveBatch: fix the blinding of every proof or of none");
-    const rs = fixed ? Buffer.concat(opts.map((o) => bigintToLe32(o.r))) : null;
-    const ss = fixed ? Buffer.concat(opts.map((o) => bigintToLe32(o.s))) : null;
-    const pbs = await native().proveBatch(this._key, witnessBins, rs, ss);
-    const out = [];
-    for (let i = 0; i < witnessBins.length; i++) out.push(proofFromBytes(pbs.subarray(256 * i, 256 * i + 256)));
-    return out;
+    const devices = opts && !Array.isArray(opts) && opts.devices ? opts.devices.map(Number) : null;
+    const blinding = Array.isArray(opts) ? opts : opts && opts.blinding;
+    if (!devices) return proveBatchOn([this._key], witnessBins, blinding);
+    if (!this._replicas || this._replicas.src !== this._key) this._replicas = { src: this._key, map: new Map([[native().keyDevice(this._key) + "#0", this._key]]) };
+    const seen = new Map(), keys = [];
+    for (const d of devices) {
+      const ord = seen.get(d) || 0;
+      seen.set(d, ord + 1);
+      const slot = d + "#" + ord;
+      if (!this._replicas.map.has(slot)) this._replicas.map.set(slot, native().keyReplicate(this._key, d, 0));
+      keys.push(this._replicas.map.get(slot));
+    }
+    return proveBatchOn(keys, witnessBins, blinding);
   }
 
   // ---- a key held on the device without the websnark buffer in between (INTEGRATION.md section 5)
@@ -154,7 +233,7 @@ class Bn128 {
     return { nVars: v[0], nPublic: v[1], domainSize: v[2], nnzA: v[3], nnzB: v[4] };
   }
 
-  terminate() { this._key = null; this._fp = null; }
+  terminate() { this._key = null; this._fp = null; this._replicas = null; }
 }
 
 async function buildBn128(device) {
@@ -381,7 +460,7 @@ class WithdrawCircuit {
 module.exports = {
   buildBn128, genProof, binarifyWitness, binarifyProvingKey, solidityProof, proofFromBytes, isValid, isValidBatch, binarifyVerifyingKey,
   binarifyR1cs, verifyingKeyFromBytes, solidityVerifyingKey, solidityVerifyingKeySource,
-  keyCacheStats: () => Object.assign({ entries: keyCache.size }, keyCacheStats), clearKeyCache,
+  keyCacheStats: () => Object.assign({ entries: keyCache.size, handles: Array.from(keyCache.values()).reduce((a, e) => a + e.size, 0) }, keyCacheStats), clearKeyCache, keyFingerprint,
   multiHash, multiHashBatch, buildBalanceTree, hashLeftRight, genPublicKey, formatPrivKeyForBabyJub, sign, verify, RollupCircuit, WithdrawCircuit,
   deviceCount: () => { native(); return deviceCount; },
   version: () => native().version(),

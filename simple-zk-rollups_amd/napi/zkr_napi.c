@@ -23,6 +23,9 @@ static struct {
   int (*key_info)(const zkr_key *, uint64_t *);
   int (*prove)(zkr_key *, const void *, size_t, const uint8_t *, const uint8_t *, uint8_t *, void *);
   int (*prove_batch)(zkr_key *, const void *const *, size_t, size_t, const uint8_t *, const uint8_t *, uint8_t *);
+  int (*prove_batch_multi)(zkr_key *const *, size_t, const void *const *, size_t, size_t, const uint8_t *, const uint8_t *, uint8_t *);
+  int (*key_replicate)(const zkr_key *, int, int, zkr_key **);
+  int (*key_device)(const zkr_key *);
   int (*verify)(const void *, size_t, const uint8_t *, const void *, size_t, int *);
   int (*verify_batch)(const void *, size_t, const uint8_t *, const void *, size_t, size_t, int *);
   int (*setup_r1cs)(const void *, size_t, const uint8_t *, int, zkr_key **, void **, size_t *);
@@ -76,7 +79,7 @@ static napi_value js_load(napi_env env, napi_callback_info info) {
   *(void **)(&Z.field) = dlsym(h, name);                                        \
   if (!Z.field) return throw_msg(env, "libzkr_hip.so lacks symbol " name);
     SYM(last_error, "zkr_last_error") SYM(version, "zkr_version") SYM(device_count, "zkr_device_count")
-    SYM(key_load_websnark, "zkr_key_load_websnark") SYM(key_free, "zkr_key_free") SYM(key_info, "zkr_key_info") SYM(prove, "zkr_prove") SYM(prove_batch, "zkr_prove_batch") SYM(verify, "zkr_verify") SYM(verify_batch, "zkr_verify_batch")
+    SYM(key_load_websnark, "zkr_key_load_websnark") SYM(key_free, "zkr_key_free") SYM(key_info, "zkr_key_info") SYM(prove, "zkr_prove") SYM(prove_batch, "zkr_prove_batch") SYM(prove_batch_multi, "zkr_prove_batch_multi") SYM(key_replicate, "zkr_key_replicate") SYM(key_device, "zkr_key_device") SYM(verify, "zkr_verify") SYM(verify_batch, "zkr_verify_batch")
     SYM(setup_r1cs, "zkr_setup_r1cs") SYM(key_save, "zkr_key_save") SYM(key_load_file, "zkr_key_load_file") SYM(free_, "zkr_free")
     SYM(multihash, "zkr_mimcsponge_multihash") SYM(pubkey, "zkr_babyjub_pubkey") SYM(eddsa_sign, "zkr_eddsa_sign") SYM(eddsa_verify, "zkr_eddsa_verify")
     SYM(multihash_batch, "zkr_mimcsponge_multihash_batch") SYM(tree_build, "zkr_balance_tree_build")
@@ -132,6 +135,36 @@ static napi_value js_key_load(napi_env env, napi_callback_info info) {
   napi_value ext;
   NAPI_OK(napi_create_external(env, key, key_finalize, NULL, &ext));
   return ext;
+}
+
+/* keyReplicate(key, device, mode) -> external handle of an independent replica on `device` (zkr_key_replicate: device-to-device
+ * copy of the key arena inside this process; mode 0 auto, 1 full arena, 2 compact arena + rebuild).  Synchronous, once per
+ * (key, device). */
+static napi_value js_key_replicate(napi_env env, napi_callback_info info) {
+  size_t argc = 3;
+  napi_value argv[3];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  if (!Z.handle) return throw_msg(env, "libzkr_hip.so not loaded");
+  zkr_key *src = NULL, *key = NULL;
+  int32_t dev = 0, mode = 0;
+  if (argc < 2 || napi_get_value_external(env, argv[0], (void **)&src) != napi_ok || napi_get_value_int32(env, argv[1], &dev) != napi_ok)
+    return throw_msg(env, "keyReplicate(key, device, mode)");
+  if (argc > 2) napi_get_value_int32(env, argv[2], &mode);
+  if (Z.key_replicate(src, dev, mode, &key)) return throw_msg(env, Z.last_error());
+  napi_value ext;
+  NAPI_OK(napi_create_external(env, key, key_finalize, NULL, &ext));
+  return ext;
+}
+/* keyDevice(key) -> HIP ordinal of the key's device */
+static napi_value js_key_device(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  zkr_key *key = NULL;
+  if (argc < 1 || napi_get_value_external(env, argv[0], (void **)&key) != napi_ok) return throw_msg(env, "keyDevice(key)");
+  napi_value out;
+  NAPI_OK(napi_create_int32(env, Z.key_device(key), &out));
+  return out;
 }
 
 /* setupR1cs(r1csBin, toxic160|null, device) -> [key handle, vkBin Buffer]: Groth16 setup on the GPU (zkr_setup_r1cs;
@@ -286,9 +319,11 @@ static napi_value js_prove(napi_env env, napi_callback_info info) {
 typedef struct {
   napi_async_work work;
   napi_deferred deferred;
-  napi_ref key_ref;
+  napi_ref key_ref;    /* the key handle, or the JS array of replica handles (proveBatchMulti): alive until the job is done */
   napi_ref *wit_refs;  /* one strong reference per witness buffer: the worker reads their memory, whatever the caller does to the array meanwhile */
   zkr_key *key;
+  zkr_key **keys;      /* proveBatchMulti: replicas of one key, one per device (zkr_prove_batch_multi); NULL for proveBatch */
+  size_t n_keys;
   const void **wits;
   size_t count, wit_len, n_refs;
   uint8_t *rs, *ss, *proofs;
@@ -302,12 +337,13 @@ static void batch_free(napi_env env, batch_job *j) {
   if (j->key_ref) napi_delete_reference(env, j->key_ref);
   for (size_t i = 0; i < j->n_refs; i++) napi_delete_reference(env, j->wit_refs[i]);
   if (j->work) napi_delete_async_work(env, j->work);
-  free(j->wit_refs); free(j->wits); free(j->rs); free(j->ss); free(j->proofs); free(j);
+  free(j->wit_refs); free(j->wits); free(j->keys); free(j->rs); free(j->ss); free(j->proofs); free(j);
 }
 static void batch_execute(napi_env env, void *data) {
   (void)env;
   batch_job *j = (batch_job *)data;
-  j->rc = Z.prove_batch(j->key, j->wits, j->wit_len, j->count, j->rs, j->ss, j->proofs);
+  j->rc = j->keys ? Z.prove_batch_multi(j->keys, j->n_keys, j->wits, j->wit_len, j->count, j->rs, j->ss, j->proofs)
+                  : Z.prove_batch(j->key, j->wits, j->wit_len, j->count, j->rs, j->ss, j->proofs);
   if (j->rc) { strncpy(j->err, Z.last_error(), sizeof(j->err) - 1); j->err[sizeof(j->err) - 1] = 0; }
 }
 static void batch_complete(napi_env env, napi_status status, void *data) {
@@ -329,16 +365,35 @@ static int is_nullish(napi_env env, napi_value v) {
   napi_valuetype t;
   return napi_typeof(env, v, &t) == napi_ok && (t == napi_undefined || t == napi_null);
 }
-static napi_value js_prove_batch(napi_env env, napi_callback_info info) {
+/* proveBatch(key, ...) and proveBatchMulti([key replicas...], ...) share everything but their first argument */
+static napi_value prove_batch_common(napi_env env, napi_callback_info info, int multi) {
   size_t argc = 4;
   napi_value argv[4];
   NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
   if (!Z.handle) return throw_msg(env, "libzkr_hip.so not loaded");
-  if (argc < 2) return throw_msg(env, "proveBatch(key, witnessBins, rs, ss)");
+  if (argc < 2) return throw_msg(env, "proveBatch(key, witnessBins, rs, ss) / proveBatchMulti(keys, witnessBins, rs, ss)");
   batch_job *j = (batch_job *)calloc(1, sizeof(batch_job));
   if (!j) return throw_msg(env, "proveBatch: out of memory");
   uint32_t count = 0;
-  if (napi_get_value_external(env, argv[0], (void **)&j->key) != napi_ok || napi_get_array_length(env, argv[1], &count) != napi_ok || count == 0) {
+  if (multi) {
+    uint32_t nk = 0;
+    if (napi_get_array_length(env, argv[0], &nk) != napi_ok || nk == 0 || !(j->keys = (zkr_key **)calloc(nk, sizeof(zkr_key *)))) {
+      batch_free(env, j);
+      return throw_msg(env, "proveBatchMulti: a non-empty array of key handles expected");
+    }
+    j->n_keys = nk;
+    for (uint32_t i = 0; i < nk; i++) {
+      napi_value kv;
+      if (napi_get_element(env, argv[0], i, &kv) != napi_ok || napi_get_value_external(env, kv, (void **)&j->keys[i]) != napi_ok) {
+        batch_free(env, j);
+        return throw_msg(env, "proveBatchMulti: every entry of keys must be a key handle");
+      }
+    }
+  } else if (napi_get_value_external(env, argv[0], (void **)&j->key) != napi_ok) {
+    batch_free(env, j);
+    return throw_msg(env, "proveBatch: a key and a non-empty array of witness buffers expected");
+  }
+  if (napi_get_array_length(env, argv[1], &count) != napi_ok || count == 0) {
     batch_free(env, j);
     return throw_msg(env, "proveBatch: a key and a non-empty array of witness buffers expected");
   }
@@ -385,6 +440,11 @@ static napi_value js_prove_batch(napi_env env, napi_callback_info info) {
   }
   return promise;
 }
+static napi_value js_prove_batch(napi_env env, napi_callback_info info) { return prove_batch_common(env, info, 0); }
+/* proveBatchMulti([key replicas], [witnessBin...], rs|null, ss|null) -> Promise<Buffer(256 * count)>: zkr_prove_batch_multi on a
+ * libuv worker, which runs one host thread per replica (proof i on keys[i mod n]); the array of handles is referenced until
+ * the promise settles, so no replica is finalized under the job. */
+static napi_value js_prove_batch_multi(napi_env env, napi_callback_info info) { return prove_batch_common(env, info, 1); }
 
 /* verify(vkBin, proofBytes256, publicBytes) -> boolean: the Groth16 pairing check on the host (zkr_verify; groth.isValid,
  * operator/src/snarks/common.ts:30-34).  Synchronous: a few milliseconds, no GPU. */
@@ -582,6 +642,8 @@ static napi_value init(napi_env env, napi_value exports) {
       {"keyLoad", NULL, js_key_load, NULL, NULL, NULL, napi_default, NULL}, {"keyInfo", NULL, js_key_info, NULL, NULL, NULL, napi_default, NULL},
       {"prove", NULL, js_prove, NULL, NULL, NULL, napi_default, NULL},     {"verify", NULL, js_verify, NULL, NULL, NULL, napi_default, NULL},
       {"proveBatch", NULL, js_prove_batch, NULL, NULL, NULL, napi_default, NULL},
+      {"proveBatchMulti", NULL, js_prove_batch_multi, NULL, NULL, NULL, napi_default, NULL},
+      {"keyReplicate", NULL, js_key_replicate, NULL, NULL, NULL, napi_default, NULL}, {"keyDevice", NULL, js_key_device, NULL, NULL, NULL, napi_default, NULL},
       {"setupR1cs", NULL, js_setup_r1cs, NULL, NULL, NULL, napi_default, NULL}, {"keySave", NULL, js_key_save, NULL, NULL, NULL, napi_default, NULL},
       {"keyLoadFile", NULL, js_key_load_file, NULL, NULL, NULL, napi_default, NULL},
       {"rollupCrypto", NULL, js_rollup_crypto, NULL, NULL, NULL, napi_default, NULL}, {"rollupCircuit", NULL, js_rollup_circuit, NULL, NULL, NULL, napi_default, NULL},

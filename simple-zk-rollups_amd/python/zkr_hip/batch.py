@@ -80,6 +80,42 @@ def broadcast_key(key, rank, world, device, dist=None, mode=None, key_cls=None):
     return key_cls.adopt_base_arena(buf.data_ptr(), buf.numel(), device)
 
 
+def replicate_key(key, rank, world, device, build_local, dist=None, side=None, mode=None, key_cls=None):
+    """broadcast_key with the fallback of SURVEY.md 8(e) row 3 ("replicas only ... if RCCL is unavailable"): when the
+    broadcast raises (RCCL cannot set up its transport: IPC handles refused, no peer access, a backend that is not there),
+    every rank builds the key itself with build_local() -- the same key from the same source: a packed key file or the
+    provingKeyBin uploaded over each GPU's own PCIe link, the seeded generator in bench.py -- and the batch goes on without
+    any collective on the key.  The ranks AGREE on the outcome over `side` (a gloo group: host TCP, independent of the GPU
+    transport): one rank falling back while another adopted the broadcast would still be a correct batch, but the reported
+    replication must be one fact.  A rank that hangs inside the collective is ended by the process group's timeout
+    (init_process_group(timeout=...)): the job then fails with a non-zero exit instead of waiting for ever.
+    ZKR_FORCE_BCAST_FAIL=1 raises in place of the broadcast (tests).  Returns (key, how): how = "single" (world 1), the
+    data backend's name ("nccl" = RCCL, "gloo") or "per-rank"."""
+    import os
+    if world == 1:
+        return key, "single"
+    if dist is None:
+        import torch.distributed as dist
+    ok, err, got = 1, None, None
+    try:
+        if os.environ.get("ZKR_FORCE_BCAST_FAIL") == "1":
+            raise RuntimeError("ZKR_FORCE_BCAST_FAIL=1: the key broadcast is made to fail")
+        got = broadcast_key(key, rank, world, device, dist, mode=mode, key_cls=key_cls)
+    except Exception as e:  # noqa: BLE001 -- whatever the transport raises: the fallback does not depend on it
+        ok, err = 0, e
+    flag = torch.tensor([ok], dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=side)   # host tensor over the side group (the default group when it is gloo itself)
+    if int(flag.item()) == 1:
+        return got, dist.get_backend()
+    if err is not None:
+        import sys
+        sys.stderr.write("zkr_hip: rank %d: key broadcast failed (%s: %s); every rank builds its own replica\n" % (rank, type(err).__name__, err))
+    got = None                                                # a replica adopted from a broadcast that failed elsewhere is dropped
+    if rank == 0 and key is not None:
+        return key, "per-rank"
+    return build_local(), "per-rank"
+
+
 def prove_batch(key, witnesses, blinding, rank=0, world=1):
     """Prove this rank's shard.  witnesses: list of bytes (or None for proofs of other ranks);
     blinding: list of (r, s).  Returns {index: proof_bytes} for the local shard."""

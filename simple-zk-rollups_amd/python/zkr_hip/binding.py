@@ -5,6 +5,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ZKR_HIP_LIB") or os.path.normpath(os.path.join(_HERE, "..", "..", "csrc", "libzkr_hip.so"))  # same override as index.js
 PROOF_BYTES = 256
+REPLICATE_MODES = {"auto": 0, "full": 1, "base": 2}   # zkr.h ZKR_REPLICATE_*
 STAGES = ("ingest", "spmv", "ntt", "msm_sort", "msm_accum_g1", "msm_accum_g2", "msm_big", "msm_reduce", "total",
           "spmv_a", "ntt_pass", "combine_h")   # the last three: single streaming kernels (bench.py roofline.streaming)
 _lib = None
@@ -45,6 +46,10 @@ def lib():
     L.zkr_key_adopt_arena.argtypes = [vp, sz, i, c.POINTER(vp)]
     L.zkr_key_base_arena.argtypes = [vp, c.POINTER(vp), c.POINTER(sz)]
     L.zkr_key_adopt_base_arena.argtypes = [vp, sz, i, c.POINTER(vp)]
+    L.zkr_key_replicate.argtypes = [vp, i, i, c.POINTER(vp)]
+    L.zkr_key_device.argtypes = [vp]
+    L.zkr_prove_batch_multi.argtypes = [c.POINTER(vp), sz, c.POINTER(c.c_char_p), sz, sz, u8p, u8p, u8p]
+    L.zkr_prove_batch_multi_device.argtypes = [c.POINTER(vp), sz, c.POINTER(vp), sz, u8p, u8p, u8p]
     L.zkr_prove.argtypes = [vp, u8p, sz, u8p, u8p, u8p, vp]
     L.zkr_prove_device.argtypes = [vp, vp, u8p, u8p, u8p, vp]
     L.zkr_prove_submit.argtypes = [vp, vp, u8p, u8p, vp, c.POINTER(i)]
@@ -178,6 +183,14 @@ class ProvingKey:
 
     def save(self, path):
         _check(lib().zkr_key_save(self._h, os.fsencode(path)))
+
+    def replicate(self, device, mode="auto"):
+        """An independent replica of this key on `device` (zkr_key_replicate): device-to-device copy inside this process,
+        no torch.distributed.  mode "full" (whole arena, adopted as is), "base" (compact arena + rebuild of the window
+        levels) or "auto" (full when the devices address each other).  `device` may be the key's own."""
+        h = ctypes.c_void_p()
+        _check(lib().zkr_key_replicate(self._h, device, REPLICATE_MODES[mode], ctypes.byref(h)))
+        return ProvingKey(h, device)
 
     def close(self):
         if self._h:
@@ -315,6 +328,40 @@ class ProvingKey:
             _check(lib().zkr_prof_get(self._h, st.encode(), ctypes.byref(ms), ctypes.byref(n)))
             out[st] = (ms.value, n.value)
         return out
+
+
+def _blinding_bytes(rs, ss):
+    rb = None if rs is None else b"".join(int(x).to_bytes(32, "little") for x in rs)
+    sb = None if ss is None else b"".join(int(x).to_bytes(32, "little") for x in ss)
+    return rb, sb
+
+
+def prove_batch_multi(keys, witnesses, rs=None, ss=None):
+    """zkr_prove_batch_multi: one batch of independent proofs over several replicas of a key (ProvingKey.replicate), proof i
+    on keys[i mod len(keys)], one host thread per key inside the library.  witnesses: host bytes of equal length."""
+    n = len(witnesses)
+    if n == 0:
+        return []
+    ks = (ctypes.c_void_p * len(keys))(*[k._h for k in keys])
+    arr = (ctypes.c_char_p * n)(*[bytes(w) for w in witnesses])
+    rb, sb = _blinding_bytes(rs, ss)
+    out = ctypes.create_string_buffer(256 * n)
+    _check(lib().zkr_prove_batch_multi(ks, len(keys), arr, len(witnesses[0]), n, rb, sb, out))
+    return [out.raw[256 * i:256 * i + 256] for i in range(n)]
+
+
+def prove_batch_multi_device(keys, d_witness_ptrs, rs=None, ss=None):
+    """zkr_prove_batch_multi_device: the same for witnesses resident in HBM; d_witness_ptrs[i] lives on the device of
+    keys[i mod len(keys)] and is complete (synchronise the producer first)."""
+    n = len(d_witness_ptrs)
+    if n == 0:
+        return []
+    ks = (ctypes.c_void_p * len(keys))(*[k._h for k in keys])
+    arr = (ctypes.c_void_p * n)(*[ctypes.c_void_p(p) for p in d_witness_ptrs])
+    rb, sb = _blinding_bytes(rs, ss)
+    out = ctypes.create_string_buffer(256 * n)
+    _check(lib().zkr_prove_batch_multi_device(ks, len(keys), arr, n, rb, sb, out))
+    return [out.raw[256 * i:256 * i + 256] for i in range(n)]
 
 
 def verify(vk_bin: bytes, proof: bytes, public_signals) -> bool:

@@ -111,35 +111,82 @@ def is_valid(verifying_key, proof, public_signals) -> bool:
 
 # Process-level cache of device keys (SURVEY.md 8(b) "Ownership").  The reference builds a NEW object for every proof
 # (`await buildBn128()` at common.ts:23, scripts/index.js:40) and hands it the same provingKeyBin again (common.ts:28),
-# so a cache on the object would re-parse, re-upload and rebuild the window tables on every call.  Keyed by
-# (device, length, digest of the first and last 4 KiB: header with alfa/beta/delta of the setup + the tail of hExps);
-# least recently used of KEY_CACHE_SLOTS entries is dropped (its device memory is freed when no proof uses it).
+# so a cache on the object would re-parse, re-upload and rebuild the window tables on every call.  An entry is one key
+# CONTENT (length + digest of the first and last 4 KiB and of 64 blocks of 4 KiB spread evenly in between: header and tail
+# alone alias two circuits of equal sizes set up from the same toxic waste) with its replicas, one per (device, ordinal)
+# asked for; the least recently used of KEY_CACHE_SLOTS contents is dropped with its replicas (a ProvingKey frees its arena
+# when the last reference goes).
 KEY_CACHE_SLOTS = 2
-_key_cache = collections.OrderedDict()
+FP_BLOCK, FP_STRIDED = 4096, 64
+_key_cache = collections.OrderedDict()   # fingerprint -> {(device, ordinal): ProvingKey}
 _key_cache_lock = threading.Lock()
-key_cache_stats = {"loads": 0, "hits": 0}
+key_cache_stats = {"loads": 0, "hits": 0, "replications": 0}
 
 
-def _key_fingerprint(device, buf):
-    head, tail = bytes(buf[:4096]), bytes(buf[-4096:])
-    return (device, len(buf), hashlib.blake2b(head + tail, digest_size=16).digest())
+def key_fingerprint(buf, full=None):
+    """(length, digest) identifying a provingKeyBin.  full (default: env ZKR_KEY_FINGERPRINT == "full"): digest of every
+    byte -- exact, ~1 ms per MB -- instead of the sampled blocks, for callers whose keys may differ in a single constraint
+    under one setup (sampling sees 0.3 MB of the buffer: any difference in geometry, setup or broad content, not a lone
+    36-byte coefficient)."""
+    import os
+    n = len(buf)
+    h = hashlib.blake2b(digest_size=16)
+    if full is None:
+        full = os.environ.get("ZKR_KEY_FINGERPRINT") == "full"
+    if full or n <= FP_BLOCK * (FP_STRIDED + 2):
+        h.update(bytes(buf))
+    else:
+        h.update(bytes(buf[:FP_BLOCK]))
+        span = n - 2 * FP_BLOCK
+        for i in range(FP_STRIDED):
+            o = FP_BLOCK + (span - FP_BLOCK) * i // (FP_STRIDED - 1)
+            h.update(bytes(buf[o:o + FP_BLOCK]))
+        h.update(bytes(buf[n - FP_BLOCK:]))
+    return (n, h.digest())
+
+
+def _entry(proving_key_bin):   # caller holds the lock
+    fp = key_fingerprint(proving_key_bin)
+    ent = _key_cache.get(fp)
+    if ent is None:
+        ent = _key_cache[fp] = {}
+    _key_cache.move_to_end(fp)
+    while len(_key_cache) > KEY_CACHE_SLOTS:
+        _key_cache.popitem(last=False)
+    return ent
+
+
+def _replica(ent, proving_key_bin, device, ordinal):
+    key = ent.get((device, ordinal))
+    if key is not None:
+        key_cache_stats["hits"] += 1
+        return key
+    if ent:   # another replica holds this content: device-to-device copy instead of a second parse
+        key = next(iter(ent.values())).replicate(device)
+        key_cache_stats["replications"] += 1
+    else:
+        key = ProvingKey.load_websnark(proving_key_bin, device)
+        key_cache_stats["loads"] += 1
+    ent[(device, ordinal)] = key
+    return key
 
 
 def cached_key(proving_key_bin, device=0):
     """The device key for this provingKeyBin: parsed and uploaded on first sight, reused afterwards by every Bn128."""
-    fp = _key_fingerprint(device, proving_key_bin)
     with _key_cache_lock:
-        key = _key_cache.get(fp)
-        if key is not None:
-            _key_cache.move_to_end(fp)
-            key_cache_stats["hits"] += 1
-            return key
-        key = ProvingKey.load_websnark(proving_key_bin, device)
-        key_cache_stats["loads"] += 1
-        _key_cache[fp] = key
-        while len(_key_cache) > KEY_CACHE_SLOTS:
-            _key_cache.popitem(last=False)   # the ProvingKey frees its arena when the last reference goes
-        return key
+        return _replica(_entry(proving_key_bin), proving_key_bin, device, 0)
+
+
+def cached_replicas(proving_key_bin, devices):
+    """One replica per entry of `devices` (a device listed twice gets two): the buffer is parsed at most once, every further
+    replica is a device-to-device copy (zkr_key_replicate)."""
+    with _key_cache_lock:
+        ent, seen, keys = _entry(proving_key_bin), {}, []
+        for d in devices:
+            ordinal = seen.get(d, 0)
+            seen[d] = ordinal + 1
+            keys.append(_replica(ent, proving_key_bin, d, ordinal))
+        return keys
 
 
 def clear_key_cache():
@@ -156,6 +203,19 @@ class Bn128:
     def groth16GenProof(self, witness_bin: bytes, proving_key_bin: bytes, r=None, s=None):
         # the reference re-encodes and re-parses the key on every call (common.ts:28-29) on a fresh object (:23)
         return proof_json_from_bytes(cached_key(proving_key_bin, self.device).prove(witness_bin, r, s))
+
+    def groth16GenProofBatch(self, witness_bins, proving_key_bin, rs=None, ss=None, devices=None):
+        """Independent proofs of one rollup batch on one key in one native call (index.js groth16GenProofBatch).  devices:
+        the GPUs of this node the batch is sharded over (proof i on devices[i mod len]; SURVEY 8(e), BASELINE config 4) --
+        zkr_prove_batch_multi over cached replicas; None: this object's device."""
+        from .binding import prove_batch_multi
+        if not witness_bins:
+            return []
+        if devices is None:
+            proofs = cached_key(proving_key_bin, self.device).prove_batch(witness_bins, rs, ss)
+        else:
+            proofs = prove_batch_multi(cached_replicas(proving_key_bin, list(devices)), witness_bins, rs, ss)
+        return [proof_json_from_bytes(p) for p in proofs]
 
 
 def build_bn128(device=0):

@@ -65,7 +65,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, mode, q):
+def _worker(rank, world, port, mode, q, fail=False):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(root, "simple-zk-rollups_amd", "python"))
@@ -75,7 +75,11 @@ def _worker(rank, world, port, mode, q):
     import zkr_hip.batch as zb
     zb.ARENA_CHUNK = 30_000                                    # the arena goes in pieces, the last one short
     key = _StubKey(_stub_base()) if rank == 0 else None
-    key = zkr_hip.broadcast_key(key, rank, world, None, dist, mode=mode, key_cls=_StubKey)   # the real replication code
+    if fail:
+        os.environ["ZKR_FORCE_BCAST_FAIL"] = "1"
+    # the real replication code: broadcast_key inside replicate_key, which falls back to a replica built by every rank itself
+    key, how = zkr_hip.replicate_key(key, rank, world, None, lambda: _StubKey(_stub_base()), dist, None, mode=mode, key_cls=_StubKey)
+    assert how == ("per-rank" if fail else "gloo"), how
     count = 9
     witnesses = [bytes([i]) * 64 for i in range(count)]
     blinding = [(100 + i, 200 + i) for i in range(count)]
@@ -112,6 +116,28 @@ def test_two_rank_batch_over_gloo(mode):
     key = _StubKey(_stub_base())
     allp = zkr_hip.prove_batch(key, [bytes([i]) * 64 for i in range(9)], [(100 + i, 200 + i) for i in range(9)])
     assert hashlib.sha256(b"".join(allp[i] for i in range(9))).hexdigest() == res[0][1]
+
+
+def test_two_rank_batch_survives_a_failed_key_broadcast():
+    """SURVEY.md 8(e) row 3 ("replicas only ... keep as fallback if RCCL is unavailable"): the key
+    broadcast raises on every rank (ZKR_FORCE_BCAST_FAIL=1 stands for an RCCL transport that cannot be set up), the ranks
+    agree on it over the control-plane group, every rank builds its own replica and the batch is the same batch."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, "full", q, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    import zkr_hip
+    key = _StubKey(_stub_base())
+    allp = zkr_hip.prove_batch(key, [bytes([i]) * 64 for i in range(9)], [(100 + i, 200 + i) for i in range(9)])
+    want = hashlib.sha256(b"".join(allp[i] for i in range(9))).hexdigest()
+    assert res[0][1] == res[1][1] == want and res[0][3] == res[1][3] == 100_003 + 32 * 64
 
 
 def test_shard_indices_partition():

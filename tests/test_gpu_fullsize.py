@@ -347,3 +347,47 @@ def test_bench_two_rank_path_rehearsal_on_one_gpu(launcher):
     assert abs(d["value"] - 2 * 6 / (d["ms_per_step"] * 6e-3)) < 1e-6 * d["value"]      # whole-job rate: all ranks' proofs / max time
     assert d["key"]["bcast_s"] is not None and d["key"]["bcast_GBps"] > 0 and d["proofs_verified"] >= 1
     assert [(p["rank"], p["proofs"]) for p in d["per_rank"]] == [(0, 6), (1, 6)]
+
+
+def test_bench_two_rank_rehearsal_survives_a_failed_broadcast():
+    """the key broadcast fails on every rank (ZKR_FORCE_BCAST_FAIL=1), bench.py's ranks agree on it over
+    the control-plane group, each builds its own replica and the line says so (`key.replication: "per-rank"`)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ZKR_BENCH_BACKEND="gloo", ZKR_BENCH_ONE_GPU="1", ZKR_FORCE_BCAST_FAIL="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--log-m", "13"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["key"]["replication"] == "per-rank" and d["key"]["bcast_GBps"] is None
+    assert [(p["rank"], p["proofs"]) for p in d["per_rank"]] == [(0, 4), (1, 4)] and d["proofs_verified"] == 4
+    assert "every rank builds its own replica" in r.stderr
+
+
+@pytest.mark.parametrize("mode", ["auto", "base"])
+def test_bench_inproc_multi_device_rehearsal_on_one_gpu(mode):
+    """`python bench.py --gpus 2 --inproc`: N GPUs from ONE process through zkr_key_replicate +
+    zkr_prove_batch_multi_device, no torch.distributed; on this one-GPU box both replicas sit on device 0 (--devices 0,0).
+    Same JSON shape as the ranks' line; every timed proof goes through the native verifier."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--inproc", "--devices", "0,0", "--replicate-mode", mode,
+                        "--steps", "5", "--warmup", "1", "--log-m", "14"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["scaling"] == "weak" and d["proofs_verified"] == 10
+    assert abs(d["value"] - 10 / (d["ms_per_step"] * 5e-3)) < 1e-6 * d["value"]
+    assert d["config"]["devices"] == [0, 0] and "REHEARSAL" in d["config"]["parallelism"]
+    assert len(d["key"]["replicas"]) == 1 and d["key"]["replicas"][0]["GBps"] > 0
+    assert d["roofline"]["frac"] > 0 and set(d) >= {"metric", "value", "unit", "roofline", "config", "dtype", "data", "vs_baseline"}

@@ -131,6 +131,47 @@ def test_js_batch_runs_concurrent_proofs_on_one_key(tmp_path, small_case):
         assert p == g.proof_to_json(g.proof_from_toxic(c["circ"], c["tox"], c["w"], c["r"] + i, c["s"] + 2 * i))
 
 
+@pytest.mark.gpu
+def test_js_batch_over_devices_replicates_the_key_and_shards_the_proofs(tmp_path, small_case):
+    """index.js groth16GenProofBatch(witnessBins, provingKeyBin, {devices, blinding}): the Node host of the
+    reference (operator/src/snarks/common.ts:23-29) shards one batch over the GPUs of its node from ONE process --
+    N-API proveBatchMulti -> zkr_prove_batch_multi over replicas made by keyReplicate -> zkr_key_replicate.  One device on
+    the box: devices = [0, 0] (two replicas side by side).  Proofs == closed form, in the caller's order; the buffer is
+    parsed once, replicated once, then only cache hits; the keyed form (setup + proveBatch({devices})) gives the same."""
+    c = small_case
+    path = _key_json(tmp_path, c)
+    out = _node("""
+      const z = require('./index.js'); const fs = require('fs');
+      const d = JSON.parse(fs.readFileSync(process.argv[1]));
+      (async () => {
+        const n = 11, devices = z.deviceCount() > 1 ? [0, 1] : [0, 0];
+        const wb = z.binarifyWitness(d.witness);
+        const blinding = [];
+        for (let i = 0; i < n; i++) blinding.push({r: (BigInt(d.r) + BigInt(i)).toString(), s: (BigInt(d.s) + BigInt(2 * i)).toString()});
+        const wbs = new Array(n).fill(wb);
+        const stats = [];
+        const multi = await (await z.buildBn128()).groth16GenProofBatch(wbs, z.binarifyProvingKey(d.pk), {devices, blinding}); stats.push(z.keyCacheStats());
+        const again = await (await z.buildBn128()).groth16GenProofBatch(wbs, z.binarifyProvingKey(d.pk), {devices, blinding}); stats.push(z.keyCacheStats());
+        const single = await (await z.buildBn128()).groth16GenProofBatch(wbs, z.binarifyProvingKey(d.pk), blinding); stats.push(z.keyCacheStats());
+        const drawn = await (await z.buildBn128()).groth16GenProofBatch([wb, wb, wb], z.binarifyProvingKey(d.pk), {devices});
+        let refused = 0;
+        for (const bad of [{devices: []}, {devices: [0, 99]}, {devices: [0, 0], blinding: blinding.slice(0, 3)}])
+          try { await (await z.buildBn128()).groth16GenProofBatch(wbs, z.binarifyProvingKey(d.pk), bad); } catch (e) { refused++; }
+        // the held key of a Bn128 (after one proof) over devices: replicas kept on the object
+        const bn = await z.buildBn128();
+        await bn.groth16GenProof(wb, z.binarifyProvingKey(d.pk));
+        const held = await bn.proveBatch(wbs, {devices, blinding});
+        console.log(JSON.stringify({multi, again, single, held, stats, refused, distinct: new Set(drawn.map((p) => p.pi_a[0])).size}));
+      })().catch(e => { console.error(e); process.exit(1); });
+    """, path).stdout
+    res = json.loads(out)
+    expect = [g.proof_to_json(g.proof_from_toxic(c["circ"], c["tox"], c["w"], c["r"] + i, c["s"] + 2 * i)) for i in range(11)]
+    assert res["multi"] == expect and res["again"] == expect and res["single"] == expect and res["held"] == expect
+    assert res["refused"] == 3 and res["distinct"] == 3
+    st = [(x["loads"], x["replications"], x["hits"], x["entries"], x["handles"]) for x in res["stats"]]
+    assert st == [(1, 1, 0, 1, 2), (1, 1, 2, 1, 2), (1, 1, 3, 1, 2)]
+
+
 def test_js_is_valid_on_native_verifier(tmp_path, small_case):
     """index.js isValid(vk, proof, publicSignals) = snarkjs groth.isValid (common.ts:30-34) on zkr_verify; CPU only."""
     c = small_case
