@@ -637,6 +637,48 @@ def roofline_record(key, info, prof, per_proof_s, device_state, log_m, shape, lo
     return roofline, whole
 
 
+def shard_leg(key, d_wit, parts, want_proof, local):
+    """Intra-proof sharding on ONE GPU (BASELINE configs[2] and [4] are single proofs): the key is cut into
+    `parts` shards side by side on this device, every shard's share of one proof runs ALONE (synchronously, one after the
+    other), and the slowest share + the host combination is what a proof would take with one shard per GPU -- a PROJECTION
+    (no xGMI, no second device involved: the shards exchange nothing but 640 bytes each at the end), labelled as such.
+    The combined proof must be the bytes of the whole key's proof."""
+    import zkr_hip
+    whole = key.prove_device(d_wit.data_ptr(), r=1000003, s=2000003)
+    t1 = time.perf_counter()
+    for i in range(3):
+        key.prove_device(d_wit.data_ptr(), r=1000003, s=2000003)
+    whole_ms = 1e3 * (time.perf_counter() - t1) / 3
+    shards, rows = [], []
+    t1 = time.perf_counter()
+    for i in range(parts):
+        shards.append(key.shard(i, parts, device=local))
+    build_s = time.perf_counter() - t1
+    partials = []
+    for sh in shards:
+        sh.prove_partial_device(d_wit.data_ptr())                       # warm: launch plans, staging
+        t1 = time.perf_counter()
+        for _ in range(3):
+            part = sh.prove_partial_device(d_wit.data_ptr())
+        ms = 1e3 * (time.perf_counter() - t1) / 3
+        partials.append(part)
+        inf = sh.info()
+        rows.append({"part": sh.shard_info()["part"], "ms": ms, "arena_bytes": sh.arena()[1], "points": sum(inf[t] for t in ("ptsA", "ptsB1", "ptsB2", "ptsC", "ptsH"))})
+    t1 = time.perf_counter()
+    proof = shards[0].prove_combine(partials, 1000003, 2000003)
+    combine_ms = 1e3 * (time.perf_counter() - t1)
+    same = proof == whole and (want_proof is None or proof == want_proof)
+    for sh in shards:
+        sh.close()
+    if not same:
+        raise SystemExit("the sharded proof differs from the whole key's proof")
+    slowest = max(r["ms"] for r in rows)
+    return {"parts": parts, "whole_key_sync_proof_ms": whole_ms, "per_shard": rows, "slowest_shard_ms": slowest, "combine_ms": combine_ms,
+            "projected_latency_ms_one_shard_per_gpu": slowest + combine_ms, "projected_speedup": whole_ms / (slowest + combine_ms),
+            "shard_build_s": build_s, "proof_identical_to_whole_key": True,
+            "note": "PROJECTED: shards measured one at a time on one GPU; every shard recomputes h (replicated compute), so the exchange is 640 B per shard"}
+
+
 def verify_timed_proofs(vk_bin, proofs, pubs_of):
     """Acceptance check outside the timed region: EVERY proof goes through the native host verifier (the pairing equation of
     common.ts:30-38 / TxVerifier.sol:258-276), merged into one pairing product by a random linear combination
@@ -962,7 +1004,7 @@ def main():
         if world == 1 and not args.no_bcast_modes:
             out["key"]["replication_modes_one_gpu"] = bcast_modes_leg(key, bytes(wits[0].cpu().numpy().tobytes()), local)
         if world == 1 and args.shards > 1:
-            out["intra_proof_sharding"] = shard_leg(key, wits[0], args.shards, proofs[0] if not args.no_pipeline else None, local)
+            out["intra_proof_sharding"] = shard_leg(key, wits[0], args.shards, proofs[0], local)
         if world == 1 and not args.no_tx_circuit:
             key.close()  # its four streams would share the hardware queues with the streams of the tx-circuit key
             out["dropin"] = dropin_leg(local)

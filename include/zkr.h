@@ -146,6 +146,31 @@ int zkr_prove_batch_multi(zkr_key *const *keys, size_t n_keys, const void *const
                           const uint8_t *s32s, uint8_t *proofs_out);
 int zkr_prove_batch_multi_device(zkr_key *const *keys, size_t n_keys, const void *const *d_witnesses_std, size_t count, const uint8_t *r32s,
                                  const uint8_t *s32s, uint8_t *proofs_out);
+/* ---- ONE proof over several GPUs (BASELINE configs[2] and [4] are single proofs) ----------------------
+ * The MSMs shard by contiguous ranges: zkr_key_shard cuts every scalar vector of the proof -- the witness w (A, B1, B2, C
+ * tables) and the quotient coefficients h (H table) -- into `parts` equal ranges and builds, on `device`, a key holding
+ * range `part` of every point table (all window levels, copied device to device from `key`: nothing is recomputed) plus the
+ * whole QAP and the twiddles: every shard computes h itself ("replicated compute"), so NOTHING is exchanged but the
+ * partial sums at the end -- 640 bytes per shard.  The key is sharded, not replicated: a shard holds about 1/parts of the
+ * table memory (78 GB at 2^24).
+ * zkr_prove_partial(_device) runs a shard's whole share of one proof (host / HBM-resident witness, the FULL witness either
+ * way) and returns its partial sums of A, B1, B2 and C + H (ZKR_PARTIAL_BYTES, this library's XYZZ points in Montgomery
+ * form: opaque to the caller); zkr_prove_combine adds the `parts` records and does the usual assembly (r32 / s32 as in
+ * zkr_prove; `key` = any of the shards, or the whole key: they carry the same alfa, beta, delta).  The proof is the same
+ * bytes as zkr_prove's on the whole key.  zkr_prove_sharded(_device): the three steps in one call, one host thread per
+ * shard (shards[i] = part i of `parts`; _device: d_witnesses_std[i] = the full witness resident on shard i's device). */
+#define ZKR_PARTIAL_BYTES 640
+int zkr_key_shard(const zkr_key *key, unsigned part, unsigned parts, int device, zkr_key **out);
+int zkr_prove_partial(zkr_key *shard, const void *witness_std, size_t witness_len, uint8_t partial_out[ZKR_PARTIAL_BYTES]);
+int zkr_prove_partial_device(zkr_key *shard, const void *d_witness_std, void *stream, uint8_t partial_out[ZKR_PARTIAL_BYTES]);
+int zkr_prove_combine(zkr_key *key, const uint8_t *partials, size_t parts, const uint8_t *r32, const uint8_t *s32, uint8_t proof_out[256]);
+int zkr_prove_sharded(zkr_key *const *shards, size_t parts, const void *witness_std, size_t witness_len, const uint8_t *r32, const uint8_t *s32,
+                      uint8_t proof_out[256]);
+int zkr_prove_sharded_device(zkr_key *const *shards, size_t parts, const void *const *d_witnesses_std, const uint8_t *r32, const uint8_t *s32,
+                             uint8_t proof_out[256]);
+/* out[0] = part, out[1] = parts (0, 1 for a whole key), out[2..3] = first scalar and count of the witness range,
+ * out[4..5] = the same for h. */
+int zkr_key_shard_info(const zkr_key *key, uint32_t out[6]);
 /* Number of proof workspaces of the key = submits that can be in flight; proofs one batch submit fuses (1 at 2^20 and above). */
 int zkr_key_slots(const zkr_key *key);
 int zkr_key_fuse(const zkr_key *key);

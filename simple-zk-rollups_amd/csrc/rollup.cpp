@@ -23,6 +23,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <map>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -805,6 +806,56 @@ static uint32_t tx_private_count(uint32_t depth) {
   return cache[depth];
 }
 
+static void batch_gadget(Builder &B, uint32_t batch, uint32_t depth);
+// ZKR_WITNESS_VERIFY=1 (CI / debugging): index of the first constraint of the EMITTED system (zkr_rollup_r1cs, cached per
+// geometry) that the witness violates, -1 when it satisfies them all.  The fast path below returns the value program's witness
+// whenever its own statement checks pass; this is the net under that hand-written list -- a missed statement would otherwise
+// only show later, as an invalid proof.
+static long first_violated_constraint(uint32_t batch, uint32_t depth, const uint8_t *witness_std, size_t n_signals) {
+  static std::mutex mu;
+  static std::map<std::pair<uint32_t, uint32_t>, std::vector<uint8_t>> systems;
+  const std::vector<uint8_t> *sys = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = systems.find({batch, depth});
+    if (it == systems.end()) {
+      Builder B(true, false);
+      B.out.resize(12);
+      batch_gadget(B, batch, depth);
+      uint32_t hdr[3] = {(uint32_t)B.w.size(), n_public_of(batch, depth), B.n_constraints};
+      memcpy(B.out.data(), hdr, 12);
+      it = systems.emplace(std::make_pair(batch, depth), std::move(B.out)).first;
+    }
+    sys = &it->second;
+  }
+  uint32_t hdr[3];
+  memcpy(hdr, sys->data(), 12);
+  if (hdr[0] != n_signals) return 0;
+  std::vector<Fr> w(n_signals);
+  for (size_t i = 0; i < n_signals; i++)
+    if (!fr_read_std(witness_std + 32 * i, w[i])) return 0;
+  size_t off = 12;
+  for (uint32_t c = 0; c < hdr[2]; c++) {
+    Fr v[3];
+    for (int side = 0; side < 3; side++) {
+      uint32_t k;
+      memcpy(&k, sys->data() + off, 4);
+      off += 4;
+      Fr acc = Fr::zero();
+      for (uint32_t e = 0; e < k; e++, off += 36) {
+        uint32_t sig;
+        memcpy(&sig, sys->data() + off, 4);
+        Fr cf;
+        if (sig >= n_signals || !fr_read_std(sys->data() + off + 4, cf)) return (long)c;
+        acc = add(acc, mul(cf, w[sig]));
+      }
+      v[side] = acc;
+    }
+    if (!(mul(v[0], v[1]) == v[2])) return (long)c;
+  }
+  return -1;
+}
+
 // Witness pass: the transactions of a batch only meet in the root chain, so each one is built on its own thread
 // (same gadget code, same signal order) and writes its private signals straight into its slice of the result, laid out
 // as binarifyWitness does (32 B standard form per signal; malloc'ed, the caller frees).
@@ -822,6 +873,14 @@ static bool batch_witness(uint32_t batch, uint32_t depth, const Fr *inputs, cons
   // holds the two builders equal signal for signal; whenever a statement fails the gadget builder below runs and names it.
   const bool no_fast = getenv("ZKR_WITNESS_GADGETS") != nullptr;  // read per call: the tests switch builders inside one process
   if (!no_fast && zkr::rollup_witness_fast_host(batch, depth, inputs_std, out)) {
+    if (const char *e = getenv("ZKR_WITNESS_VERIFY"); e && atoi(e) != 0) {
+      const long bad = first_violated_constraint(batch, depth, out, total / 32);
+      if (bad >= 0) {
+        free(out);
+        err = "internal: the fast witness builder's result violates constraint " + std::to_string(bad) + " of the emitted system (ZKR_WITNESS_VERIFY)";
+        return false;
+      }
+    }
     *out_buf = out;
     *out_len = total;
     return true;

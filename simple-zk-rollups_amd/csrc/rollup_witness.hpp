@@ -38,12 +38,22 @@ struct TxConsts {
 struct TxB {
   Fr *w;         // this transaction's private signals, in allocation order (Montgomery until the layout kernel)
   uint32_t n;    // signals allocated so far
+  uint32_t cap;  // signals `w` has room for (the structure pass's count K); a program that ran past it fails with ST_COUNT
   uint32_t err;  // first violated statement in program order (TxStmt)
   Fr *wx, *wy, *wz, *wp;  // workspace: WS_PTS coordinates each
   TxConsts k;
-  ZKR_HD Fr put(const Fr &v) { w[n++] = v; return v; }
-  ZKR_HD void fail(uint32_t code) { if (!err) err = code; }
+  ZKR_HD Fr put(const Fr &v) {
+#ifndef __HIP_DEVICE_COMPILE__
+    // host build (zkr_rollup_witness, the CPU tests): never past the slice -- one signal too many must not write into the next
+    // transaction's; the device build keeps the bare store (the program is the same: what the host run proves holds there)
+    if (n >= cap) { fail(ST_COUNT); n++; return v; }
+#endif
+    w[n++] = v;
+    return v;
+  }
+  ZKR_HD void fail(uint32_t code);
 };
+ZKR_HD void TxB::fail(uint32_t code) { if (!err) err = code; }
 struct PtD { Fr x, y, z; };
 ZKR_HDF PtD ptd_add(const TxB &b, const PtD &p, const PtD &q) {  // add-2008-bbjlp, complete on BabyJub (rollup.cpp pt_add)
   Fr A = mul(p.z, q.z), B = sqr(A), C = mul(p.x, q.x), D = mul(p.y, q.y);
@@ -356,6 +366,7 @@ ZKR_HDF uint32_t tx_finish(Fr *w, uint32_t depth, uint32_t K) {
   TxB b;
   b.w = w;
   b.n = o_base8 + TX_BASE8_SIGNALS;
+  b.cap = K;
   b.err = ST_OK;
   const Fr rx = w[o_base8 - 2], ry = w[o_base8 - 1], lx = w[b.n - 2], ly = w[b.n - 1];
   const bool ex = tx_is_zero(b, sub(lx, rx)), ey = tx_is_zero(b, sub(ly, ry));
@@ -396,6 +407,7 @@ ZKR_HDF uint32_t tx_witness(const Fr *inputs, uint32_t batch, uint32_t depth, ui
   TxB b;
   b.w = w;
   b.n = 0;
+  b.cap = K;
   b.err = ST_OK;
   if (part == 1) ws += 4 * WS_PTS;  // parts 0 and 1 both run scalar-multiplication chains, possibly at the same time
   b.wx = ws, b.wy = ws + WS_PTS, b.wz = ws + 2 * WS_PTS, b.wp = ws + 3 * WS_PTS;

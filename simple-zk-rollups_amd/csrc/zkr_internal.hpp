@@ -49,7 +49,7 @@ enum { T_A = 0, T_B1 = 1, T_B2 = 2, T_C = 3, T_H = 4, N_TABLES = 5 };
 // The device key is ONE position-independent arena: header + sections addressed by byte offsets,
 // so a replica on another GPU is a single broadcast of [arena, arena+len).
 struct ArenaHeader {
-  uint64_t magic;      // "ZKRKEY03"
+  uint64_t magic;      // "ZKRKEY04"
   uint64_t total_len;
   uint32_t n, p, m, logm;
   uint32_t nnzA, nnzB;
@@ -66,11 +66,16 @@ struct ArenaHeader {
   uint32_t win_c[N_TABLES];  // window bits of each table: off_pts[t] holds K = ceil(255/c) x npts[t] points, level k = 2^(ck) * base
   uint32_t share_ac;   // A and C are laid out over the union of their supports (missing points stored as infinity): one digit sort serves both
   uint32_t rank_identity[N_TABLES];  // rank[s] == s for every scalar of the table's vector: the sort skips the gather
-
+  // Intra-proof sharding (zkr_key_shard): a shard key multiplies only the scalars [sc_lo, sc_lo + sc_n) of
+  // each scalar vector (index 0: the witness w, serving A, B1, B2, C; index 1: h, serving H) and holds only their points; its rank
+  // maps have sc_n entries (rank[i] = point of scalar sc_lo + i).  A whole key: sc_lo = 0, sc_n = {n, m}, shard_parts = 1.
+  uint32_t sc_lo[2], sc_n[2];
+  uint32_t shard_part, shard_parts;
 };
 static_assert(sizeof(ArenaHeader) <= 1024, "header fits its slot");
 constexpr size_t ARENA_HEADER_BYTES = 1024;
-constexpr uint64_t ARENA_MAGIC = 0x333059454b524b5aull;  // "ZKRKEY03" (03: point tables in the radix-2^261 form of field29.hpp): bump with every change of ArenaHeader or of a section layout (packed key files carry it)
+constexpr uint64_t ARENA_MAGIC = 0x343059454b524b5aull;  // "ZKRKEY04" (03: point tables in the radix-2^261 form of field29.hpp; 04: scalar sub-ranges of shard keys): bump with every change of ArenaHeader or of a section layout (packed key files carry it)
+inline uint32_t rank_entries(const ArenaHeader &h, int t) { return h.sc_n[t == T_H ? 1 : 0]; }  // entries of table t's rank map = scalars the key multiplies with it
 
 // digit records of one scalar vector, split by bucket range (kernels_msm.hpp "digit sort", stage 1)
 struct DigitLists {
@@ -210,6 +215,8 @@ int ntt_tables29_build(const Fr *tw, uint32_t n_tw, const Fr *twl, uint32_t n_tw
 int run_ntt(hipStream_t s, const Fr *in0, const Fr *in1, Fr *out, const NttTables &tb, int L, bool dif, bool inverse, int pre, int nbat, Prof pf);
 int calc_h_device(zkr_key *k, ProofSlot &sl, hipStream_t s, int nbat = 1);  // sl.d_w -> sl.d_h (bit-reversed), nbat vectors end to end
 int fused_capacity(const ArenaHeader &h, const MsmPlan plan[N_TABLES]);
+void arena_layout(ArenaHeader &h);  // section offsets and total_len from the sizes in the header (n, p, m, nnz, n_wide, npts, win_c, sc_n): THE layout, whoever builds an arena
+void base_layout(const ArenaHeader &full, ArenaHeader &b);  // the same for the compact form (zkr_key_base_arena)
 MsmPlan msm_plan(size_t n_scalars, size_t n_points, int c_fixed = 0);
 int digit_lists_alloc(DigitLists &dl, size_t n_scalars, const MsmPlan &pl);
 void digit_lists_free(DigitLists &dl);

@@ -103,6 +103,29 @@ MsmPlan msm_plan(size_t n_scalars, size_t n, int c_fixed) {
   return pl;
 }
 
+// The arena's layout: header, twiddles, the two QAP sides (CSR), then per table its K window levels and its rank map.
+// Everything that builds an arena -- key_build, the receiver of a compact arena, zkr_key_shard -- takes the offsets from here,
+// so replicas and shards of one key agree byte for byte on where things are.
+void arena_layout(ArenaHeader &h) {
+  size_t off = ARENA_HEADER_BYTES;
+  auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return (uint64_t)o; };
+  h.off_tw = take((size_t)h.m * 32);
+  h.off_twl = take((size_t)(1u << TWL_LOG) * 32);
+  for (int s = 0; s < 2; s++) {
+    const uint32_t nnz = s == 0 ? h.nnzA : h.nnzB;
+    h.off_rowptr[s] = take(((size_t)h.m + 1) * 4);
+    h.off_col[s] = take((size_t)nnz * 4 + 4);
+    h.off_coef[s] = take((size_t)nnz * 32 + 32);
+    h.off_wide[s] = take((size_t)h.n_wide[s] * 4 + 4);
+  }
+  for (int t = 0; t < N_TABLES; t++) {
+    const size_t pb = t == T_B2 ? 128 : 64, K = (255 + h.win_c[t] - 1) / h.win_c[t];
+    h.off_pts[t] = take((size_t)h.npts[t] * K * pb + pb);  // K window levels per base point
+    h.off_rank[t] = take((size_t)rank_entries(h, t) * 4 + 4);
+  }
+  h.total_len = off;
+}
+
 // cap: proofs a fused batch can hold (cap bucket sets end to end; kernels_msm.hpp msm_digits_count_kernel)
 static int alloc_msm_ws(MsmWorkspace &ws, size_t n, const MsmPlan &pl, size_t xyzz_bytes, size_t cap = 1) {
   size_t nb = pl.nb * cap;
@@ -137,6 +160,7 @@ int digit_lists_alloc(DigitLists &dl, size_t n_scalars, const MsmPlan &pl) {  //
 // paid once per batch.  Bounds: the batch's bucket ranges must fit the digit sort's MAX_RANGES lists, the fused vectors
 // stay at or below 2^20 elements, at most 16.
 int fused_capacity(const ArenaHeader &h, const MsmPlan plan[N_TABLES]) {
+  if (h.shard_parts > 1) return 1;  // a shard multiplies a sub-range of one proof's vectors: nothing to lay end to end
   if (const char *e = getenv("ZKR_FUSE")) { int v = atoi(e); if (v >= 1 && v <= MAX_FUSE) { uint32_t nr = 1; for (int t = 0; t < N_TABLES; t++) nr = plan[t].nR > nr ? plan[t].nR : nr; if ((uint32_t)v * nr <= MAX_RANGES) return v; } }
   uint32_t nr = 1;
   for (int t = 0; t < N_TABLES; t++) nr = plan[t].nR > nr ? plan[t].nR : nr;
@@ -198,7 +222,7 @@ int key_alloc_workspace(zkr_key *k) {
   const ArenaHeader &h = k->h;
   // reduction streams: the chains of one proof add up to ~6 ms of serialised launches, so on a single in-order
   // stream they, not the accumulations, set the pace with two proofs in flight (94 vs 106 proofs/s with two)
-  for (int t = 0; t < N_TABLES; t++) k->plan[t] = msm_plan(t == T_H ? h.m : h.n, h.npts[t], (int)h.win_c[t]);
+  for (int t = 0; t < N_TABLES; t++) k->plan[t] = msm_plan(rank_entries(h, t), h.npts[t], (int)h.win_c[t]);
   // experiment knob: reduction group size of the G2 table alone (its reduce1 chain is the longest of a proof)
   if (const char *e = getenv("ZKR_MSM_GLOG_G2")) {
     int v = atoi(e);
@@ -271,8 +295,8 @@ int key_alloc_workspace(zkr_key *k) {
       int rc = alloc_msm_ws(sl.ws[t], h.npts[t], k->plan[t], t == T_B2 ? sizeof(G2XYZZ) : sizeof(G1XYZZ), cap);
       if (rc) return rc;
     }
-    int rc = digit_lists_alloc(sl.dig_w, (size_t)h.n * cap, k->plan[T_A]);
-    if (!rc) rc = digit_lists_alloc(sl.dig_h, (size_t)h.m * cap, k->plan[T_H]);
+    int rc = digit_lists_alloc(sl.dig_w, (size_t)h.sc_n[0] * cap, k->plan[T_A]);
+    if (!rc) rc = digit_lists_alloc(sl.dig_h, (size_t)h.sc_n[1] * cap, k->plan[T_H]);
     if (rc) return rc;
   }
   // host-side window tables of delta_1 / delta_2 for the proof assembly (a few milliseconds; kept out of the first proof)
@@ -366,19 +390,13 @@ int key_build(int device, uint32_t n, uint32_t p, uint32_t m, const std::vector<
   h.nnzB = (uint32_t)col[1].size();
   memcpy(h.alfa1, consts448, 64); memcpy(h.beta1, consts448 + 64, 64); memcpy(h.delta1, consts448 + 128, 64);
   memcpy(h.beta2, consts448 + 192, 128); memcpy(h.delta2, consts448 + 320, 128);
+  h.sc_lo[0] = h.sc_lo[1] = 0; h.sc_n[0] = n; h.sc_n[1] = m;
+  h.shard_part = 0; h.shard_parts = 1;
   std::vector<uint32_t> wide_rows[2];
-  size_t off = ARENA_HEADER_BYTES;
-  auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return (uint64_t)o; };
-  h.off_tw = take((size_t)m * 32);
-  h.off_twl = take((size_t)(1u << TWL_LOG) * 32);
   for (int s = 0; s < 2; s++) {
-    h.off_rowptr[s] = take(((size_t)m + 1) * 4);
-    h.off_col[s] = take(col[s].size() * 4 + 4);
-    h.off_coef[s] = take(coef[s].size() + 32);
     for (uint32_t r = 0; r < m; r++)
       if (rowptr[s][r + 1] - rowptr[s][r] > SPMV_WIDE) wide_rows[s].push_back(r);
     h.n_wide[s] = (uint32_t)wide_rows[s].size();
-    h.off_wide[s] = take(wide_rows[s].size() * 4 + 4);
   }
   // A and C multiply the same scalars and nearly the same signals (C lacks the public ones): when their supports
   // overlap by >= 90 % both tables are laid out over the UNION of the supports (a missing point is stored as
@@ -410,12 +428,10 @@ int key_build(int device, uint32_t n, uint32_t p, uint32_t m, const std::vector<
     h.npts[t] = (uint32_t)srcidx_eff[t]->size();
     plan[t] = msm_plan(t == T_H ? m : n, h.npts[t]);
     h.win_c[t] = (uint32_t)plan[t].c;
-    size_t pb = t == T_B2 ? 128 : 64;
-    h.off_pts[t] = take((size_t)h.npts[t] * plan[t].K * pb + pb);  // K window levels per base point
-    h.off_rank[t] = take((size_t)(t == T_H ? m : n) * 4 + 4);
   }
-  h.total_len = off;
   h.share_b = tbl_sidx[T_B1] == tbl_sidx[T_B2] ? 1 : 0;
+  arena_layout(h);
+  const size_t off = h.total_len;
 
   unsigned char *arena = nullptr;
   ZKR_HIP_CHECK(hipMalloc(&arena, off));
@@ -654,8 +670,21 @@ void zkr_key_free(zkr_key *k) {
   if (!k) return;
   hipSetDevice(k->device);
   hipStream_t streams[2 + N_TABLES] = {k->stream, k->prep_stream, k->red_stream[0], k->red_stream[1], k->red_stream[2], k->red_stream[3], k->red_stream[4]};
-  for (hipStream_t st : streams)
-    if (st) hipStreamSynchronize(st);
+  if (k->own_streams) {
+    for (hipStream_t st : streams)
+      if (st) hipStreamSynchronize(st);
+  } else {
+    // shared streams (one set per device): wait for THIS key's work only -- the last events of its proof slots and staged
+    // uploads (an event that was never recorded is complete) -- not for the proofs other keys have in flight on the same streams
+    for (ProofSlot &sl : k->slot) {
+      for (auto e : sl.ev_red)
+        if (e) hipEventSynchronize(e);
+      for (int t = 0; t < N_TABLES; t++)
+        if (sl.ev_res[t]) hipEventSynchronize(sl.ev_res[t]);
+    }
+    for (WitnessStage &ws : k->stage)
+      if (ws.ev_up) hipEventSynchronize(ws.ev_up);
+  }
   for (ProofSlot &sl : k->slot) {
     for (int t = 0; t < N_TABLES; t++) {
       if (sl.ev_done[t]) hipEventDestroy(sl.ev_done[t]);
@@ -737,7 +766,9 @@ int zkr_key_adopt_arena(void *dev_ptr, size_t len, int device, zkr_key **out) {
 // layout; win_c / npts / share flags carry over so the rebuilt arena is byte-identical to the sender's.
 constexpr uint64_t BASE_MAGIC = 0x32304245534b525aull;  // "ZRKSEB02"-ish tag: distinct from ARENA_MAGIC
 
-static void base_layout(const ArenaHeader &full, ArenaHeader &b) {
+}  // extern "C"
+namespace zkr {
+void base_layout(const ArenaHeader &full, ArenaHeader &b) {
   b = full;
   b.magic = BASE_MAGIC;
   size_t off = ARENA_HEADER_BYTES;
@@ -753,10 +784,12 @@ static void base_layout(const ArenaHeader &full, ArenaHeader &b) {
   for (int t = 0; t < N_TABLES; t++) {
     size_t pb = t == T_B2 ? 128 : 64;
     b.off_pts[t] = take((size_t)full.npts[t] * pb + pb);
-    b.off_rank[t] = take((size_t)(t == T_H ? full.m : full.n) * 4 + 4);
+    b.off_rank[t] = take((size_t)rank_entries(full, t) * 4 + 4);
   }
   b.total_len = off;
 }
+}  // namespace zkr
+extern "C" {
 
 int zkr_key_base_arena(zkr_key *k, void **dev_ptr, size_t *len) {
   if (!k || !dev_ptr || !len) { set_error("null argument"); return ZKR_ERR_ARG; }
@@ -779,7 +812,7 @@ int zkr_key_base_arena(zkr_key *k, void **dev_ptr, size_t *len) {
     }
     for (int t = 0; t < N_TABLES && e == hipSuccess; t++) {
       e = cp(b.off_pts[t], k->h.off_pts[t], (size_t)k->h.npts[t] * (t == T_B2 ? 128 : 64));
-      if (e == hipSuccess) e = cp(b.off_rank[t], k->h.off_rank[t], (size_t)(t == T_H ? k->h.m : k->h.n) * 4);
+      if (e == hipSuccess) e = cp(b.off_rank[t], k->h.off_rank[t], (size_t)rank_entries(k->h, t) * 4);
     }
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) { hipFree(buf); set_error("building the compact arena failed: %s", hipGetErrorString(e)); return ZKR_ERR_HIP; }
@@ -808,26 +841,14 @@ int zkr_key_adopt_base_arena(const void *dev_ptr, size_t len, int device, zkr_ke
   // the full layout, exactly as key_build lays it out
   ArenaHeader h = b;
   h.magic = ARENA_MAGIC;
-  size_t off = ARENA_HEADER_BYTES;
-  auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return (uint64_t)o; };
-  h.off_tw = take((size_t)h.m * 32);
-  h.off_twl = take((size_t)(1u << TWL_LOG) * 32);
-  for (int s = 0; s < 2; s++) {
-    uint32_t nnz = s == 0 ? h.nnzA : h.nnzB;
-    h.off_rowptr[s] = take(((size_t)h.m + 1) * 4);
-    h.off_col[s] = take((size_t)nnz * 4 + 4);
-    h.off_coef[s] = take((size_t)nnz * 32 + 32);
-    h.off_wide[s] = take((size_t)h.n_wide[s] * 4 + 4);
-  }
   MsmPlan plan[N_TABLES];
   for (int t = 0; t < N_TABLES; t++) {
     if (h.win_c[t] < 2 || h.win_c[t] > 26) { set_error("compact arena: bad window size"); return ZKR_ERR_BAD_KEY; }
-    plan[t] = msm_plan(t == T_H ? h.m : h.n, h.npts[t], (int)h.win_c[t]);
-    size_t pb = t == T_B2 ? 128 : 64;
-    h.off_pts[t] = take((size_t)h.npts[t] * plan[t].K * pb + pb);
-    h.off_rank[t] = take((size_t)(t == T_H ? h.m : h.n) * 4 + 4);
+    plan[t] = msm_plan(rank_entries(h, t), h.npts[t], (int)h.win_c[t]);
   }
-  h.total_len = off;
+  if (h.sc_n[0] > h.n || h.sc_lo[0] > h.n - h.sc_n[0] || h.sc_n[1] > h.m || h.sc_lo[1] > h.m - h.sc_n[1]) { set_error("compact arena: scalar ranges outside the vectors"); return ZKR_ERR_BAD_KEY; }
+  arena_layout(h);
+  const size_t off = h.total_len;
   // every section of the compact form lies inside the bytes handed over (a truncated or edited header must not drive the copies)
   {
     if (h.logm > 27 || h.m != (1u << h.logm) || h.n == 0 || h.p >= h.n) { set_error("compact arena: inconsistent sizes"); return ZKR_ERR_BAD_KEY; }
@@ -839,7 +860,7 @@ int zkr_key_adopt_base_arena(const void *dev_ptr, size_t len, int device, zkr_ke
            inside(b.off_wide[s], (uint64_t)h.n_wide[s] * 4);
     }
     for (int t = 0; t < N_TABLES && ok; t++) {
-      const uint64_t nsc = t == T_H ? h.m : h.n;
+      const uint64_t nsc = rank_entries(h, t);
       ok = h.npts[t] <= nsc && inside(b.off_pts[t], (uint64_t)h.npts[t] * (t == T_B2 ? 128 : 64)) && inside(b.off_rank[t], nsc * 4);
     }
     if (!ok) { set_error("compact arena: a section lies outside the %zu bytes handed over", len); return ZKR_ERR_BAD_KEY; }
@@ -859,7 +880,7 @@ int zkr_key_adopt_base_arena(const void *dev_ptr, size_t len, int device, zkr_ke
   }
   for (int t = 0; t < N_TABLES && e == hipSuccess; t++) {
     e = cp(h.off_pts[t], b.off_pts[t], (size_t)h.npts[t] * (t == T_B2 ? 128 : 64));
-    if (e == hipSuccess) e = cp(h.off_rank[t], b.off_rank[t], (size_t)(t == T_H ? h.m : h.n) * 4);
+    if (e == hipSuccess) e = cp(h.off_rank[t], b.off_rank[t], (size_t)rank_entries(h, t) * 4);
   }
   if (e != hipSuccess) { hipFree(arena); set_error("unpacking the compact arena failed: %s", hipGetErrorString(e)); return ZKR_ERR_HIP; }
   for (int t = 0; t < N_TABLES; t++) {

@@ -18,6 +18,7 @@ using namespace zkr;
 namespace {
 
 constexpr size_t PEER_PIECE = (size_t)1 << 30;  // bytes per peer copy (arenas reach 78 GB at 2^24)
+constexpr uint32_t RANK_NONE_U32 = 0xffffffffu;  // kernels_msm.hpp RANK_NONE (this unit includes no kernel header)
 
 // [src, src + len) on src_dev -> dst on dst_dev, in pieces; same device: a plain device copy
 int copy_between_devices(void *dst, int dst_dev, const void *src, int src_dev, size_t len) {
@@ -163,5 +164,139 @@ int zkr_prove_batch_multi_device(zkr_key *const *keys, size_t n_keys, const void
 }
 
 int zkr_key_device(const zkr_key *key) { return key ? key->device : -1; }
+
+// ---------------------------------------------------------------- ONE proof over several GPUs
+int zkr_key_shard_info(const zkr_key *key, uint32_t out[6]) {
+  if (!key || !out) { set_error("null argument"); return ZKR_ERR_ARG; }
+  out[0] = key->h.shard_part; out[1] = key->h.shard_parts;
+  out[2] = key->h.sc_lo[0]; out[3] = key->h.sc_n[0]; out[4] = key->h.sc_lo[1]; out[5] = key->h.sc_n[1];
+  return 0;
+}
+
+int zkr_key_shard(const zkr_key *src, unsigned part, unsigned parts, int device, zkr_key **out) {
+  if (!src || !out) { set_error("null argument"); return ZKR_ERR_ARG; }
+  if (parts < 1 || parts > 64 || part >= parts) { set_error("shard %u of %u: parts must be 1..64 and part below it", part, parts); return ZKR_ERR_ARG; }
+  if (src->h.shard_parts != 1) { set_error("the key is itself a shard (%u of %u): shard the whole key", src->h.shard_part, src->h.shard_parts); return ZKR_ERR_ARG; }
+  if (zkr_device_count() <= device || device < 0) { set_error("no HIP device %d (found %d)", device, zkr_device_count()); return ZKR_ERR_NO_DEVICE; }
+  const ArenaHeader &sh = src->h;
+  ArenaHeader h = sh;
+  h.shard_part = part; h.shard_parts = parts;
+  const uint32_t vec_len[2] = {sh.n, sh.m};
+  for (int v = 0; v < 2; v++) {
+    h.sc_lo[v] = (uint32_t)((uint64_t)vec_len[v] * part / parts);
+    h.sc_n[v] = (uint32_t)((uint64_t)vec_len[v] * (part + 1) / parts) - h.sc_lo[v];
+    if (h.sc_n[v] == 0) { set_error("%u parts for a vector of %u scalars: a shard would be empty", parts, vec_len[v]); return ZKR_ERR_ARG; }
+  }
+  // the points of the range: rank maps are increasing over the kept scalars (key_build numbers the points in scalar order), so a
+  // scalar range owns a contiguous point range [pt_lo, pt_lo + count) of every table
+  ZKR_HIP_CHECK(hipSetDevice(src->device));
+  std::vector<uint32_t> rank[N_TABLES];
+  uint32_t pt_lo[N_TABLES];
+  for (int t = 0; t < N_TABLES; t++) {
+    const int v = t == T_H ? 1 : 0;
+    rank[t].assign(h.sc_n[v], RANK_NONE_U32);
+    pt_lo[t] = 0;
+    if (!sh.npts[t] || !h.sc_n[v]) { h.npts[t] = 0; h.rank_identity[t] = 0; continue; }
+    ZKR_HIP_CHECK(hipMemcpy(rank[t].data(), src->arena + sh.off_rank[t] + (size_t)h.sc_lo[v] * 4, (size_t)h.sc_n[v] * 4, hipMemcpyDeviceToHost));
+    uint32_t first = RANK_NONE_U32, last = 0, cnt = 0;
+    for (uint32_t r : rank[t])
+      if (r != RANK_NONE_U32) { if (first == RANK_NONE_U32) first = r; if (cnt && r <= last) { set_error("rank map of table %d is not increasing", t); return ZKR_ERR_BAD_KEY; } last = r; cnt++; }
+    if (cnt && last - first + 1 != cnt) { set_error("table %d: the scalar range does not own a contiguous point range", t); return ZKR_ERR_BAD_KEY; }
+    pt_lo[t] = cnt ? first : 0;
+    h.npts[t] = cnt;
+    bool ident = cnt == h.sc_n[v];
+    for (uint32_t i = 0; i < (uint32_t)rank[t].size(); i++) {
+      if (rank[t][i] != RANK_NONE_U32) rank[t][i] -= pt_lo[t];
+      ident = ident && rank[t][i] == i;
+    }
+    h.rank_identity[t] = ident ? 1 : 0;
+  }
+  // tables that share a digit sort must still agree point for point (they do: the same scalar range of the same supports)
+  if (h.share_ac && h.npts[T_A] != h.npts[T_C]) h.share_ac = 0;
+  if (h.share_b && h.npts[T_B1] != h.npts[T_B2]) h.share_b = 0;
+  arena_layout(h);
+  ZKR_HIP_CHECK(hipSetDevice(device));
+  (void)peer_direct(device, src->device);
+  DevBuf buf;
+  if (int rc = buf.alloc(h.total_len)) return rc;
+  unsigned char *arena = buf.as<unsigned char>();
+  ZKR_HIP_CHECK(hipMemset(arena, 0, h.total_len));
+  ZKR_HIP_CHECK(hipMemcpy(arena, &h, sizeof(h), hipMemcpyHostToDevice));
+  auto cp = [&](uint64_t dst, uint64_t from, size_t bytes) { return bytes ? copy_between_devices(arena + dst, device, src->arena + from, src->device, bytes) : 0; };
+  int rc = cp(h.off_tw, sh.off_tw, (size_t)sh.m * 32);
+  if (!rc) rc = cp(h.off_twl, sh.off_twl, sh.off_rowptr[0] - sh.off_twl);  // the small twiddle table up to the next section (alignment slack included)
+  for (int s = 0; s < 2 && !rc; s++) {
+    const uint32_t nnz = s == 0 ? sh.nnzA : sh.nnzB;
+    rc = cp(h.off_rowptr[s], sh.off_rowptr[s], ((size_t)sh.m + 1) * 4);
+    if (!rc) rc = cp(h.off_col[s], sh.off_col[s], (size_t)nnz * 4);
+    if (!rc) rc = cp(h.off_coef[s], sh.off_coef[s], (size_t)nnz * 32);
+    if (!rc) rc = cp(h.off_wide[s], sh.off_wide[s], (size_t)sh.n_wide[s] * 4);
+  }
+  for (int t = 0; t < N_TABLES && !rc; t++) {
+    const size_t pb = t == T_B2 ? 128 : 64, K = (255 + sh.win_c[t] - 1) / sh.win_c[t];
+    for (size_t k = 0; k < K && !rc; k++)  // level k of the range: 2^(ck) P_i for the shard's points
+      rc = cp(h.off_pts[t] + k * h.npts[t] * pb, sh.off_pts[t] + (k * sh.npts[t] + pt_lo[t]) * pb, (size_t)h.npts[t] * pb);
+    if (!rc && !rank[t].empty()) {
+      ZKR_HIP_CHECK(hipSetDevice(device));
+      ZKR_HIP_CHECK(hipMemcpy(arena + h.off_rank[t], rank[t].data(), rank[t].size() * 4, hipMemcpyHostToDevice));
+    }
+  }
+  if (rc) return rc;
+  zkr_key *k = nullptr;
+  rc = zkr_key_adopt_arena(arena, h.total_len, device, &k);
+  if (rc) return rc;
+  k->owns_arena = true;
+  buf.release();
+  *out = k;
+  return 0;
+}
+
+}  // extern "C"
+
+namespace {
+template <class Partial>
+int run_sharded(zkr_key *const *shards, size_t parts, const uint8_t *r32, const uint8_t *s32, uint8_t *proof_out, Partial partial) {
+  if (!shards || parts == 0 || !proof_out) { set_error("null argument"); return ZKR_ERR_ARG; }
+  for (size_t i = 0; i < parts; i++) {
+    if (!shards[i]) { set_error("shard %zu is null", i); return ZKR_ERR_ARG; }
+    const ArenaHeader &h = shards[i]->h;
+    if (h.shard_parts != parts || h.shard_part != i) { set_error("shards[%zu] is part %u of %u: pass part i of %zu at position i", i, h.shard_part, h.shard_parts, parts); return ZKR_ERR_ARG; }
+    if (h.n != shards[0]->h.n || h.m != shards[0]->h.m || memcmp(h.delta1, shards[0]->h.delta1, 64)) { set_error("shard %zu belongs to another key", i); return ZKR_ERR_ARG; }
+  }
+  std::vector<uint8_t> partials(parts * ZKR_PARTIAL_BYTES);
+  std::vector<int> rcs(parts, 0);
+  std::vector<std::string> errs(parts);
+  auto work = [&](size_t i) {
+    try {
+      rcs[i] = partial(i, &partials[i * ZKR_PARTIAL_BYTES]);
+      if (rcs[i]) errs[i] = zkr_last_error();
+    } catch (const std::exception &e) { rcs[i] = ZKR_ERR_HIP; errs[i] = e.what(); }
+  };
+  std::vector<std::thread> thr;
+  std::vector<size_t> inline_parts;
+  for (size_t i = 1; i < parts; i++) {
+    try { thr.emplace_back(work, i); } catch (const std::system_error &) { inline_parts.push_back(i); }
+  }
+  work(0);
+  for (size_t i : inline_parts) work(i);
+  for (auto &t : thr) t.join();
+  for (size_t i = 0; i < parts; i++)
+    if (rcs[i]) { set_error("shard %zu (device %d): %s", i, shards[i]->device, errs[i].c_str()); return rcs[i]; }
+  return zkr_prove_combine(shards[0], partials.data(), parts, r32, s32, proof_out);
+}
+}  // namespace
+
+extern "C" {
+
+int zkr_prove_sharded(zkr_key *const *shards, size_t parts, const void *witness_std, size_t witness_len, const uint8_t *r32, const uint8_t *s32,
+                      uint8_t proof_out[256]) {
+  if (!witness_std) { set_error("null argument"); return ZKR_ERR_ARG; }
+  return run_sharded(shards, parts, r32, s32, proof_out, [&](size_t i, uint8_t *out) { return zkr_prove_partial(shards[i], witness_std, witness_len, out); });
+}
+int zkr_prove_sharded_device(zkr_key *const *shards, size_t parts, const void *const *d_witnesses_std, const uint8_t *r32, const uint8_t *s32,
+                             uint8_t proof_out[256]) {
+  if (!d_witnesses_std) { set_error("null argument"); return ZKR_ERR_ARG; }
+  return run_sharded(shards, parts, r32, s32, proof_out, [&](size_t i, uint8_t *out) { return zkr_prove_partial_device(shards[i], d_witnesses_std[i], nullptr, out); });
+}
 
 }  // extern "C"

@@ -526,7 +526,7 @@ static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *const *d_ws
   int sort_src[N_TABLES] = {T_A, T_B1, share_b ? T_B1 : T_B2, share_ac ? T_A : T_C, T_H};
   auto sort_table = [&](int t) -> int {
     const uint32_t *rank = h.rank_identity[t] ? nullptr : (const uint32_t *)(ar + h.off_rank[t]);
-    int rc = msm_sort_enqueue(pf, sp, rank, *dig[t], t == T_H ? h.m : h.n, h.npts[t], nbat, k->plan[t], sl.ws[t]);
+    int rc = msm_sort_enqueue(pf, sp, rank, *dig[t], rank_entries(h, t), h.npts[t], nbat, k->plan[t], sl.ws[t]);
     if (rc) return rc;
     if (!serial) ZKR_HIP_CHECK(hipEventRecord(sl.ev_sorted[t], sp));
     return 0;
@@ -625,7 +625,8 @@ static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *const *d_ws
     return 0;
   };
   // preparation chain
-  if ((rc = msm_digits_enqueue(pf, sp, sl.d_w, h.n, nbat, k->plan[T_A], sl.dig_w))) return rc;
+  // a shard key (zkr_key_shard) multiplies only its sub-range of each scalar vector; a whole key: sc_lo = 0, sc_n = n / m
+  if ((rc = msm_digits_enqueue(pf, sp, sl.d_w + h.sc_lo[0], h.sc_n[0], nbat, k->plan[T_A], sl.dig_w))) return rc;
   if ((rc = sort_table(T_B1))) return rc;
   if (!share_b && (rc = sort_table(T_B2))) return rc;
   if (early && (rc = chains({T_B2, T_B1}))) return rc;
@@ -633,7 +634,7 @@ static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *const *d_ws
   if (!share_ac && (rc = sort_table(T_C))) return rc;
   if (early && ((rc = c_big()) || (rc = chains({T_A, T_C})))) return rc;
   if ((rc = calc_h_device(k, sl, sp, nbat))) return rc;
-  if ((rc = msm_digits_enqueue(pf, sp, sl.d_h, h.m, nbat, k->plan[T_H], sl.dig_h))) return rc;
+  if ((rc = msm_digits_enqueue(pf, sp, sl.d_h + h.sc_lo[1], h.sc_n[1], nbat, k->plan[T_H], sl.dig_h))) return rc;
   if ((rc = sort_table(T_H))) return rc;
   // accumulations + reduction chains
   if (early) rc = chains({T_H});
@@ -651,9 +652,53 @@ static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *const *d_ws
   return 0;
 }
 
-// Wait for the slot's GPU work, then the host assembly of each of its sl.nbat proofs
-// (proofs_out: nbat x 256 B; a degenerate proof fails the whole group with its status).
-static int prove_collect(zkr_key *k, ProofSlot &sl, uint8_t *proofs_out) {
+// Host assembly in two phases.  Phase 1 takes A, B1, B2 only:
+//   pi_a = A + alfa + r delta;  pi_b = B2 + beta + s delta;  pi_c = C + H + s pi_a + r (B1 + beta + s delta) - r s delta
+//        = C + H + s (A + alfa) + r (B1 + beta) + r s delta
+// i.e. every scalar multiplication: three multiples of the key's delta (window tables) and one double multiplication of the two
+// MSM results with shared doublings; it writes pi_a and pi_b and returns pi_c without C + H.  Phase 2 adds C + H.
+static int assemble_ab(zkr_key *k, const G1XYZZ &A, const G1XYZZ &B1, const G2XYZZ &B2, const uint8_t *rb, const uint8_t *sb, uint8_t *proof_out, G1XYZZ &pic_part) {
+  const ArenaHeader &h = k->h;
+  std::call_once(k->delta_once, [&] {
+    k->delta1_tab = fixed_base_table(load_g1(h.delta1));
+    k->delta2_tab = fixed_base_table(load_g2(h.delta2));
+  });
+  const G1XYZZ alfa1 = to_xyzz(load_g1(h.alfa1)), beta1 = to_xyzz(load_g1(h.beta1));
+  const G2XYZZ beta2 = to_xyzz(load_g2(h.beta2));
+  U256 r = load_u256(rb), sc = load_u256(sb);
+  G1XYZZ a_alfa = add_full(A, alfa1), b_beta = add_full(B1, beta1);
+  G1XYZZ pia = add_full(a_alfa, fixed_base_mul(k->delta1_tab, r));
+  G2XYZZ pib = add_full(add_full(B2, beta2), fixed_base_mul(k->delta2_tab, sc));
+  Fr rs = mul(to_mont(load_fp<FrParams>(rb)), to_mont(load_fp<FrParams>(sb)));
+  Fr rs_std = from_mont(rs);
+  U256 rsu;
+  memcpy(rsu.v, rs_std.v, 32);
+  pic_part = add_full(double_scalar_mul(a_alfa, sc, b_beta, r), fixed_base_mul(k->delta1_tab, rsu));
+  if (pia.is_inf() || pib.is_inf()) return ZKR_ERR_DEGENERATE;
+  store_g1_std(proof_out, to_affine(pia));
+  store_g2_std(proof_out + 64, to_affine(pib));
+  return 0;
+}
+static int assemble_c(const G1XYZZ &CH, const G1XYZZ &pic_part, uint8_t *proof_out) {
+  G1XYZZ pic = add_full(CH, pic_part);
+  if (pic.is_inf()) return ZKR_ERR_DEGENERATE;
+  store_g1_std(proof_out + 192, to_affine(pic));
+  return 0;
+}
+
+// What a shard of a proof (zkr_key_shard) contributes: its partial sums of the four group elements the assembly needs -- A, B1,
+// B2 and C + H -- as this library's XYZZ points in Montgomery form.  ZKR_PARTIAL_BYTES = 128 + 128 + 256 + 128.
+struct PartialSums {
+  G1XYZZ A, B1;
+  G2XYZZ B2;
+  G1XYZZ CH;
+};
+static_assert(sizeof(PartialSums) == ZKR_PARTIAL_BYTES, "the partial-sum record of zkr.h");
+
+// Wait for the slot's GPU work, then the host assembly of each of its sl.nbat proofs (proofs_out: nbat x 256 B; a degenerate
+// proof fails the whole group with its status).  partials_out != null: no assembly -- the MSM results of the (one) proof are
+// handed out as they are (zkr_prove_partial).
+static int prove_collect(zkr_key *k, ProofSlot &sl, uint8_t *proofs_out, PartialSums *partials_out = nullptr) {
   {
     std::lock_guard<std::mutex> lk(k->mu);
     if (!sl.busy || sl.collecting) { set_error("no proof in flight in this slot"); return ZKR_ERR_ARG; }
@@ -670,10 +715,9 @@ static int prove_collect(zkr_key *k, ProofSlot &sl, uint8_t *proofs_out) {
   ZKR_HIP_CHECK(hipSetDevice(k->device));
   const ArenaHeader &h = k->h;
   static const bool serial_mode = getenv("ZKR_SERIAL") != nullptr;
-  // Host assembly in two phases.  Everything that needs A, B1, B2 only -- pi_a, pi_b and s (A + alfa) + r (B1 + beta) + r s delta,
-  // i.e. all the scalar multiplications -- is done while the LAST chains (C, H: H's sort only starts after calcH) still run
-  // on the GPU; when C + H lands, one addition and one inversion finish pi_c.  Single-proof latency: ~0.35 ms of host work
-  // off the critical path (with two proofs in flight it was hidden already).
+  // Everything that needs A, B1, B2 only (assemble_ab: all the scalar multiplications) is done while the LAST chains (C, H: H's
+  // sort only starts after calcH) still run on the GPU; when C + H lands, one addition and one inversion finish pi_c.
+  // Single-proof latency: ~0.35 ms of host work off the critical path (with two proofs in flight it was hidden already).
   auto wait_table = [&](int t) -> int {
     if (sl.res_pending[t]) ZKR_HIP_CHECK(hipEventSynchronize(sl.ev_res[t]));
     return 0;
@@ -684,35 +728,15 @@ static int prove_collect(zkr_key *k, ProofSlot &sl, uint8_t *proofs_out) {
   if (trace) clock_gettime(CLOCK_MONOTONIC, &ts0);
   if ((rcw = wait_table(T_A)) || (rcw = wait_table(T_B1)) || (rcw = wait_table(T_B2))) return rcw;
   if (trace) clock_gettime(CLOCK_MONOTONIC, &ts1);
-  std::call_once(k->delta_once, [&] {
-    k->delta1_tab = fixed_base_table(load_g1(h.delta1));
-    k->delta2_tab = fixed_base_table(load_g2(h.delta2));
-  });
-  G1XYZZ alfa1 = to_xyzz(load_g1(h.alfa1)), beta1 = to_xyzz(load_g1(h.beta1));
-  G2XYZZ beta2 = to_xyzz(load_g2(h.beta2));
   std::vector<G1XYZZ> pic_part((size_t)sl.nbat);
   int status = 0;
   for (int j = 0; j < sl.nbat; j++) {
-    const uint8_t *rb = &sl.rb[32 * j], *sb = &sl.sb[32 * j];
-    uint8_t *proof_out = proofs_out + 256 * j;
     G1XYZZ A = msm_finish<Fq>(h.npts[T_A], sl.ws[T_A], j);
     G1XYZZ B1 = msm_finish<Fq>(h.npts[T_B1], sl.ws[T_B1], j);
     G2XYZZ B2 = msm_finish<Fq2>(h.npts[T_B2], sl.ws[T_B2], j);
-    // pi_a = A + alfa + r delta;  pi_b = B2 + beta + s delta;  pi_c = C + H + s pi_a + r (B1 + beta + s delta) - r s delta
-    //      = C + H + s (A + alfa) + r (B1 + beta) + r s delta: three multiples of the key's delta (window tables) and one
-    // double multiplication of the two MSM results with shared doublings
-    U256 r = load_u256(rb), sc = load_u256(sb);
-    G1XYZZ a_alfa = add_full(A, alfa1), b_beta = add_full(B1, beta1);
-    G1XYZZ pia = add_full(a_alfa, fixed_base_mul(k->delta1_tab, r));
-    G2XYZZ pib = add_full(add_full(B2, beta2), fixed_base_mul(k->delta2_tab, sc));
-    Fr rs = mul(to_mont(load_fp<FrParams>(rb)), to_mont(load_fp<FrParams>(sb)));
-    Fr rs_std = from_mont(rs);
-    U256 rsu;
-    memcpy(rsu.v, rs_std.v, 32);
-    pic_part[j] = add_full(double_scalar_mul(a_alfa, sc, b_beta, r), fixed_base_mul(k->delta1_tab, rsu));
-    if (pia.is_inf() || pib.is_inf()) { status = ZKR_ERR_DEGENERATE; continue; }
-    store_g1_std(proof_out, to_affine(pia));
-    store_g2_std(proof_out + 64, to_affine(pib));
+    if (partials_out) { partials_out[j].A = A; partials_out[j].B1 = B1; partials_out[j].B2 = B2; continue; }
+    int rc = assemble_ab(k, A, B1, B2, &sl.rb[32 * j], &sl.sb[32 * j], proofs_out + 256 * j, pic_part[j]);
+    if (rc) status = rc;
   }
   if (trace) clock_gettime(CLOCK_MONOTONIC, &ts2);
   if ((rcw = wait_table(T_C)) || (rcw = wait_table(T_H))) return rcw;
@@ -723,9 +747,8 @@ static int prove_collect(zkr_key *k, ProofSlot &sl, uint8_t *proofs_out) {
     // merged bucket sets (prove_submit_enqueue): the one reduction result, C + H, sits in C's workspace
     G1XYZZ C = msm_finish<Fq>(h.npts[T_C], sl.ws[T_C], j);
     G1XYZZ H = sl.merged_ch ? G1XYZZ::inf() : msm_finish<Fq>(h.npts[T_H], sl.ws[T_H], j);
-    G1XYZZ pic = add_full(add_full(C, H), pic_part[j]);
-    if (pic.is_inf()) { status = ZKR_ERR_DEGENERATE; break; }
-    store_g1_std(proofs_out + 256 * j + 192, to_affine(pic));
+    if (partials_out) { partials_out[j].CH = add_full(C, H); continue; }
+    status = assemble_c(add_full(C, H), pic_part[j], proofs_out + 256 * j);
   }
   if (trace) {
     clock_gettime(CLOCK_MONOTONIC, &ts4);
@@ -954,6 +977,67 @@ int zkr_prove(zkr_key *key, const void *witness_std, size_t witness_len, const u
   if (rc) { hipStreamSynchronize(key->prep_stream); stage_release(key, st); return rc; }
   rc = prove_collect(key, key->slot[t], proof_out);
   stage_release(key, st);
+  return rc;
+}
+
+// ---- intra-proof sharding: a shard key's share of ONE proof, and the assembly from all shares
+static const uint8_t ZERO32[32] = {0};
+int zkr_prove_partial_device(zkr_key *key, const void *d_witness_std, void *stream, uint8_t partial_out[ZKR_PARTIAL_BYTES]) {
+  if (!key || !d_witness_std || !partial_out) { set_error("null argument"); return ZKR_ERR_ARG; }
+  int t = -1;
+  // blinding plays no part before the assembly: the slot gets zeros
+  int rc = with_free_slot(key, true, &t, [&](ProofSlot &sl) { return prove_submit(key, sl, (const Fr *)d_witness_std, ZERO32, ZERO32, (hipStream_t)stream); });
+  if (rc) return rc;
+  PartialSums ps;
+  rc = prove_collect(key, key->slot[t], nullptr, &ps);
+  if (!rc) memcpy(partial_out, &ps, sizeof(ps));
+  return rc;
+}
+
+int zkr_prove_partial(zkr_key *key, const void *witness_std, size_t witness_len, uint8_t partial_out[ZKR_PARTIAL_BYTES]) {
+  if (!key || !witness_std || !partial_out) { set_error("null argument"); return ZKR_ERR_ARG; }
+  if (witness_len != (size_t)key->h.n * 32) { set_error("witness is %zu bytes, key expects nVars*32 = %zu", witness_len, (size_t)key->h.n * 32); return ZKR_ERR_BAD_WITNESS; }
+  int st = -1;
+  int rc = stage_acquire(key, &st);
+  if (rc) return rc;
+  rc = stage_upload(key, st, 0, witness_std, witness_len, true);
+  int t = -1;
+  if (!rc) rc = with_free_slot(key, true, &t, [&](ProofSlot &sl) -> int {
+    return prove_submit(key, sl, key->stage[st].d_w, ZERO32, ZERO32, key->prep_stream, key->stage[st].ev_up);
+  });
+  if (rc) { hipStreamSynchronize(key->prep_stream); stage_release(key, st); return rc; }
+  PartialSums ps;
+  rc = prove_collect(key, key->slot[t], nullptr, &ps);
+  stage_release(key, st);
+  if (!rc) memcpy(partial_out, &ps, sizeof(ps));
+  return rc;
+}
+
+int zkr_prove_combine(zkr_key *key, const uint8_t *partials, size_t parts, const uint8_t *r32, const uint8_t *s32, uint8_t proof_out[256]) {
+  if (!key || !partials || !proof_out || parts == 0) { set_error("null argument"); return ZKR_ERR_ARG; }
+  if ((r32 == nullptr) != (s32 == nullptr)) { set_error("pass both r and s or neither"); return ZKR_ERR_ARG; }
+  uint8_t rb[32], sb[32];
+  if (r32) {
+    memcpy(rb, r32, 32); memcpy(sb, s32, 32);
+    uint32_t rv[8], sv[8];
+    memcpy(rv, rb, 32); memcpy(sv, sb, 32);
+    if (!u256_lt(rv, FrParams::P) || !u256_lt(sv, FrParams::P)) { set_error("blinding scalar >= r"); return ZKR_ERR_ARG; }
+  } else {
+    int rc;
+    if ((rc = draw_blinding(rb)) || (rc = draw_blinding(sb))) return rc;
+  }
+  PartialSums sum;
+  memcpy(&sum, partials, sizeof(sum));
+  for (size_t i = 1; i < parts; i++) {  // the one exchange step of the sharded proof: four additions per share
+    PartialSums ps;
+    memcpy(&ps, partials + i * sizeof(PartialSums), sizeof(ps));
+    sum.A = add_full(sum.A, ps.A); sum.B1 = add_full(sum.B1, ps.B1); sum.B2 = add_full(sum.B2, ps.B2); sum.CH = add_full(sum.CH, ps.CH);
+  }
+  G1XYZZ pic_part;
+  int rc = assemble_ab(key, sum.A, sum.B1, sum.B2, rb, sb, proof_out, pic_part);
+  if (!rc) rc = assemble_c(sum.CH, pic_part, proof_out);
+  explicit_bzero(rb, 32); explicit_bzero(sb, 32);
+  if (rc) set_error("degenerate proof element (point at infinity)");
   return rc;
 }
 

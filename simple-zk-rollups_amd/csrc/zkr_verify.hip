@@ -12,6 +12,7 @@
 #include <mutex>
 #include <vector>
 #include "pairing.hpp"
+#include <system_error>
 #include <thread>
 #include "zkr_internal.hpp"
 
@@ -136,6 +137,8 @@ void build_win8(VkEntry &e) {
 // the parsed key for these bytes (ZKR_ERR_* through *rc when they are not a well-formed key for n_public inputs)
 std::shared_ptr<const VkEntry> cached_vk(const void *vk_bin, size_t vk_len, size_t n_public, int *rc) {
   *rc = 0;
+  std::shared_ptr<VkEntry> upgrade;  // the entry whose window tables this call builds -- OUTSIDE the lock: 255 x nPublic mixed
+                                     // additions (tens of ms for the ~640 inputs of a 2^20 rollup key) must not stall the other verifiers
   {
     std::lock_guard<std::mutex> lk(vk_mu);
     for (auto it = vk_cache.begin(); it != vk_cache.end(); ++it) {
@@ -143,14 +146,18 @@ std::shared_ptr<const VkEntry> cached_vk(const void *vk_bin, size_t vk_len, size
       std::shared_ptr<VkEntry> e = *it;
       if (e->k.ics.size() != n_public) break;  // the count check below words the error
       vk_cache.splice(vk_cache.begin(), vk_cache, it);
-      if (++e->uses == 2 && e->win8.empty()) {  // second use: worth the tables.  A new entry replaces the old one (readers keep theirs)
-        auto e2 = std::make_shared<VkEntry>(*e);
-        build_win8(*e2);
-        vk_cache.front() = e2;
-        return e2;
-      }
-      return e;
+      if (++e->uses != 2 || !e->win8.empty()) return e;
+      upgrade = e;  // second use: worth the tables (uses is past 2 now: no second caller starts the same build)
+      break;
     }
+  }
+  if (upgrade) {
+    auto e2 = std::make_shared<VkEntry>(*upgrade);
+    build_win8(*e2);
+    std::lock_guard<std::mutex> lk(vk_mu);  // publish: the new entry replaces the old one where it still sits (readers keep theirs)
+    for (auto &slot : vk_cache)
+      if (slot == upgrade) { e2->uses = upgrade->uses; slot = e2; break; }
+    return e2;
   }
   auto e = std::make_shared<VkEntry>();
   if ((*rc = parse_vk(vk_bin, vk_len, n_public, e->k))) return nullptr;
@@ -216,7 +223,11 @@ extern "C" int zkr_verify(const void *vk_bin, size_t vk_len, const uint8_t proof
   };
   std::thread helper;
   if (one_thread) public_half();
-  else helper = std::thread(public_half);
+  else {
+    // no thread to be had (EAGAIN under a pids / thread limit: many libuv or Python workers verifying at once) must not
+    // terminate the host process through the C ABI: the public half then runs here
+    try { helper = std::thread(public_half); } catch (const std::system_error &) { public_half(); }
+  }
   bool ok = read_g2(proof + 64, b);  // on the twist and in G2
   pairing::Fq12 f_proof = pairing::Fq12::one();
   if (ok) {

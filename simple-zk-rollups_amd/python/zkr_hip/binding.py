@@ -5,6 +5,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ZKR_HIP_LIB") or os.path.normpath(os.path.join(_HERE, "..", "..", "csrc", "libzkr_hip.so"))  # same override as index.js
 PROOF_BYTES = 256
+PARTIAL_BYTES = 640   # zkr.h ZKR_PARTIAL_BYTES
 REPLICATE_MODES = {"auto": 0, "full": 1, "base": 2}   # zkr.h ZKR_REPLICATE_*
 STAGES = ("ingest", "spmv", "ntt", "msm_sort", "msm_accum_g1", "msm_accum_g2", "msm_big", "msm_reduce", "total",
           "spmv_a", "ntt_pass", "combine_h")   # the last three: single streaming kernels (bench.py roofline.streaming)
@@ -50,6 +51,13 @@ def lib():
     L.zkr_key_device.argtypes = [vp]
     L.zkr_prove_batch_multi.argtypes = [c.POINTER(vp), sz, c.POINTER(c.c_char_p), sz, sz, u8p, u8p, u8p]
     L.zkr_prove_batch_multi_device.argtypes = [c.POINTER(vp), sz, c.POINTER(vp), sz, u8p, u8p, u8p]
+    L.zkr_key_shard.argtypes = [vp, c.c_uint, c.c_uint, i, c.POINTER(vp)]
+    L.zkr_key_shard_info.argtypes = [vp, c.POINTER(c.c_uint32)]
+    L.zkr_prove_partial.argtypes = [vp, u8p, sz, u8p]
+    L.zkr_prove_partial_device.argtypes = [vp, vp, vp, u8p]
+    L.zkr_prove_combine.argtypes = [vp, u8p, sz, u8p, u8p, u8p]
+    L.zkr_prove_sharded.argtypes = [c.POINTER(vp), sz, u8p, sz, u8p, u8p, u8p]
+    L.zkr_prove_sharded_device.argtypes = [c.POINTER(vp), sz, c.POINTER(vp), u8p, u8p, u8p]
     L.zkr_prove.argtypes = [vp, u8p, sz, u8p, u8p, u8p, vp]
     L.zkr_prove_device.argtypes = [vp, vp, u8p, u8p, u8p, vp]
     L.zkr_prove_submit.argtypes = [vp, vp, u8p, u8p, vp, c.POINTER(i)]
@@ -191,6 +199,38 @@ class ProvingKey:
         h = ctypes.c_void_p()
         _check(lib().zkr_key_replicate(self._h, device, REPLICATE_MODES[mode], ctypes.byref(h)))
         return ProvingKey(h, device)
+
+    def shard(self, part, parts, device=None):
+        """Shard `part` of `parts` of this (whole) key on `device` (default: the key's own): the points of one contiguous range
+        of every MSM of a proof, all window levels, plus the whole QAP (zkr_key_shard)."""
+        h = ctypes.c_void_p()
+        dev = self.device if device is None else device
+        _check(lib().zkr_key_shard(self._h, part, parts, dev, ctypes.byref(h)))
+        return ProvingKey(h, dev)
+
+    def shard_info(self):
+        out = (ctypes.c_uint32 * 6)()
+        _check(lib().zkr_key_shard_info(self._h, out))
+        return dict(zip(("part", "parts", "w_lo", "w_n", "h_lo", "h_n"), [int(x) for x in out]))
+
+    def prove_partial(self, witness: bytes) -> bytes:
+        """This shard's partial sums of A, B1, B2, C + H for one proof (zkr_prove_partial), PARTIAL_BYTES opaque bytes."""
+        out = ctypes.create_string_buffer(PARTIAL_BYTES)
+        _check(lib().zkr_prove_partial(self._h, bytes(witness), len(witness), out))
+        return out.raw
+
+    def prove_partial_device(self, d_witness_ptr, stream=None) -> bytes:
+        out = ctypes.create_string_buffer(PARTIAL_BYTES)
+        _check(lib().zkr_prove_partial_device(self._h, ctypes.c_void_p(d_witness_ptr), ctypes.c_void_p(stream or 0), out))
+        return out.raw
+
+    def prove_combine(self, partials, r=None, s=None) -> bytes:
+        """The proof from the partial sums of all shards (zkr_prove_combine); self: any shard or the whole key."""
+        out = ctypes.create_string_buffer(PROOF_BYTES)
+        rb = None if r is None else int(r).to_bytes(32, "little")
+        sb = None if s is None else int(s).to_bytes(32, "little")
+        _check(lib().zkr_prove_combine(self._h, b"".join(partials), len(partials), rb, sb, out))
+        return out.raw
 
     def close(self):
         if self._h:
@@ -362,6 +402,28 @@ def prove_batch_multi_device(keys, d_witness_ptrs, rs=None, ss=None):
     out = ctypes.create_string_buffer(256 * n)
     _check(lib().zkr_prove_batch_multi_device(ks, len(keys), arr, n, rb, sb, out))
     return [out.raw[256 * i:256 * i + 256] for i in range(n)]
+
+
+def prove_sharded(shards, witness: bytes, r=None, s=None) -> bytes:
+    """ONE proof over the shards of a key (ProvingKey.shard(i, parts) at position i), one host thread per shard inside the
+    library, partial sums combined on the host (zkr_prove_sharded)."""
+    ks = (ctypes.c_void_p * len(shards))(*[k._h for k in shards])
+    out = ctypes.create_string_buffer(PROOF_BYTES)
+    rb = None if r is None else int(r).to_bytes(32, "little")
+    sb = None if s is None else int(s).to_bytes(32, "little")
+    _check(lib().zkr_prove_sharded(ks, len(shards), bytes(witness), len(witness), rb, sb, out))
+    return out.raw
+
+
+def prove_sharded_device(shards, d_witness_ptrs, r=None, s=None) -> bytes:
+    """The same with the full witness resident on every shard's device (d_witness_ptrs[i] on shards[i].device)."""
+    ks = (ctypes.c_void_p * len(shards))(*[k._h for k in shards])
+    arr = (ctypes.c_void_p * len(shards))(*[ctypes.c_void_p(p) for p in d_witness_ptrs])
+    out = ctypes.create_string_buffer(PROOF_BYTES)
+    rb = None if r is None else int(r).to_bytes(32, "little")
+    sb = None if s is None else int(s).to_bytes(32, "little")
+    _check(lib().zkr_prove_sharded_device(ks, len(shards), arr, rb, sb, out))
+    return out.raw
 
 
 def verify(vk_bin: bytes, proof: bytes, public_signals) -> bool:

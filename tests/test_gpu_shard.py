@@ -1,0 +1,104 @@
+"""ONE proof over several GPUs (BASELINE configs[2] and [4] are single proofs): zkr_key_shard cuts
+every MSM of the proof into contiguous ranges, every shard computes its partial sums, the host adds them and assembles.  On
+the one-GPU box the shards are built side by side on device 0; the combined proof must be the bytes of
+the whole key's proof and of the toxic-waste closed form."""
+import pytest
+
+import groth16 as g
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("log_m,parts", [(10, 2), (13, 3), (16, 2), (16, 4), (16, 8), (20, 2), (20, 8)])
+def test_sharded_proof_equals_whole_key_proof_and_closed_form(log_m, parts):
+    import torch
+    import zkr_hip
+    p = 73
+    key, wb, aux = zkr_hip.ProvingKey.synth(log_m, p, 0x5A4B0001, 0x5A4B00FF)
+    info = key.info()
+    have = zkr_hip.device_count()
+    shards = [key.shard(i, parts, device=i % have) for i in range(parts)]
+    # the shards partition every scalar vector and every table
+    cover_w = cover_h = 0
+    pts = {t: 0 for t in ("ptsA", "ptsB1", "ptsB2", "ptsC", "ptsH")}
+    for i, sh in enumerate(shards):
+        si = sh.shard_info()
+        assert (si["part"], si["parts"]) == (i, parts) and si["w_lo"] == cover_w and si["h_lo"] == cover_h
+        cover_w += si["w_n"]
+        cover_h += si["h_n"]
+        for t in pts:
+            pts[t] += sh.info()[t]
+        assert sh.windows() == key.windows() and sh.fuse() == 1
+    assert cover_w == info["nVars"] and cover_h == info["domainSize"] and pts == {t: info[t] for t in pts}
+    assert key.shard_info() == dict(part=0, parts=1, w_lo=0, w_n=info["nVars"], h_lo=0, h_n=info["domainSize"])
+    rng = g.SplitMix64(77 + log_m + parts)
+    r, s = rng.fr(), rng.fr()
+    whole = key.prove(wb, r, s)
+    expect, vk, pub = g.proof_from_aux(aux, wb, p, r, s)
+    assert whole == g.proof_bytes(expect)
+    # step by step: partial sums per shard, one after the other, then the combination (any shard or the whole key assembles)
+    partials = [sh.prove_partial(wb) for sh in shards]
+    assert all(len(x) == zkr_hip.PARTIAL_BYTES for x in partials)
+    assert shards[-1].prove_combine(partials, r, s) == whole
+    assert key.prove_combine(partials[::-1], r, s) == whole                  # a sum: the order of the records does not matter
+    # in one call, shards concurrently (one host thread each); host witness and resident witnesses
+    assert zkr_hip.prove_sharded(shards, wb, r, s) == whole
+    dws = [torch.frombuffer(bytearray(wb), dtype=torch.uint8).to(torch.device("cuda", sh.device)) for sh in shards]
+    torch.cuda.synchronize()
+    assert zkr_hip.prove_sharded_device(shards, [t.data_ptr() for t in dws], r, s) == whole
+    # another witness on the same shards; random blinding verifies
+    wb2 = zkr_hip.synth_witness(log_m, p, 0x5A4B0001, 4242 + parts)
+    assert zkr_hip.prove_sharded(shards, wb2, r, s) == key.prove(wb2, r, s)
+    vk_bin = key.synth_vk(aux)
+    rnd = zkr_hip.prove_sharded(shards, wb)
+    assert rnd != whole and zkr_hip.verify(vk_bin, rnd, pub)
+    # the whole key may go: shards own their memory
+    key.close()
+    assert zkr_hip.prove_sharded(shards, wb, r, s) == whole
+
+
+def test_shard_errors_and_memory():
+    import zkr_hip
+    log_m, p = 12, 73
+    key, wb, _ = zkr_hip.ProvingKey.synth(log_m, p, 0x5A4B0001, 0x5A4B00FF, want_aux=False)
+    shards = [key.shard(i, 4) for i in range(4)]
+    assert sum(sh.arena()[1] for sh in shards) < 1.5 * key.arena()[1]          # the key is sharded, not replicated (QAP + twiddles repeat)
+    assert max(sh.arena()[1] for sh in shards) < 0.5 * key.arena()[1]
+    with pytest.raises(zkr_hip.ZkrError, match="itself a shard"):
+        shards[1].shard(0, 2)
+    with pytest.raises(zkr_hip.ZkrError):
+        key.shard(4, 4)
+    with pytest.raises(zkr_hip.ZkrError):
+        key.shard(0, 65)
+    with pytest.raises(zkr_hip.ZkrError, match="position"):
+        zkr_hip.prove_sharded([shards[1], shards[0], shards[2], shards[3]], wb, 1, 2)
+    with pytest.raises(zkr_hip.ZkrError, match="position"):
+        zkr_hip.prove_sharded(shards[:3], wb, 1, 2)
+    other, _, _ = zkr_hip.ProvingKey.synth(log_m, p, 0x5A4B0001, 0x5A4B00FE, want_aux=False)
+    with pytest.raises(zkr_hip.ZkrError, match="another key"):
+        zkr_hip.prove_sharded([shards[0], other.shard(1, 4), shards[2], shards[3]], wb, 1, 2)
+    with pytest.raises(zkr_hip.ZkrError) as e:
+        zkr_hip.prove_sharded(shards, wb[:-32], 1, 2)
+    assert e.value.code == -3
+    with pytest.raises(zkr_hip.ZkrError):
+        shards[0].prove_combine([bytes(zkr_hip.PARTIAL_BYTES)] * 4, g.R, 1)   # blinding out of range
+    # a shard is a key: it survives the packed-file round trip and a replication with its ranges
+    rep = shards[2].replicate(shards[2].device, "base")
+    assert rep.shard_info() == shards[2].shard_info() and rep.prove_partial(wb) == shards[2].prove_partial(wb)
+
+
+def test_real_tx_circuit_sharded():
+    """The reference's own circuit (tx.circom = BatchProcessTx(2, 6)) set up on the device, its key cut in three."""
+    import zkr_hip
+    from zkr_hip import rollup
+    circ = rollup.RollupCircuit(2, 6)
+    key, vk_bin = zkr_hip.ProvingKey.setup_r1cs(circ.r1cs())
+    privs = [0x5A4B1000 + 7919 * i for i in range(4)]
+    state = rollup.RollupState(circ.depth)
+    for i, pv in enumerate(privs):
+        state.deposit(i, rollup.gen_public_key(pv), 10 ** 20, 0)
+    txs = [state.transfer(j % 4, (j + 1) % 4, 10 ** 17, 10 ** 15, privs[j % 4]) for j in range(circ.batch)]
+    wb = circ.calculate_witness(circ.flatten_inputs(state.batch_inputs(txs)))
+    shards = [key.shard(i, 3) for i in range(3)]
+    assert zkr_hip.prove_sharded(shards, wb, 12345, 67890) == key.prove(wb, 12345, 67890)
+    assert zkr_hip.verify(vk_bin, zkr_hip.prove_sharded(shards, wb), circ.public_signals(wb))

@@ -409,3 +409,43 @@ def test_gpu_witness_program_equals_the_host_builder_signal_for_signal():
         with pytest.raises(Exception) as e:
             c.calculate_witness(as_inputs(txs))
         assert stmt in str(e.value), (what, stmt, str(e.value))
+
+
+def test_randomly_damaged_inputs_are_refused_or_give_a_satisfying_witness(monkeypatch):
+    """ADVICE r3 (rollup.cpp fast path): zkr_rollup_witness returns the value program's witness whenever that program's own
+    statement checks pass -- so the list of checks has to be complete.  Random single-signal damage to valid circuit inputs:
+    every call either refuses (ZKR_ERR_UNSATISFIED, or ZKR_ERR_ARG for a value >= r) or returns a witness that satisfies the
+    EMITTED constraint system -- checked twice: inside the library (ZKR_WITNESS_VERIFY=1 evaluates the system on the
+    fast-path result) and here with Python integers."""
+    import rollup as o
+    import zkr_hip
+    from zkr_hip import rollup as n
+    monkeypatch.setenv("ZKR_WITNESS_VERIFY", "1")
+    c = n.RollupCircuit(2, 3)
+    nv, npub, cons = parse_r1cs(c.r1cs())
+    rnd = random.Random(20261003)
+    refused = accepted = 0
+    for trial in range(48):
+        txs, _, _ = scenario(2, 3, 300 + trial % 6)
+        flat = list(c.flatten_inputs(as_inputs(txs)))
+        k = rnd.randrange(len(flat))
+        how = rnd.randrange(4)
+        if how == 0:
+            flat[k] = (flat[k] + 1) % o.R
+        elif how == 1:
+            flat[k] = rnd.randrange(o.R)
+        elif how == 2:
+            flat[k] = flat[k] ^ (1 << rnd.randrange(250))
+        else:
+            flat[k] = flat[rnd.randrange(len(flat))]
+        try:
+            wb = c.calculate_witness(flat)
+        except zkr_hip.ZkrError as e:
+            assert e.code in (-7, -5), str(e)
+            assert "internal" not in str(e), str(e)          # the fast path never hands out what the system rejects
+            refused += 1
+            continue
+        w = ints(wb)
+        assert first_violated(cons, w, o.R) == -1, "trial %d: accepted inputs whose witness violates the system" % trial
+        accepted += 1
+    assert refused >= 30 and refused + accepted == 48

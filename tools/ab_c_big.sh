@@ -1,5 +1,5 @@
 # A/B: C's oversized-bucket kernel in front of every chain (ZKR_C_BIG_FIRST=1) or with C's turn (=0)
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}" || exit 1
 B="--no-cpu-baseline --no-js-baseline --no-tx-circuit --no-bcast-modes"
 for r in 1 2 3; do for v in "ZKR_C_BIG_FIRST=1" "ZKR_C_BIG_FIRST=0"; do
   echo "== [$v] round $r: tx single / sync 2^20 / pipelined"

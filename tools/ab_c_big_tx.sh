@@ -1,6 +1,6 @@
 # A/B of C's oversized-bucket kernel on the auxiliary stream (ZKR_C_BIG_FIRST=1) against C's turn on its chain's stream (=0):
 # fused tx-circuit throughput and the facade pipeline (five active streams against four)
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}" || exit 1
 B="--no-cpu-baseline --no-js-baseline --no-bcast-modes"
 for r in 1 2 3; do for v in "ZKR_C_BIG_FIRST=1" "ZKR_C_BIG_FIRST=0"; do
   env $v python3 bench.py --steps 50 --warmup 5 $B 2>/dev/null | python3 -c "

@@ -2,9 +2,9 @@
 # For every setting: isolated kernel times (ZKR_SERIAL=1, rocprofv3 --kernel-trace --stats), WRITE_SIZE / FETCH_SIZE traffic in
 # separate --pmc passes; then the pipelined proof rate of every setting, two rounds.  "-" = the defaults.  AB_BENCH_ARGS="--log-m 22"
 # AB_STEPS=20: another size.  AB_NO_RATE=1: kernel times and traffic only.
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:?}" || exit 1
 O=gpurun_out/${1:-abenv}; mkdir -p $O; shift
-ARGS="$AB_BENCH_ARGS --steps 3 --warmup 1 --no-cpu-baseline --no-pipeline --no-tx-circuit --no-bcast-modes"
+ARGS="$AB_BENCH_ARGS --steps 3 --warmup 1 --no-cpu-baseline --no-js-baseline --no-pipeline --no-tx-circuit --no-bcast-modes"
 i=0
 for v in "$@"; do
   [ "$v" = "-" ] && v=""

@@ -1,5 +1,5 @@
 # Sweep of the HIP runtime's hardware-queue count (GPU_MAX_HW_QUEUES, default 4): headline, fused tx circuit, facade pipeline
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}" || exit 1
 B="--no-cpu-baseline --no-js-baseline --no-bcast-modes"
 for r in 1 2; do for q in ${AB_QUEUES:-4 5 6 8}; do
   GPU_MAX_HW_QUEUES=$q python3 bench.py --steps 40 --warmup 5 $B 2>/dev/null | python3 -c "

@@ -1,4 +1,4 @@
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}" || exit 1
 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
 B="--no-cpu-baseline --no-js-baseline --no-tx-circuit --no-bcast-modes"
 for r in 1 2; do

@@ -1,5 +1,5 @@
 # Two against three reduction streams on the REAL circuit filled to 2^20 (BatchProcessTx(18, 6): bit-heavy witness) and the tx circuit
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}" || exit 1
 B="--no-cpu-baseline --no-js-baseline --no-bcast-modes"
 for r in 1 2; do for v in "ZKR_RED_STREAMS=2" "ZKR_RED_STREAMS=3"; do
   env $v python3 bench.py --steps 40 --warmup 5 $B 2>/dev/null | python3 -c "

@@ -1,4 +1,4 @@
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}" || exit 1
 for r in 1 2 3; do for v in "ZKR_SCHED=0" "ZKR_SCHED=1"; do
   echo "== [$v] round $r"
   env $v python3 tools/tx_single.py 40 2>&1 | grep "witness"

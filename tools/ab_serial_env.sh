@@ -1,4 +1,5 @@
 # isolated stage times (ZKR_SERIAL=1) under environment variants on one box:  bash tools/ab_serial_env.sh "name:ENV=val,ENV=val" ...
+cd "${GRAFT_REPO_ROOT:?}" || exit 1
 for r in 1 2; do for spec in "$@"; do
   name=${spec%%:*}; envs=${spec#*:}
   ( IFS=,; for kv in $envs; do [ -n "$kv" ] && export "$kv"; done; unset IFS; export ZKR_SERIAL=1

@@ -1,4 +1,5 @@
 # isolated stage times (ZKR_SERIAL=1, one proof at a time) of library variants on one box:
+cd "${GRAFT_REPO_ROOT:?}" || exit 1
 #   bash tools/ab_serial_stages.sh name:lib name:lib ...   (lib empty = the shipped library)
 for r in 1 2; do for spec in "$@"; do
   name=${spec%%:*}; lib=${spec#*:}

@@ -1,4 +1,4 @@
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}" || exit 1
 LIGHT="--no-cpu-baseline --no-tx-circuit --no-bcast-modes --no-js-baseline"
 for v in "" "ZKR_SORT_NBL=8192 ZKR_MSM_J=16" "ZKR_SORT_NBL=8192 ZKR_MSM_J=64" "ZKR_MSM_J=16"; do
   echo "== [$v]"

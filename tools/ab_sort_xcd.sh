@@ -1,8 +1,8 @@
 # A/B of the scatter kernel's workgroup -> XCD mapping (ZKR_SORT_XCD=0|1): isolated kernel time (ZKR_SERIAL=1, rocprofv3
 # --kernel-trace --stats), WRITE_SIZE / FETCH_SIZE traffic in separate --pmc passes, then the pipelined proof rate of both.
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:?}" || exit 1
 O=gpurun_out/${1:-absort}; mkdir -p $O
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-pipeline --no-tx-circuit --no-bcast-modes"
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-js-baseline --no-pipeline --no-tx-circuit --no-bcast-modes"
 for v in 0 1; do
   export ZKR_SORT_XCD=$v
   ZKR_SERIAL=1 rocprofv3 --kernel-trace --stats -d $O/st$v -- python3 bench.py $ARGS > /dev/null 2>$O/st$v.err

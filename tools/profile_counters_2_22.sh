@@ -1,4 +1,4 @@
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:?}" || exit 1
 O=gpurun_out/pmc22; mkdir -p $O
 for c in SQ_INSTS_VALU SQ_WAVES SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU; do
   ZKR_SERIAL=1 timeout 600 rocprofv3 --kernel-trace --pmc $c -d $O/$c -- python3 bench.py --log-m 22 --steps 2 --warmup 1 --no-cpu-baseline --no-pipeline --no-tx-circuit > /dev/null 2>$O/$c.err

@@ -1,7 +1,7 @@
 # Round-2 measurement set on one MI355X (run through gpurun): bench lines of every BASELINE size, kernel stats of the
 # benchmarked command (rocprofv3 --kernel-trace --stats), isolated kernel durations (ZKR_SERIAL=1), HBM traffic (PMC
 # FETCH_SIZE / WRITE_SIZE in separate passes).  Usage: bash tools/profile_round2.sh <tag>   -> gpurun_out/<tag>/
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:?}" || exit 1
 O=gpurun_out/${1:-r2p}; mkdir -p $O
 python bench.py > $O/bench.json 2>$O/bench.err
 python bench.py --no-pipeline --no-cpu-baseline --no-tx-circuit --no-bcast-modes > $O/bench_sync.json 2>/dev/null

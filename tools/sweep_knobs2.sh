@@ -1,4 +1,4 @@
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}" || exit 1
 B="--no-cpu-baseline --no-js-baseline --no-tx-circuit --no-bcast-modes"
 for r in 1 2 3; do for v in "ZKR_RED_STREAMS=3" "ZKR_RED_STREAMS=2" "ZKR_RED_STREAMS=1" "ZKR_RED_STREAMS=2 ZKR_MSM_BIG=128" "ZKR_RED_STREAMS=2 ZKR_MSM_BIG=64" "ZKR_RED_STREAMS=2 ZKR_NTT_PRIO=2"; do
   env $v python3 bench.py --steps 40 --warmup 5 $B 2>/dev/null | python3 -c "

@@ -1,4 +1,4 @@
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}" || exit 1
 B="--no-cpu-baseline --no-js-baseline --no-bcast-modes --steps 64"
 for r in 1 2; do for v in "ZKR_MSM_GLOG=2" "ZKR_MSM_GLOG=3" "ZKR_MSM_GLOG=4" "ZKR_MSM_GLOG=5"; do
   env $v python3 bench.py $B 2>/dev/null | python3 -c "
