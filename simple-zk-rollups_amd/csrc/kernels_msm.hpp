@@ -160,6 +160,7 @@ static_assert(MSM_THREADS == 256, "the digit kernels keep one range counter per 
 constexpr uint32_t MAX_RANGES = 256;  // x SORT_RANGE_MAX buckets = 2^21: window sizes up to c = 22 (2^24-point tables), or fused batches of small circuits
 constexpr uint32_t DIGIT_XCDS = 8;
 constexpr uint32_t DIGIT_STAGE = 2 * 256 * 13;  // records a workgroup groups in LDS (x 8 bytes = 53 KB)
+constexpr uint32_t DIGIT_CLEAR_WORDS = 2 * DIGIT_XCDS * MAX_RANGES;  // counts[range][XCD slot] | fill cursors[range][XCD slot]: zero before the count kernel
 constexpr size_t DIGIT_RNG_WORDS = 2 * DIGIT_XCDS * MAX_RANGES + MAX_RANGES + 1;  // counts[r][x] | fill cursors[r][x] | range offsets[nR + 1]
 
 __device__ __forceinline__ uint32_t digit_bucket(int d) { return (uint32_t)(d < 0 ? -d : d) - 1u; }
@@ -318,11 +319,26 @@ __device__ __forceinline__ void sort_block_to_chunk(uint32_t b, uint32_t nR, uin
   }
 }
 
+// What the later kernels of one table's sort accumulate into, cleared by the FIRST kernel of that sort (msm_hist_kernel, workgroup
+// 0) instead of by memset launches in front of it: a launch boundary lies between the clearing and every use, and two launches
+// fewer per sort are two gaps fewer in a chain of short dependent kernels (DESIGN.md "preparation chain").
+struct SortScratch {
+  uint32_t *big_count;             // [0] oversized buckets listed, [1] total entries, [2] tile ticket of the single-pass scan
+  uint32_t *size_hist;             // [2][SIZE_BINS]: size-class histogram, hand-out counters of msm_order_kernel
+  unsigned long long *scan_state;  // [tiles]: look-back words of msm_scan_fused_kernel
+  uint32_t n_tiles;
+};
+
 // cnt[(r * J + j) * nbl + b] = occupancy of bucket r * nbl + b within chunk j
 static __global__ __launch_bounds__(SORT_THREADS) void msm_hist_kernel(const uint32_t *ent_s, const uint32_t *ent_b, const uint32_t *rng_off, const uint32_t *rank,
-                                                                     uint32_t n_per, uint32_t nbl, uint32_t J, uint32_t *cnt) {
+                                                                     uint32_t n_per, uint32_t nbl, uint32_t J, uint32_t *cnt, SortScratch z) {
   ZKR_PREP_SETPRIO();
   extern __shared__ __attribute__((aligned(16))) uint32_t s_bkt[];
+  if (blockIdx.x == 0 && z.big_count) {
+    if (threadIdx.x < 3) z.big_count[threadIdx.x] = 0;
+    for (uint32_t i = threadIdx.x; i < 2 * 1024u; i += SORT_THREADS) z.size_hist[i] = 0;  // 2 * SIZE_BINS (defined below)
+    for (uint32_t i = threadIdx.x; i < z.n_tiles; i += SORT_THREADS) z.scan_state[i] = 0ull;
+  }
   const uint32_t j = blockIdx.x % J, r = blockIdx.x / J;
   for (uint32_t b = threadIdx.x; b < nbl; b += SORT_THREADS) s_bkt[b] = 0;
   __syncthreads();
@@ -482,6 +498,111 @@ static __global__ __launch_bounds__(SCAN_THREADS) void msm_scan_apply_kernel(uin
   __syncthreads();
   for (uint32_t b = threadIdx.x; b < SIZE_BINS; b += SCAN_THREADS)
     if (s_hist[b]) atomicAdd(&size_hist[b], s_hist[b]);
+}
+
+static_assert(SIZE_BINS == 1024, "msm_hist_kernel clears 2 * 1024 words of size_hist");
+
+// The four launches above (msm_colscan_kernel, msm_scan_sums_kernel, msm_scan_top_kernel, msm_scan_apply_kernel) in ONE: a
+// workgroup takes a tile of SCAN_BLOCK buckets (tiles handed out by a ticket, so every lower tile is running or done), turns
+// the per-chunk occupancies of its buckets into per-chunk prefixes and bucket totals (the column scan), scans the totals
+// within the tile, publishes the tile's sum, and gets the sum of everything below it by looking BACK over the published words
+// (single-pass scan with decoupled look-back: a word is flag << 62 | value, flag 1 = the tile's own sum, 2 = the inclusive
+// prefix up to and including the tile; wavefront 0 inspects 64 predecessors per step).  Then offsets, the oversized-bucket
+// list and the size-class histogram as before.  With 256 tiles at 2^19 buckets the look-back is a few steps; the chain of
+// short launches it replaces cost more in launch gaps than in work (isolated 8 + 4 + 3 + 7 us of kernels, ~60 us of stream time).
+constexpr unsigned long long SCAN_FLAG_SUM = 1ull << 62, SCAN_FLAG_PREFIX = 2ull << 62, SCAN_VALUE_MASK = (1ull << 62) - 1;
+static __global__ __launch_bounds__(SCAN_THREADS) void msm_scan_fused_kernel(uint32_t *chunk_cnt, uint32_t nb, uint32_t nbl, uint32_t J, uint32_t *counts, uint32_t *offsets,
+                                                                           uint32_t big_thresh, uint32_t *big_list, uint32_t big_cap, SortScratch z) {
+  ZKR_PREP_SETPRIO();
+  __shared__ uint32_t s_cnt[SCAN_BLOCK];
+  __shared__ uint32_t part[SCAN_THREADS];
+  __shared__ uint32_t s_hist[SIZE_BINS];
+  __shared__ uint32_t s_tile;
+  __shared__ unsigned long long s_before;
+  const uint32_t t = threadIdx.x;
+  if (t == 0) s_tile = atomicAdd(&z.big_count[2], 1u);
+  for (uint32_t b = t; b < SIZE_BINS; b += SCAN_THREADS) s_hist[b] = 0;
+  __syncthreads();
+  const uint32_t tile = s_tile, tile_base = tile * SCAN_BLOCK;
+  // column scan: consecutive lanes take consecutive buckets (the chunk rows of a range are contiguous over its buckets)
+#pragma unroll
+  for (int k = 0; k < SCAN_PER_THREAD; k++) {
+    const uint32_t g = tile_base + k * SCAN_THREADS + t;
+    uint32_t run = 0;
+    if (g < nb) {
+      const uint32_t r = g / nbl, b = g % nbl;
+      uint32_t *col = chunk_cnt + (size_t)r * J * nbl + b;
+      for (uint32_t j = 0; j < J; j++) {
+        const uint32_t v = col[(size_t)j * nbl];
+        col[(size_t)j * nbl] = run;
+        run += v;
+      }
+    }
+    s_cnt[k * SCAN_THREADS + t] = run;
+  }
+  __syncthreads();
+  const uint32_t base = tile_base + t * SCAN_PER_THREAD;
+  uint32_t c[SCAN_PER_THREAD], s = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_PER_THREAD; k++) { c[k] = s_cnt[t * SCAN_PER_THREAD + k]; s += c[k]; }
+  part[t] = s;
+  __syncthreads();
+  for (uint32_t off = 1; off < SCAN_THREADS; off <<= 1) {
+    uint32_t v = t >= off ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  if (t < 64) {  // wavefront 0: publish, look back
+    const unsigned long long total = part[SCAN_THREADS - 1];
+    unsigned long long before = 0;
+    if (tile > 0) {
+      if (t == 0) __hip_atomic_store(&z.scan_state[tile], SCAN_FLAG_SUM | total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      int hi = (int)tile - 1;  // highest tile not yet accounted for
+      for (;;) {
+        const int idx = hi - (int)t;
+        const unsigned long long v = idx >= 0 ? __hip_atomic_load(&z.scan_state[idx], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) : SCAN_FLAG_PREFIX;
+        const unsigned long long flag = v >> 62;
+        const unsigned long long m_prefix = __ballot(flag == 2), m_empty = __ballot(flag == 0);
+        const int first_prefix = m_prefix ? __builtin_ctzll(m_prefix) : 64, first_empty = m_empty ? __builtin_ctzll(m_empty) : 64;
+        if (first_empty < first_prefix) { __builtin_amdgcn_s_sleep(1); continue; }  // a word this step needs is not published yet
+        unsigned long long mine = (int)t <= first_prefix ? (v & SCAN_VALUE_MASK) : 0ull;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)mine, o), hi32 = (uint32_t)__shfl_xor((int)(uint32_t)(mine >> 32), o);
+          mine += ((unsigned long long)hi32 << 32) | lo;
+        }
+        before += mine;
+        if (first_prefix < 64) break;
+        hi -= 64;
+      }
+    }
+    if (t == 0) {
+      __hip_atomic_store(&z.scan_state[tile], SCAN_FLAG_PREFIX | (before + total), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      s_before = before;
+      if (tile == z.n_tiles - 1) { offsets[nb] = (uint32_t)(before + total); z.big_count[1] = (uint32_t)(before + total); }
+    }
+  }
+  __syncthreads();
+  uint32_t run = (uint32_t)s_before + part[t] - s;
+#pragma unroll
+  for (int k = 0; k < SCAN_PER_THREAD; k++) {
+    if (base + k < nb) {
+      offsets[base + k] = run;
+      bool big = false;
+      uint32_t cv = c[k];
+      if (cv > big_thresh) {
+        uint32_t slot = atomicAdd(&z.big_count[0], 1u);
+        if (slot < big_cap) { big_list[slot] = base + k; cv = BIG_MARK; big = true; }  // beyond the cap the bucket stays with msm_accum_kernel
+      }
+      counts[base + k] = cv;
+      atomicAdd(&s_hist[big ? 0u : size_bin(c[k])], 1u);
+      run += c[k];
+    }
+  }
+  __syncthreads();
+  for (uint32_t b = t; b < SIZE_BINS; b += SCAN_THREADS)
+    if (s_hist[b]) atomicAdd(&z.size_hist[b], s_hist[b]);
 }
 
 // order[] = all bucket ids sorted by occupancy, fullest first (counting sort over SIZE_BINS size classes;

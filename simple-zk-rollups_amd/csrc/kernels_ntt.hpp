@@ -86,6 +86,11 @@ struct NttPassArgs {
   int pre;         // NttPre
   int canon;       // last pass of a transform: store canonical residues (between passes values below 3 r are stored)
   int prio;        // wave priority (s_setprio) of the pass: the preparation chain paces the pipeline once the accumulations are fast
+  // a SECOND transform of the same shape in the same launch (gridDim.z = 2: calcH's transforms come in pairs -- the A and the B
+  // side, then the two products): half the launches of the preparation chain and twice the workgroups per launch, which is
+  // what a 2^17 transform lacks to fill the chip
+  const Fr *in0_b, *in1_b;
+  Fr *out_b;
 };
 
 // The butterflies run on 9 x 29-bit limbs (field29.hpp), lazily reduced: a product is 205 instructions instead of the ~300
@@ -115,6 +120,7 @@ static __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArg
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   constexpr int HL = DIF ? NTT_H_DIF : NTT_H_DIT;  // what a value read from LDS is stated to be below
   using V = L29<NttL, HL>;
+  if (blockIdx.z) { a.in0 = a.in0_b; a.in1 = a.in1_b; a.out = a.out_b; }
   if (a.prio == 1) __builtin_amdgcn_s_setprio(1);
   else if (a.prio == 2) __builtin_amdgcn_s_setprio(2);
   else if (a.prio == 3) __builtin_amdgcn_s_setprio(3);
@@ -284,7 +290,11 @@ static __global__ void twiddle_table_kernel(Fr *T, uint32_t n, Fr g) {
 
 // witness ingest: reduce every 256-bit word below r (values from calculateWitness already are; this
 // makes the path total for any buffer binarifyWitness can produce, binarify.ts:18-26)
-static __global__ void ingest_kernel(const Fr *in, Fr *out, size_t n) {
+// zero / zero_words: a few counters the NEXT kernels of the stream accumulate into (the range counts of the digit records,
+// zkr_prove.hip msm_digits_enqueue), cleared here by workgroup 0 instead of by a memset launch of their own.
+static __global__ void ingest_kernel(const Fr *in, Fr *out, size_t n, uint32_t *zero = nullptr, uint32_t zero_words = 0) {
+  if (blockIdx.x == 0)
+    for (uint32_t k = threadIdx.x; k < zero_words; k += blockDim.x) zero[k] = 0;
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   Fr x = load_fr(in + i);
@@ -298,8 +308,14 @@ static __global__ void ingest_kernel(const Fr *in, Fr *out, size_t n) {
 // occasional wide row (64-term bit-packing rows, a handful per few thousand), which would leave 63 lanes of its
 // wavefront waiting for one; rows wider than SPMV_WIDE are left to spmv_wide_kernel (one wavefront per row).
 constexpr uint32_t SPMV_WIDE = 8;
-static __global__ void spmv_kernel(const uint32_t *row_ptr, const uint32_t *col, const Fr *coef, const Fr *w, Fr *out, uint32_t m, uint32_t n) {
+// blockIdx.z = 1: the B side of the QAP in the same launch (its CSR arrays and output vector)
+struct SpmvSide { const uint32_t *row_ptr, *col; const Fr *coef; Fr *out; const uint32_t *wide; uint32_t n_wide; };
+static __global__ void spmv_kernel(SpmvSide sa, SpmvSide sb, const Fr *w, uint32_t m, uint32_t n) {
   ZKR_PREP_SETPRIO();
+  const SpmvSide &sd = blockIdx.z ? sb : sa;
+  const uint32_t *row_ptr = sd.row_ptr, *col = sd.col;
+  const Fr *coef = sd.coef;
+  Fr *out = sd.out;
   uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= m) return;
   w += (size_t)blockIdx.y * n;    // blockIdx.y: witness of a fused batch
@@ -311,11 +327,14 @@ static __global__ void spmv_kernel(const uint32_t *row_ptr, const uint32_t *col,
   store_fr(out + c, acc);
 }
 // wide[i] = index of the i-th row wider than SPMV_WIDE; one wavefront per row, terms strided over the lanes, LDS tree
-static __global__ __launch_bounds__(64) void spmv_wide_kernel(const uint32_t *row_ptr, const uint32_t *col, const Fr *coef, const Fr *w, Fr *out,
-                                                            const uint32_t *wide, uint32_t n_wide, uint32_t m, uint32_t n) {
+static __global__ __launch_bounds__(64) void spmv_wide_kernel(SpmvSide sa, SpmvSide sb, const Fr *w, uint32_t m, uint32_t n) {
   ZKR_PREP_SETPRIO();
   __shared__ uint32_t sh[8 * 64];
-  if (blockIdx.x >= n_wide) return;
+  const SpmvSide &sd = blockIdx.z ? sb : sa;
+  const uint32_t *row_ptr = sd.row_ptr, *col = sd.col, *wide = sd.wide;
+  const Fr *coef = sd.coef;
+  Fr *out = sd.out;
+  if (blockIdx.x >= sd.n_wide) return;
   w += (size_t)blockIdx.y * n;
   out += (size_t)blockIdx.y * m;
   const uint32_t c = wide[blockIdx.x], lane = threadIdx.x;
@@ -341,8 +360,10 @@ static __global__ __launch_bounds__(64) void spmv_wide_kernel(const uint32_t *ro
 
 // h (bit-reversed order) = C1*S' - C2 * g^-i * D'   (DESIGN.md "calcH on the GPU"); S', D' are the
 // unscaled inverse-DIF outputs of a.b and A(gw^c).B(gw^c); i = bitrev(pos).
-static __global__ void combine_h_kernel(const Fr *S, const Fr *D, Fr *h, const Fr *tw, int tlog, int L, Fr c1, Fr c2) {
+static __global__ void combine_h_kernel(const Fr *S, const Fr *D, Fr *h, const Fr *tw, int tlog, int L, Fr c1, Fr c2, uint32_t *zero = nullptr, uint32_t zero_words = 0) {
   ZKR_PREP_SETPRIO();
+  if (blockIdx.x == 0 && blockIdx.y == 0)  // see ingest_kernel: the counters of h's digit records
+    for (uint32_t k = threadIdx.x; k < zero_words; k += blockDim.x) zero[k] = 0;
   uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x;
   if (pos >= (1u << L)) return;
   const size_t boff = (size_t)blockIdx.y << L;  // blockIdx.y: proof of a fused batch

@@ -136,8 +136,8 @@ static int alloc_msm_ws(MsmWorkspace &ws, size_t n, const MsmPlan &pl, size_t xy
   ZKR_HIP_CHECK(hipMalloc(&ws.chunk_cnt, (size_t)pl.J * nb * 4 + 4));
   ZKR_HIP_CHECK(hipMalloc(&ws.entries, (n * pl.K * cap + 1) * 4));
   ZKR_HIP_CHECK(hipMalloc(&ws.big_list, BIG_CAP * 4));
-  ZKR_HIP_CHECK(hipMalloc(&ws.big_count, 8));
-  ZKR_HIP_CHECK(hipMalloc(&ws.block_sums, (nb / SCAN_BLOCK + 2) * 4));
+  ZKR_HIP_CHECK(hipMalloc(&ws.big_count, 16));  // [0] oversized buckets, [1] total entries, [2] tile ticket (kernels_msm.hpp SortScratch)
+  ZKR_HIP_CHECK(hipMalloc(&ws.block_sums, (nb / SCAN_BLOCK + 2) * 8));  // one 64-bit look-back word per scan tile (msm_scan_fused_kernel)
   ZKR_HIP_CHECK(hipMalloc(&ws.big_partials, (size_t)BIG_CAP * BIG_SPLIT * xyzz_bytes));
   ZKR_HIP_CHECK(hipMalloc(&ws.buckets, nb * xyzz_bytes));
   ZKR_HIP_CHECK(hipMalloc(&ws.group_out, (size_t)(pl.nbw >> pl.glog) * cap * 2 * xyzz_bytes));

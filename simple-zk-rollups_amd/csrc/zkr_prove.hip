@@ -68,18 +68,20 @@ int prof_collect(zkr_key *k, ProofSlot &sl) {  // call after the slot's work has
 
 // ------------------------------------------------------------------ NTT driver
 struct PassSpec { int lo, hi, wlog; };
-static std::vector<PassSpec> ntt_plan(int L) {
-  // contiguous pass: low min(L, 11) stages; the rest in balanced chunks of <= 9 stages, listed top-down
+// tile_log: log2 of the elements a workgroup keeps in LDS (NTT_TILE_LOG, or less for small transforms: ntt_tile_log)
+static std::vector<PassSpec> ntt_plan(int L, int tile_log) {
+  // contiguous pass: low min(L, tile_log) stages; the rest in balanced chunks of <= 9 stages, listed top-down
   std::vector<PassSpec> v;
-  int lows = L < NTT_TILE_LOG ? L : NTT_TILE_LOG;
+  int lows = L < tile_log ? L : tile_log;
   int rem = L - lows;
   if (rem > 0) {
-    int nch = (rem + NTT_STRIDED_LOG - 1) / NTT_STRIDED_LOG;
+    const int strided = NTT_STRIDED_LOG < tile_log - 1 ? NTT_STRIDED_LOG : tile_log - 1;  // at least two columns (64 contiguous bytes) per row
+    int nch = (rem + strided - 1) / strided;
     int hi = L;
     for (int i = 0; i < nch; i++) {
       int nb = (rem + (nch - i) - 1) / (nch - i);
       int lo = hi - nb;
-      int wlog = NTT_TILE_LOG - nb;
+      int wlog = tile_log - nb;
       if (wlog > lo) wlog = lo;
       v.push_back({lo, hi, wlog});
       hi = lo;
@@ -119,8 +121,23 @@ int ntt_lds_check(int device) {
   return 0;
 }
 
-int run_ntt(hipStream_t s, const Fr *in0, const Fr *in1, Fr *out, const NttTables &tb, int L, bool dif, bool inverse, int pre, int nbat, Prof pf) {
-  std::vector<PassSpec> plan = ntt_plan(L);
+// Elements per workgroup by transform size.  A transform of 2^17 (the reference's tx circuit) cut into tiles of 2048 is 64
+// workgroups -- a quarter of the CUs, eight wavefronts each -- whatever the pairing of transforms adds; tiles of 1024 spread the
+// same wavefronts over twice the CUs (same passes: 10 + 7 stages instead of 11 + 6).  From 2^19 on a pass fills the chip with
+// the large tile, which moves fewer bytes per stage.  ZKR_NTT_TILE_LOG overrides (8..11).
+static int ntt_tile_log(int L, int nbat) {
+  static const int env = getenv("ZKR_NTT_TILE_LOG") ? atoi(getenv("ZKR_NTT_TILE_LOG")) : 0;
+  if (env >= 8 && env <= NTT_TILE_LOG) return env;
+  int lg = 0;
+  while ((1 << lg) < nbat) lg++;
+  return L + lg <= 18 ? NTT_TILE_LOG - 1 : NTT_TILE_LOG;
+}
+
+// One transform, or TWO of the same shape in the same launches (in0_b / in1_b / out_b: gridDim.z = 2)
+int run_ntt(hipStream_t s, const Fr *in0, const Fr *in1, Fr *out, const NttTables &tb, int L, bool dif, bool inverse, int pre, int nbat, Prof pf,
+            const Fr *in0_b, const Fr *in1_b, Fr *out_b) {
+  const int tile_log = ntt_tile_log(L, nbat * (out_b ? 2 : 1));
+  std::vector<PassSpec> plan = ntt_plan(L, tile_log);
   if (!dif) std::reverse(plan.begin(), plan.end());
   bool first = true;
   for (auto &ps : plan) {
@@ -128,6 +145,9 @@ int run_ntt(hipStream_t s, const Fr *in0, const Fr *in1, Fr *out, const NttTable
     a.in0 = first ? in0 : out;
     a.in1 = first ? in1 : nullptr;
     a.out = out;
+    a.in0_b = first ? in0_b : out_b;
+    a.in1_b = first ? in1_b : nullptr;
+    a.out_b = out_b;
     a.tw = tb.tw; a.tw29 = tb.tw29; a.twl29 = tb.twl29; a.tlog = tb.tlog; a.L = L;
     a.lo = ps.lo; a.hi = ps.hi; a.wlog = ps.wlog;
     a.pre = first ? pre : PRE_NONE;
@@ -142,8 +162,9 @@ int run_ntt(hipStream_t s, const Fr *in0, const Fr *in1, Fr *out, const NttTable
     size_t lds = (size_t)tile * 36;  // 9 limbs per element
     // workgroup size by transform size (kernels_ntt.hpp NTT_THREADS_*); ZKR_NTT_THREADS=256|512 overrides for experiments
     static const int thr_env = getenv("ZKR_NTT_THREADS") ? atoi(getenv("ZKR_NTT_THREADS")) : 0;
-    const int threads = thr_env == NTT_THREADS_SMALL || thr_env == NTT_THREADS_LARGE ? thr_env : L >= NTT_LARGE_LOG ? NTT_THREADS_LARGE : NTT_THREADS_SMALL;
-#define ZKR_NTT_LAUNCH(DIF, INV, T) ntt_pass_kernel<DIF, INV, T><<<dim3(grid, nbat), T, lds, s>>>(a)
+    // a tile of 1024 elements has 256 four-element butterfly groups per double stage: 256 threads
+    const int threads = thr_env == NTT_THREADS_SMALL || thr_env == NTT_THREADS_LARGE ? thr_env : (L >= NTT_LARGE_LOG || tile <= 1024) ? NTT_THREADS_LARGE : NTT_THREADS_SMALL;
+#define ZKR_NTT_LAUNCH(DIF, INV, T) ntt_pass_kernel<DIF, INV, T><<<dim3(grid, nbat, out_b ? 2 : 1), T, lds, s>>>(a)
 #define ZKR_NTT_LAUNCH_T(T) do { if (dif) { if (inverse) ZKR_NTT_LAUNCH(true, true, T); else ZKR_NTT_LAUNCH(true, false, T); } \
                                  else { if (inverse) ZKR_NTT_LAUNCH(false, true, T); else ZKR_NTT_LAUNCH(false, false, T); } } while (0)
     const int psp = prof_begin(pf, s, "ntt_pass");
@@ -174,26 +195,37 @@ int calc_h_device(zkr_key *k, ProofSlot &sl, hipStream_t s, int nbat) {
   const NttTables tb{tw, k->tw29, k->twl29, tlog};
   uint32_t m = h.m;
   int sp = prof_begin(pf, s, "spmv");
+  SpmvSide side[2];
   Fr *evals[2] = {sl.va, sl.vb};
-  for (int i = 0; i < 2; i++) {
-    const uint32_t *rp = (const uint32_t *)(ar + h.off_rowptr[i]), *cl = (const uint32_t *)(ar + h.off_col[i]);
-    const Fr *cf = (const Fr *)(ar + h.off_coef[i]);
-    const int sa = i == 0 ? prof_begin(pf, s, "spmv_a") : -1;
-    spmv_kernel<<<dim3((m + 255) / 256, nbat), 256, 0, s>>>(rp, cl, cf, sl.d_w, evals[i], m, h.n);
+  for (int i = 0; i < 2; i++)
+    side[i] = SpmvSide{(const uint32_t *)(ar + h.off_rowptr[i]), (const uint32_t *)(ar + h.off_col[i]), (const Fr *)(ar + h.off_coef[i]), evals[i],
+                       (const uint32_t *)(ar + h.off_wide[i]), h.n_wide[i]};
+  {  // both sides of the QAP in one launch (blockIdx.z): one launch fewer in the chain, twice the workgroups
+    const int sa = prof_begin(pf, s, "spmv_a");
+    spmv_kernel<<<dim3((m + 255) / 256, nbat, 2), 256, 0, s>>>(side[0], side[1], sl.d_w, m, h.n);
     prof_end(pf, s, sa);
-    if (h.n_wide[i]) spmv_wide_kernel<<<dim3(h.n_wide[i], nbat), 64, 0, s>>>(rp, cl, cf, sl.d_w, evals[i], (const uint32_t *)(ar + h.off_wide[i]), h.n_wide[i], m, h.n);
+    const uint32_t nw = h.n_wide[0] > h.n_wide[1] ? h.n_wide[0] : h.n_wide[1];
+    if (nw) spmv_wide_kernel<<<dim3(nw, nbat, 2), 64, 0, s>>>(side[0], side[1], sl.d_w, m, h.n);
   }
   prof_end(pf, s, sp);
   sp = prof_begin(pf, s, "ntt");
   int rc;
-  // coefficients (x m, bit-reversed), then evaluations on the coset g*w^c (x m, natural)
-  if ((rc = run_ntt(s, sl.va, nullptr, sl.ca, tb, L, true, true, PRE_NONE, nbat, pf))) return rc;
-  if ((rc = run_ntt(s, sl.vb, nullptr, sl.cb, tb, L, true, true, PRE_NONE, nbat, pf))) return rc;
-  if ((rc = run_ntt(s, sl.ca, nullptr, sl.ca, tb, L, false, false, PRE_COSET, nbat, pf))) return rc;
-  if ((rc = run_ntt(s, sl.cb, nullptr, sl.cb, tb, L, false, false, PRE_COSET, nbat, pf))) return rc;
-  // D' = iNTT(A(gw^c).B(gw^c)) and S' = iNTT(a.b), both unscaled and bit-reversed
-  if ((rc = run_ntt(s, sl.ca, sl.cb, sl.ca, tb, L, true, true, PRE_MUL, nbat, pf))) return rc;
-  if ((rc = run_ntt(s, sl.va, sl.vb, sl.va, tb, L, true, true, PRE_MUL, nbat, pf))) return rc;
+  // The six transforms come in three pairs of the same shape, each pair in ONE set of launches (gridDim.z = 2):
+  // coefficients of a and b (x m, bit-reversed), then their evaluations on the coset g*w^c (x m, natural),
+  static const bool no_pair = getenv("ZKR_NTT_NO_PAIR") != nullptr;  // A/B: the six transforms one after the other, as in round 3
+  if (no_pair) {
+    if ((rc = run_ntt(s, sl.va, nullptr, sl.ca, tb, L, true, true, PRE_NONE, nbat, pf))) return rc;
+    if ((rc = run_ntt(s, sl.vb, nullptr, sl.cb, tb, L, true, true, PRE_NONE, nbat, pf))) return rc;
+    if ((rc = run_ntt(s, sl.ca, nullptr, sl.ca, tb, L, false, false, PRE_COSET, nbat, pf))) return rc;
+    if ((rc = run_ntt(s, sl.cb, nullptr, sl.cb, tb, L, false, false, PRE_COSET, nbat, pf))) return rc;
+    if ((rc = run_ntt(s, sl.ca, sl.cb, sl.ca, tb, L, true, true, PRE_MUL, nbat, pf))) return rc;
+    if ((rc = run_ntt(s, sl.va, sl.vb, sl.va, tb, L, true, true, PRE_MUL, nbat, pf))) return rc;
+  } else {
+    if ((rc = run_ntt(s, sl.va, nullptr, sl.ca, tb, L, true, true, PRE_NONE, nbat, pf, sl.vb, nullptr, sl.cb))) return rc;
+    if ((rc = run_ntt(s, sl.ca, nullptr, sl.ca, tb, L, false, false, PRE_COSET, nbat, pf, sl.cb, nullptr, sl.cb))) return rc;
+    // then D' = iNTT(A(gw^c).B(gw^c)) and S' = iNTT(a.b), both unscaled and bit-reversed
+    if ((rc = run_ntt(s, sl.ca, sl.cb, sl.ca, tb, L, true, true, PRE_MUL, nbat, pf, sl.va, sl.vb, sl.va))) return rc;
+  }
   // constants: S' = m S / R, D' = m^3 D g^i / R  ->  h = S'*R^2/(2m) (*1/R)  -  D' g^-i * R^2/(2 m^3) (*1/R)
   Fr r2 = Fr::r2();
   Fr minv = inv(to_mont(fr_from_u64(m)));        // Montgomery(1/m)
@@ -203,7 +235,7 @@ int calc_h_device(zkr_key *k, ProofSlot &sl, hipStream_t s, int nbat) {
   // We need the plain integer R^2/(2m) = Montgomery(R/(2m)) exactly, so c1v is already the constant to pass.
   Fr c2v = mul(mul(c1v, minv), minv);            // Montgomery(R/(2m^3)) = integer R^2/(2m^3)
   const int csp = prof_begin(pf, s, "combine_h");
-  combine_h_kernel<<<dim3((m + 255) / 256, nbat), 256, 0, s>>>(sl.va, sl.ca, sl.d_h, tw, tlog, L, c1v, c2v);
+  combine_h_kernel<<<dim3((m + 255) / 256, nbat), 256, 0, s>>>(sl.va, sl.ca, sl.d_h, tw, tlog, L, c1v, c2v, sl.dig_h.rng, DIGIT_CLEAR_WORDS);  // + the counters of h's digit records
   prof_end(pf, s, csp);
   prof_end(pf, s, sp);
   ZKR_HIP_CHECK(hipGetLastError());
@@ -231,13 +263,15 @@ template <> struct MsmCfg<Fq2> { static constexpr int ACC_W = 2, RED_W = ZKR_RED
 
 // digit records of one scalar vector, split by bucket range; shared by every table over those scalars
 // nbat vectors of n scalars end to end (fused batch; nbat = 1: one proof)
-static int msm_digits_enqueue(Prof pf, hipStream_t s, const Fr *scalars, uint32_t n_per, int nbat, const MsmPlan &pl, const DigitLists &dl) {
+// cleared: the kernel in front of this call on the stream already zeroed the lists' counters (ingest_kernel for w, combine_h_kernel
+// for h: kernels_ntt.hpp) -- the proof path; the stage hooks clear them with a memset of their own
+static int msm_digits_enqueue(Prof pf, hipStream_t s, const Fr *scalars, uint32_t n_per, int nbat, const MsmPlan &pl, const DigitLists &dl, bool cleared = false) {
   if (n_per == 0) return 0;
   const uint32_t n = n_per * (uint32_t)nbat, nR = pl.nR * (uint32_t)nbat;
   int nbl_log = 0;
   while ((1u << nbl_log) < pl.nbl) nbl_log++;
   int sp = prof_begin(pf, s, "msm_sort");
-  ZKR_HIP_CHECK(hipMemsetAsync(dl.rng, 0, 2 * DIGIT_XCDS * MAX_RANGES * 4, s));
+  if (!cleared) ZKR_HIP_CHECK(hipMemsetAsync(dl.rng, 0, DIGIT_CLEAR_WORDS * 4, s));
   // scalars per thread (kernels_msm.hpp, stage 1): four from 2^18 scalars on; the staged scatter takes what its LDS stage holds
   static const int spt_env = getenv("ZKR_DIGITS_SPT") ? atoi(getenv("ZKR_DIGITS_SPT")) : 0;
   static const bool no_stage = getenv("ZKR_DIGITS_NO_STAGE") != nullptr;  // A/B: records written in arrival order
@@ -262,19 +296,29 @@ static int msm_digits_enqueue(Prof pf, hipStream_t s, const Fr *scalars, uint32_
 static int msm_sort_enqueue(Prof pf, hipStream_t s, const uint32_t *rank, const DigitLists &dl, uint32_t n_scalars, uint32_t n, int nbat, const MsmPlan &pl, MsmWorkspace &ws) {
   if (n == 0) return 0;
   int sp = prof_begin(pf, s, "msm_sort");
-  ZKR_HIP_CHECK(hipMemsetAsync(ws.big_count, 0, 8, s));
-  ZKR_HIP_CHECK(hipMemsetAsync(ws.size_hist, 0, 2 * SIZE_BINS * 4, s));
   const uint32_t nb = pl.nb * (uint32_t)nbat;  // the bucket sets of the batch end to end
   const unsigned sort_grid = pl.nR * (unsigned)nbat * pl.J;
   const size_t lds = (size_t)pl.nbl * 4;
   const uint32_t *rng_off = dl.rng + 2 * DIGIT_XCDS * MAX_RANGES;
-  msm_hist_kernel<<<sort_grid, SORT_THREADS, lds, s>>>(dl.ent_s, dl.ent_b, rng_off, rank, n_scalars, pl.nbl, pl.J, ws.chunk_cnt);
-  msm_colscan_kernel<<<(nb + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, s>>>(ws.chunk_cnt, nb, pl.nbl, pl.J, ws.counts);
-  unsigned scan_blocks = (nb + SCAN_BLOCK - 1) / SCAN_BLOCK;
-  msm_scan_sums_kernel<<<scan_blocks, SCAN_THREADS, 0, s>>>(ws.counts, nb, ws.block_sums);
-  msm_scan_top_kernel<<<1, 1024, 0, s>>>(ws.block_sums, scan_blocks, ws.big_count + 1);
-  msm_scan_apply_kernel<<<scan_blocks, SCAN_THREADS, 0, s>>>(ws.counts, ws.block_sums, ws.big_count + 1, ws.offsets, nb, pl.big_thresh,
-                                                            ws.big_list, ws.big_count, BIG_CAP, ws.size_hist);
+  const unsigned scan_blocks = (nb + SCAN_BLOCK - 1) / SCAN_BLOCK;
+  // Four launches per table: histogram (whose first workgroup clears what the others accumulate into), single-pass scan (column
+  // scan + exclusive scan + oversized-bucket list + size classes), ordering, scatter.  ZKR_SORT_LEGACY=1: the nine of round 3
+  // (two memsets, histogram, column scan, three-launch scan, ordering, scatter) for same-box comparisons.
+  static const bool legacy = getenv("ZKR_SORT_LEGACY") != nullptr;
+  const SortScratch scratch{ws.big_count, ws.size_hist, (unsigned long long *)ws.block_sums, scan_blocks};
+  if (legacy) {
+    ZKR_HIP_CHECK(hipMemsetAsync(ws.big_count, 0, 12, s));
+    ZKR_HIP_CHECK(hipMemsetAsync(ws.size_hist, 0, 2 * SIZE_BINS * 4, s));
+    msm_hist_kernel<<<sort_grid, SORT_THREADS, lds, s>>>(dl.ent_s, dl.ent_b, rng_off, rank, n_scalars, pl.nbl, pl.J, ws.chunk_cnt, SortScratch{nullptr, nullptr, nullptr, 0});
+    msm_colscan_kernel<<<(nb + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, s>>>(ws.chunk_cnt, nb, pl.nbl, pl.J, ws.counts);
+    msm_scan_sums_kernel<<<scan_blocks, SCAN_THREADS, 0, s>>>(ws.counts, nb, ws.block_sums);
+    msm_scan_top_kernel<<<1, 1024, 0, s>>>(ws.block_sums, scan_blocks, ws.big_count + 1);
+    msm_scan_apply_kernel<<<scan_blocks, SCAN_THREADS, 0, s>>>(ws.counts, ws.block_sums, ws.big_count + 1, ws.offsets, nb, pl.big_thresh,
+                                                              ws.big_list, ws.big_count, BIG_CAP, ws.size_hist);
+  } else {
+    msm_hist_kernel<<<sort_grid, SORT_THREADS, lds, s>>>(dl.ent_s, dl.ent_b, rng_off, rank, n_scalars, pl.nbl, pl.J, ws.chunk_cnt, scratch);
+    msm_scan_fused_kernel<<<scan_blocks, SCAN_THREADS, 0, s>>>(ws.chunk_cnt, nb, pl.nbl, pl.J, ws.counts, ws.offsets, pl.big_thresh, ws.big_list, BIG_CAP, scratch);
+  }
   msm_order_kernel<<<scan_blocks, SCAN_THREADS, 0, s>>>(ws.counts, nb, ws.size_hist, ws.size_hist + SIZE_BINS, ws.order);
   static const int xcd_map = getenv("ZKR_SORT_XCD") ? atoi(getenv("ZKR_SORT_XCD")) : 1;
   msm_scatter_kernel<<<sort_grid, SORT_THREADS, lds, s>>>(dl.ent_s, dl.ent_b, rng_off, rank, n_scalars, n, pl.nbl, pl.J, ws.chunk_cnt, ws.offsets, ws.entries, xcd_map);
@@ -518,7 +562,8 @@ static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *const *d_ws
   }
   int tot = prof_begin(pf, sp, "total");
   int spn = prof_begin(pf, sp, "ingest");
-  for (int j = 0; j < nbat; j++) ingest_kernel<<<(h.n + 255) / 256, 256, 0, sp>>>(d_wsrcs[j], sl.d_w + (size_t)j * h.n, h.n);
+  for (int j = 0; j < nbat; j++)  // the last one also clears the counters of w's digit records (msm_digits_enqueue below)
+    ingest_kernel<<<(h.n + 255) / 256, 256, 0, sp>>>(d_wsrcs[j], sl.d_w + (size_t)j * h.n, h.n, j == nbat - 1 ? sl.dig_w.rng : nullptr, j == nbat - 1 ? DIGIT_CLEAR_WORDS : 0u);
   prof_end(pf, sp, spn);
   const DigitLists *dig[N_TABLES] = {&sl.dig_w, &sl.dig_w, &sl.dig_w, &sl.dig_w, &sl.dig_h};
   const bool share_b = h.share_b != 0 && h.npts[T_B1] == h.npts[T_B2];
@@ -626,7 +671,7 @@ static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *const *d_ws
   };
   // preparation chain
   // a shard key (zkr_key_shard) multiplies only its sub-range of each scalar vector; a whole key: sc_lo = 0, sc_n = n / m
-  if ((rc = msm_digits_enqueue(pf, sp, sl.d_w + h.sc_lo[0], h.sc_n[0], nbat, k->plan[T_A], sl.dig_w))) return rc;
+  if ((rc = msm_digits_enqueue(pf, sp, sl.d_w + h.sc_lo[0], h.sc_n[0], nbat, k->plan[T_A], sl.dig_w, true))) return rc;
   if ((rc = sort_table(T_B1))) return rc;
   if (!share_b && (rc = sort_table(T_B2))) return rc;
   if (early && (rc = chains({T_B2, T_B1}))) return rc;
@@ -634,7 +679,7 @@ static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *const *d_ws
   if (!share_ac && (rc = sort_table(T_C))) return rc;
   if (early && ((rc = c_big()) || (rc = chains({T_A, T_C})))) return rc;
   if ((rc = calc_h_device(k, sl, sp, nbat))) return rc;
-  if ((rc = msm_digits_enqueue(pf, sp, sl.d_h + h.sc_lo[1], h.sc_n[1], nbat, k->plan[T_H], sl.dig_h))) return rc;
+  if ((rc = msm_digits_enqueue(pf, sp, sl.d_h + h.sc_lo[1], h.sc_n[1], nbat, k->plan[T_H], sl.dig_h, true))) return rc;
   if ((rc = sort_table(T_H))) return rc;
   // accumulations + reduction chains
   if (early) rc = chains({T_H});

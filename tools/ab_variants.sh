@@ -11,6 +11,11 @@ for r in $(seq 1 $N); do
       python bench.py --no-cpu-baseline --no-js-baseline --no-bcast-modes ${ZKR_AB_ARGS:-} 2>/dev/null | python3 -c "
 import json,sys; d=json.loads(sys.stdin.read()); v=d['roofline']['valu']
 tx=(d.get('tx_circuit') or {}).get('proofs_per_s') or 0
-print('%-10s round $r: %.2f proofs/s  tx %.1f  mul %.1f  sclk %s' % ('$name', d['value'], tx, v['peak_fq_mul_per_s_G'], d['device_state_during_timed_region']['sclk_mhz_mean']))" )
+b=d['config'].get('boundary') or {}
+st=d['stage_ms_per_proof']
+print('%-10s round $r: %.2f proofs/s  sync %.2f ms  tx fused %.1f/s  tx single %s ms  dropin %s ms  pipe1024 %s/s  | sort %.2f ntt %.2f spmv %.2f | mul %.1f  sclk %s' % ('$name', d['value'], b.get('sync_latency_ms') or 0, tx,
+      b.get('tx_circuit_single_proof_ms') and round(b['tx_circuit_single_proof_ms'], 3), b.get('tx_circuit_dropin_call_ms') and round(b['tx_circuit_dropin_call_ms'], 3),
+      b.get('tx_circuit_facade_pipeline_proofs_per_s') and round(b['tx_circuit_facade_pipeline_proofs_per_s'], 1),
+      st['msm_sort'], st['ntt'], st['spmv'], v['peak_fq_mul_per_s_G'], d['device_state_during_timed_region']['sclk_mhz_mean']))" )
   done
 done
