@@ -1,5 +1,6 @@
 """Per-kernel HBM traffic from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; rocpd SQLite output).
-python profiles/summarize_pmc.py <fetch.db> <write.db> [out.json log_m]
+python profiles/summarize_pmc.py <fetch.db> <write.db> [out.json log_m round schedule]
+schedule: "isolated" (ZKR_SERIAL=1: one stream, one proof at a time -- the default) or "pipelined" (the benchmarked schedule).
 Units/corrections as MI355X_MICROARCH.md "HBM" prescribes: FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950
 FETCH_SIZE reads exactly half of a wide (16 B/lane) coalesced stream, so reads are doubled; WRITE_SIZE is
 uncalibrated.  The ingest_kernel rows (known traffic: n*32 B read + n*32 B written, coalesced 16 B/lane)
@@ -38,7 +39,10 @@ for k in sorted(fetch, key=lambda k: -(2 * fetch[k][1] + write.get(k, [0, 0])[1]
 
 if len(sys.argv) > 3:
     import json
-    out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pipeline (ZKR_SERIAL=1)",
+    sched = sys.argv[6] if len(sys.argv) > 6 else "isolated"
+    out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) -- python3 bench.py "
+                     + ("--steps 2 --warmup 1 --no-cpu-baseline --no-pipeline (ZKR_SERIAL=1)" if sched == "isolated" else "--steps 8 --warmup 2 --no-cpu-baseline (two proofs in flight, the benchmarked schedule)"),
+           "schedule": "isolated kernels (ZKR_SERIAL=1)" if sched == "isolated" else "pipelined (two proofs in flight)",
            "correction": "KiB units; FETCH_SIZE doubled on gfx950 (MI355X_MICROARCH.md HBM section); calibration row: ingest_kernel (n*32 B read + n*32 B written)",
            "config": {"log_m": int(sys.argv[4]), "n_public": 73}, "round": int(sys.argv[5]) if len(sys.argv) > 5 else 1, "kernels": {}}
     for k in fetch:

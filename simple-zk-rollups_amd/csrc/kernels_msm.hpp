@@ -511,23 +511,28 @@ static_assert(SIZE_BINS == 1024, "msm_hist_kernel clears 2 * 1024 words of size_
 // list and the size-class histogram as before.  With 256 tiles at 2^19 buckets the look-back is a few steps; the chain of
 // short launches it replaces cost more in launch gaps than in work (isolated 8 + 4 + 3 + 7 us of kernels, ~60 us of stream time).
 constexpr unsigned long long SCAN_FLAG_SUM = 1ull << 62, SCAN_FLAG_PREFIX = 2ull << 62, SCAN_VALUE_MASK = (1ull << 62) - 1;
-static __global__ __launch_bounds__(SCAN_THREADS) void msm_scan_fused_kernel(uint32_t *chunk_cnt, uint32_t nb, uint32_t nbl, uint32_t J, uint32_t *counts, uint32_t *offsets,
+// 1024 threads with two buckets each (a tile is still SCAN_BLOCK buckets): the column scan is a chain of dependent loads per
+// bucket, so what it needs is threads -- with 256 threads of eight buckets the fused kernel ran slower than the four small
+// launches it replaces (same-box: 152.5 against 155.0 proofs/s at 2^20, profiles/r4_ab_prep_chain.txt)
+constexpr int SCANF_THREADS = 1024, SCANF_PER_THREAD = SCAN_BLOCK / SCANF_THREADS;
+static_assert(SCANF_PER_THREAD == 2, "two buckets per thread");
+static __global__ __launch_bounds__(SCANF_THREADS) void msm_scan_fused_kernel(uint32_t *chunk_cnt, uint32_t nb, uint32_t nbl, uint32_t J, uint32_t *counts, uint32_t *offsets,
                                                                            uint32_t big_thresh, uint32_t *big_list, uint32_t big_cap, SortScratch z) {
   ZKR_PREP_SETPRIO();
   __shared__ uint32_t s_cnt[SCAN_BLOCK];
-  __shared__ uint32_t part[SCAN_THREADS];
+  __shared__ uint32_t part[SCANF_THREADS];
   __shared__ uint32_t s_hist[SIZE_BINS];
   __shared__ uint32_t s_tile;
   __shared__ unsigned long long s_before;
   const uint32_t t = threadIdx.x;
   if (t == 0) s_tile = atomicAdd(&z.big_count[2], 1u);
-  for (uint32_t b = t; b < SIZE_BINS; b += SCAN_THREADS) s_hist[b] = 0;
+  if (t < SIZE_BINS) s_hist[t] = 0;
   __syncthreads();
   const uint32_t tile = s_tile, tile_base = tile * SCAN_BLOCK;
   // column scan: consecutive lanes take consecutive buckets (the chunk rows of a range are contiguous over its buckets)
 #pragma unroll
-  for (int k = 0; k < SCAN_PER_THREAD; k++) {
-    const uint32_t g = tile_base + k * SCAN_THREADS + t;
+  for (int k = 0; k < SCANF_PER_THREAD; k++) {
+    const uint32_t g = tile_base + k * SCANF_THREADS + t;
     uint32_t run = 0;
     if (g < nb) {
       const uint32_t r = g / nbl, b = g % nbl;
@@ -538,23 +543,23 @@ static __global__ __launch_bounds__(SCAN_THREADS) void msm_scan_fused_kernel(uin
         run += v;
       }
     }
-    s_cnt[k * SCAN_THREADS + t] = run;
+    s_cnt[k * SCANF_THREADS + t] = run;
   }
   __syncthreads();
-  const uint32_t base = tile_base + t * SCAN_PER_THREAD;
-  uint32_t c[SCAN_PER_THREAD], s = 0;
+  const uint32_t base = tile_base + t * SCANF_PER_THREAD;
+  uint32_t c[SCANF_PER_THREAD], s = 0;
 #pragma unroll
-  for (int k = 0; k < SCAN_PER_THREAD; k++) { c[k] = s_cnt[t * SCAN_PER_THREAD + k]; s += c[k]; }
+  for (int k = 0; k < SCANF_PER_THREAD; k++) { c[k] = s_cnt[t * SCANF_PER_THREAD + k]; s += c[k]; }
   part[t] = s;
   __syncthreads();
-  for (uint32_t off = 1; off < SCAN_THREADS; off <<= 1) {
+  for (uint32_t off = 1; off < SCANF_THREADS; off <<= 1) {
     uint32_t v = t >= off ? part[t - off] : 0;
     __syncthreads();
     part[t] += v;
     __syncthreads();
   }
   if (t < 64) {  // wavefront 0: publish, look back
-    const unsigned long long total = part[SCAN_THREADS - 1];
+    const unsigned long long total = part[SCANF_THREADS - 1];
     unsigned long long before = 0;
     if (tile > 0) {
       if (t == 0) __hip_atomic_store(&z.scan_state[tile], SCAN_FLAG_SUM | total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -565,7 +570,7 @@ static __global__ __launch_bounds__(SCAN_THREADS) void msm_scan_fused_kernel(uin
         const unsigned long long flag = v >> 62;
         const unsigned long long m_prefix = __ballot(flag == 2), m_empty = __ballot(flag == 0);
         const int first_prefix = m_prefix ? __builtin_ctzll(m_prefix) : 64, first_empty = m_empty ? __builtin_ctzll(m_empty) : 64;
-        if (first_empty < first_prefix) { __builtin_amdgcn_s_sleep(1); continue; }  // a word this step needs is not published yet
+        if (first_empty < first_prefix) { __builtin_amdgcn_s_sleep(8); continue; }  // a word this step needs is not published yet
         unsigned long long mine = (int)t <= first_prefix ? (v & SCAN_VALUE_MASK) : 0ull;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
@@ -586,7 +591,7 @@ static __global__ __launch_bounds__(SCAN_THREADS) void msm_scan_fused_kernel(uin
   __syncthreads();
   uint32_t run = (uint32_t)s_before + part[t] - s;
 #pragma unroll
-  for (int k = 0; k < SCAN_PER_THREAD; k++) {
+  for (int k = 0; k < SCANF_PER_THREAD; k++) {
     if (base + k < nb) {
       offsets[base + k] = run;
       bool big = false;
@@ -601,8 +606,7 @@ static __global__ __launch_bounds__(SCAN_THREADS) void msm_scan_fused_kernel(uin
     }
   }
   __syncthreads();
-  for (uint32_t b = t; b < SIZE_BINS; b += SCAN_THREADS)
-    if (s_hist[b]) atomicAdd(&z.size_hist[b], s_hist[b]);
+  if (t < SIZE_BINS && s_hist[t]) atomicAdd(&z.size_hist[t], s_hist[t]);
 }
 
 // order[] = all bucket ids sorted by occupancy, fullest first (counting sort over SIZE_BINS size classes;
@@ -1007,6 +1011,85 @@ static __global__ __launch_bounds__(MSM_THREADS) void fq_mul_bench_kernel(Fq *io
   Fq r;
   pack29(weak(add(add(la, lb), add(lc, ld))), r.v);
   store_pod(io + i, r);
+}
+
+// Batched-affine addition over Fq2 against the XYZZ mixed addition, on silicon (DESIGN "measured and
+// rejected").  The design measured: thread per bucket, the accumulator stays in registers (no HBM round trip) but in AFFINE
+// form; per round every lane of the 256-lane workgroup has ONE pending addition acc += q and the lanes share one Fq2 inversion:
+// the denominators x_q - x_acc go through an LDS product scan in both directions (prefix and suffix products, Hillis-Steele,
+// 8 steps), lane 0 inverts the total, every lane gets 1 / d_i = (1 / T) E_i S_i and finishes lambda, x3, y3 (1 product, 1 square,
+// 1 product).  AFFINE = false: the same additions as the hot path does them (XYZZ += affine, add_mixed29).  The synthetic walk
+// over the table never meets equal x (distinct multiples of one point), so neither form takes its special-case branches.
+constexpr int AFF_THREADS = 256;
+template <bool AFFINE>
+static __global__ __launch_bounds__(AFF_THREADS) void g2_add_bench_kernel(const G2Affine *table, uint32_t n_table, int iters, G2Affine *out_aff, XYZZ<Fq2> *out_xyzz) {
+  using C = G2C;
+  const uint32_t t = threadIdx.x, g = blockIdx.x * AFF_THREADS + t;
+  if constexpr (!AFFINE) {
+    XYZZ29<C> acc = XYZZ29<C>::inf();
+    acc = add_mixed29<C>(acc, unpack_affine(load_pod(table + g % n_table)), false);
+    for (int it = 0; it < iters; it++) {
+      const G2Affine q = load_pod(table + (g * 7u + 13u * (uint32_t)it + 1u) % n_table);
+      acc = add_mixed29<C>(acc, unpack_affine(q), false);
+    }
+    store_pod(out_xyzz + g, xyzz_to_256(pack_xyzz<Fq2>(acc)));
+  } else {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];  // prefix [18][256] | suffix [18][256] | 1 / total [18]
+    uint32_t *lp = lds, *ls = lds + 18 * AFF_THREADS, *li = lds + 36 * AFF_THREADS;
+    auto put = [&](uint32_t *base, uint32_t e, const Q29<4> &v) {
+#pragma unroll
+      for (int k = 0; k < 9; k++) { base[k * AFF_THREADS + e] = v.a.v[k]; base[(9 + k) * AFF_THREADS + e] = v.b.v[k]; }
+    };
+    auto get = [&](const uint32_t *base, uint32_t e) {
+      Q29<4> v;
+#pragma unroll
+      for (int k = 0; k < 9; k++) { v.a.v[k] = base[k * AFF_THREADS + e]; v.b.v[k] = base[(9 + k) * AFF_THREADS + e]; }
+      return v;
+    };
+    const Q29<4> one = C::one().template to<4>();
+    const Affine29<C> p0 = unpack_affine(load_pod(table + g % n_table));
+    Q29<5> ax = p0.x.template to<5>(), ay = p0.y.template to<5>();
+    for (int it = 0; it < iters; it++) {
+      const Affine29<C> q = unpack_affine(load_pod(table + (g * 7u + 13u * (uint32_t)it + 1u) % n_table));
+      const auto d = sub(q.x, ax);    // x_q - x_acc, never 0 here
+      const auto num = sub(q.y, ay);
+      Q29<4> pre = mul(d, one).template to<4>(), suf = pre;  // reduced once: the scan multiplies it up to 8 times
+      put(lp, t, pre);
+      put(ls, t, suf);
+      __syncthreads();
+      for (uint32_t off = 1; off < AFF_THREADS; off <<= 1) {
+        const Q29<4> a = t >= off ? get(lp, t - off) : one, b = t + off < AFF_THREADS ? get(ls, t + off) : one;
+        __syncthreads();
+        pre = mul(pre, a).template to<4>();
+        suf = mul(suf, b).template to<4>();
+        put(lp, t, pre);
+        put(ls, t, suf);
+        __syncthreads();
+      }
+      if (t == 0) {  // the one inversion of the round: lane 0's suffix product is the product of all 256 denominators
+        const Q29<4> total = get(ls, 0);
+        const Q29<4> inv = inv29(total);
+#pragma unroll
+        for (int k = 0; k < 9; k++) { li[k] = inv.a.v[k]; li[9 + k] = inv.b.v[k]; }
+      }
+      __syncthreads();
+      Q29<4> inv_t;
+#pragma unroll
+      for (int k = 0; k < 9; k++) { inv_t.a.v[k] = li[k]; inv_t.b.v[k] = li[9 + k]; }
+      const Q29<4> e = t > 0 ? get(lp, t - 1) : one, sx = t + 1 < AFF_THREADS ? get(ls, t + 1) : one;
+      const auto inv_d = mul(mul(inv_t, e), sx);
+      const auto lam = mul(num, inv_d);
+      const auto x3 = barrett(sub(sub(sqr(lam), ax), q.x));
+      const auto y3 = barrett(sub(mul(lam, sub(ax, x3)), ay));
+      ax = x3;
+      ay = y3;
+      __syncthreads();  // the scan arrays are rewritten by the next round
+    }
+    G2Affine o{C::template pack<2>(canonical_small(ax)), C::template pack<2>(canonical_small(ay))};
+    o.x = radix_to_256(o.x);
+    o.y = radix_to_256(o.y);
+    store_pod(out_aff + g, o);
+  }
 }
 
 // Limb-level self test of the product forms of field29.hpp as the DEVICE runs them (one asm statement each,

@@ -305,11 +305,14 @@ static int msm_sort_enqueue(Prof pf, hipStream_t s, const uint32_t *rank, const 
   // scan + exclusive scan + oversized-bucket list + size classes), ordering, scatter.  ZKR_SORT_LEGACY=1: the nine of round 3
   // (two memsets, histogram, column scan, three-launch scan, ordering, scatter) for same-box comparisons.
   static const bool legacy = getenv("ZKR_SORT_LEGACY") != nullptr;
+  static const bool split_scan = getenv("ZKR_SORT_SPLIT_SCAN") != nullptr;  // the separate scan launches, counters still cleared by the histogram kernel (seven launches)
   const SortScratch scratch{ws.big_count, ws.size_hist, (unsigned long long *)ws.block_sums, scan_blocks};
-  if (legacy) {
-    ZKR_HIP_CHECK(hipMemsetAsync(ws.big_count, 0, 12, s));
-    ZKR_HIP_CHECK(hipMemsetAsync(ws.size_hist, 0, 2 * SIZE_BINS * 4, s));
-    msm_hist_kernel<<<sort_grid, SORT_THREADS, lds, s>>>(dl.ent_s, dl.ent_b, rng_off, rank, n_scalars, pl.nbl, pl.J, ws.chunk_cnt, SortScratch{nullptr, nullptr, nullptr, 0});
+  if (legacy || split_scan) {
+    if (legacy) {
+      ZKR_HIP_CHECK(hipMemsetAsync(ws.big_count, 0, 12, s));
+      ZKR_HIP_CHECK(hipMemsetAsync(ws.size_hist, 0, 2 * SIZE_BINS * 4, s));
+    }
+    msm_hist_kernel<<<sort_grid, SORT_THREADS, lds, s>>>(dl.ent_s, dl.ent_b, rng_off, rank, n_scalars, pl.nbl, pl.J, ws.chunk_cnt, legacy ? SortScratch{nullptr, nullptr, nullptr, 0} : SortScratch{ws.big_count, ws.size_hist, (unsigned long long *)ws.block_sums, 0});
     msm_colscan_kernel<<<(nb + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, s>>>(ws.chunk_cnt, nb, pl.nbl, pl.J, ws.counts);
     msm_scan_sums_kernel<<<scan_blocks, SCAN_THREADS, 0, s>>>(ws.counts, nb, ws.block_sums);
     msm_scan_top_kernel<<<1, 1024, 0, s>>>(ws.block_sums, scan_blocks, ws.big_count + 1);
@@ -317,7 +320,7 @@ static int msm_sort_enqueue(Prof pf, hipStream_t s, const uint32_t *rank, const 
                                                               ws.big_list, ws.big_count, BIG_CAP, ws.size_hist);
   } else {
     msm_hist_kernel<<<sort_grid, SORT_THREADS, lds, s>>>(dl.ent_s, dl.ent_b, rng_off, rank, n_scalars, pl.nbl, pl.J, ws.chunk_cnt, scratch);
-    msm_scan_fused_kernel<<<scan_blocks, SCAN_THREADS, 0, s>>>(ws.chunk_cnt, nb, pl.nbl, pl.J, ws.counts, ws.offsets, pl.big_thresh, ws.big_list, BIG_CAP, scratch);
+    msm_scan_fused_kernel<<<scan_blocks, SCANF_THREADS, 0, s>>>(ws.chunk_cnt, nb, pl.nbl, pl.J, ws.counts, ws.offsets, pl.big_thresh, ws.big_list, BIG_CAP, scratch);
   }
   msm_order_kernel<<<scan_blocks, SCAN_THREADS, 0, s>>>(ws.counts, nb, ws.size_hist, ws.size_hist + SIZE_BINS, ws.order);
   static const int xcd_map = getenv("ZKR_SORT_XCD") ? atoi(getenv("ZKR_SORT_XCD")) : 1;
@@ -1273,6 +1276,64 @@ int zkr_selftest_f29_forms(int device, int field, int form, const uint32_t *reco
   hipFree(d_out);
   if (rc) set_error("HIP failure in the product-form self test");
   return rc;
+}
+
+// Batched-affine Fq2 addition (256 lanes share one inversion through an LDS product scan) against the hot path's XYZZ mixed
+// addition: nanoseconds of kernel time per addition per lane for each form, chip-wide launch; *equal = 1 when both forms end in
+// the same points.  The measurement behind the decision recorded in DESIGN.md.
+int zkr_bench_g2_affine(int device, double *ns_per_add_affine, double *ns_per_add_mixed, int *equal) {
+  if (!ns_per_add_affine || !ns_per_add_mixed || !equal) { set_error("null argument"); return ZKR_ERR_ARG; }
+  if (zkr_device_count() <= device || device < 0) { set_error("no HIP device %d", device); return ZKR_ERR_NO_DEVICE; }
+  ZKR_HIP_CHECK(hipSetDevice(device));
+  const uint32_t n_table = 1u << 16;
+  const unsigned blocks = 256 * 4;
+  const int iters = 64;
+  const size_t nthreads = (size_t)blocks * AFF_THREADS;
+  void *d_tab = nullptr;
+  {  // distinct multiples k G2, k = 1 .. 2^16 (fixed-base kernel of the setup)
+    std::vector<uint8_t> sc((size_t)n_table * 32, 0);
+    for (uint32_t i = 0; i < n_table; i++) { const uint32_t k = i + 1; memcpy(&sc[(size_t)i * 32], &k, 4); }
+    int rc = fixed_base_points(device, true, sc.data(), n_table, &d_tab);
+    if (rc) return rc;
+  }
+  DevBuf tab, oa, ox;
+  tab.p = d_tab;
+  int rc;
+  if ((rc = radix_convert(device, true, d_tab, n_table, true))) return rc;  // the table form of the hot path (x 2^261)
+  ScopedEvent e0, e1;
+  if ((rc = oa.alloc(nthreads * sizeof(G2Affine))) || (rc = ox.alloc(nthreads * sizeof(G2XYZZ))) || (rc = e0.create()) || (rc = e1.create())) return rc;
+  const size_t lds = (size_t)(36 * AFF_THREADS + 18) * 4;
+  double ns[2] = {0, 0};
+  for (int form = 0; form < 2; form++) {
+    for (int rep = 0; rep < 3; rep++) {  // first launch warms the clocks; best of the other two
+      ZKR_HIP_CHECK(hipEventRecord(e0.e, nullptr));
+      if (form == 0) g2_add_bench_kernel<true><<<blocks, AFF_THREADS, lds>>>((const G2Affine *)d_tab, n_table, iters, oa.as<G2Affine>(), nullptr);
+      else g2_add_bench_kernel<false><<<blocks, AFF_THREADS>>>((const G2Affine *)d_tab, n_table, iters, nullptr, ox.as<G2XYZZ>());
+      ZKR_HIP_CHECK(hipEventRecord(e1.e, nullptr));
+      ZKR_HIP_CHECK(hipEventSynchronize(e1.e));
+      ZKR_HIP_CHECK(hipGetLastError());
+      float ms = 0;
+      ZKR_HIP_CHECK(hipEventElapsedTime(&ms, e0.e, e1.e));
+      const double v = (double)ms * 1e6 / ((double)iters);  // per round of one addition per lane, all lanes in parallel
+      if (rep == 1 || (rep == 2 && v < ns[form])) ns[form] = v;
+    }
+  }
+  std::vector<G2Affine> ha(nthreads);
+  std::vector<G2XYZZ> hx(nthreads);
+  ZKR_HIP_CHECK(hipMemcpy(ha.data(), oa.p, nthreads * sizeof(G2Affine), hipMemcpyDeviceToHost));
+  ZKR_HIP_CHECK(hipMemcpy(hx.data(), ox.p, nthreads * sizeof(G2XYZZ), hipMemcpyDeviceToHost));
+  int same = 1;
+  for (size_t i = 0; i < nthreads && same; i += 257) {  // a sample across the launch
+    const G2Affine want = to_affine(hx[i]);
+    same = (want.x == ha[i].x && want.y == ha[i].y) ? 1 : 0;
+  }
+  // per addition per lane-slot: the launch keeps `blocks` workgroups of 256 lanes busy; report the time of one round of the whole
+  // launch divided by the additions it makes per SIMD lane in flight is not meaningful across forms -- both forms run the SAME
+  // number of additions on the SAME grid, so the ratio of the two numbers is the ratio of the costs
+  *ns_per_add_affine = ns[0];
+  *ns_per_add_mixed = ns[1];
+  *equal = same;
+  return 0;
 }
 
 int zkr_bench_fq_mul(int device, double *gmuls_per_s) { return bench_fq_mul(device, gmuls_per_s, 0); }
