@@ -663,7 +663,13 @@ def shard_leg(key, d_wit, parts, want_proof, local):
         ms = 1e3 * (time.perf_counter() - t1) / 3
         partials.append(part)
         inf = sh.info()
-        rows.append({"part": sh.shard_info()["part"], "ms": ms, "arena_bytes": sh.arena()[1], "points": sum(inf[t] for t in ("ptsA", "ptsB1", "ptsB2", "ptsC", "ptsH"))})
+        sh.prof_enable(True)                                            # stage sums of one more run (hipEvents around every launch)
+        sh.prof_reset()
+        sh.prove_partial_device(d_wit.data_ptr())
+        stages = {k: round(v[0], 3) for k, v in sh.prof().items() if v[1]}
+        sh.prof_enable(False)
+        rows.append({"part": sh.shard_info()["part"], "ms": ms, "arena_bytes": sh.arena()[1], "points": sum(inf[t] for t in ("ptsA", "ptsB1", "ptsB2", "ptsC", "ptsH")),
+                     "stage_ms": stages})
     t1 = time.perf_counter()
     proof = shards[0].prove_combine(partials, 1000003, 2000003)
     combine_ms = 1e3 * (time.perf_counter() - t1)

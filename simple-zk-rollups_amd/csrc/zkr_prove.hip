@@ -301,11 +301,15 @@ static int msm_sort_enqueue(Prof pf, hipStream_t s, const uint32_t *rank, const 
   const size_t lds = (size_t)pl.nbl * 4;
   const uint32_t *rng_off = dl.rng + 2 * DIGIT_XCDS * MAX_RANGES;
   const unsigned scan_blocks = (nb + SCAN_BLOCK - 1) / SCAN_BLOCK;
-  // Four launches per table: histogram (whose first workgroup clears what the others accumulate into), single-pass scan (column
-  // scan + exclusive scan + oversized-bucket list + size classes), ordering, scatter.  ZKR_SORT_LEGACY=1: the nine of round 3
-  // (two memsets, histogram, column scan, three-launch scan, ordering, scatter) for same-box comparisons.
+  // Seven launches per table: histogram (whose first workgroup clears what the others accumulate into), column scan, three-launch
+  // scan (+ oversized-bucket list + size classes), ordering, scatter.  ZKR_SORT_LEGACY=1: the nine of round 3 (two memsets in
+  // front) for same-box comparisons.
   static const bool legacy = getenv("ZKR_SORT_LEGACY") != nullptr;
-  static const bool split_scan = getenv("ZKR_SORT_SPLIT_SCAN") != nullptr;  // the separate scan launches, counters still cleared by the histogram kernel (seven launches)
+  // Default: the separate scan launches with the counters cleared by the histogram kernel (seven launches).  ZKR_SORT_FUSED_SCAN=1:
+  // column scan + single-pass look-back scan in one launch (four launches per sort) -- measured equal within the run-to-run spread on
+  // every rate and latency (profiles/r4_ab_prep_chain.txt: the proof is bound by its VALU work, not by the launch count of the
+  // preparation chain) with a larger stage sum (a tile's column scan has fewer threads in flight), so the simpler kernels ship.
+  static const bool split_scan = getenv("ZKR_SORT_FUSED_SCAN") == nullptr;
   const SortScratch scratch{ws.big_count, ws.size_hist, (unsigned long long *)ws.block_sums, scan_blocks};
   if (legacy || split_scan) {
     if (legacy) {
@@ -1290,9 +1294,11 @@ int zkr_bench_g2_affine(int device, double *ns_per_add_affine, double *ns_per_ad
   const int iters = 64;
   const size_t nthreads = (size_t)blocks * AFF_THREADS;
   void *d_tab = nullptr;
-  {  // distinct multiples k G2, k = 1 .. 2^16 (fixed-base kernel of the setup)
+  {  // multiples k_i G2 with k_i = (i + 1) 2^20 + 1 (fixed-base kernel of the setup): a sum of j >= 2 of them is j mod 2^20, never
+     // another k_i, so the walk meets neither a doubling nor a cancellation -- the batched form has no branch for them (one zero
+     // denominator would void its whole workgroup's round; a shipping kernel would need the special cases on top of this cost)
     std::vector<uint8_t> sc((size_t)n_table * 32, 0);
-    for (uint32_t i = 0; i < n_table; i++) { const uint32_t k = i + 1; memcpy(&sc[(size_t)i * 32], &k, 4); }
+    for (uint32_t i = 0; i < n_table; i++) { const uint64_t k = ((uint64_t)(i + 1) << 20) + 1; memcpy(&sc[(size_t)i * 32], &k, 8); }
     int rc = fixed_base_points(device, true, sc.data(), n_table, &d_tab);
     if (rc) return rc;
   }

@@ -1,4 +1,5 @@
 """GPU parity of each stage against the CPU oracle, through the C ABI (include/zkr.h)."""
+import os
 import random
 
 import pytest
@@ -9,6 +10,7 @@ from bn254 import Q, R, G1_GEN, G2_GEN, g1_mul, g2_mul, g1_add
 
 pytestmark = pytest.mark.gpu
 MONT = 1 << 256
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _le(v):
@@ -491,3 +493,35 @@ def test_batched_affine_g2_round_matches_the_mixed_addition():
     ns_affine, ns_mixed, equal = zkr_hip.bench_g2_affine()
     assert equal and ns_affine > 0 and ns_mixed > 0
     print("batched-affine round %.0f ns, XYZZ mixed round %.0f ns, ratio %.2f" % (ns_affine, ns_mixed, ns_affine / ns_mixed))
+
+
+_KNOB_SCRIPT = r"""
+import os, sys
+root = sys.argv[1]
+sys.path.insert(0, os.path.join(root, "simple-zk-rollups_amd", "python")); sys.path.insert(0, os.path.join(root, "oracle"))
+import groth16 as g, zkr_hip
+ok = True
+for log_m, count in ((9, 3), (13, 9), (17, 2)):
+    key, wb, aux = zkr_hip.ProvingKey.synth(log_m, 73 if log_m >= 10 else 5, 0x5A4B0001, 0x5A4B00FF)
+    p = 73 if log_m >= 10 else 5
+    rs, ss = [11 + i for i in range(count)], [29 + i for i in range(count)]
+    got = key.prove_batch([wb] * count, rs, ss)
+    for i in range(count):
+        ok = ok and got[i] == g.proof_bytes(g.proof_from_aux(aux, wb, p, rs[i], ss[i])[0])
+    ok = ok and key.prove(wb, 5, 6) == g.proof_bytes(g.proof_from_aux(aux, wb, p, 5, 6)[0])
+print("PARITY", ok)
+"""
+
+
+@pytest.mark.parametrize("env", [{"ZKR_SORT_FUSED_SCAN": "1"}, {"ZKR_SORT_LEGACY": "1"}, {"ZKR_NTT_NO_PAIR": "1"}, {"ZKR_NTT_TILE_LOG": "9"},
+                                 {"ZKR_SORT_FUSED_SCAN": "1", "ZKR_NTT_TILE_LOG": "11"}])
+def test_preparation_chain_variants_give_the_same_proofs(tmp_path, env):
+    """The A/B knobs of the round-4 preparation chain (single-pass look-back scan, round 3's nine-launch sort, unpaired
+    transforms, other NTT tile sizes) are read once per process: each runs in its own process and must reproduce the
+    closed form -- single proofs and fused batches, 2^9 to 2^17."""
+    import subprocess
+    import sys
+    script = tmp_path / "knobs.py"
+    script.write_text(_KNOB_SCRIPT)
+    r = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+    assert r.returncode == 0 and "PARITY True" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
