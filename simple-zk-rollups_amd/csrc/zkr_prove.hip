@@ -576,11 +576,22 @@ static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *const *d_ws
   const bool share_b = h.share_b != 0 && h.npts[T_B1] == h.npts[T_B2];
   const bool share_ac = h.share_ac != 0 && h.npts[T_A] == h.npts[T_C];  // A and C laid out over one support
   int sort_src[N_TABLES] = {T_A, T_B1, share_b ? T_B1 : T_B2, share_ac ? T_A : T_C, T_H};
+  // A shard key's proof is as long as its replicated calcH plus what follows it (digits and sort of h, H's accumulation, the
+  // last chain): the digit records and sorts of w -- an eighth of a whole key's, but in FRONT of calcH on the preparation stream --
+  // go to the auxiliary stream instead and run beside it (ZKR_SHARD_PAR_SORTS=0: one preparation stream, as for whole keys).
+  static const bool par_sorts_env = !(getenv("ZKR_SHARD_PAR_SORTS") && atoi(getenv("ZKR_SHARD_PAR_SORTS")) == 0);
+  const bool par_sorts = par_sorts_env && h.shard_parts > 1 && !serial;
+  hipStream_t sw = par_sorts ? k->aux_stream : sp;  // where w's digit records and the sorts of A, B1, B2, C are made
+  if (par_sorts) {
+    ZKR_HIP_CHECK(hipEventRecord(sl.ev_w, sp));  // the ingested witness (and the cleared counters of its digit records)
+    ZKR_HIP_CHECK(hipStreamWaitEvent(sw, sl.ev_w, 0));
+  }
   auto sort_table = [&](int t) -> int {
     const uint32_t *rank = h.rank_identity[t] ? nullptr : (const uint32_t *)(ar + h.off_rank[t]);
-    int rc = msm_sort_enqueue(pf, sp, rank, *dig[t], rank_entries(h, t), h.npts[t], nbat, k->plan[t], sl.ws[t]);
+    hipStream_t st = t == T_H ? sp : sw;
+    int rc = msm_sort_enqueue(pf, st, rank, *dig[t], rank_entries(h, t), h.npts[t], nbat, k->plan[t], sl.ws[t]);
     if (rc) return rc;
-    if (!serial) ZKR_HIP_CHECK(hipEventRecord(sl.ev_sorted[t], sp));
+    if (!serial) ZKR_HIP_CHECK(hipEventRecord(sl.ev_sorted[t], st));
     return 0;
   };
   // C and H are only ever needed as C + H (App. B step 4: pi_c): when their bucket geometry agrees, H is accumulated ONTO
@@ -678,7 +689,7 @@ static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *const *d_ws
   };
   // preparation chain
   // a shard key (zkr_key_shard) multiplies only its sub-range of each scalar vector; a whole key: sc_lo = 0, sc_n = n / m
-  if ((rc = msm_digits_enqueue(pf, sp, sl.d_w + h.sc_lo[0], h.sc_n[0], nbat, k->plan[T_A], sl.dig_w, true))) return rc;
+  if ((rc = msm_digits_enqueue(pf, sw, sl.d_w + h.sc_lo[0], h.sc_n[0], nbat, k->plan[T_A], sl.dig_w, true))) return rc;
   if ((rc = sort_table(T_B1))) return rc;
   if (!share_b && (rc = sort_table(T_B2))) return rc;
   if (early && (rc = chains({T_B2, T_B1}))) return rc;
