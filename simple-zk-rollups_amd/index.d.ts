@@ -6,7 +6,8 @@ export interface Groth16Proof {
   pi_c: [string, string, string];
   protocol?: "groth";
 }
-export interface ProveOptions { r?: bigint | string; s?: bigint | string; device?: number; }
+/** devices (groth16GenProof): ONE proof over these GPUs -- the key is cut into devices.length shards (cached), the proof is the same bytes. */
+export interface ProveOptions { r?: bigint | string; s?: bigint | string; device?: number; devices?: number[]; }
 /** devices: HIP ordinals of the GPUs a batch is sharded over (a device may be listed twice: two proof pipelines on it). */
 export interface BatchOptions { devices?: number[]; blinding?: ProveOptions[]; }
 export interface Bn128 {

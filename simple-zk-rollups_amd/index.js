@@ -82,6 +82,11 @@ function keyFingerprint(buf, full) {
 const KEY_CACHE_SLOTS = 2;
 const keyCache = new Map();  // fingerprint -> Map("device#ordinal" -> native key handle), in recency order
 const keyCacheStats = { loads: 0, hits: 0, replications: 0 };
+// a whole-key replica of the entry (any device), or undefined: the source of device-to-device copies and of shards
+function anyReplica(ent) {
+  for (const [slot, key] of ent) if (!slot.startsWith("shards:")) return key;
+  return undefined;
+}
 function cacheEntry(provingKeyBin) {
   const fp = keyFingerprint(provingKeyBin);
   let ent = keyCache.get(fp);
@@ -97,7 +102,7 @@ function cachedKey(provingKeyBin, device) {
   if (key !== undefined) keyCacheStats.hits++;
   else {
     // another device already holds this key: copy it device to device instead of parsing the buffer again
-    const src = ent.size ? ent.values().next().value : undefined;
+    const src = anyReplica(ent);
     if (src !== undefined) { key = native().keyReplicate(src, device, 0); keyCacheStats.replications++; }
     else { key = native().keyLoad(provingKeyBin, device); keyCacheStats.loads++; }
     ent.set(slot, key);
@@ -115,7 +120,7 @@ function cachedReplicas(provingKeyBin, devices) {
     let key = ent.get(slot);
     if (key !== undefined) keyCacheStats.hits++;
     else {
-      const src = ent.size ? ent.values().next().value : undefined;
+      const src = anyReplica(ent);
       if (src !== undefined) { key = native().keyReplicate(src, d, 0); keyCacheStats.replications++; }
       else { key = native().keyLoad(provingKeyBin, d); keyCacheStats.loads++; }
       ent.set(slot, key);
@@ -123,6 +128,19 @@ function cachedReplicas(provingKeyBin, devices) {
     keys.push(key);
   }
   return keys;
+}
+// the shards of a key over `devices` (one shard per entry, shard i = part i of devices.length on devices[i]): built once from the
+// cached whole key (zkr_key_shard: window levels copied device to device) and kept with it in the cache entry
+function cachedShards(provingKeyBin, devices) {
+  const ent = cacheEntry(provingKeyBin), slot = "shards:" + devices.join(",");
+  let shards = ent.get(slot);
+  if (shards !== undefined) { keyCacheStats.hits++; return shards; }
+  let whole = anyReplica(ent);
+  if (whole === undefined) { whole = native().keyLoad(provingKeyBin, devices[0]); keyCacheStats.loads++; ent.set(devices[0] + "#0", whole); }
+  shards = devices.map((d, i) => native().keyShard(whole, i, devices.length, d));
+  keyCacheStats.shardings = (keyCacheStats.shardings || 0) + 1;
+  ent.set(slot, shards);
+  return shards;
 }
 function clearKeyCache() { keyCache.clear(); }
 
@@ -145,12 +163,22 @@ class Bn128 {
   // websnark signature.  The reference re-encodes and re-parses the key on every call (common.ts:28-29), on a fresh
   // object (common.ts:23); here the parsed, uploaded key is looked up in the process-level cache above, so only the
   // first proof of a key in a process pays for it.  opts.r / opts.s (BigInt|string) fix the blinding.
+  // opts.devices: ONE proof over several GPUs (BASELINE configs[2] / [4] are single proofs; SURVEY 8(e) row 2) -- every MSM of the
+  // proof is cut into devices.length contiguous ranges, shard i lives on devices[i] with 1/length of the key's tables, each shard
+  // computes its partial sums (one host thread per shard inside zkr_prove_sharded), the host adds 640 bytes per shard and
+  // assembles: the same proof as on one device.  The shards are built once per (key, devices) and cached with the key.
   async groth16GenProof(witnessBin, provingKeyBin, opts) {
     const a = native();
-    this._key = cachedKey(provingKeyBin, this.device);
-    this._fp = "websnark";
     const r = opts && opts.r !== undefined ? bigintToLe32(opts.r) : null;
     const s = opts && opts.s !== undefined ? bigintToLe32(opts.s) : null;
+    if (opts && opts.devices && opts.devices.length > 1) {
+      const devices = opts.devices.map(Number);
+      if (devices.some((d) => !Number.isInteger(d) || d < 0 || d >= deviceCount)) throw new Error("groth16GenProof: opts.devices names a GPU this node does not have (" + deviceCount + " visible)");
+      const shards = cachedShards(provingKeyBin, devices);
+      return proofFromBytes(await a.proveSharded(shards.slice(), witnessBin, r, s));
+    }
+    this._key = cachedKey(provingKeyBin, opts && opts.devices && opts.devices.length === 1 ? Number(opts.devices[0]) : this.device);
+    this._fp = "websnark";
     const pb = await a.prove(this._key, witnessBin, r, s);
     return proofFromBytes(pb);
   }
@@ -460,7 +488,7 @@ class WithdrawCircuit {
 module.exports = {
   buildBn128, genProof, binarifyWitness, binarifyProvingKey, solidityProof, proofFromBytes, isValid, isValidBatch, binarifyVerifyingKey,
   binarifyR1cs, verifyingKeyFromBytes, solidityVerifyingKey, solidityVerifyingKeySource,
-  keyCacheStats: () => Object.assign({ entries: keyCache.size, handles: Array.from(keyCache.values()).reduce((a, e) => a + e.size, 0) }, keyCacheStats), clearKeyCache, keyFingerprint,
+  keyCacheStats: () => Object.assign({ entries: keyCache.size, handles: Array.from(keyCache.values()).reduce((a, e) => a + Array.from(e.values()).reduce((b, v) => b + (Array.isArray(v) ? v.length : 1), 0), 0) }, keyCacheStats), clearKeyCache, keyFingerprint,
   multiHash, multiHashBatch, buildBalanceTree, hashLeftRight, genPublicKey, formatPrivKeyForBabyJub, sign, verify, RollupCircuit, WithdrawCircuit,
   deviceCount: () => { native(); return deviceCount; },
   version: () => native().version(),

@@ -25,6 +25,8 @@ static struct {
   int (*prove_batch)(zkr_key *, const void *const *, size_t, size_t, const uint8_t *, const uint8_t *, uint8_t *);
   int (*prove_batch_multi)(zkr_key *const *, size_t, const void *const *, size_t, size_t, const uint8_t *, const uint8_t *, uint8_t *);
   int (*key_replicate)(const zkr_key *, int, int, zkr_key **);
+  int (*key_shard)(const zkr_key *, unsigned, unsigned, int, zkr_key **);
+  int (*prove_sharded)(zkr_key *const *, size_t, const void *, size_t, const uint8_t *, const uint8_t *, uint8_t *);
   int (*key_device)(const zkr_key *);
   int (*verify)(const void *, size_t, const uint8_t *, const void *, size_t, int *);
   int (*verify_batch)(const void *, size_t, const uint8_t *, const void *, size_t, size_t, int *);
@@ -79,7 +81,7 @@ static napi_value js_load(napi_env env, napi_callback_info info) {
   *(void **)(&Z.field) = dlsym(h, name);                                        \
   if (!Z.field) return throw_msg(env, "libzkr_hip.so lacks symbol " name);
     SYM(last_error, "zkr_last_error") SYM(version, "zkr_version") SYM(device_count, "zkr_device_count")
-    SYM(key_load_websnark, "zkr_key_load_websnark") SYM(key_free, "zkr_key_free") SYM(key_info, "zkr_key_info") SYM(prove, "zkr_prove") SYM(prove_batch, "zkr_prove_batch") SYM(prove_batch_multi, "zkr_prove_batch_multi") SYM(key_replicate, "zkr_key_replicate") SYM(key_device, "zkr_key_device") SYM(verify, "zkr_verify") SYM(verify_batch, "zkr_verify_batch")
+    SYM(key_load_websnark, "zkr_key_load_websnark") SYM(key_free, "zkr_key_free") SYM(key_info, "zkr_key_info") SYM(prove, "zkr_prove") SYM(prove_batch, "zkr_prove_batch") SYM(prove_batch_multi, "zkr_prove_batch_multi") SYM(key_replicate, "zkr_key_replicate") SYM(key_shard, "zkr_key_shard") SYM(prove_sharded, "zkr_prove_sharded") SYM(key_device, "zkr_key_device") SYM(verify, "zkr_verify") SYM(verify_batch, "zkr_verify_batch")
     SYM(setup_r1cs, "zkr_setup_r1cs") SYM(key_save, "zkr_key_save") SYM(key_load_file, "zkr_key_load_file") SYM(free_, "zkr_free")
     SYM(multihash, "zkr_mimcsponge_multihash") SYM(pubkey, "zkr_babyjub_pubkey") SYM(eddsa_sign, "zkr_eddsa_sign") SYM(eddsa_verify, "zkr_eddsa_verify")
     SYM(multihash_batch, "zkr_mimcsponge_multihash_batch") SYM(tree_build, "zkr_balance_tree_build")
@@ -151,6 +153,24 @@ static napi_value js_key_replicate(napi_env env, napi_callback_info info) {
     return throw_msg(env, "keyReplicate(key, device, mode)");
   if (argc > 2) napi_get_value_int32(env, argv[2], &mode);
   if (Z.key_replicate(src, dev, mode, &key)) return throw_msg(env, Z.last_error());
+  napi_value ext;
+  NAPI_OK(napi_create_external(env, key, key_finalize, NULL, &ext));
+  return ext;
+}
+/* keyShard(key, part, parts, device) -> external handle of shard `part` of `parts` of the whole key on `device` (zkr_key_shard: one
+ * contiguous range of every MSM of a proof, all window levels copied device to device, plus the whole QAP).  Synchronous. */
+static napi_value js_key_shard(napi_env env, napi_callback_info info) {
+  size_t argc = 4;
+  napi_value argv[4];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  if (!Z.handle) return throw_msg(env, "libzkr_hip.so not loaded");
+  zkr_key *src = NULL, *key = NULL;
+  uint32_t part = 0, parts = 0;
+  int32_t dev = 0;
+  if (argc < 4 || napi_get_value_external(env, argv[0], (void **)&src) != napi_ok || napi_get_value_uint32(env, argv[1], &part) != napi_ok ||
+      napi_get_value_uint32(env, argv[2], &parts) != napi_ok || napi_get_value_int32(env, argv[3], &dev) != napi_ok)
+    return throw_msg(env, "keyShard(key, part, parts, device)");
+  if (Z.key_shard(src, part, parts, dev, &key)) return throw_msg(env, Z.last_error());
   napi_value ext;
   NAPI_OK(napi_create_external(env, key, key_finalize, NULL, &ext));
   return ext;
@@ -252,6 +272,8 @@ typedef struct {
   napi_deferred deferred;
   napi_ref key_ref, wit_ref;
   zkr_key *key;
+  zkr_key **shards;   /* proveSharded: the shards of one key, part i at position i (zkr_prove_sharded); NULL for prove */
+  size_t n_shards;
   const uint8_t *wit;
   size_t wit_len;
   int have_rs;
@@ -263,7 +285,8 @@ typedef struct {
 static void prove_execute(napi_env env, void *data) {  /* libuv worker thread: the event loop is not blocked */
   (void)env;
   prove_job *j = (prove_job *)data;
-  j->rc = Z.prove(j->key, j->wit, j->wit_len, j->have_rs ? j->r : NULL, j->have_rs ? j->s : NULL, j->proof, NULL);
+  j->rc = j->shards ? Z.prove_sharded(j->shards, j->n_shards, j->wit, j->wit_len, j->have_rs ? j->r : NULL, j->have_rs ? j->s : NULL, j->proof)
+                    : Z.prove(j->key, j->wit, j->wit_len, j->have_rs ? j->r : NULL, j->have_rs ? j->s : NULL, j->proof, NULL);
   if (j->rc) { strncpy(j->err, Z.last_error(), sizeof(j->err) - 1); j->err[sizeof(j->err) - 1] = 0; }
 }
 
@@ -283,23 +306,37 @@ static void prove_complete(napi_env env, napi_status status, void *data) {
   napi_delete_reference(env, j->key_ref);
   napi_delete_reference(env, j->wit_ref);
   napi_delete_async_work(env, j->work);
+  free(j->shards);
   free(j);
 }
 
 /* prove(key, witnessBin, r32|null, s32|null) -> Promise<Buffer(256)>; the witness buffer is pinned by a
- * reference until the promise settles (the reference's caller may reuse it only afterwards). */
-static napi_value js_prove(napi_env env, napi_callback_info info) {
+ * reference until the promise settles (the reference's caller may reuse it only afterwards).
+ * proveSharded([shard0, shard1, ...], witnessBin, r32|null, s32|null): ONE proof over the shards of a key (zkr_prove_sharded: one
+ * host thread per shard, 640 bytes of partial sums each, assembled on the host); the array of handles is referenced until the
+ * promise settles. */
+static napi_value prove_common(napi_env env, napi_callback_info info, int sharded) {
   size_t argc = 4;
   napi_value argv[4];
   NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
   if (!Z.handle) return throw_msg(env, "libzkr_hip.so not loaded");
+  if (argc < 2) return throw_msg(env, "prove(key, witnessBin, r, s) / proveSharded(shards, witnessBin, r, s)");
   prove_job *j = (prove_job *)calloc(1, sizeof(prove_job));
-  NAPI_OK(napi_get_value_external(env, argv[0], (void **)&j->key));
-  if (!get_bytes(env, argv[1], &j->wit, &j->wit_len)) { free(j); return throw_msg(env, "witnessBin must be an ArrayBuffer / Buffer / TypedArray"); }
+  if (!j) return throw_msg(env, "prove: out of memory");
+  if (sharded) {
+    uint32_t ns = 0;
+    if (napi_get_array_length(env, argv[0], &ns) != napi_ok || ns == 0 || !(j->shards = (zkr_key **)calloc(ns, sizeof(zkr_key *)))) { free(j); return throw_msg(env, "proveSharded: a non-empty array of shard handles expected"); }
+    j->n_shards = ns;
+    for (uint32_t i = 0; i < ns; i++) {
+      napi_value kv;
+      if (napi_get_element(env, argv[0], i, &kv) != napi_ok || napi_get_value_external(env, kv, (void **)&j->shards[i]) != napi_ok) { free(j->shards); free(j); return throw_msg(env, "proveSharded: every entry must be a key handle"); }
+    }
+  } else if (napi_get_value_external(env, argv[0], (void **)&j->key) != napi_ok) { free(j); return throw_msg(env, "prove: a key handle expected"); }
+  if (!get_bytes(env, argv[1], &j->wit, &j->wit_len)) { free(j->shards); free(j); return throw_msg(env, "witnessBin must be an ArrayBuffer / Buffer / TypedArray"); }
   const uint8_t *p; size_t n;
   if (argc >= 4 && get_bytes(env, argv[2], &p, &n) && n == 32) {
     memcpy(j->r, p, 32);
-    if (!get_bytes(env, argv[3], &p, &n) || n != 32) { free(j); return throw_msg(env, "r and s must both be 32-byte buffers"); }
+    if (!get_bytes(env, argv[3], &p, &n) || n != 32) { free(j->shards); free(j); return throw_msg(env, "r and s must both be 32-byte buffers"); }
     memcpy(j->s, p, 32);
     j->have_rs = 1;
   }
@@ -312,6 +349,8 @@ static napi_value js_prove(napi_env env, napi_callback_info info) {
   NAPI_OK(napi_queue_async_work(env, j->work));
   return promise;
 }
+static napi_value js_prove(napi_env env, napi_callback_info info) { return prove_common(env, info, 0); }
+static napi_value js_prove_sharded(napi_env env, napi_callback_info info) { return prove_common(env, info, 1); }
 
 /* proveBatch(key, [witnessBin...], rs|null, ss|null) -> Promise<Buffer(256 * count)>: zkr_prove_batch on a libuv worker --
  * uploads and proofs pipelined over the key's two workspaces, proofs of small circuits (the reference's tx circuit) fused
@@ -643,6 +682,7 @@ static napi_value init(napi_env env, napi_value exports) {
       {"prove", NULL, js_prove, NULL, NULL, NULL, napi_default, NULL},     {"verify", NULL, js_verify, NULL, NULL, NULL, napi_default, NULL},
       {"proveBatch", NULL, js_prove_batch, NULL, NULL, NULL, napi_default, NULL},
       {"proveBatchMulti", NULL, js_prove_batch_multi, NULL, NULL, NULL, napi_default, NULL},
+      {"keyShard", NULL, js_key_shard, NULL, NULL, NULL, napi_default, NULL}, {"proveSharded", NULL, js_prove_sharded, NULL, NULL, NULL, napi_default, NULL},
       {"keyReplicate", NULL, js_key_replicate, NULL, NULL, NULL, napi_default, NULL}, {"keyDevice", NULL, js_key_device, NULL, NULL, NULL, napi_default, NULL},
       {"setupR1cs", NULL, js_setup_r1cs, NULL, NULL, NULL, napi_default, NULL}, {"keySave", NULL, js_key_save, NULL, NULL, NULL, napi_default, NULL},
       {"keyLoadFile", NULL, js_key_load_file, NULL, NULL, NULL, napi_default, NULL},

@@ -161,8 +161,9 @@ def _replica(ent, proving_key_bin, device, ordinal):
     if key is not None:
         key_cache_stats["hits"] += 1
         return key
-    if ent:   # another replica holds this content: device-to-device copy instead of a second parse
-        key = next(iter(ent.values())).replicate(device)
+    src = next((k for s, k in ent.items() if s[0] != "shards"), None)
+    if src is not None:   # another replica holds this content: device-to-device copy instead of a second parse
+        key = src.replicate(device)
         key_cache_stats["replications"] += 1
     else:
         key = ProvingKey.load_websnark(proving_key_bin, device)
@@ -189,6 +190,23 @@ def cached_replicas(proving_key_bin, devices):
         return keys
 
 
+def cached_shards(proving_key_bin, devices):
+    """The shards of this key over `devices` (shard i = part i of len(devices) on devices[i]; zkr_key_shard), built once from
+    the cached whole key and kept with it."""
+    with _key_cache_lock:
+        ent = _entry(proving_key_bin)
+        slot = ("shards",) + tuple(devices)
+        shards = ent.get(slot)
+        if shards is not None:
+            key_cache_stats["hits"] += 1
+            return shards
+        whole = next((k for s, k in ent.items() if s[0] != "shards"), None)
+        if whole is None:
+            whole = _replica(ent, proving_key_bin, devices[0], 0)
+        shards = ent[slot] = [whole.shard(i, len(devices), d) for i, d in enumerate(devices)]
+        return shards
+
+
 def clear_key_cache():
     with _key_cache_lock:
         _key_cache.clear()
@@ -200,8 +218,11 @@ class Bn128:
     def __init__(self, device=0):
         self.device = device
 
-    def groth16GenProof(self, witness_bin: bytes, proving_key_bin: bytes, r=None, s=None):
+    def groth16GenProof(self, witness_bin: bytes, proving_key_bin: bytes, r=None, s=None, devices=None):
         # the reference re-encodes and re-parses the key on every call (common.ts:28-29) on a fresh object (:23)
+        if devices is not None and len(devices) > 1:   # ONE proof over several GPUs: cached shards, zkr_prove_sharded
+            from .binding import prove_sharded
+            return proof_json_from_bytes(prove_sharded(cached_shards(proving_key_bin, list(devices)), witness_bin, r, s))
         return proof_json_from_bytes(cached_key(proving_key_bin, self.device).prove(witness_bin, r, s))
 
     def groth16GenProofBatch(self, witness_bins, proving_key_bin, rs=None, ss=None, devices=None):

@@ -112,6 +112,9 @@ def test_facade_batch_over_devices_parses_the_key_once(small_case):
     d = {k: zkr_hip.key_cache_stats[k] - before[k] for k in before}
     assert d == {"loads": 1, "replications": 1, "hits": 2}
     assert zkr_hip.build_bn128().groth16GenProofBatch([c["wb"]] * 3, bytes(c["pkb"]), rs[:3], ss[:3]) == expect[:3]   # single device: the first replica
+    # ONE proof over the devices: shards cut from the cached key, cached themselves
+    for i in range(2):
+        assert zkr_hip.build_bn128().groth16GenProof(c["wb"], bytes(c["pkb"]), rs[i], ss[i], devices=_devices(3)) == expect[i]
     assert zkr_hip.key_cache_stats["loads"] - before["loads"] == 1
     zkr_hip.clear_key_cache()
 

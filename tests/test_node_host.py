@@ -188,13 +188,18 @@ def test_js_batch_over_devices_replicates_the_key_and_shards_the_proofs(tmp_path
         const bn = await z.buildBn128();
         await bn.groth16GenProof(wb, z.binarifyProvingKey(d.pk));
         const held = await bn.proveBatch(wbs, {devices, blinding});
-        console.log(JSON.stringify({multi, again, single, held, stats, refused, distinct: new Set(drawn.map((p) => p.pi_a[0])).size}));
+        // ONE proof over the devices: the key cut into shards (cached), same bytes as on one device
+        const sharded = [];
+        for (let i = 0; i < 3; i++) sharded.push(await (await z.buildBn128()).groth16GenProof(wb, z.binarifyProvingKey(d.pk), Object.assign({devices: [0, 0, 0]}, blinding[i])));
+        const st2 = z.keyCacheStats();
+        console.log(JSON.stringify({multi, again, single, held, sharded, st2, stats, refused, distinct: new Set(drawn.map((p) => p.pi_a[0])).size}));
       })().catch(e => { console.error(e); process.exit(1); });
     """, path).stdout
     res = json.loads(out)
     expect = [g.proof_to_json(g.proof_from_toxic(c["circ"], c["tox"], c["w"], c["r"] + i, c["s"] + 2 * i)) for i in range(11)]
     assert res["multi"] == expect and res["again"] == expect and res["single"] == expect and res["held"] == expect
     assert res["refused"] == 3 and res["distinct"] == 3
+    assert res["sharded"] == expect[:3] and res["st2"]["shardings"] == 1 and res["st2"]["loads"] == 1 and res["st2"]["handles"] == 5
     st = [(x["loads"], x["replications"], x["hits"], x["entries"], x["handles"]) for x in res["stats"]]
     assert st == [(1, 1, 0, 1, 2), (1, 1, 2, 1, 2), (1, 1, 3, 1, 2)]
 
