@@ -576,8 +576,9 @@ def roofline_record(key, info, prof, per_proof_s, device_state, log_m, shape, lo
     # over the launch's own duration (hipEvents around every launch, two proofs in flight: the kernels share the chip
     # with the accumulations; isolated durations are in profiles/)
     m_, n_ = info["domainSize"], info["nVars"]
-    stream_bytes = {"ingest": ("ingest_kernel", 64.0 * n_), "spmv_a": ("spmv_kernel (A side)", 36.0 * info["nnzA"] + 32.0 * n_ + 32.0 * m_),
-                    "ntt_pass": ("ntt_pass_kernel", 64.0 * m_), "combine_h": ("combine_h_kernel", 96.0 * m_)}
+    # round 4: one spmv_kernel launch evaluates BOTH sides of the QAP and one ntt_pass_kernel launch runs a pass of TWO transforms
+    stream_bytes = {"ingest": ("ingest_kernel", 64.0 * n_), "spmv_a": ("spmv_kernel (A and B sides)", 36.0 * (info["nnzA"] + info["nnzB"]) + 64.0 * n_ + 64.0 * m_),
+                    "ntt_pass": ("ntt_pass_kernel (a pass of two transforms)", 128.0 * m_), "combine_h": ("combine_h_kernel", 96.0 * m_)}
     streaming = {}
     for st_name, (kname, nbytes) in stream_bytes.items():
         ms_t, nl = prof.get(st_name, (0.0, 0))

@@ -354,13 +354,18 @@ static int msm_accum_enqueue(Prof pf, hipStream_t s, const Affine<F> *pts, uint3
   const int split = split_env ? atoi(split_env) : nb <= (1u << 15) ? 4 : nb <= (1u << 17) ? 2 : 1;
   if (split > 1) {
     const unsigned sgrid = (unsigned)(((size_t)nb * split + ACC_THREADS - 1) / ACC_THREADS);
-#define ZKR_ACC_SPLIT_LAUNCH(SP) msm_accum_split_kernel<F, MsmCfg<F>::ACC_W, SP><<<sgrid, ACC_THREADS, 0, s>>>(pts, srt.offsets, srt.entries, nb, srt.counts, srt.order, (XYZZ<F> *)ws.buckets, onto)
+    // wavefronts per SIMD the split kernel is built for: at two the Fq2 form (its lane exchange holds two XYZZ points of 72
+    // words) spills 170-200 bytes per lane; ZKR_ACC_SPLIT_W_G2=1 builds it for one (512 VGPRs, no scratch) -- A/B knob
+    static const int split_w_g2 = getenv("ZKR_ACC_SPLIT_W_G2") ? atoi(getenv("ZKR_ACC_SPLIT_W_G2")) : MsmCfg<F>::ACC_W;
+#define ZKR_ACC_SPLIT_LAUNCH_W(W, SP) msm_accum_split_kernel<F, W, SP><<<sgrid, ACC_THREADS, 0, s>>>(pts, srt.offsets, srt.entries, nb, srt.counts, srt.order, (XYZZ<F> *)ws.buckets, onto)
+#define ZKR_ACC_SPLIT_LAUNCH(SP) do { if (sizeof(F) != 32 && split_w_g2 == 1) ZKR_ACC_SPLIT_LAUNCH_W(1, SP); else ZKR_ACC_SPLIT_LAUNCH_W(MsmCfg<F>::ACC_W, SP); } while (0)
     switch (split) {
       case 2: ZKR_ACC_SPLIT_LAUNCH(2); break;
       case 8: ZKR_ACC_SPLIT_LAUNCH(8); break;
       default: ZKR_ACC_SPLIT_LAUNCH(4); break;
     }
 #undef ZKR_ACC_SPLIT_LAUNCH
+#undef ZKR_ACC_SPLIT_LAUNCH_W
     prof_end(pf, s, sp);
     ZKR_HIP_CHECK(hipGetLastError());
     return 0;
