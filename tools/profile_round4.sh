@@ -4,6 +4,7 @@
 #   part b: ONE set for DESIGN.md section 5: kernel stats of the benchmarked command (rocprofv3 --kernel-trace --stats), queue
 #           occupancy, isolated kernel durations (ZKR_SERIAL=1), HBM traffic (FETCH_SIZE / WRITE_SIZE in separate --pmc passes) for
 #           BOTH schedules (isolated and pipelined), SQ_INSTS_VALU / SQ_WAVES per kernel
+#   part c: the counter set BASELINE configs[2] asks for at 2^22 (FETCH_SIZE, WRITE_SIZE, SQ_INSTS_VALU, SQ_WAVES, LDS bank conflicts), isolated kernels
 #   part d: timeline of one synchronous proof of the tx circuit (2^17) -- launches per proof -- and of one 2^20 proof
 # rocprofv3 is always given the program itself after `--` (python3 ...), and --pmc passes carry --kernel-trace only.
 cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:?}" || exit 1
@@ -38,6 +39,17 @@ if [ $PART = b ]; then
     rm -rf $O/$c
   done
   head -14 $O/kernel_stats.md | cut -c1-160; head -12 $O/pmc_traffic.md; head -12 $O/pmc_traffic_pipelined.md
+fi
+if [ $PART = c ]; then
+  for c in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU SQ_WAVES SQ_LDS_BANK_CONFLICT; do
+    ZKR_SERIAL=1 timeout 900 rocprofv3 --kernel-trace --pmc $c -d $O/$c -- python3 bench.py --log-m 22 --steps 2 --warmup 1 --no-pipeline $LIGHT > /dev/null 2>$O/$c.err
+    DB=$(find $O/$c -name "*.db" | head -1)
+    if [ -n "$DB" ]; then python3 profiles/summarize_counter.py $DB $c > $O/c22_$c.md; else tail -3 $O/$c.err; fi
+    rm -rf $O/$c
+  done
+  ZKR_SERIAL=1 rocprofv3 --kernel-trace --stats -d $O/st22 -- python3 bench.py --log-m 22 --steps 3 --warmup 1 --no-pipeline $LIGHT > $O/bench_2_22_serial.json 2>$O/st22.err
+  python3 profiles/summarize_rocpd.py $(find $O/st22 -name "*.db" | head -1) 0 > $O/serial_kernel_stats_2_22.md; rm -rf $O/st22
+  head -12 $O/c22_FETCH_SIZE.md; head -12 $O/c22_SQ_LDS_BANK_CONFLICT.md
 fi
 if [ $PART = d ]; then
   rocprofv3 --kernel-trace -d $O/ttx -- python3 tools/tx_single.py 12 > $O/tx_single.txt 2>$O/ttx.err
