@@ -843,19 +843,19 @@ def main():
     if one_gpu:
         local = 0
     torch.cuda.set_device(local)
-    dist = side = None
+    dist = side = data_group = None
     if world > 1:
         import torch.distributed as dist
         # every collective is bounded: a rank that hangs in the first RCCL exchange is ended by the watchdog after this many
         # seconds and the job exits non-zero (the 4.47 GB arena takes ~30 ms per xGMI link, ~1 s through host memory)
         tmo = datetime.timedelta(seconds=int(os.environ.get("ZKR_BENCH_TIMEOUT_S", "180")))
+        # The DEFAULT group is gloo (host TCP on 127.0.0.1): rendezvous, barriers, the max over ranks and the fallback agreement
+        # do not depend on the GPU transport.  RCCL is a second group that only carries the key bytes; its communicator is made at
+        # its first collective, i.e. inside replicate_key's try: an RCCL that cannot initialise (IPC handles refused, no peer
+        # access) ends in per-rank replicas, not in a dead job.
+        dist.init_process_group("gloo", timeout=tmo)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=tmo)
-            # control plane on gloo (host TCP on 127.0.0.1): barriers, the max over ranks and the fallback agreement do not
-            # depend on the GPU transport, so a failed key broadcast can be survived (zkr_hip.replicate_key)
-            side = dist.new_group(backend="gloo", timeout=tmo)
-        else:
-            dist.init_process_group(backend, timeout=tmo)
+            data_group = dist.new_group(backend="nccl", timeout=tmo)
 
     def barrier():
         if dist:
@@ -874,7 +874,7 @@ def main():
     t_bcast = time.time()
     # fallback ("replicas only"): every rank derives the key from the seeds itself -- in production: from the
     # packed key file / the provingKeyBin over its own PCIe link
-    key, replication = zkr_hip.replicate_key(key, rank, world, local, lambda: synth(False)[0], dist, side)
+    key, replication = zkr_hip.replicate_key(key, rank, world, local, lambda: synth(False)[0], dist, side, data_group=data_group)
     torch.cuda.synchronize()
     bcast_s = time.time() - t_bcast
     info = key.info()

@@ -928,10 +928,19 @@ static int take_slot(zkr_key *key, int &in_flight, int *ticket, Fn enqueue, Coll
 
 using namespace zkr;
 
+// a shard key (zkr_key_shard) holds a range of every table: assembled as a proof, its sums would be a wrong proof without a sign of
+// it -- the proof entry points refuse it; zkr_prove_partial / zkr_prove_sharded are its callers
+static int refuse_shard(const zkr_key *key) {
+  if (key->h.shard_parts <= 1) return 0;
+  set_error("this key is shard %u of %u of a proving key: use zkr_prove_partial / zkr_prove_sharded", key->h.shard_part, key->h.shard_parts);
+  return ZKR_ERR_ARG;
+}
+
 extern "C" {
 
 int zkr_prove_submit(zkr_key *key, const void *d_witness_std, const uint8_t *r32, const uint8_t *s32, void *stream, int *ticket) {
   if (!key || !d_witness_std || !ticket) { set_error("null argument"); return ZKR_ERR_ARG; }
+  if (int rs = refuse_shard(key)) return rs;
   return with_free_slot(key, false, ticket, [&](ProofSlot &sl) { return prove_submit(key, sl, (const Fr *)d_witness_std, r32, s32, (hipStream_t)stream); });
 }
 
@@ -943,6 +952,7 @@ int zkr_prove_collect(zkr_key *key, int ticket, uint8_t proof_out[256]) {
 int zkr_prove_batch(zkr_key *key, const void *const *witnesses_std, size_t witness_len, size_t count, const uint8_t *r32s, const uint8_t *s32s,
                     uint8_t *proofs_out) {
   if (!key || (!witnesses_std && count) || !proofs_out) { set_error("null argument"); return ZKR_ERR_ARG; }
+  if (int rs = refuse_shard(key)) return rs;
   if (witness_len != (size_t)key->h.n * 32) { set_error("witness is %zu bytes, key expects nVars*32 = %zu", witness_len, (size_t)key->h.n * 32); return ZKR_ERR_BAD_WITNESS; }
   for (size_t i = 0; i < count; i++)
     if (!witnesses_std[i]) { set_error("witness %zu is null", i); return ZKR_ERR_ARG; }
@@ -991,6 +1001,7 @@ int zkr_prove_batch(zkr_key *key, const void *const *witnesses_std, size_t witne
 int zkr_prove_batch_device(zkr_key *key, const void *const *d_witnesses_std, size_t count, const uint8_t *r32s, const uint8_t *s32s, void *stream,
                            uint8_t *proofs_out) {
   if (!key || (!d_witnesses_std && count) || !proofs_out) { set_error("null argument"); return ZKR_ERR_ARG; }
+  if (int rs = refuse_shard(key)) return rs;
   for (size_t i = 0; i < count; i++)
     if (!d_witnesses_std[i]) { set_error("witness %zu is null", i); return ZKR_ERR_ARG; }
   size_t groups_left = group_count(key, count);
@@ -1022,6 +1033,7 @@ int zkr_prove_batch_device(zkr_key *key, const void *const *d_witnesses_std, siz
 
 int zkr_prove_device(zkr_key *key, const void *d_witness_std, const uint8_t *r32, const uint8_t *s32, uint8_t proof_out[256], void *stream) {
   if (!key || !d_witness_std || !proof_out) { set_error("null argument"); return ZKR_ERR_ARG; }
+  if (int rs = refuse_shard(key)) return rs;
   int t = -1;
   int rc = with_free_slot(key, true, &t, [&](ProofSlot &sl) { return prove_submit(key, sl, (const Fr *)d_witness_std, r32, s32, (hipStream_t)stream); });
   if (rc) return rc;
@@ -1030,6 +1042,7 @@ int zkr_prove_device(zkr_key *key, const void *d_witness_std, const uint8_t *r32
 
 int zkr_prove(zkr_key *key, const void *witness_std, size_t witness_len, const uint8_t *r32, const uint8_t *s32, uint8_t proof_out[256], void *stream) {
   if (!key || !witness_std || !proof_out) { set_error("null argument"); return ZKR_ERR_ARG; }
+  if (int rs = refuse_shard(key)) return rs;
   if (witness_len != (size_t)key->h.n * 32) { set_error("witness is %zu bytes, key expects nVars*32 = %zu", witness_len, (size_t)key->h.n * 32); return ZKR_ERR_BAD_WITNESS; }
   (void)stream;  // a host buffer is complete when the call is made: nothing on the caller's stream to wait for
   // Upload first (own staging buffer, outside the key's lock: concurrent callers copy in parallel and a third caller

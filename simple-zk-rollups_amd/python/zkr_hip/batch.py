@@ -13,19 +13,19 @@ def shard_indices(count, rank, world):
 ARENA_CHUNK = 1 << 30
 
 
-def broadcast_arena(arena, rank, dist, device, chunk=None):
+def broadcast_arena(arena, rank, dist, device, chunk=None, group=None):
     """Broadcast a uint8 tensor (the key arena) from rank 0; other ranks pass None and get a new tensor
     on `device`.  The length, then the bytes in 1 GiB pieces (arenas reach 78 GB at 2^24: every collective stays far
-    below any 32-bit element count)."""
+    below any 32-bit element count).  group: the process group that carries the bytes (default: the default group)."""
     chunk = chunk or ARENA_CHUNK
     n = torch.zeros(1, dtype=torch.int64, device=device)
     if rank == 0:
         n[0] = arena.numel()
-    dist.broadcast(n, src=0)
+    dist.broadcast(n, src=0, group=group)
     if rank != 0:
         arena = torch.empty(int(n.item()), dtype=torch.uint8, device=device)
     for off in range(0, arena.numel(), chunk):
-        dist.broadcast(arena[off:off + chunk], src=0)
+        dist.broadcast(arena[off:off + chunk], src=0, group=group)
     return arena
 
 
@@ -47,7 +47,7 @@ def _tensor_from_ptr(ptr, nbytes, device):
 BCAST_MODES = ("full", "base")
 
 
-def broadcast_key(key, rank, world, device, dist=None, mode=None, key_cls=None):
+def broadcast_key(key, rank, world, device, dist=None, mode=None, key_cls=None, group=None):
     """rank 0 holds `key`; every other rank receives it over ONE broadcast and returns its own ProvingKey (rank 0: the
     same object).  mode (default: env ZKR_BCAST_MODE or "full"):
       "full"  the whole arena, window tables included (4.47 GB at 2^20): adopted in place (zkr_key_adopt_arena), nothing
@@ -70,9 +70,9 @@ def broadcast_key(key, rank, world, device, dist=None, mode=None, key_cls=None):
     dev = torch.device("cpu") if device is None else torch.device("cuda", device)
     if rank == 0:
         ptr, length = key.arena() if mode == "full" else key.base_arena()
-        broadcast_arena(_tensor_from_ptr(ptr, length, device), 0, dist, dev)
+        broadcast_arena(_tensor_from_ptr(ptr, length, device), 0, dist, dev, group=group)
         return key
-    buf = broadcast_arena(None, rank, dist, dev)
+    buf = broadcast_arena(None, rank, dist, dev, group=group)
     if device is not None:
         torch.cuda.synchronize(dev)
     if mode == "full":
@@ -80,14 +80,16 @@ def broadcast_key(key, rank, world, device, dist=None, mode=None, key_cls=None):
     return key_cls.adopt_base_arena(buf.data_ptr(), buf.numel(), device)
 
 
-def replicate_key(key, rank, world, device, build_local, dist=None, side=None, mode=None, key_cls=None):
+def replicate_key(key, rank, world, device, build_local, dist=None, side=None, mode=None, key_cls=None, data_group=None):
     """broadcast_key with the fallback of SURVEY.md 8(e) row 3 ("replicas only ... if RCCL is unavailable"): when the
     broadcast raises (RCCL cannot set up its transport: IPC handles refused, no peer access, a backend that is not there),
     every rank builds the key itself with build_local() -- the same key from the same source: a packed key file or the
     provingKeyBin uploaded over each GPU's own PCIe link, the seeded generator in bench.py -- and the batch goes on without
-    any collective on the key.  The ranks AGREE on the outcome over `side` (a gloo group: host TCP, independent of the GPU
-    transport): one rank falling back while another adopted the broadcast would still be a correct batch, but the reported
-    replication must be one fact.  A rank that hangs inside the collective is ended by the process group's timeout
+    any collective on the key.  data_group: the group that carries the key bytes (RCCL; default: the default group) -- made
+    lazily, so an RCCL that cannot even initialise fails HERE, inside the try, not at start-up.  The ranks AGREE on the
+    outcome over `side` (a gloo group: host TCP, independent of the GPU transport; default: the default group): one rank
+    falling back while another adopted the broadcast would still be a correct batch, but the reported replication must be
+    one fact.  A rank that hangs inside the collective is ended by the process group's timeout
     (init_process_group(timeout=...)): the job then fails with a non-zero exit instead of waiting for ever.
     ZKR_FORCE_BCAST_FAIL=1 raises in place of the broadcast (tests).  Returns (key, how): how = "single" (world 1), the
     data backend's name ("nccl" = RCCL, "gloo") or "per-rank"."""
@@ -100,13 +102,13 @@ def replicate_key(key, rank, world, device, build_local, dist=None, side=None, m
     try:
         if os.environ.get("ZKR_FORCE_BCAST_FAIL") == "1":
             raise RuntimeError("ZKR_FORCE_BCAST_FAIL=1: the key broadcast is made to fail")
-        got = broadcast_key(key, rank, world, device, dist, mode=mode, key_cls=key_cls)
+        got = broadcast_key(key, rank, world, device, dist, mode=mode, key_cls=key_cls, group=data_group)
     except Exception as e:  # noqa: BLE001 -- whatever the transport raises: the fallback does not depend on it
         ok, err = 0, e
     flag = torch.tensor([ok], dtype=torch.int32)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=side)   # host tensor over the side group (the default group when it is gloo itself)
     if int(flag.item()) == 1:
-        return got, dist.get_backend()
+        return got, dist.get_backend(data_group)
     if err is not None:
         import sys
         sys.stderr.write("zkr_hip: rank %d: key broadcast failed (%s: %s); every rank builds its own replica\n" % (rank, type(err).__name__, err))

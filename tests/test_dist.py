@@ -176,18 +176,21 @@ import torch, torch.distributed as dist
 import zkr_hip
 from zkr_hip.batch import _tensor_from_ptr, broadcast_arena
 torch.cuda.set_device(0)
-dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%s" % sys.argv[2], rank=0, world_size=1, device_id=torch.device("cuda", 0))
+# as bench.py sets its groups up: the default group on gloo (control plane), RCCL as a second group that carries the key bytes
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % sys.argv[2], rank=0, world_size=1)
+data = dist.new_group(backend="nccl")
 key, wb, _ = zkr_hip.ProvingKey.synth(14, 73, 0x5A4B0001, 0x5A4B00FF, want_aux=False)
 want = key.prove(wb, 5, 7)
 out = {}
 for mode in ("full", "base"):
     ptr, n = key.arena() if mode == "full" else key.base_arena()
     view = _tensor_from_ptr(ptr, n, 0)                       # library-owned hipMalloc memory as a torch tensor
-    got = broadcast_arena(view, 0, dist, torch.device("cuda", 0), chunk=1 << 20)    # ncclBroadcast (RCCL) on that memory, in pieces
+    got = broadcast_arena(view, 0, dist, torch.device("cuda", 0), chunk=1 << 20, group=data)    # ncclBroadcast (RCCL) on that memory, in pieces
     torch.cuda.synchronize()
-    assert got.data_ptr() == view.data_ptr()
-    t = torch.zeros(1, dtype=torch.float64, device="cuda"); t[0] = 3.5
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)                 # the timing collective of bench.py
+    assert got.data_ptr() == view.data_ptr() and dist.get_backend(data) == "nccl"
+    t = torch.zeros(1, dtype=torch.float64); t[0] = 3.5
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)                 # the timing collective of bench.py (host tensor, gloo)
+    g = torch.ones(1, device="cuda"); dist.all_reduce(g, group=data); torch.cuda.synchronize()   # and one RCCL reduction on device memory
     replica = got.clone()                                    # what a second rank would hold after the broadcast
     torch.cuda.synchronize()
     k2 = zkr_hip.ProvingKey.adopt_arena(replica.data_ptr(), n, 0, keepalive=replica) if mode == "full" else zkr_hip.ProvingKey.adopt_base_arena(replica.data_ptr(), n, 0)

@@ -66,6 +66,10 @@ def test_shard_errors_and_memory():
     assert max(sh.arena()[1] for sh in shards) < 0.5 * key.arena()[1]
     with pytest.raises(zkr_hip.ZkrError, match="itself a shard"):
         shards[1].shard(0, 2)
+    # a shard's sums assembled as a proof would be a wrong proof without a sign of it: every proof entry point refuses a shard
+    for call in (lambda: shards[0].prove(wb, 1, 2), lambda: shards[0].prove_batch([wb, wb]), lambda: zkr_hip.prove_batch_multi([shards[0], shards[1]], [wb, wb])):
+        with pytest.raises(zkr_hip.ZkrError, match="zkr_prove_partial"):
+            call()
     with pytest.raises(zkr_hip.ZkrError):
         key.shard(4, 4)
     with pytest.raises(zkr_hip.ZkrError):
