@@ -105,6 +105,7 @@ struct ProfSpan {
   hipEvent_t e0, e1;
 };
 
+constexpr int LAT_GLOG = 3;  // reduction groups of a chain nothing can hide (a synchronous proof's last one): 2^3 buckets, see msm_reduce_enqueue
 struct MsmPlan {
   int c, K, glog;
   uint32_t nbw, nb, big_thresh;  // nb = nbw = 2^(c-1) buckets, one set shared by the K windows

@@ -140,8 +140,11 @@ static int alloc_msm_ws(MsmWorkspace &ws, size_t n, const MsmPlan &pl, size_t xy
   ZKR_HIP_CHECK(hipMalloc(&ws.block_sums, (nb / SCAN_BLOCK + 2) * 8));  // one 64-bit look-back word per scan tile (msm_scan_fused_kernel)
   ZKR_HIP_CHECK(hipMalloc(&ws.big_partials, (size_t)BIG_CAP * BIG_SPLIT * xyzz_bytes));
   ZKR_HIP_CHECK(hipMalloc(&ws.buckets, nb * xyzz_bytes));
-  ZKR_HIP_CHECK(hipMalloc(&ws.group_out, (size_t)(pl.nbw >> pl.glog) * cap * 2 * xyzz_bytes));
-  ZKR_HIP_CHECK(hipMalloc(&ws.task_out, (size_t)(pl.c + 2) * pl.S * cap * xyzz_bytes));
+  // sized for the plan's groups AND for the smaller groups of a latency-mode chain (zkr_prove.hip msm_reduce_enqueue: groups of
+  // 2^LAT_GLOG buckets when nothing else is in flight), whose task sums take up to 16 splits
+  const int g_min = pl.glog < LAT_GLOG ? pl.glog : LAT_GLOG;
+  ZKR_HIP_CHECK(hipMalloc(&ws.group_out, (size_t)(pl.nbw >> g_min) * cap * 2 * xyzz_bytes));
+  ZKR_HIP_CHECK(hipMalloc(&ws.task_out, (size_t)(pl.c + 2) * (pl.S > 16 ? pl.S : 16) * cap * xyzz_bytes));
   ZKR_HIP_CHECK(hipMalloc(&ws.result, xyzz_bytes * cap));
   ZKR_HIP_CHECK(hipHostMalloc(&ws.h_result, xyzz_bytes * cap, hipHostMallocDefault));
   ws.max_nb = nb;

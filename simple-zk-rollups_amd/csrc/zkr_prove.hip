@@ -410,7 +410,7 @@ static int msm_big_finish_enqueue(Prof pf, hipStream_t s, uint32_t n, const MsmW
 // bucket reduction -> the MSM result in ws.h_result: short launches of few, long-running wavefronts (raised wave
 // priority), meant to run beside the next table's accumulation
 template <class F>
-static int msm_reduce_enqueue(Prof pf, hipStream_t s, uint32_t n, int nbat, const MsmPlan &pl, const MsmWorkspace &srt, MsmWorkspace &ws) {
+static int msm_reduce_enqueue(Prof pf, hipStream_t s, uint32_t n, int nbat, const MsmPlan &pl, const MsmWorkspace &srt, MsmWorkspace &ws, bool latency = false) {
   if (n == 0) return 0;
   // Group size of a FUSED launch: the plan's groups keep about 2^14 of them per proof, which is what a single proof of a small
   // circuit needs to fill the chip (msm_plan); nbat proofs in one launch bring nbat times the groups, so they take larger ones --
@@ -419,6 +419,19 @@ static int msm_reduce_enqueue(Prof pf, hipStream_t s, uint32_t n, int nbat, cons
   // plan's (smaller) groups.  ZKR_MSM_GLOG_FUSED overrides.
   int glog = pl.glog;
   uint32_t S = pl.S;
+  // Latency mode: the LAST chain of a proof that has nothing in flight beside it (a synchronous caller's proof: the other slot is
+  // idle) is pure latency -- 62 dependent additions per thread in reduce1 at groups of 32 buckets.  Groups of 8 make that 14,
+  // for four times the group results in reduce2 (8 additions + the tree per thread instead of 2): 0.41 + 0.11 -> ~0.10 + 0.15 ms
+  // at 2^19 buckets.  It costs 0.7 % more field multiplications, so chains that run under an accumulation keep the large groups.
+  static const bool lat_env = !(getenv("ZKR_RED_LATENCY") && atoi(getenv("ZKR_RED_LATENCY")) == 0);
+  if (latency && lat_env && nbat == 1 && glog > LAT_GLOG) {
+    glog = LAT_GLOG;
+    const uint32_t ng = pl.nbw >> glog, ntask = (uint32_t)(pl.c - 1 - glog) + 2;
+    S = (ng + 2047) / 2048;
+    if (S > 16) S = 16;
+    if (S > MSM_THREADS / ntask) S = MSM_THREADS / ntask;
+    if (S < 1) S = 1;
+  }
   if (nbat > 1) {
     static const int fused_env = getenv("ZKR_MSM_GLOG_FUSED") ? atoi(getenv("ZKR_MSM_GLOG_FUSED")) : 0;
     int lg = 0;
@@ -622,6 +635,10 @@ static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *const *d_ws
   const bool early = (sched & 1) != 0 && !serial, acc_on_chain = (sched & 2) != 0 && !serial;
   static const int c_big_env = getenv("ZKR_C_BIG_FIRST") ? atoi(getenv("ZKR_C_BIG_FIRST")) : -1;  // 0 / 1: never / always (A/B)
   const bool c_big_first = merge_ch && !serial && (c_big_env >= 0 ? c_big_env != 0 : (nbat == 1 && sl.cap > 1));
+  // nothing else of this key in flight (the caller holds the key's lock: with_free_slot): this proof's last chain is latency
+  bool alone = !serial;
+  for (const ProofSlot &o : k->slot)
+    if (&o != &sl && o.busy) alone = false;
   auto accum_table = [&](int t, hipStream_t rs) -> int {
     const MsmWorkspace &srt = sl.ws[sort_src[t]];
     MsmWorkspace &dst = t == T_H && merge_ch ? sl.ws[T_C] : sl.ws[t];  // whose bucket set / reduction buffers the table lands in
@@ -662,10 +679,10 @@ static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *const *d_ws
       MsmWorkspace mix = dst;
       mix.big_partials = sl.ws[t].big_partials;
       if ((rc = msm_big_finish_enqueue<Fq>(pf, rs, h.npts[t], srt, mix, true))) return rc;
-      return result_event(t, rs, msm_reduce_enqueue<Fq>(pf, rs, h.npts[t], nbat, k->plan[t], srt, dst));
+      return result_event(t, rs, msm_reduce_enqueue<Fq>(pf, rs, h.npts[t], nbat, k->plan[t], srt, dst, alone));
     }
     if ((rc = msm_big_finish_enqueue<Fq>(pf, rs, h.npts[t], srt, sl.ws[t]))) return rc;
-    return result_event(t, rs, msm_reduce_enqueue<Fq>(pf, rs, h.npts[t], nbat, k->plan[t], srt, sl.ws[t]));
+    return result_event(t, rs, msm_reduce_enqueue<Fq>(pf, rs, h.npts[t], nbat, k->plan[t], srt, sl.ws[t], alone && t == T_H));
   };
   // C shares H's bucket set and has no chain of its own: its oversized-bucket partial sums (needed by H's chain, which adds them
   // to the shared set) normally take C's turn on a G1 chain's stream.  There they wait for the chains in front of them: in a
