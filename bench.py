@@ -6,6 +6,11 @@ one rank per GPU).  A step = one proof (QAP rows -> 6 NTTs -> 5 MSMs -> assembly
 rollup-shaped circuit with 73 public inputs (BASELINE.json configs[1]); witnesses are resident in
 HBM when the timed region starts.  N>1: the key is generated on rank 0 and broadcast over RCCL, each
 rank proves its own K witnesses (weak scaling, no data-path collective).  Prints ONE JSON line.
+
+Other forms (same JSON shape):  --gpus N --inproc [--devices 0,0]   N devices from ONE process through zkr_key_replicate +
+zkr_prove_batch_multi_device (no torch.distributed: the shape of the reference's Node host);  --shards P   adds the
+intra-proof sharding leg (one proof cut into P shards, each timed alone: projected one-shard-per-GPU latency);
+--log-m 22 / 24, --shape dense: the other BASELINE configs;  --no-pipeline: synchronous proofs.
 """
 import argparse
 import json
