@@ -882,6 +882,8 @@ def main():
     key, replication = zkr_hip.replicate_key(key, rank, world, local, lambda: synth(False)[0], dist, side, data_group=data_group)
     torch.cuda.synchronize()
     bcast_s = time.time() - t_bcast
+    from zkr_hip import batch as _zb
+    bcast_timing = dict(_zb.last_timing)
     info = key.info()
     arena_bytes = key.arena()[1]
 
@@ -996,8 +998,11 @@ def main():
             "stage_ms_per_proof": per_proof_ms,
             "per_rank": per_rank,
             "key": {"arena_bytes": arena_bytes, "setup_s": setup_s, "replication": {"nccl": "rccl"}.get(replication, replication),
-                    "bcast_s": bcast_s if world > 1 else None,
+                    "bcast_s": bcast_s if world > 1 else None,   # the whole replication on rank 0: collective + its synchronisation
                     "bcast_GBps": (arena_bytes / bcast_s / 1e9) if world > 1 and bcast_s > 0 and replication != "per-rank" else None,
+                    # the collective alone as rank 0 saw it (receivers add the adoption of the bytes: workspace allocation, ~20 ms)
+                    "bcast_wire_s": bcast_timing.get("wire_s") if world > 1 and replication != "per-rank" else None,
+                    "bcast_wire_GBps": (bcast_timing["bytes"] / bcast_timing["wire_s"] / 1e9) if world > 1 and replication != "per-rank" and bcast_timing.get("wire_s") else None,
                     "xgmi_link_GBps": 153.0},  # one RCCL broadcast over xGMI: a ring / chain is bound by one link
             "pcie_inclusive_proofs_per_s": boundary and boundary["host_buffer_sync_proofs_per_s"],
             "pcie_inclusive_concurrent_callers_proofs_per_s": boundary and boundary["host_buffer_concurrent_callers_proofs_per_s"],

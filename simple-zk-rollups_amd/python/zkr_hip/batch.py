@@ -45,6 +45,7 @@ def _tensor_from_ptr(ptr, nbytes, device):
 
 
 BCAST_MODES = ("full", "base")
+last_timing = {}   # of the last broadcast_key call on this rank: {"mode", "bytes", "wire_s" (the collective alone), "adopt_s"}
 
 
 def broadcast_key(key, rank, world, device, dist=None, mode=None, key_cls=None, group=None):
@@ -67,17 +68,26 @@ def broadcast_key(key, rank, world, device, dist=None, mode=None, key_cls=None, 
         raise ValueError("unknown key broadcast mode %r (use one of %r)" % (mode, BCAST_MODES))
     if dist is None:
         import torch.distributed as dist
+    import time
     dev = torch.device("cpu") if device is None else torch.device("cuda", device)
+    t0 = time.perf_counter()
     if rank == 0:
         ptr, length = key.arena() if mode == "full" else key.base_arena()
         broadcast_arena(_tensor_from_ptr(ptr, length, device), 0, dist, dev, group=group)
+        if device is not None:
+            torch.cuda.synchronize(dev)
+        last_timing.update(mode=mode, bytes=length, wire_s=time.perf_counter() - t0, adopt_s=0.0)
         return key
     buf = broadcast_arena(None, rank, dist, dev, group=group)
     if device is not None:
         torch.cuda.synchronize(dev)
+    t1 = time.perf_counter()
     if mode == "full":
-        return key_cls.adopt_arena(buf.data_ptr(), buf.numel(), device, keepalive=buf)
-    return key_cls.adopt_base_arena(buf.data_ptr(), buf.numel(), device)
+        got = key_cls.adopt_arena(buf.data_ptr(), buf.numel(), device, keepalive=buf)
+    else:
+        got = key_cls.adopt_base_arena(buf.data_ptr(), buf.numel(), device)
+    last_timing.update(mode=mode, bytes=buf.numel(), wire_s=t1 - t0, adopt_s=time.perf_counter() - t1)
+    return got
 
 
 def replicate_key(key, rank, world, device, build_local, dist=None, side=None, mode=None, key_cls=None, data_group=None):
