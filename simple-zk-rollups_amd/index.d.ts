@@ -77,7 +77,7 @@ export class WithdrawCircuit {
 
 // ---- process-level key cache (the reference builds a new Bn128 per proof: common.ts:23) and verifier constants
 /** Device keys loaded / found in the cache by groth16GenProof so far in this process. */
-export function keyCacheStats(): { loads: number; hits: number; replications: number; entries: number; handles: number };
+export function keyCacheStats(): { loads: number; hits: number; replications: number; shardings?: number; entries: number; handles: number };
 export function keyFingerprint(provingKeyBin: ArrayBuffer | Uint8Array, full?: boolean): string;
 export function clearKeyCache(): void;
 /** vk_bin -> the constants of the generated verifier's verifyingKey() in the contract's encoding (G2 as [im, re]). */
