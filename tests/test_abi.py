@@ -45,6 +45,26 @@ def test_no_gpu_means_loud_failure_not_fallback():
         zkr_hip.ProvingKey.synth(6, 3)
 
 
+def test_multi_device_and_shard_entry_points_check_their_arguments():
+    """The round-4 entry points (zkr_key_replicate, zkr_prove_batch_multi, zkr_key_shard, zkr_prove_partial, zkr_prove_combine,
+    zkr_prove_sharded) refuse null arguments with ZKR_ERR_ARG and a message instead of dereferencing them -- checked here without
+    a device (the calls return before any HIP work)."""
+    import zkr_hip
+    L = zkr_hip.lib()
+    vp, out, proof = ctypes.c_void_p, ctypes.c_void_p(), ctypes.create_string_buffer(256)
+    assert L.zkr_key_replicate(None, 0, 0, ctypes.byref(out)) == -5
+    assert L.zkr_key_shard(None, 0, 2, 0, ctypes.byref(out)) == -5
+    assert L.zkr_key_device(None) == -1
+    assert L.zkr_prove_batch_multi(None, 0, None, 0, 0, None, None, proof) == -5
+    assert L.zkr_prove_batch_multi_device(None, 0, None, 0, None, None, proof) == -5
+    assert L.zkr_prove_partial(None, b"", 0, proof) == -5 and L.zkr_prove_partial_device(None, None, None, proof) == -5
+    assert L.zkr_prove_combine(None, b"", 0, None, None, proof) == -5
+    assert L.zkr_prove_sharded(None, 0, b"", 0, None, None, proof) == -5 and L.zkr_prove_sharded_device(None, 0, None, None, None, proof) == -5
+    info = (ctypes.c_uint32 * 6)()
+    assert L.zkr_key_shard_info(None, info) == -5
+    assert b"null" in L.zkr_last_error()
+
+
 def test_product_never_imports_oracle():
     """The product path must not route through oracle/: no source under the package mentions it as an import/link."""
     pkg = os.path.join(ROOT, "simple-zk-rollups_amd")

@@ -93,6 +93,49 @@ def test_three_replicas_ragged_counts_and_errors():
     assert zkr_hip.lib().zkr_key_replicate(key._h, 0, 7, ctypes.byref(h)) == -5
 
 
+def test_concurrent_multi_batches_and_sharded_proofs_on_the_same_keys():
+    """Two host threads inside zkr_prove_batch_multi on the SAME replicas at once (two libuv workers behind two
+    groth16GenProofBatch calls), a third proving sharded on shards of the same key: the per-key slot hand-out serialises
+    nothing wrongly and every proof is the closed form's."""
+    import threading
+    import zkr_hip
+    log_m, p = 13, 73
+    key, wb, aux = zkr_hip.ProvingKey.synth(log_m, p, 0x5A4B0001, 0x5A4B00FF)
+    devs = _devices(2)
+    rep = key.replicate(devs[1])
+    shards = [key.shard(i, 2, devs[i]) for i in range(2)]
+    wbs = [wb] + [zkr_hip.synth_witness(log_m, p, 0x5A4B0001, 8800 + i) for i in range(1, 3)]
+    out, errs = {}, []
+
+    def batch(tag, base):
+        try:
+            n = 10
+            ws = [wbs[(base + i) % 3] for i in range(n)]
+            rs, ss = [base + 7 * i + 1 for i in range(n)], [base + 11 * i + 3 for i in range(n)]
+            out[tag] = (ws, rs, ss, zkr_hip.prove_batch_multi([key, rep], ws, rs, ss))
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    def sharded(tag):
+        try:
+            out[tag] = [zkr_hip.prove_sharded(shards, wbs[i % 3], 500 + i, 900 + i) for i in range(6)]
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ths = [threading.Thread(target=batch, args=("a", 100)), threading.Thread(target=batch, args=("b", 2000)), threading.Thread(target=sharded, args=("s",))]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs
+    for tag in ("a", "b"):
+        ws, rs, ss, proofs = out[tag]
+        for w, r, s_, got in zip(ws, rs, ss, proofs):
+            assert got == g.proof_bytes(g.proof_from_aux(aux, w, p, r, s_)[0])
+    for i, got in enumerate(out["s"]):
+        assert got == g.proof_bytes(g.proof_from_aux(aux, wbs[i % 3], p, 500 + i, 900 + i)[0])
+
+
 def test_facade_batch_over_devices_parses_the_key_once(small_case):
     """facade.Bn128.groth16GenProofBatch(devices=[0, 0]) from the websnark buffer, as the reference's caller holds it
     (common.ts:28): one parse + one device-to-device replication, afterwards only cache hits; proofs == oracle."""
