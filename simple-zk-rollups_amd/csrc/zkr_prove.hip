@@ -121,16 +121,14 @@ int ntt_lds_check(int device) {
   return 0;
 }
 
-// Elements per workgroup by transform size.  A transform of 2^17 (the reference's tx circuit) cut into tiles of 2048 is 64
-// workgroups -- a quarter of the CUs, eight wavefronts each -- whatever the pairing of transforms adds; tiles of 1024 spread the
-// same wavefronts over twice the CUs (same passes: 10 + 7 stages instead of 11 + 6).  From 2^19 on a pass fills the chip with
-// the large tile, which moves fewer bytes per stage.  ZKR_NTT_TILE_LOG overrides (8..11).
+// Elements per workgroup: 2048 (NTT_TILE_LOG) for every transform.  Smaller tiles for small transforms -- a 2^17 transform cut into
+// tiles of 2048 is 64 workgroups, a quarter of the CUs -- were measured (ZKR_NTT_TILE_LOG=9 / 10: 512 / 1024 elements) and change
+// nothing: the wavefront count of a transform does not depend on the tile, and the single tx proof takes 2.00 / 2.04 / 1.97-2.02 ms
+// at 9 / 10 / 11 (profiles/r4_19_tx_single_ntt_tile.txt).  The knob stays for experiments (8..11).
 static int ntt_tile_log(int L, int nbat) {
+  (void)L; (void)nbat;
   static const int env = getenv("ZKR_NTT_TILE_LOG") ? atoi(getenv("ZKR_NTT_TILE_LOG")) : 0;
-  if (env >= 8 && env <= NTT_TILE_LOG) return env;
-  int lg = 0;
-  while ((1 << lg) < nbat) lg++;
-  return L + lg <= 18 ? NTT_TILE_LOG - 1 : NTT_TILE_LOG;
+  return env >= 8 && env <= NTT_TILE_LOG ? env : NTT_TILE_LOG;
 }
 
 // One transform, or TWO of the same shape in the same launches (in0_b / in1_b / out_b: gridDim.z = 2)
