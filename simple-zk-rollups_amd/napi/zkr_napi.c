@@ -340,13 +340,18 @@ static napi_value prove_common(napi_env env, napi_callback_info info, int sharde
     memcpy(j->s, p, 32);
     j->have_rs = 1;
   }
+  /* nothing below may leave the job, its references or its work item behind when an N-API call fails (nothing was queued then) */
   napi_value promise, name;
-  NAPI_OK(napi_create_promise(env, &j->deferred, &promise));
-  NAPI_OK(napi_create_reference(env, argv[0], 1, &j->key_ref));
-  NAPI_OK(napi_create_reference(env, argv[1], 1, &j->wit_ref));
-  NAPI_OK(napi_create_string_utf8(env, "zkr_prove", NAPI_AUTO_LENGTH, &name));
-  NAPI_OK(napi_create_async_work(env, NULL, name, prove_execute, prove_complete, j, &j->work));
-  NAPI_OK(napi_queue_async_work(env, j->work));
+  if (napi_create_promise(env, &j->deferred, &promise) != napi_ok || napi_create_reference(env, argv[0], 1, &j->key_ref) != napi_ok ||
+      napi_create_reference(env, argv[1], 1, &j->wit_ref) != napi_ok || napi_create_string_utf8(env, "zkr_prove", NAPI_AUTO_LENGTH, &name) != napi_ok ||
+      napi_create_async_work(env, NULL, name, prove_execute, prove_complete, j, &j->work) != napi_ok || napi_queue_async_work(env, j->work) != napi_ok) {
+    if (j->key_ref) napi_delete_reference(env, j->key_ref);
+    if (j->wit_ref) napi_delete_reference(env, j->wit_ref);
+    if (j->work) napi_delete_async_work(env, j->work);
+    free(j->shards);
+    free(j);
+    return throw_msg(env, "prove: could not queue the proof job");
+  }
   return promise;
 }
 static napi_value js_prove(napi_env env, napi_callback_info info) { return prove_common(env, info, 0); }
