@@ -637,6 +637,14 @@ static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *const *d_ws
   bool alone = !serial;
   for (const ProofSlot &o : k->slot)
     if (&o != &sl && o.busy) alone = false;
+  // Deferred accumulations.  Beside a running calcH an accumulation and the NTT passes slow each other to more than the sum of
+  // their times alone (a shard of a 2^22 key: the G2 accumulation of 0.6 ms of work ran 4.9 ms under passes that took 4.4 instead
+  // of 2.3, and the four G1 accumulations queued behind it: profiles/r4_23_timeline_shard_default.txt).  When nothing else is
+  // there to fill the gaps -- a shard key's proof, or ZKR_DEFER_ACC=1 for any proof with nothing else in flight -- the
+  // accumulation stream waits for calcH and then runs the five tables back to back.  ZKR_DEFER_ACC=0: never.
+  static const int defer_env = getenv("ZKR_DEFER_ACC") ? atoi(getenv("ZKR_DEFER_ACC")) : -1;
+  const bool defer_acc = !serial && !early && defer_env != 0 && nbat == 1 && (h.shard_parts > 1 || (defer_env == 1 && alone));
+  bool acc_waits_calch = defer_acc;  // the first accumulation enqueued carries the wait (the stream is in order)
   auto accum_table = [&](int t, hipStream_t rs) -> int {
     const MsmWorkspace &srt = sl.ws[sort_src[t]];
     MsmWorkspace &dst = t == T_H && merge_ch ? sl.ws[T_C] : sl.ws[t];  // whose bucket set / reduction buffers the table lands in
@@ -647,6 +655,7 @@ static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *const *d_ws
     if (!serial) {
       ZKR_HIP_CHECK(hipStreamWaitEvent(rs, sl.ev_sorted[sort_src[t]], 0));
       if (sa != rs) ZKR_HIP_CHECK(hipStreamWaitEvent(sa, sl.ev_sorted[sort_src[t]], 0));
+      if (acc_waits_calch) { ZKR_HIP_CHECK(hipStreamWaitEvent(sa, sl.ev_calch, 0)); acc_waits_calch = false; }
     }
     // oversized buckets: partial sums into the table's OWN partials buffer (needs only the sort, runs beside the accumulation).
     // C's, when C shares H's bucket set, were enqueued in front of every chain (c_big_first below)
@@ -717,6 +726,7 @@ static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *const *d_ws
   if (!share_ac && (rc = sort_table(T_C))) return rc;
   if (early && ((rc = c_big()) || (rc = chains({T_A, T_C})))) return rc;
   if ((rc = calc_h_device(k, sl, sp, nbat))) return rc;
+  if (!serial) ZKR_HIP_CHECK(hipEventRecord(sl.ev_calch, sp));
   if ((rc = msm_digits_enqueue(pf, sp, sl.d_h + h.sc_lo[1], h.sc_n[1], nbat, k->plan[T_H], sl.dig_h, true))) return rc;
   if ((rc = sort_table(T_H))) return rc;
   // accumulations + reduction chains
