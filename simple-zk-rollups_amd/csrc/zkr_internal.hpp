@@ -221,6 +221,7 @@ int fused_capacity(const ArenaHeader &h, const MsmPlan plan[N_TABLES]);
 void arena_layout(ArenaHeader &h);  // section offsets and total_len from the sizes in the header (n, p, m, nnz, n_wide, npts, win_c, sc_n): THE layout, whoever builds an arena
 void base_layout(const ArenaHeader &full, ArenaHeader &b);  // the same for the compact form (zkr_key_base_arena)
 MsmPlan msm_plan(size_t n_scalars, size_t n_points, int c_fixed = 0);
+uint32_t big_threshold(size_t n_points, int K, uint32_t nbw, int nbat);  // occupancy above which a bucket goes to msm_big_kernel (zkr_key.hip)
 int digit_lists_alloc(DigitLists &dl, size_t n_scalars, const MsmPlan &pl);
 void digit_lists_free(DigitLists &dl);
 int msm_precompute(int device, bool g2, void *d_table, uint32_t n, const MsmPlan &pl);  // fills levels 1..K-1 of a table whose level 0 is in place, then converts the table to the hot path's radix

@@ -45,6 +45,23 @@ static Fr fr_root_of_unity(unsigned k) {
 }
 Fr host_root_of_unity(unsigned k) { return fr_root_of_unity(k); }
 
+// Oversized buckets (summed by msm_big_kernel's workgroups instead of one thread of the accumulation).  A bucket of E entries is
+// E dependent additions on one lane -- 7 us each for G1, 18 us for G2 -- so any bucket longer than the accumulation's bulk
+// time stretches the whole kernel: the bulk is the launch's additions (n K per proof, nbat proofs in a fused launch) at ~100 k
+// additions per chain step chip-wide, i.e. the threshold is n K nbat / 2^17, between twice and eight times the mean occupancy,
+// never below 64.  Round 3's rule (max(8 mean, 256)) left buckets of up to 256 entries to single lanes of SPARSE bucket sets: a
+// shard of a 2^22 key (mean 9) spent 4.9 ms in a G2 accumulation of 0.8 ms of work (profiles/r4_25_shard_big_threshold.txt).
+// ZKR_MSM_BIG_RULE=3: that rule; ZKR_MSM_BIG=<n>: a fixed threshold.
+uint32_t big_threshold(size_t n, int K, uint32_t nbw, int nbat) {
+  if (const char *e = getenv("ZKR_MSM_BIG")) { int v = atoi(e); if (v >= 1) return (uint32_t)v; }
+  const uint64_t mean = (uint64_t)n * K / nbw + 1;
+  if (const char *e = getenv("ZKR_MSM_BIG_RULE"); e && atoi(e) == 3) return mean * 8 > 256 ? (uint32_t)(mean * 8) : 256u;
+  const uint64_t by_bulk = ((uint64_t)n * K * (uint64_t)(nbat < 1 ? 1 : nbat)) >> 17;
+  uint64_t thr = by_bulk < mean * 8 ? by_bulk : mean * 8;
+  if (thr < 2 * mean) thr = 2 * mean;  // dense little bucket sets (tiny circuits): only real outliers leave the accumulation
+  return thr > 64 ? (uint32_t)thr : 64u;
+}
+
 // Window size from the length of the SCALAR vector (tables that share scalars share the digit codes,
 // kernels_msm.hpp msm_digits_kernel) unless the key fixes it (c_fixed: the window tables in the arena were built
 // for that c); chunking and the oversized-bucket threshold from the table itself.
@@ -74,19 +91,7 @@ MsmPlan msm_plan(size_t n_scalars, size_t n, int c_fixed) {
   int glog = c - 1 - 14 < 2 ? 2 : c - 1 - 14 > 5 ? 5 : c - 1 - 14;
   if (const char *e = getenv("ZKR_MSM_GLOG")) { int v = atoi(e); if (v >= 1 && v <= 6) glog = v; }
   pl.glog = c - 1 < glog ? c - 1 : glog;
-  // Oversized buckets (summed by msm_big_kernel's workgroups instead of one thread of the accumulation).  A bucket of E entries is
-  // E dependent additions on one lane -- 7 us each for G1, 18 us for G2 -- so any bucket longer than the accumulation's bulk
-  // time stretches the whole kernel: the bulk is n K additions at ~100 k additions per chain step chip-wide, i.e. the threshold
-  // is n K / 2^17, between twice and eight times the mean occupancy, never below 64.  Round 3's rule (max(8 mean, 256)) left buckets of
-  // up to 256 entries to single lanes of SPARSE bucket sets: a shard of a 2^22 key (mean 9) spent 4.9 ms in a G2 accumulation of
-  // 0.8 ms of work (profiles/r4_25_shard_big_threshold.txt).  ZKR_MSM_BIG_RULE=3: that rule; ZKR_MSM_BIG=<n>: a fixed threshold.
-  uint64_t mean = (uint64_t)n * pl.K / pl.nbw + 1;
-  uint64_t by_bulk = ((uint64_t)n * pl.K) >> 17;
-  uint64_t thr = by_bulk < mean * 8 ? by_bulk : mean * 8;
-  if (thr < 2 * mean) thr = 2 * mean;  // dense little bucket sets (tiny circuits): only real outliers leave the accumulation
-  pl.big_thresh = thr > 64 ? (uint32_t)thr : 64;
-  if (const char *e = getenv("ZKR_MSM_BIG_RULE"); e && atoi(e) == 3) pl.big_thresh = mean * 8 > 256 ? (uint32_t)(mean * 8) : 256;
-  if (const char *e = getenv("ZKR_MSM_BIG")) { int v = atoi(e); if (v >= 1) pl.big_thresh = (uint32_t)v; }
+  pl.big_thresh = big_threshold(n, pl.K, pl.nbw, 1);
   // digit sort: one workgroup per (bucket range, chunk).  Ranges of 2048 buckets, chunks of ~3300 records: what counts is the
   // window of the entry array that the workgroups resident on one XCD scatter into together -- it has to stay in that XCD's
   // 4 MB L2 until its lines are complete (kernels_msm.hpp sort_block_to_chunk).  At 2^20 points: 256 ranges x 16 chunks, a

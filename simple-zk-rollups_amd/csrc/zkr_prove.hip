@@ -309,6 +309,7 @@ static int msm_sort_enqueue(Prof pf, hipStream_t s, const uint32_t *rank, const 
   // preparation chain) with a larger stage sum (a tile's column scan has fewer threads in flight), so the simpler kernels ship.
   static const bool split_scan = getenv("ZKR_SORT_FUSED_SCAN") == nullptr;
   const SortScratch scratch{ws.big_count, ws.size_hist, (unsigned long long *)ws.block_sums, scan_blocks};
+  const uint32_t big_thresh = nbat > 1 ? big_threshold(n, pl.K, pl.nbw, nbat) : pl.big_thresh;  // a fused launch's bulk is nbat proofs long
   if (legacy || split_scan) {
     if (legacy) {
       ZKR_HIP_CHECK(hipMemsetAsync(ws.big_count, 0, 12, s));
@@ -318,11 +319,11 @@ static int msm_sort_enqueue(Prof pf, hipStream_t s, const uint32_t *rank, const 
     msm_colscan_kernel<<<(nb + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, s>>>(ws.chunk_cnt, nb, pl.nbl, pl.J, ws.counts);
     msm_scan_sums_kernel<<<scan_blocks, SCAN_THREADS, 0, s>>>(ws.counts, nb, ws.block_sums);
     msm_scan_top_kernel<<<1, 1024, 0, s>>>(ws.block_sums, scan_blocks, ws.big_count + 1);
-    msm_scan_apply_kernel<<<scan_blocks, SCAN_THREADS, 0, s>>>(ws.counts, ws.block_sums, ws.big_count + 1, ws.offsets, nb, pl.big_thresh,
+    msm_scan_apply_kernel<<<scan_blocks, SCAN_THREADS, 0, s>>>(ws.counts, ws.block_sums, ws.big_count + 1, ws.offsets, nb, big_thresh,
                                                               ws.big_list, ws.big_count, BIG_CAP, ws.size_hist);
   } else {
     msm_hist_kernel<<<sort_grid, SORT_THREADS, lds, s>>>(dl.ent_s, dl.ent_b, rng_off, rank, n_scalars, pl.nbl, pl.J, ws.chunk_cnt, scratch);
-    msm_scan_fused_kernel<<<scan_blocks, SCANF_THREADS, 0, s>>>(ws.chunk_cnt, nb, pl.nbl, pl.J, ws.counts, ws.offsets, pl.big_thresh, ws.big_list, BIG_CAP, scratch);
+    msm_scan_fused_kernel<<<scan_blocks, SCANF_THREADS, 0, s>>>(ws.chunk_cnt, nb, pl.nbl, pl.J, ws.counts, ws.offsets, big_thresh, ws.big_list, BIG_CAP, scratch);
   }
   msm_order_kernel<<<scan_blocks, SCAN_THREADS, 0, s>>>(ws.counts, nb, ws.size_hist, ws.size_hist + SIZE_BINS, ws.order);
   static const int xcd_map = getenv("ZKR_SORT_XCD") ? atoi(getenv("ZKR_SORT_XCD")) : 1;
@@ -637,13 +638,12 @@ static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *const *d_ws
   bool alone = !serial;
   for (const ProofSlot &o : k->slot)
     if (&o != &sl && o.busy) alone = false;
-  // Deferred accumulations.  Beside a running calcH an accumulation and the NTT passes slow each other to more than the sum of
-  // their times alone (a shard of a 2^22 key: the G2 accumulation of 0.6 ms of work ran 4.9 ms under passes that took 4.4 instead
-  // of 2.3, and the four G1 accumulations queued behind it: profiles/r4_23_timeline_shard_default.txt).  When nothing else is
-  // there to fill the gaps -- a shard key's proof, or ZKR_DEFER_ACC=1 for any proof with nothing else in flight -- the
-  // accumulation stream waits for calcH and then runs the five tables back to back.  ZKR_DEFER_ACC=0: never.
-  static const int defer_env = getenv("ZKR_DEFER_ACC") ? atoi(getenv("ZKR_DEFER_ACC")) : -1;
-  const bool defer_acc = !serial && !early && defer_env != 0 && nbat == 1 && (h.shard_parts > 1 || (defer_env == 1 && alone));
+  // Deferred accumulations (ZKR_DEFER_ACC=1, experiment; off): the accumulation stream waits for calcH, then runs the five tables back
+  // to back.  Measured WORSE everywhere -- a 2^22 shard 11.9 against 9.8 ms, a synchronous 2^20 proof 7.55 against 7.35 ms, a tx proof
+  // 2.25 against 2.0 ms (profiles/r4_24_deferred_accumulations.txt): the passes of calcH do not fill the chip on their own, and what
+  // looked like mutual slow-down in the shard's timeline was one G2 accumulation waiting for a few 250-entry buckets (big_threshold).
+  static const int defer_env = getenv("ZKR_DEFER_ACC") ? atoi(getenv("ZKR_DEFER_ACC")) : 0;
+  const bool defer_acc = !serial && !early && defer_env == 1 && nbat == 1 && (h.shard_parts > 1 || alone);
   bool acc_waits_calch = defer_acc;  // the first accumulation enqueued carries the wait (the stream is in order)
   auto accum_table = [&](int t, hipStream_t rs) -> int {
     const MsmWorkspace &srt = sl.ws[sort_src[t]];
