@@ -219,6 +219,7 @@ int run_ntt(hipStream_t s, const Fr *in0, const Fr *in1, Fr *out, const NttTable
 int calc_h_device(zkr_key *k, ProofSlot &sl, hipStream_t s, int nbat = 1);  // sl.d_w -> sl.d_h (bit-reversed), nbat vectors end to end
 int fused_capacity(const ArenaHeader &h, const MsmPlan plan[N_TABLES]);
 void arena_layout(ArenaHeader &h);  // section offsets and total_len from the sizes in the header (n, p, m, nnz, n_wide, npts, win_c, sc_n): THE layout, whoever builds an arena
+const char *arena_header_fault(const ArenaHeader &h, size_t len);  // null when a full arena's header is consistent with its sizes
 void base_layout(const ArenaHeader &full, ArenaHeader &b);  // the same for the compact form (zkr_key_base_arena)
 MsmPlan msm_plan(size_t n_scalars, size_t n_points, int c_fixed = 0);
 uint32_t big_threshold(size_t n_points, int K, uint32_t nbw, int nbat);  // occupancy above which a bucket goes to msm_big_kernel (zkr_key.hip)

@@ -141,6 +141,41 @@ void arena_layout(ArenaHeader &h) {
   h.total_len = off;
 }
 
+// A full arena's header against the layout its own sizes imply (arena_layout is the only producer): a damaged file or a foreign
+// buffer must be refused here, not found by a kernel reading past a section.  Null when consistent, else what is wrong.
+const char *arena_header_fault(const ArenaHeader &h, size_t len) {
+  if (h.magic != ARENA_MAGIC) return "not a packed zkr key of this version (magic)";
+  if (h.total_len != len) return "header total length differs from the bytes handed over";
+  if (h.logm > 27 || h.m != (1u << h.logm) || h.n == 0 || h.p >= h.n) return "inconsistent circuit sizes";
+  if (h.shard_parts < 1 || h.shard_parts > 64 || h.shard_part >= h.shard_parts) return "bad shard numbering";
+  if (h.sc_n[0] > h.n || h.sc_lo[0] > h.n - h.sc_n[0] || h.sc_n[1] > h.m || h.sc_lo[1] > h.m - h.sc_n[1]) return "scalar ranges outside the vectors";
+  if (h.shard_parts == 1 && (h.sc_lo[0] || h.sc_lo[1] || h.sc_n[0] != h.n || h.sc_n[1] != h.m)) return "a whole key whose scalar ranges are not the whole vectors";
+  for (int s = 0; s < 2; s++)
+    if (h.n_wide[s] > h.m) return "more wide rows than rows";
+  for (int t = 0; t < N_TABLES; t++) {
+    if (h.win_c[t] < 2 || h.win_c[t] > 26) return "bad window size";
+    if (h.npts[t] > rank_entries(h, t)) return "more points than scalars in a table";
+  }
+  ArenaHeader want = h;
+  arena_layout(want);
+  bool same = want.total_len == h.total_len && want.off_tw == h.off_tw && want.off_twl == h.off_twl;
+  for (int s = 0; s < 2; s++)
+    same = same && want.off_rowptr[s] == h.off_rowptr[s] && want.off_col[s] == h.off_col[s] && want.off_coef[s] == h.off_coef[s] && want.off_wide[s] == h.off_wide[s];
+  for (int t = 0; t < N_TABLES; t++) same = same && want.off_pts[t] == h.off_pts[t] && want.off_rank[t] == h.off_rank[t];
+  return same ? nullptr : "section offsets differ from the layout the sizes imply";
+}
+
+// ... and the one size the layout rounds away: the CSR row pointers of both QAP sides end at the header's term counts
+static int arena_rows_check(const unsigned char *arena, const ArenaHeader &h) {
+  for (int s = 0; s < 2; s++) {
+    uint32_t last = 0;
+    ZKR_HIP_CHECK(hipMemcpy(&last, arena + h.off_rowptr[s] + (size_t)h.m * 4, 4, hipMemcpyDeviceToHost));
+    const uint32_t nnz = s == 0 ? h.nnzA : h.nnzB;
+    if (last != nnz) { set_error("arena: QAP side %d has %u terms by its row pointers, %u by the header", s, last, nnz); return ZKR_ERR_BAD_KEY; }
+  }
+  return 0;
+}
+
 // cap: proofs a fused batch can hold (cap bucket sets end to end; kernels_msm.hpp msm_digits_count_kernel)
 static int alloc_msm_ws(MsmWorkspace &ws, size_t n, const MsmPlan &pl, size_t xyzz_bytes, size_t cap = 1) {
   size_t nb = pl.nb * cap;
@@ -767,7 +802,8 @@ int zkr_key_adopt_arena(void *dev_ptr, size_t len, int device, zkr_key **out) {
   ArenaHeader h;
   if (len < ARENA_HEADER_BYTES) { set_error("arena too small"); return ZKR_ERR_BAD_KEY; }
   ZKR_HIP_CHECK(hipMemcpy(&h, dev_ptr, sizeof(h), hipMemcpyDeviceToHost));
-  if (h.magic != ARENA_MAGIC || h.total_len != len) { set_error("arena header mismatch (magic/len)"); return ZKR_ERR_BAD_KEY; }
+  if (const char *fault = arena_header_fault(h, len)) { set_error("arena header: %s", fault); return ZKR_ERR_BAD_KEY; }
+  if (int rc = arena_rows_check((const unsigned char *)dev_ptr, h)) return rc;
   zkr_key *k = new zkr_key();
   k->device = device;
   k->arena = (unsigned char *)dev_ptr;
@@ -960,6 +996,7 @@ int zkr_key_load_file(const char *path, int device, zkr_key **out) {
   fseek(f, 0, SEEK_END);
   long flen = ftell(f);
   if (flen < 0 || (uint64_t)flen != h.total_len) { fclose(f); set_error("%s: length %ld != header total %llu", path, flen, (unsigned long long)h.total_len); return ZKR_ERR_BAD_KEY; }
+  if (const char *fault = arena_header_fault(h, h.total_len)) { fclose(f); set_error("%s: %s", path, fault); return ZKR_ERR_BAD_KEY; }
   fseek(f, 0, SEEK_SET);
   unsigned char *arena = nullptr;
   const size_t CHUNK = (size_t)64 << 20;
@@ -975,6 +1012,7 @@ int zkr_key_load_file(const char *path, int device, zkr_key **out) {
   }
   fclose(f);
   if (stage) hipHostFree(stage);
+  if (!rc) rc = arena_rows_check(arena, h);
   if (rc) { hipFree(arena); return rc; }
   zkr_key *k = new zkr_key();
   k->device = device;

@@ -249,8 +249,8 @@ def test_synth_generator_and_device_setup_match_oracle(log_m, p):
 
 
 def test_packed_key_file_roundtrip(tmp_path, small_case):
-    """zkr_key_save / zkr_key_load_file: the reloaded key proves bit-identically; a truncated or
-    foreign file is refused."""
+    """zkr_key_save / zkr_key_load_file: the reloaded key proves bit-identically; a truncated, foreign or
+    header-damaged file is refused."""
     import zkr_hip
     c = small_case
     key = zkr_hip.ProvingKey.load_websnark(c["pkb"])
@@ -267,6 +267,13 @@ def test_packed_key_file_roundtrip(tmp_path, small_case):
     open(bad, "wb").write(b"\0" * 4096)
     with pytest.raises(zkr_hip.ZkrError):
         zkr_hip.ProvingKey.load_file(bad)
+    # a header whose sizes or offsets were altered (right magic, right length) is refused before any kernel reads through it:
+    # off_tw at byte 64, npts[0] at byte 40, nnzA at byte 32 of the arena header (csrc/zkr_internal.hpp ArenaHeader)
+    for at, width, delta in ((64, 8, 4096), (40, 4, 1), (32, 4, -1), (16, 4, 7)):
+        v = int.from_bytes(blob[at:at + width], "little") + delta
+        open(bad, "wb").write(blob[:at] + v.to_bytes(width, "little") + blob[at + width:])
+        with pytest.raises(zkr_hip.ZkrError):
+            zkr_hip.ProvingKey.load_file(bad)
 
 
 def test_dense_random_shape_matches_oracle_generator():
