@@ -149,8 +149,9 @@ int zkr_prove_batch_multi_device(zkr_key *const *keys, size_t n_keys, const void
 /* ---- ONE proof over several GPUs (BASELINE configs[2] and [4] are single proofs) ----------------------
  * The MSMs shard by contiguous ranges: zkr_key_shard cuts every scalar vector of the proof -- the witness w (A, B1, B2, C
  * tables) and the quotient coefficients h (H table) -- into `parts` equal ranges and builds, on `device`, a key holding
- * range `part` of every point table (all window levels, copied device to device from `key`: nothing is recomputed) plus the
- * whole QAP and the twiddles: every shard computes h itself ("replicated compute"), so NOTHING is exchanged but the
+ * range `part` of every point table (all window levels; the shard's window size is the one a key of ITS size would choose, so
+ * the levels are rebuilt on `device` from the range's base points unless the window stays the same, in which case they are
+ * copied device to device) plus the whole QAP and the twiddles: every shard computes h itself ("replicated compute"), so NOTHING is exchanged but the
  * partial sums at the end -- 640 bytes per shard.  The key is sharded, not replicated: a shard holds about 1/parts of the
  * table memory (78 GB at 2^24).
  * zkr_prove_partial(_device) runs a shard's whole share of one proof (host / HBM-resident witness, the FULL witness either

@@ -6,6 +6,7 @@
 // awaits proofs -- so the proof-level sharding of BASELINE configs[3] has to be reachable from ONE process through the
 // library the N-API shim binds, not only from one-process-per-GPU launchers (python/zkr_hip/batch.py keeps that form for
 // torchrun + RCCL).
+#include <stdlib.h>
 #include <string.h>
 #include <exception>
 #include <string>
@@ -214,6 +215,20 @@ int zkr_key_shard(const zkr_key *src, unsigned part, unsigned parts, int device,
   // tables that share a digit sort must still agree point for point (they do: the same scalar range of the same supports)
   if (h.share_ac && h.npts[T_A] != h.npts[T_C]) h.share_ac = 0;
   if (h.share_b && h.npts[T_B1] != h.npts[T_B2]) h.share_b = 0;
+  // Window size of the shard: from ITS scalar count, as a key load would choose it.  A shard's point range shrinks with the
+  // number of parts, its bucket sets do not: 1/8 of a 2^20 key at the whole key's c = 20 sorts 2^17 scalars into 2^19 buckets per
+  // table (3 entries each) and then walks four reduction chains over all of them -- the chains were 2/3 of such a shard's 4.1 ms.
+  // At c = 17 it is an ordinary 2^17-point key (2^16 buckets).  The levels 2^(ck) P are then rebuilt from level 0 on the shard's
+  // device (msm_precompute, as a key load does); tables whose window does not change are copied level by level.
+  // ZKR_SHARD_KEEP_WINDOW=1: always the whole key's windows.
+  const char *keep_env = getenv("ZKR_SHARD_KEEP_WINDOW");
+  const bool keep_window = keep_env && atoi(keep_env) != 0;
+  bool rebuild[N_TABLES];
+  for (int t = 0; t < N_TABLES; t++) {
+    const uint32_t c = keep_window ? sh.win_c[t] : (uint32_t)msm_plan(rank_entries(h, t), h.npts[t], 0).c;
+    rebuild[t] = c != sh.win_c[t];
+    h.win_c[t] = c;
+  }
   arena_layout(h);
   ZKR_HIP_CHECK(hipSetDevice(device));
   (void)peer_direct(device, src->device);
@@ -234,8 +249,14 @@ int zkr_key_shard(const zkr_key *src, unsigned part, unsigned parts, int device,
   }
   for (int t = 0; t < N_TABLES && !rc; t++) {
     const size_t pb = t == T_B2 ? 128 : 64, K = (255 + sh.win_c[t] - 1) / sh.win_c[t];
-    for (size_t k = 0; k < K && !rc; k++)  // level k of the range: 2^(ck) P_i for the shard's points
-      rc = cp(h.off_pts[t] + k * h.npts[t] * pb, sh.off_pts[t] + (k * sh.npts[t] + pt_lo[t]) * pb, (size_t)h.npts[t] * pb);
+    if (rebuild[t]) {  // level 0 of the range back in the key's wire radix, then the shard's own levels
+      rc = cp(h.off_pts[t], sh.off_pts[t] + (size_t)pt_lo[t] * pb, (size_t)h.npts[t] * pb);
+      if (!rc) rc = radix_convert(device, t == T_B2, arena + h.off_pts[t], h.npts[t], false);
+      if (!rc) rc = msm_precompute(device, t == T_B2, arena + h.off_pts[t], h.npts[t], msm_plan(rank_entries(h, t), h.npts[t], (int)h.win_c[t]));
+    } else {
+      for (size_t k = 0; k < K && !rc; k++)  // level k of the range: 2^(ck) P_i for the shard's points
+        rc = cp(h.off_pts[t] + k * h.npts[t] * pb, sh.off_pts[t] + (k * sh.npts[t] + pt_lo[t]) * pb, (size_t)h.npts[t] * pb);
+    }
     if (!rc && !rank[t].empty()) {
       ZKR_HIP_CHECK(hipSetDevice(device));
       ZKR_HIP_CHECK(hipMemcpy(arena + h.off_rank[t], rank[t].data(), rank[t].size() * 4, hipMemcpyHostToDevice));

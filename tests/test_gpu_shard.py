@@ -28,7 +28,11 @@ def test_sharded_proof_equals_whole_key_proof_and_closed_form(log_m, parts):
         cover_h += si["h_n"]
         for t in pts:
             pts[t] += sh.info()[t]
-        assert sh.windows() == key.windows() and sh.fuse() == 1
+        # a shard picks its window from ITS scalar counts, as a key of that size would (csrc/zkr_key.hip msm_plan)
+        c_of = lambda nsc: min(20, max(4, (nsc - 1).bit_length()))
+        win = sh.windows()
+        assert all(win[t][0] == c_of(si["w_n"]) for t in ("A", "B1", "B2", "C")) and win["H"][0] == c_of(si["h_n"]) and sh.fuse() == 1
+        assert all(k == -(-255 // c) for c, k in win.values())
     assert cover_w == info["nVars"] and cover_h == info["domainSize"] and pts == {t: info[t] for t in pts}
     assert key.shard_info() == dict(part=0, parts=1, w_lo=0, w_n=info["nVars"], h_lo=0, h_n=info["domainSize"])
     rng = g.SplitMix64(77 + log_m + parts)
@@ -57,12 +61,32 @@ def test_sharded_proof_equals_whole_key_proof_and_closed_form(log_m, parts):
     assert zkr_hip.prove_sharded(shards, wb, r, s) == whole
 
 
+def test_shards_with_the_whole_keys_windows(monkeypatch):
+    """ZKR_SHARD_KEEP_WINDOW=1: the levels of the whole key's tables copied range by range (no rebuild); same proof."""
+    import zkr_hip
+    log_m, p, parts = 14, 73, 4
+    key, wb, aux = zkr_hip.ProvingKey.synth(log_m, p, 0x5A4B0001, 0x5A4B00FF)
+    own = [key.shard(i, parts) for i in range(parts)]
+    monkeypatch.setenv("ZKR_SHARD_KEEP_WINDOW", "1")
+    kept = [key.shard(i, parts) for i in range(parts)]
+    monkeypatch.delenv("ZKR_SHARD_KEEP_WINDOW")
+    assert all(sh.windows() == key.windows() for sh in kept) and all(sh.windows() != key.windows() for sh in own)
+    want = g.proof_bytes(g.proof_from_aux(aux, wb, p, 11, 13)[0])
+    assert key.prove(wb, 11, 13) == want
+    assert zkr_hip.prove_sharded(kept, wb, 11, 13) == want and zkr_hip.prove_sharded(own, wb, 11, 13) == want
+    # partial sums are group elements: records of the two kinds of shard mix
+    mixed = [(own if i % 2 else kept)[i].prove_partial(wb) for i in range(parts)]
+    assert key.prove_combine(mixed, 11, 13) == want
+
+
 def test_shard_errors_and_memory():
     import zkr_hip
     log_m, p = 12, 73
     key, wb, _ = zkr_hip.ProvingKey.synth(log_m, p, 0x5A4B0001, 0x5A4B00FF, want_aux=False)
     shards = [key.shard(i, 4) for i in range(4)]
-    assert sum(sh.arena()[1] for sh in shards) < 1.5 * key.arena()[1]          # the key is sharded, not replicated (QAP + twiddles repeat)
+    # the key is sharded, not replicated: the QAP and the twiddles repeat, and a shard's smaller windows mean more levels per point
+    # (K = 26 at c = 10 against 22 at c = 12 here)
+    assert sum(sh.arena()[1] for sh in shards) < 2 * key.arena()[1]
     assert max(sh.arena()[1] for sh in shards) < 0.5 * key.arena()[1]
     with pytest.raises(zkr_hip.ZkrError, match="itself a shard"):
         shards[1].shard(0, 2)
