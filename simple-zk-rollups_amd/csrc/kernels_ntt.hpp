@@ -91,6 +91,10 @@ struct NttPassArgs {
   // what a 2^17 transform lacks to fill the chip
   const Fr *in0_b, *in1_b;
   Fr *out_b;
+  // first workgroup of the pass (0 = all of it).  A pass over stages [lo, hi) only mixes elements inside aligned blocks of 2^hi,
+  // so when only a range of the OUTPUT is wanted -- a shard's part of h (zkr_prove.hip calc_h_device) -- the passes below
+  // the top one run on the blocks that cover the range and on nothing else
+  uint32_t blk_off;
 };
 
 // The butterflies run on 9 x 29-bit limbs (field29.hpp), lazily reduced: a product is 205 instructions instead of the ~300
@@ -128,7 +132,8 @@ static __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArg
   const uint32_t rows = 1u << nb, W = 1u << a.wlog;
   const uint32_t tile = rows << a.wlog;
   const uint32_t lb = (1u << a.lo) >> a.wlog;  // tiles per q
-  const uint32_t q = blockIdx.x / lb, l0 = (blockIdx.x % lb) << a.wlog;
+  const uint32_t bx = blockIdx.x + a.blk_off;
+  const uint32_t q = bx / lb, l0 = (bx % lb) << a.wlog;
   const size_t base = ((size_t)blockIdx.y << a.L) + ((size_t)q << a.hi) + l0;  // blockIdx.y: transform of a fused batch (vectors end to end)
 
   auto lds_get = [&](uint32_t e) {
@@ -360,12 +365,14 @@ static __global__ __launch_bounds__(64) void spmv_wide_kernel(SpmvSide sa, SpmvS
 
 // h (bit-reversed order) = C1*S' - C2 * g^-i * D'   (DESIGN.md "calcH on the GPU"); S', D' are the
 // unscaled inverse-DIF outputs of a.b and A(gw^c).B(gw^c); i = bitrev(pos).
-static __global__ void combine_h_kernel(const Fr *S, const Fr *D, Fr *h, const Fr *tw, int tlog, int L, Fr c1, Fr c2, uint32_t *zero = nullptr, uint32_t zero_words = 0) {
+// pos0 / pos1: the positions wanted (a shard: its range of h; otherwise 0 and 2^L)
+static __global__ void combine_h_kernel(const Fr *S, const Fr *D, Fr *h, const Fr *tw, int tlog, int L, Fr c1, Fr c2, uint32_t *zero, uint32_t zero_words,
+                                        uint32_t pos0, uint32_t pos1) {
   ZKR_PREP_SETPRIO();
   if (blockIdx.x == 0 && blockIdx.y == 0)  // see ingest_kernel: the counters of h's digit records
     for (uint32_t k = threadIdx.x; k < zero_words; k += blockDim.x) zero[k] = 0;
-  uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x;
-  if (pos >= (1u << L)) return;
+  uint32_t pos = pos0 + blockIdx.x * blockDim.x + threadIdx.x;
+  if (pos >= pos1) return;
   const size_t boff = (size_t)blockIdx.y << L;  // blockIdx.y: proof of a fused batch
   S += boff; D += boff; h += boff;
   uint32_t i = __brev(pos) >> (32 - L);

@@ -215,7 +215,8 @@ struct NttTables { const Fr *tw; const Tw29 *tw29, *twl29; int tlog; };  // x 2^
 int ntt_lds_check(int device);  // ZKR_ERR_NO_DEVICE with a clear message when the device cannot hold an NTT tile in LDS
 int ntt_tables29_build(const Fr *tw, uint32_t n_tw, const Fr *twl, uint32_t n_twl, hipStream_t s, Tw29 **tw29, Tw29 **twl29);
 int run_ntt(hipStream_t s, const Fr *in0, const Fr *in1, Fr *out, const NttTables &tb, int L, bool dif, bool inverse, int pre, int nbat, Prof pf,
-            const Fr *in0_b = nullptr, const Fr *in1_b = nullptr, Fr *out_b = nullptr);  // in0_b / in1_b / out_b: a second transform of the same shape in the same launches
+            const Fr *in0_b = nullptr, const Fr *in1_b = nullptr, Fr *out_b = nullptr,  // in0_b / in1_b / out_b: a second transform of the same shape in the same launches
+            uint32_t want_lo = 0, uint32_t want_n = 0);  // DIF: only this range of the output is wanted (0, 0: all of it)
 int calc_h_device(zkr_key *k, ProofSlot &sl, hipStream_t s, int nbat = 1);  // sl.d_w -> sl.d_h (bit-reversed), nbat vectors end to end
 int fused_capacity(const ArenaHeader &h, const MsmPlan plan[N_TABLES]);
 void arena_layout(ArenaHeader &h);  // section offsets and total_len from the sizes in the header (n, p, m, nnz, n_wide, npts, win_c, sc_n): THE layout, whoever builds an arena

@@ -132,8 +132,11 @@ static int ntt_tile_log(int L, int nbat) {
 }
 
 // One transform, or TWO of the same shape in the same launches (in0_b / in1_b / out_b: gridDim.z = 2)
+// want_lo / want_n (DIF only; 0, 0 = everything): only positions [want_lo, want_lo + want_n) of the output are wanted -- the
+// passes run on the aligned blocks that cover them (kernels_ntt.hpp NttPassArgs::blk_off); the rest of `out` is left half done
 int run_ntt(hipStream_t s, const Fr *in0, const Fr *in1, Fr *out, const NttTables &tb, int L, bool dif, bool inverse, int pre, int nbat, Prof pf,
-            const Fr *in0_b, const Fr *in1_b, Fr *out_b) {
+            const Fr *in0_b, const Fr *in1_b, Fr *out_b, uint32_t want_lo, uint32_t want_n) {
+  if (want_n && (!dif || (uint64_t)want_lo + want_n > (1ull << L))) { set_error("run_ntt: an output range needs a DIF transform and must lie inside it"); return ZKR_ERR_ARG; }
   const int tile_log = ntt_tile_log(L, nbat * (out_b ? 2 : 1));
   std::vector<PassSpec> plan = ntt_plan(L, tile_log);
   if (!dif) std::reverse(plan.begin(), plan.end());
@@ -157,6 +160,13 @@ int run_ntt(hipStream_t s, const Fr *in0, const Fr *in1, Fr *out, const NttTable
     a.prio = ntt_prio;
     uint32_t tile = 1u << (ps.hi - ps.lo + ps.wlog);
     uint32_t grid = (1u << L) / tile;
+    a.blk_off = 0;
+    if (want_n) {  // the 2^hi-blocks that cover the range, 2^hi / tile workgroups each
+      const uint32_t per_block = (1u << ps.hi) / tile;
+      const uint32_t q0 = want_lo >> ps.hi, q1 = (uint32_t)(((uint64_t)want_lo + want_n + (1u << ps.hi) - 1) >> ps.hi);
+      a.blk_off = q0 * per_block;
+      grid = (q1 - q0) * per_block;
+    }
     size_t lds = (size_t)tile * 36;  // 9 limbs per element
     // workgroup size by transform size (kernels_ntt.hpp NTT_THREADS_*); ZKR_NTT_THREADS=256|512 overrides for experiments
     static const int thr_env = getenv("ZKR_NTT_THREADS") ? atoi(getenv("ZKR_NTT_THREADS")) : 0;
@@ -211,6 +221,14 @@ int calc_h_device(zkr_key *k, ProofSlot &sl, hipStream_t s, int nbat) {
   // The six transforms come in three pairs of the same shape, each pair in ONE set of launches (gridDim.z = 2):
   // coefficients of a and b (x m, bit-reversed), then their evaluations on the coset g*w^c (x m, natural),
   static const bool no_pair = getenv("ZKR_NTT_NO_PAIR") != nullptr;  // A/B: the six transforms one after the other, as in round 3
+  // A shard multiplies only positions [sc_lo, sc_lo + sc_n) of h (bit-reversed order, as the H table is laid out): the last pair of
+  // transforms -- inverse DIF, whose passes below the top one stay inside aligned blocks -- and the combination run on the
+  // blocks that cover that range only (at 2^22: 16 of 22 stages of two of the six transforms on 1/8 of the vector for 8 shards).
+  // ZKR_SHARD_FULL_H=1: the whole of h on every shard, as before.
+  const char *full_env = getenv("ZKR_SHARD_FULL_H");  // read per call: tests switch it within one process
+  const bool full_h = full_env && atoi(full_env) != 0;
+  const bool ranged = h.shard_parts > 1 && !full_h && !no_pair && h.sc_n[1] < m;
+  const uint32_t h_lo = ranged ? h.sc_lo[1] : 0, h_n = ranged ? h.sc_n[1] : 0;
   if (no_pair) {
     if ((rc = run_ntt(s, sl.va, nullptr, sl.ca, tb, L, true, true, PRE_NONE, nbat, pf))) return rc;
     if ((rc = run_ntt(s, sl.vb, nullptr, sl.cb, tb, L, true, true, PRE_NONE, nbat, pf))) return rc;
@@ -222,7 +240,7 @@ int calc_h_device(zkr_key *k, ProofSlot &sl, hipStream_t s, int nbat) {
     if ((rc = run_ntt(s, sl.va, nullptr, sl.ca, tb, L, true, true, PRE_NONE, nbat, pf, sl.vb, nullptr, sl.cb))) return rc;
     if ((rc = run_ntt(s, sl.ca, nullptr, sl.ca, tb, L, false, false, PRE_COSET, nbat, pf, sl.cb, nullptr, sl.cb))) return rc;
     // then D' = iNTT(A(gw^c).B(gw^c)) and S' = iNTT(a.b), both unscaled and bit-reversed
-    if ((rc = run_ntt(s, sl.ca, sl.cb, sl.ca, tb, L, true, true, PRE_MUL, nbat, pf, sl.va, sl.vb, sl.va))) return rc;
+    if ((rc = run_ntt(s, sl.ca, sl.cb, sl.ca, tb, L, true, true, PRE_MUL, nbat, pf, sl.va, sl.vb, sl.va, h_lo, h_n))) return rc;
   }
   // constants: S' = m S / R, D' = m^3 D g^i / R  ->  h = S'*R^2/(2m) (*1/R)  -  D' g^-i * R^2/(2 m^3) (*1/R)
   Fr r2 = Fr::r2();
@@ -233,7 +251,8 @@ int calc_h_device(zkr_key *k, ProofSlot &sl, hipStream_t s, int nbat) {
   // We need the plain integer R^2/(2m) = Montgomery(R/(2m)) exactly, so c1v is already the constant to pass.
   Fr c2v = mul(mul(c1v, minv), minv);            // Montgomery(R/(2m^3)) = integer R^2/(2m^3)
   const int csp = prof_begin(pf, s, "combine_h");
-  combine_h_kernel<<<dim3((m + 255) / 256, nbat), 256, 0, s>>>(sl.va, sl.ca, sl.d_h, tw, tlog, L, c1v, c2v, sl.dig_h.rng, DIGIT_CLEAR_WORDS);  // + the counters of h's digit records
+  const uint32_t pos0 = ranged ? h_lo : 0, pos1 = ranged ? h_lo + h_n : m;
+  combine_h_kernel<<<dim3((pos1 - pos0 + 255) / 256, nbat), 256, 0, s>>>(sl.va, sl.ca, sl.d_h, tw, tlog, L, c1v, c2v, sl.dig_h.rng, DIGIT_CLEAR_WORDS, pos0, pos1);  // + the counters of h's digit records
   prof_end(pf, s, csp);
   prof_end(pf, s, sp);
   ZKR_HIP_CHECK(hipGetLastError());

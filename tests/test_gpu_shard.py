@@ -77,6 +77,28 @@ def test_shards_with_the_whole_keys_windows(monkeypatch):
     # partial sums are group elements: records of the two kinds of shard mix
     mixed = [(own if i % 2 else kept)[i].prove_partial(wb) for i in range(parts)]
     assert key.prove_combine(mixed, 11, 13) == want
+    # ZKR_SHARD_FULL_H=1: every shard computes the whole of h instead of the blocks of the last transforms that cover its range
+    monkeypatch.setenv("ZKR_SHARD_FULL_H", "1")
+    assert zkr_hip.prove_sharded(own, wb, 11, 13) == want
+    monkeypatch.delenv("ZKR_SHARD_FULL_H")
+
+
+@pytest.mark.parametrize("log_m,parts", [(12, 3), (12, 5), (12, 7), (18, 6), (22, 8)])
+def test_ranges_of_h_that_are_not_aligned_blocks(log_m, parts):
+    """A shard runs the last pair of calcH's transforms only on the aligned blocks that cover its range of h (csrc/zkr_prove.hip
+    calc_h_device): ranges of m / 3, m / 5, ... start and end inside a block; 2^12 has two passes, 2^18 two, 2^22 three."""
+    import zkr_hip
+    p = 73
+    key, wb, aux = zkr_hip.ProvingKey.synth(log_m, p, 0x5A4B0001, 0x5A4B00FF, want_aux=log_m <= 18)
+    want = key.prove(wb, 21, 22)
+    if aux is not None:
+        assert want == g.proof_bytes(g.proof_from_aux(aux, wb, p, 21, 22)[0])
+    partials = []
+    for i in range(parts):          # one shard at a time: a 2^22 key and eight shards side by side would not fit comfortably
+        sh = key.shard(i, parts)
+        partials.append(sh.prove_partial(wb))
+        sh.close()
+    assert key.prove_combine(partials, 21, 22) == want
 
 
 def test_shard_errors_and_memory():
