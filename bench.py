@@ -8,7 +8,7 @@ HBM when the timed region starts.  N>1: the key is generated on rank 0 and broad
 rank proves its own K witnesses (weak scaling, no data-path collective).  Prints ONE JSON line.
 
 Other forms (same JSON shape):  --gpus N --inproc [--devices 0,0]   N devices from ONE process through zkr_key_replicate +
-zkr_prove_batch_multi_device (no torch.distributed: the shape of the reference's Node host);  --shards P   adds the
+zkr_prove_batch_multi_device (no torch.distributed: the shape of the reference's Node host);  --shards P   (default 8; 0 skips) is the
 intra-proof sharding leg (one proof cut into P shards, each timed alone: projected one-shard-per-GPU latency);
 --log-m 22 / 24, --shape dense: the other BASELINE configs;  --no-pipeline: synchronous proofs.
 """
@@ -687,7 +687,7 @@ def shard_leg(key, d_wit, parts, want_proof, local):
     return {"parts": parts, "whole_key_sync_proof_ms": whole_ms, "per_shard": rows, "slowest_shard_ms": slowest, "combine_ms": combine_ms,
             "projected_latency_ms_one_shard_per_gpu": slowest + combine_ms, "projected_speedup": whole_ms / (slowest + combine_ms),
             "shard_build_s": build_s, "proof_identical_to_whole_key": True,
-            "note": "PROJECTED: shards measured one at a time on one GPU; every shard recomputes h (replicated compute), so the exchange is 640 B per shard"}
+            "note": "PROJECTED: shards measured one at a time on one GPU; every shard computes its part of h itself (the first four of calcH's six transforms in full, the last two on its range), so the exchange is 640 B per shard"}
 
 
 def verify_timed_proofs(vk_bin, proofs, pubs_of):
@@ -818,7 +818,7 @@ def main():
     ap.add_argument("--inproc", action="store_true", help="N GPUs from ONE process through zkr_key_replicate + zkr_prove_batch_multi_device (no torch.distributed)")
     ap.add_argument("--devices", default=None, help="--inproc: comma-separated HIP ordinals, one per --gpus slot (a device may repeat)")
     ap.add_argument("--replicate-mode", choices=["auto", "full", "base"], default="auto", help="--inproc: form of the device-to-device key copy")
-    ap.add_argument("--shards", type=int, default=0, help="intra-proof sharding leg (SURVEY 8(e) row 2): split every MSM of ONE proof into this many contiguous point ranges, "
+    ap.add_argument("--shards", type=int, default=8, help="(0 = skip) intra-proof sharding leg (SURVEY 8(e) row 2): split every MSM of ONE proof into this many contiguous point ranges, "
                                                           "run the shards one after the other on this GPU and report the per-shard time (= projected latency with one shard per GPU)")
     args = ap.parse_args()
 
@@ -1020,7 +1020,10 @@ def main():
         if world == 1 and not args.no_bcast_modes:
             out["key"]["replication_modes_one_gpu"] = bcast_modes_leg(key, bytes(wits[0].cpu().numpy().tobytes()), local)
         if world == 1 and args.shards > 1:
-            out["intra_proof_sharding"] = shard_leg(key, wits[0], args.shards, proofs[0], local)
+            try:
+                out["intra_proof_sharding"] = shard_leg(key, wits[0], args.shards, proofs[0], local)
+            except (Exception, SystemExit) as e:  # a side leg never costs the headline line; a differing proof shows here
+                out["intra_proof_sharding"] = {"error": str(e)}
         if world == 1 and not args.no_tx_circuit:
             key.close()  # its four streams would share the hardware queues with the streams of the tx-circuit key
             out["dropin"] = dropin_leg(local)
