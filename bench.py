@@ -658,6 +658,8 @@ def shard_leg(key, d_wit, parts, want_proof, local):
     # one shard at a time (built, timed, released): on a real node every GPU holds ONE shard; eight of a 2^24 key side by side
     # beside the whole key would not fit one GPU's 288 GB
     rows, partials, build_s = [], [], 0.0
+    m_ = key.info()["domainSize"]
+    split_ok = parts in (2, 4, 8) and m_ // (parts * parts) >= 64       # zkr_prove_sharded splits calcH over such shards (zkr_multi.hip run_sharded)
     for i in range(parts):
         t1 = time.perf_counter()
         sh = key.shard(i, parts, device=local)
@@ -674,8 +676,12 @@ def shard_leg(key, d_wit, parts, want_proof, local):
         sh.prove_partial_device(d_wit.data_ptr())
         stages = {k: round(v[0], 3) for k, v in sh.prof().items() if v[1]}
         sh.prof_enable(False)
-        rows.append({"part": sh.shard_info()["part"], "ms": ms, "arena_bytes": sh.arena()[1], "points": sum(inf[t] for t in ("ptsA", "ptsB1", "ptsB2", "ptsC", "ptsH")),
-                     "stage_ms": stages})
+        row = {"part": sh.shard_info()["part"], "ms": ms, "arena_bytes": sh.arena()[1], "points": sum(inf[t] for t in ("ptsA", "ptsB1", "ptsB2", "ptsC", "ptsH")),
+               "stage_ms": stages}
+        if split_ok:                                                    # the shard's share when calcH is split over the shards, alone on the GPU
+            sh.bench_split_solo(d_wit.data_ptr())
+            row["split_calch_solo_ms"] = sorted(sh.bench_split_solo(d_wit.data_ptr()) for _ in range(3))[1]
+        rows.append(row)
         sh.close()
     t1 = time.perf_counter()
     proof = key.prove_combine(partials, 1000003, 2000003)
@@ -684,8 +690,53 @@ def shard_leg(key, d_wit, parts, want_proof, local):
     if not same:
         raise SystemExit("the sharded proof differs from the whole key's proof")
     slowest = max(r["ms"] for r in rows)
+    split = None
+    if split_ok:
+        # What zkr_prove_sharded does with these shards on a node: calcH split over them (csrc/zkr_prove.hip calc_h_split).  MEASURED
+        # here: every shard's share alone on the GPU with its own buffers standing in for the others' (zkr_bench_shard_split_solo)
+        # and, separately, the whole sharded proof with all shards concurrently on this one GPU (same bytes as the whole key's).
+        # MODELLED: the exchange -- in the cross passes a shard reads 6 and writes 4 vector-columns-of-every-block, (P - 1) / P of
+        # them in other GPUs' memory, over 7 xGMI links at once at an ASSUMED half of 153 GB/s each -- and 5 host barriers of 50 us.
+        solo = max(r["split_calch_solo_ms"] for r in rows)
+        remote_bytes = 10 * (m_ // parts) * 32 * (parts - 1) / parts
+        exchange_ms = 1e3 * remote_bytes / (7 * 153e9 * 0.5)
+        barriers_ms = 5 * 0.05
+        shards_all, agg_ms, agg_rep_ms, same_split = [], None, None, None
+        try:                                                            # all shards side by side: may not fit beside the whole key at 2^24
+            for i in range(parts):
+                shards_all.append(key.shard(i, parts, device=local))
+            ptrs = [d_wit.data_ptr()] * parts
+            same_split = zkr_hip.prove_sharded_device(shards_all, ptrs, 1000003, 2000003) == whole and zkr_hip.sharded_split_stats() is not None
+            t1 = time.perf_counter()
+            for _ in range(3):
+                zkr_hip.prove_sharded_device(shards_all, ptrs, 1000003, 2000003)
+            agg_ms = 1e3 * (time.perf_counter() - t1) / 3
+            os.environ["ZKR_SHARD_SPLIT_H"] = "0"
+            try:
+                zkr_hip.prove_sharded_device(shards_all, ptrs, 1000003, 2000003)
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    zkr_hip.prove_sharded_device(shards_all, ptrs, 1000003, 2000003)
+                agg_rep_ms = 1e3 * (time.perf_counter() - t1) / 3
+            finally:
+                del os.environ["ZKR_SHARD_SPLIT_H"]
+        except zkr_hip.ZkrError as e:
+            sys.stderr.write("shard leg: all shards side by side: %s\n" % e)
+        finally:
+            for sh in shards_all:
+                sh.close()
+        if same_split is False:
+            raise SystemExit("the sharded proof with a split calcH differs from the whole key's proof")
+        lat = solo + combine_ms + exchange_ms + barriers_ms
+        split = {"slowest_shard_solo_ms": solo, "modelled_exchange_ms": exchange_ms, "modelled_barriers_ms": barriers_ms,
+                 "remote_bytes_per_shard": remote_bytes, "assumed_link_efficiency": 0.5,
+                 "projected_latency_ms": lat, "projected_speedup": whole_ms / lat,
+                 "all_shards_on_this_gpu_ms_per_proof": agg_ms, "all_shards_on_this_gpu_ms_per_proof_replicated_calch": agg_rep_ms,
+                 "proof_identical_to_whole_key": same_split,
+                 "note": "compute MEASURED (a shard alone; all shards together on one GPU), exchange and barriers MODELLED: no multi-GPU node was available"}
     return {"parts": parts, "whole_key_sync_proof_ms": whole_ms, "per_shard": rows, "slowest_shard_ms": slowest, "combine_ms": combine_ms,
             "projected_latency_ms_one_shard_per_gpu": slowest + combine_ms, "projected_speedup": whole_ms / (slowest + combine_ms),
+            "split_calch": split,
             "shard_build_s": build_s, "proof_identical_to_whole_key": True,
             "note": "PROJECTED: shards measured one at a time on one GPU; every shard computes its part of h itself (the first four of calcH's six transforms in full, the last two on its range), so the exchange is 640 B per shard"}
 

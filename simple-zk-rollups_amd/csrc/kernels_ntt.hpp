@@ -95,6 +95,17 @@ struct NttPassArgs {
   // so when only a range of the OUTPUT is wanted -- a shard's part of h (zkr_prove.hip calc_h_device) -- the passes below
   // the top one run on the blocks that cover the range and on nothing else
   uint32_t blk_off;
+  // first pass of a transform that is one aligned BLOCK of a larger one (a shard's block of a split calcH, zkr_prove.hip
+  // calc_h_split): the coset factor of position gi of the block is that of coefficient (bitrev(gi) << pre_shift) | pre_add of the
+  // whole transform of 2^(L + pre_shift) points.  0, 0: the transform is the whole one.
+  uint32_t pre_shift, pre_add;
+  // CROSS passes (template parameter): the top hi - lo <= 3 stages of a transform whose 2^(hi - lo) row blocks live in DIFFERENT
+  // buffers -- the blocks of a vector split over the shards of a proof, each on its owner's device (peer access), or a local
+  // buffer holding this shard's columns of every block.  Row r, column cg (position within the block): element
+  // x_in0[r][cg - x_in_sub], stored to x_out[r][cg - x_out_sub].  Twiddles come from the true position (r << lo) + cg.
+  const Fr *x_in0[8], *x_in1[8];
+  Fr *x_out[8];
+  uint32_t x_in_sub, x_out_sub;
 };
 
 // The butterflies run on 9 x 29-bit limbs (field29.hpp), lazily reduced: a product is 205 instructions instead of the ~300
@@ -119,12 +130,16 @@ static_assert(NTT_STRIDED_LOG <= NTT_TILE_LOG, "a strided pass has no more stage
 using NttL = Fr29;
 
 // one pass; grid = 2^L / tile, block = NTT_THREADS, dynamic LDS = 36 * tile bytes
-template <bool DIF, bool INV, int NTT_THREADS>
-static __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs a) {
+template <bool DIF, bool INV, int NTT_THREADS, bool CROSS = false>
+static __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(const NttPassArgs a_in) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   constexpr int HL = DIF ? NTT_H_DIF : NTT_H_DIT;  // what a value read from LDS is stated to be below
   using V = L29<NttL, HL>;
-  if (blockIdx.z) { a.in0 = a.in0_b; a.in1 = a.in1_b; a.out = a.out_b; }
+  // the three pointers a paired launch swaps, apart from the argument block (CROSS indexes its row tables per lane: they stay
+  // where the kernel arguments are)
+  const NttPassArgs &a = a_in;
+  const Fr *const in0 = blockIdx.z ? a.in0_b : a.in0, *const in1 = blockIdx.z ? a.in1_b : a.in1;
+  Fr *const out = blockIdx.z ? a.out_b : a.out;
   if (a.prio == 1) __builtin_amdgcn_s_setprio(1);
   else if (a.prio == 2) __builtin_amdgcn_s_setprio(2);
   else if (a.prio == 3) __builtin_amdgcn_s_setprio(3);
@@ -150,13 +165,21 @@ static __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArg
 
   for (uint32_t e = threadIdx.x; e < tile; e += NTT_THREADS) {
     uint32_t r = e >> a.wlog, c = e & (W - 1);
-    size_t gi = base + ((size_t)r << a.lo) + c;
-    Fr x = load_fr(a.in0 + gi);
-    if (a.pre == PRE_COSET) {  // first pass of a transform: canonical input, 32-bit product with the x 2^256 table (once per element)
-      uint32_t br = __brev((uint32_t)gi << (32 - a.L));  // coefficient index of a bit-reversed position (low L bits of gi: position within its transform)
-      x = mul(x, load_fr(a.tw + ((size_t)br << (a.tlog - a.L))));
-    } else if (a.pre == PRE_MUL) {
-      x = mul(x, load_fr(a.in1 + gi));
+    Fr x;
+    if constexpr (CROSS) {
+      const uint32_t ci = l0 + c - a.x_in_sub;
+      x = load_fr(a.x_in0[r] + ci);
+      if (a.pre == PRE_MUL) x = mul(x, load_fr(a.x_in1[r] + ci));
+    } else {
+      size_t gi = base + ((size_t)r << a.lo) + c;
+      x = load_fr(in0 + gi);
+      if (a.pre == PRE_COSET) {  // first pass of a transform: canonical input, 32-bit product with the x 2^256 table (once per element)
+        uint32_t br = __brev((uint32_t)gi << (32 - a.L));  // coefficient index of a bit-reversed position (low L bits of gi: position within its transform)
+        br = (br << a.pre_shift) | a.pre_add;
+        x = mul(x, load_fr(a.tw + ((size_t)br << (a.tlog - a.L - a.pre_shift))));
+      } else if (a.pre == PRE_MUL) {
+        x = mul(x, load_fr(in1 + gi));
+      }
     }
     lds_put(e, unpack29<NttL, DIF ? NTT_H_DIF : NTT_H_IN>(x.v));
   }
@@ -257,7 +280,6 @@ static __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArg
 
   for (uint32_t e = threadIdx.x; e < tile; e += NTT_THREADS) {
     uint32_t r = e >> a.wlog, c = e & (W - 1);
-    size_t gi = base + ((size_t)r << a.lo) + c;
     V x = lds_get(e);
     Fr o;
     if constexpr (DIF) {
@@ -267,7 +289,8 @@ static __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArg
       auto y = barrett(x);  // < 2.5 r <= NTT_H_IN
       if (a.canon) pack29(canonical_small(y), o.v); else pack29(y, o.v);
     }
-    store_fr(a.out + gi, o);
+    if constexpr (CROSS) store_fr(a.x_out[r] + (l0 + c - a.x_out_sub), o);
+    else store_fr(out + base + ((size_t)r << a.lo) + c, o);
   }
 }
 
@@ -315,14 +338,15 @@ static __global__ void ingest_kernel(const Fr *in, Fr *out, size_t n, uint32_t *
 constexpr uint32_t SPMV_WIDE = 8;
 // blockIdx.z = 1: the B side of the QAP in the same launch (its CSR arrays and output vector)
 struct SpmvSide { const uint32_t *row_ptr, *col; const Fr *coef; Fr *out; const uint32_t *wide; uint32_t n_wide; };
-static __global__ void spmv_kernel(SpmvSide sa, SpmvSide sb, const Fr *w, uint32_t m, uint32_t n) {
+// row0 / row1: the rows wanted (a shard of a split calcH evaluates its block of the domain; otherwise 0 and m)
+static __global__ void spmv_kernel(SpmvSide sa, SpmvSide sb, const Fr *w, uint32_t m, uint32_t n, uint32_t row0, uint32_t row1) {
   ZKR_PREP_SETPRIO();
   const SpmvSide &sd = blockIdx.z ? sb : sa;
   const uint32_t *row_ptr = sd.row_ptr, *col = sd.col;
   const Fr *coef = sd.coef;
   Fr *out = sd.out;
-  uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= m) return;
+  uint32_t c = row0 + blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= row1) return;
   w += (size_t)blockIdx.y * n;    // blockIdx.y: witness of a fused batch
   out += (size_t)blockIdx.y * m;
   uint32_t k0 = row_ptr[c], k1 = row_ptr[c + 1];
@@ -332,7 +356,7 @@ static __global__ void spmv_kernel(SpmvSide sa, SpmvSide sb, const Fr *w, uint32
   store_fr(out + c, acc);
 }
 // wide[i] = index of the i-th row wider than SPMV_WIDE; one wavefront per row, terms strided over the lanes, LDS tree
-static __global__ __launch_bounds__(64) void spmv_wide_kernel(SpmvSide sa, SpmvSide sb, const Fr *w, uint32_t m, uint32_t n) {
+static __global__ __launch_bounds__(64) void spmv_wide_kernel(SpmvSide sa, SpmvSide sb, const Fr *w, uint32_t m, uint32_t n, uint32_t row0, uint32_t row1) {
   ZKR_PREP_SETPRIO();
   __shared__ uint32_t sh[8 * 64];
   const SpmvSide &sd = blockIdx.z ? sb : sa;
@@ -343,6 +367,7 @@ static __global__ __launch_bounds__(64) void spmv_wide_kernel(SpmvSide sa, SpmvS
   w += (size_t)blockIdx.y * n;
   out += (size_t)blockIdx.y * m;
   const uint32_t c = wide[blockIdx.x], lane = threadIdx.x;
+  if (c < row0 || c >= row1) return;
   uint32_t k0 = row_ptr[c], k1 = row_ptr[c + 1];
   Fr acc = Fr::zero();
   for (uint32_t k = k0 + lane; k < k1; k += 64) acc = add(acc, mul(load_fr(coef + k), load_fr(w + col[k])));

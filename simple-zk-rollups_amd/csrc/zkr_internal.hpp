@@ -183,6 +183,7 @@ struct zkr_key {
   zkr::ProofSlot slot[zkr::PROOF_SLOTS];
   int next_slot = 0;
   std::mutex mu;  // slot hand-out, the enqueue phase of a proof (so two host threads do not interleave launches), stage totals
+  std::mutex split_mu;  // a shard key: held by the sharded proof that splits calcH over it and its siblings (zkr_multi.hip run_sharded)
   std::condition_variable slot_freed;
   zkr::MsmPlan plan[zkr::N_TABLES];
   // proof assembly on the host: 4-bit window tables of delta_1 / delta_2 (built on first use)
@@ -216,8 +217,45 @@ int ntt_lds_check(int device);  // ZKR_ERR_NO_DEVICE with a clear message when t
 int ntt_tables29_build(const Fr *tw, uint32_t n_tw, const Fr *twl, uint32_t n_twl, hipStream_t s, Tw29 **tw29, Tw29 **twl29);
 int run_ntt(hipStream_t s, const Fr *in0, const Fr *in1, Fr *out, const NttTables &tb, int L, bool dif, bool inverse, int pre, int nbat, Prof pf,
             const Fr *in0_b = nullptr, const Fr *in1_b = nullptr, Fr *out_b = nullptr,  // in0_b / in1_b / out_b: a second transform of the same shape in the same launches
-            uint32_t want_lo = 0, uint32_t want_n = 0);  // DIF: only this range of the output is wanted (0, 0: all of it)
+            uint32_t want_lo = 0, uint32_t want_n = 0,   // DIF: only this range of the output is wanted (0, 0: all of it)
+            uint32_t coset_shift = 0, uint32_t coset_add = 0);  // PRE_COSET when the transform is one block of a larger one (NttPassArgs::pre_shift)
 int calc_h_device(zkr_key *k, ProofSlot &sl, hipStream_t s, int nbat = 1);  // sl.d_w -> sl.d_h (bit-reversed), nbat vectors end to end
+
+// The shards of ONE proof running concurrently in this process (zkr_multi.hip run_sharded), one host thread each: what a split
+// calcH needs from the others -- where their vectors are, and a barrier.  A shard that fails aborts the group: everybody waiting
+// (now or later) returns false instead of waiting for a thread that will never arrive.
+struct ShardGroup {
+  struct Vecs { Fr *va, *vb, *ca, *cb, *dh; };
+  unsigned parts = 0;
+  int klog = 0;                       // parts = 2^klog
+  std::vector<Vecs> vecs;             // [part], published by the part's thread before the first barrier
+  bool split_h = false;               // every precondition of the split holds (zkr_multi.hip run_sharded)
+  bool solo = false;                  // measurement only (zkr_bench_shard_split_solo): ONE shard runs its phases with its own buffers
+                                      // standing in for the others' -- the time of a shard alone on its GPU, the result meaningless
+  double phase_ms[8][8] = {};         // [part][phase]: host time enqueue -> stream idle of the split's phases (bench / tests)
+  std::mutex mu;
+  std::condition_variable cv;
+  unsigned waiting = 0, generation = 0;
+  bool failed = false;
+  bool barrier() {                    // false: the group was aborted
+    std::unique_lock<std::mutex> lk(mu);
+    if (failed) return false;
+    if (solo) return true;
+    const unsigned gen = generation;
+    if (++waiting == parts) { waiting = 0; generation++; cv.notify_all(); return true; }
+    cv.wait(lk, [&] { return generation != gen || failed; });
+    return !failed;
+  }
+  void abort() {
+    std::lock_guard<std::mutex> lk(mu);
+    failed = true;
+    cv.notify_all();
+  }
+};
+// set by run_sharded's worker threads around zkr_prove_partial(_device): the proof this thread enqueues is part `shard_group_part`
+// of that group (null: a shard proving on its own -- replicated calcH)
+extern thread_local ShardGroup *shard_group;
+extern thread_local unsigned shard_group_part;
 int fused_capacity(const ArenaHeader &h, const MsmPlan plan[N_TABLES]);
 void arena_layout(ArenaHeader &h);  // section offsets and total_len from the sizes in the header (n, p, m, nnz, n_wide, npts, win_c, sc_n): THE layout, whoever builds an arena
 const char *arena_header_fault(const ArenaHeader &h, size_t len);  // null when a full arena's header is consistent with its sizes

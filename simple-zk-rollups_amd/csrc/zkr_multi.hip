@@ -8,7 +8,11 @@
 // torchrun + RCCL).
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <exception>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -33,10 +37,19 @@ int copy_between_devices(void *dst, int dst_dev, const void *src, int src_dev, s
   return 0;
 }
 
+bool peer_direct_ask(int dst_dev, int src_dev);
 // direct loads/stores between the two devices (xGMI on an MI355X node).  Without it hipMemcpyPeer still works -- staged
 // through host memory by the runtime -- which is what the compact form is for.
 bool peer_direct(int dst_dev, int src_dev) {
   if (dst_dev == src_dev) return true;
+  static std::atomic<int> known[16][16];  // 0 not asked yet, 1 yes, 2 no: asked once per pair (a sharded proof asks for every pair)
+  const bool cached = dst_dev >= 0 && dst_dev < 16 && src_dev >= 0 && src_dev < 16;
+  if (cached && known[dst_dev][src_dev].load()) return known[dst_dev][src_dev].load() == 1;
+  const bool ok = peer_direct_ask(dst_dev, src_dev);
+  if (cached) known[dst_dev][src_dev].store(ok ? 1 : 2);
+  return ok;
+}
+bool peer_direct_ask(int dst_dev, int src_dev) {
   int can = 0;
   if (hipDeviceCanAccessPeer(&can, dst_dev, src_dev) != hipSuccess || !can) return false;
   if (hipSetDevice(dst_dev) != hipSuccess) return false;
@@ -275,6 +288,10 @@ int zkr_key_shard(const zkr_key *src, unsigned part, unsigned parts, int device,
 }  // extern "C"
 
 namespace {
+// phase times of the calling thread's last sharded proof with a split calcH (zkr_prove_sharded_split_stats)
+thread_local double last_split_phase_ms[8][8];
+thread_local unsigned last_split_parts = 0;
+
 template <class Partial>
 int run_sharded(zkr_key *const *shards, size_t parts, const uint8_t *r32, const uint8_t *s32, uint8_t *proof_out, Partial partial) {
   if (!shards || parts == 0 || !proof_out) { set_error("null argument"); return ZKR_ERR_ARG; }
@@ -287,20 +304,66 @@ int run_sharded(zkr_key *const *shards, size_t parts, const uint8_t *r32, const 
   std::vector<uint8_t> partials(parts * ZKR_PARTIAL_BYTES);
   std::vector<int> rcs(parts, 0);
   std::vector<std::string> errs(parts);
+  // The shards run concurrently, so calcH can be split over them instead of repeated by every one (zkr_prove.hip calc_h_split):
+  // a power of two of shards, each owning one aligned block of h with enough columns for its share of the cross passes, and
+  // every device able to read and write every other's memory.  ZKR_SHARD_SPLIT_H=0: every shard computes h for itself.
+  ShardGroup group;
+  group.parts = (unsigned)parts;
+  group.vecs.resize(parts);
+  {
+    const char *e = getenv("ZKR_SHARD_SPLIT_H");
+    const uint32_t m = shards[0]->h.m;
+    int klog = 0;
+    while ((1u << klog) < parts) klog++;
+    bool ok = !(e && atoi(e) == 0) && parts >= 2 && parts <= 8 && (1u << klog) == parts && (m >> (2 * klog)) >= 64;
+    for (size_t i = 0; i < parts && ok; i++) ok = shards[i]->h.sc_n[1] == m >> klog && shards[i]->h.sc_lo[1] == (uint32_t)i * (m >> klog);
+    for (size_t i = 0; i < parts && ok; i++)
+      for (size_t j = 0; j < parts && ok; j++) ok = peer_direct(shards[i]->device, shards[j]->device);
+    group.klog = klog;
+    group.split_h = ok;
+  }
+  // A split calcH makes the shards' threads wait for one another INSIDE their enqueue, each holding its shard's lock: two such
+  // proofs on the same shards at once could wait for each other's locks for ever.  They take turns (locks in address order).
+  std::vector<std::unique_lock<std::mutex>> turn;
+  if (group.split_h) {
+    std::vector<zkr_key *> order(shards, shards + parts);
+    std::sort(order.begin(), order.end());
+    for (zkr_key *k : order) turn.emplace_back(k->split_mu);
+  }
+  std::vector<char> threaded(parts, 0);
   auto work = [&](size_t i) {
+    shard_group = group.split_h && threaded[i] ? &group : nullptr;  // a shard run inline after the others cannot meet them at a barrier
+    shard_group_part = (unsigned)i;
     try {
       rcs[i] = partial(i, &partials[i * ZKR_PARTIAL_BYTES]);
       if (rcs[i]) errs[i] = zkr_last_error();
     } catch (const std::exception &e) { rcs[i] = ZKR_ERR_HIP; errs[i] = e.what(); }
+    if (rcs[i]) group.abort();
+    shard_group = nullptr;
   };
+  // a split calcH needs every shard on a thread of its own, all at once: when a thread cannot be started the group falls back to
+  // replicated calcH BEFORE anybody runs (the threads wait for the decision)
   std::vector<std::thread> thr;
   std::vector<size_t> inline_parts;
+  std::mutex go_mu;
+  std::condition_variable go_cv;
+  bool go = false;
+  auto gated = [&](size_t i) {
+    { std::unique_lock<std::mutex> lk(go_mu); go_cv.wait(lk, [&] { return go; }); }
+    work(i);
+  };
+  threaded[0] = 1;
   for (size_t i = 1; i < parts; i++) {
-    try { thr.emplace_back(work, i); } catch (const std::system_error &) { inline_parts.push_back(i); }
+    try { thr.emplace_back(gated, i); threaded[i] = 1; } catch (const std::system_error &) { inline_parts.push_back(i); }
   }
+  if (!inline_parts.empty()) group.split_h = false;
+  { std::lock_guard<std::mutex> lk(go_mu); go = true; }
+  go_cv.notify_all();
   work(0);
   for (size_t i : inline_parts) work(i);
   for (auto &t : thr) t.join();
+  if (group.split_h) memcpy(last_split_phase_ms, group.phase_ms, sizeof(last_split_phase_ms));
+  last_split_parts = group.split_h ? (unsigned)parts : 0;
   for (size_t i = 0; i < parts; i++)
     if (rcs[i]) { set_error("shard %zu (device %d): %s", i, shards[i]->device, errs[i].c_str()); return rcs[i]; }
   return zkr_prove_combine(shards[0], partials.data(), parts, r32, s32, proof_out);
@@ -313,6 +376,12 @@ int zkr_prove_sharded(zkr_key *const *shards, size_t parts, const void *witness_
                       uint8_t proof_out[256]) {
   if (!witness_std) { set_error("null argument"); return ZKR_ERR_ARG; }
   return run_sharded(shards, parts, r32, s32, proof_out, [&](size_t i, uint8_t *out) { return zkr_prove_partial(shards[i], witness_std, witness_len, out); });
+}
+int zkr_prove_sharded_split_stats(unsigned *parts_out, double phase_ms_out[64]) {
+  if (!parts_out || !phase_ms_out) { set_error("null argument"); return ZKR_ERR_ARG; }
+  *parts_out = last_split_parts;
+  memcpy(phase_ms_out, last_split_phase_ms, sizeof(last_split_phase_ms));
+  return 0;
 }
 int zkr_prove_sharded_device(zkr_key *const *shards, size_t parts, const void *const *d_witnesses_std, const uint8_t *r32, const uint8_t *s32,
                              uint8_t proof_out[256]) {

@@ -135,14 +135,15 @@ static int ntt_tile_log(int L, int nbat) {
 // want_lo / want_n (DIF only; 0, 0 = everything): only positions [want_lo, want_lo + want_n) of the output are wanted -- the
 // passes run on the aligned blocks that cover them (kernels_ntt.hpp NttPassArgs::blk_off); the rest of `out` is left half done
 int run_ntt(hipStream_t s, const Fr *in0, const Fr *in1, Fr *out, const NttTables &tb, int L, bool dif, bool inverse, int pre, int nbat, Prof pf,
-            const Fr *in0_b, const Fr *in1_b, Fr *out_b, uint32_t want_lo, uint32_t want_n) {
+            const Fr *in0_b, const Fr *in1_b, Fr *out_b, uint32_t want_lo, uint32_t want_n, uint32_t coset_shift, uint32_t coset_add) {
   if (want_n && (!dif || (uint64_t)want_lo + want_n > (1ull << L))) { set_error("run_ntt: an output range needs a DIF transform and must lie inside it"); return ZKR_ERR_ARG; }
   const int tile_log = ntt_tile_log(L, nbat * (out_b ? 2 : 1));
   std::vector<PassSpec> plan = ntt_plan(L, tile_log);
   if (!dif) std::reverse(plan.begin(), plan.end());
   bool first = true;
   for (auto &ps : plan) {
-    NttPassArgs a;
+    NttPassArgs a = {};
+    a.pre_shift = coset_shift; a.pre_add = coset_add;  // PRE_COSET of a block of a larger transform (calc_h_split)
     a.in0 = first ? in0 : out;
     a.in1 = first ? in1 : nullptr;
     a.out = out;
@@ -210,10 +211,10 @@ int calc_h_device(zkr_key *k, ProofSlot &sl, hipStream_t s, int nbat) {
                        (const uint32_t *)(ar + h.off_wide[i]), h.n_wide[i]};
   {  // both sides of the QAP in one launch (blockIdx.z): one launch fewer in the chain, twice the workgroups
     const int sa = prof_begin(pf, s, "spmv_a");
-    spmv_kernel<<<dim3((m + 255) / 256, nbat, 2), 256, 0, s>>>(side[0], side[1], sl.d_w, m, h.n);
+    spmv_kernel<<<dim3((m + 255) / 256, nbat, 2), 256, 0, s>>>(side[0], side[1], sl.d_w, m, h.n, 0, m);
     prof_end(pf, s, sa);
     const uint32_t nw = h.n_wide[0] > h.n_wide[1] ? h.n_wide[0] : h.n_wide[1];
-    if (nw) spmv_wide_kernel<<<dim3(nw, nbat, 2), 64, 0, s>>>(side[0], side[1], sl.d_w, m, h.n);
+    if (nw) spmv_wide_kernel<<<dim3(nw, nbat, 2), 64, 0, s>>>(side[0], side[1], sl.d_w, m, h.n, 0, m);
   }
   prof_end(pf, s, sp);
   sp = prof_begin(pf, s, "ntt");
@@ -256,6 +257,162 @@ int calc_h_device(zkr_key *k, ProofSlot &sl, hipStream_t s, int nbat) {
   prof_end(pf, s, csp);
   prof_end(pf, s, sp);
   ZKR_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------ calcH split over the shards of one proof
+thread_local ShardGroup *shard_group = nullptr;
+thread_local unsigned shard_group_part = 0;
+
+// The top klog stages of a transform of 2^L points whose 2^klog blocks live in different buffers (kernels_ntt.hpp CROSS): this
+// shard's columns [col_lo, col_lo + col_n) of every block.  rows_*[r]: where block r starts (x_sub = 0) or where this shard's
+// columns of block r start in a local buffer (x_sub = col_lo).
+static int run_ntt_cross(hipStream_t s, const NttTables &tb, int L, int klog, bool dif, bool inverse, int pre, bool canon, const Fr *const *rows_in0,
+                         const Fr *const *rows_in1, Fr *const *rows_out, uint32_t in_sub, uint32_t out_sub, uint32_t col_lo, uint32_t col_n, Prof pf) {
+  NttPassArgs a = {};
+  a.tw = tb.tw; a.tw29 = tb.tw29; a.twl29 = tb.twl29; a.tlog = tb.tlog; a.L = L;
+  a.lo = L - klog; a.hi = L;
+  int wlog = NTT_TILE_LOG - klog;
+  while ((1u << wlog) > col_n) wlog--;
+  a.wlog = wlog;
+  a.pre = pre;
+  a.canon = canon ? 1 : 0;
+  a.prio = 1;
+  for (int r = 0; r < (1 << klog); r++) { a.x_in0[r] = rows_in0[r]; a.x_in1[r] = rows_in1 ? rows_in1[r] : nullptr; a.x_out[r] = rows_out[r]; }
+  a.x_in_sub = in_sub; a.x_out_sub = out_sub;
+  const uint32_t tile = 1u << (klog + wlog);
+  a.blk_off = col_lo >> wlog;
+  const uint32_t grid = col_n >> wlog;
+  const size_t lds = (size_t)tile * 36;
+  const int psp = prof_begin(pf, s, "ntt_pass");
+  if (dif) { if (inverse) ntt_pass_kernel<true, true, NTT_THREADS_LARGE, true><<<grid, NTT_THREADS_LARGE, lds, s>>>(a); else ntt_pass_kernel<true, false, NTT_THREADS_LARGE, true><<<grid, NTT_THREADS_LARGE, lds, s>>>(a); }
+  else { if (inverse) ntt_pass_kernel<false, true, NTT_THREADS_LARGE, true><<<grid, NTT_THREADS_LARGE, lds, s>>>(a); else ntt_pass_kernel<false, false, NTT_THREADS_LARGE, true><<<grid, NTT_THREADS_LARGE, lds, s>>>(a); }
+  prof_end(pf, s, psp);
+  ZKR_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// calcH of ONE proof split over the P = 2^klog shards that run it (zkr_prove_sharded): shard j owns block j -- positions
+// [j m/P, (j + 1) m/P) -- of every vector, which is also its range of h.  Of a transform's log2 m stages all but the top klog stay
+// inside a block; the top ones (first in the inverse DIF transforms, last in the forward DIT ones) pair the same column of
+// different blocks, and run as CROSS passes in which shard j takes columns [j m/P^2, (j + 1) m/P^2) of every block, reading and
+// writing the other shards' buffers directly (peer access; on one device: plain loads).  Per shard: 1/P of the QAP rows and 1/P
+// of every transform's butterflies instead of four transforms in full and two in part.  Phases, with a host barrier of the
+// group after each (every shard's stream is idle when its thread arrives):
+//   1  QAP rows of the block                                                  -> va, vb (block j)
+//   2  CROSS top stages of iNTT(a), iNTT(b), iNTT(a.b)   [all blocks' va, vb] -> ca, cb, d_h (this shard's columns of every block)
+//   3  the blocks' own stages: rest of iNTT(a), iNTT(b); the coset transforms up to their top stages; rest of iNTT(a.b)
+//   4  CROSS top stages of the coset transforms [all blocks' ca, cb] -> this shard's columns, kept locally (va, vb: free since 2);
+//      their product; CROSS top stages of iNTT(product)                       -> ca (this shard's columns of every block)
+//   5  the block's own stages of that; h = combination on the block           -> d_h (block j).  No barrier: the rest is the shard's own
+// The enqueue lock of the device is released while the thread waits (shards on one device share its streams and its lock).
+static int calc_h_split_phases(zkr_key *k, ProofSlot &sl, hipStream_t s, ShardGroup &g, unsigned part, std::unique_lock<std::mutex> &lock);
+static int calc_h_split(zkr_key *k, ProofSlot &sl, hipStream_t s, ShardGroup &g, unsigned part, std::unique_lock<std::mutex> &lock) {
+  const int rc = calc_h_split_phases(k, sl, s, g, part, lock);
+  if (rc) g.abort();  // whoever waits for this shard (now or at a later barrier) gives up too
+  return rc;
+}
+static int calc_h_split_phases(zkr_key *k, ProofSlot &sl, hipStream_t s, ShardGroup &g, unsigned part, std::unique_lock<std::mutex> &lock) {
+  const Prof pf{k, &sl};
+  const ArenaHeader &h = k->h;
+  const unsigned char *ar = k->arena;
+  const Fr *tw = (const Fr *)(ar + h.off_tw);
+  const int L = (int)h.logm, tlog = (int)h.tlog, klog = g.klog, Lb = L - klog;
+  const NttTables tb{tw, k->tw29, k->twl29, tlog};
+  const uint32_t m = h.m, P = g.parts, Bk = m >> klog, cols = Bk >> klog, col_lo = part * cols, blk = part * Bk;
+  struct timespec t0;
+  int phase = 0;
+  auto phase_begin = [&] { clock_gettime(CLOCK_MONOTONIC, &t0); };
+  // end of a phase: this shard's part of it has run, then everybody's
+  auto phase_end = [&]() -> int {
+    hipError_t e = hipGetLastError();
+    lock.unlock();
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    struct timespec t1;
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    if (phase < 8) g.phase_ms[part][phase] = (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6;
+    phase++;
+    int rc = 0;
+    if (e != hipSuccess) { set_error("split calcH, phase %d: %s", phase, hipGetErrorString(e)); g.abort(); rc = ZKR_ERR_HIP; }
+    else if (!g.barrier()) { set_error("split calcH: another shard of the proof failed"); rc = ZKR_ERR_HIP; }
+    lock.lock();
+    if (!rc) ZKR_HIP_CHECK(hipSetDevice(k->device));
+    return rc;
+  };
+  int rc;
+  // 0: where everybody's vectors are
+  g.vecs[part] = ShardGroup::Vecs{sl.va, sl.vb, sl.ca, sl.cb, sl.d_h};
+  if (g.solo)
+    for (unsigned b = 0; b < P; b++) g.vecs[b] = g.vecs[part];
+  phase_begin();
+  if ((rc = phase_end())) return rc;
+  const Fr *r_va[8], *r_vb[8], *r_ca[8], *r_cb[8], *r_ga[8], *r_gb[8];
+  Fr *w_ca[8], *w_cb[8], *w_dh[8], *w_ga[8], *w_gb[8];
+  for (unsigned b = 0; b < P; b++) {
+    const ShardGroup::Vecs &v = g.vecs[b];
+    r_va[b] = v.va + (size_t)b * Bk; r_vb[b] = v.vb + (size_t)b * Bk;
+    r_ca[b] = w_ca[b] = v.ca + (size_t)b * Bk; r_cb[b] = w_cb[b] = v.cb + (size_t)b * Bk;
+    w_dh[b] = v.dh + (size_t)b * Bk;
+    r_ga[b] = w_ga[b] = sl.va + blk + (size_t)b * cols;  // this shard's columns of block b, kept in its own block of va / vb
+    r_gb[b] = w_gb[b] = sl.vb + blk + (size_t)b * cols;
+  }
+  // 1: QAP rows of the block
+  phase_begin();
+  {
+    const int sp = prof_begin(pf, s, "spmv");
+    SpmvSide side[2];
+    Fr *evals[2] = {sl.va, sl.vb};
+    for (int i = 0; i < 2; i++)
+      side[i] = SpmvSide{(const uint32_t *)(ar + h.off_rowptr[i]), (const uint32_t *)(ar + h.off_col[i]), (const Fr *)(ar + h.off_coef[i]), evals[i],
+                         (const uint32_t *)(ar + h.off_wide[i]), h.n_wide[i]};
+    const int sa = prof_begin(pf, s, "spmv_a");
+    spmv_kernel<<<dim3((Bk + 255) / 256, 1, 2), 256, 0, s>>>(side[0], side[1], sl.d_w, m, h.n, blk, blk + Bk);
+    prof_end(pf, s, sa);
+    const uint32_t nw = h.n_wide[0] > h.n_wide[1] ? h.n_wide[0] : h.n_wide[1];
+    if (nw) spmv_wide_kernel<<<dim3(nw, 1, 2), 64, 0, s>>>(side[0], side[1], sl.d_w, m, h.n, blk, blk + Bk);
+    prof_end(pf, s, sp);
+  }
+  if ((rc = phase_end())) return rc;
+  const int ntt_span = prof_begin(pf, s, "ntt");
+  // 2: top stages of the three inverse transforms that start from the evaluations on the domain
+  phase_begin();
+  if ((rc = run_ntt_cross(s, tb, L, klog, true, true, PRE_NONE, false, r_va, nullptr, w_ca, 0, 0, col_lo, cols, pf))) return rc;
+  if ((rc = run_ntt_cross(s, tb, L, klog, true, true, PRE_NONE, false, r_vb, nullptr, w_cb, 0, 0, col_lo, cols, pf))) return rc;
+  if ((rc = run_ntt_cross(s, tb, L, klog, true, true, PRE_MUL, false, r_va, r_vb, w_dh, 0, 0, col_lo, cols, pf))) return rc;
+  if ((rc = phase_end())) return rc;
+  // 3: the block's own stages
+  phase_begin();
+  {
+    Fr *ca = sl.ca + blk, *cb = sl.cb + blk, *dh = sl.d_h + blk;
+    uint32_t rev = 0;  // the block's index bit-reversed: low bits of its coefficients' indices
+    for (int i = 0; i < klog; i++) rev |= ((part >> i) & 1u) << (klog - 1 - i);
+    if ((rc = run_ntt(s, ca, nullptr, ca, tb, Lb, true, true, PRE_NONE, 1, pf, cb, nullptr, cb))) return rc;              // coefficients of a, b (x m, bit-reversed)
+    if ((rc = run_ntt(s, ca, nullptr, ca, tb, Lb, false, false, PRE_COSET, 1, pf, cb, nullptr, cb, 0, 0, (uint32_t)klog, rev))) return rc;  // coset transforms below their top stages
+    if ((rc = run_ntt(s, dh, nullptr, dh, tb, Lb, true, true, PRE_NONE, 1, pf))) return rc;                             // S' on the block
+  }
+  if ((rc = phase_end())) return rc;
+  // 4: top stages of the coset transforms into local columns, product, top stages of the last inverse transform
+  phase_begin();
+  if ((rc = run_ntt_cross(s, tb, L, klog, false, false, PRE_NONE, true, r_ca, nullptr, w_ga, 0, col_lo, col_lo, cols, pf))) return rc;
+  if ((rc = run_ntt_cross(s, tb, L, klog, false, false, PRE_NONE, true, r_cb, nullptr, w_gb, 0, col_lo, col_lo, cols, pf))) return rc;
+  if ((rc = run_ntt_cross(s, tb, L, klog, true, true, PRE_MUL, false, r_ga, r_gb, w_ca, col_lo, 0, col_lo, cols, pf))) return rc;
+  if ((rc = phase_end())) return rc;
+  // 5: D' on the block, then h
+  phase_begin();
+  if ((rc = run_ntt(s, sl.ca + blk, nullptr, sl.ca + blk, tb, Lb, true, true, PRE_NONE, 1, pf))) return rc;
+  Fr r2 = Fr::r2();
+  Fr minv = inv(to_mont(fr_from_u64(m)));
+  Fr half = inv(to_mont(fr_from_u64(2)));
+  Fr c1v = mul(mul(r2, half), minv);
+  Fr c2v = mul(mul(c1v, minv), minv);
+  const int csp = prof_begin(pf, s, "combine_h");
+  combine_h_kernel<<<dim3((Bk + 255) / 256, 1), 256, 0, s>>>(sl.d_h, sl.ca, sl.d_h, tw, tlog, L, c1v, c2v, sl.dig_h.rng, DIGIT_CLEAR_WORDS, blk, blk + Bk);
+  prof_end(pf, s, csp);
+  prof_end(pf, s, ntt_span);
+  ZKR_HIP_CHECK(hipGetLastError());
+  struct timespec t1;
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  if (phase < 8) g.phase_ms[part][phase] = (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6;  // enqueue time only: nothing waits here
   return 0;
 }
 
@@ -567,7 +724,7 @@ static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *const *d_ws
   clock_gettime(CLOCK_MONOTONIC, &sl.t_submit);
   // The streams are the device's, shared by every key on it (zkr_key.hip DeviceStreams): the launches of one proof are enqueued
   // without another key's in between, so that every cross-stream wait below points at work enqueued before it
-  std::lock_guard<std::mutex> enqueue_lock(*k->enqueue_mu);
+  std::unique_lock<std::mutex> enqueue_lock(*k->enqueue_mu);
 
   // The caller's stream only orders the witness before the proof (it may carry unrelated work, and with two
   // proofs in flight it must not chain them).  Schedule on the key's own streams (HIP multiplexes streams onto a
@@ -650,7 +807,11 @@ static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *const *d_ws
   // stream (tables then accumulate concurrently).  Defaults per key size below.
   static const int sched_env = getenv("ZKR_SCHED") ? atoi(getenv("ZKR_SCHED")) : -1;
   const int sched = sched_env >= 0 ? sched_env : 0;
-  const bool early = (sched & 1) != 0 && !serial, acc_on_chain = (sched & 2) != 0 && !serial;
+  // part of a sharded proof whose calcH is split over the shards (calc_h_split: host barriers in the middle of this enqueue): the
+  // chains of the four w tables are handed over BEFORE it, so that they run while the threads wait for one another
+  ShardGroup *const group = shard_group;
+  const bool split_h = group && group->split_h && !serial && nbat == 1 && h.shard_parts == group->parts && h.shard_part == shard_group_part;
+  const bool early = ((sched & 1) != 0 || split_h) && !serial, acc_on_chain = (sched & 2) != 0 && !serial;
   static const int c_big_env = getenv("ZKR_C_BIG_FIRST") ? atoi(getenv("ZKR_C_BIG_FIRST")) : -1;  // 0 / 1: never / always (A/B)
   const bool c_big_first = merge_ch && !serial && (c_big_env >= 0 ? c_big_env != 0 : (nbat == 1 && sl.cap > 1));
   // nothing else of this key in flight (the caller holds the key's lock: with_free_slot): this proof's last chain is latency
@@ -744,7 +905,9 @@ static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *const *d_ws
   if ((rc = sort_table(T_A))) return rc;
   if (!share_ac && (rc = sort_table(T_C))) return rc;
   if (early && ((rc = c_big()) || (rc = chains({T_A, T_C})))) return rc;
-  if ((rc = calc_h_device(k, sl, sp, nbat))) return rc;
+  if (split_h) rc = calc_h_split(k, sl, sp, *group, shard_group_part, enqueue_lock);
+  else rc = calc_h_device(k, sl, sp, nbat);
+  if (rc) return rc;
   if (!serial) ZKR_HIP_CHECK(hipEventRecord(sl.ev_calch, sp));
   if ((rc = msm_digits_enqueue(pf, sp, sl.d_h + h.sc_lo[1], h.sc_n[1], nbat, k->plan[T_H], sl.dig_h, true))) return rc;
   if ((rc = sort_table(T_H))) return rc;
@@ -1135,6 +1298,33 @@ int zkr_prove_partial(zkr_key *key, const void *witness_std, size_t witness_len,
   rc = prove_collect(key, key->slot[t], nullptr, &ps);
   stage_release(key, st);
   if (!rc) memcpy(partial_out, &ps, sizeof(ps));
+  return rc;
+}
+
+int zkr_bench_shard_split_solo(zkr_key *shard, const void *d_witness_std, double *ms_out) {
+  if (!shard || !d_witness_std || !ms_out) { set_error("null argument"); return ZKR_ERR_ARG; }
+  const ArenaHeader &h = shard->h;
+  int klog = 0;
+  while ((1u << klog) < h.shard_parts) klog++;
+  if (h.shard_parts < 2 || h.shard_parts > 8 || (1u << klog) != h.shard_parts || (h.m >> (2 * klog)) < 64 || h.sc_n[1] != h.m >> klog || h.sc_lo[1] != h.shard_part * (h.m >> klog)) {
+    set_error("not a shard whose calcH can be split (2, 4 or 8 parts, blocks of at least 64 columns per shard)");
+    return ZKR_ERR_ARG;
+  }
+  ShardGroup g;
+  g.parts = h.shard_parts;
+  g.klog = klog;
+  g.vecs.resize(g.parts);
+  g.split_h = true;
+  g.solo = true;
+  uint8_t partial[ZKR_PARTIAL_BYTES];
+  shard_group = &g;
+  shard_group_part = h.shard_part;
+  struct timespec t0, t1;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  const int rc = zkr_prove_partial_device(shard, d_witness_std, nullptr, partial);
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  shard_group = nullptr;
+  *ms_out = (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6;
   return rc;
 }
 

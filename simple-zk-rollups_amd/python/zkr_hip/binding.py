@@ -209,6 +209,13 @@ class ProvingKey:
         _check(lib().zkr_key_shard(self._h, part, parts, dev, ctypes.byref(h)))
         return ProvingKey(h, dev)
 
+    def bench_split_solo(self, d_witness_ptr) -> float:
+        """Measurement only: this shard's share of a proof with a split calcH, alone, own buffers standing in for the other
+        shards' (zkr_bench_shard_split_solo) -> milliseconds.  The result of the computation is meaningless and discarded."""
+        ms = ctypes.c_double(0)
+        _check(lib().zkr_bench_shard_split_solo(self._h, ctypes.c_void_p(d_witness_ptr), ctypes.byref(ms)))
+        return ms.value
+
     def shard_info(self):
         out = (ctypes.c_uint32 * 6)()
         _check(lib().zkr_key_shard_info(self._h, out))
@@ -425,6 +432,17 @@ def prove_sharded_device(shards, d_witness_ptrs, r=None, s=None) -> bytes:
     sb = None if s is None else int(s).to_bytes(32, "little")
     _check(lib().zkr_prove_sharded_device(ks, len(shards), arr, rb, sb, out))
     return out.raw
+
+
+def sharded_split_stats():
+    """Of this thread's last sharded proof: None when every shard computed h for itself, else [part][phase] host milliseconds of
+    the split calcH's phases (zkr_prove_sharded_split_stats)."""
+    parts = ctypes.c_uint(0)
+    ms = (ctypes.c_double * 64)()
+    _check(lib().zkr_prove_sharded_split_stats(ctypes.byref(parts), ms))
+    if parts.value == 0:
+        return None
+    return [[ms[8 * p + f] for f in range(6)] for p in range(parts.value)]
 
 
 def verify(vk_bin: bytes, proof: bytes, public_signals) -> bool:

@@ -101,6 +101,65 @@ def test_ranges_of_h_that_are_not_aligned_blocks(log_m, parts):
     assert key.prove_combine(partials, 21, 22) == want
 
 
+@pytest.mark.parametrize("log_m,parts", [(12, 2), (14, 4), (14, 8), (16, 8), (18, 4), (20, 8), (22, 8)])
+def test_calc_h_split_over_the_shards(log_m, parts, monkeypatch):
+    """zkr_prove_sharded with 2 / 4 / 8 shards splits calcH over them (csrc/zkr_prove.hip calc_h_split: every shard its block of the
+    QAP rows and of every transform, the cross-block stages through the other shards' buffers): the same proof bytes as with h
+    computed by every shard for itself, as the whole key's, as the closed form."""
+    import torch
+    import zkr_hip
+    p = 73
+    key, wb, aux = zkr_hip.ProvingKey.synth(log_m, p, 0x5A4B0001, 0x5A4B00FF, want_aux=log_m <= 18)
+    want = key.prove(wb, 31, 32)
+    if aux is not None:
+        assert want == g.proof_bytes(g.proof_from_aux(aux, wb, p, 31, 32)[0])
+    shards = [key.shard(i, parts) for i in range(parts)]
+    assert zkr_hip.prove_sharded(shards, wb, 31, 32) == want
+    stats = zkr_hip.sharded_split_stats()
+    assert stats is not None and len(stats) == parts and all(ms > 0 for row in stats for ms in row[1:5])
+    dw = torch.frombuffer(bytearray(wb), dtype=torch.uint8).cuda(0)
+    torch.cuda.synchronize()
+    for _ in range(3):                                   # the barriers and the buffers survive being used again
+        assert zkr_hip.prove_sharded_device(shards, [dw.data_ptr()] * parts, 31, 32) == want
+    wb2 = zkr_hip.synth_witness(log_m, p, 0x5A4B0001, 777 + parts)
+    assert zkr_hip.prove_sharded(shards, wb2, 5, 6) == key.prove(wb2, 5, 6)
+    monkeypatch.setenv("ZKR_SHARD_SPLIT_H", "0")
+    assert zkr_hip.prove_sharded(shards, wb, 31, 32) == want and zkr_hip.sharded_split_stats() is None
+    monkeypatch.delenv("ZKR_SHARD_SPLIT_H")
+    # three shards (not a power of two), or blocks too small for the cross passes: every shard for itself, silently
+    if log_m == 12:
+        three = [key.shard(i, 3) for i in range(3)]
+        assert zkr_hip.prove_sharded(three, wb, 31, 32) == want and zkr_hip.sharded_split_stats() is None
+        eight = [key.shard(i, 8) for i in range(8)]      # 2^12 / 64 = 64 columns per shard: still split
+        assert zkr_hip.prove_sharded(eight, wb, 31, 32) == want and zkr_hip.sharded_split_stats() is not None
+    # two sharded proofs on the same shards at once take turns (their threads wait for one another inside the enqueue), a third
+    # caller uses one of the shards on its own meanwhile
+    if log_m == 16:
+        import threading
+        got, errs = {}, []
+        def sharded(tag, r):
+            try:
+                got[tag] = [zkr_hip.prove_sharded(shards, wb, r, 32) for _ in range(4)]
+            except Exception as e:  # noqa: BLE001
+                errs.append(e)
+        def alone():
+            try:
+                got["alone"] = [shards[3].prove_partial(wb) for _ in range(6)]
+            except Exception as e:  # noqa: BLE001
+                errs.append(e)
+        ths = [threading.Thread(target=sharded, args=("x", 31)), threading.Thread(target=sharded, args=("y", 41)), threading.Thread(target=alone)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join(timeout=120)
+        assert not errs and not any(t.is_alive() for t in ths)
+        assert got["x"] == [want] * 4 and got["y"] == [key.prove(wb, 41, 32)] * 4 and len(got["alone"]) == 6
+    # a failing shard (short witness) takes the group down with an error, not with a hang
+    with pytest.raises(zkr_hip.ZkrError):
+        zkr_hip.prove_sharded(shards, wb[:-32], 31, 32)
+    assert zkr_hip.prove_sharded(shards, wb, 31, 32) == want
+
+
 def test_shard_errors_and_memory():
     import zkr_hip
     log_m, p = 12, 73
