@@ -696,11 +696,11 @@ def shard_leg(key, d_wit, parts, want_proof, local):
         # here: every shard's share alone on the GPU with its own buffers standing in for the others' (zkr_bench_shard_split_solo)
         # and, separately, the whole sharded proof with all shards concurrently on this one GPU (same bytes as the whole key's).
         # MODELLED: the exchange -- in the cross passes a shard reads 6 and writes 4 vector-columns-of-every-block, (P - 1) / P of
-        # them in other GPUs' memory, over 7 xGMI links at once at an ASSUMED half of 153 GB/s each -- and 5 host barriers of 50 us.
+        # them in other GPUs' memory, over 7 xGMI links at once at an ASSUMED half of 153 GB/s each -- and 4 host barriers of 50 us.
         solo = max(r["split_calch_solo_ms"] for r in rows)
         remote_bytes = 10 * (m_ // parts) * 32 * (parts - 1) / parts
         exchange_ms = 1e3 * remote_bytes / (7 * 153e9 * 0.5)
-        barriers_ms = 5 * 0.05
+        barriers_ms = 4 * 0.05
         shards_all, agg_ms, agg_rep_ms, same_split = [], None, None, None
         try:                                                            # all shards side by side: may not fit beside the whole key at 2^24
             for i in range(parts):

@@ -173,10 +173,10 @@ int zkr_prove_sharded_device(zkr_key *const *shards, size_t parts, const void *c
  * (each owning one aligned block of h) on devices that can access one another's memory, shard j evaluates 1/parts of the QAP rows
  * and 1/parts of every transform's butterflies; the stages that pair elements of different blocks read and write the other
  * shards' buffers directly (xGMI peer access; shards on one device: plain loads), with a host barrier of the shards' threads
- * between the five phases.  The proof is the same bytes.  ZKR_SHARD_SPLIT_H=0: every shard computes h for itself (what
+ * between the five phases (four barriers).  The proof is the same bytes.  ZKR_SHARD_SPLIT_H=0: every shard computes h for itself (what
  * zkr_prove_partial on its own always does).  zkr_prove_sharded_split_stats: of the calling thread's last sharded proof --
  * *parts_out = its shards if calcH was split (else 0), phase_ms_out[8 * part + phase] = host time of that shard's phase
- * (enqueue until its stream was idle; phases 0..5 as in csrc/zkr_prove.hip calc_h_split). */
+ * (enqueue until its stream was idle; phases 0..4 = 1..5 of csrc/zkr_prove.hip calc_h_split, the last one enqueue time only). */
 int zkr_prove_sharded_split_stats(unsigned *parts_out, double phase_ms_out[64]);
 /* Measurement only (bench.py's shard leg on a one-GPU box): ONE shard runs its share of a proof with a split calcH ALONE, its own
  * buffers standing in for the other shards' -- the time a shard takes with a GPU to itself and no exchange (*ms_out); what it

@@ -298,7 +298,7 @@ static int run_ntt_cross(hipStream_t s, const NttTables &tb, int L, int klog, bo
 // different blocks, and run as CROSS passes in which shard j takes columns [j m/P^2, (j + 1) m/P^2) of every block, reading and
 // writing the other shards' buffers directly (peer access; on one device: plain loads).  Per shard: 1/P of the QAP rows and 1/P
 // of every transform's butterflies instead of four transforms in full and two in part.  Phases, with a host barrier of the
-// group after each (every shard's stream is idle when its thread arrives):
+// group after each of the first four (every shard's stream is idle when its thread arrives):
 //   1  QAP rows of the block                                                  -> va, vb (block j)
 //   2  CROSS top stages of iNTT(a), iNTT(b), iNTT(a.b)   [all blocks' va, vb] -> ca, cb, d_h (this shard's columns of every block)
 //   3  the blocks' own stages: rest of iNTT(a), iNTT(b); the coset transforms up to their top stages; rest of iNTT(a.b)
@@ -340,22 +340,10 @@ static int calc_h_split_phases(zkr_key *k, ProofSlot &sl, hipStream_t s, ShardGr
     return rc;
   };
   int rc;
-  // 0: where everybody's vectors are
+  // where this shard's vectors are: read by the others after the first barrier
   g.vecs[part] = ShardGroup::Vecs{sl.va, sl.vb, sl.ca, sl.cb, sl.d_h};
   if (g.solo)
     for (unsigned b = 0; b < P; b++) g.vecs[b] = g.vecs[part];
-  phase_begin();
-  if ((rc = phase_end())) return rc;
-  const Fr *r_va[8], *r_vb[8], *r_ca[8], *r_cb[8], *r_ga[8], *r_gb[8];
-  Fr *w_ca[8], *w_cb[8], *w_dh[8], *w_ga[8], *w_gb[8];
-  for (unsigned b = 0; b < P; b++) {
-    const ShardGroup::Vecs &v = g.vecs[b];
-    r_va[b] = v.va + (size_t)b * Bk; r_vb[b] = v.vb + (size_t)b * Bk;
-    r_ca[b] = w_ca[b] = v.ca + (size_t)b * Bk; r_cb[b] = w_cb[b] = v.cb + (size_t)b * Bk;
-    w_dh[b] = v.dh + (size_t)b * Bk;
-    r_ga[b] = w_ga[b] = sl.va + blk + (size_t)b * cols;  // this shard's columns of block b, kept in its own block of va / vb
-    r_gb[b] = w_gb[b] = sl.vb + blk + (size_t)b * cols;
-  }
   // 1: QAP rows of the block
   phase_begin();
   {
@@ -373,6 +361,16 @@ static int calc_h_split_phases(zkr_key *k, ProofSlot &sl, hipStream_t s, ShardGr
     prof_end(pf, s, sp);
   }
   if ((rc = phase_end())) return rc;
+  const Fr *r_va[8], *r_vb[8], *r_ca[8], *r_cb[8], *r_ga[8], *r_gb[8];
+  Fr *w_ca[8], *w_cb[8], *w_dh[8], *w_ga[8], *w_gb[8];
+  for (unsigned b = 0; b < P; b++) {
+    const ShardGroup::Vecs &v = g.vecs[b];
+    r_va[b] = v.va + (size_t)b * Bk; r_vb[b] = v.vb + (size_t)b * Bk;
+    r_ca[b] = w_ca[b] = v.ca + (size_t)b * Bk; r_cb[b] = w_cb[b] = v.cb + (size_t)b * Bk;
+    w_dh[b] = v.dh + (size_t)b * Bk;
+    r_ga[b] = w_ga[b] = sl.va + blk + (size_t)b * cols;  // this shard's columns of block b, kept in its own block of va / vb
+    r_gb[b] = w_gb[b] = sl.vb + blk + (size_t)b * cols;
+  }
   const int ntt_span = prof_begin(pf, s, "ntt");
   // 2: top stages of the three inverse transforms that start from the evaluations on the domain
   phase_begin();

@@ -442,7 +442,7 @@ def sharded_split_stats():
     _check(lib().zkr_prove_sharded_split_stats(ctypes.byref(parts), ms))
     if parts.value == 0:
         return None
-    return [[ms[8 * p + f] for f in range(6)] for p in range(parts.value)]
+    return [[ms[8 * p + f] for f in range(5)] for p in range(parts.value)]
 
 
 def verify(vk_bin: bytes, proof: bytes, public_signals) -> bool:
