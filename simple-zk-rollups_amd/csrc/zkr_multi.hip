@@ -364,8 +364,13 @@ int run_sharded(zkr_key *const *shards, size_t parts, const uint8_t *r32, const 
   for (auto &t : thr) t.join();
   if (group.split_h) memcpy(last_split_phase_ms, group.phase_ms, sizeof(last_split_phase_ms));
   last_split_parts = group.split_h ? (unsigned)parts : 0;
-  for (size_t i = 0; i < parts; i++)
-    if (rcs[i]) { set_error("shard %zu (device %d): %s", i, shards[i]->device, errs[i].c_str()); return rcs[i]; }
+  // the shard that failed first, not one that gave up because of it
+  for (int pass = 0; pass < 2; pass++)
+    for (size_t i = 0; i < parts; i++)
+      if (rcs[i] && (pass == 1 || errs[i].find("another shard of the proof failed") == std::string::npos)) {
+        set_error("shard %zu (device %d): %s", i, shards[i]->device, errs[i].c_str());
+        return rcs[i];
+      }
   return zkr_prove_combine(shards[0], partials.data(), parts, r32, s32, proof_out);
 }
 }  // namespace

@@ -157,6 +157,10 @@ def test_calc_h_split_over_the_shards(log_m, parts, monkeypatch):
     # a failing shard (short witness) takes the group down with an error, not with a hang
     with pytest.raises(zkr_hip.ZkrError):
         zkr_hip.prove_sharded(shards, wb[:-32], 31, 32)
+    # ONE shard fails (no witness on its device) while the others are already waiting for it: the group is aborted, and the error
+    # names the shard that failed, not one that gave up
+    with pytest.raises(zkr_hip.ZkrError, match="shard 1 "):
+        zkr_hip.prove_sharded_device(shards, [dw.data_ptr(), 0] + [dw.data_ptr()] * (parts - 2), 31, 32)
     assert zkr_hip.prove_sharded(shards, wb, 31, 32) == want
 
 
