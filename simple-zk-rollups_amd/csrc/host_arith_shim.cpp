@@ -102,7 +102,42 @@ template <class F> static void jac_levels29(const uint8_t *pt, int c, int levels
   }
 }
 
+#include <atomic>
+#include <thread>
+#include "shard_group.hpp"
+
+// ShardGroup on the host: `parts` threads meet at `rounds` barriers; thread `fail_part` (if < parts) aborts the group instead of
+// arriving at barrier `fail_round`.  Returns 0 when every thread saw what it must: all barriers passed in step (nobody a
+// round ahead), or -- with a failure -- every thread returned false at or after the failing round and none hung.
+static int shard_group_selftest(unsigned parts, unsigned rounds, unsigned fail_part, unsigned fail_round) {
+  zkr::ShardGroup g;
+  g.parts = parts;
+  g.vecs.resize(parts);
+  std::vector<std::atomic<unsigned>> at(parts);
+  for (auto &a : at) a.store(0);
+  std::atomic<int> bad{0};
+  auto work = [&](unsigned i) {
+    for (unsigned r = 0; r < rounds; r++) {
+      if (i == fail_part && r == fail_round) { g.abort(); return; }
+      at[i].store(r + 1);
+      const bool ok = g.barrier();
+      if (!ok) { if (fail_part >= parts || r < fail_round) bad++; return; }  // a refusal without (or before) the failure
+      for (unsigned j = 0; j < parts; j++)
+        if (at[j].load() < r + 1) bad++;                                     // somebody had not arrived: the barrier let us through early
+    }
+    if (fail_part < parts && fail_round < rounds) bad++;                     // ran to the end although a shard failed
+  };
+  std::vector<std::thread> thr;
+  for (unsigned i = 1; i < parts; i++) thr.emplace_back(work, i);
+  work(0);
+  for (auto &t : thr) t.join();
+  return bad.load();
+}
+
 extern "C" {
+int zkr_host_shard_group_selftest(unsigned parts, unsigned rounds, unsigned fail_part, unsigned fail_round) {
+  return shard_group_selftest(parts, rounds, fail_part, fail_round);
+}
 // field 0 = Fq, 1 = Fr; ops: see f29_op above; inputs / outputs standard form
 void zkt29_fp(int field, int op, const uint8_t *a, const uint8_t *b, uint8_t *out) {
   if (field == 0) f29_op<Fq29>(op, a, b, out); else f29_op<Fr29>(op, a, b, out);

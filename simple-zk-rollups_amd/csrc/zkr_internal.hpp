@@ -9,6 +9,7 @@
 #include <vector>
 #include "../../include/zkr.h"
 #include "hostops.hpp"
+#include "shard_group.hpp"
 
 namespace zkr {
 
@@ -221,37 +222,7 @@ int run_ntt(hipStream_t s, const Fr *in0, const Fr *in1, Fr *out, const NttTable
             uint32_t coset_shift = 0, uint32_t coset_add = 0);  // PRE_COSET when the transform is one block of a larger one (NttPassArgs::pre_shift)
 int calc_h_device(zkr_key *k, ProofSlot &sl, hipStream_t s, int nbat = 1);  // sl.d_w -> sl.d_h (bit-reversed), nbat vectors end to end
 
-// The shards of ONE proof running concurrently in this process (zkr_multi.hip run_sharded), one host thread each: what a split
-// calcH needs from the others -- where their vectors are, and a barrier.  A shard that fails aborts the group: everybody waiting
-// (now or later) returns false instead of waiting for a thread that will never arrive.
-struct ShardGroup {
-  struct Vecs { Fr *va, *vb, *ca, *cb, *dh; };
-  unsigned parts = 0;
-  int klog = 0;                       // parts = 2^klog
-  std::vector<Vecs> vecs;             // [part], published by the part's thread before the first barrier
-  bool split_h = false;               // every precondition of the split holds (zkr_multi.hip run_sharded)
-  bool solo = false;                  // measurement only (zkr_bench_shard_split_solo): ONE shard runs its phases with its own buffers
-                                      // standing in for the others' -- the time of a shard alone on its GPU, the result meaningless
-  double phase_ms[8][8] = {};         // [part][phase]: host time enqueue -> stream idle of the split's phases (bench / tests)
-  std::mutex mu;
-  std::condition_variable cv;
-  unsigned waiting = 0, generation = 0;
-  bool failed = false;
-  bool barrier() {                    // false: the group was aborted
-    std::unique_lock<std::mutex> lk(mu);
-    if (failed) return false;
-    if (solo) return true;
-    const unsigned gen = generation;
-    if (++waiting == parts) { waiting = 0; generation++; cv.notify_all(); return true; }
-    cv.wait(lk, [&] { return generation != gen || failed; });
-    return !failed;
-  }
-  void abort() {
-    std::lock_guard<std::mutex> lk(mu);
-    failed = true;
-    cv.notify_all();
-  }
-};
+// ShardGroup (the shards of one proof running concurrently; barrier + abort): shard_group.hpp, no HIP in it
 // set by run_sharded's worker threads around zkr_prove_partial(_device): the proof this thread enqueues is part `shard_group_part`
 // of that group (null: a shard proving on its own -- replicated calcH)
 extern thread_local ShardGroup *shard_group;

@@ -365,9 +365,9 @@ static int calc_h_split_phases(zkr_key *k, ProofSlot &sl, hipStream_t s, ShardGr
   Fr *w_ca[8], *w_cb[8], *w_dh[8], *w_ga[8], *w_gb[8];
   for (unsigned b = 0; b < P; b++) {
     const ShardGroup::Vecs &v = g.vecs[b];
-    r_va[b] = v.va + (size_t)b * Bk; r_vb[b] = v.vb + (size_t)b * Bk;
-    r_ca[b] = w_ca[b] = v.ca + (size_t)b * Bk; r_cb[b] = w_cb[b] = v.cb + (size_t)b * Bk;
-    w_dh[b] = v.dh + (size_t)b * Bk;
+    r_va[b] = (const Fr *)v.va + (size_t)b * Bk; r_vb[b] = (const Fr *)v.vb + (size_t)b * Bk;
+    r_ca[b] = w_ca[b] = (Fr *)v.ca + (size_t)b * Bk; r_cb[b] = w_cb[b] = (Fr *)v.cb + (size_t)b * Bk;
+    w_dh[b] = (Fr *)v.dh + (size_t)b * Bk;
     r_ga[b] = w_ga[b] = sl.va + blk + (size_t)b * cols;  // this shard's columns of block b, kept in its own block of va / vb
     r_gb[b] = w_gb[b] = sl.vb + blk + (size_t)b * cols;
   }

@@ -337,3 +337,15 @@ def test_inversion_free_miller_loop_equals_the_affine_one(L):
     g2 = b"".join(int(v).to_bytes(32, "little") for v in (b.G2_GEN[0][0], b.G2_GEN[0][1], b.G2_GEN[1][0], b.G2_GEN[1][1]))
     L.zkt_miller_loops_agree.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_int]
     assert L.zkt_miller_loops_agree(g1, g2, 0x5A4B0999, 3) == 12
+
+
+def test_shard_group_barrier_and_abort(L):
+    """csrc/shard_group.hpp (the barrier of a sharded proof's host threads, zkr_prove.hip calc_h_split): threads pass the
+    barriers in step; a thread that fails instead of arriving releases everybody with a refusal, at whatever round."""
+    L.zkr_host_shard_group_selftest.restype = ctypes.c_int
+    L.zkr_host_shard_group_selftest.argtypes = [ctypes.c_uint] * 4
+    for parts in (1, 2, 3, 8):
+        assert L.zkr_host_shard_group_selftest(parts, 50, 99, 0) == 0               # nobody fails
+        for fail_part in {0, parts - 1}:
+            for fail_round in (0, 1, 7, 49):
+                assert L.zkr_host_shard_group_selftest(parts, 50, fail_part, fail_round) == 0
