@@ -243,8 +243,11 @@ int zkr_key_shard(const zkr_key *src, unsigned part, unsigned parts, int device,
     h.win_c[t] = c;
   }
   arena_layout(h);
+  // peer access between the shard's device and every other one, both ways, BEFORE anything of the shard is allocated: its
+  // siblings' kernels read and write its vectors directly when a sharded proof splits calcH (zkr_prove.hip calc_h_split)
+  for (int d = 0, nd = zkr_device_count(); d < nd; d++)
+    if (d != device) { (void)peer_direct(device, d); (void)peer_direct(d, device); }
   ZKR_HIP_CHECK(hipSetDevice(device));
-  (void)peer_direct(device, src->device);
   DevBuf buf;
   if (int rc = buf.alloc(h.total_len)) return rc;
   unsigned char *arena = buf.as<unsigned char>();
