@@ -4,7 +4,7 @@
 # AB_STEPS=20: another size.  AB_NO_RATE=1: kernel times and traffic only.
 cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:?}" || exit 1
 O=gpurun_out/${1:-abenv}; mkdir -p $O; shift
-ARGS="$AB_BENCH_ARGS --steps 3 --warmup 1 --no-cpu-baseline --no-js-baseline --no-pipeline --no-tx-circuit --no-bcast-modes"
+ARGS="$AB_BENCH_ARGS --steps 3 --warmup 1 --no-cpu-baseline --no-js-baseline --no-pipeline --no-tx-circuit --no-bcast-modes --shards 0"
 i=0
 for v in "$@"; do
   [ "$v" = "-" ] && v=""
@@ -20,6 +20,6 @@ done
 [ -n "$AB_NO_RATE" ] && exit 0
 for r in 1 2; do for v in "$@"; do
   [ "$v" = "-" ] && v=""
-  ( [ -n "$v" ] && export $v; python3 bench.py $AB_BENCH_ARGS --steps ${AB_STEPS:-40} --warmup 5 --no-cpu-baseline --no-js-baseline --no-tx-circuit --no-bcast-modes 2>/dev/null | python3 -c "
+  ( [ -n "$v" ] && export $v; python3 bench.py $AB_BENCH_ARGS --steps ${AB_STEPS:-40} --warmup 5 --no-cpu-baseline --no-js-baseline --no-tx-circuit --no-bcast-modes --shards 0 2>/dev/null | python3 -c "
 import json,sys; d=json.loads(sys.stdin.read()); print('[$v] round $r: %.2f proofs/s' % d['value'], {k: round(x,2) for k,x in d['stage_ms_per_proof'].items()})" )
 done; done

@@ -1,6 +1,6 @@
 cd "${GRAFT_REPO_ROOT:?}" || exit 1
 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
-B="--no-cpu-baseline --no-js-baseline --no-tx-circuit --no-bcast-modes"
+B="--no-cpu-baseline --no-js-baseline --no-tx-circuit --no-bcast-modes --shards 0"
 for r in 1 2; do
 for v in "" "ZKR_HIP_LIB=tools/bin/libzkr_hip_prep3.so" "ZKR_HIP_LIB=tools/bin/libzkr_hip_prep3.so ZKR_NTT_PRIO=3" "ZKR_NTT_PRIO=3"; do
   echo "== [$v] pipelined / sync"

@@ -1,5 +1,5 @@
 cd "${GRAFT_REPO_ROOT:?}" || exit 1
-LIGHT="--no-cpu-baseline --no-tx-circuit --no-bcast-modes --no-js-baseline"
+LIGHT="--no-cpu-baseline --no-tx-circuit --no-bcast-modes --shards 0 --no-js-baseline"
 for v in "" "ZKR_SORT_NBL=8192 ZKR_MSM_J=16" "ZKR_SORT_NBL=8192 ZKR_MSM_J=64" "ZKR_MSM_J=16"; do
   echo "== [$v]"
   env $v python3 bench.py --log-m 24 --steps 6 --warmup 1 $LIGHT 2>/dev/null | python3 -c "

@@ -9,7 +9,7 @@ for r in $(seq 1 $N); do
     name=${spec%%:*}; envs=${spec#*:}
     ( IFS=,; for kv in $envs; do [ -n "$kv" ] && export "$kv"; done; unset IFS
       [ -n "$ZKR_HIP_LIB" ] && export ZKR_HIP_LIB=$(realpath $ZKR_HIP_LIB)
-      python bench.py --no-cpu-baseline --no-js-baseline --no-bcast-modes ${ZKR_AB_ARGS:-} 2>/dev/null | python3 -c "
+      python bench.py --no-cpu-baseline --no-js-baseline --no-bcast-modes --shards 0 ${ZKR_AB_ARGS:-} 2>/dev/null | python3 -c "
 import json,sys; d=json.loads(sys.stdin.read()); v=d['roofline']['valu']
 tx=(d.get('tx_circuit') or {}).get('proofs_per_s') or 0
 b=d['config'].get('boundary') or {}

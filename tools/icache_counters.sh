@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:?}" || exit 1
 O=gpurun_out/icache; mkdir -p $O
-LIGHT="--no-cpu-baseline --no-js-baseline --no-tx-circuit --no-bcast-modes"
+LIGHT="--no-cpu-baseline --no-js-baseline --no-tx-circuit --no-bcast-modes --shards 0"
 rocprofv3 --list-avail 2>/dev/null | grep -B3 "SQ_IFETCH_LEVEL, HIGH_RES" | head -8
 for c in SQC_ICACHE_REQ SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH; do
   ZKR_SERIAL=1 timeout 600 rocprofv3 --kernel-trace --pmc $c -d $O/$c -- python3 bench.py --steps 2 --warmup 1 --no-pipeline $LIGHT > /dev/null 2>$O/$c.err

@@ -7,7 +7,7 @@
 # rocprofv3 is always given the program itself after `--` (python3 ...), and --pmc passes carry --kernel-trace only.
 cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:?}" || exit 1
 PART=${1:-a}; O=gpurun_out/${2:-r3p}; mkdir -p $O
-LIGHT="--no-cpu-baseline --no-js-baseline --no-tx-circuit --no-bcast-modes"
+LIGHT="--no-cpu-baseline --no-js-baseline --no-tx-circuit --no-bcast-modes --shards 0"
 if [ $PART = a ]; then
   python3 bench.py --no-pipeline $LIGHT > $O/bench_sync.json 2>/dev/null
   python3 bench.py --log-m 22 --steps 20 $LIGHT > $O/bench_2_22.json 2>/dev/null

@@ -9,12 +9,12 @@
 # rocprofv3 is always given the program itself after `--` (python3 ...), and --pmc passes carry --kernel-trace only.
 cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:?}" || exit 1
 PART=${1:-a}; O=gpurun_out/${2:-r4p}; mkdir -p $O
-LIGHT="--no-cpu-baseline --no-js-baseline --no-tx-circuit --no-bcast-modes"
+LIGHT="--no-cpu-baseline --no-js-baseline --no-tx-circuit --no-bcast-modes --shards 0"
 if [ $PART = a ]; then
   python3 bench.py --no-pipeline $LIGHT > $O/bench_sync.json 2>/dev/null
-  python3 bench.py --log-m 22 --steps 20 --shards 8 $LIGHT > $O/bench_2_22.json 2>/dev/null
-  python3 bench.py --log-m 24 --steps 6 --warmup 1 --shards 8 $LIGHT > $O/bench_2_24_rollup.json 2>/dev/null
-  python3 bench.py --log-m 24 --shape dense --steps 6 --warmup 1 --shards 8 $LIGHT > $O/bench_2_24_dense.json 2>/dev/null
+  python3 bench.py --log-m 22 --steps 20 $LIGHT --shards 8 > $O/bench_2_22.json 2>/dev/null
+  python3 bench.py --log-m 24 --steps 6 --warmup 1 $LIGHT --shards 8 > $O/bench_2_24_rollup.json 2>/dev/null
+  python3 bench.py --log-m 24 --shape dense --steps 6 --warmup 1 $LIGHT --shards 8 > $O/bench_2_24_dense.json 2>/dev/null
   python3 bench.py --gpus 2 --inproc --devices 0,0 --steps 20 --warmup 3 > $O/bench_inproc_0_0.json 2>/dev/null
   for f in bench_sync bench_2_22 bench_2_24_rollup bench_2_24_dense bench_inproc_0_0; do python3 -c "
 import json; d=json.load(open('$O/$f.json')); s=d.get('intra_proof_sharding') or {}

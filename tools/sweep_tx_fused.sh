@@ -1,6 +1,6 @@
 # Knob sweep on the fused tx-circuit rate (bench.py tx_circuit leg), same box, two rounds
 cd "${GRAFT_REPO_ROOT:?}" || exit 1
-B="--no-cpu-baseline --no-js-baseline --no-bcast-modes --steps 64"
+B="--no-cpu-baseline --no-js-baseline --no-bcast-modes --shards 0 --steps 64"
 for r in 1 2; do for v in "ZKR_UNUSED=0" "ZKR_FUSE=4" "ZKR_FUSE=16" "ZKR_MSM_GLOG=1" "ZKR_MSM_GLOG=3" "ZKR_MSM_J=8" "ZKR_MSM_J=32" "ZKR_DIGITS_SPT=1" "ZKR_DIGITS_SPT=2" "ZKR_SORT_NBL=1024" "ZKR_SORT_NBL=4096" "ZKR_ACC_W_G1=3"; do
   env $v python3 bench.py $B 2>/dev/null | python3 -c "
 import json,sys; d=json.loads(sys.stdin.read()); print('[$v] round $r:', round(d['tx_circuit']['proofs_per_s'],1), round(d['facade_pipeline_1024']['end_to_end_proofs_per_s'],1))"
