@@ -1,5 +1,5 @@
 """Soak test of the concurrent paths on one GPU: for `seconds`, several host threads prove on the SAME key material at once --
-batches over two replicas (zkr_prove_batch_multi), sharded proofs over four shards (zkr_prove_sharded), single synchronous
+batches over two replicas (zkr_prove_batch_multi), sharded proofs over four shards from two callers (zkr_prove_sharded), single synchronous
 proofs and pipelined device batches on the whole key -- with random blinding; every proof goes through the native verifier
 (zkr_verify_batch) and a sample is compared with the toxic-waste closed form.  Prints counts; exits non-zero on any failure.
     python tools/soak.py [log_m=16] [seconds=120]"""
@@ -47,8 +47,8 @@ def multi_batches(tag, seed):
         i += 1
 
 
-def sharded(tag):
-    i = 0
+def sharded(tag, start=0):
+    i = start
     while time.time() < stop and not failures:
         k = i % len(wbs)
         r, s = 1000 + i, 7000 + 3 * i
@@ -80,7 +80,8 @@ def device_batches(tag):
 
 
 threads = [threading.Thread(target=multi_batches, args=("multi_a", 0)), threading.Thread(target=multi_batches, args=("multi_b", 5)),
-           threading.Thread(target=sharded, args=("sharded",)), threading.Thread(target=singles, args=("single",)),
+           threading.Thread(target=sharded, args=("sharded",)), threading.Thread(target=sharded, args=("sharded_b", 1)),  # two at once: they take turns (calcH split over the shards)
+           threading.Thread(target=singles, args=("single",)),
            threading.Thread(target=device_batches, args=("device_batch",))]
 t0 = time.time()
 for t in threads:
@@ -89,6 +90,6 @@ for t in threads:
     t.join()
 el = time.time() - t0
 total = sum(counts.values())
-print("soak 2^%d, %.0f s, 5 host threads on one key + one replica + four shards: %d proofs verified (%s), %.0f proofs/s, failures: %s"
+print("soak 2^%d, %.0f s, 6 host threads on one key + one replica + four shards: %d proofs verified (%s), %.0f proofs/s, failures: %s"
       % (log_m, el, total, ", ".join("%s %d" % kv for kv in sorted(counts.items())), total / el, failures or "none"))
 sys.exit(1 if failures else 0)
