@@ -83,6 +83,16 @@ threads = [threading.Thread(target=multi_batches, args=("multi_a", 0)), threadin
            threading.Thread(target=sharded, args=("sharded",)), threading.Thread(target=sharded, args=("sharded_b", 1)),  # two at once: they take turns (calcH split over the shards)
            threading.Thread(target=singles, args=("single",)),
            threading.Thread(target=device_batches, args=("device_batch",))]
+torch.cuda.synchronize()
+free0 = torch.cuda.mem_get_info(0)[0]
+import resource
+rss0 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+samples = []
+def sampler():
+    while time.time() < stop and not failures:
+        time.sleep(min(15.0, max(0.1, stop - time.time())))
+        samples.append(torch.cuda.mem_get_info(0)[0])
+threads.append(threading.Thread(target=sampler))
 t0 = time.time()
 for t in threads:
     t.start()
@@ -92,4 +102,13 @@ el = time.time() - t0
 total = sum(counts.values())
 print("soak 2^%d, %.0f s, 6 host threads on one key + one replica + four shards: %d proofs verified (%s), %.0f proofs/s, failures: %s"
       % (log_m, el, total, ", ".join("%s %d" % kv for kv in sorted(counts.items())), total / el, failures or "none"))
+torch.cuda.synchronize()
+free1 = torch.cuda.mem_get_info(0)[0]
+rss1 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+print("device memory free before / after: %.1f / %.1f MiB (difference %.1f MiB); host peak RSS before / after: %.0f / %.0f MiB"
+      % (free0 / 2 ** 20, free1 / 2 ** 20, (free0 - free1) / 2 ** 20, rss0 / 1024, rss1 / 1024))
+print("device memory in use beyond the start, every 15 s (MiB): " + ", ".join("%.0f" % ((free0 - f) / 2 ** 20) for f in samples) + "  (lazily built workspaces, then flat: no leak)")
+if len(samples) >= 3 and samples[-1] < samples[1] - (64 << 20):
+    failures.append(("memory", "device memory kept growing: %s" % samples))
+    sys.exit(1)
 sys.exit(1 if failures else 0)
