@@ -220,3 +220,33 @@ def test_real_tx_circuit_sharded():
     shards = [key.shard(i, 3) for i in range(3)]
     assert zkr_hip.prove_sharded(shards, wb, 12345, 67890) == key.prove(wb, 12345, 67890)
     assert zkr_hip.verify(vk_bin, zkr_hip.prove_sharded(shards, wb), circ.public_signals(wb))
+
+
+def test_keys_come_and_go_without_leaking_device_memory(tmp_path):
+    """Replicas, shards (with their rebuilt window levels), packed-file reloads and fresh keys created, used and closed in a loop:
+    device memory returns to where it was (tools/key_lifecycle.py is the longer form)."""
+    import torch
+    import zkr_hip
+    log_m = 12
+    key, wb, _ = zkr_hip.ProvingKey.synth(log_m, 73, 0x5A4B0001, 0x5A4B00FF, want_aux=False)
+    want = key.prove(wb, 3, 4)
+    path = str(tmp_path / "k.zkrkey")
+    key.save(path)
+
+    def one_round():
+        rep = key.replicate(0, "base")
+        assert rep.prove(wb, 3, 4) == want
+        shards = [key.shard(i, 4) for i in range(4)]
+        assert zkr_hip.prove_sharded(shards, wb, 3, 4) == want
+        again = zkr_hip.ProvingKey.load_file(path)
+        assert again.prove_batch([wb, wb], [3, 3], [4, 4]) == [want, want]
+        for k in [rep, again] + shards:
+            k.close()
+
+    one_round()                                   # what is built once per process or per key is in place
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info(0)[0]
+    for _ in range(5):
+        one_round()
+    torch.cuda.synchronize()
+    assert free0 - torch.cuda.mem_get_info(0)[0] <= 8 << 20
