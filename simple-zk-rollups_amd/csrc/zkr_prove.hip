@@ -416,7 +416,10 @@ static int calc_h_split_phases(zkr_key *k, ProofSlot &sl, hipStream_t s, ShardGr
 
 // ------------------------------------------------------------------ MSM driver
 template <class F> struct MsmCfg;
-template <> struct MsmCfg<Fq> { static constexpr int ACC_W = 2, RED_W = 2; static constexpr bool ACC_PREFETCH = true; static constexpr const char *ACC_STAGE = "msm_accum_g1"; };
+#ifndef ZKR_RED_W_G1
+#define ZKR_RED_W_G1 2
+#endif
+template <> struct MsmCfg<Fq> { static constexpr int ACC_W = 2, RED_W = ZKR_RED_W_G1; static constexpr bool ACC_PREFETCH = true; static constexpr const char *ACC_STAGE = "msm_accum_g1"; };
 // RED_W = minimum wavefronts per SIMD the oversized-bucket and reduction kernels are compiled for, i.e. their register
 // ceiling (512 / RED_W): they are few long-running wavefronts that must find room on SIMDs whose register file two
 // accumulation wavefronts already fill to 2 x 156 of 512 (G1).  Unconstrained, the G2 forms take ~400 VGPRs on the
