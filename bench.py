@@ -70,6 +70,9 @@ def cpu_baseline(sample_log_m, target_log_m, gpu_key=None):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import coracle
     import zkr_hip
+    # BASELINE.md section 3 promises `-O3 -march=native`: the shipped library is the portable x86-64-v2 build (it has to run on
+    # whatever CPU the box has), so the timed one is compiled here, on this host, before the first call
+    build = coracle.use_native()
     pkb, wb = zkr_hip.synth_websnark(sample_log_m, N_PUBLIC, CIRCUIT_SEED, TOXIC_SEED, device=0)
     r, s = 12345, 67890
     t0 = time.time()
@@ -85,13 +88,15 @@ def cpu_baseline(sample_log_m, target_log_m, gpu_key=None):
     how = "measured at m=2^%d (the benchmarked size, no extrapolation)" % sample_log_m if scale == 1.0 else \
           "measured at m=2^%d, value = 1/(t * 2^%d) i.e. linearly scaled to m=2^%d" % (sample_log_m, target_log_m - sample_log_m, target_log_m)
     return {"value": 1.0 / (dt * scale), "unit": "proofs/s", "cores": 1, "kind": "port",
-            "sample": "oracle/zkr_oracle.c zo_prove, 1 thread, one proof of the rollup-shaped key: %.2f s (calcH %.2f s, MSM %.2f s); %s" % (dt, tm[0], tm[1], how),
-            "seconds_per_proof": dt * scale,
+            "sample": "zo_prove 1 thread, %s, one 2^%d proof: %.2f s (calcH %.2f, MSM %.2f); %s" % (build, sample_log_m, dt, tm[0], tm[1], how),
+            "seconds_per_proof": dt * scale, "build": build,
+            # the same figures as scalars: the driver's record keeps scalars and short strings only
+            "all_threads_proofs_per_s": 1.0 / (dtm * scale), "all_threads_cores": int(tmm[3]), "all_threads_seconds_per_proof": dtm * scale,
             "all_threads": {"value": 1.0 / (dtm * scale), "unit": "proofs/s", "cores": int(tmm[3]), "kind": "port",
                             "sample": "oracle/zkr_oracle.c zo_prove_mt (OpenMP: five multiexps cut into point slices, parallel NTT butterflies), %d threads, "
                                       "same key and witness: %.2f s (calcH %.2f s, MSM %.2f s); %s" % (int(tmm[3]), dtm, tmm[0], tmm[1], how),
                             "seconds_per_proof": dtm * scale},
-            "cpu_proofs_identical_to_each_other_and_to_the_gpu_proof": bool(same)}
+            "cpu_and_gpu_proofs_identical": bool(same)}
 
 
 def cpu_baseline_js(sample_log_m, target_log_m):
@@ -364,6 +369,130 @@ def tx_circuit_leg(local, steps, batch=2, depth=6):
             "proofs_verified": ok, "facade_sequential": seq}
 
 
+def size_leg(local, log_m, shape="rollup", steps=6, warmup=2, peak_gmul=None, device_state=None):
+    """Another BASELINE.json config on this GPU, beside the headline line: configs[2] (2^22 rollup-shaped, the default leg) or
+    configs[4] (2^24 dense random, --with-2-24-dense).  Same measurement as the headline at its size: key computed on the
+    device, resident witnesses, `steps` pipelined proofs timed, every one through the native verifier afterwards (the vk
+    comes from the setup, not from the proofs), the dominant kernel's roofline by the same formula, and the synchronous
+    proof a single awaiting caller sees.  Returns a dict; the caller copies the rates into `config` / `roofline` as scalars."""
+    import torch
+    import zkr_hip
+    zkr_hip.synth_set_shape(1 if shape == "dense" else 0)
+    try:
+        t0 = time.time()
+        key, w0, aux = zkr_hip.ProvingKey.synth(log_m, N_PUBLIC, CIRCUIT_SEED, TOXIC_SEED, device=local, want_aux=True)
+        vk_bin = key.synth_vk(aux)
+        del aux
+        wits = [torch.frombuffer(bytearray(w0), dtype=torch.uint8).cuda(local),
+                torch.frombuffer(bytearray(zkr_hip.synth_witness(log_m, N_PUBLIC, CIRCUIT_SEED, CIRCUIT_SEED + 1)), dtype=torch.uint8).cuda(local)]
+        del w0
+        setup_s = time.time() - t0
+        info = key.info()
+        stream = torch.cuda.current_stream().cuda_stream
+        run = lambda first, count: key.prove_batch_device([wits[i % 2].data_ptr() for i in range(first, first + count)],
+                                                          [3000003 + i for i in range(first, first + count)],
+                                                          [4000003 + i for i in range(first, first + count)], stream)
+        run(0, warmup)
+        key.prof_enable(True)
+        key.prof_reset()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        proofs = run(0, steps)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t1
+        prof = key.prof()
+        key.prof_enable(False)
+        pubs = [public_signals_of(w) for w in wits]
+        verify_timed_proofs(vk_bin, proofs, lambda i: pubs[i % 2])
+        roofline, _ = roofline_record(key, info, prof, el / steps, device_state, log_m, shape, local, peak_gmul=peak_gmul)
+        key.prove_device(wits[0].data_ptr(), r=5, s=7, stream=stream)
+        t1 = time.perf_counter()
+        for i in range(3):
+            key.prove_device(wits[i % 2].data_ptr(), r=21 + i, s=23 + i, stream=stream)
+        sync_ms = 1e3 * (time.perf_counter() - t1) / 3
+        arena = key.arena()[1]
+        key.close()
+        return {"workload": "2^%d-constraint synthetic %s" % (log_m, "rollup circuit" if shape == "rollup" else "dense random R1CS"),
+                "proofs": steps, "proofs_per_s": steps / el, "ms_per_proof": 1e3 * el / steps, "sync_latency_ms": sync_ms, "proofs_verified": steps,
+                "setup_s": setup_s, "arena_bytes": arena, "nVars": info["nVars"], "nnzA": info["nnzA"], "nnzB": info["nnzB"],
+                "roofline": {k: v for k, v in roofline.items() if k not in ("streaming", "note")},
+                "stage_ms_per_proof": {k: v[0] / steps for k, v in prof.items()}}
+    finally:
+        zkr_hip.synth_set_shape(0)
+
+
+def withdraw_leg(local, steps=256):
+    """The reference's MOST-CALLED proof (operator/src/snarks/withdraw.ts:6-10 = createProofGenerator on withdraw.circom; five call
+    sites in contracts/__tests__/rollup.test.ts:105,179,208,233,295): Withdraw() through the same three forms as the tx circuit --
+    one awaited proof from a host witness (what `genWithdrawVerifierProof` awaits), the reference's unchanged drop-in call
+    (new Bn128 object + provingKeyBin per proof: key cache), and fused batches of resident witnesses.  Every proof verified."""
+    import torch
+    import zkr_hip
+    from zkr_hip import rollup
+    circ = rollup.WithdrawCircuit()
+    r1cs = circ.r1cs()
+    key, vk_bin = zkr_hip.ProvingKey.setup_r1cs(r1cs, device=local)
+    pkb, vk_bin2 = zkr_hip.setup_r1cs_websnark(r1cs, device=local)
+    privs = [0x5A4B2000 + 104729 * i for i in range(8)]
+    t1 = time.perf_counter()
+    wbs = [circ.calculate_witness({"privateKey": rollup.format_priv_key(pv), "nullifier": 1000 + i}) for i, pv in enumerate(privs)]
+    wit_ms = 1e3 * (time.perf_counter() - t1) / len(privs)
+    pubs = [circ.public_signals(wb) for wb in wbs]
+    info = key.info()
+    # (1) one awaited proof at a time from a host buffer
+    for i in range(4):
+        key.prove(wbs[i % 8])
+    times, single = [], []
+    for i in range(24):
+        t1 = time.perf_counter()
+        single.append(key.prove(wbs[i % 8]))
+        times.append(1e3 * (time.perf_counter() - t1))
+    ok = zkr_hip.verify_batch(vk_bin, single, [pubs[i % 8] for i in range(24)])
+    single_ms = sorted(times)[len(times) // 2]
+    # (2) the reference's sequence: calculateWitness -> groth16GenProof -> isValid (common.ts:15-38)
+    parts = [0.0, 0.0, 0.0]
+    n_seq = 12
+    for it in range(n_seq):
+        ta = time.perf_counter()
+        wb = circ.calculate_witness({"privateKey": rollup.format_priv_key(privs[it % 8]), "nullifier": 1000 + it % 8})
+        tb = time.perf_counter()
+        pr = key.prove(wb)
+        tc = time.perf_counter()
+        ok = zkr_hip.verify(vk_bin, pr, circ.public_signals(wb)) and ok
+        td = time.perf_counter()
+        parts = [parts[0] + tb - ta, parts[1] + tc - tb, parts[2] + td - tc]
+    # (3) fused batches of resident witnesses
+    d_w = [torch.frombuffer(bytearray(wb), dtype=torch.uint8).cuda(local) for wb in wbs]
+    stream = torch.cuda.current_stream().cuda_stream
+    ptrs = [d_w[i % 8].data_ptr() for i in range(steps)]
+    key.prove_batch_device(ptrs[:32], stream=stream)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    fused = key.prove_batch_device(ptrs, stream=stream)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t1
+    ok = zkr_hip.verify_batch(vk_bin, fused, [pubs[i % 8] for i in range(steps)]) and ok
+    key.close()
+    # (4) the unchanged caller: new Bn128 + the provingKeyBin buffer per proof
+    zkr_hip.clear_key_cache()
+    dt, dp = [], []
+    for i in range(8):
+        t1 = time.perf_counter()
+        bn = zkr_hip.build_bn128(local)
+        dp.append(bn.groth16GenProof(wbs[i], pkb))
+        dt.append(1e3 * (time.perf_counter() - t1))
+    ok = all(zkr_hip.verify(vk_bin2, zkr_hip.proof_bytes_from_json(p), pubs[i]) for i, p in enumerate(dp)) and ok
+    zkr_hip.clear_key_cache()
+    steady = sorted(dt[1:])
+    if not ok:
+        raise SystemExit("a proof of the withdraw circuit failed the pairing check")
+    return {"circuit": "Withdraw() (withdraw.circom)", "nVars": info["nVars"], "domainSize": info["domainSize"], "nPublic": circ.n_public,
+            "witness_ms_host": wit_ms, "single_proof_ms": single_ms, "fused_proofs_per_s": steps / el, "fused_ms_per_proof": 1e3 * el / steps,
+            "dropin_first_ms": dt[0], "dropin_steady_ms": steady[len(steady) // 2],
+            "sequence_ms": {"witness": 1e3 * parts[0] / n_seq, "proof": 1e3 * parts[1] / n_seq, "is_valid": 1e3 * parts[2] / n_seq, "total": 1e3 * sum(parts) / n_seq},
+            "proofs_verified": 24 + n_seq + steps + 8}
+
+
 def facade_pipeline_leg(local, n_batches=256, chunk=64, witness="gpu"):
     """The whole of createProofGenerator (operator/src/snarks/common.ts:10-53) for a stream of rollup batches of the
     reference's tx circuit, every step native and overlapped: witness (`calculateWitness`, :15-17) -> proof
@@ -543,7 +672,7 @@ def self_launch(n_gpus):
     return rc
 
 
-def roofline_record(key, info, prof, per_proof_s, device_state, log_m, shape, local):
+def roofline_record(key, info, prof, per_proof_s, device_state, log_m, shape, local, peak_gmul=None):
     """The `roofline` object of the line: the dominant kernel's algorithmic bytes per launch -- every base
     point and every scalar of the MSM read once (64 B G1 / 128 B G2 point + 32 B scalar) -- over its average
     launch duration (hipEvents around every launch, on the stream it is launched on: zkr_prof_*), against the HBM peak; the
@@ -601,10 +730,13 @@ def roofline_record(key, info, prof, per_proof_s, device_state, log_m, shape, lo
                         "plus the 4-byte entries; the PMC figure applies the x2 read rule, an upper bound for 64-byte gathers. "
                         "avg_launch_ms is measured with two proofs in flight (the kernel shares the chip with the other streams); isolated it runs 0.79 ms"}
     try:
-        peak_gmul = zkr_hip.bench_fq_mul(local)
+        legacy = None
+        if peak_gmul is None:
+            peak_gmul = zkr_hip.bench_fq_mul(local)
+            legacy = zkr_hip.bench_fq_mul(local, legacy=True)
         gm = fqmul_per_launch / (avg_ms * 1e-3) / 1e9
         roofline["valu"] = {"bound": "valu", "peak_fq_mul_per_s_G": peak_gmul, "unit": "G Fq-mul/s (162 mad32 each: 9 x 29-bit limbs, no carry words)",
-                            "peak_fq_mul_per_s_G_legacy_8x32": zkr_hip.bench_fq_mul(local, legacy=True),
+                            "peak_fq_mul_per_s_G_legacy_8x32": legacy,
                             "achieved_fq_mul_per_s_G": gm, "frac": gm / peak_gmul,
                             "window_bits": win["A"][0], "additions_per_point": win["A"][1]}
         # the same rate against the chip's own bound, not only against this library's multiplier:
@@ -634,12 +766,23 @@ def roofline_record(key, info, prof, per_proof_s, device_state, log_m, shape, lo
                      + info["nnzA"] + info["nnzB"] + red)
         gw = total_mul / per_proof_s / 1e9
         roofline["valu"]["whole_proof"] = {"fq_mul_per_proof": total_mul, "achieved_fq_mul_per_s_G": gw, "frac": gw / peak_gmul}
+        # the same as SCALARS of `roofline` (the driver's record keeps scalars and short strings of this object, not nested ones):
+        # *_kernel = the dominant kernel in flight, *_proof = every field multiplication of the proof over the time per proof;
+        # valu_frac_* against the in-process multiplier microbenchmark, mad_bound_frac_* against 1024 SIMDs x 16 lanes x clock / 162
+        roofline.update({"valu_peak_fq_mul_G": peak_gmul, "valu_fq_mul_G_kernel": gm, "valu_fq_mul_G_proof": gw,
+                         "valu_frac_kernel": gm / peak_gmul, "valu_frac_proof": gw / peak_gmul,
+                         "mad_bound_frac_kernel": gm / bound(mhz) if mhz else None, "mad_bound_frac_proof": gw / bound(mhz) if mhz else None,
+                         "sclk_mhz_sampled": mhz})
     except Exception as e:  # microbench is informative only
         roofline["valu"] = {"error": str(e)}
     whole = None if proof_traffic is None else {
         "bytes_per_proof": proof_traffic, "GBps_per_gpu": proof_traffic / per_proof_s / 1e9,
         "frac_of_peak": proof_traffic / per_proof_s / 1e9 / HBM_PEAK_GBPS,
         "source": "sum over the proving kernels of profiles/%s (x2 read rule: an upper bound for the 64-byte gathers)" % pmc_file}
+    if whole:
+        roofline.update({"hbm_traffic_GB_per_proof": whole["bytes_per_proof"] / 1e9, "hbm_traffic_frac_proof": whole["frac_of_peak"]})
+    for k, v in streaming.items():   # the streaming kernels' fractions of the HBM peak as scalars: hbm_frac_ingest, _spmv, _ntt_pass, _combine_h
+        roofline["hbm_frac_" + k.split("_kernel")[0].split(" ")[0]] = v["frac_of_hbm_peak"]
     return roofline, whole
 
 
@@ -701,12 +844,13 @@ def shard_leg(key, d_wit, parts, want_proof, local):
         remote_bytes = 10 * (m_ // parts) * 32 * (parts - 1) / parts
         exchange_ms = 1e3 * remote_bytes / (7 * 153e9 * 0.5)
         barriers_ms = 4 * 0.05
-        shards_all, agg_ms, agg_rep_ms, same_split = [], None, None, None
+        shards_all, agg_ms, agg_rep_ms, same_split, all_form = [], None, None, None, None
         try:                                                            # all shards side by side: may not fit beside the whole key at 2^24
             for i in range(parts):
                 shards_all.append(key.shard(i, parts, device=local))
             ptrs = [d_wit.data_ptr()] * parts
             same_split = zkr_hip.prove_sharded_device(shards_all, ptrs, 1000003, 2000003) == whole and zkr_hip.sharded_split_stats() is not None
+            all_form = zkr_hip.sharded_last_form()
             t1 = time.perf_counter()
             for _ in range(3):
                 zkr_hip.prove_sharded_device(shards_all, ptrs, 1000003, 2000003)
@@ -732,13 +876,99 @@ def shard_leg(key, d_wit, parts, want_proof, local):
                  "remote_bytes_per_shard": remote_bytes, "assumed_link_efficiency": 0.5,
                  "projected_latency_ms": lat, "projected_speedup": whole_ms / lat,
                  "all_shards_on_this_gpu_ms_per_proof": agg_ms, "all_shards_on_this_gpu_ms_per_proof_replicated_calch": agg_rep_ms,
-                 "proof_identical_to_whole_key": same_split,
+                 "proof_identical_to_whole_key": same_split, "all_shards_form": all_form and all_form["form"], "all_shards_reason": all_form and all_form["reason"],
                  "note": "compute MEASURED (a shard alone; all shards together on one GPU), exchange and barriers MODELLED: no multi-GPU node was available"}
-    return {"parts": parts, "whole_key_sync_proof_ms": whole_ms, "per_shard": rows, "slowest_shard_ms": slowest, "combine_ms": combine_ms,
+    return {"parts": parts, "measured": False, "whole_key_sync_proof_ms": whole_ms, "per_shard": rows, "slowest_shard_ms": slowest, "combine_ms": combine_ms,
             "projected_latency_ms_one_shard_per_gpu": slowest + combine_ms, "projected_speedup": whole_ms / (slowest + combine_ms),
             "split_calch": split,
             "shard_build_s": build_s, "proof_identical_to_whole_key": True,
             "note": "PROJECTED: shards measured one at a time on one GPU; every shard computes its part of h itself (the first four of calcH's six transforms in full, the last two on its range), so the exchange is 640 B per shard"}
+
+
+def sharded_multi_leg(key, wit_bytes, devices, r=1000003, s_=2000003, reps=5):
+    """ONE proof over SEVERAL devices, MEASURED: shard i of the key on devices[i], the
+    full witness resident on each, zkr_prove_sharded_device timed as a caller sees it -- host threads, barriers, the cross passes
+    through the other devices' memory, the combination.  Reports which form ran (split / replicated calcH) and why
+    (zkr_prove_sharded_last_form), the split's per-phase host milliseconds per shard, the remote GB/s of its cross phases, and
+    the same proof with every shard computing h for itself (ZKR_SHARD_SPLIT_H=0).  devices may repeat (rehearsal on one GPU:
+    labelled, never a scaling number).  The proof must be the whole key's bytes."""
+    import torch
+    import zkr_hip
+    parts = len(devices)
+    rehearsal = len(set(devices)) < parts
+    dev0 = key.device
+    d0 = torch.frombuffer(bytearray(wit_bytes), dtype=torch.uint8).to(torch.device("cuda", dev0))
+    torch.cuda.synchronize(dev0)
+    whole = key.prove_device(d0.data_ptr(), r=r, s=s_)
+    t1 = time.perf_counter()
+    for _ in range(3):
+        key.prove_device(d0.data_ptr(), r=r, s=s_)
+    whole_ms = 1e3 * (time.perf_counter() - t1) / 3
+    t1 = time.perf_counter()
+    shards = [key.shard(i, parts, device=d) for i, d in enumerate(devices)]
+    build_s = time.perf_counter() - t1
+    out = {"parts": parts, "devices": list(devices), "measured": True, "rehearsal_on_one_gpu": rehearsal, "whole_key_sync_proof_ms": whole_ms, "shard_build_s": build_s,
+           "shard_arena_bytes": [sh.arena()[1] for sh in shards]}
+    try:
+        dws = [torch.frombuffer(bytearray(wit_bytes), dtype=torch.uint8).to(torch.device("cuda", d)) for d in devices]
+        for d in set(devices):
+            torch.cuda.synchronize(d)
+        ptrs = [t.data_ptr() for t in dws]
+        t1 = time.perf_counter()
+        first = zkr_hip.prove_sharded_device(shards, ptrs, r, s_)     # distinct devices: proves both ways and compares (first use)
+        out["first_call_ms"] = 1e3 * (time.perf_counter() - t1)
+        out["first_call"] = zkr_hip.sharded_last_form()
+        same = first == whole
+
+        def timed():
+            zkr_hip.prove_sharded_device(shards, ptrs, r, s_)
+            t = time.perf_counter()
+            for _ in range(reps):
+                pr = zkr_hip.prove_sharded_device(shards, ptrs, r, s_)
+            return 1e3 * (time.perf_counter() - t) / reps, pr
+        ms, pr = timed()
+        same = same and pr == whole
+        form = zkr_hip.sharded_last_form()
+        stats = zkr_hip.sharded_split_stats()
+        out.update({"form": form["form"], "reason": form["reason"], "ms_per_proof": ms, "speedup_vs_whole_key": whole_ms / ms})
+        if stats is not None:
+            m_ = key.info()["domainSize"]
+            remote = 10 * (m_ // parts) * 32 * (parts - 1) / parts     # 6 reads + 4 writes of vector-columns-of-every-block, (P - 1) / P of them remote
+            out["split_phase_ms_per_shard"] = [[round(x, 4) for x in row] for row in stats]
+            cross = [row[1] + row[3] for row in stats]                   # phases 2 and 4 are the cross passes (host time: enqueue -> stream idle)
+            out["remote_bytes_per_shard"] = remote
+            out["remote_GBps_per_shard_in_cross_phases"] = [remote / (c * 1e-3) / 1e9 if c > 0 else None for c in cross]
+        os.environ["ZKR_SHARD_SPLIT_H"] = "0"
+        try:
+            ms0, pr0 = timed()
+            out["replicated_calch_ms_per_proof"] = ms0
+            out["replicated_calch_speedup_vs_whole_key"] = whole_ms / ms0
+            same = same and pr0 == whole
+        finally:
+            del os.environ["ZKR_SHARD_SPLIT_H"]
+        out["proof_identical_to_whole_key"] = bool(same)
+        if not same:
+            raise SystemExit("the sharded proof over devices %s differs from the whole key's proof" % devices)
+    finally:
+        for sh in shards:
+            sh.close()
+    return out
+
+
+def sharding_scalars(leg):
+    """The sharding leg as scalars of `config` (same keys for N = 1 and N > 1; the driver's record keeps scalars only)."""
+    if not leg or "error" in leg:
+        return {"sharded_error": (leg or {}).get("error")}
+    if leg.get("measured"):
+        return {"sharded_parts": leg["parts"], "sharded_measured": not leg["rehearsal_on_one_gpu"], "sharded_form": leg.get("form"), "sharded_reason": leg.get("reason"),
+                "sharded_ms": leg.get("ms_per_proof"), "sharded_speedup": leg.get("speedup_vs_whole_key"), "sharded_replicated_calch_ms": leg.get("replicated_calch_ms_per_proof"),
+                "sharded_whole_key_ms": leg["whole_key_sync_proof_ms"]}
+    sp = leg.get("split_calch") or {}
+    return {"sharded_parts": leg["parts"], "sharded_measured": False, "sharded_form": "projected (one GPU: shards timed one at a time, exchange modelled)",
+            "sharded_ms": sp.get("projected_latency_ms", leg["projected_latency_ms_one_shard_per_gpu"]),
+            "sharded_speedup": sp.get("projected_speedup", leg["projected_speedup"]), "sharded_replicated_calch_ms": leg["projected_latency_ms_one_shard_per_gpu"],
+            "sharded_whole_key_ms": leg["whole_key_sync_proof_ms"], "sharded_all_on_one_gpu_ms": sp.get("all_shards_on_this_gpu_ms_per_proof"),
+            "sharded_all_on_one_gpu_form": sp.get("all_shards_form")}
 
 
 def verify_timed_proofs(vk_bin, proofs, pubs_of):
@@ -845,6 +1075,18 @@ def inproc_main(args):
         "proofs_verified": len(proofs), "verify_ms_per_proof_host": verify_ms,
         "device_state_during_timed_region": device_state, "hbm_whole_proof": whole,
     }
+    modes = [k.replication() for k in keys[1:]]
+    out["key"]["replica_modes"] = modes
+    out["config"].update({"key_replication": "peer-copy: " + (",".join(sorted(set("%s%s" % (m["mode"], "" if m["peer_direct"] else " (staged through the host)") for m in modes))) or "none"),
+                          "key_replicate_GBps_min": min([r_["GBps"] for r_ in repl], default=None)})
+    if n > 1 and args.shards > 1:
+        for k in keys[1:]:
+            k.close()
+        try:
+            out["intra_proof_sharding"] = sharded_multi_leg(keys[0], w0, devices)
+        except (Exception, SystemExit) as e:
+            out["intra_proof_sharding"] = {"error": str(e)}
+        out["config"].update(sharding_scalars(out["intra_proof_sharding"]))
     print(json.dumps(out))
 
 
@@ -871,6 +1113,9 @@ def main():
     ap.add_argument("--replicate-mode", choices=["auto", "full", "base"], default="auto", help="--inproc: form of the device-to-device key copy")
     ap.add_argument("--shards", type=int, default=8, help="(0 = skip) intra-proof sharding leg (SURVEY 8(e) row 2): split every MSM of ONE proof into this many contiguous point ranges, "
                                                           "run the shards one after the other on this GPU and report the per-shard time (= projected latency with one shard per GPU)")
+    ap.add_argument("--no-2-22", action="store_true", help="skip the BASELINE configs[2] leg (one 2^22 key, 6 timed proofs; about 20 s)")
+    ap.add_argument("--with-2-24-dense", action="store_true", help="add the BASELINE configs[4] leg (2^24 dense random R1CS: setup about 150 s)")
+    ap.add_argument("--no-withdraw", action="store_true", help="skip the withdraw-circuit leg (withdraw.ts:6-10)")
     args = ap.parse_args()
 
     if args.inproc:
@@ -1075,8 +1320,60 @@ def main():
                 out["intra_proof_sharding"] = shard_leg(key, wits[0], args.shards, proofs[0], local)
             except (Exception, SystemExit) as e:  # a side leg never costs the headline line; a differing proof shows here
                 out["intra_proof_sharding"] = {"error": str(e)}
+        elif world > 1 and args.shards > 1:
+            # N > 1: ONE proof over the N devices for real (the other ranks wait at the barrier below, their GPUs idle): rank 0
+            # builds shard i on device i -- no projection
+            try:
+                if one_gpu:
+                    devs = [0] * world
+                elif torch.cuda.device_count() >= world:
+                    devs = list(range(world))
+                else:
+                    raise RuntimeError("rank 0 sees %d devices, the job has %d ranks" % (torch.cuda.device_count(), world))
+                out["intra_proof_sharding"] = sharded_multi_leg(key, bytes(wits[0].cpu().numpy().tobytes()), devs)
+            except (Exception, SystemExit) as e:
+                out["intra_proof_sharding"] = {"error": str(e)}
+        if "intra_proof_sharding" in out:
+            out["config"].update(sharding_scalars(out["intra_proof_sharding"]))
+        out["config"].update({"key_replication": out["key"]["replication"], "key_bcast_GBps": out["key"]["bcast_GBps"], "key_bcast_wire_GBps": out["key"]["bcast_wire_GBps"]})
+        flat = out["config"]                                   # scalars next to the nested objects: what the driver's record keeps
+        if boundary:
+            flat.update({"sync_latency_ms": boundary["sync_latency_ms"], "sync_resident_proofs_per_s": boundary["sync_resident_proofs_per_s"],
+                         "host_buffer_sync_proofs_per_s": boundary["host_buffer_sync_proofs_per_s"],
+                         "host_buffer_sync_ms": 1e3 / boundary["host_buffer_sync_proofs_per_s"],
+                         "host_buffer_concurrent_proofs_per_s": boundary["host_buffer_concurrent_callers_proofs_per_s"],
+                         "host_buffer_batch_proofs_per_s": boundary["host_buffer_batch_proofs_per_s"]})
+        side_legs = world == 1 and args.log_m == 20 and args.shape == "rollup"
+        if world == 1 and (not args.no_tx_circuit or (side_legs and (not args.no_2_22 or args.with_2_24_dense or not args.no_withdraw))):
+            key.close()  # its streams would share the hardware queues with the streams of the next leg's key
+            key = None
+        peak_gmul = (roofline.get("valu") or {}).get("peak_fq_mul_per_s_G")
+        if side_legs and not args.no_2_22:                   # BASELINE configs[2]
+            try:
+                leg = out["config_2_22"] = size_leg(local, 22, "rollup", peak_gmul=peak_gmul, device_state=device_state)
+                flat.update({"rate_2_22_proofs_per_s": leg["proofs_per_s"], "ms_per_proof_2_22": leg["ms_per_proof"], "sync_latency_ms_2_22": leg["sync_latency_ms"],
+                             "proofs_verified_2_22": leg["proofs_verified"]})
+                out["roofline"].update({"frac_2_22": leg["roofline"]["frac"], "achieved_2_22": leg["roofline"]["achieved"], "kernel_2_22": leg["roofline"]["kernel"],
+                                        "avg_launch_ms_2_22": leg["roofline"]["avg_launch_ms"], "valu_frac_proof_2_22": leg["roofline"].get("valu_frac_proof")})
+            except (Exception, SystemExit) as e:
+                out["config_2_22"] = {"error": str(e)}
+        if side_legs and args.with_2_24_dense:                 # BASELINE configs[4]
+            try:
+                leg = out["config_2_24_dense"] = size_leg(local, 24, "dense", steps=4, warmup=1, peak_gmul=peak_gmul, device_state=device_state)
+                flat.update({"rate_2_24_dense_proofs_per_s": leg["proofs_per_s"], "ms_per_proof_2_24_dense": leg["ms_per_proof"],
+                             "sync_latency_ms_2_24_dense": leg["sync_latency_ms"]})
+                out["roofline"].update({"frac_2_24_dense": leg["roofline"]["frac"], "kernel_2_24_dense": leg["roofline"]["kernel"],
+                                        "avg_launch_ms_2_24_dense": leg["roofline"]["avg_launch_ms"]})
+            except (Exception, SystemExit) as e:
+                out["config_2_24_dense"] = {"error": str(e)}
+        if side_legs and not args.no_withdraw:
+            try:
+                leg = out["withdraw_circuit"] = withdraw_leg(local)
+                flat.update({"withdraw_single_proof_ms": leg["single_proof_ms"], "withdraw_fused_proofs_per_s": leg["fused_proofs_per_s"],
+                             "withdraw_dropin_call_ms": leg["dropin_steady_ms"], "withdraw_sequence_ms": leg["sequence_ms"]["total"]})
+            except (Exception, SystemExit) as e:
+                out["withdraw_circuit"] = {"error": str(e)}
         if world == 1 and not args.no_tx_circuit:
-            key.close()  # its four streams would share the hardware queues with the streams of the tx-circuit key
             out["dropin"] = dropin_leg(local)
             out["tx_circuit"] = tx_circuit_leg(local, max(args.steps, 4))
             # the same circuit family filled up to the headline size: 18 transactions per batch = 1 008 108 constraints, 2^20 domain
@@ -1085,9 +1382,13 @@ def main():
             out["facade_pipeline_1024"] = facade_pipeline_leg(local, n_batches=1024)  # a longer stream: the one-off builder latency weighs less
             out["facade_pipeline_host_witness"] = facade_pipeline_leg(local, chunk=32, witness="host")
             # the reference's own circuit through the drop-in boundary, kept by the driver's record with `config`
-            out["config"]["boundary"].update({
-                "tx_circuit_dropin_call_ms": out["dropin"]["dropin_steady_ms"], "tx_circuit_single_proof_ms": (out["tx_circuit"]["facade_sequential"] or {}).get("proof_ms"),
-                "tx_circuit_fused_proofs_per_s": out["tx_circuit"]["proofs_per_s"], "tx_circuit_facade_pipeline_proofs_per_s": out["facade_pipeline_1024"]["end_to_end_proofs_per_s"]})
+            txf = {"tx_dropin_call_ms": out["dropin"]["dropin_steady_ms"], "tx_single_proof_ms": (out["tx_circuit"]["facade_sequential"] or {}).get("proof_ms"),
+                   "tx_sequence_ms": (out["tx_circuit"]["facade_sequential"] or {}).get("total_ms"),
+                   "tx_fused_proofs_per_s": out["tx_circuit"]["proofs_per_s"], "tx_facade_pipeline_proofs_per_s": out["facade_pipeline_1024"]["end_to_end_proofs_per_s"],
+                   "rollup_18tx_2_20_proofs_per_s": out["rollup_circuit_2_20"]["proofs_per_s"]}
+            flat.update(txf)
+            if out["config"]["boundary"] is not None:
+                out["config"]["boundary"].update(txf)
         print(json.dumps(out))
     if dist:
         barrier()

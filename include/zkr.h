@@ -97,6 +97,10 @@ enum { ZKR_REPLICATE_AUTO = 0, ZKR_REPLICATE_FULL = 1, ZKR_REPLICATE_BASE = 2 };
 int zkr_key_replicate(const zkr_key *key, int dst_device, int mode, zkr_key **out);
 /* HIP ordinal of the device the key lives on. */
 int zkr_key_device(const zkr_key *key);
+/* How the key came to its device: *mode_out = 0 (loaded, built or adopted there) or the form zkr_key_replicate chose
+ * (ZKR_REPLICATE_FULL / ZKR_REPLICATE_BASE); *peer_direct_out (may be NULL) = whether source and destination could address each
+ * other's memory (0 with FULL: the runtime staged the copy through the host). */
+int zkr_key_replication(const zkr_key *key, int *mode_out, int *peer_direct_out);
 
 /* ---- the hot path --------------------------------------------------------------------------- */
 /* One Groth16 proof.  witness_std: nVars x 32 B standard form (binarifyWitness layout, host memory).
@@ -178,6 +182,14 @@ int zkr_prove_sharded_device(zkr_key *const *shards, size_t parts, const void *c
  * *parts_out = its shards if calcH was split (else 0), phase_ms_out[8 * part + phase] = host time of that shard's phase
  * (enqueue until its stream was idle; phases 0..4 = 1..5 of csrc/zkr_prove.hip calc_h_split, the last one enqueue time only). */
 int zkr_prove_sharded_split_stats(unsigned *parts_out, double phase_ms_out[64]);
+/* WHICH form the calling thread's last zkr_prove_sharded(_device) took, and why -- a sharded proof that fell back to replicated
+ * calcH is otherwise only a slower number: *form_out = ZKR_SHARDED_SPLIT_H / ZKR_SHARDED_REPLICATED_H (NONE: no sharded proof on
+ * this thread yet, or it failed before running), reason_out = one line ("no peer access from device 2 to device 5", "3 shards:
+ * the split needs 2, 4 or 8", "ZKR_SHARD_SPLIT_H=0", "all shards on one device", ...).
+ * Shards on DIFFERENT devices: their first sharded proof runs BOTH forms and compares the sums; the split is kept only if they
+ * agree (a warning on stderr and replicated calcH from then on otherwise).  ZKR_SHARD_SPLIT_H=1 skips that check. */
+enum { ZKR_SHARDED_NONE = 0, ZKR_SHARDED_SPLIT_H = 1, ZKR_SHARDED_REPLICATED_H = 2 };
+int zkr_prove_sharded_last_form(int *form_out, char *reason_out, size_t reason_len);
 /* Measurement only (bench.py's shard leg on a one-GPU box): ONE shard runs its share of a proof with a split calcH ALONE, its own
  * buffers standing in for the other shards' -- the time a shard takes with a GPU to itself and no exchange (*ms_out); what it
  * computes is meaningless and is discarded. */

@@ -7,10 +7,37 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _lib = None
 
 
+_path = None   # the library lib() loads; use_native() points it at a build for THIS host's CPU
+
+
+def use_native():
+    """CPU-baseline timing only (bench.py cpu_baseline): compile zkr_oracle.c with `-O3 -march=native` ON THIS HOST (the
+    shipped libzkr_oracle.so is -march=x86-64-v2 so that it runs on every box: no BMI2 / ADX) and make lib() load that
+    build.  Returns a short description of what will be loaded; falls back to the portable build when gcc or the compile
+    fails.  Must be called before the first lib()."""
+    global _path
+    import subprocess
+    import tempfile
+    if _lib is not None:
+        return "already loaded: " + os.path.basename(_path or "libzkr_oracle.so")
+    src = os.path.join(_HERE, "zkr_oracle.c")
+    flags = ["-O3", "-march=native", "-fPIC", "-fopenmp", "-shared"]
+    for out_dir in (_HERE, tempfile.gettempdir()):
+        out = os.path.join(out_dir, "libzkr_oracle_native.so")
+        try:
+            subprocess.check_call(["gcc"] + flags + ["-o", out, src], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+            ctypes.CDLL(out)   # an unloadable build (missing libgomp ...) must not replace the portable one
+            _path = out
+            return "gcc " + " ".join(flags[:2]) + " (built on this host)"
+        except Exception:
+            continue
+    return "gcc -O3 -march=x86-64-v2 (portable build: the native compile failed on this host)"
+
+
 def lib():
     global _lib
     if _lib is None:
-        path = os.path.join(_HERE, "libzkr_oracle.so")
+        path = _path or os.path.join(_HERE, "libzkr_oracle.so")
         if not os.path.exists(path):
             raise RuntimeError("oracle/libzkr_oracle.so missing: run `make -C oracle` (or __graft_entry__.build())")
         L = ctypes.CDLL(path)

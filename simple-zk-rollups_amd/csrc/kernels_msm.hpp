@@ -978,17 +978,20 @@ static __global__ __launch_bounds__(MSM_THREADS, MINW) void fixed_base_kernel(co
 }
 
 // out[j] = in[idx[j]]  (table compaction / permutation at key build)
+// One 16-byte piece per thread (4 per G1 point, 8 per G2 point): consecutive lanes write consecutive pieces, and no lane ever
+// holds a whole point (round 4's thread-per-point form spilled the 128-byte G2 struct: 132 B of scratch per lane for a copy).
 template <class T>
 static __global__ void gather_kernel(const T *in, const uint32_t *idx, size_t n, T *out) {
-  size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  constexpr unsigned PIECES = sizeof(T) / 16;
+  static_assert(sizeof(T) % 16 == 0, "points are copied in 16-byte pieces");
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t j = t / PIECES;
+  const unsigned i = (unsigned)(t % PIECES);
   if (j >= n) return;
-  uint32_t src = idx[j];
-  if (src == 0xffffffffu) {  // no source point: the point at infinity (x = 0)
-    uint4 *q = reinterpret_cast<uint4 *>(out + j);
-    for (unsigned i = 0; i < sizeof(T) / 16; i++) q[i] = make_uint4(0, 0, 0, 0);
-    return;
-  }
-  store_pod(out + j, load_pod(in + src));
+  const uint32_t src = idx[j];
+  uint4 v = make_uint4(0, 0, 0, 0);  // no source point: the point at infinity (x = 0)
+  if (src != 0xffffffffu) v = reinterpret_cast<const uint4 *>(in + src)[i];
+  reinterpret_cast<uint4 *>(out + j)[i] = v;
 }
 
 // VALU roofline microbenchmark: dependent chains of the hot path's Fq Montgomery product (9 x 29-bit limbs, field29.hpp),

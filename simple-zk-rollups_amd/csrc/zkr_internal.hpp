@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <time.h>
+#include <atomic>
 #include <condition_variable>
 #include <mutex>
 #include <string>
@@ -184,7 +185,12 @@ struct zkr_key {
   zkr::ProofSlot slot[zkr::PROOF_SLOTS];
   int next_slot = 0;
   std::mutex mu;  // slot hand-out, the enqueue phase of a proof (so two host threads do not interleave launches), stage totals
-  std::mutex split_mu;  // a shard key: held by the sharded proof that splits calcH over it and its siblings (zkr_multi.hip run_sharded)
+  std::mutex split_mu;  // a shard key: held by the sharded proof that splits calcH over it and its siblings (zkr_multi.hip run_sharded),
+                        // and by a shard proving on its own (zkr_prove_partial outside a split group)
+  std::atomic<int> split_checked{0};  // a shard key: 0 = the split calcH has not been compared with the replicated form on this shard set yet,
+                                      // 1 = compared, identical, 2 = it disagreed or failed: never split again (zkr_multi.hip run_sharded)
+  int replica_mode = 0;        // how the key came to its device: 0 = loaded / built there, ZKR_REPLICATE_FULL / _BASE = zkr_key_replicate in that form
+  bool replica_direct = false;  // ... and whether the two devices could address each other
   std::condition_variable slot_freed;
   zkr::MsmPlan plan[zkr::N_TABLES];
   // proof assembly on the host: 4-bit window tables of delta_1 / delta_2 (built on first use)
@@ -227,6 +233,7 @@ int calc_h_device(zkr_key *k, ProofSlot &sl, hipStream_t s, int nbat = 1);  // s
 // of that group (null: a shard proving on its own -- replicated calcH)
 extern thread_local ShardGroup *shard_group;
 extern thread_local unsigned shard_group_part;
+extern thread_local bool shard_turn_held;  // the caller of this thread's zkr_prove_partial(_device) holds the shard's split_mu already (run_sharded with a split calcH)
 int fused_capacity(const ArenaHeader &h, const MsmPlan plan[N_TABLES]);
 void arena_layout(ArenaHeader &h);  // section offsets and total_len from the sizes in the header (n, p, m, nnz, n_wide, npts, win_c, sc_n): THE layout, whoever builds an arena
 const char *arena_header_fault(const ArenaHeader &h, size_t len);  // null when a full arena's header is consistent with its sizes

@@ -514,7 +514,7 @@ int key_build(int device, uint32_t n, uint32_t p, uint32_t m, const std::vector<
       uint32_t *d_idx = nullptr;
       ZKR_HIP_CHECK(hipMalloc(&d_idx, np * 4));
       ZKR_HIP_CHECK(hipMemcpy(d_idx, srcidx_eff[t]->data(), np * 4, hipMemcpyHostToDevice));
-      unsigned grid = (unsigned)((np + 255) / 256);
+      unsigned grid = (unsigned)((np * (pb / 16) + 255) / 256);  // one 16-byte piece per thread
       if (t == T_B2)
         gather_kernel<G2Affine><<<grid, 256>>>((const G2Affine *)tbl_src[t], d_idx, np, (G2Affine *)(arena + h.off_pts[t]));
       else

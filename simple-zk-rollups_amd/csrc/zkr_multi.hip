@@ -6,6 +6,8 @@
 // awaits proofs -- so the proof-level sharding of BASELINE configs[3] has to be reachable from ONE process through the
 // library the N-API shim binds, not only from one-process-per-GPU launchers (python/zkr_hip/batch.py keeps that form for
 // torchrun + RCCL).
+#include <stdarg.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
@@ -82,6 +84,7 @@ int zkr_key_replicate(const zkr_key *src, int dst_device, int mode, zkr_key **ou
     int rc = zkr_key_adopt_arena(buf.p, src->arena_len, dst_device, &k);
     if (rc) return rc;
     k->owns_arena = true;  // unlike an adopted broadcast buffer, this copy belongs to the replica
+    k->replica_mode = ZKR_REPLICATE_FULL; k->replica_direct = direct;
     buf.release();
     *out = k;
     return 0;
@@ -90,12 +93,17 @@ int zkr_key_replicate(const zkr_key *src, int dst_device, int mode, zkr_key **ou
   void *base = nullptr;
   size_t base_len = 0;
   if (int rc = zkr_key_base_arena(const_cast<zkr_key *>(src), &base, &base_len)) return rc;
-  if (dst_device == src->device) return zkr_key_adopt_base_arena(base, base_len, dst_device, out);
-  ZKR_HIP_CHECK(hipSetDevice(dst_device));
-  DevBuf tmp;
-  if (int rc = tmp.alloc(base_len)) return rc;
-  if (int rc = copy_between_devices(tmp.p, dst_device, base, src->device, base_len)) return rc;
-  return zkr_key_adopt_base_arena(tmp.p, base_len, dst_device, out);
+  int rc;
+  if (dst_device == src->device) rc = zkr_key_adopt_base_arena(base, base_len, dst_device, out);
+  else {
+    ZKR_HIP_CHECK(hipSetDevice(dst_device));
+    DevBuf tmp;
+    if ((rc = tmp.alloc(base_len))) return rc;
+    if ((rc = copy_between_devices(tmp.p, dst_device, base, src->device, base_len))) return rc;
+    rc = zkr_key_adopt_base_arena(tmp.p, base_len, dst_device, out);
+  }
+  if (!rc) { (*out)->replica_mode = ZKR_REPLICATE_BASE; (*out)->replica_direct = direct; }
+  return rc;
 }
 
 }  // extern "C"
@@ -294,55 +302,54 @@ namespace {
 // phase times of the calling thread's last sharded proof with a split calcH (zkr_prove_sharded_split_stats)
 thread_local double last_split_phase_ms[8][8];
 thread_local unsigned last_split_parts = 0;
+// which form the calling thread's last sharded proof took, and why (zkr_prove_sharded_last_form)
+thread_local int last_form = ZKR_SHARDED_NONE;
+thread_local char last_reason[256] = "";
+void set_form(int form, const char *fmt, ...) {
+  last_form = form;
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(last_reason, sizeof(last_reason), fmt, ap);
+  va_end(ap);
+}
 
-template <class Partial>
-int run_sharded(zkr_key *const *shards, size_t parts, const uint8_t *r32, const uint8_t *s32, uint8_t *proof_out, Partial partial) {
-  if (!shards || parts == 0 || !proof_out) { set_error("null argument"); return ZKR_ERR_ARG; }
+// every stream of every shard idle: after a failed group the stragglers' CROSS kernels (which write the OTHER shards' vectors) have
+// ended before the caller -- who still holds the shards' turns -- lets anybody reuse a proof slot of these keys
+void drain_shards(zkr_key *const *shards, size_t parts) {
   for (size_t i = 0; i < parts; i++) {
-    if (!shards[i]) { set_error("shard %zu is null", i); return ZKR_ERR_ARG; }
-    const ArenaHeader &h = shards[i]->h;
-    if (h.shard_parts != parts || h.shard_part != i) { set_error("shards[%zu] is part %u of %u: pass part i of %zu at position i", i, h.shard_part, h.shard_parts, parts); return ZKR_ERR_ARG; }
-    if (h.n != shards[0]->h.n || h.m != shards[0]->h.m || memcmp(h.delta1, shards[0]->h.delta1, 64)) { set_error("shard %zu belongs to another key", i); return ZKR_ERR_ARG; }
+    zkr_key *k = shards[i];
+    if (hipSetDevice(k->device) != hipSuccess) continue;
+    (void)hipStreamSynchronize(k->stream);
+    (void)hipStreamSynchronize(k->prep_stream);
+    for (int j = 0; j < k->n_all; j++) (void)hipStreamSynchronize(k->red_stream[j]);
   }
-  std::vector<uint8_t> partials(parts * ZKR_PARTIAL_BYTES);
+  (void)hipGetLastError();
+}
+
+// One pass over the shards, one host thread each: split = calcH split over them (the caller has checked the preconditions and
+// holds the shards' turns), else every shard computes h for itself.  *ran_split: whether the split really ran (false when a
+// thread could not be started).
+template <class Partial>
+int run_shards_once(zkr_key *const *shards, size_t parts, bool split, int klog, std::vector<uint8_t> &partials, Partial partial, bool *ran_split) {
   std::vector<int> rcs(parts, 0);
   std::vector<std::string> errs(parts);
-  // The shards run concurrently, so calcH can be split over them instead of repeated by every one (zkr_prove.hip calc_h_split):
-  // a power of two of shards, each owning one aligned block of h with enough columns for its share of the cross passes, and
-  // every device able to read and write every other's memory.  ZKR_SHARD_SPLIT_H=0: every shard computes h for itself.
   ShardGroup group;
   group.parts = (unsigned)parts;
   group.vecs.resize(parts);
-  {
-    const char *e = getenv("ZKR_SHARD_SPLIT_H");
-    const uint32_t m = shards[0]->h.m;
-    int klog = 0;
-    while ((1u << klog) < parts) klog++;
-    bool ok = !(e && atoi(e) == 0) && parts >= 2 && parts <= 8 && (1u << klog) == parts && (m >> (2 * klog)) >= 64;
-    for (size_t i = 0; i < parts && ok; i++) ok = shards[i]->h.sc_n[1] == m >> klog && shards[i]->h.sc_lo[1] == (uint32_t)i * (m >> klog);
-    for (size_t i = 0; i < parts && ok; i++)
-      for (size_t j = 0; j < parts && ok; j++) ok = peer_direct(shards[i]->device, shards[j]->device);
-    group.klog = klog;
-    group.split_h = ok;
-  }
-  // A split calcH makes the shards' threads wait for one another INSIDE their enqueue, each holding its shard's lock: two such
-  // proofs on the same shards at once could wait for each other's locks for ever.  They take turns (locks in address order).
-  std::vector<std::unique_lock<std::mutex>> turn;
-  if (group.split_h) {
-    std::vector<zkr_key *> order(shards, shards + parts);
-    std::sort(order.begin(), order.end());
-    for (zkr_key *k : order) turn.emplace_back(k->split_mu);
-  }
+  group.klog = klog;
+  group.split_h = split;
   std::vector<char> threaded(parts, 0);
   auto work = [&](size_t i) {
     shard_group = group.split_h && threaded[i] ? &group : nullptr;  // a shard run inline after the others cannot meet them at a barrier
     shard_group_part = (unsigned)i;
+    shard_turn_held = split;  // the caller took every shard's turn for a split pass (also when the split is then given up: no thread)
     try {
       rcs[i] = partial(i, &partials[i * ZKR_PARTIAL_BYTES]);
       if (rcs[i]) errs[i] = zkr_last_error();
     } catch (const std::exception &e) { rcs[i] = ZKR_ERR_HIP; errs[i] = e.what(); }
     if (rcs[i]) group.abort();
     shard_group = nullptr;
+    shard_turn_held = false;
   };
   // a split calcH needs every shard on a thread of its own, all at once: when a thread cannot be started the group falls back to
   // replicated calcH BEFORE anybody runs (the threads wait for the decision)
@@ -365,8 +372,12 @@ int run_sharded(zkr_key *const *shards, size_t parts, const uint8_t *r32, const 
   work(0);
   for (size_t i : inline_parts) work(i);
   for (auto &t : thr) t.join();
+  *ran_split = group.split_h;
   if (group.split_h) memcpy(last_split_phase_ms, group.phase_ms, sizeof(last_split_phase_ms));
   last_split_parts = group.split_h ? (unsigned)parts : 0;
+  bool any = false;
+  for (size_t i = 0; i < parts; i++) any = any || rcs[i];
+  if (any && split) drain_shards(shards, parts);  // the failing shard drained its own streams (prove_submit_group); its siblings' cross passes may still run
   // the shard that failed first, not one that gave up because of it
   for (int pass = 0; pass < 2; pass++)
     for (size_t i = 0; i < parts; i++)
@@ -374,6 +385,100 @@ int run_sharded(zkr_key *const *shards, size_t parts, const uint8_t *r32, const 
         set_error("shard %zu (device %d): %s", i, shards[i]->device, errs[i].c_str());
         return rcs[i];
       }
+  return 0;
+}
+
+template <class Partial>
+int run_sharded(zkr_key *const *shards, size_t parts, const uint8_t *r32, const uint8_t *s32, uint8_t *proof_out, Partial partial) {
+  set_form(ZKR_SHARDED_NONE, "");
+  last_split_parts = 0;
+  if (!shards || parts == 0 || !proof_out) { set_error("null argument"); return ZKR_ERR_ARG; }
+  for (size_t i = 0; i < parts; i++) {
+    if (!shards[i]) { set_error("shard %zu is null", i); return ZKR_ERR_ARG; }
+    const ArenaHeader &h = shards[i]->h;
+    if (h.shard_parts != parts || h.shard_part != i) { set_error("shards[%zu] is part %u of %u: pass part i of %zu at position i", i, h.shard_part, h.shard_parts, parts); return ZKR_ERR_ARG; }
+    if (h.n != shards[0]->h.n || h.m != shards[0]->h.m || memcmp(h.delta1, shards[0]->h.delta1, 64)) { set_error("shard %zu belongs to another key", i); return ZKR_ERR_ARG; }
+  }
+  std::vector<uint8_t> partials(parts * ZKR_PARTIAL_BYTES);
+  // The shards run concurrently, so calcH can be split over them instead of repeated by every one (zkr_prove.hip calc_h_split):
+  // a power of two of shards, each owning one aligned block of h with enough columns for its share of the cross passes, and
+  // every device able to read and write every other's memory.  ZKR_SHARD_SPLIT_H=0: every shard computes h for itself; =1: split
+  // whenever the preconditions hold, unchecked; unset: split, but shards that sit on DIFFERENT devices -- where the cross passes
+  // really cross a link, ordered only by stream synchronisation + a host barrier -- prove their first proof BOTH ways and keep the
+  // split only if the two forms' sums agree (ZKR_SHARD_SPLIT_CHECK=1 forces that check for shards on one device: tests).
+  const char *e = getenv("ZKR_SHARD_SPLIT_H");
+  const int policy = e ? (atoi(e) == 0 ? 0 : 1) : 2;  // 0 never, 1 always, 2 checked
+  const uint32_t m = shards[0]->h.m;
+  int klog = 0;
+  while ((1u << klog) < parts) klog++;
+  char why[200] = "";
+  bool ok = true;
+  if (policy == 0) { ok = false; snprintf(why, sizeof(why), "ZKR_SHARD_SPLIT_H=0"); }
+  else if (parts < 2 || parts > 8 || (1u << klog) != parts) { ok = false; snprintf(why, sizeof(why), "%zu shards: the split needs 2, 4 or 8", parts); }
+  else if ((m >> (2 * klog)) < 64) { ok = false; snprintf(why, sizeof(why), "domain 2^%u too small for %zu shards (fewer than 64 columns per cross pass)", shards[0]->h.logm, parts); }
+  for (size_t i = 0; i < parts && ok; i++)
+    if (shards[i]->h.sc_n[1] != m >> klog || shards[i]->h.sc_lo[1] != (uint32_t)i * (m >> klog)) { ok = false; snprintf(why, sizeof(why), "shard %zu does not own block %zu of h", i, i); }
+  bool distinct = false;
+  for (size_t i = 1; i < parts; i++) distinct = distinct || shards[i]->device != shards[0]->device;
+  for (size_t i = 0; i < parts && ok; i++)
+    for (size_t j = 0; j < parts && ok; j++)
+      if (!peer_direct(shards[i]->device, shards[j]->device)) { ok = false; snprintf(why, sizeof(why), "no peer access from device %d to device %d", shards[i]->device, shards[j]->device); }
+  const char *ce = getenv("ZKR_SHARD_SPLIT_CHECK");
+  const int force_check = ce ? atoi(ce) : 0;  // 1: check although the shards share a device; 2: and pretend the forms disagreed (tests of the fallback)
+  int state = shards[0]->split_checked.load();
+  if (ok && policy == 2 && state == 2) { ok = false; snprintf(why, sizeof(why), "the split form failed its first-use check on these shards"); }
+  const bool check = ok && policy == 2 && state == 0 && (distinct || force_check);
+  // A split calcH makes the shards' threads wait for one another INSIDE their enqueue, each holding its shard's lock: two such
+  // proofs on the same shards at once could wait for each other's locks for ever.  They take turns (locks in address order; a
+  // shard proving on its own -- zkr_prove_partial outside a split group -- takes its own shard's turn too).
+  std::vector<std::unique_lock<std::mutex>> turn;
+  if (ok) {
+    std::vector<zkr_key *> order(shards, shards + parts);
+    std::sort(order.begin(), order.end());
+    for (zkr_key *k : order) turn.emplace_back(k->split_mu);
+  }
+  bool ran_split = false;
+  int rc;
+  if (check) {
+    // first use on these devices: the split form, then the replicated one; their sums must be the same group elements (compared
+    // through the proof both assemble with a fixed blinding -- the XYZZ coordinates of a sum depend on the order of additions)
+    std::vector<uint8_t> split_partials(parts * ZKR_PARTIAL_BYTES);
+    uint8_t one[32] = {1}, pa[256], pb[256];
+    rc = run_shards_once(shards, parts, true, klog, split_partials, partial, &ran_split);
+    double keep_ms[8][8];
+    memcpy(keep_ms, last_split_phase_ms, sizeof(keep_ms));
+    const bool split_ran = rc == 0 && ran_split;
+    turn.clear();  // the replicated pass: every shard takes its own turn
+    bool dummy = false;
+    int rc2 = run_shards_once(shards, parts, false, klog, partials, partial, &dummy);
+    if (rc2) return rc2;
+    bool same = false;
+    if (split_ran) {
+      if ((rc2 = zkr_prove_combine(shards[0], split_partials.data(), parts, one, one, pa))) return rc2;
+      if ((rc2 = zkr_prove_combine(shards[0], partials.data(), parts, one, one, pb))) return rc2;
+      same = memcmp(pa, pb, 256) == 0 && force_check != 2;
+    }
+    if (rc == 0 && !ran_split) {
+      set_form(ZKR_SHARDED_REPLICATED_H, "replicated calcH: a shard's host thread could not be started");
+    } else {
+      for (size_t i = 0; i < parts; i++) shards[i]->split_checked.store(same ? 1 : 2);
+      if (same) {
+        memcpy(last_split_phase_ms, keep_ms, sizeof(keep_ms));
+        last_split_parts = (unsigned)parts;
+        set_form(ZKR_SHARDED_SPLIT_H, "split calcH: first use on devices %d..%d proved both ways, sums identical; proofs from now on split", shards[0]->device, shards[parts - 1]->device);
+      } else {
+        fprintf(stderr, "zkr: sharded proof: the split calcH %s on first use over devices %d..%d -- every shard computes h for itself from now on (ZKR_SHARD_SPLIT_H=1 forces the split)\n",
+                split_ran ? "DISAGREED with the replicated form" : "failed", shards[0]->device, shards[parts - 1]->device);
+        set_form(ZKR_SHARDED_REPLICATED_H, "replicated calcH: the split form %s on first use over devices %d..%d", split_ran ? "disagreed with the replicated one" : "failed",
+                 shards[0]->device, shards[parts - 1]->device);
+      }
+    }
+    return zkr_prove_combine(shards[0], partials.data(), parts, r32, s32, proof_out);  // the replicated pass' sums either way
+  }
+  rc = run_shards_once(shards, parts, ok, klog, partials, partial, &ran_split);
+  if (rc) return rc;
+  if (ran_split) set_form(ZKR_SHARDED_SPLIT_H, "split calcH: %s", policy == 1 ? "ZKR_SHARD_SPLIT_H=1" : distinct ? "checked against the replicated form on first use" : "all shards on one device");
+  else set_form(ZKR_SHARDED_REPLICATED_H, "replicated calcH: %s", ok ? "a shard's host thread could not be started" : why);
   return zkr_prove_combine(shards[0], partials.data(), parts, r32, s32, proof_out);
 }
 }  // namespace
@@ -389,6 +494,18 @@ int zkr_prove_sharded_split_stats(unsigned *parts_out, double phase_ms_out[64]) 
   if (!parts_out || !phase_ms_out) { set_error("null argument"); return ZKR_ERR_ARG; }
   *parts_out = last_split_parts;
   memcpy(phase_ms_out, last_split_phase_ms, sizeof(last_split_phase_ms));
+  return 0;
+}
+int zkr_prove_sharded_last_form(int *form_out, char *reason_out, size_t reason_len) {
+  if (!form_out) { set_error("null argument"); return ZKR_ERR_ARG; }
+  *form_out = last_form;
+  if (reason_out && reason_len) { strncpy(reason_out, last_reason, reason_len - 1); reason_out[reason_len - 1] = 0; }
+  return 0;
+}
+int zkr_key_replication(const zkr_key *key, int *mode_out, int *peer_direct_out) {
+  if (!key || !mode_out) { set_error("null argument"); return ZKR_ERR_ARG; }
+  *mode_out = key->replica_mode;
+  if (peer_direct_out) *peer_direct_out = key->replica_direct ? 1 : 0;
   return 0;
 }
 int zkr_prove_sharded_device(zkr_key *const *shards, size_t parts, const void *const *d_witnesses_std, const uint8_t *r32, const uint8_t *s32,

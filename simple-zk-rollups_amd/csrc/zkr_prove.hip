@@ -263,6 +263,7 @@ int calc_h_device(zkr_key *k, ProofSlot &sl, hipStream_t s, int nbat) {
 // ------------------------------------------------------------------ calcH split over the shards of one proof
 thread_local ShardGroup *shard_group = nullptr;
 thread_local unsigned shard_group_part = 0;
+thread_local bool shard_turn_held = false;
 
 // The top klog stages of a transform of 2^L points whose 2^klog blocks live in different buffers (kernels_ntt.hpp CROSS): this
 // shard's columns [col_lo, col_lo + col_n) of every block.  rows_*[r]: where block r starts (x_sub = 0) or where this shard's
@@ -1273,6 +1274,10 @@ int zkr_prove(zkr_key *key, const void *witness_std, size_t witness_len, const u
 static const uint8_t ZERO32[32] = {0};
 int zkr_prove_partial_device(zkr_key *key, const void *d_witness_std, void *stream, uint8_t partial_out[ZKR_PARTIAL_BYTES]) {
   if (!key || !d_witness_std || !partial_out) { set_error("null argument"); return ZKR_ERR_ARG; }
+  // a shard proving on its own takes its shard's turn: a split group that failed on this shard set drains its stragglers (whose
+  // cross passes write THIS shard's vectors) before it gives the turns back (zkr_multi.hip run_shards_once)
+  std::unique_lock<std::mutex> own_turn;
+  if (key->h.shard_parts > 1 && !shard_turn_held) own_turn = std::unique_lock<std::mutex>(key->split_mu);
   int t = -1;
   // blinding plays no part before the assembly: the slot gets zeros
   int rc = with_free_slot(key, true, &t, [&](ProofSlot &sl) { return prove_submit(key, sl, (const Fr *)d_witness_std, ZERO32, ZERO32, (hipStream_t)stream); });
@@ -1286,6 +1291,8 @@ int zkr_prove_partial_device(zkr_key *key, const void *d_witness_std, void *stre
 int zkr_prove_partial(zkr_key *key, const void *witness_std, size_t witness_len, uint8_t partial_out[ZKR_PARTIAL_BYTES]) {
   if (!key || !witness_std || !partial_out) { set_error("null argument"); return ZKR_ERR_ARG; }
   if (witness_len != (size_t)key->h.n * 32) { set_error("witness is %zu bytes, key expects nVars*32 = %zu", witness_len, (size_t)key->h.n * 32); return ZKR_ERR_BAD_WITNESS; }
+  std::unique_lock<std::mutex> own_turn;  // as in zkr_prove_partial_device
+  if (key->h.shard_parts > 1 && !shard_turn_held) own_turn = std::unique_lock<std::mutex>(key->split_mu);
   int st = -1;
   int rc = stage_acquire(key, &st);
   if (rc) return rc;

@@ -137,6 +137,7 @@ void build_win8(VkEntry &e) {
 // the parsed key for these bytes (ZKR_ERR_* through *rc when they are not a well-formed key for n_public inputs)
 std::shared_ptr<const VkEntry> cached_vk(const void *vk_bin, size_t vk_len, size_t n_public, int *rc) {
   *rc = 0;
+  std::shared_ptr<VkEntry> copy;     // ... and the private copy of it they are built on
   std::shared_ptr<VkEntry> upgrade;  // the entry whose window tables this call builds -- OUTSIDE the lock: 255 x nPublic mixed
                                      // additions (tens of ms for the ~640 inputs of a 2^20 rollup key) must not stall the other verifiers
   {
@@ -148,11 +149,12 @@ std::shared_ptr<const VkEntry> cached_vk(const void *vk_bin, size_t vk_len, size
       vk_cache.splice(vk_cache.begin(), vk_cache, it);
       if (++e->uses != 2 || !e->win8.empty()) return e;
       upgrade = e;  // second use: worth the tables (uses is past 2 now: no second caller starts the same build)
+      copy = std::make_shared<VkEntry>(*e);  // the copy is taken UNDER the lock: other verifiers bump e->uses under it meanwhile
       break;
     }
   }
   if (upgrade) {
-    auto e2 = std::make_shared<VkEntry>(*upgrade);
+    std::shared_ptr<VkEntry> e2 = copy;
     build_win8(*e2);
     std::lock_guard<std::mutex> lk(vk_mu);  // publish: the new entry replaces the old one where it still sits (readers keep theirs)
     for (auto &slot : vk_cache)

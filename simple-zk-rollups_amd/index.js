@@ -46,31 +46,38 @@ function bigintToLe32(v) {
 // snarkjs would reduce mod r, the chain refuses: the facade sides with the chain)
 const signalsInRange = (ps) => ps.every((x) => { const v = BigInt(x); return v >= 0n && v < R; });
 
-// Identity of a provingKeyBin: its length and a SHA-256 over the first 4 KiB (geometry, alfa / beta / delta of the setup), the
-// last 4 KiB (the last hExps points) and 64 blocks of 4 KiB spread evenly over everything in between.  Header and tail alone
-// would alias two circuits of equal sizes set up from the same toxic waste (seeded test setups: same header points, same
-// t^i Z / delta tail) and the cache would prove with the wrong key where the reference re-parses on every call
-// (operator/src/snarks/common.ts:28); the strided blocks reach into the QAP rows and every point section.  About 0.3 MB
-// hashed whatever the key's size (< 0.1 ms); tests/test_gpu_multi.py and tests/test_node_host.py hold the aliasing case.
-// full (default: env ZKR_KEY_FINGERPRINT === "full"): every byte is hashed -- exact, a few ms per MB -- for callers whose keys
-// may differ in a single constraint under one setup (sampling sees geometry, setup and broad content, not a lone coefficient).
+// Identity of a provingKeyBin: its length and a SHA-256.  Default (round 5): over EVERY byte -- exact, as the reference is by
+// re-parsing the key on every call (operator/src/snarks/common.ts:28); a few ms per MB, paid once per buffer OBJECT (memoised in a
+// WeakMap; a memo hit re-checks the cheap sampled digest, so an object refilled with another key is hashed again).
+// full === false or env ZKR_KEY_FINGERPRINT=sampled: the first 4 KiB (geometry, alfa / beta / delta of the setup), the last 4 KiB
+// and 64 blocks of 4 KiB spread evenly in between -- 0.3 MB whatever the size (< 0.1 ms): sees geometry, setup and broad content,
+// not a lone coefficient (two keys of one setup that differ in a single constraint alias) -- for callers that rebuild a large
+// buffer per call and know their keys differ broadly.
 const FP_BLOCK = 4096, FP_STRIDED = 64;
+const fpMemo = new WeakMap();  // buffer object -> {sampled, full}
+function sampledDigest(u8) {
+  const n = u8.length, h = require("crypto").createHash("sha256");
+  h.update(u8.subarray(0, FP_BLOCK));
+  const span = n - 2 * FP_BLOCK;
+  for (let i = 0; i < FP_STRIDED; i++) {
+    const o = FP_BLOCK + Math.floor((span - FP_BLOCK) * i / (FP_STRIDED - 1));
+    h.update(u8.subarray(o, o + FP_BLOCK));
+  }
+  h.update(u8.subarray(n - FP_BLOCK, n));
+  return h.digest("hex");
+}
 function keyFingerprint(buf, full) {
   const u8 = buf instanceof ArrayBuffer ? new Uint8Array(buf) : new Uint8Array(buf.buffer, buf.byteOffset, buf.byteLength);
   const n = u8.length;
-  const h = require("crypto").createHash("sha256");
-  if (full === undefined) full = process.env.ZKR_KEY_FINGERPRINT === "full";
-  if (full || n <= FP_BLOCK * (FP_STRIDED + 2)) h.update(u8);
-  else {
-    h.update(u8.subarray(0, FP_BLOCK));
-    const span = n - 2 * FP_BLOCK;
-    for (let i = 0; i < FP_STRIDED; i++) {
-      const o = FP_BLOCK + Math.floor((span - FP_BLOCK) * i / (FP_STRIDED - 1));
-      h.update(u8.subarray(o, o + FP_BLOCK));
-    }
-    h.update(u8.subarray(n - FP_BLOCK, n));
-  }
-  return n + ":" + h.digest("hex");
+  if (full === undefined) full = process.env.ZKR_KEY_FINGERPRINT !== "sampled";
+  if (n <= FP_BLOCK * (FP_STRIDED + 2)) return n + ":" + require("crypto").createHash("sha256").update(u8).digest("hex");
+  const sampled = sampledDigest(u8);
+  if (!full) return n + ":" + sampled;
+  const hit = fpMemo.get(buf);
+  if (hit !== undefined && hit.sampled === sampled && hit.n === n) return hit.full;
+  const fp = n + ":" + require("crypto").createHash("sha256").update(u8).digest("hex");
+  fpMemo.set(buf, { sampled, n, full: fp });
+  return fp;
 }
 
 // Process-level cache of device keys (SURVEY.md 8(b) "Ownership").  The reference builds a NEW object for every proof
@@ -80,6 +87,7 @@ function keyFingerprint(buf, full) {
 // (groth16GenProofBatch with opts.devices); the least recently used of KEY_CACHE_SLOTS contents is dropped with all its
 // replicas (their device memory goes with the handles).
 const KEY_CACHE_SLOTS = 2;
+const MAX_SHARD_SETS = 2;    // device lists whose shards an entry keeps (least recently used dropped)
 const keyCache = new Map();  // fingerprint -> Map("device#ordinal" -> native key handle), in recency order
 const keyCacheStats = { loads: 0, hits: 0, replications: 0 };
 // a whole-key replica of the entry (any device), or undefined: the source of device-to-device copies and of shards
@@ -134,11 +142,13 @@ function cachedReplicas(provingKeyBin, devices) {
 function cachedShards(provingKeyBin, devices) {
   const ent = cacheEntry(provingKeyBin), slot = "shards:" + devices.join(",");
   let shards = ent.get(slot);
-  if (shards !== undefined) { keyCacheStats.hits++; return shards; }
+  if (shards !== undefined) { keyCacheStats.hits++; ent.delete(slot); ent.set(slot, shards); return shards; }
   let whole = anyReplica(ent);
   if (whole === undefined) { whole = native().keyLoad(provingKeyBin, devices[0]); keyCacheStats.loads++; ent.set(devices[0] + "#0", whole); }
   shards = devices.map((d, i) => native().keyShard(whole, i, devices.length, d));
   keyCacheStats.shardings = (keyCacheStats.shardings || 0) + 1;
+  const sets = Array.from(ent.keys()).filter((k) => k.startsWith("shards:"));
+  while (sets.length >= MAX_SHARD_SETS) ent.delete(sets.shift());  // bounded: a caller cycling through device lists does not pile up shard sets
   ent.set(slot, shards);
   return shards;
 }
@@ -488,7 +498,9 @@ class WithdrawCircuit {
 module.exports = {
   buildBn128, genProof, binarifyWitness, binarifyProvingKey, solidityProof, proofFromBytes, isValid, isValidBatch, binarifyVerifyingKey,
   binarifyR1cs, verifyingKeyFromBytes, solidityVerifyingKey, solidityVerifyingKeySource,
-  keyCacheStats: () => Object.assign({ entries: keyCache.size, handles: Array.from(keyCache.values()).reduce((a, e) => a + Array.from(e.values()).reduce((b, v) => b + (Array.isArray(v) ? v.length : 1), 0), 0) }, keyCacheStats), clearKeyCache, keyFingerprint,
+  // which form the last sharded proof took and why ({form: "split" | "replicated" | "none", reason}); how a key handle came to its device
+  shardedLastForm: () => native().shardedLastForm(), keyReplication: (key) => native().keyReplication(key),
+  keyCacheStats: () => Object.assign({ shardedLastForm: addon ? native().shardedLastForm() : { form: "none", reason: "" } }, { entries: keyCache.size, handles: Array.from(keyCache.values()).reduce((a, e) => a + Array.from(e.values()).reduce((b, v) => b + (Array.isArray(v) ? v.length : 1), 0), 0) }, keyCacheStats), clearKeyCache, keyFingerprint,
   multiHash, multiHashBatch, buildBalanceTree, hashLeftRight, genPublicKey, formatPrivKeyForBabyJub, sign, verify, RollupCircuit, WithdrawCircuit,
   deviceCount: () => { native(); return deviceCount; },
   version: () => native().version(),

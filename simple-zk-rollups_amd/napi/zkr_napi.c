@@ -46,7 +46,13 @@ static struct {
   int (*rollup_info)(uint32_t, uint32_t, uint32_t *, uint32_t *, uint32_t *);
   int (*rollup_r1cs)(uint32_t, uint32_t, void **, size_t *);
   int (*rollup_witness)(uint32_t, uint32_t, const uint8_t *, size_t, void **, size_t *);
+  int (*sharded_last_form)(int *, char *, size_t);
+  int (*key_replication)(const zkr_key *, int *, int *);
 } Z;
+/* which form the last sharded proof took (zkr_prove_sharded_last_form, read on the worker thread that ran it, published on the JS
+ * thread when its promise settles) */
+static int g_sharded_form = 0;
+static char g_sharded_reason[256] = "";
 
 #define NAPI_OK(call)                                                     \
   do {                                                                    \
@@ -87,6 +93,7 @@ static napi_value js_load(napi_env env, napi_callback_info info) {
     SYM(multihash_batch, "zkr_mimcsponge_multihash_batch") SYM(tree_build, "zkr_balance_tree_build")
     SYM(format_privkey, "zkr_babyjub_format_privkey") SYM(withdraw_r1cs, "zkr_withdraw_r1cs") SYM(withdraw_witness, "zkr_withdraw_witness")
     SYM(rollup_info, "zkr_rollup_info") SYM(rollup_r1cs, "zkr_rollup_r1cs") SYM(rollup_witness, "zkr_rollup_witness")
+    SYM(sharded_last_form, "zkr_prove_sharded_last_form") SYM(key_replication, "zkr_key_replication")
     Z.handle = h;
   }
   napi_value out;
@@ -280,6 +287,8 @@ typedef struct {
   uint8_t r[32], s[32], proof[256];
   int rc;
   char err[512];
+  int form;            /* proveSharded: split / replicated calcH and why */
+  char reason[256];
 } prove_job;
 
 static void prove_execute(napi_env env, void *data) {  /* libuv worker thread: the event loop is not blocked */
@@ -288,11 +297,13 @@ static void prove_execute(napi_env env, void *data) {  /* libuv worker thread: t
   j->rc = j->shards ? Z.prove_sharded(j->shards, j->n_shards, j->wit, j->wit_len, j->have_rs ? j->r : NULL, j->have_rs ? j->s : NULL, j->proof)
                     : Z.prove(j->key, j->wit, j->wit_len, j->have_rs ? j->r : NULL, j->have_rs ? j->s : NULL, j->proof, NULL);
   if (j->rc) { strncpy(j->err, Z.last_error(), sizeof(j->err) - 1); j->err[sizeof(j->err) - 1] = 0; }
+  if (j->shards) Z.sharded_last_form(&j->form, j->reason, sizeof(j->reason));  /* thread-local in the library: this thread ran the proof */
 }
 
 static void prove_complete(napi_env env, napi_status status, void *data) {
   prove_job *j = (prove_job *)data;
   napi_value v;
+  if (j->shards && status == napi_ok) { g_sharded_form = j->form; memcpy(g_sharded_reason, j->reason, sizeof(g_sharded_reason)); }
   if (status == napi_ok && j->rc == 0) {
     void *out;
     napi_create_buffer_copy(env, 256, j->proof, &out, &v);
@@ -345,6 +356,11 @@ static napi_value prove_common(napi_env env, napi_callback_info info, int sharde
   if (napi_create_promise(env, &j->deferred, &promise) != napi_ok || napi_create_reference(env, argv[0], 1, &j->key_ref) != napi_ok ||
       napi_create_reference(env, argv[1], 1, &j->wit_ref) != napi_ok || napi_create_string_utf8(env, "zkr_prove", NAPI_AUTO_LENGTH, &name) != napi_ok ||
       napi_create_async_work(env, NULL, name, prove_execute, prove_complete, j, &j->work) != napi_ok || napi_queue_async_work(env, j->work) != napi_ok) {
+    if (j->deferred) {  /* the promise exists but nothing will ever settle it: reject it before the job goes (it is not returned) */
+      napi_value msg, err;
+      if (napi_create_string_utf8(env, "prove: could not queue the proof job", NAPI_AUTO_LENGTH, &msg) == napi_ok && napi_create_error(env, NULL, msg, &err) == napi_ok)
+        napi_reject_deferred(env, j->deferred, err);
+    }
     if (j->key_ref) napi_delete_reference(env, j->key_ref);
     if (j->wit_ref) napi_delete_reference(env, j->wit_ref);
     if (j->work) napi_delete_async_work(env, j->work);
@@ -353,6 +369,37 @@ static napi_value prove_common(napi_env env, napi_callback_info info, int sharde
     return throw_msg(env, "prove: could not queue the proof job");
   }
   return promise;
+}
+/* shardedLastForm() -> {form: "none" | "split" | "replicated", reason}: of the last proveSharded whose promise has settled */
+static napi_value js_sharded_last_form(napi_env env, napi_callback_info info) {
+  (void)info;
+  static const char *names[] = {"none", "split", "replicated"};
+  napi_value out, f, r;
+  NAPI_OK(napi_create_object(env, &out));
+  NAPI_OK(napi_create_string_utf8(env, names[g_sharded_form >= 0 && g_sharded_form <= 2 ? g_sharded_form : 0], NAPI_AUTO_LENGTH, &f));
+  NAPI_OK(napi_create_string_utf8(env, g_sharded_reason, NAPI_AUTO_LENGTH, &r));
+  NAPI_OK(napi_set_named_property(env, out, "form", f));
+  NAPI_OK(napi_set_named_property(env, out, "reason", r));
+  return out;
+}
+/* keyReplication(key) -> {mode: "none" | "full" | "base", peerDirect}: how the key came to its device (zkr_key_replication) */
+static napi_value js_key_replication(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  if (!Z.handle) return throw_msg(env, "libzkr_hip.so not loaded");
+  zkr_key *key = NULL;
+  if (argc < 1 || napi_get_value_external(env, argv[0], (void **)&key) != napi_ok) return throw_msg(env, "keyReplication(key)");
+  int mode = 0, direct = 0;
+  if (Z.key_replication(key, &mode, &direct)) return throw_msg(env, Z.last_error());
+  static const char *names[] = {"none", "full", "base"};
+  napi_value out, m, d;
+  NAPI_OK(napi_create_object(env, &out));
+  NAPI_OK(napi_create_string_utf8(env, names[mode >= 0 && mode <= 2 ? mode : 0], NAPI_AUTO_LENGTH, &m));
+  NAPI_OK(napi_get_boolean(env, direct != 0, &d));
+  NAPI_OK(napi_set_named_property(env, out, "mode", m));
+  NAPI_OK(napi_set_named_property(env, out, "peerDirect", d));
+  return out;
 }
 static napi_value js_prove(napi_env env, napi_callback_info info) { return prove_common(env, info, 0); }
 static napi_value js_prove_sharded(napi_env env, napi_callback_info info) { return prove_common(env, info, 1); }
@@ -479,6 +526,11 @@ static napi_value prove_batch_common(napi_env env, napi_callback_info info, int 
   if (napi_create_promise(env, &j->deferred, &promise) != napi_ok || napi_create_reference(env, argv[0], 1, &j->key_ref) != napi_ok ||
       napi_create_string_utf8(env, "zkr_prove_batch", NAPI_AUTO_LENGTH, &name) != napi_ok ||
       napi_create_async_work(env, NULL, name, batch_execute, batch_complete, j, &j->work) != napi_ok || napi_queue_async_work(env, j->work) != napi_ok) {
+    if (j->deferred) {  /* as in prove_common: a promise nobody will settle is rejected before the job goes */
+      napi_value msg, err;
+      if (napi_create_string_utf8(env, "proveBatch: could not queue the proof job", NAPI_AUTO_LENGTH, &msg) == napi_ok && napi_create_error(env, NULL, msg, &err) == napi_ok)
+        napi_reject_deferred(env, j->deferred, err);
+    }
     batch_free(env, j);  /* nothing was queued: the job and its references go here */
     return throw_msg(env, "proveBatch: could not queue the proof job");
   }
@@ -695,6 +747,8 @@ static napi_value init(napi_env env, napi_value exports) {
       {"withdrawCircuit", NULL, js_withdraw_circuit, NULL, NULL, NULL, napi_default, NULL},
       {"rollupGpuHash", NULL, js_rollup_gpu_hash, NULL, NULL, NULL, napi_default, NULL},
       {"verifyBatch", NULL, js_verify_batch, NULL, NULL, NULL, napi_default, NULL},
+      {"shardedLastForm", NULL, js_sharded_last_form, NULL, NULL, NULL, napi_default, NULL},
+      {"keyReplication", NULL, js_key_replication, NULL, NULL, NULL, napi_default, NULL},
   };
   napi_define_properties(env, exports, sizeof(props) / sizeof(props[0]), props);
   return exports;

@@ -49,6 +49,8 @@ def lib():
     L.zkr_key_adopt_base_arena.argtypes = [vp, sz, i, c.POINTER(vp)]
     L.zkr_key_replicate.argtypes = [vp, i, i, c.POINTER(vp)]
     L.zkr_key_device.argtypes = [vp]
+    L.zkr_key_replication.argtypes = [vp, c.POINTER(i), c.POINTER(i)]
+    L.zkr_prove_sharded_last_form.argtypes = [c.POINTER(i), c.c_char_p, sz]
     L.zkr_prove_batch_multi.argtypes = [c.POINTER(vp), sz, c.POINTER(c.c_char_p), sz, sz, u8p, u8p, u8p]
     L.zkr_prove_batch_multi_device.argtypes = [c.POINTER(vp), sz, c.POINTER(vp), sz, u8p, u8p, u8p]
     L.zkr_key_shard.argtypes = [vp, c.c_uint, c.c_uint, i, c.POINTER(vp)]
@@ -201,6 +203,12 @@ class ProvingKey:
         _check(lib().zkr_key_replicate(self._h, device, REPLICATE_MODES[mode], ctypes.byref(h)))
         return ProvingKey(h, device)
 
+    def replication(self):
+        """How this key came to its device (zkr_key_replication): {"mode": "none" | "full" | "base", "peer_direct": bool}."""
+        mode, direct = ctypes.c_int(0), ctypes.c_int(0)
+        _check(lib().zkr_key_replication(self._h, ctypes.byref(mode), ctypes.byref(direct)))
+        return {"mode": {0: "none", 1: "full", 2: "base"}[mode.value], "peer_direct": bool(direct.value)}
+
     def shard(self, part, parts, device=None):
         """Shard `part` of `parts` of this (whole) key on `device` (default: the key's own): the points of one contiguous range
         of every MSM of a proof, all window levels, plus the whole QAP (zkr_key_shard)."""
@@ -322,8 +330,7 @@ class ProvingKey:
             if n == 0:
                 return []
             arr = (ctypes.c_void_p * n)(*[ctypes.c_void_p(p) for p in d_witness_ptrs])
-            rb = None if rs is None else b"".join(int(x).to_bytes(32, "little") for x in rs)
-            sb = None if ss is None else b"".join(int(x).to_bytes(32, "little") for x in ss)
+            rb, sb = _blinding_bytes(rs, ss, n)
             out = ctypes.create_string_buffer(256 * n)
             _check(lib().zkr_prove_batch_device(self._h, arr, n, rb, sb, ctypes.c_void_p(stream or 0), out))
             return [out.raw[256 * i:256 * i + 256] for i in range(n)]
@@ -341,11 +348,11 @@ class ProvingKey:
         n = len(witnesses)
         if n == 0:
             return []
+        wlen = _equal_length(witnesses)
         arr = (ctypes.c_char_p * n)(*[bytes(w) for w in witnesses])
-        rb = None if rs is None else b"".join(int(x).to_bytes(32, "little") for x in rs)
-        sb = None if ss is None else b"".join(int(x).to_bytes(32, "little") for x in ss)
+        rb, sb = _blinding_bytes(rs, ss, n)
         out = ctypes.create_string_buffer(256 * n)
-        _check(lib().zkr_prove_batch(self._h, arr, len(witnesses[0]), n, rb, sb, out))
+        _check(lib().zkr_prove_batch(self._h, arr, wlen, n, rb, sb, out))
         return [out.raw[256 * i:256 * i + 256] for i in range(n)]
 
     def slots(self):
@@ -378,10 +385,24 @@ class ProvingKey:
         return out
 
 
-def _blinding_bytes(rs, ss):
+def _blinding_bytes(rs, ss, n=None):
+    """r / s of a batch as 32-byte LE records.  The C side reads 32 * count bytes of each: a short list must not reach it."""
+    if (rs is None) != (ss is None):
+        raise ValueError("pass both rs and ss or neither")
+    if rs is not None and n is not None and (len(rs) != n or len(ss) != n):
+        raise ValueError("a batch of %d proofs needs %d blinding scalars of each kind, got %d and %d" % (n, n, len(rs), len(ss)))
     rb = None if rs is None else b"".join(int(x).to_bytes(32, "little") for x in rs)
     sb = None if ss is None else b"".join(int(x).to_bytes(32, "little") for x in ss)
     return rb, sb
+
+
+def _equal_length(witnesses):
+    """The batch calls pass ONE witness_len for every pointer: a shorter buffer would be read past its end."""
+    n0 = len(witnesses[0])
+    for i, w in enumerate(witnesses):
+        if len(w) != n0:
+            raise ValueError("witness %d is %d bytes, witness 0 is %d: a batch takes witnesses of one circuit" % (i, len(w), n0))
+    return n0
 
 
 def prove_batch_multi(keys, witnesses, rs=None, ss=None):
@@ -391,10 +412,11 @@ def prove_batch_multi(keys, witnesses, rs=None, ss=None):
     if n == 0:
         return []
     ks = (ctypes.c_void_p * len(keys))(*[k._h for k in keys])
+    wlen = _equal_length(witnesses)
     arr = (ctypes.c_char_p * n)(*[bytes(w) for w in witnesses])
-    rb, sb = _blinding_bytes(rs, ss)
+    rb, sb = _blinding_bytes(rs, ss, n)
     out = ctypes.create_string_buffer(256 * n)
-    _check(lib().zkr_prove_batch_multi(ks, len(keys), arr, len(witnesses[0]), n, rb, sb, out))
+    _check(lib().zkr_prove_batch_multi(ks, len(keys), arr, wlen, n, rb, sb, out))
     return [out.raw[256 * i:256 * i + 256] for i in range(n)]
 
 
@@ -406,7 +428,7 @@ def prove_batch_multi_device(keys, d_witness_ptrs, rs=None, ss=None):
         return []
     ks = (ctypes.c_void_p * len(keys))(*[k._h for k in keys])
     arr = (ctypes.c_void_p * n)(*[ctypes.c_void_p(p) for p in d_witness_ptrs])
-    rb, sb = _blinding_bytes(rs, ss)
+    rb, sb = _blinding_bytes(rs, ss, n)
     out = ctypes.create_string_buffer(256 * n)
     _check(lib().zkr_prove_batch_multi_device(ks, len(keys), arr, n, rb, sb, out))
     return [out.raw[256 * i:256 * i + 256] for i in range(n)]
@@ -443,6 +465,18 @@ def sharded_split_stats():
     if parts.value == 0:
         return None
     return [[ms[8 * p + f] for f in range(5)] for p in range(parts.value)]
+
+
+SHARDED_FORMS = {0: "none", 1: "split", 2: "replicated"}
+
+
+def sharded_last_form():
+    """Which form this thread's last sharded proof took and why (zkr_prove_sharded_last_form): {"form": "split" | "replicated" |
+    "none", "reason": one line}.  A sharded proof that fell back to replicated calcH is otherwise only a slower number."""
+    form = ctypes.c_int(0)
+    buf = ctypes.create_string_buffer(256)
+    _check(lib().zkr_prove_sharded_last_form(ctypes.byref(form), buf, 256))
+    return {"form": SHARDED_FORMS.get(form.value, str(form.value)), "reason": buf.value.decode()}
 
 
 def verify(vk_bin: bytes, proof: bytes, public_signals) -> bool:

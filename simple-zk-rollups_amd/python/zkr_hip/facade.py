@@ -112,8 +112,7 @@ def is_valid(verifying_key, proof, public_signals) -> bool:
 # Process-level cache of device keys (SURVEY.md 8(b) "Ownership").  The reference builds a NEW object for every proof
 # (`await buildBn128()` at common.ts:23, scripts/index.js:40) and hands it the same provingKeyBin again (common.ts:28),
 # so a cache on the object would re-parse, re-upload and rebuild the window tables on every call.  An entry is one key
-# CONTENT (length + digest of the first and last 4 KiB and of 64 blocks of 4 KiB spread evenly in between: header and tail
-# alone alias two circuits of equal sizes set up from the same toxic waste) with its replicas, one per (device, ordinal)
+# CONTENT (length + digest of every byte, key_fingerprint below) with its replicas, one per (device, ordinal)
 # asked for; the least recently used of KEY_CACHE_SLOTS contents is dropped with its replicas (a ProvingKey frees its arena
 # when the last reference goes).
 KEY_CACHE_SLOTS = 2
@@ -123,18 +122,30 @@ _key_cache_lock = threading.Lock()
 key_cache_stats = {"loads": 0, "hits": 0, "replications": 0}
 
 
+_fp_memo = collections.OrderedDict()   # id(bytes object) -> (the object: kept alive so that its id stays its own, fingerprint)
+FP_MEMO_SLOTS = 4
+MAX_SHARD_SETS = 2                      # device lists whose shards an entry keeps (least recently used dropped)
+
+
 def key_fingerprint(buf, full=None):
-    """(length, digest) identifying a provingKeyBin.  full (default: env ZKR_KEY_FINGERPRINT == "full"): digest of every
-    byte -- exact, ~1 ms per MB -- instead of the sampled blocks, for callers whose keys may differ in a single constraint
-    under one setup (sampling sees 0.3 MB of the buffer: any difference in geometry, setup or broad content, not a lone
-    36-byte coefficient)."""
+    """(length, digest) identifying a provingKeyBin.  Default (round 5): the digest of EVERY byte -- exact, as the
+    reference is by re-parsing the key on every call (common.ts:28); ~0.5 ms per MB, paid once per buffer OBJECT for immutable
+    `bytes` (memoised by identity, the object is kept alive).  full=False or env ZKR_KEY_FINGERPRINT=sampled: first and last
+    4 KiB + 64 blocks of 4 KiB spread evenly in between (0.3 MB whatever the size: sees any difference in geometry, setup or broad
+    content, not a lone 36-byte coefficient) -- for callers that rebuild a large buffer per call and know their keys differ broadly."""
     import os
     n = len(buf)
-    h = hashlib.blake2b(digest_size=16)
     if full is None:
-        full = os.environ.get("ZKR_KEY_FINGERPRINT") == "full"
+        full = os.environ.get("ZKR_KEY_FINGERPRINT") != "sampled"
+    memo = full and type(buf) is bytes and n > FP_BLOCK * (FP_STRIDED + 2)
+    if memo:
+        hit = _fp_memo.get(id(buf))
+        if hit is not None and hit[0] is buf:
+            _fp_memo.move_to_end(id(buf))
+            return hit[1]
+    h = hashlib.blake2b(digest_size=16)
     if full or n <= FP_BLOCK * (FP_STRIDED + 2):
-        h.update(bytes(buf))
+        h.update(buf if isinstance(buf, (bytes, bytearray, memoryview)) else bytes(buf))
     else:
         h.update(bytes(buf[:FP_BLOCK]))
         span = n - 2 * FP_BLOCK
@@ -142,7 +153,12 @@ def key_fingerprint(buf, full=None):
             o = FP_BLOCK + (span - FP_BLOCK) * i // (FP_STRIDED - 1)
             h.update(bytes(buf[o:o + FP_BLOCK]))
         h.update(bytes(buf[n - FP_BLOCK:]))
-    return (n, h.digest())
+    fp = (n, h.digest())
+    if memo:
+        _fp_memo[id(buf)] = (buf, fp)
+        while len(_fp_memo) > FP_MEMO_SLOTS:
+            _fp_memo.popitem(last=False)
+    return fp
 
 
 def _entry(proving_key_bin):   # caller holds the lock
@@ -199,17 +215,23 @@ def cached_shards(proving_key_bin, devices):
         shards = ent.get(slot)
         if shards is not None:
             key_cache_stats["hits"] += 1
+            ent[slot] = ent.pop(slot)                      # most recently used last
             return shards
         whole = next((k for s, k in ent.items() if s[0] != "shards"), None)
         if whole is None:
             whole = _replica(ent, proving_key_bin, devices[0], 0)
-        shards = ent[slot] = [whole.shard(i, len(devices), d) for i, d in enumerate(devices)]
+        shards = [whole.shard(i, len(devices), d) for i, d in enumerate(devices)]
+        sets = [k for k in ent if k[0] == "shards"]
+        while len(sets) >= MAX_SHARD_SETS:                 # bounded: a caller cycling through device lists does not pile up shard sets
+            del ent[sets.pop(0)]
+        ent[slot] = shards
         return shards
 
 
 def clear_key_cache():
     with _key_cache_lock:
         _key_cache.clear()
+        _fp_memo.clear()
 
 
 class Bn128:

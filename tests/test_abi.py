@@ -63,6 +63,29 @@ def test_multi_device_and_shard_entry_points_check_their_arguments():
     info = (ctypes.c_uint32 * 6)()
     assert L.zkr_key_shard_info(None, info) == -5
     assert b"null" in L.zkr_last_error()
+    # round 5: which form a sharded proof took / how a replica came to its device -- nothing ran on this thread yet
+    form, mode = ctypes.c_int(7), ctypes.c_int(7)
+    assert L.zkr_prove_sharded_last_form(None, None, 0) == -5 and L.zkr_key_replication(None, ctypes.byref(mode), None) == -5
+    assert zkr_hip.sharded_last_form() == {"form": "none", "reason": ""}
+    buf = ctypes.create_string_buffer(4)
+    assert L.zkr_prove_sharded_last_form(ctypes.byref(form), buf, 4) == 0 and form.value == 0 and buf.value == b""
+
+
+def test_ctypes_batch_calls_refuse_ragged_witnesses_and_short_blinding_lists():
+    """the batch wrappers pass ONE witness length and read 32 bytes of r and s per proof -- a shorter witness or a
+    shorter rs / ss list must be refused in Python, before the C side reads past the objects (no device needed: the check
+    comes first)."""
+    import zkr_hip
+    from zkr_hip import binding
+    k = binding.ProvingKey(ctypes.c_void_p(0), 0)      # never dereferenced: every call below fails its argument check
+    k._h = None                                         # ... and its finaliser has nothing to free
+    w = b"\0" * 64
+    for call in (lambda: zkr_hip.prove_batch_multi([k, k], [w, w[:32]]), lambda: k.prove_batch([w, w + w]),
+                 lambda: zkr_hip.prove_batch_multi([k], [w, w], rs=[1], ss=[1, 2]), lambda: zkr_hip.prove_batch_multi([k], [w, w], rs=[1, 2], ss=None),
+                 lambda: k.prove_batch([w, w], rs=[1, 2, 3], ss=[1, 2, 3]), lambda: k.prove_batch_device([1, 2], rs=[1], ss=[1]),
+                 lambda: zkr_hip.prove_batch_multi_device([k], [1, 2, 3], rs=[1, 2], ss=[1, 2])):
+        with pytest.raises(ValueError):
+            call()
 
 
 def test_product_never_imports_oracle():

@@ -347,6 +347,15 @@ def test_bench_two_rank_path_rehearsal_on_one_gpu(launcher):
     assert abs(d["value"] - 2 * 6 / (d["ms_per_step"] * 6e-3)) < 1e-6 * d["value"]      # whole-job rate: all ranks' proofs / max time
     assert d["key"]["bcast_s"] is not None and d["key"]["bcast_GBps"] > 0 and d["proofs_verified"] >= 1
     assert [(p["rank"], p["proofs"]) for p in d["per_rank"]] == [(0, 6), (1, 6)]
+    # round 5: with N > 1 the intra-proof sharding leg is MEASURED -- rank 0 builds shard i on device i (here both on cuda:0)
+    # and times zkr_prove_sharded_device; which form ran is in the line, as scalars of `config` too
+    sh = d["intra_proof_sharding"]
+    assert sh["measured"] is True and sh["parts"] == 2 and sh["devices"] == [0, 0] and sh["rehearsal_on_one_gpu"] is True
+    assert sh["proof_identical_to_whole_key"] is True and sh["form"] == "split" and sh["ms_per_proof"] > 0 and sh["replicated_calch_ms_per_proof"] > 0
+    assert len(sh["split_phase_ms_per_shard"]) == 2 and all(x > 0 for x in sh["remote_GBps_per_shard_in_cross_phases"])
+    cfg = d["config"]
+    assert cfg["sharded_parts"] == 2 and cfg["sharded_form"] == "split" and cfg["sharded_measured"] is False and cfg["sharded_ms"] == sh["ms_per_proof"]
+    assert cfg["key_replication"] == "gloo" and cfg["key_bcast_GBps"] > 0
 
 
 def test_bench_two_rank_rehearsal_survives_a_failed_broadcast():
@@ -391,3 +400,37 @@ def test_bench_inproc_multi_device_rehearsal_on_one_gpu(mode):
     assert d["config"]["devices"] == [0, 0] and "REHEARSAL" in d["config"]["parallelism"]
     assert len(d["key"]["replicas"]) == 1 and d["key"]["replicas"][0]["GBps"] > 0
     assert d["roofline"]["frac"] > 0 and set(d) >= {"metric", "value", "unit", "roofline", "config", "dtype", "data", "vs_baseline"}
+    # round 5: how the replica was made and the measured sharded proof over the same device list, in the line and as scalars
+    assert d["key"]["replica_modes"] == [{"mode": "full" if mode == "auto" else "base", "peer_direct": True}]
+    assert d["config"]["key_replication"].startswith("peer-copy: " + ("full" if mode == "auto" else "base"))
+    sh = d["intra_proof_sharding"]
+    assert sh["measured"] is True and sh["devices"] == [0, 0] and sh["proof_identical_to_whole_key"] is True and sh["form"] == "split"
+    assert d["config"]["sharded_parts"] == 2 and d["config"]["sharded_ms"] > 0 and d["config"]["sharded_reason"] == sh["reason"]
+    assert d["roofline"]["valu_frac_kernel"] > 0 and d["roofline"]["valu_frac_proof"] > 0          # scalars the driver's record keeps
+
+
+def test_multi_gpu_preflight_rehearsal_on_one_gpu():
+    """tools/multi_gpu_preflight.py --devices 0,0: peer matrix, a device-to-device copy, the key replicated
+    in both forms, a 2-shard sharded proof (first-use form reported, proof == whole key's, verifies), and the RCCL step -- which on
+    ONE device must end in the per-rank fallback (RCCL refuses two ranks per device), printed, not hung."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "multi_gpu_preflight.py"), "--devices", "0,0", "--copy-mib", "256", "--log-m", "14", "--rccl-timeout", "20"],
+                       capture_output=True, text=True, timeout=400, env=env, cwd=root)
+    rows = {}
+    for ln in r.stdout.splitlines():
+        if ln.startswith("{"):
+            d = json.loads(ln)
+            rows[d["step"]] = d
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    assert set(rows) >= {"peers", "peer_copy", "replicate", "sharded", "rccl", "summary"}
+    assert rows["peers"]["can_access"] == [[True]] and rows["peer_copy"]["pairs"][0]["intact"] and rows["peer_copy"]["pairs"][0]["GBps"] > 50
+    assert [x["mode"] for x in rows["replicate"]["replicas"]] == ["full", "base"] and all(x["proof_identical"] for x in rows["replicate"]["replicas"])
+    run = rows["sharded"]["runs"][0]
+    assert run["parts"] == 2 and run["identical_to_whole_key"] and run["verifies"] and run["form"] == "split"
+    assert rows["summary"]["ok"] is True and rows["summary"]["rehearsal"] is True
+    assert "key_replication_would_use" in rows["summary"]     # rccl or the per-rank fallback: either way a diagnosis

@@ -196,8 +196,9 @@ def test_key_cache_does_not_alias_equal_sized_circuits_of_one_setup():
     pk2, _ = zkr_hip.setup_r1cs_websnark(_r1cs(narrow), toxl)
     assert len(pk0) == len(pk1) == len(pk2) > 4096 * 66                    # the sampled path, not the whole-buffer one
     assert pk0[:4096] == pk1[:4096] == pk2[:4096] and pk0[-4096:] == pk1[-4096:] == pk2[-4096:]   # what round 3 hashed: aliases
-    assert zkr_hip.key_fingerprint(pk0) != zkr_hip.key_fingerprint(pk1)
+    assert zkr_hip.key_fingerprint(pk0, full=False) != zkr_hip.key_fingerprint(pk1, full=False)
     assert len({zkr_hip.key_fingerprint(k, full=True) for k in (pk0, pk1, pk2)}) == 3
+    assert len({zkr_hip.key_fingerprint(k) for k in (pk0, pk1, pk2)}) == 3         # round 5: the default is the exact one
     wb = g.binarify_witness(circ["witness"])
     rng = g.SplitMix64(8)
     r, s = rng.fr(), rng.fr()
@@ -208,4 +209,8 @@ def test_key_cache_does_not_alias_equal_sized_circuits_of_one_setup():
     assert zkr_hip.key_cache_stats["loads"] - before["loads"] == 2 and got0 != got1
     assert got0 == g.proof_to_json(g.proof_from_toxic(circ, tox, circ["witness"], r, s))
     assert got1 == g.proof_to_json(g.proof_from_toxic(broad, tox, circ["witness"], r, s))
+    # the single edited constraint: a third key for the cache, its own proof (round 4 proved with pk0's key here unless ZKR_KEY_FINGERPRINT=full)
+    got2 = zkr_hip.groth16_gen_proof(wb, pk2, r=r, s=s)
+    assert zkr_hip.key_cache_stats["loads"] - before["loads"] == 3 and got2 not in (got0, got1)
+    assert got2 == g.proof_to_json(g.proof_from_toxic(narrow, tox, circ["witness"], r, s))
     zkr_hip.clear_key_cache()
