@@ -71,8 +71,9 @@ def cpu_baseline(sample_log_m, target_log_m, gpu_key=None):
     import coracle
     import zkr_hip
     # BASELINE.md section 3 promises `-O3 -march=native`: the shipped library is the portable x86-64-v2 build (it has to run on
-    # whatever CPU the box has), so the timed one is compiled here, on this host, before the first call
-    build = coracle.use_native()
+    # whatever CPU the box has), so a native one is compiled here, on this host, before the first call, and the faster of the two
+    # on a small proof is the one timed (on the EPYC 9575F boxes gcc 11's -march=native came out 10 % SLOWER)
+    build = coracle.use_fastest(*zkr_hip.synth_websnark(14, N_PUBLIC, CIRCUIT_SEED, TOXIC_SEED, device=0))   # native or portable, whichever is faster HERE
     pkb, wb = zkr_hip.synth_websnark(sample_log_m, N_PUBLIC, CIRCUIT_SEED, TOXIC_SEED, device=0)
     r, s = 12345, 67890
     t0 = time.time()

@@ -34,6 +34,39 @@ def use_native():
     return "gcc -O3 -march=x86-64-v2 (portable build: the native compile failed on this host)"
 
 
+def use_fastest(pk: bytes, witness: bytes):
+    """CPU-baseline timing only: build the native library (use_native) and time ONE single-thread proof of the given small case
+    with it and with the portable build; lib() then loads whichever was faster ON THIS HOST (gcc's -march=native is not always a
+    win for this code: no ADX/MULX chains are generated, and on some hosts the wider vector unit only changes the scheduling).
+    Returns a description with both times."""
+    global _path
+    import time
+    if _lib is not None:
+        return "already loaded: " + os.path.basename(_path or "libzkr_oracle.so")
+    what = use_native()
+    native, portable = _path, os.path.join(_HERE, "libzkr_oracle.so")
+    if native is None:
+        return what
+    times = {}
+    for name, path in (("native", native), ("x86-64-v2", portable)):
+        L = ctypes.CDLL(path)
+        L.zo_prove.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double)]
+        L.zo_prove.restype = ctypes.c_int
+        out, tm = ctypes.create_string_buffer(256), (ctypes.c_double * 3)()
+        one = (1).to_bytes(32, "little")
+        best = None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            if L.zo_prove(pk, len(pk), witness, len(witness) // 32, one, one, out, tm):
+                raise RuntimeError("zo_prove failed")
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        times[name] = best
+    pick = "native" if times["native"] <= times["x86-64-v2"] else "x86-64-v2"
+    _path = native if pick == "native" else None
+    return "gcc -O3 -march=%s (the faster on this host: native %.3f s, x86-64-v2 %.3f s on a small proof)" % (pick, times["native"], times["x86-64-v2"])
+
+
 def lib():
     global _lib
     if _lib is None:

@@ -61,11 +61,27 @@ ZKR_HD XYZZ29<C> make_xyzz(const X &x, const Y &y, const ZZ &zz, const ZZZ &zzz)
 }
 
 // ---- packed <-> registers
+#ifdef ZKR_EXP_FAKE_UNPACK
+// MEASUREMENT ONLY (tools/r5_gpu_02.sh; never shipped): a table point's words taken as limbs as they are -- what an accumulation
+// would cost if the tables stored 9 x 29-bit limbs (72-byte rows) and needed no unpacking.  The sums are garbage.
+template <class PM, int H>
+ZKR_HD L29<PM, H> fake_limbs(const uint32_t (&w)[8]) {
+  L29<PM, H> r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.v[i] = w[i < 8 ? i : 7];
+  return r;
+}
+ZKR_HD Affine29<G1C> unpack_affine(const Affine<Fq> &p) { return Affine29<G1C>{fake_limbs<Fq29, 2>(p.x.v), fake_limbs<Fq29, 2>(p.y.v)}; }
+ZKR_HD Affine29<G2C> unpack_affine(const Affine<Fq2> &p) {
+  return Affine29<G2C>{G2C::unpack<2>(p.x), G2C::unpack<2>(p.y)};
+}
+#else
 template <class F>
 ZKR_HD Affine29<typename CoordOf<F>::C> unpack_affine(const Affine<F> &p) {
   using C = typename CoordOf<F>::C;
   return Affine29<C>{C::template unpack<2>(p.x), C::template unpack<2>(p.y)};
 }
+#endif
 template <class F>
 ZKR_HD XYZZ29<typename CoordOf<F>::C> unpack_xyzz(const XYZZ<F> &p) {  // stored coordinates are below 2 p (pack_xyzz)
   using C = typename CoordOf<F>::C;
@@ -199,6 +215,26 @@ template <class F>
 ZKR_HD_COLD F radix_to_256(const F &w) {
   using C = typename CoordOf<F>::C;
   return C::template pack<2>(canonical(mul(C::template unpack<10>(w), C::to256())));
+}
+// The same ON coordinates in memory (global or LDS): the non-inlined call takes a pointer in registers, where the by-value forms
+// above put their 32 / 64-byte argument and result on the stack -- the only scratch the kernels that call them once per thread
+// had (msm_reduce3_kernel 208 / 464 B per lane, msm_precompute_kernel 128 / 320 B, radix_convert_kernel 128 / 320 B).
+// (canonical_small, the inline form, instead of the out-of-line canonical(): a product is below 2 p, one conditional subtraction;
+// a nested out-of-line call would bring the stack frame back.)
+template <class F>
+ZKR_HD_COLD void radix_to_261_at(F *w) {
+  using C = typename CoordOf<F>::C;
+  *w = C::template pack<2>(canonical_small(mul(C::template unpack<10>(*w), C::to261())));
+}
+template <class F>
+ZKR_HD_COLD void radix_to_256_at(F *w) {
+  using C = typename CoordOf<F>::C;
+  *w = C::template pack<2>(canonical_small(mul(C::template unpack<10>(*w), C::to256())));
+}
+template <class F>
+ZKR_HD void xyzz_to_256_at(XYZZ<F> *p) {  // inline: the four leaf calls are made from the kernel itself (a nested call would save its return address on the stack)
+  if (p->is_inf()) return;
+  radix_to_256_at(&p->x); radix_to_256_at(&p->y); radix_to_256_at(&p->zz); radix_to_256_at(&p->zzz);
 }
 template <class F>
 ZKR_HD_COLD XYZZ<F> xyzz_to_256(const XYZZ<F> &p) {  // an MSM result on its way to the host assembly (hostops.hpp, field.hpp arithmetic)

@@ -893,7 +893,10 @@ static __global__ __launch_bounds__(MSM_THREADS, MINW) void msm_reduce3_kernel(c
     if (threadIdx.x < s) sh[threadIdx.x] = tree_add(sh[threadIdx.x], sh[threadIdx.x + s]);
     __syncthreads();
   }
-  if (threadIdx.x == 0) store_pod(result, xyzz_to_256(sh[0]));  // back to the key's radix (2^256), canonical: the host assembly takes over
+  if (threadIdx.x == 0) {  // back to the key's radix (2^256), canonical: the host assembly takes over
+    store_pod(result, sh[0]);
+    xyzz_to_256_at(result);  // in place: no stack frame for the one cold call of the kernel
+  }
 }
 
 // ---------------------------------------------------------------- window tables (key load)
@@ -916,9 +919,9 @@ static __global__ __launch_bounds__(MSM_THREADS, MINW) void msm_precompute_kerne
     for (int k = 1; k < K; k++) store_pod(tbl + (size_t)k * n + i, p);
     return;
   }
-  p.x = radix_to_261(p.x);
-  p.y = radix_to_261(p.y);
-  store_pod(tbl + i, p);
+  radix_to_261_at(&tbl[i].x);  // in place (pointer arguments: no stack frame for the two cold calls)
+  radix_to_261_at(&tbl[i].y);
+  p = load_pod(tbl + i);
   Jac29<C> q{C::template unpack<2>(p.x).template to<JX>(), C::template unpack<2>(p.y).template to<JY>(), C::one().template to<JZ>()};
   for (int k0 = 1; k0 < K; k0 += PRE_LEVELS) {
     const int nl = K - k0 < PRE_LEVELS ? K - k0 : PRE_LEVELS;
@@ -951,10 +954,8 @@ template <class F>
 static __global__ __launch_bounds__(MSM_THREADS) void radix_convert_kernel(Affine<F> *pts, size_t count, int to261) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
-  Affine<F> p = load_pod(pts + i);
-  if (p.is_inf()) return;
-  if (to261) { p.x = radix_to_261(p.x); p.y = radix_to_261(p.y); } else { p.x = radix_to_256(p.x); p.y = radix_to_256(p.y); }
-  store_pod(pts + i, p);
+  if (pts[i].is_inf()) return;
+  if (to261) { radix_to_261_at(&pts[i].x); radix_to_261_at(&pts[i].y); } else { radix_to_256_at(&pts[i].x); radix_to_256_at(&pts[i].y); }
 }
 
 // ---------------------------------------------------------------- device-side setup
