@@ -95,6 +95,7 @@ struct MsmWorkspace {
   void *buckets = nullptr, *group_out = nullptr, *task_out = nullptr, *result = nullptr;
   void *h_result = nullptr;  // pinned host copy of the MSM result point (XYZZ)
   size_t max_nb = 0, max_entries = 0;
+  size_t sets = 1;  // bucket sets (and reduction buffers) per proof: 2 in B1's workspace when A is reduced with it (zkr_key.hip alloc_msm_ws)
 };
 
 struct ProfStage {
@@ -115,6 +116,8 @@ struct MsmPlan {
   uint32_t J;         // digit sort: J chunks per bucket range
   uint32_t S;         // reduction: workgroups per task in msm_reduce2_kernel
 };
+// two tables whose bucket sets ONE reduction launch set can walk end to end (msm_reduce*_kernel take `batch` sets of one geometry)
+inline bool same_reduce_geometry(const MsmPlan &a, const MsmPlan &b) { return a.c == b.c && a.K == b.K && a.nbw == b.nbw && a.nb == b.nb && a.glog == b.glog && a.S == b.S; }
 
 }  // namespace zkr
 
@@ -153,6 +156,8 @@ struct ProofSlot {
   int nbat = 0;   // proofs of the group in flight
   struct timespec t_submit = {0, 0};  // when the group's enqueue began (ZKR_TRACE_COLLECT)
   bool merged_ch = false;  // this group's H was accumulated onto C's bucket set: C's workspace holds C + H
+  bool joint_ab = false;   // this group's A was accumulated behind B1's bucket sets and reduced with them in one chain: B1's workspace holds
+                           // the results of both, B1's first (zkr_prove.hip prove_submit_enqueue)
   std::vector<uint8_t> rb, sb;  // blinding scalars of the proofs in flight, cap x 32 B each
   bool busy = false, collecting = false;
   std::vector<ProfSpan> spans;

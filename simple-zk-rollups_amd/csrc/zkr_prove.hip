@@ -797,6 +797,14 @@ static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *const *d_ws
   const MsmPlan &pc = k->plan[T_C], &ph = k->plan[T_H];
   const bool merge_ch = !no_merge && h.npts[T_C] && h.npts[T_H] && pc.c == ph.c && pc.nbw == ph.nbw && pc.glog == ph.glog && pc.S == ph.S;
   sl.merged_ch = merge_ch;
+  // A and B1 in ONE reduction chain (round 5): the G1 chains share one stream, and in a single proof of a small circuit that stream
+  // is the critical path from B1's accumulation to the end (three chains of ~0.4 ms back to back: H's chain starts 0.19 ms after H's
+  // accumulation has ended, profiles/r4_05_timeline_one_tx_proof.txt).  A is accumulated into the bucket sets BEHIND B1's (B1's
+  // workspace holds two sets per proof when the two tables' geometry agrees) and one launch set reduces both: a chain of latency-bound
+  // launches less per proof.  ZKR_NO_JOINT_AB=1: a chain per table.
+  static const bool no_joint = getenv("ZKR_NO_JOINT_AB") != nullptr;
+  const bool joint_ab = !no_joint && !serial && k->n_red == 2 && h.npts[T_A] && h.npts[T_B1] && same_reduce_geometry(k->plan[T_A], k->plan[T_B1]) && sl.ws[T_B1].sets == 2;
+  sl.joint_ab = false;  // set below, once the schedule is known (not with accumulations on their chains' streams or handed over early)
   for (int t = 0; t < N_TABLES; t++) sl.res_pending[t] = false;
   auto result_event = [&](int t, hipStream_t rs, int rc) -> int {  // after a table's reduction chain (its D2H copy is the last thing enqueued)
     if (rc) return rc;
@@ -827,9 +835,13 @@ static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *const *d_ws
   static const int defer_env = getenv("ZKR_DEFER_ACC") ? atoi(getenv("ZKR_DEFER_ACC")) : 0;
   const bool defer_acc = !serial && !early && defer_env == 1 && nbat == 1 && (h.shard_parts > 1 || alone);
   bool acc_waits_calch = defer_acc;  // the first accumulation enqueued carries the wait (the stream is in order)
+  sl.joint_ab = joint_ab && !early && !acc_on_chain;
   auto accum_table = [&](int t, hipStream_t rs) -> int {
     const MsmWorkspace &srt = sl.ws[sort_src[t]];
-    MsmWorkspace &dst = t == T_H && merge_ch ? sl.ws[T_C] : sl.ws[t];  // whose bucket set / reduction buffers the table lands in
+    MsmWorkspace dst = t == T_H && merge_ch ? sl.ws[T_C] : sl.ws[t];  // whose bucket set / reduction buffers the table lands in (a copy: pointers)
+    if (sl.joint_ab && t == T_A) {  // behind B1's bucket sets; its oversized-bucket partial sums stay its own
+      dst.buckets = (char *)sl.ws[T_B1].buckets + (size_t)nbat * k->plan[T_B1].nb * sizeof(G1XYZZ);
+    }
     const bool onto = t == T_H && merge_ch;
     const void *pts = ar + h.off_pts[t];
     hipStream_t sa = acc_on_chain ? rs : s;
@@ -869,6 +881,14 @@ static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *const *d_ws
       mix.big_partials = sl.ws[t].big_partials;
       if ((rc = msm_big_finish_enqueue<Fq>(pf, rs, h.npts[t], srt, mix, true))) return rc;
       return result_event(t, rs, msm_reduce_enqueue<Fq>(pf, rs, h.npts[t], nbat, k->plan[t], srt, dst, alone));
+    }
+    if (sl.joint_ab && t == T_B1) return 0;  // reduced with A's buckets, by A's turn on this stream (B1's oversized-bucket sums are on their way on it)
+    if (sl.joint_ab && t == T_A) {
+      // the stream is in order: B1's partial sums (enqueued at B1's turn) are done; both accumulations ran on the one accumulation
+      // stream, A's last (ev_done[T_A] is waited for above)
+      if ((rc = msm_big_finish_enqueue<Fq>(pf, rs, h.npts[T_B1], sl.ws[sort_src[T_B1]], sl.ws[T_B1]))) return rc;
+      if ((rc = msm_big_finish_enqueue<Fq>(pf, rs, h.npts[T_A], srt, dst))) return rc;
+      return result_event(T_A, rs, msm_reduce_enqueue<Fq>(pf, rs, h.npts[T_B1], 2 * nbat, k->plan[T_B1], sl.ws[sort_src[T_B1]], sl.ws[T_B1]));
     }
     if ((rc = msm_big_finish_enqueue<Fq>(pf, rs, h.npts[t], srt, sl.ws[t]))) return rc;
     return result_event(t, rs, msm_reduce_enqueue<Fq>(pf, rs, h.npts[t], nbat, k->plan[t], srt, sl.ws[t], alone && t == T_H));
@@ -1008,7 +1028,8 @@ static int prove_collect(zkr_key *k, ProofSlot &sl, uint8_t *proofs_out, Partial
   std::vector<G1XYZZ> pic_part((size_t)sl.nbat);
   int status = 0;
   for (int j = 0; j < sl.nbat; j++) {
-    G1XYZZ A = msm_finish<Fq>(h.npts[T_A], sl.ws[T_A], j);
+    // joint chain of A and B1 (prove_submit_enqueue): B1's workspace holds both results, B1's nbat first
+    G1XYZZ A = sl.joint_ab ? msm_finish<Fq>(h.npts[T_A], sl.ws[T_B1], sl.nbat + j) : msm_finish<Fq>(h.npts[T_A], sl.ws[T_A], j);
     G1XYZZ B1 = msm_finish<Fq>(h.npts[T_B1], sl.ws[T_B1], j);
     G2XYZZ B2 = msm_finish<Fq2>(h.npts[T_B2], sl.ws[T_B2], j);
     if (partials_out) { partials_out[j].A = A; partials_out[j].B1 = B1; partials_out[j].B2 = B2; continue; }
