@@ -804,7 +804,7 @@ static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *const *d_ws
   // launches less per proof.  ZKR_NO_JOINT_AB=1: a chain per table.
   static const bool no_joint = getenv("ZKR_NO_JOINT_AB") != nullptr;
   const bool joint_ab = !no_joint && !serial && k->n_red == 2 && h.npts[T_A] && h.npts[T_B1] && same_reduce_geometry(k->plan[T_A], k->plan[T_B1]) && sl.ws[T_B1].sets == 2;
-  sl.joint_ab = false;  // set below, once the schedule is known (not with accumulations on their chains' streams or handed over early)
+  sl.joint_ab = false;  // set below, once the schedule is known (not with accumulations on their chains' streams)
   for (int t = 0; t < N_TABLES; t++) sl.res_pending[t] = false;
   auto result_event = [&](int t, hipStream_t rs, int rc) -> int {  // after a table's reduction chain (its D2H copy is the last thing enqueued)
     if (rc) return rc;
@@ -835,7 +835,7 @@ static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *const *d_ws
   static const int defer_env = getenv("ZKR_DEFER_ACC") ? atoi(getenv("ZKR_DEFER_ACC")) : 0;
   const bool defer_acc = !serial && !early && defer_env == 1 && nbat == 1 && (h.shard_parts > 1 || alone);
   bool acc_waits_calch = defer_acc;  // the first accumulation enqueued carries the wait (the stream is in order)
-  sl.joint_ab = joint_ab && !early && !acc_on_chain;
+  sl.joint_ab = joint_ab && !acc_on_chain;  // (the accumulations all run on the one accumulation stream, B1's before A's, whenever they are handed over)
   auto accum_table = [&](int t, hipStream_t rs) -> int {
     const MsmWorkspace &srt = sl.ws[sort_src[t]];
     MsmWorkspace dst = t == T_H && merge_ch ? sl.ws[T_C] : sl.ws[t];  // whose bucket set / reduction buffers the table lands in (a copy: pointers)
