@@ -695,7 +695,7 @@ def roofline_record(key, info, prof, per_proof_s, device_state, log_m, shape, lo
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
     traffic, traffic_src, proof_traffic, pmc_file = None, None, None, None
     try:  # HBM bytes per launch from the committed PMC passes (bench.py cannot collect PMCs itself)
-        pmc_file = next(f for f in ("r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+        pmc_file = next(f for f in ("r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
         pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
         if pmc["config"]["log_m"] == log_m and shape == "rollup":
             # whole proof: every kernel of the proving path (not key build), per ingest_kernel launch = per proof

@@ -77,7 +77,12 @@ export class WithdrawCircuit {
 
 // ---- process-level key cache (the reference builds a new Bn128 per proof: common.ts:23) and verifier constants
 /** Device keys loaded / found in the cache by groth16GenProof so far in this process. */
-export function keyCacheStats(): { loads: number; hits: number; replications: number; shardings?: number; entries: number; handles: number };
+export function keyCacheStats(): { loads: number; hits: number; replications: number; shardings?: number; entries: number; handles: number; shardedLastForm: ShardedForm };
+/** Which form the last sharded proof (groth16GenProof with opts.devices) took and why: calcH split over the shards, or computed by every shard for itself. */
+export interface ShardedForm { form: "none" | "split" | "replicated"; reason: string }
+export function shardedLastForm(): ShardedForm;
+/** How a native key handle came to its device: loaded there ("none") or copied device to device (zkr_key_replicate) in the full or the compact form. */
+export function keyReplication(key: unknown): { mode: "none" | "full" | "base"; peerDirect: boolean };
 export function keyFingerprint(provingKeyBin: ArrayBuffer | Uint8Array, full?: boolean): string;
 export function clearKeyCache(): void;
 /** vk_bin -> the constants of the generated verifier's verifyingKey() in the contract's encoding (G2 as [im, re]). */

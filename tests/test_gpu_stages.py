@@ -521,11 +521,14 @@ print("PARITY", ok)
 
 
 @pytest.mark.parametrize("env", [{"ZKR_SORT_FUSED_SCAN": "1"}, {"ZKR_SORT_LEGACY": "1"}, {"ZKR_NTT_NO_PAIR": "1"}, {"ZKR_NTT_TILE_LOG": "9"},
-                                 {"ZKR_SORT_FUSED_SCAN": "1", "ZKR_NTT_TILE_LOG": "11"}])
+                                 {"ZKR_SORT_FUSED_SCAN": "1", "ZKR_NTT_TILE_LOG": "11"},
+                                 {"ZKR_NO_JOINT_AB": "1"}, {"ZKR_SCHED": "1"}, {"ZKR_RED_STREAMS": "3"}, {"ZKR_SERIAL": "1"}])
 def test_preparation_chain_variants_give_the_same_proofs(tmp_path, env):
     """The A/B knobs of the round-4 preparation chain (single-pass look-back scan, round 3's nine-launch sort, unpaired
     transforms, other NTT tile sizes) are read once per process: each runs in its own process and must reproduce the
-    closed form -- single proofs and fused batches, 2^9 to 2^17."""
+    closed form -- single proofs and fused batches, 2^9 to 2^17.  Round 5: the joint reduction chain of A and B1 (the default)
+    against a chain per table (ZKR_NO_JOINT_AB=1), the joint chain under the early hand-over (ZKR_SCHED=1), and the schedules in
+    which it must switch itself off (three reduction streams; one serial stream)."""
     import subprocess
     import sys
     script = tmp_path / "knobs.py"

@@ -205,7 +205,8 @@ def test_js_batch_over_devices_replicates_the_key_and_shards_the_proofs(tmp_path
         const sharded = [];
         for (let i = 0; i < 3; i++) sharded.push(await (await z.buildBn128()).groth16GenProof(wb, z.binarifyProvingKey(d.pk), Object.assign({devices: [0, 0, 0]}, blinding[i])));
         const st2 = z.keyCacheStats();
-        console.log(JSON.stringify({multi, again, single, held, sharded, st2, stats, refused, distinct: new Set(drawn.map((p) => p.pi_a[0])).size}));
+        const form = z.shardedLastForm(), how = z.keyReplication(bn._key);   // round 5: which form the sharded proof took; how a key came to its device
+        console.log(JSON.stringify({multi, again, single, held, sharded, st2, stats, refused, form, how, distinct: new Set(drawn.map((p) => p.pi_a[0])).size}));
       })().catch(e => { console.error(e); process.exit(1); });
     """, path).stdout
     res = json.loads(out)
@@ -213,6 +214,8 @@ def test_js_batch_over_devices_replicates_the_key_and_shards_the_proofs(tmp_path
     assert res["multi"] == expect and res["again"] == expect and res["single"] == expect and res["held"] == expect
     assert res["refused"] == 3 and res["distinct"] == 3
     assert res["sharded"] == expect[:3] and res["st2"]["shardings"] == 1 and res["st2"]["loads"] == 1 and res["st2"]["handles"] == 5
+    assert res["form"]["form"] == "replicated" and "3 shards" in res["form"]["reason"] and res["st2"]["shardedLastForm"] == res["form"]
+    assert res["how"] == {"mode": "none", "peerDirect": False}
     st = [(x["loads"], x["replications"], x["hits"], x["entries"], x["handles"]) for x in res["stats"]]
     assert st == [(1, 1, 0, 1, 2), (1, 1, 2, 1, 2), (1, 1, 3, 1, 2)]
 
