@@ -1,8 +1,9 @@
 """Soak test of the concurrent paths on one GPU: for `seconds`, several host threads prove on the SAME key material at once --
 batches over two replicas (zkr_prove_batch_multi), sharded proofs over four shards from two callers (zkr_prove_sharded), single synchronous
 proofs and pipelined device batches on the whole key -- with random blinding; every proof goes through the native verifier
-(zkr_verify_batch) and a sample is compared with the toxic-waste closed form.  Prints counts; exits non-zero on any failure.
-    python tools/soak.py [log_m=16] [seconds=120]"""
+(zkr_verify_batch) and a sample is compared with the toxic-waste closed form (the oracle: that is why this driver lives under
+tests/, not tools/).  Prints counts; exits non-zero on any failure.
+    python tests/soak.py [log_m=16] [seconds=120]"""
 import os
 import sys
 import threading

@@ -1,5 +1,5 @@
 """zkr_verify / zkr_verify_batch on the host alone (no GPU): one proof of a 73-public-input statement (the tx circuit's
-count, TxVerifier.sol:281) through the oracle's setup at m = 2^8.   python tools/verify_time.py"""
+count, TxVerifier.sol:281) through the oracle's setup at m = 2^8.   python tests/verify_time.py (under tests/: the inputs come from the oracle)"""
 import os, sys, time
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, os.path.join(ROOT, "simple-zk-rollups_amd", "python")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
