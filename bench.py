@@ -89,7 +89,11 @@ def cpu_baseline(sample_log_m, target_log_m, gpu_key=None):
     how = "measured at m=2^%d (the benchmarked size, no extrapolation)" % sample_log_m if scale == 1.0 else \
           "measured at m=2^%d, value = 1/(t * 2^%d) i.e. linearly scaled to m=2^%d" % (sample_log_m, target_log_m - sample_log_m, target_log_m)
     return {"value": 1.0 / (dt * scale), "unit": "proofs/s", "cores": 1, "kind": "port",
-            "sample": "zo_prove 1 thread, %s, one 2^%d proof: %.2f s (calcH %.2f, MSM %.2f); %s" % (build, sample_log_m, dt, tm[0], tm[1], how),
+            # short: the driver's record keeps the first 120 characters of a string
+            "sample": "C oracle zo_prove, 1 thread, one 2^%d proof %s: %.1f s (calcH %.1f + MSM %.1f); gcc -O3 -march=%s" % (
+                sample_log_m, "MEASURED" if scale == 1.0 else "measured, scaled x2^%d" % (target_log_m - sample_log_m), dt, tm[0], tm[1],
+                "native" if "march=native" in build else "x86-64-v2"),
+            "sample_detail": how,
             "seconds_per_proof": dt * scale, "build": build,
             # the same figures as scalars: the driver's record keeps scalars and short strings only
             "all_threads_proofs_per_s": 1.0 / (dtm * scale), "all_threads_cores": int(tmm[3]), "all_threads_seconds_per_proof": dtm * scale,
