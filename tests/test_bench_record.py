@@ -1,0 +1,62 @@
+"""bench.py's line as the DRIVER keeps it: the driver's record holds the scalars and the first ~120 characters of the
+strings of `config`, `roofline` and `cpu_baseline`, with key names cut at 40 characters -- so the figures that matter are scalars
+with short names next to the nested objects.  CPU only: the helpers are exercised on recorded legs (profiles/r5_*), no GPU."""
+import importlib.util
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def _driver_view(obj):
+    """What the driver keeps of one of the three objects: scalars, strings cut at 120, key names cut at 40."""
+    return {k[:40]: (v[:120] if isinstance(v, str) else v) for k, v in obj.items() if not isinstance(v, (dict, list))}
+
+
+def test_recorded_default_line_carries_the_claim_as_scalars():
+    d = json.load(open(os.path.join(ROOT, "profiles", "r5_09_bench_default.json")))
+    cfg, roof, cpu = _driver_view(d["config"]), _driver_view(d["roofline"]), _driver_view(d["cpu_baseline"])
+    # no two keys collide once cut at 40 characters
+    for obj in (d["config"], d["roofline"], d["cpu_baseline"]):
+        flat = [k for k, v in obj.items() if not isinstance(v, (dict, list))]
+        assert len({k[:40] for k in flat}) == len(flat)
+    # the reference's calling pattern, the other BASELINE config, the reference's two circuits, the sharding leg
+    for k in ("sync_latency_ms", "host_buffer_sync_proofs_per_s", "host_buffer_batch_proofs_per_s", "rate_2_22_proofs_per_s", "ms_per_proof_2_22",
+              "tx_single_proof_ms", "tx_fused_proofs_per_s", "tx_dropin_call_ms", "withdraw_single_proof_ms", "withdraw_fused_proofs_per_s",
+              "withdraw_dropin_call_ms", "sharded_parts", "sharded_ms", "sharded_speedup", "sharded_measured", "sharded_form"):
+        assert cfg.get(k) is not None, k
+    assert cfg["sharded_measured"] is False and cfg["sharded_form"].startswith("projected")        # one GPU: a projection, and it says so
+    for k in ("frac", "achieved", "peak", "traffic", "valu_frac_kernel", "valu_frac_proof", "mad_bound_frac_proof", "hbm_traffic_frac_proof", "frac_2_22",
+              "hbm_frac_ingest", "hbm_frac_spmv", "hbm_frac_ntt_pass", "hbm_frac_combine_h"):
+        assert isinstance(roof.get(k), float), k
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12 and 0 < roof["frac_2_22"] < 0.05
+    for k in ("value", "cores", "all_threads_proofs_per_s", "all_threads_cores", "seconds_per_proof"):
+        assert cpu.get(k) is not None, k
+    assert cpu["kind"] == "port" and cpu["cpu_and_gpu_proofs_identical"] is True
+    assert len(d["cpu_baseline"]["sample"]) <= 120 and "MEASURED" in cpu["sample"] and "march=" in cpu["sample"]   # survives the cut whole
+    # what the nested objects say and what the scalars say is the same number
+    assert cfg["sync_latency_ms"] == d["config"]["boundary"]["sync_latency_ms"]
+    assert cfg["rate_2_22_proofs_per_s"] == d["config_2_22"]["proofs_per_s"] and d["config_2_22"]["proofs_verified"] == d["config_2_22"]["proofs"]
+    assert cfg["withdraw_single_proof_ms"] == d["withdraw_circuit"]["single_proof_ms"]
+    assert roof["valu_frac_proof"] == d["roofline"]["valu"]["whole_proof"]["frac"]
+
+
+def test_sharding_scalars_have_one_schema_for_projected_measured_and_failed_legs():
+    b = _bench()
+    proj = json.load(open(os.path.join(ROOT, "profiles", "r5_09_bench_default.json")))["intra_proof_sharding"]
+    meas = json.load(open(os.path.join(ROOT, "profiles", "r5_08_bench_inproc8_one_gpu.json")))["intra_proof_sharding"]
+    a, m = b.sharding_scalars(proj), b.sharding_scalars(meas)
+    common = {"sharded_parts", "sharded_measured", "sharded_form", "sharded_ms", "sharded_speedup", "sharded_replicated_calch_ms", "sharded_whole_key_ms"}
+    assert common <= set(a) and common <= set(m)
+    assert a["sharded_measured"] is False and m["sharded_measured"] is False          # eight shards on ONE device: a rehearsal is not a measurement
+    assert m["sharded_form"] == "split" and m["sharded_parts"] == 8 and "one device" in m["sharded_reason"]
+    real = dict(meas, rehearsal_on_one_gpu=False)                                      # the same leg as a multi-GPU node would report it
+    assert b.sharding_scalars(real)["sharded_measured"] is True
+    assert b.sharding_scalars({"error": "boom"}) == {"sharded_error": "boom"} and b.sharding_scalars(None) == {"sharded_error": None}
