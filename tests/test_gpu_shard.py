@@ -237,6 +237,21 @@ def test_first_use_check_of_the_split_form_and_its_fallback(monkeypatch, capfd):
     assert zkr_hip.sharded_last_form()["form"] == "split" and "both ways" not in zkr_hip.sharded_last_form()["reason"]
     rnd = zkr_hip.prove_sharded(good, wb)                           # random blinding through the checked path
     assert zkr_hip.verify(key.synth_vk(aux), rnd, g.proof_from_aux(aux, wb, p, 1, 1)[2])
+    # two callers meet a FRESH shard set at the same moment: both may run the first-use check (each proves both ways), both get the proof
+    import threading
+    fresh = [key.shard(i, parts) for i in range(parts)]
+    got, forms = {}, {}
+    def first_use(tag, r):
+        got[tag] = zkr_hip.prove_sharded(fresh, wb, r, 62)
+        forms[tag] = zkr_hip.sharded_last_form()                     # thread-local: each caller sees its own proof's form
+    ths = [threading.Thread(target=first_use, args=(t, r)) for t, r in (("x", 61), ("y", 71))]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in ths)
+    assert got["x"] == want and got["y"] == closed_form(aux, wb, p, 71, 62, log_m)
+    assert forms["x"]["form"] == "split" and forms["y"]["form"] == "split" and any("both ways" in f["reason"] for f in forms.values())
     monkeypatch.setenv("ZKR_SHARD_SPLIT_CHECK", "2")
     bad = [key.shard(i, parts) for i in range(parts)]
     capfd.readouterr()
