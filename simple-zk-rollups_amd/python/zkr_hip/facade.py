@@ -123,7 +123,7 @@ key_cache_stats = {"loads": 0, "hits": 0, "replications": 0}
 
 
 _fp_memo = collections.OrderedDict()   # id(bytes object) -> (the object: kept alive so that its id stays its own, fingerprint)
-FP_MEMO_SLOTS = 4
+FP_MEMO_SLOTS = 2                       # strong references to the last two buffer objects hashed (as many as key contents are cached): bounded host memory
 MAX_SHARD_SETS = 2                      # device lists whose shards an entry keeps (least recently used dropped)
 
 
