@@ -46,38 +46,30 @@ function bigintToLe32(v) {
 // snarkjs would reduce mod r, the chain refuses: the facade sides with the chain)
 const signalsInRange = (ps) => ps.every((x) => { const v = BigInt(x); return v >= 0n && v < R; });
 
-// Identity of a provingKeyBin: its length and a SHA-256.  Default (round 5): over EVERY byte -- exact, as the reference is by
-// re-parsing the key on every call (operator/src/snarks/common.ts:28); a few ms per MB, paid once per buffer OBJECT (memoised in a
-// WeakMap; a memo hit re-checks the cheap sampled digest, so an object refilled with another key is hashed again).
-// full === false or env ZKR_KEY_FINGERPRINT=sampled: the first 4 KiB (geometry, alfa / beta / delta of the setup), the last 4 KiB
-// and 64 blocks of 4 KiB spread evenly in between -- 0.3 MB whatever the size (< 0.1 ms): sees geometry, setup and broad content,
-// not a lone coefficient (two keys of one setup that differ in a single constraint alias) -- for callers that rebuild a large
-// buffer per call and know their keys differ broadly.
+// Identity of a provingKeyBin -- EXACT, as the reference is by re-parsing the key on every call (operator/src/snarks/common.ts:28;
+// ADVICE r4): candidates are found by the cheap SAMPLED digest (length + SHA-256 of the first 4 KiB -- geometry, alfa / beta / delta
+// of the setup --, the last 4 KiB and 64 blocks of 4 KiB spread evenly in between: 0.3 MB whatever the size, < 0.1 ms) and confirmed
+// by comparing the caller's buffer with the buffer the entry was built from, byte for byte (Buffer.compare = memcmp: ~8 ms for the tx
+// circuit's 57 MB, against ~50 ms for a SHA-256 of it); the SAME buffer object is recognised without the comparison.  The entry
+// keeps a reference to that buffer (it must not be rewritten in place afterwards; the reference's callers build a new one per call).
+// ZKR_KEY_FINGERPRINT=sampled: the sampled digest alone (two keys of one setup that differ in a lone coefficient alias);
+// =full: a SHA-256 of every byte instead of the comparison (nothing retained).
 const FP_BLOCK = 4096, FP_STRIDED = 64;
-const fpMemo = new WeakMap();  // buffer object -> {sampled, full}
-function sampledDigest(u8) {
-  const n = u8.length, h = require("crypto").createHash("sha256");
-  h.update(u8.subarray(0, FP_BLOCK));
-  const span = n - 2 * FP_BLOCK;
-  for (let i = 0; i < FP_STRIDED; i++) {
-    const o = FP_BLOCK + Math.floor((span - FP_BLOCK) * i / (FP_STRIDED - 1));
-    h.update(u8.subarray(o, o + FP_BLOCK));
-  }
-  h.update(u8.subarray(n - FP_BLOCK, n));
-  return h.digest("hex");
-}
+function bytesOf(buf) { return buf instanceof ArrayBuffer ? new Uint8Array(buf) : new Uint8Array(buf.buffer, buf.byteOffset, buf.byteLength); }
 function keyFingerprint(buf, full) {
-  const u8 = buf instanceof ArrayBuffer ? new Uint8Array(buf) : new Uint8Array(buf.buffer, buf.byteOffset, buf.byteLength);
-  const n = u8.length;
-  if (full === undefined) full = process.env.ZKR_KEY_FINGERPRINT !== "sampled";
-  if (n <= FP_BLOCK * (FP_STRIDED + 2)) return n + ":" + require("crypto").createHash("sha256").update(u8).digest("hex");
-  const sampled = sampledDigest(u8);
-  if (!full) return n + ":" + sampled;
-  const hit = fpMemo.get(buf);
-  if (hit !== undefined && hit.sampled === sampled && hit.n === n) return hit.full;
-  const fp = n + ":" + require("crypto").createHash("sha256").update(u8).digest("hex");
-  fpMemo.set(buf, { sampled, n, full: fp });
-  return fp;
+  const u8 = bytesOf(buf), n = u8.length, h = require("crypto").createHash("sha256");
+  if (full === undefined) full = process.env.ZKR_KEY_FINGERPRINT === "full";
+  if (full || n <= FP_BLOCK * (FP_STRIDED + 2)) h.update(u8);
+  else {
+    h.update(u8.subarray(0, FP_BLOCK));
+    const span = n - 2 * FP_BLOCK;
+    for (let i = 0; i < FP_STRIDED; i++) {
+      const o = FP_BLOCK + Math.floor((span - FP_BLOCK) * i / (FP_STRIDED - 1));
+      h.update(u8.subarray(o, o + FP_BLOCK));
+    }
+    h.update(u8.subarray(n - FP_BLOCK, n));
+  }
+  return n + ":" + h.digest("hex");
 }
 
 // Process-level cache of device keys (SURVEY.md 8(b) "Ownership").  The reference builds a NEW object for every proof
@@ -88,19 +80,30 @@ function keyFingerprint(buf, full) {
 // replicas (their device memory goes with the handles).
 const KEY_CACHE_SLOTS = 2;
 const MAX_SHARD_SETS = 2;    // device lists whose shards an entry keeps (least recently used dropped)
-const keyCache = new Map();  // fingerprint -> Map("device#ordinal" -> native key handle), in recency order
-const keyCacheStats = { loads: 0, hits: 0, replications: 0 };
+const keyCache = new Map();  // "fingerprint#variant" -> Map("device#ordinal" -> native key handle; "ref" -> the buffer the entry was built from), in recency order
+const keyCacheStats = { loads: 0, hits: 0, replications: 0, compares: 0 };
 // a whole-key replica of the entry (any device), or undefined: the source of device-to-device copies and of shards
 function anyReplica(ent) {
-  for (const [slot, key] of ent) if (!slot.startsWith("shards:")) return key;
+  for (const [slot, key] of ent) if (slot !== "ref" && !slot.startsWith("shards:")) return key;
   return undefined;
 }
 function cacheEntry(provingKeyBin) {
-  const fp = keyFingerprint(provingKeyBin);
-  let ent = keyCache.get(fp);
-  if (ent !== undefined) keyCache.delete(fp);  // re-insert: most recently used last
-  else ent = new Map();
-  keyCache.set(fp, ent);
+  const mode = process.env.ZKR_KEY_FINGERPRINT || "", fp = keyFingerprint(provingKeyBin);
+  const u8 = bytesOf(provingKeyBin);
+  const exact = mode !== "sampled" && mode !== "full" && u8.length > FP_BLOCK * (FP_STRIDED + 2);  // small buffers are hashed whole anyway
+  let found, top = -1;
+  for (const [k, ent] of keyCache) {
+    if (!k.startsWith(fp + "#")) continue;
+    top = Math.max(top, Number(k.slice(fp.length + 1)));
+    const ref = ent.get("ref");
+    if (!exact || ref === provingKeyBin) { found = k; break; }
+    keyCacheStats.compares++;
+    if (Buffer.compare(bytesOf(ref), u8) === 0) { found = k; break; }
+  }
+  let ent;
+  if (found !== undefined) { ent = keyCache.get(found); keyCache.delete(found); }  // re-insert: most recently used last
+  else { found = fp + "#" + (top + 1); ent = new Map(); if (exact) ent.set("ref", provingKeyBin); }
+  keyCache.set(found, ent);
   while (keyCache.size > KEY_CACHE_SLOTS) keyCache.delete(keyCache.keys().next().value);
   return ent;
 }
@@ -500,7 +503,7 @@ module.exports = {
   binarifyR1cs, verifyingKeyFromBytes, solidityVerifyingKey, solidityVerifyingKeySource,
   // which form the last sharded proof took and why ({form: "split" | "replicated" | "none", reason}); how a key handle came to its device
   shardedLastForm: () => native().shardedLastForm(), keyReplication: (key) => native().keyReplication(key),
-  keyCacheStats: () => Object.assign({ shardedLastForm: addon ? native().shardedLastForm() : { form: "none", reason: "" } }, { entries: keyCache.size, handles: Array.from(keyCache.values()).reduce((a, e) => a + Array.from(e.values()).reduce((b, v) => b + (Array.isArray(v) ? v.length : 1), 0), 0) }, keyCacheStats), clearKeyCache, keyFingerprint,
+  keyCacheStats: () => Object.assign({ shardedLastForm: addon ? native().shardedLastForm() : { form: "none", reason: "" } }, { entries: keyCache.size, handles: Array.from(keyCache.values()).reduce((a, e) => a + Array.from(e.entries()).reduce((b, [k, v]) => b + (k === "ref" ? 0 : Array.isArray(v) ? v.length : 1), 0), 0) }, keyCacheStats), clearKeyCache, keyFingerprint,
   multiHash, multiHashBatch, buildBalanceTree, hashLeftRight, genPublicKey, formatPrivKeyForBabyJub, sign, verify, RollupCircuit, WithdrawCircuit,
   deviceCount: () => { native(); return deviceCount; },
   version: () => native().version(),

@@ -112,37 +112,33 @@ def is_valid(verifying_key, proof, public_signals) -> bool:
 # Process-level cache of device keys (SURVEY.md 8(b) "Ownership").  The reference builds a NEW object for every proof
 # (`await buildBn128()` at common.ts:23, scripts/index.js:40) and hands it the same provingKeyBin again (common.ts:28),
 # so a cache on the object would re-parse, re-upload and rebuild the window tables on every call.  An entry is one key
-# CONTENT (length + digest of every byte, key_fingerprint below) with its replicas, one per (device, ordinal)
-# asked for; the least recently used of KEY_CACHE_SLOTS contents is dropped with its replicas (a ProvingKey frees its arena
-# when the last reference goes).
+# CONTENT with its replicas, one per (device, ordinal) asked for; the least recently used of KEY_CACHE_SLOTS contents is dropped
+# with its replicas (a ProvingKey frees its arena when the last reference goes).
+#
+# Identity of a content -- EXACT, as the reference is by re-parsing the key on every call: candidates are found by the
+# cheap SAMPLED digest (length + first and last 4 KiB + 64 blocks of 4 KiB spread evenly: 0.3 MB whatever the size, < 0.2 ms) and
+# confirmed by comparing the caller's buffer with the buffer the entry was built from, byte for byte (a memcmp: ~8 ms for the tx
+# circuit's 57 MB, against 50-100 ms for a cryptographic digest of it); the SAME buffer object is recognised without the
+# comparison.  The entry keeps that buffer alive (a reference to immutable `bytes`, a private copy of anything mutable).
+# ZKR_KEY_FINGERPRINT=sampled: the sampled digest alone (keys of one setup that differ in a lone coefficient alias);
+# =full: a digest of every byte instead of the comparison (nothing retained).
 KEY_CACHE_SLOTS = 2
 FP_BLOCK, FP_STRIDED = 4096, 64
-_key_cache = collections.OrderedDict()   # fingerprint -> {(device, ordinal): ProvingKey}
-_key_cache_lock = threading.Lock()
-key_cache_stats = {"loads": 0, "hits": 0, "replications": 0}
-
-
-_fp_memo = collections.OrderedDict()   # id(bytes object) -> (the object: kept alive so that its id stays its own, fingerprint)
-FP_MEMO_SLOTS = 2                       # strong references to the last two buffer objects hashed (as many as key contents are cached): bounded host memory
 MAX_SHARD_SETS = 2                      # device lists whose shards an entry keeps (least recently used dropped)
+_key_cache = collections.OrderedDict()   # (fingerprint, variant) -> {"ref": buffer or None, (device, ordinal): ProvingKey, ("shards", ...): [...]}
+_key_cache_lock = threading.Lock()
+key_cache_stats = {"loads": 0, "hits": 0, "replications": 0, "compares": 0}
 
 
 def key_fingerprint(buf, full=None):
-    """(length, digest) identifying a provingKeyBin.  Default (round 5): the digest of EVERY byte -- exact, as the
-    reference is by re-parsing the key on every call (common.ts:28); ~0.5 ms per MB, paid once per buffer OBJECT for immutable
-    `bytes` (memoised by identity, the object is kept alive).  full=False or env ZKR_KEY_FINGERPRINT=sampled: first and last
-    4 KiB + 64 blocks of 4 KiB spread evenly in between (0.3 MB whatever the size: sees any difference in geometry, setup or broad
-    content, not a lone 36-byte coefficient) -- for callers that rebuild a large buffer per call and know their keys differ broadly."""
+    """(length, digest) of a provingKeyBin.  full=True (or env ZKR_KEY_FINGERPRINT=full): digest of every byte; full=False: first and
+    last 4 KiB + 64 blocks of 4 KiB spread evenly in between (0.3 MB whatever the size: sees any difference in geometry, setup or
+    broad content, not a lone 36-byte coefficient); default: the sampled one unless the environment asks for `full` -- the key cache
+    makes the sampled digest exact by comparing buffers (see above)."""
     import os
     n = len(buf)
     if full is None:
-        full = os.environ.get("ZKR_KEY_FINGERPRINT") != "sampled"
-    memo = full and type(buf) is bytes and n > FP_BLOCK * (FP_STRIDED + 2)
-    if memo:
-        hit = _fp_memo.get(id(buf))
-        if hit is not None and hit[0] is buf:
-            _fp_memo.move_to_end(id(buf))
-            return hit[1]
+        full = os.environ.get("ZKR_KEY_FINGERPRINT") == "full"
     h = hashlib.blake2b(digest_size=16)
     if full or n <= FP_BLOCK * (FP_STRIDED + 2):
         h.update(buf if isinstance(buf, (bytes, bytearray, memoryview)) else bytes(buf))
@@ -153,23 +149,35 @@ def key_fingerprint(buf, full=None):
             o = FP_BLOCK + (span - FP_BLOCK) * i // (FP_STRIDED - 1)
             h.update(bytes(buf[o:o + FP_BLOCK]))
         h.update(bytes(buf[n - FP_BLOCK:]))
-    fp = (n, h.digest())
-    if memo:
-        _fp_memo[id(buf)] = (buf, fp)
-        while len(_fp_memo) > FP_MEMO_SLOTS:
-            _fp_memo.popitem(last=False)
-    return fp
+    return (n, h.digest())
 
 
 def _entry(proving_key_bin):   # caller holds the lock
+    import os
+    mode = os.environ.get("ZKR_KEY_FINGERPRINT", "")
     fp = key_fingerprint(proving_key_bin)
-    ent = _key_cache.get(fp)
-    if ent is None:
-        ent = _key_cache[fp] = {}
-    _key_cache.move_to_end(fp)
+    exact = mode not in ("sampled", "full") and len(proving_key_bin) > FP_BLOCK * (FP_STRIDED + 2)   # small buffers are hashed whole anyway
+    found = None
+    variants = [k for k in _key_cache if k[0] == fp]
+    for k in variants:
+        ref = _key_cache[k]["ref"]
+        if not exact or ref is proving_key_bin:
+            found = k
+            break
+        key_cache_stats["compares"] += 1
+        if ref == proving_key_bin:                          # bytes / bytearray / memoryview compare by content (memcmp)
+            found = k
+            break
+    if found is None:
+        found = (fp, 1 + max([k[1] for k in variants], default=-1))
+        ref = None
+        if exact:
+            ref = proving_key_bin if type(proving_key_bin) is bytes else bytes(proving_key_bin)
+        _key_cache[found] = {"ref": ref}
+    _key_cache.move_to_end(found)
     while len(_key_cache) > KEY_CACHE_SLOTS:
         _key_cache.popitem(last=False)
-    return ent
+    return _key_cache[found]
 
 
 def _replica(ent, proving_key_bin, device, ordinal):
@@ -177,7 +185,7 @@ def _replica(ent, proving_key_bin, device, ordinal):
     if key is not None:
         key_cache_stats["hits"] += 1
         return key
-    src = next((k for s, k in ent.items() if s[0] != "shards"), None)
+    src = next((k for s, k in ent.items() if s != "ref" and s[0] != "shards"), None)
     if src is not None:   # another replica holds this content: device-to-device copy instead of a second parse
         key = src.replicate(device)
         key_cache_stats["replications"] += 1
@@ -217,11 +225,11 @@ def cached_shards(proving_key_bin, devices):
             key_cache_stats["hits"] += 1
             ent[slot] = ent.pop(slot)                      # most recently used last
             return shards
-        whole = next((k for s, k in ent.items() if s[0] != "shards"), None)
+        whole = next((k for s, k in ent.items() if s != "ref" and s[0] != "shards"), None)
         if whole is None:
             whole = _replica(ent, proving_key_bin, devices[0], 0)
         shards = [whole.shard(i, len(devices), d) for i, d in enumerate(devices)]
-        sets = [k for k in ent if k[0] == "shards"]
+        sets = [k for k in ent if k != "ref" and k[0] == "shards"]
         while len(sets) >= MAX_SHARD_SETS:                 # bounded: a caller cycling through device lists does not pile up shard sets
             del ent[sets.pop(0)]
         ent[slot] = shards
@@ -231,7 +239,6 @@ def cached_shards(proving_key_bin, devices):
 def clear_key_cache():
     with _key_cache_lock:
         _key_cache.clear()
-        _fp_memo.clear()
 
 
 class Bn128:

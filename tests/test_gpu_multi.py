@@ -152,7 +152,7 @@ def test_facade_batch_over_devices_parses_the_key_once(small_case):
     for _ in range(2):
         bn = zkr_hip.build_bn128()
         assert bn.groth16GenProofBatch([c["wb"]] * n, bytes(c["pkb"]), rs, ss, devices=devs) == expect
-    d = {k: zkr_hip.key_cache_stats[k] - before[k] for k in before}
+    d = {k: zkr_hip.key_cache_stats[k] - before[k] for k in ("loads", "replications", "hits")}
     assert d == {"loads": 1, "replications": 1, "hits": 2}
     assert zkr_hip.build_bn128().groth16GenProofBatch([c["wb"]] * 3, bytes(c["pkb"]), rs[:3], ss[:3]) == expect[:3]   # single device: the first replica
     # ONE proof over the devices: shards cut from the cached key, cached themselves
@@ -198,7 +198,8 @@ def test_key_cache_does_not_alias_equal_sized_circuits_of_one_setup():
     assert pk0[:4096] == pk1[:4096] == pk2[:4096] and pk0[-4096:] == pk1[-4096:] == pk2[-4096:]   # what round 3 hashed: aliases
     assert zkr_hip.key_fingerprint(pk0, full=False) != zkr_hip.key_fingerprint(pk1, full=False)
     assert len({zkr_hip.key_fingerprint(k, full=True) for k in (pk0, pk1, pk2)}) == 3
-    assert len({zkr_hip.key_fingerprint(k) for k in (pk0, pk1, pk2)}) == 3         # round 5: the default is the exact one
+    # round 5: the cache finds candidates by the sampled digest and CONFIRMS them by comparing the buffers, so the lone edited
+    # constraint (which the sampled digest may or may not see) gets its own key either way -- checked on the proofs below
     wb = g.binarify_witness(circ["witness"])
     rng = g.SplitMix64(8)
     r, s = rng.fr(), rng.fr()

@@ -60,9 +60,11 @@ def test_js_binarify_matches_reference_layouts(tmp_path, small_case):
 
 
 def test_js_and_python_key_fingerprints_cover_the_whole_buffer():
-    """VERDICT r3 weak 6, host side (no GPU): the key-cache identity of index.js and facade.py covers the buffer's middle, not
-    only its first and last 4 KiB -- two buffers of equal length, equal head and equal tail that differ broadly get different
-    fingerprints; a single differing byte between two sampled blocks is only seen by the full mode (documented residual)."""
+    """VERDICT r3 weak 6 / ADVICE r4, host side (no GPU): the SAMPLED digest that finds cache candidates covers the buffer's middle,
+    not only its first and last 4 KiB -- two buffers of equal length, equal head and equal tail that differ broadly get different
+    digests; a single differing byte between two sampled blocks is only seen by the full digest -- which is why the key cache
+    confirms a candidate by comparing the buffers byte for byte (tests/test_gpu_multi.py holds that case on the cache itself, and
+    the Python cache's lookup is exercised below with a stand-in loader)."""
     import zkr_hip
     n = 3 << 20
     out = _node("""
@@ -71,32 +73,35 @@ def test_js_and_python_key_fingerprints_cover_the_whole_buffer():
       const a = Buffer.alloc(n, 7), b = Buffer.alloc(n, 7), c = Buffer.alloc(n, 7);
       for (let i = 8192; i < n - 8192; i += 997) b[i] ^= 1;          // broad difference, head and tail untouched
       c[5000 + 4096 * 3] ^= 1;                                        // one byte, in a gap between sampled blocks
-      const f0 = z.keyFingerprint(a);                                  // default: every byte, memoised per buffer object
-      const memo = z.keyFingerprint(a) === f0;
-      a[5000 + 4096 * 5] ^= 1;                                        // the memoised object edited between sampled blocks: documented residual of the memo
-      const stale = z.keyFingerprint(a) === f0;
-      a[5000 + 4096 * 5] ^= 1; a[100] ^= 1;                           // ... but an object refilled visibly (a sampled block changed) is hashed again
-      const refreshed = z.keyFingerprint(a) !== f0;
-      a[100] ^= 1;
-      console.log(JSON.stringify({ab: z.keyFingerprint(a, false) !== z.keyFingerprint(b, false), ac: z.keyFingerprint(a, false) !== z.keyFingerprint(c, false),
-                                  ac_default: z.keyFingerprint(a) !== z.keyFingerprint(c), memo, stale, refreshed,
+      console.log(JSON.stringify({ab: z.keyFingerprint(a) !== z.keyFingerprint(b), ac: z.keyFingerprint(a) !== z.keyFingerprint(c),
+                                  dflt: z.keyFingerprint(a) === z.keyFingerprint(a, false),
                                   ac_full: z.keyFingerprint(a, true) !== z.keyFingerprint(c, true), small: z.keyFingerprint(a.subarray(0, 100000)) !== z.keyFingerprint(Buffer.concat([a.subarray(0, 50000), Buffer.from([9]), a.subarray(50001, 100000)]))}));
     """, str(n)).stdout
     res = json.loads(out)
-    assert res == {"ab": True, "ac": False, "ac_default": True, "memo": True, "stale": True, "refreshed": True, "ac_full": True, "small": True}
+    assert res == {"ab": True, "ac": False, "dflt": True, "ac_full": True, "small": True}
     a = bytes([7]) * n
     b = bytearray(a)
     for i in range(8192, n - 8192, 997):
         b[i] ^= 1
     c = bytearray(a)
     c[5000 + 4096 * 3] ^= 1
-    assert zkr_hip.key_fingerprint(a, full=False) != zkr_hip.key_fingerprint(bytes(b), full=False)
-    assert zkr_hip.key_fingerprint(a, full=False) == zkr_hip.key_fingerprint(bytes(c), full=False) and zkr_hip.key_fingerprint(a, full=True) != zkr_hip.key_fingerprint(bytes(c), full=True)
-    # round 5 (ADVICE r4): the DEFAULT is the exact one; immutable bytes objects are hashed once (memo by identity, object kept alive)
-    assert zkr_hip.key_fingerprint(a) != zkr_hip.key_fingerprint(bytes(c)) and zkr_hip.key_fingerprint(a) == zkr_hip.key_fingerprint(a, full=True)
+    assert zkr_hip.key_fingerprint(a) != zkr_hip.key_fingerprint(bytes(b)) and zkr_hip.key_fingerprint(a) == zkr_hip.key_fingerprint(a, full=False)
+    assert zkr_hip.key_fingerprint(a) == zkr_hip.key_fingerprint(bytes(c)) and zkr_hip.key_fingerprint(a, full=True) != zkr_hip.key_fingerprint(bytes(c), full=True)
+    # the cache's lookup itself (no device: only the entry bookkeeping runs): same sampled digest, different bytes -> different
+    # entries; the same object -> no comparison; an equal copy -> one comparison, the same entry; a mutable buffer is copied
     from zkr_hip import facade
-    assert id(a) in facade._fp_memo and facade._fp_memo[id(a)][0] is a
-    assert id(b) not in facade._fp_memo and zkr_hip.key_fingerprint(b) == zkr_hip.key_fingerprint(bytes(b))     # a bytearray is never memoised
+    facade.clear_key_cache()
+    cmp0 = facade.key_cache_stats["compares"]
+    with facade._key_cache_lock:
+        ea = facade._entry(a)
+        assert facade._entry(a) is ea and facade.key_cache_stats["compares"] == cmp0          # identity: nothing compared
+        a2 = bytes(bytearray(a))
+        assert a2 is not a and facade._entry(a2) is ea and facade.key_cache_stats["compares"] == cmp0 + 1
+        ec = facade._entry(c)                                                                  # a lone byte differs: the sampled digest is a's
+        assert ec is not ea and ec["ref"] == bytes(c) and ec["ref"] is not c                   # ... its own entry; the bytearray was copied
+        c[0] ^= 1                                                                              # the caller rewrites ITS buffer: the entry's copy is untouched
+        assert facade._entry(bytes(c)) is not ec and len(facade._key_cache) == facade.KEY_CACHE_SLOTS   # (and the least recently used entry went)
+    facade.clear_key_cache()
 
 
 def test_js_rejects_without_gpu(tmp_path, small_case):
