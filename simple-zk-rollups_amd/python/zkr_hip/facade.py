@@ -152,10 +152,25 @@ def key_fingerprint(buf, full=None):
     return (n, h.digest())
 
 
+_fp_of_object = []   # [(bytes object, fingerprint)]: immutable buffers seen last, so that the SAME object costs no digest at all (two slots)
+
+
+def _fingerprint_memoised(buf):
+    if type(buf) is not bytes:           # anything mutable is digested on every call
+        return key_fingerprint(buf)
+    for obj, fp in _fp_of_object:
+        if obj is buf:
+            return fp
+    fp = key_fingerprint(buf)
+    _fp_of_object.insert(0, (buf, fp))
+    del _fp_of_object[2:]
+    return fp
+
+
 def _entry(proving_key_bin):   # caller holds the lock
     import os
     mode = os.environ.get("ZKR_KEY_FINGERPRINT", "")
-    fp = key_fingerprint(proving_key_bin)
+    fp = _fingerprint_memoised(proving_key_bin)
     exact = mode not in ("sampled", "full") and len(proving_key_bin) > FP_BLOCK * (FP_STRIDED + 2)   # small buffers are hashed whole anyway
     found = None
     variants = [k for k in _key_cache if k[0] == fp]
@@ -239,6 +254,7 @@ def cached_shards(proving_key_bin, devices):
 def clear_key_cache():
     with _key_cache_lock:
         _key_cache.clear()
+        del _fp_of_object[:]
 
 
 class Bn128:
