@@ -61,27 +61,11 @@ ZKR_HD XYZZ29<C> make_xyzz(const X &x, const Y &y, const ZZ &zz, const ZZZ &zzz)
 }
 
 // ---- packed <-> registers
-#ifdef ZKR_EXP_FAKE_UNPACK
-// MEASUREMENT ONLY (tools/r5_gpu_02.sh; never shipped): a table point's words taken as limbs as they are -- what an accumulation
-// would cost if the tables stored 9 x 29-bit limbs (72-byte rows) and needed no unpacking.  The sums are garbage.
-template <class PM, int H>
-ZKR_HD L29<PM, H> fake_limbs(const uint32_t (&w)[8]) {
-  L29<PM, H> r;
-#pragma unroll
-  for (int i = 0; i < 9; i++) r.v[i] = w[i < 8 ? i : 7];
-  return r;
-}
-ZKR_HD Affine29<G1C> unpack_affine(const Affine<Fq> &p) { return Affine29<G1C>{fake_limbs<Fq29, 2>(p.x.v), fake_limbs<Fq29, 2>(p.y.v)}; }
-ZKR_HD Affine29<G2C> unpack_affine(const Affine<Fq2> &p) {
-  return Affine29<G2C>{G2C::unpack<2>(p.x), G2C::unpack<2>(p.y)};
-}
-#else
 template <class F>
 ZKR_HD Affine29<typename CoordOf<F>::C> unpack_affine(const Affine<F> &p) {
   using C = typename CoordOf<F>::C;
   return Affine29<C>{C::template unpack<2>(p.x), C::template unpack<2>(p.y)};
 }
-#endif
 template <class F>
 ZKR_HD XYZZ29<typename CoordOf<F>::C> unpack_xyzz(const XYZZ<F> &p) {  // stored coordinates are below 2 p (pack_xyzz)
   using C = typename CoordOf<F>::C;
