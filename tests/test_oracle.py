@@ -176,6 +176,32 @@ def test_c_oracle_all_threads_prover_and_dot_product(small_case):
     assert coracle.fr_dot(b"", b"") == 0
 
 
+def test_cpu_baseline_build_choice_keeps_the_oracles_results(tmp_path, small_case):
+    """bench.py's CPU baseline compiles the C oracle with `-march=native` on the box and times whichever of the native and the
+    portable (x86-64-v2) build is faster there (coracle.use_fastest; BASELINE.md section 3 promises a native build): whichever is
+    chosen must produce the portable build's bytes.  Its own process: the choice is made once, before the library is loaded."""
+    import pickle
+    import subprocess
+    import sys
+    c = small_case
+    want = coracle.prove(c["pkb"], c["wb"], c["r"], c["s"])
+    case = tmp_path / "case.pkl"
+    case.write_bytes(pickle.dumps((c["pkb"], c["wb"], c["r"], c["s"])))
+    script = (
+        "import sys, pickle; sys.path.insert(0, %r); import coracle\n"
+        "pk, w, r, s = pickle.load(open(%r, 'rb'))\n"
+        "how = coracle.use_fastest(pk, w)\n"
+        "print('HOW', how)\n"
+        "sys.stdout.write('PROOF ' + coracle.prove(pk, w, r, s).hex() + '\\n')\n"
+        "print('AGAIN', coracle.use_fastest(pk, w))\n" % (os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"), str(case)))
+    r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:]
+    lines = dict(ln.split(" ", 1) for ln in r.stdout.splitlines() if " " in ln)
+    assert lines["PROOF"] == want.hex()
+    assert "march=" in lines["HOW"] and ("faster on this host" in lines["HOW"] or "portable build" in lines["HOW"])
+    assert lines["AGAIN"].startswith("already loaded")          # the choice cannot change under a loaded library
+
+
 @pytest.mark.parametrize("name", ["synth_m5.json", "synth_m7.json"])
 def test_golden_fixture_reproduces(name):
     fx = json.load(open(os.path.join(GOLD, name)))
