@@ -153,6 +153,21 @@ def cpu_baseline_js(sample_log_m, target_log_m):
                          sec["h"], sec["msm"], target_log_m - sample_log_m)}
 
 
+def cpu_baseline_scalars(cb, gpu_proofs_per_s, js_sample_log_m):
+    """The north star's ratios ("x snarkjs single-thread CPU", BASELINE.json) as SCALARS of `cpu_baseline`: the driver's record
+    keeps scalars and short strings only, so the nested `snarkjs_style` object (the denominator of the >= 50x claim) is repeated
+    flat, next to the ratios against the C oracle on one thread and on all host threads."""
+    js_leg = cb.get("snarkjs_style") or {}
+    v = js_leg.get("value")
+    cb["snarkjs_style_proofs_per_s"] = v
+    cb["snarkjs_style_sample_log_m"] = js_sample_log_m if v else None
+    cb["snarkjs_style_seconds_per_proof"] = (1.0 / v) if v else None
+    cb["speedup_vs_snarkjs_style"] = (gpu_proofs_per_s / v) if v else None
+    cb["speedup_vs_c_1thread"] = (gpu_proofs_per_s / cb["value"]) if cb.get("value") else None
+    cb["speedup_vs_c_all_threads"] = (gpu_proofs_per_s / cb["all_threads_proofs_per_s"]) if cb.get("all_threads_proofs_per_s") else None
+    return cb
+
+
 class GpuSampler:
     """Device clock (MHz) and board power (W) sampled from sysfs while the timed region runs (the sustained
     clock under this integer load must be a recorded number, not an inference).  Sources, first that works:
@@ -1318,6 +1333,7 @@ def main():
             out["cpu_baseline"]["host_hardware_threads"] = os.cpu_count()
             if not args.no_js_baseline:
                 out["cpu_baseline"]["snarkjs_style"] = cpu_baseline_js(args.js_sample_log_m, args.log_m)
+            cpu_baseline_scalars(out["cpu_baseline"], out["value"], args.js_sample_log_m)
         if world == 1 and not args.no_bcast_modes:
             out["key"]["replication_modes_one_gpu"] = bcast_modes_leg(key, bytes(wits[0].cpu().numpy().tobytes()), local)
         if world == 1 and args.shards > 1:

@@ -60,3 +60,27 @@ def test_sharding_scalars_have_one_schema_for_projected_measured_and_failed_legs
     real = dict(meas, rehearsal_on_one_gpu=False)                                      # the same leg as a multi-GPU node would report it
     assert b.sharding_scalars(real)["sharded_measured"] is True
     assert b.sharding_scalars({"error": "boom"}) == {"sharded_error": "boom"} and b.sharding_scalars(None) == {"sharded_error": None}
+
+
+def test_north_star_ratios_are_scalars_of_cpu_baseline():
+    """the denominator of the ">= 50x snarkjs single-thread" claim and the three ratios are scalars (the driver's
+    record drops the nested `snarkjs_style` object)."""
+    b = _bench()
+    d = json.load(open(os.path.join(ROOT, "profiles", "r5_09_bench_default.json")))
+    cb = dict(d["cpu_baseline"])
+    b.cpu_baseline_scalars(cb, d["value"], 12)
+    cpu = _driver_view(cb)
+    for k in ("snarkjs_style_proofs_per_s", "snarkjs_style_sample_log_m", "snarkjs_style_seconds_per_proof", "speedup_vs_snarkjs_style",
+              "speedup_vs_c_1thread", "speedup_vs_c_all_threads", "cores", "all_threads_cores"):
+        assert isinstance(cpu.get(k), (int, float)), k
+    assert cpu["snarkjs_style_proofs_per_s"] == d["cpu_baseline"]["snarkjs_style"]["value"] and cpu["snarkjs_style_sample_log_m"] == 12
+    assert abs(cpu["speedup_vs_snarkjs_style"] * cpu["snarkjs_style_proofs_per_s"] - d["value"]) < 1e-9
+    assert abs(cpu["speedup_vs_c_1thread"] * cpu["value"] - d["value"]) < 1e-9
+    assert abs(cpu["speedup_vs_c_all_threads"] * cpu["all_threads_proofs_per_s"] - d["value"]) < 1e-9
+    assert cpu["speedup_vs_snarkjs_style"] >= 50                                        # the north star's single-GPU target
+    flat = [k for k, v in cb.items() if not isinstance(v, (dict, list))]
+    assert len({k[:40] for k in flat}) == len(flat)
+    # no JS leg (node missing / --no-js-baseline): the keys exist and are null, the C ratios stay
+    cb2 = {k: v for k, v in d["cpu_baseline"].items() if k != "snarkjs_style"}
+    b.cpu_baseline_scalars(cb2, d["value"], 12)
+    assert cb2["snarkjs_style_proofs_per_s"] is None and cb2["speedup_vs_snarkjs_style"] is None and cb2["speedup_vs_c_1thread"] > 1
