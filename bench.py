@@ -700,8 +700,12 @@ def roofline_record(key, info, prof, per_proof_s, device_state, log_m, shape, lo
     import zkr_hip
     g1_pts = info["ptsA"] + info["ptsB1"] + info["ptsC"] + info["ptsH"]
     win = key.windows()  # K mixed additions per point (one per window level of the key table)
+    # launches of the G1 accumulation per proof: 2 since round 6 (B1 + A + C in ONE launch, then H), 4 before -- taken from the
+    # profile itself (one ingest_kernel launch per proof), so `achieved` stays bytes of ONE launch over the duration of ONE launch
+    proofs_profiled = max(prof.get("ingest", (0.0, 0))[1], 1)
+    g1_lpp = max(prof["msm_accum_g1"][1] / proofs_profiled, 1e-9)
     cands = {
-        "msm_accum_kernel<Fq>": ("msm_accum_g1", 96.0 * g1_pts / 4.0, MADD_G1 * g1_pts / 4.0 * win["A"][1]),
+        "msm_accum_kernel<Fq>": ("msm_accum_g1", 96.0 * g1_pts / g1_lpp, MADD_G1 * g1_pts / g1_lpp * win["A"][1]),
         "msm_accum_kernel<Fq2>": ("msm_accum_g2", 160.0 * info["ptsB2"], MADD_G2 * info["ptsB2"] * win["B2"][1]),
     }
     dom, best = None, -1.0
@@ -743,7 +747,7 @@ def roofline_record(key, info, prof, per_proof_s, device_state, log_m, shape, lo
     roofline = {"bound": "hbm", "binding_bound": "valu", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "streaming": streaming,
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
-                "avg_launch_ms": avg_ms, "launches": launches,
+                "avg_launch_ms": avg_ms, "launches": launches, "launches_per_proof": launches / proofs_profiled,
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "note": "Pippenger bucket accumulation is integer-VALU bound (v_mad_u64_u32), not HBM bound; see valu. traffic > algorithmic bytes by design: "
                         "the kernel gathers one precomputed 64-byte multiple per window (13 per point, 832 B) instead of re-deriving it, "

@@ -660,31 +660,52 @@ static __global__ __launch_bounds__(SCAN_THREADS) void msm_order_kernel(const ui
 // bucket accumulation: thread per bucket, buckets taken in `order` (fullest first): the 64 lanes of a
 // wavefront get buckets of (almost) equal occupancy, so no lane idles while another finishes, and the long
 // buckets start first.  The next entry and its point are fetched while the current addition runs.
-constexpr int ACC_ONTO = 1, ACC_ZERO_BIG = 2;  // flags of the accumulation kernels' `onto` argument
-#ifndef ZKR_ACC_THREADS
-#define ZKR_ACC_THREADS 256
-#endif
-constexpr int ACC_THREADS = ZKR_ACC_THREADS;
+//
+// One launch, several tables (round 6).  A launch is a list of up to ACC_MAX_JOBS tables over the same kind of point; workgroup
+// b works on the job whose block range holds b.  Why: a table's launch ends with its emptiest buckets, and the stream's next
+// launch starts only when the last of them is done -- with ~4 workgroups per resident slot and jobs of 50 .. 5 additions the
+// slots finish up to one small job apart (profiles/r6_01_census_isolated.md: 1.76 of 2 wavefronts resident per SIMD over an
+// isolated launch; a list-scheduling model of the same bucket sizes gives 0.90-0.93).  The three tables that multiply the
+// witness and wait for nothing else (B1, A, C) therefore go into ONE launch: the slots B1's tail frees take A's fullest buckets
+// at once, and a proof pays three launch tails (B2, B1 + A + C, H) instead of five.
+constexpr int ACC_ONTO = 1, ACC_ZERO_BIG = 2;  // flags of an accumulation job's `onto`
+constexpr int ACC_THREADS = 256;
+constexpr int ACC_MAX_JOBS = 3;
+template <class F> struct AccumJob {
+  const Affine<F> *points;   // the table's window levels
+  const uint32_t *offsets, *entries, *counts, *order;  // the digit sort it walks (possibly another table's over the same signals)
+  XYZZ<F> *buckets;
+  uint32_t nb;               // buckets (of every fused proof, end to end)
+  int onto;
+};
+template <class F> struct AccumJobs {
+  AccumJob<F> job[ACC_MAX_JOBS];
+  uint32_t first_block[ACC_MAX_JOBS + 1];  // job j owns workgroups [first_block[j], first_block[j + 1])
+  int n;
+};
 template <class F, int MINW, bool PREFETCH = true>
-static __global__ __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per_eu(MINW, MINW))) void msm_accum_kernel(const Affine<F> *points, const uint32_t *offsets, const uint32_t *entries,
-                                                                     uint32_t nb, const uint32_t *counts, const uint32_t *order, XYZZ<F> *buckets, int prio, int onto) {
+static __global__ __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per_eu(MINW, MINW))) void msm_accum_kernel(AccumJobs<F> jobs) {
   using C = typename CoordOf<F>::C;
-  if (prio == 1) __builtin_amdgcn_s_setprio(1);
-  else if (prio == 2) __builtin_amdgcn_s_setprio(2);
-  else if (prio == 3) __builtin_amdgcn_s_setprio(3);
-  const uint32_t t = blockIdx.x * ACC_THREADS + threadIdx.x;
-  if (t >= nb) return;
-  const uint32_t b = order[t];
+  // the job of this workgroup: uniform, so the selects below are scalar
+  AccumJob<F> job = jobs.job[0];
+  uint32_t first = 0;
+  if (jobs.n > 1 && blockIdx.x >= jobs.first_block[1]) { job = jobs.job[1]; first = jobs.first_block[1]; }
+  if (jobs.n > 2 && blockIdx.x >= jobs.first_block[2]) { job = jobs.job[2]; first = jobs.first_block[2]; }
+  const Affine<F> *points = job.points;
+  const uint32_t *entries = job.entries;
+  const uint32_t t = (blockIdx.x - first) * ACC_THREADS + threadIdx.x;
+  if (t >= job.nb) return;
+  const uint32_t b = job.order[t];
   // msm_big_kernel owns an oversized bucket.  ACC_ZERO_BIG: its slot is cleared here, because the partial sums will be ADDED
   // to it later (the first table of a shared bucket set: see ACC_ONTO)
-  if (counts[b] == BIG_MARK) {
-    if (onto & ACC_ZERO_BIG) store_pod(buckets + b, XYZZ<F>::inf());
+  if (job.counts[b] == BIG_MARK) {
+    if (job.onto & ACC_ZERO_BIG) store_pod(job.buckets + b, XYZZ<F>::inf());
     return;
   }
-  uint32_t o0 = offsets[b], o1 = offsets[b + 1];
+  uint32_t o0 = job.offsets[b], o1 = job.offsets[b + 1];
   // ACC_ONTO: the bucket set already holds another table's sums over the same bucket geometry (C before H: only C + H is
   // ever needed, so one bucket set and ONE reduction chain serve both tables)
-  XYZZ29<C> acc = (onto & ACC_ONTO) ? unpack_xyzz(load_pod(buckets + b)) : XYZZ29<C>::inf();
+  XYZZ29<C> acc = (job.onto & ACC_ONTO) ? unpack_xyzz(load_pod(job.buckets + b)) : XYZZ29<C>::inf();
   if (PREFETCH) {
     if (o0 < o1) {
       uint32_t e = entries[o0];
@@ -707,7 +728,7 @@ static __global__ __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per
       e = en;
     }
   }
-  store_pod(buckets + b, pack_xyzz<F>(acc));
+  store_pod(job.buckets + b, pack_xyzz<F>(acc));
 }
 
 // The same for small bucket sets (circuits of 2^17 constraints and below: fewer buckets than the chip has lanes):

@@ -146,7 +146,6 @@ struct ProofSlot {
   DigitLists dig_w, dig_h;  // digit records of w (shared by A, B1, B2, C) and of h
   MsmWorkspace ws[N_TABLES];
   hipEvent_t ev_w = nullptr, ev_h = nullptr;
-  hipEvent_t ev_calch = nullptr;  // calcH of the proof has been enqueued and run: what deferred accumulations wait for (zkr_prove.hip defer_acc)
   hipEvent_t ev_red[N_TABLES] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // end of the proof's work on each reduction stream
   hipEvent_t ev_done[N_TABLES] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_sorted[N_TABLES] = {nullptr, nullptr, nullptr, nullptr, nullptr};

@@ -343,7 +343,6 @@ int key_alloc_workspace(zkr_key *k) {
     }
     ZKR_HIP_CHECK(hipEventCreateWithFlags(&sl.ev_w, hipEventDisableTiming));
     ZKR_HIP_CHECK(hipEventCreateWithFlags(&sl.ev_h, hipEventDisableTiming));
-    ZKR_HIP_CHECK(hipEventCreateWithFlags(&sl.ev_calch, hipEventDisableTiming));
     for (int j = 0; j < k->n_all; j++) ZKR_HIP_CHECK(hipEventCreateWithFlags(&sl.ev_red[j], hipEventDisableTiming));
     ZKR_HIP_CHECK(hipMalloc(&sl.d_w, (size_t)h.n * 32 * cap));
     Fr **vecs[5] = {&sl.va, &sl.vb, &sl.ca, &sl.cb, &sl.d_h};
@@ -752,7 +751,6 @@ void zkr_key_free(zkr_key *k) {
     }
     if (sl.ev_w) hipEventDestroy(sl.ev_w);
     if (sl.ev_h) hipEventDestroy(sl.ev_h);
-    if (sl.ev_calch) hipEventDestroy(sl.ev_calch);
     for (auto e : sl.ev_red)
       if (e) hipEventDestroy(e);
     digit_lists_free(sl.dig_w); digit_lists_free(sl.dig_h);

@@ -511,55 +511,62 @@ static int msm_sort_enqueue(Prof pf, hipStream_t s, const uint32_t *rank, const 
   return 0;
 }
 
-// bucket accumulation of one point table over a finished sort (`srt` may belong to another table with the
-// same point set: B1 and B2 share one)
+// bucket accumulation of up to ACC_MAX_JOBS point tables over finished sorts in ONE launch (kernels_msm.hpp msm_accum_kernel: the
+// tables' workgroups end to end, so a table's launch tail is filled by the next table's fullest buckets).  `srt` may belong to
+// another table with the same point set (B1 and B2 share a sort); `buckets`: where the sums land (the table's own set, a set behind
+// another table's, or -- ACC_ONTO -- a set that already holds another table's sums).
+template <class F> struct AccumTable {
+  const Affine<F> *pts;
+  uint32_t n;                // points (0: the table is empty, skipped)
+  const MsmPlan *pl;
+  const MsmWorkspace *srt;
+  void *buckets;
+  int onto;
+};
 template <class F>
-static int msm_accum_enqueue(Prof pf, hipStream_t s, const Affine<F> *pts, uint32_t n, int nbat, const MsmPlan &pl, const MsmWorkspace &srt, MsmWorkspace &ws, int onto = 0) {
-  if (n == 0) return 0;
-  const uint32_t nb = pl.nb * (uint32_t)nbat;
-  int sp = prof_begin(pf, s, MsmCfg<F>::ACC_STAGE);
-  // wavefronts per SIMD the kernel is built for (amdgpu_waves_per_eu pins the occupancy: the G1 form needs ~150 VGPRs, so
-  // three would fit): 2 for both G1 and G2.  With three G1 wavefronts the reduction kernels of the other streams find no
-  // registers beside them (116.2 against 125.6 proofs/s; 126.3 at one); four spill.  ZKR_ACC_W_G1 / ZKR_ACC_W_G2 override for experiments
-  static const char *acc_env = getenv(sizeof(F) == 32 ? "ZKR_ACC_W_G1" : "ZKR_ACC_W_G2");
-  static const int acc_w = acc_env ? atoi(acc_env) : MsmCfg<F>::ACC_W;
-  // small bucket sets: several lanes per bucket (kernels_msm.hpp msm_accum_split_kernel)
-  static const char *split_env = getenv("ZKR_ACC_SPLIT");
-  // lanes per bucket by bucket count, from single-proof latencies on the round's last tree: 2^11 / 2^13 / 2^15 buckets (circuits of
-  // 2^12 / 2^14 / 2^16): 1.52 / 1.31 / 1.33, 1.83 / 1.64 / 1.68, 1.76 / 1.69 / 2.00 ms at 2 / 4 / 8 lanes; the tx circuit's 2^16
-  // buckets: 2.30 / 2.02 / 2.15 / 2.52 ms at 1 / 2 / 4 / 8 (and 631 against 614 unfused pipelined proofs/s at 2 / 4)
-  const int split = split_env ? atoi(split_env) : nb <= (1u << 15) ? 4 : nb <= (1u << 17) ? 2 : 1;
-  if (split > 1) {
-    const unsigned sgrid = (unsigned)(((size_t)nb * split + ACC_THREADS - 1) / ACC_THREADS);
-    // wavefronts per SIMD the split kernel is built for: at two the Fq2 form (its lane exchange holds two XYZZ points of 72
-    // words) spills 170-200 bytes per lane; ZKR_ACC_SPLIT_W_G2=1 builds it for one (512 VGPRs, no scratch) -- A/B knob
-    static const int split_w_g2 = getenv("ZKR_ACC_SPLIT_W_G2") ? atoi(getenv("ZKR_ACC_SPLIT_W_G2")) : MsmCfg<F>::ACC_W;
-#define ZKR_ACC_SPLIT_LAUNCH_W(W, SP) msm_accum_split_kernel<F, W, SP><<<sgrid, ACC_THREADS, 0, s>>>(pts, srt.offsets, srt.entries, nb, srt.counts, srt.order, (XYZZ<F> *)ws.buckets, onto)
-#define ZKR_ACC_SPLIT_LAUNCH(SP) do { if (sizeof(F) != 32 && split_w_g2 == 1) ZKR_ACC_SPLIT_LAUNCH_W(1, SP); else ZKR_ACC_SPLIT_LAUNCH_W(MsmCfg<F>::ACC_W, SP); } while (0)
-    switch (split) {
-      case 2: ZKR_ACC_SPLIT_LAUNCH(2); break;
-      case 8: ZKR_ACC_SPLIT_LAUNCH(8); break;
-      default: ZKR_ACC_SPLIT_LAUNCH(4); break;
+static int msm_accum_enqueue(Prof pf, hipStream_t s, int nbat, const AccumTable<F> *tabs, int ntab) {
+  AccumJobs<F> jobs;
+  memset(&jobs, 0, sizeof(jobs));
+  unsigned grid = 0;
+  int sp = -1;
+  for (int i = 0; i < ntab; i++) {
+    const AccumTable<F> &t = tabs[i];
+    if (t.n == 0) continue;
+    const uint32_t nb = t.pl->nb * (uint32_t)nbat;
+    // small bucket sets: several lanes per bucket (kernels_msm.hpp msm_accum_split_kernel), one launch per table.
+    // lanes per bucket by bucket count, from single-proof latencies: 2^11 / 2^13 / 2^15 buckets (circuits of 2^12 / 2^14 / 2^16):
+    // 1.52 / 1.31 / 1.33, 1.83 / 1.64 / 1.68, 1.76 / 1.69 / 2.00 ms at 2 / 4 / 8 lanes; the tx circuit's 2^16 buckets: 2.30 / 2.02 /
+    // 2.15 / 2.52 ms at 1 / 2 / 4 / 8 (and 631 against 614 unfused pipelined proofs/s at 2 / 4)
+    const int split = nb <= (1u << 15) ? 4 : nb <= (1u << 17) ? 2 : 1;
+    if (split > 1) {
+      const unsigned sgrid = (unsigned)(((size_t)nb * split + ACC_THREADS - 1) / ACC_THREADS);
+      int ssp = prof_begin(pf, s, MsmCfg<F>::ACC_STAGE);
+      if (split == 2) msm_accum_split_kernel<F, MsmCfg<F>::ACC_W, 2><<<sgrid, ACC_THREADS, 0, s>>>(t.pts, t.srt->offsets, t.srt->entries, nb, t.srt->counts, t.srt->order, (XYZZ<F> *)t.buckets, t.onto);
+      else msm_accum_split_kernel<F, MsmCfg<F>::ACC_W, 4><<<sgrid, ACC_THREADS, 0, s>>>(t.pts, t.srt->offsets, t.srt->entries, nb, t.srt->counts, t.srt->order, (XYZZ<F> *)t.buckets, t.onto);
+      prof_end(pf, s, ssp);
+      continue;
     }
-#undef ZKR_ACC_SPLIT_LAUNCH
-#undef ZKR_ACC_SPLIT_LAUNCH_W
+    AccumJob<F> &j = jobs.job[jobs.n];
+    j.points = t.pts; j.offsets = t.srt->offsets; j.entries = t.srt->entries; j.counts = t.srt->counts; j.order = t.srt->order;
+    j.buckets = (XYZZ<F> *)t.buckets; j.nb = nb; j.onto = t.onto;
+    jobs.first_block[jobs.n] = grid;
+    grid += (nb + ACC_THREADS - 1) / ACC_THREADS;
+    jobs.first_block[++jobs.n] = grid;
+  }
+  if (jobs.n) {
+    sp = prof_begin(pf, s, MsmCfg<F>::ACC_STAGE);
+    // two wavefronts per SIMD for both G1 and G2 (amdgpu_waves_per_eu pins the register budget): with three G1 wavefronts the
+    // other streams' kernels find no registers beside them, one loses the latency cover (HISTORY.md 7b)
+    msm_accum_kernel<F, MsmCfg<F>::ACC_W, MsmCfg<F>::ACC_PREFETCH><<<grid, ACC_THREADS, 0, s>>>(jobs);
     prof_end(pf, s, sp);
-    ZKR_HIP_CHECK(hipGetLastError());
-    return 0;
   }
-  const unsigned grid = (nb + ACC_THREADS - 1) / ACC_THREADS;
-  static const int acc_prio = getenv("ZKR_ACC_PRIO") ? atoi(getenv("ZKR_ACC_PRIO")) : 0;
-#define ZKR_ACC_LAUNCH(W) msm_accum_kernel<F, W, MsmCfg<F>::ACC_PREFETCH><<<grid, ACC_THREADS, 0, s>>>(pts, srt.offsets, srt.entries, nb, srt.counts, srt.order, (XYZZ<F> *)ws.buckets, acc_prio, onto)
-  switch (acc_w) {
-    case 1: ZKR_ACC_LAUNCH(1); break;
-    case 3: ZKR_ACC_LAUNCH(3); break;
-    case 4: ZKR_ACC_LAUNCH(4); break;
-    default: ZKR_ACC_LAUNCH(2); break;
-  }
-#undef ZKR_ACC_LAUNCH
-  prof_end(pf, s, sp);
   ZKR_HIP_CHECK(hipGetLastError());
   return 0;
+}
+template <class F>
+static int msm_accum_enqueue(Prof pf, hipStream_t s, const Affine<F> *pts, uint32_t n, int nbat, const MsmPlan &pl, const MsmWorkspace &srt, MsmWorkspace &ws, int onto = 0) {
+  const AccumTable<F> t{pts, n, &pl, &srt, ws.buckets, onto};
+  return msm_accum_enqueue<F>(pf, s, nbat, &t, 1);
 }
 
 // oversized buckets (digit +-1 of 0/1-heavy witnesses): needs only the sort, so it runs beside the table's accumulation
@@ -585,23 +592,24 @@ static int msm_big_finish_enqueue(Prof pf, hipStream_t s, uint32_t n, const MsmW
   return 0;
 }
 // bucket reduction -> the MSM result in ws.h_result: short launches of few, long-running wavefronts (raised wave
-// priority), meant to run beside the next table's accumulation
+// priority), meant to run beside the next table's accumulation.  nbat: proofs fused into the launches; sets: bucket sets per
+// proof that ONE launch set walks end to end (2: A's sets behind B1's, the joint chain) -- the group-size rules below key on the
+// fused proofs only.
 template <class F>
-static int msm_reduce_enqueue(Prof pf, hipStream_t s, uint32_t n, int nbat, const MsmPlan &pl, const MsmWorkspace &srt, MsmWorkspace &ws, bool latency = false) {
+static int msm_reduce_enqueue(Prof pf, hipStream_t s, uint32_t n, int nbat, int sets, const MsmPlan &pl, const MsmWorkspace &srt, MsmWorkspace &ws, bool latency = false) {
   if (n == 0) return 0;
   // Group size of a FUSED launch: the plan's groups keep about 2^14 of them per proof, which is what a single proof of a small
   // circuit needs to fill the chip (msm_plan); nbat proofs in one launch bring nbat times the groups, so they take larger ones --
   // about 2^15 groups per launch -- and reduce2 / reduce3 have that much less to sum: the tx circuit in batches of eight 1 063 /
   // 1 149 / 1 192 / 1 185 proofs/s at groups of 4 / 8 / 16 / 32 (tools/sweep_tx_fused_glog.sh).  The buffers are sized for the
-  // plan's (smaller) groups.  ZKR_MSM_GLOG_FUSED overrides.
+  // plan's (smaller) groups.
   int glog = pl.glog;
   uint32_t S = pl.S;
   // Latency mode: the LAST chain of a proof that has nothing in flight beside it (a synchronous caller's proof: the other slot is
   // idle) is pure latency -- 62 dependent additions per thread in reduce1 at groups of 32 buckets.  Groups of 8 make that 14,
   // for four times the group results in reduce2 (8 additions + the tree per thread instead of 2): 0.41 + 0.11 -> ~0.10 + 0.15 ms
   // at 2^19 buckets.  It costs 0.7 % more field multiplications, so chains that run under an accumulation keep the large groups.
-  static const bool lat_env = !(getenv("ZKR_RED_LATENCY") && atoi(getenv("ZKR_RED_LATENCY")) == 0);
-  if (latency && lat_env && nbat == 1 && glog > LAT_GLOG) {
+  if (latency && nbat == 1 && sets == 1 && glog > LAT_GLOG) {
     glog = LAT_GLOG;
     const uint32_t ng = pl.nbw >> glog, ntask = (uint32_t)(pl.c - 1 - glog) + 2;
     S = (ng + 2047) / 2048;
@@ -610,10 +618,9 @@ static int msm_reduce_enqueue(Prof pf, hipStream_t s, uint32_t n, int nbat, cons
     if (S < 1) S = 1;
   }
   if (nbat > 1) {
-    static const int fused_env = getenv("ZKR_MSM_GLOG_FUSED") ? atoi(getenv("ZKR_MSM_GLOG_FUSED")) : 0;
     int lg = 0;
     while (((uint64_t)1 << lg) < (uint64_t)pl.nbw * (uint64_t)nbat) lg++;
-    int want = fused_env >= 1 ? fused_env : lg - 15;
+    int want = lg - 15;
     if (want > 5) want = 5;
     if (want > pl.c - 1) want = pl.c - 1;
     if (want > glog) {
@@ -623,16 +630,17 @@ static int msm_reduce_enqueue(Prof pf, hipStream_t s, uint32_t n, int nbat, cons
       S = s2 < 1 ? 1 : s2 > pl.S ? pl.S : s2;
     }
   }
+  const int nset = nbat * sets;  // bucket sets of the launch, end to end
   MsmGeom g;
-  g.n = n; g.c = pl.c; g.K = pl.K; g.nbw = pl.nbw; g.big_thresh = pl.big_thresh; g.glog = glog; g.S = S; g.batch = (uint32_t)nbat;
+  g.n = n; g.c = pl.c; g.K = pl.K; g.nbw = pl.nbw; g.big_thresh = pl.big_thresh; g.glog = glog; g.S = S; g.batch = (uint32_t)nset;
   int sp = prof_begin(pf, s, "msm_reduce");
-  uint32_t ngroups = (pl.nbw >> glog) * (uint32_t)nbat;
+  uint32_t ngroups = (pl.nbw >> glog) * (uint32_t)nset;
   uint32_t ntask = (uint32_t)(pl.c - 1 - glog) + 2;
   msm_reduce1_kernel<F, MsmCfg<F>::RED_W><<<(ngroups + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, s>>>((const XYZZ<F> *)ws.buckets, g, (XYZZ<F> *)ws.group_out);
-  msm_reduce2_kernel<F, MsmCfg<F>::RED_W><<<dim3(ntask * S, nbat), MSM_THREADS, MSM_THREADS * sizeof(XYZZ<F>), s>>>((const XYZZ<F> *)ws.group_out, g, (XYZZ<F> *)ws.task_out);
-  msm_reduce3_kernel<F, MsmCfg<F>::RED_W><<<nbat, MSM_THREADS, MSM_THREADS * sizeof(XYZZ<F>), s>>>((const XYZZ<F> *)ws.task_out, g, (XYZZ<F> *)ws.result);
+  msm_reduce2_kernel<F, MsmCfg<F>::RED_W><<<dim3(ntask * S, nset), MSM_THREADS, MSM_THREADS * sizeof(XYZZ<F>), s>>>((const XYZZ<F> *)ws.group_out, g, (XYZZ<F> *)ws.task_out);
+  msm_reduce3_kernel<F, MsmCfg<F>::RED_W><<<nset, MSM_THREADS, MSM_THREADS * sizeof(XYZZ<F>), s>>>((const XYZZ<F> *)ws.task_out, g, (XYZZ<F> *)ws.result);
   prof_end(pf, s, sp);
-  ZKR_HIP_CHECK(hipMemcpyAsync(ws.h_result, ws.result, sizeof(XYZZ<F>) * nbat, hipMemcpyDeviceToHost, s));
+  ZKR_HIP_CHECK(hipMemcpyAsync(ws.h_result, ws.result, sizeof(XYZZ<F>) * nset, hipMemcpyDeviceToHost, s));
   ZKR_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -648,7 +656,7 @@ static int msm_enqueue(Prof pf, hipStream_t s, const Affine<F> *pts, const uint3
   if ((rc = msm_big_enqueue<F>(pf, s, pts, n, pl, ws, ws))) return rc;
   if ((rc = msm_accum_enqueue<F>(pf, s, pts, n, 1, pl, ws, ws))) return rc;
   if ((rc = msm_big_finish_enqueue<F>(pf, s, n, ws, ws))) return rc;
-  return msm_reduce_enqueue<F>(pf, s, n, 1, pl, ws, ws);
+  return msm_reduce_enqueue<F>(pf, s, n, 1, 1, pl, ws, ws);
 }
 
 // the MSM result point as the reduction left it in the pinned host buffer
@@ -746,14 +754,9 @@ static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *const *d_ws
   static const bool serial = getenv("ZKR_SERIAL") != nullptr;  // profiling aid: one stream, isolated kernel durations
   hipStream_t s = k->stream;
   hipStream_t sp = serial ? s : k->prep_stream;
-  int g1_next = 0;
-  static const int h_aux_env = getenv("ZKR_H_CHAIN_AUX") ? atoi(getenv("ZKR_H_CHAIN_AUX")) : 0;
-  const bool h_chain_aux = h_aux_env != 0 && !serial;
-  auto red_of = [&](int t) -> hipStream_t {  // G2 chain on [0]; G1 chains round-robin over the others
+  auto red_of = [&](int t) -> hipStream_t {  // G2 chain on [0], the G1 chains one after the other on [1] (zkr_key.hip key_alloc_workspace)
     if (serial) return s;
-    if (t == T_H && h_chain_aux) return k->aux_stream;  // the proof's last chain does not queue behind the earlier G1 chains
-    if (t == T_B2 || k->n_red == 1) return k->red_stream[0];
-    return k->red_stream[1 + (g1_next++ % (k->n_red - 1))];
+    return k->red_stream[t == T_B2 ? 0 : 1];
   };
   int rc;
   if (readies) {
@@ -773,9 +776,8 @@ static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *const *d_ws
   int sort_src[N_TABLES] = {T_A, T_B1, share_b ? T_B1 : T_B2, share_ac ? T_A : T_C, T_H};
   // A shard key's proof is as long as its replicated calcH plus what follows it (digits and sort of h, H's accumulation, the
   // last chain): the digit records and sorts of w -- an eighth of a whole key's, but in FRONT of calcH on the preparation stream --
-  // go to the auxiliary stream instead and run beside it (ZKR_SHARD_PAR_SORTS=0: one preparation stream, as for whole keys).
-  static const bool par_sorts_env = !(getenv("ZKR_SHARD_PAR_SORTS") && atoi(getenv("ZKR_SHARD_PAR_SORTS")) == 0);
-  const bool par_sorts = par_sorts_env && h.shard_parts > 1 && !serial;
+  // go to the auxiliary stream instead and run beside it.
+  const bool par_sorts = h.shard_parts > 1 && !serial;
   hipStream_t sw = par_sorts ? k->aux_stream : sp;  // where w's digit records and the sorts of A, B1, B2, C are made
   if (par_sorts) {
     ZKR_HIP_CHECK(hipEventRecord(sl.ev_w, sp));  // the ingested witness (and the cleared counters of its digit records)
@@ -793,18 +795,16 @@ static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *const *d_ws
   // C's bucket set and one reduction chain serves both -- a bucket reduction (2 x 2^19 full additions, ~1.6 % of a proof's
   // instructions) and one latency chain less.  Oversized buckets of either table are ADDED to the shared set after H's
   // accumulation (C's accumulation clears their slots), so no accumulation waits for a reduction stream.
-  static const bool no_merge = getenv("ZKR_NO_MERGE_CH") != nullptr;
   const MsmPlan &pc = k->plan[T_C], &ph = k->plan[T_H];
-  const bool merge_ch = !no_merge && h.npts[T_C] && h.npts[T_H] && pc.c == ph.c && pc.nbw == ph.nbw && pc.glog == ph.glog && pc.S == ph.S;
+  const bool merge_ch = h.npts[T_C] && h.npts[T_H] && pc.c == ph.c && pc.nbw == ph.nbw && pc.glog == ph.glog && pc.S == ph.S;
   sl.merged_ch = merge_ch;
   // A and B1 in ONE reduction chain (round 5): the G1 chains share one stream, and in a single proof of a small circuit that stream
   // is the critical path from B1's accumulation to the end (three chains of ~0.4 ms back to back: H's chain starts 0.19 ms after H's
   // accumulation has ended, profiles/r4_05_timeline_one_tx_proof.txt).  A is accumulated into the bucket sets BEHIND B1's (B1's
   // workspace holds two sets per proof when the two tables' geometry agrees) and one launch set reduces both: a chain of latency-bound
-  // launches less per proof.  ZKR_NO_JOINT_AB=1: a chain per table.
-  static const bool no_joint = getenv("ZKR_NO_JOINT_AB") != nullptr;
-  const bool joint_ab = !no_joint && !serial && k->n_red == 2 && h.npts[T_A] && h.npts[T_B1] && same_reduce_geometry(k->plan[T_A], k->plan[T_B1]) && sl.ws[T_B1].sets == 2;
-  sl.joint_ab = false;  // set below, once the schedule is known (not with accumulations on their chains' streams)
+  // launches less per proof.
+  const bool joint_ab = !serial && h.npts[T_A] && h.npts[T_B1] && same_reduce_geometry(k->plan[T_A], k->plan[T_B1]) && sl.ws[T_B1].sets == 2;
+  sl.joint_ab = joint_ab;
   for (int t = 0; t < N_TABLES; t++) sl.res_pending[t] = false;
   auto result_event = [&](int t, hipStream_t rs, int rc) -> int {  // after a table's reduction chain (its D2H copy is the last thing enqueued)
     if (rc) return rc;
@@ -812,86 +812,92 @@ static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *const *d_ws
     sl.res_pending[t] = true;
     return 0;
   };
-  // Schedule knobs (ZKR_SCHED, bits): 1 = hand each table's chain to its streams right after its sort is enqueued instead of
-  // after the whole preparation chain; 2 = the table's accumulation runs on its chain's stream instead of the one accumulation
-  // stream (tables then accumulate concurrently).  Defaults per key size below.
-  static const int sched_env = getenv("ZKR_SCHED") ? atoi(getenv("ZKR_SCHED")) : -1;
-  const int sched = sched_env >= 0 ? sched_env : 0;
   // part of a sharded proof whose calcH is split over the shards (calc_h_split: host barriers in the middle of this enqueue): the
-  // chains of the four w tables are handed over BEFORE it, so that they run while the threads wait for one another
+  // chains of the four w tables are handed over BEFORE it, so that they run while the threads wait for one another.  Everywhere
+  // else the accumulations are handed over after the whole preparation chain: started early they fill the chip's wavefront slots
+  // and the preparation stream -- whose end, the sort of H, the last accumulation waits for -- waits for its dispatches
+  // (HISTORY.md 7b / 13: a tx proof 2.13-2.40 against 1.98 ms, 2^20 the same).
   ShardGroup *const group = shard_group;
   const bool split_h = group && group->split_h && !serial && nbat == 1 && h.shard_parts == group->parts && h.shard_part == shard_group_part;
-  const bool early = ((sched & 1) != 0 || split_h) && !serial, acc_on_chain = (sched & 2) != 0 && !serial;
-  static const int c_big_env = getenv("ZKR_C_BIG_FIRST") ? atoi(getenv("ZKR_C_BIG_FIRST")) : -1;  // 0 / 1: never / always (A/B)
-  const bool c_big_first = merge_ch && !serial && (c_big_env >= 0 ? c_big_env != 0 : (nbat == 1 && sl.cap > 1));
+  const bool early = split_h;
+  // C's oversized-bucket sums on the auxiliary stream for ONE proof of a key that can fuse batches (the latency case; c_big below)
+  const bool c_big_first = merge_ch && !serial && nbat == 1 && sl.cap > 1;
   // nothing else of this key in flight (the caller holds the key's lock: with_free_slot): this proof's last chain is latency
   bool alone = !serial;
   for (const ProofSlot &o : k->slot)
     if (&o != &sl && o.busy) alone = false;
-  // Deferred accumulations (ZKR_DEFER_ACC=1, experiment; off): the accumulation stream waits for calcH, then runs the five tables back
-  // to back.  Measured WORSE everywhere -- a 2^22 shard 11.9 against 9.8 ms, a synchronous 2^20 proof 7.55 against 7.35 ms, a tx proof
-  // 2.25 against 2.0 ms (profiles/r4_24_deferred_accumulations.txt): the passes of calcH do not fill the chip on their own, and what
-  // looked like mutual slow-down in the shard's timeline was one G2 accumulation waiting for a few 250-entry buckets (big_threshold).
-  static const int defer_env = getenv("ZKR_DEFER_ACC") ? atoi(getenv("ZKR_DEFER_ACC")) : 0;
-  const bool defer_acc = !serial && !early && defer_env == 1 && nbat == 1 && (h.shard_parts > 1 || alone);
-  bool acc_waits_calch = defer_acc;  // the first accumulation enqueued carries the wait (the stream is in order)
-  sl.joint_ab = joint_ab && !acc_on_chain;  // (the accumulations all run on the one accumulation stream, B1's before A's, whenever they are handed over)
-  auto accum_table = [&](int t, hipStream_t rs) -> int {
-    const MsmWorkspace &srt = sl.ws[sort_src[t]];
-    MsmWorkspace dst = t == T_H && merge_ch ? sl.ws[T_C] : sl.ws[t];  // whose bucket set / reduction buffers the table lands in (a copy: pointers)
-    if (sl.joint_ab && t == T_A) {  // behind B1's bucket sets; its oversized-bucket partial sums stay its own
-      dst.buckets = (char *)sl.ws[T_B1].buckets + (size_t)nbat * k->plan[T_B1].nb * sizeof(G1XYZZ);
-    }
-    const bool onto = t == T_H && merge_ch;
-    const void *pts = ar + h.off_pts[t];
-    hipStream_t sa = acc_on_chain ? rs : s;
+  hipStream_t last = s;
+  // One accumulation launch for the tables of `ts` (one G2 table, or up to three G1 tables: kernels_msm.hpp msm_accum_kernel) and
+  // the chain of each: (1) the chain's stream waits for the table's sort and takes its oversized buckets (they need only the
+  // sort and run beside the accumulation), (2) the launch on the accumulation stream, (3) oversized-bucket sums into the buckets
+  // and the bucket reduction, on the chain's stream again.
+  auto accum_group = [&](std::initializer_list<int> ts) -> int {
     int rc;
-    if (!serial) {
-      ZKR_HIP_CHECK(hipStreamWaitEvent(rs, sl.ev_sorted[sort_src[t]], 0));
-      if (sa != rs) ZKR_HIP_CHECK(hipStreamWaitEvent(sa, sl.ev_sorted[sort_src[t]], 0));
-      if (acc_waits_calch) { ZKR_HIP_CHECK(hipStreamWaitEvent(sa, sl.ev_calch, 0)); acc_waits_calch = false; }
-    }
-    // oversized buckets: partial sums into the table's OWN partials buffer (needs only the sort, runs beside the accumulation).
-    // C's, when C shares H's bucket set, were enqueued in front of every chain (c_big_first below)
-    if (!(t == T_C && c_big_first)) {
+    const int t0 = *ts.begin();
+    for (int t : ts) {
+      hipStream_t rs = red_of(t);
+      last = rs;
+      const MsmWorkspace &srt = sl.ws[sort_src[t]];
+      const void *pts = ar + h.off_pts[t];
+      if (!serial) ZKR_HIP_CHECK(hipStreamWaitEvent(rs, sl.ev_sorted[sort_src[t]], 0));
+      // partial sums into the table's OWN partials buffer.  C's, when C shares H's bucket set, may have been enqueued in front of
+      // every chain (c_big_first)
+      if (t == T_C && c_big_first) continue;
       if (t == T_B2) rc = msm_big_enqueue<Fq2>(pf, rs, (const G2Affine *)pts, h.npts[t], k->plan[t], srt, sl.ws[t]);
       else rc = msm_big_enqueue<Fq>(pf, rs, (const G1Affine *)pts, h.npts[t], k->plan[t], srt, sl.ws[t]);
       if (rc) return rc;
       if (t == T_C && merge_ch && !serial) ZKR_HIP_CHECK(hipEventRecord(sl.ev_h, rs));  // C's partial sums are on their way: H's chain adds them in
     }
-    if (onto && acc_on_chain && !serial) ZKR_HIP_CHECK(hipStreamWaitEvent(sa, sl.ev_done[T_C], 0));  // C's accumulation ran on another stream
-    // shared bucket set: C's accumulation clears the slots of ITS oversized buckets (their sums are added after H's
-    // accumulation, so H's accumulation waits for nothing but C's accumulation in front of it on the same stream)
-    const int flags = onto ? ACC_ONTO : (t == T_C && merge_ch ? ACC_ZERO_BIG : 0);
-    if (t == T_B2) rc = msm_accum_enqueue<Fq2>(pf, sa, (const G2Affine *)pts, h.npts[t], nbat, k->plan[t], srt, dst);
-    else rc = msm_accum_enqueue<Fq>(pf, sa, (const G1Affine *)pts, h.npts[t], nbat, k->plan[t], srt, dst, flags);
-    if (rc) return rc;
-    if (!serial) ZKR_HIP_CHECK(hipEventRecord(sl.ev_done[t], sa));
-    if (t == T_C && merge_ch) return 0;
-    if (!serial && sa != rs) ZKR_HIP_CHECK(hipStreamWaitEvent(rs, sl.ev_done[t], 0));
-    if (t == T_B2) {
-      if ((rc = msm_big_finish_enqueue<Fq2>(pf, rs, h.npts[t], srt, sl.ws[t]))) return rc;
-      return result_event(t, rs, msm_reduce_enqueue<Fq2>(pf, rs, h.npts[t], nbat, k->plan[t], srt, sl.ws[t]));
+    if (!serial)
+      for (int t : ts) ZKR_HIP_CHECK(hipStreamWaitEvent(s, sl.ev_sorted[sort_src[t]], 0));
+    if (t0 == T_B2) {
+      if ((rc = msm_accum_enqueue<Fq2>(pf, s, (const G2Affine *)(ar + h.off_pts[T_B2]), h.npts[T_B2], nbat, k->plan[T_B2], sl.ws[sort_src[T_B2]], sl.ws[T_B2]))) return rc;
+    } else {
+      AccumTable<Fq> tabs[ACC_MAX_JOBS];
+      int nt = 0;
+      for (int t : ts) {
+        if (nt == ACC_MAX_JOBS) { set_error("accumulation group of more than %d tables", ACC_MAX_JOBS); return ZKR_ERR_ARG; }
+        // whose bucket set the table lands in: H onto C's (merge_ch), A behind B1's sets (joint chain); its oversized-bucket sums stay its own.
+        // Shared set: C's accumulation clears the slots of ITS oversized buckets (their sums are added after H's accumulation, so
+        // H's accumulation waits for nothing but C's, in front of it on the same stream)
+        void *buckets = t == T_H && merge_ch ? sl.ws[T_C].buckets : sl.ws[t].buckets;
+        if (joint_ab && t == T_A) buckets = (char *)sl.ws[T_B1].buckets + (size_t)nbat * k->plan[T_B1].nb * sizeof(G1XYZZ);
+        const int flags = t == T_H && merge_ch ? ACC_ONTO : (t == T_C && merge_ch ? ACC_ZERO_BIG : 0);
+        tabs[nt++] = AccumTable<Fq>{(const G1Affine *)(ar + h.off_pts[t]), h.npts[t], &k->plan[t], &sl.ws[sort_src[t]], buckets, flags};
+      }
+      if ((rc = msm_accum_enqueue<Fq>(pf, s, nbat, tabs, nt))) return rc;
     }
-    if (onto) {  // both tables' oversized buckets are ADDED to what the shared set holds: C's partial sums (its own sort's list), then H's
-      if (!serial) ZKR_HIP_CHECK(hipStreamWaitEvent(rs, sl.ev_h, 0));
-      MsmWorkspace mixc = dst;  // C's workspace: its partials, its buckets
-      if ((rc = msm_big_finish_enqueue<Fq>(pf, rs, h.npts[T_C], sl.ws[sort_src[T_C]], mixc, true))) return rc;
-      MsmWorkspace mix = dst;
-      mix.big_partials = sl.ws[t].big_partials;
-      if ((rc = msm_big_finish_enqueue<Fq>(pf, rs, h.npts[t], srt, mix, true))) return rc;
-      return result_event(t, rs, msm_reduce_enqueue<Fq>(pf, rs, h.npts[t], nbat, k->plan[t], srt, dst, alone));
+    if (!serial) ZKR_HIP_CHECK(hipEventRecord(sl.ev_done[t0], s));
+    for (int t : ts) {
+      hipStream_t rs = red_of(t);
+      const MsmWorkspace &srt = sl.ws[sort_src[t]];
+      if (t == T_C && merge_ch) continue;             // reduced with H
+      if (joint_ab && t == T_B1) continue;            // reduced with A, by A's turn on this stream (B1's oversized-bucket sums are on their way on it)
+      if (!serial) ZKR_HIP_CHECK(hipStreamWaitEvent(rs, sl.ev_done[t0], 0));
+      if (t == T_B2) {
+        if ((rc = msm_big_finish_enqueue<Fq2>(pf, rs, h.npts[t], srt, sl.ws[t]))) return rc;
+        if ((rc = result_event(t, rs, msm_reduce_enqueue<Fq2>(pf, rs, h.npts[t], nbat, 1, k->plan[t], srt, sl.ws[t])))) return rc;
+      } else if (t == T_H && merge_ch) {  // both tables' oversized buckets are ADDED to what the shared set holds: C's partial sums (its own sort's list), then H's
+        if (!serial) ZKR_HIP_CHECK(hipStreamWaitEvent(rs, sl.ev_h, 0));
+        MsmWorkspace mixc = sl.ws[T_C];   // C's workspace: its partials, its buckets
+        if ((rc = msm_big_finish_enqueue<Fq>(pf, rs, h.npts[T_C], sl.ws[sort_src[T_C]], mixc, true))) return rc;
+        MsmWorkspace mix = sl.ws[T_C];
+        mix.big_partials = sl.ws[t].big_partials;
+        if ((rc = msm_big_finish_enqueue<Fq>(pf, rs, h.npts[t], srt, mix, true))) return rc;
+        if ((rc = result_event(t, rs, msm_reduce_enqueue<Fq>(pf, rs, h.npts[t], nbat, 1, k->plan[t], srt, mixc, alone)))) return rc;
+      } else if (joint_ab && t == T_A) {
+        // the stream is in order: B1's partial sums (enqueued at B1's turn) are done; both accumulations have run (B1's in this launch or an earlier one)
+        MsmWorkspace dst = sl.ws[t];
+        dst.buckets = (char *)sl.ws[T_B1].buckets + (size_t)nbat * k->plan[T_B1].nb * sizeof(G1XYZZ);
+        if ((rc = msm_big_finish_enqueue<Fq>(pf, rs, h.npts[T_B1], sl.ws[sort_src[T_B1]], sl.ws[T_B1]))) return rc;
+        if ((rc = msm_big_finish_enqueue<Fq>(pf, rs, h.npts[T_A], srt, dst))) return rc;
+        if ((rc = result_event(T_A, rs, msm_reduce_enqueue<Fq>(pf, rs, h.npts[T_B1], nbat, 2, k->plan[T_B1], sl.ws[sort_src[T_B1]], sl.ws[T_B1])))) return rc;
+      } else {
+        if ((rc = msm_big_finish_enqueue<Fq>(pf, rs, h.npts[t], srt, sl.ws[t]))) return rc;
+        if ((rc = result_event(t, rs, msm_reduce_enqueue<Fq>(pf, rs, h.npts[t], nbat, 1, k->plan[t], srt, sl.ws[t], alone && t == T_H)))) return rc;
+      }
     }
-    if (sl.joint_ab && t == T_B1) return 0;  // reduced with A's buckets, by A's turn on this stream (B1's oversized-bucket sums are on their way on it)
-    if (sl.joint_ab && t == T_A) {
-      // the stream is in order: B1's partial sums (enqueued at B1's turn) are done; both accumulations ran on the one accumulation
-      // stream, A's last (ev_done[T_A] is waited for above)
-      if ((rc = msm_big_finish_enqueue<Fq>(pf, rs, h.npts[T_B1], sl.ws[sort_src[T_B1]], sl.ws[T_B1]))) return rc;
-      if ((rc = msm_big_finish_enqueue<Fq>(pf, rs, h.npts[T_A], srt, dst))) return rc;
-      return result_event(T_A, rs, msm_reduce_enqueue<Fq>(pf, rs, h.npts[T_B1], 2 * nbat, k->plan[T_B1], sl.ws[sort_src[T_B1]], sl.ws[T_B1]));
-    }
-    if ((rc = msm_big_finish_enqueue<Fq>(pf, rs, h.npts[t], srt, sl.ws[t]))) return rc;
-    return result_event(t, rs, msm_reduce_enqueue<Fq>(pf, rs, h.npts[t], nbat, k->plan[t], srt, sl.ws[t], alone && t == T_H));
+    return 0;
   };
   // C shares H's bucket set and has no chain of its own: its oversized-bucket partial sums (needed by H's chain, which adds them
   // to the shared set) normally take C's turn on a G1 chain's stream.  There they wait for the chains in front of them: in a
@@ -909,34 +915,23 @@ static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *const *d_ws
     ZKR_HIP_CHECK(hipEventRecord(sl.ev_h, bs));
     return 0;
   };
-  hipStream_t last = s;
-  auto chains = [&](std::initializer_list<int> ts) -> int {
-    for (int t : ts) {
-      last = red_of(t);
-      int rc = accum_table(t, last);
-      if (rc) return rc;
-    }
-    return 0;
-  };
   // preparation chain
   // a shard key (zkr_key_shard) multiplies only its sub-range of each scalar vector; a whole key: sc_lo = 0, sc_n = n / m
   if ((rc = msm_digits_enqueue(pf, sw, sl.d_w + h.sc_lo[0], h.sc_n[0], nbat, k->plan[T_A], sl.dig_w, true))) return rc;
   if ((rc = sort_table(T_B1))) return rc;
   if (!share_b && (rc = sort_table(T_B2))) return rc;
-  if (early && (rc = chains({T_B2, T_B1}))) return rc;
+  if (early && ((rc = accum_group({T_B2})) || (rc = accum_group({T_B1})))) return rc;
   if ((rc = sort_table(T_A))) return rc;
   if (!share_ac && (rc = sort_table(T_C))) return rc;
-  if (early && ((rc = c_big()) || (rc = chains({T_A, T_C})))) return rc;
+  if (early && ((rc = c_big()) || (rc = accum_group({T_A, T_C})))) return rc;
   if (split_h) rc = calc_h_split(k, sl, sp, *group, shard_group_part, enqueue_lock);
   else rc = calc_h_device(k, sl, sp, nbat);
   if (rc) return rc;
-  if (!serial) ZKR_HIP_CHECK(hipEventRecord(sl.ev_calch, sp));
   if ((rc = msm_digits_enqueue(pf, sp, sl.d_h + h.sc_lo[1], h.sc_n[1], nbat, k->plan[T_H], sl.dig_h, true))) return rc;
   if ((rc = sort_table(T_H))) return rc;
-  // accumulations + reduction chains
-  if (early) rc = chains({T_H});
-  else { if ((rc = c_big())) return rc; rc = chains({T_B2, T_B1, T_A, T_C, T_H}); }
-  if (rc) return rc;
+  // accumulations + reduction chains: B2 first (its chain is the longest), then the three G1 tables of the witness in ONE launch, then H
+  if (!early && ((rc = c_big()) || (rc = accum_group({T_B2})) || (rc = accum_group({T_B1, T_A, T_C})))) return rc;
+  if ((rc = accum_group({T_H}))) return rc;
   // completion = every reduction stream done (prove_collect waits for the events on the host).  No stream is made
   // to wait for another, so nothing of the next proof queues behind this one's tail.
   prof_end(pf, last, tot);
