@@ -909,6 +909,12 @@ def shard_leg(key, d_wit, parts, want_proof, local):
             "note": "PROJECTED: shards measured one at a time on one GPU; every shard computes its part of h itself (the first four of calcH's six transforms in full, the last two on its range), so the exchange is 640 B per shard"}
 
 
+def shards_share_a_gpu(devices, bus_ids):
+    """True unless every shard sat on a PHYSICAL GPU of its own: distinct device ordinals AND distinct PCI bus ids
+    (zkr_device_pci_bus_id) -- only then is a sharded timing a measurement (`sharded_measured`), otherwise it is a rehearsal."""
+    return len(set(devices)) < len(devices) or len(set(bus_ids)) < len(bus_ids) or any(not b for b in bus_ids)
+
+
 def sharded_multi_leg(key, wit_bytes, devices, r=1000003, s_=2000003, reps=5):
     """ONE proof over SEVERAL devices, MEASURED: shard i of the key on devices[i], the
     full witness resident on each, zkr_prove_sharded_device timed as a caller sees it -- host threads, barriers, the cross passes
@@ -919,7 +925,8 @@ def sharded_multi_leg(key, wit_bytes, devices, r=1000003, s_=2000003, reps=5):
     import torch
     import zkr_hip
     parts = len(devices)
-    rehearsal = len(set(devices)) < parts
+    bus_ids = [zkr_hip.device_pci_bus_id(d).lower() for d in devices]
+    rehearsal = shards_share_a_gpu(devices, bus_ids)
     dev0 = key.device
     d0 = torch.frombuffer(bytearray(wit_bytes), dtype=torch.uint8).to(torch.device("cuda", dev0))
     torch.cuda.synchronize(dev0)
@@ -931,7 +938,7 @@ def sharded_multi_leg(key, wit_bytes, devices, r=1000003, s_=2000003, reps=5):
     t1 = time.perf_counter()
     shards = [key.shard(i, parts, device=d) for i, d in enumerate(devices)]
     build_s = time.perf_counter() - t1
-    out = {"parts": parts, "devices": list(devices), "measured": True, "rehearsal_on_one_gpu": rehearsal, "whole_key_sync_proof_ms": whole_ms, "shard_build_s": build_s,
+    out = {"parts": parts, "devices": list(devices), "device_pci_bus_ids": bus_ids, "measured": True, "rehearsal_on_one_gpu": rehearsal, "whole_key_sync_proof_ms": whole_ms, "shard_build_s": build_s,
            "shard_arena_bytes": [sh.arena()[1] for sh in shards]}
     try:
         dws = [torch.frombuffer(bytearray(wit_bytes), dtype=torch.uint8).to(torch.device("cuda", d)) for d in devices]

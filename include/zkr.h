@@ -335,10 +335,6 @@ const char *zkr_rollup_statement_text(uint32_t stmt);
  * give the same limbs bit for bit: tests/test_gpu_stages.py. */
 int zkr_selftest_f29_forms(int device, int field, int form, const uint32_t *records, size_t n, uint32_t *out);
 int zkr_bench_fq_mul(int device, double *gmuls_per_s);
-/* Batched-affine G2 addition (thread per bucket, 256 lanes share one Fq2 inversion through an LDS product scan) against the
- * hot path's XYZZ mixed addition: kernel time in ns of one round (one addition on each of 262 144 lanes) for either form, and
- * whether both end in the same points.  The silicon measurement behind DESIGN.md's "measured and rejected" row. */
-int zkr_bench_g2_affine(int device, double *ns_per_round_affine, double *ns_per_round_mixed, int *equal);
 int zkr_bench_fq_mul_legacy(int device, double *gmuls_per_s);
 
 #ifdef __cplusplus

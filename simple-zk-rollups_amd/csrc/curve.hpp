@@ -10,12 +10,6 @@
 #pragma once
 #include "field.hpp"
 
-// wave priority (s_setprio) of the digit / sort / QAP kernels of the preparation chain (0..3; the NTT passes take theirs as an argument)
-#ifndef ZKR_PREP_PRIO
-#define ZKR_PREP_PRIO 0
-#endif
-#define ZKR_PREP_SETPRIO() do { if (ZKR_PREP_PRIO) __builtin_amdgcn_s_setprio(ZKR_PREP_PRIO); } while (0)
-
 namespace zkr {
 
 template <class F>

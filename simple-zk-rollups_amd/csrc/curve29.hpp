@@ -109,6 +109,15 @@ ZKR_HD XYZZ29<C> dbl_xyzz29(const XYZZ29<C> &p) {
   return make_xyzz<C>(x3, y3, mul(v, p.zz), mul(w, p.zzz));
 }
 
+// The products of the group law in the order they are WRITTEN (a scheduling barrier after each): every product consumes operands the
+// next ones no longer need, so at most eight coordinates are alive at any point.  Left to itself the compiler interleaves the
+// independent products (each is one opaque asm statement: nothing to gain) and needs 30-150 VGPRs more -- registers that decide
+// which kernels can share a SIMD with the accumulations (kernels_msm.hpp, "built to FIT").
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ZKR_PIN_ORDER() __builtin_amdgcn_sched_barrier(0)  // the products below in THIS order: each consumes operands the next no longer needs
+#else
+#define ZKR_PIN_ORDER() ((void)0)
+#endif
 // acc + q (q affine, not infinity: callers filter); neg_q adds -q.  The sign goes into the product Y2 ZZZ1 as a factor
 // without its carry sweep (field29.hpp U29), as do Q - X3 and -Y1 in the Y coordinate: three sweeps and a select less per
 // addition; the negated y itself is only formed on the rare paths that store it.
@@ -120,7 +129,9 @@ ZKR_HD XYZZ29<C> add_mixed29(const XYZZ29<C> &acc, const Affine29<C> &q, bool ne
     return make_xyzz<C>(q.x, qy, C::one(), C::one());
   }
   auto u2 = mul(q.x, acc.zz);
+  ZKR_PIN_ORDER();
   auto s2 = mul_cneg(q.y, neg_q, acc.zzz);
+  ZKR_PIN_ORDER();
   auto p = sub(u2, acc.x);
   auto r = sub(s2, acc.y);
   auto pp = sqr(p);
@@ -132,36 +143,65 @@ ZKR_HD XYZZ29<C> add_mixed29(const XYZZ29<C> &acc, const Affine29<C> &q, bool ne
     }
     return XYZZ29<C>::inf();
   }
+  ZKR_PIN_ORDER();
   auto ppp = mul(p, pp);
+  ZKR_PIN_ORDER();
   auto qq = mul(acc.x, pp);
-  auto x3 = sub_sub_dbl(sqr(r), ppp, qq);  // R^2 - P^3 - 2 Q, one carry sweep
+  ZKR_PIN_ORDER();
   auto zz3 = mul(acc.zz, pp);
+  ZKR_PIN_ORDER();
   auto zzz3 = mul(acc.zzz, ppp);
+  ZKR_PIN_ORDER();
+  auto x3 = sub_sub_dbl(sqr(r), ppp, qq);  // R^2 - P^3 - 2 Q, one carry sweep
   auto y3 = mul_sub(r, sub_factor(qq, x3), acc.y, ppp);
   return make_xyzz<C>(x3, y3, zz3, zzz3);
 }
 
-// a + b, both XYZZ
-template <class C>
-ZKR_HD XYZZ29<C> add_full29(const XYZZ29<C> &a, const XYZZ29<C> &b) {
+// a + b, both XYZZ.  `again()` yields b once more (from the memory it came from): the one case that needs a whole operand after
+// the first products -- a == b, the doubling -- fetches it again instead of keeping its X and Y in registers through every
+// addition, and the products of the ZZ / ZZZ pairs are formed first so that the four inputs die early.  In the kernels whose
+// register count decides where they can run (the bucket reductions beside the accumulations, kernels_msm.hpp) that is 30-60 VGPRs.
+template <class C, class Again>
+ZKR_HD XYZZ29<C> add_full29(const XYZZ29<C> &a, const XYZZ29<C> &b, Again again) {
   if (a.is_inf()) return b;
   if (b.is_inf()) return a;
+  // at most eight coordinates alive at any point (the compiler's own order interleaves the independent products and needs
+  // 30-60 registers more)
   auto u1 = mul(a.x, b.zz);
+  ZKR_PIN_ORDER();
   auto u2 = mul(b.x, a.zz);
+  ZKR_PIN_ORDER();
   auto s1 = mul(a.y, b.zzz);
+  ZKR_PIN_ORDER();
   auto s2 = mul(b.y, a.zzz);
+  ZKR_PIN_ORDER();
+  auto zzp = mul(a.zz, b.zz);
+  ZKR_PIN_ORDER();
+  auto zzzp = mul(a.zzz, b.zzz);
+  ZKR_PIN_ORDER();
   auto p = sub(u2, u1);
   auto r = sub(s2, s1);
   auto pp = sqr(p);
   if (maybe_zero_mod_p(pp) && is_zero_mod_p(pp)) {
-    if (is_zero_mod_p(sqr(r))) return dbl_xyzz29(a);
+    if (is_zero_mod_p(sqr(r))) return dbl_xyzz29(again());
     return XYZZ29<C>::inf();
   }
+  ZKR_PIN_ORDER();
   auto ppp = mul(p, pp);
+  ZKR_PIN_ORDER();
   auto qq = mul(u1, pp);
+  ZKR_PIN_ORDER();
+  auto zz3 = mul(zzp, pp);
+  ZKR_PIN_ORDER();
+  auto zzz3 = mul(zzzp, ppp);
+  ZKR_PIN_ORDER();
   auto x3 = sub_sub_dbl(sqr(r), ppp, qq);
   auto y3 = mul_sub(r, sub_factor(qq, x3), s1, ppp);
-  return make_xyzz<C>(x3, y3, mul(mul(a.zz, b.zz), pp), mul(mul(a.zzz, b.zzz), ppp));
+  return make_xyzz<C>(x3, y3, zz3, zzz3);
+}
+template <class C>
+ZKR_HD XYZZ29<C> add_full29(const XYZZ29<C> &a, const XYZZ29<C> &b) {
+  return add_full29<C>(a, b, [&]() { return b; });
 }
 
 // ---- Jacobian doubling chain of the window-table build (key load; kernels_msm.hpp msm_precompute_kernel).  (X, Y, Z) with

@@ -337,18 +337,22 @@ ZKR_HD Fp<PM> from_mont(const Fp<PM> &a) {
 
 // a^(p-2): used only off the hot path (affine conversion in the setup kernels)
 template <class PM>
-ZKR_HD_COLD Fp<PM> inv(const Fp<PM> &a) {
+ZKR_HD Fp<PM> inv_inline(const Fp<PM> &a) {
   Fp<PM> r = Fp<PM>::one(), b = a;
-  uint32_t e[8];
-#pragma unroll
-  for (int i = 0; i < 8; i++) e[i] = PM::P[i];
-  e[0] -= 2;  // low limb of both moduli is > 2
-  for (int i = 0; i < 254; i++) {
-    if ((e[i >> 5] >> (i & 31)) & 1) r = mul(r, b);
-    b = sqr(b);
+  // the exponent's words come from the modulus table as they are needed: a local copy indexed by the loop counter would live in
+  // scratch memory on the device (the 144 / 48 B per lane fixed_base_kernel had)
+  for (int w = 0; w < 8; w++) {
+    uint32_t e = PM::P[w] - (w == 0 ? 2u : 0u);  // low limb of both moduli is > 2
+    const int bits = w == 7 ? 254 - 224 : 32;
+    for (int i = 0; i < bits; i++) {
+      if ((e >> i) & 1) r = mul(r, b);
+      b = sqr(b);
+    }
   }
   return r;
 }
+template <class PM>
+ZKR_HD_COLD Fp<PM> inv(const Fp<PM> &a) { return inv_inline(a); }  // out of line: the host and the cold device paths
 
 #include "field_fused.hpp"  // mul_sum2 / mul_sum4 (generated by tools/gen_mul_sum.py)
 

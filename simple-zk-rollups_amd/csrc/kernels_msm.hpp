@@ -30,9 +30,7 @@
 
 namespace zkr {
 
-#ifndef ZKR_RED_PRIO
-#define ZKR_RED_PRIO 3  // wave priority of the oversized-bucket and reduction kernels (0..3)
-#endif
+#define ZKR_RED_PRIO 3  // wave priority of the oversized-bucket and reduction kernels (s_setprio takes a literal)
 constexpr int MSM_THREADS = 256;
 constexpr uint32_t BIG_CAP = 1024;  // oversized buckets tracked per MSM
 
@@ -57,6 +55,16 @@ __device__ __forceinline__ void store_pod(T *p, const T &v) {
   const uint4 *s = reinterpret_cast<const uint4 *>(&v);
 #pragma unroll
   for (unsigned i = 0; i < sizeof(T) / 16; i++) q[i] = s[i];
+}
+
+// 16-byte pieces straight from one place to another (global or LDS): a copy through a local T goes through the stack
+template <class T>
+__device__ __forceinline__ void copy_pod(T *dst, const T *src) {
+  static_assert(sizeof(T) % 16 == 0, "16-byte granules");
+  const uint4 *q = reinterpret_cast<const uint4 *>(src);
+  uint4 *d = reinterpret_cast<uint4 *>(dst);
+#pragma unroll
+  for (unsigned i = 0; i < sizeof(T) / 16; i++) d[i] = q[i];
 }
 
 struct MsmGeom {
@@ -169,7 +177,6 @@ __device__ __forceinline__ uint32_t digit_bucket(int d) { return (uint32_t)(d < 
 // end to end, n_per scalars each; proof p owns the bucket ranges [p * nR1, (p + 1) * nR1) -- i.e. its own bucket set --
 // so one sort / accumulation / reduction launch serves every proof of the batch.  One proof: n_per = n, nR1 = nR.
 static __global__ __launch_bounds__(MSM_THREADS) void msm_digits_count_kernel(const Fr *scalars, uint32_t n, uint32_t n_per, int c, int K, int nbl_log, uint32_t nR1, uint32_t nR, uint32_t *rng_cnt, uint32_t tmax, int spt) {
-  ZKR_PREP_SETPRIO();
   __shared__ uint32_t s_cnt[MAX_RANGES];
   if (threadIdx.x < nR) s_cnt[threadIdx.x] = 0;
   __syncthreads();
@@ -195,7 +202,6 @@ template <bool STAGED>
 static __global__ __launch_bounds__(MSM_THREADS) void msm_digits_scatter_kernel(const Fr *scalars, uint32_t n, uint32_t n_per, int c, int K, int nbl_log, uint32_t nR1, uint32_t nR,
                                                                               const uint32_t *rng_cnt, uint32_t *rng_fill, uint32_t *rng_off,
                                                                               uint32_t *ent_s, uint32_t *ent_b, uint32_t tmax, int spt) {
-  ZKR_PREP_SETPRIO();
   extern __shared__ __attribute__((aligned(16))) uint32_t s_stage[];  // STAGED: [DIGIT_STAGE] scalar indices, [DIGIT_STAGE] tagged records
   __shared__ uint32_t s_cnt[MAX_RANGES], s_base[MAX_RANGES], s_loc[MAX_RANGES];
   const uint32_t t = threadIdx.x, x = blockIdx.x % DIGIT_XCDS;
@@ -306,10 +312,10 @@ __device__ __forceinline__ void sort_chunk(const uint32_t *rng_off, uint32_t r, 
 // (its buckets' slots, ~850 KB at 2^20) from all J chunks of that range: a 64-byte line gets its sixteen entries from
 // sixteen workgroups.  Workgroups go to the eight XCDs round robin by index, and each XCD has its own L2: with the plain
 // mapping (r = index / J) the chunks of a range sit on all eight, every L2 holds the line partially and writes it back
-// with a byte mask (522 MB of traffic for 54 MB of entries, rocprofv3 WRITE_SIZE, round 2).  xcd_map: all chunks of a
+// with a byte mask (522 MB of traffic for 54 MB of entries, rocprofv3 WRITE_SIZE, round 2).  So: all chunks of a
 // range on the XCD (r mod 8), whose L2 then merges the line before it leaves.
-__device__ __forceinline__ void sort_block_to_chunk(uint32_t b, uint32_t nR, uint32_t J, int xcd_map, uint32_t &r, uint32_t &j) {
-  if (xcd_map && nR % 8 == 0) {
+__device__ __forceinline__ void sort_block_to_chunk(uint32_t b, uint32_t nR, uint32_t J, uint32_t &r, uint32_t &j) {
+  if (nR % 8 == 0) {
     const uint32_t xcd = b % 8, q = b / 8;  // q-th workgroup of this XCD
     r = xcd + 8 * (q / J);
     j = q % J;
@@ -323,21 +329,17 @@ __device__ __forceinline__ void sort_block_to_chunk(uint32_t b, uint32_t nR, uin
 // 0) instead of by memset launches in front of it: a launch boundary lies between the clearing and every use, and two launches
 // fewer per sort are two gaps fewer in a chain of short dependent kernels (DESIGN.md "preparation chain").
 struct SortScratch {
-  uint32_t *big_count;             // [0] oversized buckets listed, [1] total entries, [2] tile ticket of the single-pass scan
+  uint32_t *big_count;             // [0] oversized buckets listed, [1] total entries
   uint32_t *size_hist;             // [2][SIZE_BINS]: size-class histogram, hand-out counters of msm_order_kernel
-  unsigned long long *scan_state;  // [tiles]: look-back words of msm_scan_fused_kernel
-  uint32_t n_tiles;
 };
 
 // cnt[(r * J + j) * nbl + b] = occupancy of bucket r * nbl + b within chunk j
 static __global__ __launch_bounds__(SORT_THREADS) void msm_hist_kernel(const uint32_t *ent_s, const uint32_t *ent_b, const uint32_t *rng_off, const uint32_t *rank,
                                                                      uint32_t n_per, uint32_t nbl, uint32_t J, uint32_t *cnt, SortScratch z) {
-  ZKR_PREP_SETPRIO();
   extern __shared__ __attribute__((aligned(16))) uint32_t s_bkt[];
   if (blockIdx.x == 0 && z.big_count) {
-    if (threadIdx.x < 3) z.big_count[threadIdx.x] = 0;
+    if (threadIdx.x < 2) z.big_count[threadIdx.x] = 0;
     for (uint32_t i = threadIdx.x; i < 2 * 1024u; i += SORT_THREADS) z.size_hist[i] = 0;  // 2 * SIZE_BINS (defined below)
-    for (uint32_t i = threadIdx.x; i < z.n_tiles; i += SORT_THREADS) z.scan_state[i] = 0ull;
   }
   const uint32_t j = blockIdx.x % J, r = blockIdx.x / J;
   for (uint32_t b = threadIdx.x; b < nbl; b += SORT_THREADS) s_bkt[b] = 0;
@@ -366,7 +368,6 @@ static __global__ __launch_bounds__(SORT_THREADS) void msm_hist_kernel(const uin
 
 // per bucket: exclusive prefix over the J chunks (in place) and the bucket total -> counts[]
 static __global__ __launch_bounds__(MSM_THREADS) void msm_colscan_kernel(uint32_t *cnt, uint32_t nb, uint32_t nbl, uint32_t J, uint32_t *counts) {
-  ZKR_PREP_SETPRIO();
   uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= nb) return;
   uint32_t r = g / nbl, b = g % nbl;
@@ -384,11 +385,10 @@ static __global__ __launch_bounds__(MSM_THREADS) void msm_colscan_kernel(uint32_
 // grouped by bucket: LDS cursors = bucket offset + chunk prefix
 static __global__ __launch_bounds__(SORT_THREADS) void msm_scatter_kernel(const uint32_t *ent_s, const uint32_t *ent_b, const uint32_t *rng_off, const uint32_t *rank,
                                                                         uint32_t n_per, uint32_t n, uint32_t nbl, uint32_t J, const uint32_t *cnt, const uint32_t *offsets,
-                                                                        uint32_t *entries, int xcd_map) {
-  ZKR_PREP_SETPRIO();
+                                                                        uint32_t *entries) {
   extern __shared__ __attribute__((aligned(16))) uint32_t s_bkt[];
   uint32_t j, r;
-  sort_block_to_chunk(blockIdx.x, gridDim.x / J, J, xcd_map, r, j);
+  sort_block_to_chunk(blockIdx.x, gridDim.x / J, J, r, j);
   const uint32_t *pre = cnt + ((size_t)r * J + j) * nbl, *off = offsets + (size_t)r * nbl;
   for (uint32_t b = threadIdx.x; b < nbl; b += SORT_THREADS) s_bkt[b] = off[b] + pre[b];
   __syncthreads();
@@ -420,7 +420,6 @@ constexpr int SCAN_PER_THREAD = 8;
 constexpr int SCAN_BLOCK = SCAN_THREADS * SCAN_PER_THREAD;
 
 static __global__ __launch_bounds__(SCAN_THREADS) void msm_scan_sums_kernel(const uint32_t *counts, uint32_t nb, uint32_t *block_sums) {
-  ZKR_PREP_SETPRIO();
   __shared__ uint32_t part[SCAN_THREADS];
   uint32_t base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_PER_THREAD;
   uint32_t s = 0;
@@ -437,7 +436,6 @@ static __global__ __launch_bounds__(SCAN_THREADS) void msm_scan_sums_kernel(cons
 
 // in-place exclusive scan of nblocks block sums by one workgroup; writes the grand total to *total
 static __global__ __launch_bounds__(1024) void msm_scan_top_kernel(uint32_t *block_sums, uint32_t nblocks, uint32_t *total) {
-  ZKR_PREP_SETPRIO();
   __shared__ uint32_t part[1024];
   uint32_t t = threadIdx.x;
   uint32_t per = (nblocks + 1023) / 1024;
@@ -463,7 +461,6 @@ constexpr uint32_t BIG_MARK = 0xffffffffu;  // counts[b] after the scan: bucket 
 static __global__ __launch_bounds__(SCAN_THREADS) void msm_scan_apply_kernel(uint32_t *counts, const uint32_t *block_sums, const uint32_t *total,
                                                                            uint32_t *offsets, uint32_t nb, uint32_t big_thresh,
                                                                            uint32_t *big_list, uint32_t *big_count, uint32_t big_cap, uint32_t *size_hist) {
-  ZKR_PREP_SETPRIO();
   __shared__ uint32_t part[SCAN_THREADS];
   __shared__ uint32_t s_hist[SIZE_BINS];
   for (uint32_t b = threadIdx.x; b < SIZE_BINS; b += SCAN_THREADS) s_hist[b] = 0;
@@ -502,118 +499,10 @@ static __global__ __launch_bounds__(SCAN_THREADS) void msm_scan_apply_kernel(uin
 
 static_assert(SIZE_BINS == 1024, "msm_hist_kernel clears 2 * 1024 words of size_hist");
 
-// The four launches above (msm_colscan_kernel, msm_scan_sums_kernel, msm_scan_top_kernel, msm_scan_apply_kernel) in ONE: a
-// workgroup takes a tile of SCAN_BLOCK buckets (tiles handed out by a ticket, so every lower tile is running or done), turns
-// the per-chunk occupancies of its buckets into per-chunk prefixes and bucket totals (the column scan), scans the totals
-// within the tile, publishes the tile's sum, and gets the sum of everything below it by looking BACK over the published words
-// (single-pass scan with decoupled look-back: a word is flag << 62 | value, flag 1 = the tile's own sum, 2 = the inclusive
-// prefix up to and including the tile; wavefront 0 inspects 64 predecessors per step).  Then offsets, the oversized-bucket
-// list and the size-class histogram as before.  With 256 tiles at 2^19 buckets the look-back is a few steps; the chain of
-// short launches it replaces cost more in launch gaps than in work (isolated 8 + 4 + 3 + 7 us of kernels, ~60 us of stream time).
-constexpr unsigned long long SCAN_FLAG_SUM = 1ull << 62, SCAN_FLAG_PREFIX = 2ull << 62, SCAN_VALUE_MASK = (1ull << 62) - 1;
-// 1024 threads with two buckets each (a tile is still SCAN_BLOCK buckets): the column scan is a chain of dependent loads per
-// bucket, so what it needs is threads -- with 256 threads of eight buckets the fused kernel ran slower than the four small
-// launches it replaces (same-box: 152.5 against 155.0 proofs/s at 2^20, profiles/r4_ab_prep_chain.txt)
-constexpr int SCANF_THREADS = 1024, SCANF_PER_THREAD = SCAN_BLOCK / SCANF_THREADS;
-static_assert(SCANF_PER_THREAD == 2, "two buckets per thread");
-static __global__ __launch_bounds__(SCANF_THREADS) void msm_scan_fused_kernel(uint32_t *chunk_cnt, uint32_t nb, uint32_t nbl, uint32_t J, uint32_t *counts, uint32_t *offsets,
-                                                                           uint32_t big_thresh, uint32_t *big_list, uint32_t big_cap, SortScratch z) {
-  ZKR_PREP_SETPRIO();
-  __shared__ uint32_t s_cnt[SCAN_BLOCK];
-  __shared__ uint32_t part[SCANF_THREADS];
-  __shared__ uint32_t s_hist[SIZE_BINS];
-  __shared__ uint32_t s_tile;
-  __shared__ unsigned long long s_before;
-  const uint32_t t = threadIdx.x;
-  if (t == 0) s_tile = atomicAdd(&z.big_count[2], 1u);
-  if (t < SIZE_BINS) s_hist[t] = 0;
-  __syncthreads();
-  const uint32_t tile = s_tile, tile_base = tile * SCAN_BLOCK;
-  // column scan: consecutive lanes take consecutive buckets (the chunk rows of a range are contiguous over its buckets)
-#pragma unroll
-  for (int k = 0; k < SCANF_PER_THREAD; k++) {
-    const uint32_t g = tile_base + k * SCANF_THREADS + t;
-    uint32_t run = 0;
-    if (g < nb) {
-      const uint32_t r = g / nbl, b = g % nbl;
-      uint32_t *col = chunk_cnt + (size_t)r * J * nbl + b;
-      for (uint32_t j = 0; j < J; j++) {
-        const uint32_t v = col[(size_t)j * nbl];
-        col[(size_t)j * nbl] = run;
-        run += v;
-      }
-    }
-    s_cnt[k * SCANF_THREADS + t] = run;
-  }
-  __syncthreads();
-  const uint32_t base = tile_base + t * SCANF_PER_THREAD;
-  uint32_t c[SCANF_PER_THREAD], s = 0;
-#pragma unroll
-  for (int k = 0; k < SCANF_PER_THREAD; k++) { c[k] = s_cnt[t * SCANF_PER_THREAD + k]; s += c[k]; }
-  part[t] = s;
-  __syncthreads();
-  for (uint32_t off = 1; off < SCANF_THREADS; off <<= 1) {
-    uint32_t v = t >= off ? part[t - off] : 0;
-    __syncthreads();
-    part[t] += v;
-    __syncthreads();
-  }
-  if (t < 64) {  // wavefront 0: publish, look back
-    const unsigned long long total = part[SCANF_THREADS - 1];
-    unsigned long long before = 0;
-    if (tile > 0) {
-      if (t == 0) __hip_atomic_store(&z.scan_state[tile], SCAN_FLAG_SUM | total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      int hi = (int)tile - 1;  // highest tile not yet accounted for
-      for (;;) {
-        const int idx = hi - (int)t;
-        const unsigned long long v = idx >= 0 ? __hip_atomic_load(&z.scan_state[idx], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) : SCAN_FLAG_PREFIX;
-        const unsigned long long flag = v >> 62;
-        const unsigned long long m_prefix = __ballot(flag == 2), m_empty = __ballot(flag == 0);
-        const int first_prefix = m_prefix ? __builtin_ctzll(m_prefix) : 64, first_empty = m_empty ? __builtin_ctzll(m_empty) : 64;
-        if (first_empty < first_prefix) { __builtin_amdgcn_s_sleep(8); continue; }  // a word this step needs is not published yet
-        unsigned long long mine = (int)t <= first_prefix ? (v & SCAN_VALUE_MASK) : 0ull;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-          const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)mine, o), hi32 = (uint32_t)__shfl_xor((int)(uint32_t)(mine >> 32), o);
-          mine += ((unsigned long long)hi32 << 32) | lo;
-        }
-        before += mine;
-        if (first_prefix < 64) break;
-        hi -= 64;
-      }
-    }
-    if (t == 0) {
-      __hip_atomic_store(&z.scan_state[tile], SCAN_FLAG_PREFIX | (before + total), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      s_before = before;
-      if (tile == z.n_tiles - 1) { offsets[nb] = (uint32_t)(before + total); z.big_count[1] = (uint32_t)(before + total); }
-    }
-  }
-  __syncthreads();
-  uint32_t run = (uint32_t)s_before + part[t] - s;
-#pragma unroll
-  for (int k = 0; k < SCANF_PER_THREAD; k++) {
-    if (base + k < nb) {
-      offsets[base + k] = run;
-      bool big = false;
-      uint32_t cv = c[k];
-      if (cv > big_thresh) {
-        uint32_t slot = atomicAdd(&z.big_count[0], 1u);
-        if (slot < big_cap) { big_list[slot] = base + k; cv = BIG_MARK; big = true; }  // beyond the cap the bucket stays with msm_accum_kernel
-      }
-      counts[base + k] = cv;
-      atomicAdd(&s_hist[big ? 0u : size_bin(c[k])], 1u);
-      run += c[k];
-    }
-  }
-  __syncthreads();
-  if (t < SIZE_BINS && s_hist[t]) atomicAdd(&z.size_hist[t], s_hist[t]);
-}
-
 // order[] = all bucket ids sorted by occupancy, fullest first (counting sort over SIZE_BINS size classes;
 // msm_big_kernel-owned and empty buckets go last).  Same 2048-bucket partition as the scan.  size_hist is
 // complete when this runs; `taken` (zeroed) hands out ranges inside each size class.
 static __global__ __launch_bounds__(SCAN_THREADS) void msm_order_kernel(const uint32_t *counts, uint32_t nb, const uint32_t *size_hist, uint32_t *taken, uint32_t *order) {
-  ZKR_PREP_SETPRIO();
   __shared__ uint32_t s_start[SIZE_BINS];  // first: global histogram -> start of each class (descending sizes)
   __shared__ uint32_t s_hist[SIZE_BINS];   // local histogram, then base of this workgroup's range in each class
   __shared__ uint32_t part[SCAN_THREADS];
@@ -706,26 +595,36 @@ static __global__ __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per
   // ACC_ONTO: the bucket set already holds another table's sums over the same bucket geometry (C before H: only C + H is
   // ever needed, so one bucket set and ONE reduction chain serve both tables)
   XYZZ29<C> acc = (job.onto & ACC_ONTO) ? unpack_xyzz(load_pod(job.buckets + b)) : XYZZ29<C>::inf();
-  if (PREFETCH) {
-    if (o0 < o1) {
-      uint32_t e = entries[o0];
+  // Software pipeline of the chain (round 6): the entry index runs TWO additions ahead and the point ONE, so the gather's address
+  // has been in a register for a whole addition when the gather is issued.  Before, index and point were loaded back to back at
+  // the top of every step and the wave stood still for the index load's latency (s_waitcnt vmcnt(0) between the two: 15 % of a
+  // wavefront's cycles in SQ_WAIT_ANY, profiles/r6_01_census_isolated.md).  The loads past the end of the chain re-read its last
+  // entry / point (no branch around a load, nothing out of bounds).
+  if (o0 < o1) {
+    const uint32_t last = o1 - 1;
+    uint32_t e = entries[o0], e1 = entries[min(o0 + 1, last)];
+    if (PREFETCH) {
       Affine<F> p = load_pod(points + (e >> 1));
-      for (uint32_t j = o0 + 1; j < o1; j++) {
-        uint32_t en = entries[j];
-        Affine<F> pn = load_pod(points + (en >> 1));
+      for (uint32_t j = o0; j < o1; j++) {
+        const uint32_t e2 = entries[min(j + 2, last)];
+        const Affine<F> pn = load_pod(points + (e1 >> 1));
         if (!p.is_inf()) acc = add_mixed29<C>(acc, unpack_affine(p), (e & 1) != 0);  // infinity: placeholder of a shared-support table
-        e = en;
-        p = pn;
+        e = e1; e1 = e2; p = pn;
       }
-      if (!p.is_inf()) acc = add_mixed29<C>(acc, unpack_affine(p), (e & 1) != 0);
-    }
-  } else {  // only the next entry index is fetched ahead: for wide points the second point in flight costs spills
-    uint32_t e = o0 < o1 ? entries[o0] : 0u;
-    for (uint32_t j = o0; j < o1; j++) {
-      uint32_t en = j + 1 < o1 ? entries[j + 1] : 0u;
-      Affine<F> p = load_pod(points + (e >> 1));
-      if (!p.is_inf()) acc = add_mixed29<C>(acc, unpack_affine(p), (e & 1) != 0);
-      e = en;
+    } else {
+      // wide points (G2: 128 B): a second point in registers would spill; the NEXT point's two cache lines are touched instead
+      // (one word each), so that the load at the top of the next step finds them in L2 with their translation in place
+      for (uint32_t j = o0; j < o1; j++) {
+        const uint32_t e2 = entries[min(j + 2, last)];
+        const Affine<F> p = load_pod(points + (e >> 1));
+        const uint32_t *nx = reinterpret_cast<const uint32_t *>(points + (e1 >> 1));
+        uint32_t touch = 0;
+#pragma unroll
+        for (unsigned l = 0; l < sizeof(Affine<F>) / 64; l++) touch |= nx[16 * l];
+        if (!p.is_inf()) acc = add_mixed29<C>(acc, unpack_affine(p), (e & 1) != 0);
+        asm volatile("" ::"v"(touch));  // the touches are waited for here, after the addition, not before it
+        e = e1; e1 = e2;
+      }
     }
   }
   store_pod(job.buckets + b, pack_xyzz<F>(acc));
@@ -775,15 +674,22 @@ static __global__ __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per
 template <class F>
 __device__ __forceinline__ XYZZ<F> tree_add(const XYZZ<F> &a, const XYZZ<F> &b) {
   using C = typename CoordOf<F>::C;
-  return pack_xyzz<F>(add_full29<C>(unpack_xyzz(a), unpack_xyzz(b)));
+  return pack_xyzz<F>(add_full29<C>(unpack_xyzz(a), unpack_xyzz(b), [&]() { return unpack_xyzz(b); }));
 }
 constexpr int BIG_SPLIT = 8;
 constexpr int BIG_SLOTS = 64;  // bucket slots per launch round (grid = BIG_SLOTS * BIG_SPLIT)
 
-template <class F, int MINW>
-static __global__ __launch_bounds__(MSM_THREADS, MINW) void msm_big_kernel(const Affine<F> *points, const uint32_t *offsets, const uint32_t *entries,
-                                                                   const uint32_t *big_list, const uint32_t *big_count, uint32_t big_cap,
-                                                                   XYZZ<F> *partials) {
+// The oversized-bucket and reduction kernels below are few, long-running wavefronts that must find room on SIMDs whose register
+// file the accumulations already hold (two wavefronts of 176 VGPRs for G1, of 248 for G2, out of 512).  Round 6 builds them to
+// FIT: the G1 forms in 160 VGPRs -- beside BOTH accumulation wavefronts of a SIMD, a third resident wavefront that displaces
+// nothing -- and the G2 forms in 320, beside ONE (the Fq2 running sums of reduce1 took 394 before: its workgroups could only start
+// on CUs that had drained completely, i.e. in the tail of an accumulation launch, and then kept a quarter of the chip to
+// themselves at one dependent chain per SIMD; profiles/r6_03_steady_timeline_r5.md).  The bodies are templates over the field; the
+// kernels are instantiated per field because the register cap is an attribute (amdgpu_num_vgpr counts half of the unified file
+// on gfx950: 80 -> 160, 160 -> 320).  No kernel spills (tools/kernel_resources.py).
+template <class F>
+__device__ __forceinline__ void msm_big_body(const Affine<F> *points, const uint32_t *offsets, const uint32_t *entries,
+                                             const uint32_t *big_list, const uint32_t *big_count, uint32_t big_cap, XYZZ<F> *partials) {
   __builtin_amdgcn_s_setprio(ZKR_RED_PRIO);  // few long-running wavefronts on the critical path: win VALU arbitration against the bulk accumulation
   using C = typename CoordOf<F>::C;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -805,21 +711,27 @@ static __global__ __launch_bounds__(MSM_THREADS, MINW) void msm_big_kernel(const
       if (threadIdx.x < s) sh[threadIdx.x] = tree_add(sh[threadIdx.x], sh[threadIdx.x + s]);
       __syncthreads();
     }
-    if (threadIdx.x == 0) store_pod(partials + (size_t)w * BIG_SPLIT + sub, sh[0]);
+    if (threadIdx.x == 0) copy_pod(partials + (size_t)w * BIG_SPLIT + sub, sh);
     __syncthreads();
   }
 }
 
-template <class F, int MINW>
-static __global__ __launch_bounds__(64, MINW) void msm_big_finish_kernel(const XYZZ<F> *partials, const uint32_t *big_list, const uint32_t *big_count,
-                                                                         uint32_t big_cap, XYZZ<F> *buckets, int onto) {
-  __builtin_amdgcn_s_setprio(ZKR_RED_PRIO);  // few long-running wavefronts on the critical path: win VALU arbitration against the bulk accumulation
+template <class F>
+__device__ __forceinline__ void msm_big_finish_body(const XYZZ<F> *partials, const uint32_t *big_list, const uint32_t *big_count,
+                                                    uint32_t big_cap, XYZZ<F> *buckets, int onto) {
+  __builtin_amdgcn_s_setprio(ZKR_RED_PRIO);
   uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= min(*big_count, big_cap)) return;
   using C = typename CoordOf<F>::C;
   XYZZ29<C> acc = unpack_xyzz(load_pod(partials + (size_t)w * BIG_SPLIT));
-  for (int k = 1; k < BIG_SPLIT; k++) acc = add_full29<C>(acc, unpack_xyzz(load_pod(partials + (size_t)w * BIG_SPLIT + k)));
-  if (onto) acc = add_full29<C>(acc, unpack_xyzz(load_pod(buckets + big_list[w])));  // the bucket keeps the other table's sum (msm_accum_kernel skipped it)
+  for (int k = 1; k < BIG_SPLIT; k++) {
+    const XYZZ<F> *src = partials + (size_t)w * BIG_SPLIT + k;
+    acc = add_full29<C>(acc, unpack_xyzz(load_pod(src)), [&]() { return unpack_xyzz(load_pod(src)); });
+  }
+  if (onto) {  // the bucket keeps the other table's sum (msm_accum_kernel skipped it)
+    const XYZZ<F> *src = buckets + big_list[w];
+    acc = add_full29<C>(acc, unpack_xyzz(load_pod(src)), [&]() { return unpack_xyzz(load_pod(src)); });
+  }
   store_pod(buckets + big_list[w], pack_xyzz<F>(acc));
 }
 
@@ -832,25 +744,49 @@ static __global__ __launch_bounds__(64, MINW) void msm_big_finish_kernel(const X
 //   reduce3 : one workgroup: adds the splits, turns Q_j into 2^(j+glog) Q_j by doublings (one lane per task,
 //             in parallel), and adds the tasks in an LDS tree -> the MSM result
 // group_out: R[ng] then T[ng];  task_out: [ntask][S] with ntask = log2(ng) + 2.
-template <class F, int MINW>
-static __global__ __launch_bounds__(MSM_THREADS, MINW) void msm_reduce1_kernel(const XYZZ<F> *buckets, MsmGeom g, XYZZ<F> *group_out) {
-  __builtin_amdgcn_s_setprio(ZKR_RED_PRIO);  // few long-running wavefronts on the critical path: win VALU arbitration against the bulk accumulation
+//
+// reduce1 keeps NEITHER running sum in registers across an addition (round 6): the suffix sums run_j = B_j + ... + B_{g-1} are
+// written back over the buckets they end at (the bucket set is dead once its reduction has read it: the next accumulation starts
+// from infinity) and read again by the next step; T waits in LDS (word w of lane t at [w][t]: conflict-free).  Either addition
+// then has two operands that die inside it, which is what the register cap above needs; the price is a packed store + load and
+// 2 x 36 / 72 LDS words per bucket, against ~6 000 / 12 000 instructions of the two additions.
+template <class P>
+__device__ __forceinline__ void lds_park(uint32_t *lds, const P &v) {
+  static_assert(sizeof(P) % 4 == 0, "made of 32-bit words");
+  const uint32_t *src = reinterpret_cast<const uint32_t *>(&v);
+#pragma unroll
+  for (unsigned w = 0; w < sizeof(P) / 4; w++) lds[w * MSM_THREADS + threadIdx.x] = src[w];
+}
+template <class P>
+__device__ __forceinline__ P lds_unpark(const uint32_t *lds) {
+  P v;
+  uint32_t *dst = reinterpret_cast<uint32_t *>(&v);
+#pragma unroll
+  for (unsigned w = 0; w < sizeof(P) / 4; w++) dst[w] = lds[w * MSM_THREADS + threadIdx.x];
+  return v;
+}
+template <class F> constexpr size_t reduce1_lds_bytes() { return sizeof(XYZZ29<typename CoordOf<F>::C>) * MSM_THREADS; }
+template <class F>
+__device__ __forceinline__ void msm_reduce1_body(XYZZ<F> *buckets, MsmGeom g, XYZZ<F> *group_out) {
+  __builtin_amdgcn_s_setprio(ZKR_RED_PRIO);
+  extern __shared__ __attribute__((aligned(16))) uint32_t s_park[];
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t ng = (g.nbw >> g.glog) * g.batch, gs = 1u << g.glog;  // groups of every bucket set of the batch, end to end
   if (t >= ng) return;
   using C = typename CoordOf<F>::C;
-  const XYZZ<F> *B = buckets + (size_t)t * gs;
-  XYZZ29<C> run = unpack_xyzz(load_pod(B + gs - 1)), T = run;
+  XYZZ<F> *B = buckets + (size_t)t * gs;
+  lds_park(s_park, unpack_xyzz(load_pod(B + gs - 1)));  // T = run = the last bucket
   for (int j = (int)gs - 2; j >= 0; j--) {
-    run = add_full29<C>(run, unpack_xyzz(load_pod(B + j)));
-    T = add_full29<C>(T, run);
+    const XYZZ29<C> run = add_full29<C>(unpack_xyzz(load_pod(B + j + 1)), unpack_xyzz(load_pod(B + j)), [&]() { return unpack_xyzz(load_pod(B + j)); });
+    store_pod(B + j, pack_xyzz<F>(run));  // the suffix sum, in place
+    lds_park(s_park, add_full29<C>(run, lds_unpark<XYZZ29<C>>(s_park), [&]() { return lds_unpark<XYZZ29<C>>(s_park); }));  // T += run
   }
-  store_pod(group_out + t, pack_xyzz<F>(run));
-  store_pod(group_out + (size_t)ng + t, pack_xyzz<F>(T));
+  copy_pod(group_out + t, B);
+  store_pod(group_out + (size_t)ng + t, pack_xyzz<F>(lds_unpark<XYZZ29<C>>(s_park)));
 }
 
-template <class F, int MINW>
-static __global__ __launch_bounds__(MSM_THREADS, MINW) void msm_reduce2_kernel(const XYZZ<F> *group_out, MsmGeom g, XYZZ<F> *task_out) {
+template <class F>
+__device__ __forceinline__ void msm_reduce2_body(const XYZZ<F> *group_out, MsmGeom g, XYZZ<F> *task_out) {
   __builtin_amdgcn_s_setprio(ZKR_RED_PRIO);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   XYZZ<F> *sh = reinterpret_cast<XYZZ<F> *>(smem);
@@ -864,13 +800,13 @@ static __global__ __launch_bounds__(MSM_THREADS, MINW) void msm_reduce2_kernel(c
     const uint32_t half = ng / 2, u0 = (uint32_t)((uint64_t)half * q / g.S), u1 = (uint32_t)((uint64_t)half * (q + 1) / g.S);
     for (uint32_t u = u0 + threadIdx.x; u < u1; u += MSM_THREADS) {
       uint32_t t = ((u >> j) << (j + 1)) | (1u << j) | (u & ((1u << j) - 1u));
-      acc = add_full29<C>(acc, unpack_xyzz(load_pod(R + t)));
+      acc = add_full29<C>(acc, unpack_xyzz(load_pod(R + t)), [&]() { return unpack_xyzz(load_pod(R + t)); });
     }
   } else {
     const XYZZ<F> *T = group_out + (size_t)ng * g.batch + (size_t)proof * ng;
     const uint32_t h = j - nglog, lo = h * ng / 2, len = (h + 1) * ng / 2 - lo;
     const uint32_t t0 = lo + (uint32_t)((uint64_t)len * q / g.S), t1 = lo + (uint32_t)((uint64_t)len * (q + 1) / g.S);
-    for (uint32_t t = t0 + threadIdx.x; t < t1; t += MSM_THREADS) acc = add_full29<C>(acc, unpack_xyzz(load_pod(T + t)));
+    for (uint32_t t = t0 + threadIdx.x; t < t1; t += MSM_THREADS) acc = add_full29<C>(acc, unpack_xyzz(load_pod(T + t)), [&]() { return unpack_xyzz(load_pod(T + t)); });
   }
   sh[threadIdx.x] = pack_xyzz<F>(acc);
   __syncthreads();
@@ -878,12 +814,12 @@ static __global__ __launch_bounds__(MSM_THREADS, MINW) void msm_reduce2_kernel(c
     if (threadIdx.x < s) sh[threadIdx.x] = tree_add(sh[threadIdx.x], sh[threadIdx.x + s]);
     __syncthreads();
   }
-  if (threadIdx.x == 0) store_pod(task_out + (size_t)proof * gridDim.x + blockIdx.x, sh[0]);
+  if (threadIdx.x == 0) copy_pod(task_out + (size_t)proof * gridDim.x + blockIdx.x, sh);
 }
 
 // one workgroup of MSM_THREADS lanes per bucket set; needs ntask * S <= MSM_THREADS (msm_plan guarantees it)
-template <class F, int MINW>
-static __global__ __launch_bounds__(MSM_THREADS, MINW) void msm_reduce3_kernel(const XYZZ<F> *task_out, MsmGeom g, XYZZ<F> *result) {
+template <class F>
+__device__ __forceinline__ void msm_reduce3_body(const XYZZ<F> *task_out, MsmGeom g, XYZZ<F> *result) {
   __builtin_amdgcn_s_setprio(ZKR_RED_PRIO);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   XYZZ<F> *sh = reinterpret_cast<XYZZ<F> *>(smem);
@@ -915,10 +851,53 @@ static __global__ __launch_bounds__(MSM_THREADS, MINW) void msm_reduce3_kernel(c
     __syncthreads();
   }
   if (threadIdx.x == 0) {  // back to the key's radix (2^256), canonical: the host assembly takes over
-    store_pod(result, sh[0]);
+    copy_pod(result, sh);
     xyzz_to_256_at(result);  // in place: no stack frame for the one cold call of the kernel
   }
 }
+
+// TEMPORARY (round-6 A/B, removed before the round ends): -DZKR_EXP_FAT_CHAIN builds the same kernels with round 5's register
+// ALLOCATIONS (a clobbered high register: 200 VGPRs for the G1 forms, 394 for the G2 forms) -- same instructions, old footprint
+#ifdef ZKR_EXP_FAT_CHAIN
+#define ZKR_RED_ATTR(NV) __attribute__((amdgpu_waves_per_eu(1, 2)))
+#define ZKR_RED_FAT(NV) do { if (NV == 80) asm volatile("" ::: "v167"); else asm volatile("" ::: "v255", "a59"); } while (0)
+#define ZKR_RED_FAT1(NV) do { if (NV == 80) asm volatile("" ::: "v199"); else asm volatile("" ::: "v255", "a137"); } while (0)
+#else
+#define ZKR_RED_ATTR(NV) __attribute__((amdgpu_num_vgpr(NV)))
+#define ZKR_RED_FAT(NV) ((void)0)
+#define ZKR_RED_FAT1(NV) ((void)0)
+#endif
+#define ZKR_RED_KERNELS(F, SFX, NV)                                                                                                                          \
+  static __global__ __launch_bounds__(MSM_THREADS) ZKR_RED_ATTR(NV) void msm_big_kernel_##SFX(                                           \
+      const Affine<F> *points, const uint32_t *offsets, const uint32_t *entries, const uint32_t *big_list, const uint32_t *big_count, uint32_t big_cap,       \
+      XYZZ<F> *partials) { ZKR_RED_FAT(NV); msm_big_body<F>(points, offsets, entries, big_list, big_count, big_cap, partials); }                                              \
+  static __global__ __launch_bounds__(64) ZKR_RED_ATTR(NV) void msm_big_finish_kernel_##SFX(                                             \
+      const XYZZ<F> *partials, const uint32_t *big_list, const uint32_t *big_count, uint32_t big_cap, XYZZ<F> *buckets, int onto) {                          \
+    ZKR_RED_FAT(NV); msm_big_finish_body<F>(partials, big_list, big_count, big_cap, buckets, onto); }                                                                         \
+  static __global__ __launch_bounds__(MSM_THREADS) ZKR_RED_ATTR(NV) void msm_reduce1_kernel_##SFX(XYZZ<F> *buckets, MsmGeom g,           \
+      XYZZ<F> *group_out) { ZKR_RED_FAT1(NV); msm_reduce1_body<F>(buckets, g, group_out); }                                                                                    \
+  static __global__ __launch_bounds__(MSM_THREADS) ZKR_RED_ATTR(NV) void msm_reduce2_kernel_##SFX(const XYZZ<F> *group_out, MsmGeom g,   \
+      XYZZ<F> *task_out) { ZKR_RED_FAT(NV); msm_reduce2_body<F>(group_out, g, task_out); }                                                                                    \
+  static __global__ __launch_bounds__(MSM_THREADS) ZKR_RED_ATTR(NV) void msm_reduce3_kernel_##SFX(const XYZZ<F> *task_out, MsmGeom g,    \
+      XYZZ<F> *result) { ZKR_RED_FAT(NV); msm_reduce3_body<F>(task_out, g, result); }
+ZKR_RED_KERNELS(Fq, g1, 80)
+ZKR_RED_KERNELS(Fq2, g2, 160)
+#undef ZKR_RED_KERNELS
+template <class F> struct RedKernels;
+template <> struct RedKernels<Fq> {
+  static constexpr auto big = msm_big_kernel_g1;
+  static constexpr auto big_finish = msm_big_finish_kernel_g1;
+  static constexpr auto reduce1 = msm_reduce1_kernel_g1;
+  static constexpr auto reduce2 = msm_reduce2_kernel_g1;
+  static constexpr auto reduce3 = msm_reduce3_kernel_g1;
+};
+template <> struct RedKernels<Fq2> {
+  static constexpr auto big = msm_big_kernel_g2;
+  static constexpr auto big_finish = msm_big_finish_kernel_g2;
+  static constexpr auto reduce1 = msm_reduce1_kernel_g2;
+  static constexpr auto reduce2 = msm_reduce2_kernel_g2;
+  static constexpr auto reduce3 = msm_reduce3_kernel_g2;
+};
 
 // ---------------------------------------------------------------- window tables (key load)
 // tbl[k * n + i] = 2^(ck) * tbl[i] for k = 1..K-1, affine, x 2^261; level 0 comes in the key's radix (x 2^256, the wire
@@ -979,6 +958,22 @@ static __global__ __launch_bounds__(MSM_THREADS) void radix_convert_kernel(Affin
   if (to261) { radix_to_261_at(&pts[i].x); radix_to_261_at(&pts[i].y); } else { radix_to_256_at(&pts[i].x); radix_to_256_at(&pts[i].y); }
 }
 
+// to_affine (curve.hpp) for a kernel, inlined down to the inversion's loop: an out-of-line call takes its argument by reference,
+// i.e. from memory, and keeps the caller's live registers in a stack frame across it -- all the "scratch" fixed_base_kernel had
+// (160 / 464 B per lane, tools/kernel_resources.py).  Setup path: the code size does not matter.
+__device__ __forceinline__ Fq inv_leaf(const Fq &x) { return inv_inline(x); }
+__device__ __forceinline__ Fq2 inv_leaf(const Fq2 &x) {
+  Fq n = inv_inline(add(sqr(x.a), sqr(x.b)));
+  return Fq2{mul(x.a, n), neg(mul(x.b, n))};
+}
+template <class F>
+__device__ __forceinline__ Affine<F> to_affine_leaf(const XYZZ<F> &p) {
+  if (p.is_inf()) return Affine<F>{F::zero(), F::one()};
+  F zi = inv_leaf(p.zzz);                  // 1/ZZZ
+  F inv_zz = mul(sqr(p.zz), sqr(zi));      // ZZ^3 = ZZZ^2  =>  1/ZZ = ZZ^2/ZZZ^2
+  return Affine<F>{mul(p.x, inv_zz), mul(p.y, zi)};
+}
+
 // ---------------------------------------------------------------- device-side setup
 // out[i] = scalar[i] * G through a fixed-base table T[j][d] = d * 2^(8j) * G (j < 32, d < 256; d = 0 unused),
 // converted to the affine Montgomery wire form (infinity -> x = 0, y = one; binarify.ts:92-102).
@@ -996,7 +991,7 @@ static __global__ __launch_bounds__(MSM_THREADS, MINW) void fixed_base_kernel(co
     it.s[7] >>= 8;
     if (d) acc = add_mixed(acc, load_pod(table + j * 256 + d));
   }
-  store_pod(out + i, to_affine(acc));
+  store_pod(out + i, to_affine_leaf(acc));
 }
 
 // out[j] = in[idx[j]]  (table compaction / permutation at key build)
@@ -1036,85 +1031,6 @@ static __global__ __launch_bounds__(MSM_THREADS) void fq_mul_bench_kernel(Fq *io
   Fq r;
   pack29(weak(add(add(la, lb), add(lc, ld))), r.v);
   store_pod(io + i, r);
-}
-
-// Batched-affine addition over Fq2 against the XYZZ mixed addition, on silicon (DESIGN "measured and
-// rejected").  The design measured: thread per bucket, the accumulator stays in registers (no HBM round trip) but in AFFINE
-// form; per round every lane of the 256-lane workgroup has ONE pending addition acc += q and the lanes share one Fq2 inversion:
-// the denominators x_q - x_acc go through an LDS product scan in both directions (prefix and suffix products, Hillis-Steele,
-// 8 steps), lane 0 inverts the total, every lane gets 1 / d_i = (1 / T) E_i S_i and finishes lambda, x3, y3 (1 product, 1 square,
-// 1 product).  AFFINE = false: the same additions as the hot path does them (XYZZ += affine, add_mixed29).  The synthetic walk
-// over the table never meets equal x (distinct multiples of one point), so neither form takes its special-case branches.
-constexpr int AFF_THREADS = 256;
-template <bool AFFINE>
-static __global__ __launch_bounds__(AFF_THREADS) void g2_add_bench_kernel(const G2Affine *table, uint32_t n_table, int iters, G2Affine *out_aff, XYZZ<Fq2> *out_xyzz) {
-  using C = G2C;
-  const uint32_t t = threadIdx.x, g = blockIdx.x * AFF_THREADS + t;
-  if constexpr (!AFFINE) {
-    XYZZ29<C> acc = XYZZ29<C>::inf();
-    acc = add_mixed29<C>(acc, unpack_affine(load_pod(table + g % n_table)), false);
-    for (int it = 0; it < iters; it++) {
-      const G2Affine q = load_pod(table + (g * 7u + 13u * (uint32_t)it + 1u) % n_table);
-      acc = add_mixed29<C>(acc, unpack_affine(q), false);
-    }
-    store_pod(out_xyzz + g, xyzz_to_256(pack_xyzz<Fq2>(acc)));
-  } else {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];  // prefix [18][256] | suffix [18][256] | 1 / total [18]
-    uint32_t *lp = lds, *ls = lds + 18 * AFF_THREADS, *li = lds + 36 * AFF_THREADS;
-    auto put = [&](uint32_t *base, uint32_t e, const Q29<4> &v) {
-#pragma unroll
-      for (int k = 0; k < 9; k++) { base[k * AFF_THREADS + e] = v.a.v[k]; base[(9 + k) * AFF_THREADS + e] = v.b.v[k]; }
-    };
-    auto get = [&](const uint32_t *base, uint32_t e) {
-      Q29<4> v;
-#pragma unroll
-      for (int k = 0; k < 9; k++) { v.a.v[k] = base[k * AFF_THREADS + e]; v.b.v[k] = base[(9 + k) * AFF_THREADS + e]; }
-      return v;
-    };
-    const Q29<4> one = C::one().template to<4>();
-    const Affine29<C> p0 = unpack_affine(load_pod(table + g % n_table));
-    Q29<5> ax = p0.x.template to<5>(), ay = p0.y.template to<5>();
-    for (int it = 0; it < iters; it++) {
-      const Affine29<C> q = unpack_affine(load_pod(table + (g * 7u + 13u * (uint32_t)it + 1u) % n_table));
-      const auto d = sub(q.x, ax);    // x_q - x_acc, never 0 here
-      const auto num = sub(q.y, ay);
-      Q29<4> pre = mul(d, one).template to<4>(), suf = pre;  // reduced once: the scan multiplies it up to 8 times
-      put(lp, t, pre);
-      put(ls, t, suf);
-      __syncthreads();
-      for (uint32_t off = 1; off < AFF_THREADS; off <<= 1) {
-        const Q29<4> a = t >= off ? get(lp, t - off) : one, b = t + off < AFF_THREADS ? get(ls, t + off) : one;
-        __syncthreads();
-        pre = mul(pre, a).template to<4>();
-        suf = mul(suf, b).template to<4>();
-        put(lp, t, pre);
-        put(ls, t, suf);
-        __syncthreads();
-      }
-      if (t == 0) {  // the one inversion of the round: lane 0's suffix product is the product of all 256 denominators
-        const Q29<4> total = get(ls, 0);
-        const Q29<4> inv = inv29(total);
-#pragma unroll
-        for (int k = 0; k < 9; k++) { li[k] = inv.a.v[k]; li[9 + k] = inv.b.v[k]; }
-      }
-      __syncthreads();
-      Q29<4> inv_t;
-#pragma unroll
-      for (int k = 0; k < 9; k++) { inv_t.a.v[k] = li[k]; inv_t.b.v[k] = li[9 + k]; }
-      const Q29<4> e = t > 0 ? get(lp, t - 1) : one, sx = t + 1 < AFF_THREADS ? get(ls, t + 1) : one;
-      const auto inv_d = mul(mul(inv_t, e), sx);
-      const auto lam = mul(num, inv_d);
-      const auto x3 = barrett(sub(sub(sqr(lam), ax), q.x));
-      const auto y3 = barrett(sub(mul(lam, sub(ax, x3)), ay));
-      ax = x3;
-      ay = y3;
-      __syncthreads();  // the scan arrays are rewritten by the next round
-    }
-    G2Affine o{C::template pack<2>(canonical_small(ax)), C::template pack<2>(canonical_small(ay))};
-    o.x = radix_to_256(o.x);
-    o.y = radix_to_256(o.y);
-    store_pod(out_aff + g, o);
-  }
 }
 
 // Limb-level self test of the product forms of field29.hpp as the DEVICE runs them (one asm statement each,

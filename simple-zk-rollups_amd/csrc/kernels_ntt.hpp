@@ -340,7 +340,6 @@ constexpr uint32_t SPMV_WIDE = 8;
 struct SpmvSide { const uint32_t *row_ptr, *col; const Fr *coef; Fr *out; const uint32_t *wide; uint32_t n_wide; };
 // row0 / row1: the rows wanted (a shard of a split calcH evaluates its block of the domain; otherwise 0 and m)
 static __global__ void spmv_kernel(SpmvSide sa, SpmvSide sb, const Fr *w, uint32_t m, uint32_t n, uint32_t row0, uint32_t row1) {
-  ZKR_PREP_SETPRIO();
   const SpmvSide &sd = blockIdx.z ? sb : sa;
   const uint32_t *row_ptr = sd.row_ptr, *col = sd.col;
   const Fr *coef = sd.coef;
@@ -357,7 +356,6 @@ static __global__ void spmv_kernel(SpmvSide sa, SpmvSide sb, const Fr *w, uint32
 }
 // wide[i] = index of the i-th row wider than SPMV_WIDE; one wavefront per row, terms strided over the lanes, LDS tree
 static __global__ __launch_bounds__(64) void spmv_wide_kernel(SpmvSide sa, SpmvSide sb, const Fr *w, uint32_t m, uint32_t n, uint32_t row0, uint32_t row1) {
-  ZKR_PREP_SETPRIO();
   __shared__ uint32_t sh[8 * 64];
   const SpmvSide &sd = blockIdx.z ? sb : sa;
   const uint32_t *row_ptr = sd.row_ptr, *col = sd.col, *wide = sd.wide;
@@ -393,7 +391,6 @@ static __global__ __launch_bounds__(64) void spmv_wide_kernel(SpmvSide sa, SpmvS
 // pos0 / pos1: the positions wanted (a shard: its range of h; otherwise 0 and 2^L)
 static __global__ void combine_h_kernel(const Fr *S, const Fr *D, Fr *h, const Fr *tw, int tlog, int L, Fr c1, Fr c2, uint32_t *zero, uint32_t zero_words,
                                         uint32_t pos0, uint32_t pos1) {
-  ZKR_PREP_SETPRIO();
   if (blockIdx.x == 0 && blockIdx.y == 0)  // see ingest_kernel: the counters of h's digit records
     for (uint32_t k = threadIdx.x; k < zero_words; k += blockDim.x) zero[k] = 0;
   uint32_t pos = pos0 + blockIdx.x * blockDim.x + threadIdx.x;

@@ -6,6 +6,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <vector>
 #include "../../include/zkr.h"
@@ -125,10 +126,7 @@ namespace zkr {
 // Everything one proof in flight owns: witness + calcH vectors, digit codes, the five MSM workspaces, its
 // events and timing spans.  A key has PROOF_SLOTS of them so that the GPU work of the next proof is enqueued
 // (zkr_prove_submit) while the host still assembles the previous one (zkr_prove_collect).
-#ifndef ZKR_PROOF_SLOTS
-#define ZKR_PROOF_SLOTS 2
-#endif
-constexpr int PROOF_SLOTS = ZKR_PROOF_SLOTS;
+constexpr int PROOF_SLOTS = 2;  // three measured the same (134.1 against 134.1 / 134.3 proofs/s, HISTORY.md 7b)
 constexpr int MAX_FUSE = 16;  // most proofs one launch set carries (zkr_key.hip fused_capacity)
 // Host witnesses (zkr_prove, zkr_prove_batch: the ArrayBuffer of binarifyWitness) reach the GPU through a ring of device
 // staging buffers, one more than there are proof slots: the witness of the NEXT proof crosses PCIe while both slots
@@ -136,7 +134,6 @@ constexpr int MAX_FUSE = 16;  // most proofs one launch set carries (zkr_key.hip
 // witnesses do.
 constexpr int STAGE_BUFS = PROOF_SLOTS + 1;
 struct WitnessStage {
-  void *h_pinned = nullptr;  // optional pinned bounce buffer (ZKR_STAGE_PINNED), nVars x 32 B x fused capacity
   Fr *d_w = nullptr;         // its device copy, read by ingest_kernel
   hipEvent_t ev_up = nullptr;
   bool busy = false;
@@ -153,7 +150,6 @@ struct ProofSlot {
   bool res_pending[N_TABLES] = {false, false, false, false, false};
   int cap = 1;    // proofs one submit can fuse into shared launches (small circuits; every buffer above is cap times one proof's)
   int nbat = 0;   // proofs of the group in flight
-  struct timespec t_submit = {0, 0};  // when the group's enqueue began (ZKR_TRACE_COLLECT)
   bool merged_ch = false;  // this group's H was accumulated onto C's bucket set: C's workspace holds C + H
   bool joint_ab = false;   // this group's A was accumulated behind B1's bucket sets and reduced with them in one chain: B1's workspace holds
                            // the results of both, B1's first (zkr_prove.hip prove_submit_enqueue)
@@ -180,7 +176,6 @@ struct zkr_key {
   hipStream_t prep_stream = nullptr;               // digit records, digit sorts, calcH
   hipStream_t red_stream[zkr::N_TABLES] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // reduction chains: [0] the G2 table, the G1 tables
                                                                                            // round-robin over [1..n_red)
-  bool own_streams = false;                        // ZKR_PRIVATE_STREAMS: this key made its streams itself and destroys them
   void *streams_owner = nullptr;                   // the DeviceStreams set (zkr_key.hip) the stream handles below come from
   std::mutex *enqueue_mu = nullptr;                // the device's enqueue lock (shared streams: one proof's launches are enqueued without interleaving)
   hipStream_t aux_stream = nullptr;                // = red_stream[n_all - 1]: C's oversized-bucket partial sums when C shares H's bucket set (zkr_prove.hip c_big)
@@ -189,10 +184,11 @@ struct zkr_key {
   zkr::ProofSlot slot[zkr::PROOF_SLOTS];
   int next_slot = 0;
   std::mutex mu;  // slot hand-out, the enqueue phase of a proof (so two host threads do not interleave launches), stage totals
-  std::mutex split_mu;  // a shard key: held by the sharded proof that splits calcH over it and its siblings (zkr_multi.hip run_sharded),
-                        // and by a shard proving on its own (zkr_prove_partial outside a split group)
-  std::atomic<int> split_checked{0};  // a shard key: 0 = the split calcH has not been compared with the replicated form on this shard set yet,
-                                      // 1 = compared, identical, 2 = it disagreed or failed: never split again (zkr_multi.hip run_sharded)
+  std::shared_mutex split_mu;  // a shard key: held EXCLUSIVELY by the sharded proof that splits calcH over it and its siblings (zkr_multi.hip
+                               // run_sharded), SHARED by a shard proving on its own (zkr_prove_partial outside a split group)
+  std::atomic<int> split_checked{0};  // a shard key: 0 = the split calcH has not been compared with the replicated form on this shard set yet
+                                      // (or the comparison could not be made: it is tried again), 1 = compared, identical, 2 = it DISAGREED:
+                                      // never split again (zkr_multi.hip run_sharded)
   int replica_mode = 0;        // how the key came to its device: 0 = loaded / built there, ZKR_REPLICATE_FULL / _BASE = zkr_key_replicate in that form
   bool replica_direct = false;  // ... and whether the two devices could address each other
   std::condition_variable slot_freed;

@@ -51,11 +51,8 @@ Fr host_root_of_unity(unsigned k) { return fr_root_of_unity(k); }
 // additions per chain step chip-wide, i.e. the threshold is n K nbat / 2^17, between twice and eight times the mean occupancy,
 // never below 64.  Round 3's rule (max(8 mean, 256)) left buckets of up to 256 entries to single lanes of SPARSE bucket sets: a
 // shard of a 2^22 key (mean 9) spent 4.9 ms in a G2 accumulation of 0.8 ms of work (profiles/r4_25_shard_big_threshold.txt).
-// ZKR_MSM_BIG_RULE=3: that rule; ZKR_MSM_BIG=<n>: a fixed threshold.
 uint32_t big_threshold(size_t n, int K, uint32_t nbw, int nbat) {
-  if (const char *e = getenv("ZKR_MSM_BIG")) { int v = atoi(e); if (v >= 1) return (uint32_t)v; }
   const uint64_t mean = (uint64_t)n * K / nbw + 1;
-  if (const char *e = getenv("ZKR_MSM_BIG_RULE"); e && atoi(e) == 3) return mean * 8 > 256 ? (uint32_t)(mean * 8) : 256u;
   const uint64_t by_bulk = ((uint64_t)n * K * (uint64_t)(nbat < 1 ? 1 : nbat)) >> 17;
   uint64_t thr = by_bulk < mean * 8 ? by_bulk : mean * 8;
   if (thr < 2 * mean) thr = 2 * mean;  // dense little bucket sets (tiny circuits): only real outliers leave the accumulation
@@ -76,7 +73,7 @@ MsmPlan msm_plan(size_t n_scalars, size_t n, int c_fixed) {
   // buckets: 1961 vs 2078 M multiplications per G1 table), but measured on the 2^24 rollup-shaped key it loses: 8.19 /
   // 7.50 proofs/s at c = 20 / 21, and at c = 22 the accumulation of a table takes 26.6 ms instead of 18 ms alone
   // (2 M bucket threads with short chains gather worse) and 3.5 -> 0.37 proofs/s with two proofs in flight; at 2^22
-  // the counts already tie (530 / 544 / 532 M).  ZKR_MSM_C overrides for experiments.
+  // the counts already tie (530 / 544 / 532 M).  ZKR_MSM_C overrides (a documented knob: window bits of keys built in this process).
   if (c > 20) c = 20;
   if (const char *e = getenv("ZKR_MSM_C")) { int v = atoi(e); if (v >= 2 && v <= 22) c = v; }
   if (c_fixed) c = c_fixed;
@@ -89,7 +86,6 @@ MsmPlan msm_plan(size_t n_scalars, size_t n, int c_fixed) {
   // fewer buckets the chip is not filled and the chain length is what counts: keep about 2^14 groups
   // (tx circuit, 2^16 buckets: 233 / 320 / 349 / 351 / 322 proofs/s at 32 / 16 / 8 / 4 / 2)
   int glog = c - 1 - 14 < 2 ? 2 : c - 1 - 14 > 5 ? 5 : c - 1 - 14;
-  if (const char *e = getenv("ZKR_MSM_GLOG")) { int v = atoi(e); if (v >= 1 && v <= 6) glog = v; }
   pl.glog = c - 1 < glog ? c - 1 : glog;
   pl.big_thresh = big_threshold(n, pl.K, pl.nbw, 1);
   // digit sort: one workgroup per (bucket range, chunk).  Ranges of 2048 buckets, chunks of ~3300 records: what counts is the
@@ -99,14 +95,12 @@ MsmPlan msm_plan(size_t n_scalars, size_t n, int c_fixed) {
   // kept 6.8 MB in flight per XCD and every line left L2 in pieces (WRITE_SIZE 386 MB per launch for 54 MB of entries, against
   // 98 MB now; kernel 159 -> 83 us; profiles/r3_ab_sort_ranges.md).
   uint32_t range_max = SORT_RANGE_DEFAULT;
-  if (const char *e = getenv("ZKR_SORT_NBL")) { uint32_t v = (uint32_t)atoi(e); if (v >= 64 && v <= SORT_RANGE_MAX && (v & (v - 1)) == 0) range_max = v; }
   if (pl.nbw / range_max > MAX_RANGES) range_max = pl.nbw / MAX_RANGES;
   pl.nbl = pl.nbw < range_max ? pl.nbw : range_max;
   pl.nR = pl.nbw / pl.nbl;
   uint64_t J64 = ((uint64_t)n * pl.K + (uint64_t)pl.nR * SORT_CHUNK_RECORDS - 1) / ((uint64_t)pl.nR * SORT_CHUNK_RECORDS);
   uint32_t J = J64 > 64 ? 64u : (uint32_t)J64;
   if (J < 1) J = 1;
-  if (const char *e = getenv("ZKR_MSM_J")) { int v = atoi(e); if (v >= 1 && v <= 256) J = (uint32_t)v; }
   pl.J = J;
   // reduction: every task sums ng/2 .. ng group results; one workgroup per 2048 of them, all tasks together at
   // most one workgroup per CU (msm_reduce3_kernel takes ntask * S <= MSM_THREADS partial sums)
@@ -217,7 +211,6 @@ int digit_lists_alloc(DigitLists &dl, size_t n_scalars, const MsmPlan &pl) {  //
 // stay at or below 2^20 elements, at most 16.
 int fused_capacity(const ArenaHeader &h, const MsmPlan plan[N_TABLES]) {
   if (h.shard_parts > 1) return 1;  // a shard multiplies a sub-range of one proof's vectors: nothing to lay end to end
-  if (const char *e = getenv("ZKR_FUSE")) { int v = atoi(e); if (v >= 1 && v <= MAX_FUSE) { uint32_t nr = 1; for (int t = 0; t < N_TABLES; t++) nr = plan[t].nR > nr ? plan[t].nR : nr; if ((uint32_t)v * nr <= MAX_RANGES) return v; } }
   uint32_t nr = 1;
   for (int t = 0; t < N_TABLES; t++) nr = plan[t].nR > nr ? plan[t].nR : nr;
   uint32_t cap = MAX_RANGES / nr;
@@ -260,7 +253,6 @@ static int make_streams(DeviceStreams &ds, int n_red) {
   // delay stalls it (the next sort, the proof's completion), so their workgroups are dispatched first.
   int prio_lo = 0, prio_hi = 0;
   ZKR_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));  // numerically lower = higher priority
-  if (getenv("ZKR_NO_PRIO")) prio_hi = prio_lo;
   if (!ds.accum) ZKR_HIP_CHECK(hipStreamCreateWithPriority(&ds.accum, hipStreamNonBlocking, prio_lo));
   if (!ds.prep) ZKR_HIP_CHECK(hipStreamCreateWithPriority(&ds.prep, hipStreamNonBlocking, prio_hi));
   for (int j = 0; j < n_red; j++)
@@ -279,19 +271,6 @@ int key_alloc_workspace(zkr_key *k) {
   // reduction streams: the chains of one proof add up to ~6 ms of serialised launches, so on a single in-order
   // stream they, not the accumulations, set the pace with two proofs in flight (94 vs 106 proofs/s with two)
   for (int t = 0; t < N_TABLES; t++) k->plan[t] = msm_plan(rank_entries(h, t), h.npts[t], (int)h.win_c[t]);
-  // experiment knob: reduction group size of the G2 table alone (its reduce1 chain is the longest of a proof)
-  if (const char *e = getenv("ZKR_MSM_GLOG_G2")) {
-    int v = atoi(e);
-    MsmPlan &pl = k->plan[T_B2];
-    if (v >= 1 && v <= 6 && v <= pl.c - 1) {
-      pl.glog = v;
-      uint32_t ng = pl.nbw >> pl.glog, ntask = (uint32_t)(pl.c - 1 - pl.glog) + 2;
-      uint32_t S = (ng + 2047) / 2048;
-      if (S > 16) S = 16;
-      if (S > MSM_THREADS / ntask) S = MSM_THREADS / ntask;
-      pl.S = S < 1 ? 1 : S;
-    }
-  }
   // Two reduction streams: the G2 chain on [0], the G1 chains one after the other on [1].  Round 2 ran circuits that fill the
   // chip alone with three (136.3 against 132.1 proofs/s at 2^20); since C and H share one chain and the G2 reductions take a
   // whole SIMD's registers, the third stream only adds contention for the accumulations: 152.5-153.5 against 145.9-146.6
@@ -300,13 +279,9 @@ int key_alloc_workspace(zkr_key *k) {
   // chains: 2^16 1745 against 1680, 2^17 943 against 910, 2^18 514 against 492, 2^19 237 against 231, the tx circuit 988
   // against 957 proofs/s).
   k->n_red = 2;
-  if (const char *e = getenv("ZKR_RED_STREAMS")) { int v = atoi(e); if (v >= 1 && v < N_TABLES) k->n_red = v; }
   {
     DeviceStreams *ds = nullptr;
-    k->own_streams = getenv("ZKR_PRIVATE_STREAMS") != nullptr;
-    if (k->own_streams) {
-      ds = new DeviceStreams();  // its mutex is this key's alone; freed with the key
-    } else {
+    {
       std::lock_guard<std::mutex> lk(g_streams_mu);
       DeviceStreams *&slot = g_streams[k->device];
       if (!slot) slot = new DeviceStreams();
@@ -317,7 +292,7 @@ int key_alloc_workspace(zkr_key *k) {
       std::lock_guard<std::mutex> lk(g_streams_mu);  // creation of missing streams of a shared set, one key at a time
       src = make_streams(*ds, k->n_red);
     }
-    if (src) { if (k->own_streams) delete ds; return src; }
+    if (src) return src;
     k->streams_owner = ds;
     k->enqueue_mu = &ds->enqueue_mu;
     k->stream = ds->accum;
@@ -474,7 +449,7 @@ int key_build(int device, uint32_t n, uint32_t p, uint32_t m, const std::vector<
       if (a == s) i++;
       if (c == s) j++;
     }
-    if (!u_sidx.empty() && both * 10 >= u_sidx.size() * 9 && !getenv("ZKR_NO_SHARE_AC")) {
+    if (!u_sidx.empty() && both * 10 >= u_sidx.size() * 9) {
       h.share_ac = 1;
       srcidx_eff[T_A] = &uA_src; srcidx_eff[T_C] = &uC_src;
       sidx_eff[T_A] = sidx_eff[T_C] = &u_sidx;
@@ -726,22 +701,16 @@ int zkr_key_load_websnark(const void *pk_bin, size_t pk_len, int device, zkr_key
 void zkr_key_free(zkr_key *k) {
   if (!k) return;
   hipSetDevice(k->device);
-  hipStream_t streams[2 + N_TABLES] = {k->stream, k->prep_stream, k->red_stream[0], k->red_stream[1], k->red_stream[2], k->red_stream[3], k->red_stream[4]};
-  if (k->own_streams) {
-    for (hipStream_t st : streams)
-      if (st) hipStreamSynchronize(st);
-  } else {
-    // shared streams (one set per device): wait for THIS key's work only -- the last events of its proof slots and staged
-    // uploads (an event that was never recorded is complete) -- not for the proofs other keys have in flight on the same streams
-    for (ProofSlot &sl : k->slot) {
-      for (auto e : sl.ev_red)
-        if (e) hipEventSynchronize(e);
-      for (int t = 0; t < N_TABLES; t++)
-        if (sl.ev_res[t]) hipEventSynchronize(sl.ev_res[t]);
-    }
-    for (WitnessStage &ws : k->stage)
-      if (ws.ev_up) hipEventSynchronize(ws.ev_up);
+  // the streams are the device's (one set per device, shared by its keys): wait for THIS key's work only -- the last events of its
+  // proof slots and staged uploads (an event that was never recorded is complete) -- not for the proofs other keys have in flight
+  for (ProofSlot &sl : k->slot) {
+    for (auto e : sl.ev_red)
+      if (e) hipEventSynchronize(e);
+    for (int t = 0; t < N_TABLES; t++)
+      if (sl.ev_res[t]) hipEventSynchronize(sl.ev_res[t]);
   }
+  for (WitnessStage &ws : k->stage)
+    if (ws.ev_up) hipEventSynchronize(ws.ev_up);
   for (ProofSlot &sl : k->slot) {
     for (int t = 0; t < N_TABLES; t++) {
       if (sl.ev_done[t]) hipEventDestroy(sl.ev_done[t]);
@@ -757,13 +726,7 @@ void zkr_key_free(zkr_key *k) {
     hipFree(sl.d_w); hipFree(sl.va); hipFree(sl.vb); hipFree(sl.ca); hipFree(sl.cb); hipFree(sl.d_h);
     for (auto e : sl.event_pool) hipEventDestroy(e);
   }
-  if (k->own_streams) {
-    for (hipStream_t st : streams)
-      if (st) hipStreamDestroy(st);
-    delete static_cast<DeviceStreams *>(k->streams_owner);
-  }
   for (WitnessStage &ws : k->stage) {
-    if (ws.h_pinned) hipHostFree(ws.h_pinned);
     if (ws.d_w) hipFree(ws.d_w);
     if (ws.ev_up) hipEventDestroy(ws.ev_up);
   }

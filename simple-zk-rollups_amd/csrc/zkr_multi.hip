@@ -241,12 +241,9 @@ int zkr_key_shard(const zkr_key *src, unsigned part, unsigned parts, int device,
   // table (3 entries each) and then walks four reduction chains over all of them -- the chains were 2/3 of such a shard's 4.1 ms.
   // At c = 17 it is an ordinary 2^17-point key (2^16 buckets).  The levels 2^(ck) P are then rebuilt from level 0 on the shard's
   // device (msm_precompute, as a key load does); tables whose window does not change are copied level by level.
-  // ZKR_SHARD_KEEP_WINDOW=1: always the whole key's windows.
-  const char *keep_env = getenv("ZKR_SHARD_KEEP_WINDOW");
-  const bool keep_window = keep_env && atoi(keep_env) != 0;
   bool rebuild[N_TABLES];
   for (int t = 0; t < N_TABLES; t++) {
-    const uint32_t c = keep_window ? sh.win_c[t] : (uint32_t)msm_plan(rank_entries(h, t), h.npts[t], 0).c;
+    const uint32_t c = (uint32_t)msm_plan(rank_entries(h, t), h.npts[t], 0).c;
     rebuild[t] = c != sh.win_c[t];
     h.win_c[t] = c;
   }
@@ -330,7 +327,7 @@ void drain_shards(zkr_key *const *shards, size_t parts) {
 // holds the shards' turns), else every shard computes h for itself.  *ran_split: whether the split really ran (false when a
 // thread could not be started).
 template <class Partial>
-int run_shards_once(zkr_key *const *shards, size_t parts, bool split, int klog, std::vector<uint8_t> &partials, Partial partial, bool *ran_split) {
+int run_shards_once(zkr_key *const *shards, size_t parts, bool split, int klog, std::vector<uint8_t> &partials, Partial partial, bool *ran_split, bool turns_held) {
   std::vector<int> rcs(parts, 0);
   std::vector<std::string> errs(parts);
   ShardGroup group;
@@ -342,7 +339,7 @@ int run_shards_once(zkr_key *const *shards, size_t parts, bool split, int klog, 
   auto work = [&](size_t i) {
     shard_group = group.split_h && threaded[i] ? &group : nullptr;  // a shard run inline after the others cannot meet them at a barrier
     shard_group_part = (unsigned)i;
-    shard_turn_held = split;  // the caller took every shard's turn for a split pass (also when the split is then given up: no thread)
+    shard_turn_held = turns_held;  // the caller holds every shard's turn (a split pass, also when the split is then given up: no thread; the first-use check's second pass)
     try {
       rcs[i] = partial(i, &partials[i * ZKR_PARTIAL_BYTES]);
       if (rcs[i]) errs[i] = zkr_last_error();
@@ -425,57 +422,67 @@ int run_sharded(zkr_key *const *shards, size_t parts, const uint8_t *r32, const 
       if (!peer_direct(shards[i]->device, shards[j]->device)) { ok = false; snprintf(why, sizeof(why), "no peer access from device %d to device %d", shards[i]->device, shards[j]->device); }
   const char *ce = getenv("ZKR_SHARD_SPLIT_CHECK");
   const int force_check = ce ? atoi(ce) : 0;  // 1: check although the shards share a device; 2: and pretend the forms disagreed (tests of the fallback)
-  int state = shards[0]->split_checked.load();
-  if (ok && policy == 2 && state == 2) { ok = false; snprintf(why, sizeof(why), "the split form failed its first-use check on these shards"); }
-  const bool check = ok && policy == 2 && state == 0 && (distinct || force_check);
   // A split calcH makes the shards' threads wait for one another INSIDE their enqueue, each holding its shard's lock: two such
-  // proofs on the same shards at once could wait for each other's locks for ever.  They take turns (locks in address order; a
-  // shard proving on its own -- zkr_prove_partial outside a split group -- takes its own shard's turn too).
-  std::vector<std::unique_lock<std::mutex>> turn;
+  // proofs on the same shards at once could wait for each other's locks for ever.  They take turns (locks in address order,
+  // exclusive; a shard proving on its own -- zkr_prove_partial outside a split group -- takes its own shard's turn shared).
+  std::vector<std::unique_lock<std::shared_mutex>> turn;
   if (ok) {
     std::vector<zkr_key *> order(shards, shards + parts);
     std::sort(order.begin(), order.end());
     for (zkr_key *k : order) turn.emplace_back(k->split_mu);
   }
+  // The state of the first-use check belongs to the shard SET: read under the turns (a concurrent first caller has finished its
+  // check by now) and over every shard -- a set that reuses a checked shard with new siblings is unchecked, one member that saw
+  // the forms disagree condemns the set.
+  int state = 1;
+  for (size_t i = 0; i < parts; i++) {
+    const int st = shards[i]->split_checked.load();
+    if (st == 2) { state = 2; break; }
+    if (st == 0) state = 0;
+  }
+  if (ok && policy == 2 && state == 2) { ok = false; turn.clear(); snprintf(why, sizeof(why), "the split form failed its first-use check on these shards (it disagreed with the replicated one)"); }
+  const bool check = ok && policy == 2 && state == 0 && (distinct || force_check);
   bool ran_split = false;
   int rc;
   if (check) {
-    // first use on these devices: the split form, then the replicated one; their sums must be the same group elements (compared
-    // through the proof both assemble with a fixed blinding -- the XYZZ coordinates of a sum depend on the order of additions)
+    // first use on these devices: the split form, then the replicated one (the turns stay held: nobody else starts on these shards
+    // in between); their sums must be the same group elements (compared through the proof both assemble with a fixed blinding --
+    // the XYZZ coordinates of a sum depend on the order of additions)
     std::vector<uint8_t> split_partials(parts * ZKR_PARTIAL_BYTES);
     uint8_t one[32] = {1}, pa[256], pb[256];
-    rc = run_shards_once(shards, parts, true, klog, split_partials, partial, &ran_split);
+    rc = run_shards_once(shards, parts, true, klog, split_partials, partial, &ran_split, true);
     double keep_ms[8][8];
     memcpy(keep_ms, last_split_phase_ms, sizeof(keep_ms));
     const bool split_ran = rc == 0 && ran_split;
-    turn.clear();  // the replicated pass: every shard takes its own turn
     bool dummy = false;
-    int rc2 = run_shards_once(shards, parts, false, klog, partials, partial, &dummy);
+    int rc2 = run_shards_once(shards, parts, false, klog, partials, partial, &dummy, true);
     if (rc2) return rc2;
-    bool same = false;
-    if (split_ran) {
-      if ((rc2 = zkr_prove_combine(shards[0], split_partials.data(), parts, one, one, pa))) return rc2;
-      if ((rc2 = zkr_prove_combine(shards[0], partials.data(), parts, one, one, pb))) return rc2;
+    // compared: the split pass ran and both sets of sums assemble; a pass that could not run (a transient HIP failure, no thread)
+    // or sums that do not assemble with r = s = 1 decide nothing -- the set stays unchecked and the next proof tries again
+    bool compared = false, same = false;
+    if (split_ran && zkr_prove_combine(shards[0], split_partials.data(), parts, one, one, pa) == 0 && zkr_prove_combine(shards[0], partials.data(), parts, one, one, pb) == 0) {
+      compared = true;
       same = memcmp(pa, pb, 256) == 0 && force_check != 2;
     }
-    if (rc == 0 && !ran_split) {
-      set_form(ZKR_SHARDED_REPLICATED_H, "replicated calcH: a shard's host thread could not be started");
-    } else {
+    if (compared) {
       for (size_t i = 0; i < parts; i++) shards[i]->split_checked.store(same ? 1 : 2);
       if (same) {
         memcpy(last_split_phase_ms, keep_ms, sizeof(keep_ms));
         last_split_parts = (unsigned)parts;
         set_form(ZKR_SHARDED_SPLIT_H, "split calcH: first use on devices %d..%d proved both ways, sums identical; proofs from now on split", shards[0]->device, shards[parts - 1]->device);
       } else {
-        fprintf(stderr, "zkr: sharded proof: the split calcH %s on first use over devices %d..%d -- every shard computes h for itself from now on (ZKR_SHARD_SPLIT_H=1 forces the split)\n",
-                split_ran ? "DISAGREED with the replicated form" : "failed", shards[0]->device, shards[parts - 1]->device);
-        set_form(ZKR_SHARDED_REPLICATED_H, "replicated calcH: the split form %s on first use over devices %d..%d", split_ran ? "disagreed with the replicated one" : "failed",
-                 shards[0]->device, shards[parts - 1]->device);
+        fprintf(stderr, "zkr: sharded proof: the split calcH DISAGREED with the replicated form on first use over devices %d..%d -- every shard computes h for itself from now on (ZKR_SHARD_SPLIT_H=1 forces the split)\n",
+                shards[0]->device, shards[parts - 1]->device);
+        set_form(ZKR_SHARDED_REPLICATED_H, "replicated calcH: the split form disagreed with the replicated one on first use over devices %d..%d", shards[0]->device, shards[parts - 1]->device);
       }
+    } else {
+      set_form(ZKR_SHARDED_REPLICATED_H, "replicated calcH: the split form's first-use check could not be made (%s); it is tried again with the next proof",
+               rc ? "the split pass failed" : !ran_split ? "a shard's host thread could not be started" : "the sums did not assemble");
     }
+    turn.clear();
     return zkr_prove_combine(shards[0], partials.data(), parts, r32, s32, proof_out);  // the replicated pass' sums either way
   }
-  rc = run_shards_once(shards, parts, ok, klog, partials, partial, &ran_split);
+  rc = run_shards_once(shards, parts, ok, klog, partials, partial, &ran_split, ok);
   if (rc) return rc;
   if (ran_split) set_form(ZKR_SHARDED_SPLIT_H, "split calcH: %s", policy == 1 ? "ZKR_SHARD_SPLIT_H=1" : distinct ? "checked against the replicated form on first use" : "all shards on one device");
   else set_form(ZKR_SHARDED_REPLICATED_H, "replicated calcH: %s", ok ? "a shard's host thread could not be started" : why);

@@ -122,14 +122,8 @@ int ntt_lds_check(int device) {
 }
 
 // Elements per workgroup: 2048 (NTT_TILE_LOG) for every transform.  Smaller tiles for small transforms -- a 2^17 transform cut into
-// tiles of 2048 is 64 workgroups, a quarter of the CUs -- were measured (ZKR_NTT_TILE_LOG=9 / 10: 512 / 1024 elements) and change
-// nothing: the wavefront count of a transform does not depend on the tile, and the single tx proof takes 2.00 / 2.04 / 1.97-2.02 ms
-// at 9 / 10 / 11 (profiles/r4_19_tx_single_ntt_tile.txt).  The knob stays for experiments (8..11).
-static int ntt_tile_log(int L, int nbat) {
-  (void)L; (void)nbat;
-  static const int env = getenv("ZKR_NTT_TILE_LOG") ? atoi(getenv("ZKR_NTT_TILE_LOG")) : 0;
-  return env >= 8 && env <= NTT_TILE_LOG ? env : NTT_TILE_LOG;
-}
+// tiles of 2048 is 64 workgroups, a quarter of the CUs -- were measured (512 / 1024 elements) and change nothing: the wavefront
+// count of a transform does not depend on the tile (a single tx proof 2.00 / 2.04 / 1.97-2.02 ms, profiles/r4_19_tx_single_ntt_tile.txt).
 
 // One transform, or TWO of the same shape in the same launches (in0_b / in1_b / out_b: gridDim.z = 2)
 // want_lo / want_n (DIF only; 0, 0 = everything): only positions [want_lo, want_lo + want_n) of the output are wanted -- the
@@ -137,8 +131,7 @@ static int ntt_tile_log(int L, int nbat) {
 int run_ntt(hipStream_t s, const Fr *in0, const Fr *in1, Fr *out, const NttTables &tb, int L, bool dif, bool inverse, int pre, int nbat, Prof pf,
             const Fr *in0_b, const Fr *in1_b, Fr *out_b, uint32_t want_lo, uint32_t want_n, uint32_t coset_shift, uint32_t coset_add) {
   if (want_n && (!dif || (uint64_t)want_lo + want_n > (1ull << L))) { set_error("run_ntt: an output range needs a DIF transform and must lie inside it"); return ZKR_ERR_ARG; }
-  const int tile_log = ntt_tile_log(L, nbat * (out_b ? 2 : 1));
-  std::vector<PassSpec> plan = ntt_plan(L, tile_log);
+  std::vector<PassSpec> plan = ntt_plan(L, NTT_TILE_LOG);
   if (!dif) std::reverse(plan.begin(), plan.end());
   bool first = true;
   for (auto &ps : plan) {
@@ -157,8 +150,7 @@ int run_ntt(hipStream_t s, const Fr *in0, const Fr *in1, Fr *out, const NttTable
     // wave priority 1 for the NTT passes: with the 29-bit-limb accumulations the preparation chain (sorts + calcH) became
     // the stream that paces two proofs in flight (its kernels starved behind the accumulation's wavefronts: 4.1 ms of NTT
     // spans per proof at priority 0, 2.9 ms at 1; 120.9 -> 125.2 proofs/s; 2 and 3 measure the same as 1)
-    static const int ntt_prio = getenv("ZKR_NTT_PRIO") ? atoi(getenv("ZKR_NTT_PRIO")) : 1;
-    a.prio = ntt_prio;
+    a.prio = 1;
     uint32_t tile = 1u << (ps.hi - ps.lo + ps.wlog);
     uint32_t grid = (1u << L) / tile;
     a.blk_off = 0;
@@ -169,10 +161,9 @@ int run_ntt(hipStream_t s, const Fr *in0, const Fr *in1, Fr *out, const NttTable
       grid = (q1 - q0) * per_block;
     }
     size_t lds = (size_t)tile * 36;  // 9 limbs per element
-    // workgroup size by transform size (kernels_ntt.hpp NTT_THREADS_*); ZKR_NTT_THREADS=256|512 overrides for experiments
-    static const int thr_env = getenv("ZKR_NTT_THREADS") ? atoi(getenv("ZKR_NTT_THREADS")) : 0;
-    // a tile of 1024 elements has 256 four-element butterfly groups per double stage: 256 threads
-    const int threads = thr_env == NTT_THREADS_SMALL || thr_env == NTT_THREADS_LARGE ? thr_env : (L >= NTT_LARGE_LOG || tile <= 1024) ? NTT_THREADS_LARGE : NTT_THREADS_SMALL;
+    // workgroup size by transform size (kernels_ntt.hpp NTT_THREADS_*); a tile of 1024 elements has 256 four-element butterfly
+    // groups per double stage: 256 threads
+    const int threads = (L >= NTT_LARGE_LOG || tile <= 1024) ? NTT_THREADS_LARGE : NTT_THREADS_SMALL;
 #define ZKR_NTT_LAUNCH(DIF, INV, T) ntt_pass_kernel<DIF, INV, T><<<dim3(grid, nbat, out_b ? 2 : 1), T, lds, s>>>(a)
 #define ZKR_NTT_LAUNCH_T(T) do { if (dif) { if (inverse) ZKR_NTT_LAUNCH(true, true, T); else ZKR_NTT_LAUNCH(true, false, T); } \
                                  else { if (inverse) ZKR_NTT_LAUNCH(false, true, T); else ZKR_NTT_LAUNCH(false, false, T); } } while (0)
@@ -221,28 +212,15 @@ int calc_h_device(zkr_key *k, ProofSlot &sl, hipStream_t s, int nbat) {
   int rc;
   // The six transforms come in three pairs of the same shape, each pair in ONE set of launches (gridDim.z = 2):
   // coefficients of a and b (x m, bit-reversed), then their evaluations on the coset g*w^c (x m, natural),
-  static const bool no_pair = getenv("ZKR_NTT_NO_PAIR") != nullptr;  // A/B: the six transforms one after the other, as in round 3
   // A shard multiplies only positions [sc_lo, sc_lo + sc_n) of h (bit-reversed order, as the H table is laid out): the last pair of
   // transforms -- inverse DIF, whose passes below the top one stay inside aligned blocks -- and the combination run on the
   // blocks that cover that range only (at 2^22: 16 of 22 stages of two of the six transforms on 1/8 of the vector for 8 shards).
-  // ZKR_SHARD_FULL_H=1: the whole of h on every shard, as before.
-  const char *full_env = getenv("ZKR_SHARD_FULL_H");  // read per call: tests switch it within one process
-  const bool full_h = full_env && atoi(full_env) != 0;
-  const bool ranged = h.shard_parts > 1 && !full_h && !no_pair && h.sc_n[1] < m;
+  const bool ranged = h.shard_parts > 1 && h.sc_n[1] < m;
   const uint32_t h_lo = ranged ? h.sc_lo[1] : 0, h_n = ranged ? h.sc_n[1] : 0;
-  if (no_pair) {
-    if ((rc = run_ntt(s, sl.va, nullptr, sl.ca, tb, L, true, true, PRE_NONE, nbat, pf))) return rc;
-    if ((rc = run_ntt(s, sl.vb, nullptr, sl.cb, tb, L, true, true, PRE_NONE, nbat, pf))) return rc;
-    if ((rc = run_ntt(s, sl.ca, nullptr, sl.ca, tb, L, false, false, PRE_COSET, nbat, pf))) return rc;
-    if ((rc = run_ntt(s, sl.cb, nullptr, sl.cb, tb, L, false, false, PRE_COSET, nbat, pf))) return rc;
-    if ((rc = run_ntt(s, sl.ca, sl.cb, sl.ca, tb, L, true, true, PRE_MUL, nbat, pf))) return rc;
-    if ((rc = run_ntt(s, sl.va, sl.vb, sl.va, tb, L, true, true, PRE_MUL, nbat, pf))) return rc;
-  } else {
-    if ((rc = run_ntt(s, sl.va, nullptr, sl.ca, tb, L, true, true, PRE_NONE, nbat, pf, sl.vb, nullptr, sl.cb))) return rc;
-    if ((rc = run_ntt(s, sl.ca, nullptr, sl.ca, tb, L, false, false, PRE_COSET, nbat, pf, sl.cb, nullptr, sl.cb))) return rc;
-    // then D' = iNTT(A(gw^c).B(gw^c)) and S' = iNTT(a.b), both unscaled and bit-reversed
-    if ((rc = run_ntt(s, sl.ca, sl.cb, sl.ca, tb, L, true, true, PRE_MUL, nbat, pf, sl.va, sl.vb, sl.va, h_lo, h_n))) return rc;
-  }
+  if ((rc = run_ntt(s, sl.va, nullptr, sl.ca, tb, L, true, true, PRE_NONE, nbat, pf, sl.vb, nullptr, sl.cb))) return rc;
+  if ((rc = run_ntt(s, sl.ca, nullptr, sl.ca, tb, L, false, false, PRE_COSET, nbat, pf, sl.cb, nullptr, sl.cb))) return rc;
+  // then D' = iNTT(A(gw^c).B(gw^c)) and S' = iNTT(a.b), both unscaled and bit-reversed
+  if ((rc = run_ntt(s, sl.ca, sl.cb, sl.ca, tb, L, true, true, PRE_MUL, nbat, pf, sl.va, sl.vb, sl.va, h_lo, h_n))) return rc;
   // constants: S' = m S / R, D' = m^3 D g^i / R  ->  h = S'*R^2/(2m) (*1/R)  -  D' g^-i * R^2/(2 m^3) (*1/R)
   Fr r2 = Fr::r2();
   Fr minv = inv(to_mont(fr_from_u64(m)));        // Montgomery(1/m)
@@ -417,24 +395,8 @@ static int calc_h_split_phases(zkr_key *k, ProofSlot &sl, hipStream_t s, ShardGr
 
 // ------------------------------------------------------------------ MSM driver
 template <class F> struct MsmCfg;
-#ifndef ZKR_RED_W_G1
-#define ZKR_RED_W_G1 2
-#endif
-template <> struct MsmCfg<Fq> { static constexpr int ACC_W = 2, RED_W = ZKR_RED_W_G1; static constexpr bool ACC_PREFETCH = true; static constexpr const char *ACC_STAGE = "msm_accum_g1"; };
-// RED_W = minimum wavefronts per SIMD the oversized-bucket and reduction kernels are compiled for, i.e. their register
-// ceiling (512 / RED_W): they are few long-running wavefronts that must find room on SIMDs whose register file two
-// accumulation wavefronts already fill to 2 x 156 of 512 (G1).  Unconstrained, the G2 forms take ~400 VGPRs on the
-// 29-bit-limb arithmetic and cannot co-reside: they wait for a CU to drain instead of running under the accumulation
-// (116.7 proofs/s).  Measured with the budget for 1 / 2 / 3 wavefronts per SIMD once the NTT priority was in place:
-// 132.9 / 133.1 / 129.6 proofs/s (at 3 the spills of the Fq2 running sums cost more than the co-residency buys).
-// Round 3: 1 -- at one wavefront per SIMD the Fq2 forms keep everything in registers (arch + accumulation VGPRs: 314-394, no
-// scratch in reduce1 / reduce2 / big / big_finish, where the budget for two left 496 / 192 / 196 / 208 B per lane spilled);
-// proof rate, tx-circuit rate and single-proof latencies are the same either way in same-box runs (141.6 / 140.7 against
-// 140.6 / 141.5 proofs/s, 2.28 against 2.27 ms, 8.50 against 8.52 ms), so the variant without the scratch traffic ships.
-#ifndef ZKR_RED_W_G2
-#define ZKR_RED_W_G2 1
-#endif
-template <> struct MsmCfg<Fq2> { static constexpr int ACC_W = 2, RED_W = ZKR_RED_W_G2; static constexpr bool ACC_PREFETCH = false;  // a second 128-byte point in flight only costs spills (same speed)
+template <> struct MsmCfg<Fq> { static constexpr int ACC_W = 2, SPLIT_W = 2; static constexpr bool ACC_PREFETCH = true; static constexpr const char *ACC_STAGE = "msm_accum_g1"; };
+template <> struct MsmCfg<Fq2> { static constexpr int ACC_W = 2, SPLIT_W = 1; static constexpr bool ACC_PREFETCH = false;  // a second 128-byte point in flight only costs spills (same speed)
   static constexpr const char *ACC_STAGE = "msm_accum_g2"; };
 
 // digit records of one scalar vector, split by bucket range; shared by every table over those scalars
@@ -449,15 +411,12 @@ static int msm_digits_enqueue(Prof pf, hipStream_t s, const Fr *scalars, uint32_
   int sp = prof_begin(pf, s, "msm_sort");
   if (!cleared) ZKR_HIP_CHECK(hipMemsetAsync(dl.rng, 0, DIGIT_CLEAR_WORDS * 4, s));
   // scalars per thread (kernels_msm.hpp, stage 1): four from 2^18 scalars on; the staged scatter takes what its LDS stage holds
-  static const int spt_env = getenv("ZKR_DIGITS_SPT") ? atoi(getenv("ZKR_DIGITS_SPT")) : 0;
-  static const bool no_stage = getenv("ZKR_DIGITS_NO_STAGE") != nullptr;  // A/B: records written in arrival order
-  int spt = spt_env >= 1 && spt_env <= 16 ? spt_env : n >= (1u << 18) ? 4 : n >= (1u << 17) ? 2 : 1;
+  int spt = n >= (1u << 18) ? 4 : n >= (1u << 17) ? 2 : 1;
   const uint32_t per_scalar = (uint32_t)pl.K * MSM_THREADS;
-  const bool staged = !no_stage && per_scalar <= DIGIT_STAGE;
+  const bool staged = per_scalar <= DIGIT_STAGE;
   if (staged && (uint32_t)spt * per_scalar > DIGIT_STAGE) spt = (int)(DIGIT_STAGE / per_scalar);
   unsigned grid = (n + MSM_THREADS * spt - 1) / (MSM_THREADS * spt);
-  static const bool no_spread = getenv("ZKR_NO_TOP_SPREAD") != nullptr;  // A/B: the top window as it falls (DigitIter)
-  const uint32_t tmax = no_spread ? 0u : digit_spread_tmax(pl.c, pl.K);
+  const uint32_t tmax = digit_spread_tmax(pl.c, pl.K);
   uint32_t *cnt = dl.rng, *fill = dl.rng + DIGIT_XCDS * MAX_RANGES, *off = dl.rng + 2 * DIGIT_XCDS * MAX_RANGES;
   msm_digits_count_kernel<<<grid, MSM_THREADS, 0, s>>>(scalars, n, n_per, pl.c, pl.K, nbl_log, pl.nR, nR, cnt, tmax, spt);
   if (staged) msm_digits_scatter_kernel<true><<<grid, MSM_THREADS, (size_t)DIGIT_STAGE * 8, s>>>(scalars, n, n_per, pl.c, pl.K, nbl_log, pl.nR, nR, cnt, fill, off, dl.ent_s, dl.ent_b, tmax, spt);
@@ -477,35 +436,20 @@ static int msm_sort_enqueue(Prof pf, hipStream_t s, const uint32_t *rank, const 
   const size_t lds = (size_t)pl.nbl * 4;
   const uint32_t *rng_off = dl.rng + 2 * DIGIT_XCDS * MAX_RANGES;
   const unsigned scan_blocks = (nb + SCAN_BLOCK - 1) / SCAN_BLOCK;
-  // Seven launches per table: histogram (whose first workgroup clears what the others accumulate into), column scan, three-launch
-  // scan (+ oversized-bucket list + size classes), ordering, scatter.  ZKR_SORT_LEGACY=1: the nine of round 3 (two memsets in
-  // front) for same-box comparisons.
-  static const bool legacy = getenv("ZKR_SORT_LEGACY") != nullptr;
-  // Default: the separate scan launches with the counters cleared by the histogram kernel (seven launches).  ZKR_SORT_FUSED_SCAN=1:
-  // column scan + single-pass look-back scan in one launch (four launches per sort) -- measured equal within the run-to-run spread on
-  // every rate and latency (profiles/r4_ab_prep_chain.txt: the proof is bound by its VALU work, not by the launch count of the
-  // preparation chain) with a larger stage sum (a tile's column scan has fewer threads in flight), so the simpler kernels ship.
-  static const bool split_scan = getenv("ZKR_SORT_FUSED_SCAN") == nullptr;
-  const SortScratch scratch{ws.big_count, ws.size_hist, (unsigned long long *)ws.block_sums, scan_blocks};
+  // Seven launches per table: histogram (whose first workgroup clears what the later ones accumulate into), column scan, three-launch
+  // scan (+ oversized-bucket list + size classes), ordering, scatter.  A single-pass look-back scan in one launch (four launches per
+  // sort) measured equal within the run-to-run spread on every rate and latency with a larger stage sum (a tile's column scan has
+  // fewer threads in flight; profiles/r4_ab_prep_chain.txt: the proof is bound by its VALU work, not by the launch count of the
+  // preparation chain), so the simpler kernels ship.
   const uint32_t big_thresh = nbat > 1 ? big_threshold(n, pl.K, pl.nbw, nbat) : pl.big_thresh;  // a fused launch's bulk is nbat proofs long
-  if (legacy || split_scan) {
-    if (legacy) {
-      ZKR_HIP_CHECK(hipMemsetAsync(ws.big_count, 0, 12, s));
-      ZKR_HIP_CHECK(hipMemsetAsync(ws.size_hist, 0, 2 * SIZE_BINS * 4, s));
-    }
-    msm_hist_kernel<<<sort_grid, SORT_THREADS, lds, s>>>(dl.ent_s, dl.ent_b, rng_off, rank, n_scalars, pl.nbl, pl.J, ws.chunk_cnt, legacy ? SortScratch{nullptr, nullptr, nullptr, 0} : SortScratch{ws.big_count, ws.size_hist, (unsigned long long *)ws.block_sums, 0});
-    msm_colscan_kernel<<<(nb + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, s>>>(ws.chunk_cnt, nb, pl.nbl, pl.J, ws.counts);
-    msm_scan_sums_kernel<<<scan_blocks, SCAN_THREADS, 0, s>>>(ws.counts, nb, ws.block_sums);
-    msm_scan_top_kernel<<<1, 1024, 0, s>>>(ws.block_sums, scan_blocks, ws.big_count + 1);
-    msm_scan_apply_kernel<<<scan_blocks, SCAN_THREADS, 0, s>>>(ws.counts, ws.block_sums, ws.big_count + 1, ws.offsets, nb, big_thresh,
-                                                              ws.big_list, ws.big_count, BIG_CAP, ws.size_hist);
-  } else {
-    msm_hist_kernel<<<sort_grid, SORT_THREADS, lds, s>>>(dl.ent_s, dl.ent_b, rng_off, rank, n_scalars, pl.nbl, pl.J, ws.chunk_cnt, scratch);
-    msm_scan_fused_kernel<<<scan_blocks, SCANF_THREADS, 0, s>>>(ws.chunk_cnt, nb, pl.nbl, pl.J, ws.counts, ws.offsets, big_thresh, ws.big_list, BIG_CAP, scratch);
-  }
+  msm_hist_kernel<<<sort_grid, SORT_THREADS, lds, s>>>(dl.ent_s, dl.ent_b, rng_off, rank, n_scalars, pl.nbl, pl.J, ws.chunk_cnt, SortScratch{ws.big_count, ws.size_hist});
+  msm_colscan_kernel<<<(nb + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, s>>>(ws.chunk_cnt, nb, pl.nbl, pl.J, ws.counts);
+  msm_scan_sums_kernel<<<scan_blocks, SCAN_THREADS, 0, s>>>(ws.counts, nb, ws.block_sums);
+  msm_scan_top_kernel<<<1, 1024, 0, s>>>(ws.block_sums, scan_blocks, ws.big_count + 1);
+  msm_scan_apply_kernel<<<scan_blocks, SCAN_THREADS, 0, s>>>(ws.counts, ws.block_sums, ws.big_count + 1, ws.offsets, nb, big_thresh,
+                                                            ws.big_list, ws.big_count, BIG_CAP, ws.size_hist);
   msm_order_kernel<<<scan_blocks, SCAN_THREADS, 0, s>>>(ws.counts, nb, ws.size_hist, ws.size_hist + SIZE_BINS, ws.order);
-  static const int xcd_map = getenv("ZKR_SORT_XCD") ? atoi(getenv("ZKR_SORT_XCD")) : 1;
-  msm_scatter_kernel<<<sort_grid, SORT_THREADS, lds, s>>>(dl.ent_s, dl.ent_b, rng_off, rank, n_scalars, n, pl.nbl, pl.J, ws.chunk_cnt, ws.offsets, ws.entries, xcd_map);
+  msm_scatter_kernel<<<sort_grid, SORT_THREADS, lds, s>>>(dl.ent_s, dl.ent_b, rng_off, rank, n_scalars, n, pl.nbl, pl.J, ws.chunk_cnt, ws.offsets, ws.entries);
   prof_end(pf, s, sp);
   ZKR_HIP_CHECK(hipGetLastError());
   return 0;
@@ -541,8 +485,10 @@ static int msm_accum_enqueue(Prof pf, hipStream_t s, int nbat, const AccumTable<
     if (split > 1) {
       const unsigned sgrid = (unsigned)(((size_t)nb * split + ACC_THREADS - 1) / ACC_THREADS);
       int ssp = prof_begin(pf, s, MsmCfg<F>::ACC_STAGE);
-      if (split == 2) msm_accum_split_kernel<F, MsmCfg<F>::ACC_W, 2><<<sgrid, ACC_THREADS, 0, s>>>(t.pts, t.srt->offsets, t.srt->entries, nb, t.srt->counts, t.srt->order, (XYZZ<F> *)t.buckets, t.onto);
-      else msm_accum_split_kernel<F, MsmCfg<F>::ACC_W, 4><<<sgrid, ACC_THREADS, 0, s>>>(t.pts, t.srt->offsets, t.srt->entries, nb, t.srt->counts, t.srt->order, (XYZZ<F> *)t.buckets, t.onto);
+      // (the Fq2 form is built for ONE wavefront per SIMD: its lane exchange holds two XYZZ points of 72 words, and the budget for
+      // two spilled 170-200 B per lane; a tx proof measures the same either way, profiles/r4_11_tx_single_split_w_g2.txt)
+      if (split == 2) msm_accum_split_kernel<F, MsmCfg<F>::SPLIT_W, 2><<<sgrid, ACC_THREADS, 0, s>>>(t.pts, t.srt->offsets, t.srt->entries, nb, t.srt->counts, t.srt->order, (XYZZ<F> *)t.buckets, t.onto);
+      else msm_accum_split_kernel<F, MsmCfg<F>::SPLIT_W, 4><<<sgrid, ACC_THREADS, 0, s>>>(t.pts, t.srt->offsets, t.srt->entries, nb, t.srt->counts, t.srt->order, (XYZZ<F> *)t.buckets, t.onto);
       prof_end(pf, s, ssp);
       continue;
     }
@@ -574,7 +520,7 @@ template <class F>
 static int msm_big_enqueue(Prof pf, hipStream_t s, const Affine<F> *pts, uint32_t n, const MsmPlan &pl, const MsmWorkspace &srt, MsmWorkspace &ws) {
   if (n == 0) return 0;
   int sp = prof_begin(pf, s, "msm_big");
-  msm_big_kernel<F, MsmCfg<F>::RED_W><<<BIG_SLOTS * BIG_SPLIT, MSM_THREADS, MSM_THREADS * sizeof(XYZZ<F>), s>>>(pts, srt.offsets, srt.entries, srt.big_list, srt.big_count,
+  RedKernels<F>::big<<<BIG_SLOTS * BIG_SPLIT, MSM_THREADS, MSM_THREADS * sizeof(XYZZ<F>), s>>>(pts, srt.offsets, srt.entries, srt.big_list, srt.big_count,
                                                                                                              BIG_CAP, (XYZZ<F> *)ws.big_partials);
   prof_end(pf, s, sp);
   ZKR_HIP_CHECK(hipGetLastError());
@@ -586,7 +532,7 @@ template <class F>
 static int msm_big_finish_enqueue(Prof pf, hipStream_t s, uint32_t n, const MsmWorkspace &srt, MsmWorkspace &ws, bool onto = false) {
   if (n == 0) return 0;
   int sp = prof_begin(pf, s, "msm_big");
-  msm_big_finish_kernel<F, MsmCfg<F>::RED_W><<<BIG_CAP / 64, 64, 0, s>>>((const XYZZ<F> *)ws.big_partials, srt.big_list, srt.big_count, BIG_CAP, (XYZZ<F> *)ws.buckets, onto ? 1 : 0);
+  RedKernels<F>::big_finish<<<BIG_CAP / 64, 64, 0, s>>>((const XYZZ<F> *)ws.big_partials, srt.big_list, srt.big_count, BIG_CAP, (XYZZ<F> *)ws.buckets, onto ? 1 : 0);
   prof_end(pf, s, sp);
   ZKR_HIP_CHECK(hipGetLastError());
   return 0;
@@ -636,9 +582,9 @@ static int msm_reduce_enqueue(Prof pf, hipStream_t s, uint32_t n, int nbat, int 
   int sp = prof_begin(pf, s, "msm_reduce");
   uint32_t ngroups = (pl.nbw >> glog) * (uint32_t)nset;
   uint32_t ntask = (uint32_t)(pl.c - 1 - glog) + 2;
-  msm_reduce1_kernel<F, MsmCfg<F>::RED_W><<<(ngroups + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, s>>>((const XYZZ<F> *)ws.buckets, g, (XYZZ<F> *)ws.group_out);
-  msm_reduce2_kernel<F, MsmCfg<F>::RED_W><<<dim3(ntask * S, nset), MSM_THREADS, MSM_THREADS * sizeof(XYZZ<F>), s>>>((const XYZZ<F> *)ws.group_out, g, (XYZZ<F> *)ws.task_out);
-  msm_reduce3_kernel<F, MsmCfg<F>::RED_W><<<nset, MSM_THREADS, MSM_THREADS * sizeof(XYZZ<F>), s>>>((const XYZZ<F> *)ws.task_out, g, (XYZZ<F> *)ws.result);
+  RedKernels<F>::reduce1<<<(ngroups + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, reduce1_lds_bytes<F>(), s>>>((XYZZ<F> *)ws.buckets, g, (XYZZ<F> *)ws.group_out);
+  RedKernels<F>::reduce2<<<dim3(ntask * S, nset), MSM_THREADS, MSM_THREADS * sizeof(XYZZ<F>), s>>>((const XYZZ<F> *)ws.group_out, g, (XYZZ<F> *)ws.task_out);
+  RedKernels<F>::reduce3<<<nset, MSM_THREADS, MSM_THREADS * sizeof(XYZZ<F>), s>>>((const XYZZ<F> *)ws.task_out, g, (XYZZ<F> *)ws.result);
   prof_end(pf, s, sp);
   ZKR_HIP_CHECK(hipMemcpyAsync(ws.h_result, ws.result, sizeof(XYZZ<F>) * nset, hipMemcpyDeviceToHost, s));
   ZKR_HIP_CHECK(hipGetLastError());
@@ -731,7 +677,6 @@ static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *const *d_ws
     }
   }
   sl.nbat = nbat;
-  clock_gettime(CLOCK_MONOTONIC, &sl.t_submit);
   // The streams are the device's, shared by every key on it (zkr_key.hip DeviceStreams): the launches of one proof are enqueued
   // without another key's in between, so that every cross-stream wait below points at work enqueued before it
   std::unique_lock<std::mutex> enqueue_lock(*k->enqueue_mu);
@@ -930,7 +875,15 @@ static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *const *d_ws
   if ((rc = msm_digits_enqueue(pf, sp, sl.d_h + h.sc_lo[1], h.sc_n[1], nbat, k->plan[T_H], sl.dig_h, true))) return rc;
   if ((rc = sort_table(T_H))) return rc;
   // accumulations + reduction chains: B2 first (its chain is the longest), then the three G1 tables of the witness in ONE launch, then H
-  if (!early && ((rc = c_big()) || (rc = accum_group({T_B2})) || (rc = accum_group({T_B1, T_A, T_C})))) return rc;
+  static const int exp_merge = getenv("ZKR_EXP_MERGE") ? atoi(getenv("ZKR_EXP_MERGE")) : 3;  // TEMPORARY (round-6 A/B): 3 = B1 + A + C, 2 = B1 + A | C, 1 = B1 | A + C, 0 = one launch per table
+  if (!early) {
+    if ((rc = c_big()) || (rc = accum_group({T_B2}))) return rc;
+    if (exp_merge == 3) rc = accum_group({T_B1, T_A, T_C});
+    else if (exp_merge == 2) { if (!(rc = accum_group({T_B1, T_A}))) rc = accum_group({T_C}); }
+    else if (exp_merge == 1) { if (!(rc = accum_group({T_B1}))) rc = accum_group({T_A, T_C}); }
+    else { if (!(rc = accum_group({T_B1})) && !(rc = accum_group({T_A}))) rc = accum_group({T_C}); }
+    if (rc) return rc;
+  }
   if ((rc = accum_group({T_H}))) return rc;
   // completion = every reduction stream done (prove_collect waits for the events on the host).  No stream is made
   // to wait for another, so nothing of the next proof queues behind this one's tail.
@@ -1015,11 +968,7 @@ static int prove_collect(zkr_key *k, ProofSlot &sl, uint8_t *proofs_out, Partial
     return 0;
   };
   int rcw;
-  static const bool trace = getenv("ZKR_TRACE_COLLECT") != nullptr;
-  struct timespec ts0, ts1, ts2, ts3, ts4;
-  if (trace) clock_gettime(CLOCK_MONOTONIC, &ts0);
   if ((rcw = wait_table(T_A)) || (rcw = wait_table(T_B1)) || (rcw = wait_table(T_B2))) return rcw;
-  if (trace) clock_gettime(CLOCK_MONOTONIC, &ts1);
   std::vector<G1XYZZ> pic_part((size_t)sl.nbat);
   int status = 0;
   for (int j = 0; j < sl.nbat; j++) {
@@ -1031,9 +980,7 @@ static int prove_collect(zkr_key *k, ProofSlot &sl, uint8_t *proofs_out, Partial
     int rc = assemble_ab(k, A, B1, B2, &sl.rb[32 * j], &sl.sb[32 * j], proofs_out + 256 * j, pic_part[j]);
     if (rc) status = rc;
   }
-  if (trace) clock_gettime(CLOCK_MONOTONIC, &ts2);
   if ((rcw = wait_table(T_C)) || (rcw = wait_table(T_H))) return rcw;
-  if (trace) clock_gettime(CLOCK_MONOTONIC, &ts3);
   for (int j = 0; j < (serial_mode ? 1 : k->n_all); j++) ZKR_HIP_CHECK(hipEventSynchronize(sl.ev_red[j]));  // every stream of the slot is idle (all of it precedes the table events)
   if (k->prof_on) { std::lock_guard<std::mutex> lk(k->mu); prof_collect(k, sl); }
   for (int j = 0; j < sl.nbat && !status; j++) {
@@ -1042,12 +989,6 @@ static int prove_collect(zkr_key *k, ProofSlot &sl, uint8_t *proofs_out, Partial
     G1XYZZ H = sl.merged_ch ? G1XYZZ::inf() : msm_finish<Fq>(h.npts[T_H], sl.ws[T_H], j);
     if (partials_out) { partials_out[j].CH = add_full(C, H); continue; }
     status = assemble_c(add_full(C, H), pic_part[j], proofs_out + 256 * j);
-  }
-  if (trace) {
-    clock_gettime(CLOCK_MONOTONIC, &ts4);
-    auto us = [](const timespec &a, const timespec &b) { return (b.tv_sec - a.tv_sec) * 1e6 + (b.tv_nsec - a.tv_nsec) * 1e-3; };
-    fprintf(stderr, "collect: submit->collect %.0f us, wait A/B %.0f us, host phase 1 %.0f us, wait C/H %.0f us, host phase 2 %.0f us\n",
-            us(sl.t_submit, ts0), us(ts0, ts1), us(ts1, ts2), us(ts2, ts3), us(ts3, ts4));
   }
   if (status) { set_error("degenerate proof element (point at infinity)"); return status; }
   return 0;
@@ -1068,7 +1009,6 @@ static int stage_acquire(zkr_key *k, int *idx, bool wait = true) {
         const size_t bytes = (size_t)k->h.n * 32 * (size_t)k->slot[0].cap;  // one fused group of witnesses
         if (!ws.ev_up) ZKR_HIP_CHECK(hipEventCreateWithFlags(&ws.ev_up, hipEventDisableTiming));
         ZKR_HIP_CHECK(hipMalloc(&ws.d_w, bytes));  // last: a stage with d_w set is complete
-        if (getenv("ZKR_STAGE_PINNED") && hipHostMalloc(&ws.h_pinned, bytes, hipHostMallocDefault) != hipSuccess) ws.h_pinned = nullptr;
       }
       ws.busy = true;
       *idx = i;
@@ -1086,16 +1026,12 @@ static void stage_release(zkr_key *k, int idx) {
 // The copy goes on the key's preparation stream (a fifth stream would share one of the four hardware queues with the
 // accumulation or a reduction stream and serialise with it: 448 -> 365 proofs/s on the tx circuit when tried).  Default:
 // hipMemcpyAsync straight from the caller's pageable buffer -- the runtime pins the pages and DMAs from them, about 0.5 ms
-// for 32 MB, blocking only this caller thread and, unlike round 1, outside the key's lock.  ZKR_STAGE_PINNED=1: copy into
-// the stage's own pinned buffer first (2-3 ms of memcpy per 32 MB on one thread; slower for a single caller: 79.9 vs 93.9
-// proofs/s at 2^20), kept for hosts where pinning user pages on the fly is slow.
+// for 32 MB, blocking only this caller thread and, unlike round 1, outside the key's lock.  (A copy into a pinned bounce buffer
+// first -- 2-3 ms of memcpy per 32 MB on one thread -- was slower for a single caller: 79.9 against 93.9 proofs/s at 2^20.)
 static int stage_upload(zkr_key *k, int idx, int j, const void *witness_std, size_t len, bool last) {
   WitnessStage &ws = k->stage[idx];
   ZKR_HIP_CHECK(hipSetDevice(k->device));
-  static const bool via_pinned = getenv("ZKR_STAGE_PINNED") != nullptr;
-  const void *src = witness_std;
-  if (via_pinned && ws.h_pinned) { memcpy((uint8_t *)ws.h_pinned + (size_t)j * len, witness_std, len); src = (uint8_t *)ws.h_pinned + (size_t)j * len; }
-  ZKR_HIP_CHECK(hipMemcpyAsync((uint8_t *)ws.d_w + (size_t)j * len, src, len, hipMemcpyHostToDevice, k->prep_stream));
+  ZKR_HIP_CHECK(hipMemcpyAsync((uint8_t *)ws.d_w + (size_t)j * len, witness_std, len, hipMemcpyHostToDevice, k->prep_stream));
   if (last) ZKR_HIP_CHECK(hipEventRecord(ws.ev_up, k->prep_stream));
   return 0;
 }
@@ -1291,9 +1227,10 @@ static const uint8_t ZERO32[32] = {0};
 int zkr_prove_partial_device(zkr_key *key, const void *d_witness_std, void *stream, uint8_t partial_out[ZKR_PARTIAL_BYTES]) {
   if (!key || !d_witness_std || !partial_out) { set_error("null argument"); return ZKR_ERR_ARG; }
   // a shard proving on its own takes its shard's turn: a split group that failed on this shard set drains its stragglers (whose
-  // cross passes write THIS shard's vectors) before it gives the turns back (zkr_multi.hip run_shards_once)
-  std::unique_lock<std::mutex> own_turn;
-  if (key->h.shard_parts > 1 && !shard_turn_held) own_turn = std::unique_lock<std::mutex>(key->split_mu);
+  // cross passes write THIS shard's vectors) before it gives the turns back (zkr_multi.hip run_shards_once).  SHARED: standalone
+  // partial proofs from several host threads still pipeline through the shard's two proof slots; only a split group is exclusive
+  std::shared_lock<std::shared_mutex> own_turn;
+  if (key->h.shard_parts > 1 && !shard_turn_held) own_turn = std::shared_lock<std::shared_mutex>(key->split_mu);
   int t = -1;
   // blinding plays no part before the assembly: the slot gets zeros
   int rc = with_free_slot(key, true, &t, [&](ProofSlot &sl) { return prove_submit(key, sl, (const Fr *)d_witness_std, ZERO32, ZERO32, (hipStream_t)stream); });
@@ -1307,8 +1244,8 @@ int zkr_prove_partial_device(zkr_key *key, const void *d_witness_std, void *stre
 int zkr_prove_partial(zkr_key *key, const void *witness_std, size_t witness_len, uint8_t partial_out[ZKR_PARTIAL_BYTES]) {
   if (!key || !witness_std || !partial_out) { set_error("null argument"); return ZKR_ERR_ARG; }
   if (witness_len != (size_t)key->h.n * 32) { set_error("witness is %zu bytes, key expects nVars*32 = %zu", witness_len, (size_t)key->h.n * 32); return ZKR_ERR_BAD_WITNESS; }
-  std::unique_lock<std::mutex> own_turn;  // as in zkr_prove_partial_device
-  if (key->h.shard_parts > 1 && !shard_turn_held) own_turn = std::unique_lock<std::mutex>(key->split_mu);
+  std::shared_lock<std::shared_mutex> own_turn;  // as in zkr_prove_partial_device
+  if (key->h.shard_parts > 1 && !shard_turn_held) own_turn = std::shared_lock<std::shared_mutex>(key->split_mu);
   int st = -1;
   int rc = stage_acquire(key, &st);
   if (rc) return rc;
@@ -1567,66 +1504,6 @@ int zkr_selftest_f29_forms(int device, int field, int form, const uint32_t *reco
   hipFree(d_out);
   if (rc) set_error("HIP failure in the product-form self test");
   return rc;
-}
-
-// Batched-affine Fq2 addition (256 lanes share one inversion through an LDS product scan) against the hot path's XYZZ mixed
-// addition: nanoseconds of kernel time per addition per lane for each form, chip-wide launch; *equal = 1 when both forms end in
-// the same points.  The measurement behind the decision recorded in DESIGN.md.
-int zkr_bench_g2_affine(int device, double *ns_per_add_affine, double *ns_per_add_mixed, int *equal) {
-  if (!ns_per_add_affine || !ns_per_add_mixed || !equal) { set_error("null argument"); return ZKR_ERR_ARG; }
-  if (zkr_device_count() <= device || device < 0) { set_error("no HIP device %d", device); return ZKR_ERR_NO_DEVICE; }
-  ZKR_HIP_CHECK(hipSetDevice(device));
-  const uint32_t n_table = 1u << 16;
-  const unsigned blocks = 256 * 4;
-  const int iters = 64;
-  const size_t nthreads = (size_t)blocks * AFF_THREADS;
-  void *d_tab = nullptr;
-  {  // multiples k_i G2 with k_i = (i + 1) 2^20 + 1 (fixed-base kernel of the setup): a sum of j >= 2 of them is j mod 2^20, never
-     // another k_i, so the walk meets neither a doubling nor a cancellation -- the batched form has no branch for them (one zero
-     // denominator would void its whole workgroup's round; a shipping kernel would need the special cases on top of this cost)
-    std::vector<uint8_t> sc((size_t)n_table * 32, 0);
-    for (uint32_t i = 0; i < n_table; i++) { const uint64_t k = ((uint64_t)(i + 1) << 20) + 1; memcpy(&sc[(size_t)i * 32], &k, 8); }
-    int rc = fixed_base_points(device, true, sc.data(), n_table, &d_tab);
-    if (rc) return rc;
-  }
-  DevBuf tab, oa, ox;
-  tab.p = d_tab;
-  int rc;
-  if ((rc = radix_convert(device, true, d_tab, n_table, true))) return rc;  // the table form of the hot path (x 2^261)
-  ScopedEvent e0, e1;
-  if ((rc = oa.alloc(nthreads * sizeof(G2Affine))) || (rc = ox.alloc(nthreads * sizeof(G2XYZZ))) || (rc = e0.create()) || (rc = e1.create())) return rc;
-  const size_t lds = (size_t)(36 * AFF_THREADS + 18) * 4;
-  double ns[2] = {0, 0};
-  for (int form = 0; form < 2; form++) {
-    for (int rep = 0; rep < 3; rep++) {  // first launch warms the clocks; best of the other two
-      ZKR_HIP_CHECK(hipEventRecord(e0.e, nullptr));
-      if (form == 0) g2_add_bench_kernel<true><<<blocks, AFF_THREADS, lds>>>((const G2Affine *)d_tab, n_table, iters, oa.as<G2Affine>(), nullptr);
-      else g2_add_bench_kernel<false><<<blocks, AFF_THREADS>>>((const G2Affine *)d_tab, n_table, iters, nullptr, ox.as<G2XYZZ>());
-      ZKR_HIP_CHECK(hipEventRecord(e1.e, nullptr));
-      ZKR_HIP_CHECK(hipEventSynchronize(e1.e));
-      ZKR_HIP_CHECK(hipGetLastError());
-      float ms = 0;
-      ZKR_HIP_CHECK(hipEventElapsedTime(&ms, e0.e, e1.e));
-      const double v = (double)ms * 1e6 / ((double)iters);  // per round of one addition per lane, all lanes in parallel
-      if (rep == 1 || (rep == 2 && v < ns[form])) ns[form] = v;
-    }
-  }
-  std::vector<G2Affine> ha(nthreads);
-  std::vector<G2XYZZ> hx(nthreads);
-  ZKR_HIP_CHECK(hipMemcpy(ha.data(), oa.p, nthreads * sizeof(G2Affine), hipMemcpyDeviceToHost));
-  ZKR_HIP_CHECK(hipMemcpy(hx.data(), ox.p, nthreads * sizeof(G2XYZZ), hipMemcpyDeviceToHost));
-  int same = 1;
-  for (size_t i = 0; i < nthreads && same; i += 257) {  // a sample across the launch
-    const G2Affine want = to_affine(hx[i]);
-    same = (want.x == ha[i].x && want.y == ha[i].y) ? 1 : 0;
-  }
-  // per addition per lane-slot: the launch keeps `blocks` workgroups of 256 lanes busy; report the time of one round of the whole
-  // launch divided by the additions it makes per SIMD lane in flight is not meaningful across forms -- both forms run the SAME
-  // number of additions on the SAME grid, so the ratio of the two numbers is the ratio of the costs
-  *ns_per_add_affine = ns[0];
-  *ns_per_add_mixed = ns[1];
-  *equal = same;
-  return 0;
 }
 
 int zkr_bench_fq_mul(int device, double *gmuls_per_s) { return bench_fq_mul(device, gmuls_per_s, 0); }

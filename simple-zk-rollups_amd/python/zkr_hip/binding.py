@@ -87,7 +87,6 @@ def lib():
     L.zkr_free.restype = None
     L.zkr_bench_fq_mul.argtypes = [i, c.POINTER(c.c_double)]
     L.zkr_bench_fq_mul_legacy.argtypes = [i, c.POINTER(c.c_double)]
-    L.zkr_bench_g2_affine.argtypes = [i, c.POINTER(c.c_double), c.POINTER(c.c_double), c.POINTER(i)]
     L.zkr_selftest_f29_forms.argtypes = [i, i, i, c.POINTER(c.c_uint32), sz, c.POINTER(c.c_uint32)]
     L.zkr_mimcsponge_multihash.argtypes = [u8p, sz, u8p]
     L.zkr_babyjub_pubkey.argtypes = [u8p, u8p]
@@ -569,13 +568,6 @@ def selftest_f29_forms(field, form, records, device=0):
     out = (ctypes.c_uint32 * (9 * n))()
     _check(lib().zkr_selftest_f29_forms(device, field, form, flat, n, out))
     return [list(out[9 * k:9 * k + 9]) for k in range(n)]
-
-
-def bench_g2_affine(device=0):
-    """zkr_bench_g2_affine: (ns per round batched-affine, ns per round XYZZ mixed, results equal)."""
-    a, m, eq = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
-    _check(lib().zkr_bench_g2_affine(device, ctypes.byref(a), ctypes.byref(m), ctypes.byref(eq)))
-    return a.value, m.value, bool(eq.value)
 
 
 def bench_fq_mul(device=0, legacy=False) -> float:

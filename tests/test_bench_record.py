@@ -84,3 +84,22 @@ def test_north_star_ratios_are_scalars_of_cpu_baseline():
     cb2 = {k: v for k, v in d["cpu_baseline"].items() if k != "snarkjs_style"}
     b.cpu_baseline_scalars(cb2, d["value"], 12)
     assert cb2["snarkjs_style_proofs_per_s"] is None and cb2["speedup_vs_snarkjs_style"] is None and cb2["speedup_vs_c_1thread"] > 1
+
+
+def test_multi_rank_line_schema_and_what_counts_as_measured():
+    """a `--gpus N` line has `per_rank` of length N, says how the key was replicated and at what rate, and calls a
+    sharded timing MEASURED only when every shard sat on a physical GPU of its own (distinct ordinals and distinct PCI bus ids)."""
+    b = _bench()
+    d = json.load(open(os.path.join(ROOT, "profiles", "r5_08_bench_ranks8_one_gpu.json")))     # eight ranks rehearsed on the one GPU
+    assert d["n_gpus"] == 8 and len(d["per_rank"]) == 8 and sorted(p["rank"] for p in d["per_rank"]) == list(range(8))
+    assert sum(p["proofs"] for p in d["per_rank"]) == d["steps"] * 8 and d["scaling"] == "weak"
+    cfg = _driver_view(d["config"])
+    assert cfg["key_replication"] in ("nccl", "rccl", "gloo", "per-rank") and isinstance(cfg["key_bcast_GBps"], float) and cfg["key_bcast_GBps"] > 0
+    assert cfg["sharded_parts"] == 8 and cfg["sharded_measured"] is False and "one device" in cfg["sharded_reason"]
+    one = "0000:f4:00.0"
+    assert b.shards_share_a_gpu([0, 0], [one, one]) is True                       # the rehearsal: one device twice
+    assert b.shards_share_a_gpu([0, 1], [one, one]) is True                       # two ordinals that are ONE physical GPU (same bus id)
+    assert b.shards_share_a_gpu([0, 1], [one, ""]) is True                        # a bus id that could not be read decides nothing
+    assert b.shards_share_a_gpu([0, 1, 2, 3], ["0000:%02x:00.0" % (0x10 + i) for i in range(4)]) is False
+    leg = dict(d["intra_proof_sharding"], rehearsal_on_one_gpu=b.shards_share_a_gpu([0, 1], [one, "0000:f5:00.0"]))
+    assert b.sharding_scalars(leg)["sharded_measured"] is True

@@ -140,6 +140,66 @@ def test_two_rank_batch_survives_a_failed_key_broadcast():
     assert res[0][1] == res[1][1] == want and res[0][3] == res[1][3] == 100_003 + 32 * 64
 
 
+def _worker_one_fails(rank, world, port, q, failing):
+    """world ranks over TWO gloo groups, as bench.py sets its groups up: the default group (control plane: agreement, gather, timing) and a
+    second group that carries the key bytes (RCCL on the GPU box).  Rank `failing` cannot take part in the broadcast (its transport
+    'cannot be set up'): the others run into the data group's timeout, everybody agrees on the failure over the control group and builds
+    its own replica."""
+    import datetime
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "simple-zk-rollups_amd", "python"))
+    import zkr_hip
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    data = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=6))    # every collective on the key bytes is bounded
+    import zkr_hip.batch as zb
+    zb.ARENA_CHUNK = 30_000
+    key = _StubKey(_stub_base()) if rank == 0 else None
+    if rank == failing:
+        os.environ["ZKR_FORCE_BCAST_FAIL"] = "1"
+    key, how = zkr_hip.replicate_key(key, rank, world, None, lambda: _StubKey(_stub_base()), dist, None, mode="full", key_cls=_StubKey, data_group=data)
+    assert how == "per-rank", how                              # ONE fact on every rank, whoever saw the failure first
+    count = 11                                                 # ragged over four ranks: 3 + 3 + 3 + 2
+    witnesses = [bytes([i]) * 64 for i in range(count)]
+    blinding = [(100 + i, 200 + i) for i in range(count)]
+    local = zkr_hip.prove_batch(key, witnesses, blinding, rank, world)
+    assert sorted(local) == zkr_hip.shard_indices(count, rank, world)
+    merged = zkr_hip.gather_proofs(local, count, dist)
+    per_rank = [None] * world
+    dist.all_gather_object(per_rank, {"rank": rank, "proofs": len(local)})
+    dist.barrier()
+    q.put((rank, hashlib.sha256(b"".join(merged[i] for i in range(count))).hexdigest(), [p["proofs"] for p in per_rank], key.arena()[1]))
+    q.close()
+    q.join_thread()                                            # the result has left this process
+    os._exit(0)                                                # the data group holds a timed-out collective: no orderly teardown to wait for
+
+
+def test_four_ranks_ragged_batch_with_one_rank_failing_the_broadcast():
+    """world 4, a proof count that does not divide, and ONE rank (not the root) that cannot join the key broadcast.
+    The ranks that did enter the collective leave it by its timeout; all four agree (MIN over the control group) and prove the batch
+    from replicas they built themselves: every proof once, the same bytes as a single process."""
+    world, failing = 4, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_one_fails, args=(r, world, port, q, failing)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    import zkr_hip
+    key = _StubKey(_stub_base())
+    count = 11
+    allp = zkr_hip.prove_batch(key, [bytes([i]) * 64 for i in range(count)], [(100 + i, 200 + i) for i in range(count)])
+    want = hashlib.sha256(b"".join(allp[i] for i in range(count))).hexdigest()
+    assert all(r[1] == want for r in res)
+    assert all(r[2] == [3, 3, 3, 2] for r in res)              # per-rank shares as every rank saw them
+    assert all(r[3] == 100_003 + 32 * 64 for r in res)
+
+
 def test_shard_indices_partition():
     import zkr_hip
     for count in (0, 1, 7, 64):

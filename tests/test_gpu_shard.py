@@ -68,28 +68,6 @@ def test_sharded_proof_equals_whole_key_proof_and_closed_form(log_m, parts):
     assert zkr_hip.prove_sharded(shards, wb, r, s) == whole
 
 
-def test_shards_with_the_whole_keys_windows(monkeypatch):
-    """ZKR_SHARD_KEEP_WINDOW=1: the levels of the whole key's tables copied range by range (no rebuild); same proof."""
-    import zkr_hip
-    log_m, p, parts = 14, 73, 4
-    key, wb, aux = zkr_hip.ProvingKey.synth(log_m, p, 0x5A4B0001, 0x5A4B00FF)
-    own = [key.shard(i, parts) for i in range(parts)]
-    monkeypatch.setenv("ZKR_SHARD_KEEP_WINDOW", "1")
-    kept = [key.shard(i, parts) for i in range(parts)]
-    monkeypatch.delenv("ZKR_SHARD_KEEP_WINDOW")
-    assert all(sh.windows() == key.windows() for sh in kept) and all(sh.windows() != key.windows() for sh in own)
-    want = g.proof_bytes(g.proof_from_aux(aux, wb, p, 11, 13)[0])
-    assert key.prove(wb, 11, 13) == want
-    assert zkr_hip.prove_sharded(kept, wb, 11, 13) == want and zkr_hip.prove_sharded(own, wb, 11, 13) == want
-    # partial sums are group elements: records of the two kinds of shard mix
-    mixed = [(own if i % 2 else kept)[i].prove_partial(wb) for i in range(parts)]
-    assert key.prove_combine(mixed, 11, 13) == want
-    # ZKR_SHARD_FULL_H=1: every shard computes the whole of h instead of the blocks of the last transforms that cover its range
-    monkeypatch.setenv("ZKR_SHARD_FULL_H", "1")
-    assert zkr_hip.prove_sharded(own, wb, 11, 13) == want
-    monkeypatch.delenv("ZKR_SHARD_FULL_H")
-
-
 @pytest.mark.parametrize("log_m,parts", [(12, 3), (12, 5), (12, 7), (18, 6), (22, 8)])
 def test_ranges_of_h_that_are_not_aligned_blocks(log_m, parts):
     """A shard runs the last pair of calcH's transforms only on the aligned blocks that cover its range of h (csrc/zkr_prove.hip
@@ -252,6 +230,10 @@ def test_first_use_check_of_the_split_form_and_its_fallback(monkeypatch, capfd):
     assert not any(t.is_alive() for t in ths)
     assert got["x"] == want and got["y"] == closed_form(aux, wb, p, 71, 62, log_m)
     assert forms["x"]["form"] == "split" and forms["y"]["form"] == "split" and any("both ways" in f["reason"] for f in forms.values())
+    # the check belongs to the shard SET: a checked shard 0 with NEW siblings is an unchecked set and proves both ways again
+    mixed = [good[0]] + [key.shard(i, parts) for i in range(1, parts)]
+    assert zkr_hip.prove_sharded(mixed, wb, 61, 62) == want and "proved both ways" in zkr_hip.sharded_last_form()["reason"]
+    assert zkr_hip.prove_sharded(mixed, wb, 61, 62) == want and "both ways" not in zkr_hip.sharded_last_form()["reason"]
     monkeypatch.setenv("ZKR_SHARD_SPLIT_CHECK", "2")
     bad = [key.shard(i, parts) for i in range(parts)]
     capfd.readouterr()
