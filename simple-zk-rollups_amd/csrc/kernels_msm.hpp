@@ -600,14 +600,45 @@ static __global__ __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per
   // the top of every step and the wave stood still for the index load's latency (s_waitcnt vmcnt(0) between the two: 15 % of a
   // wavefront's cycles in SQ_WAIT_ANY, profiles/r6_01_census_isolated.md).  The loads past the end of the chain re-read its last
   // entry / point (no branch around a load, nothing out of bounds).
+#ifdef ZKR_EXP_FAKE_GATHER   // TEMPORARY (round-6 bound, measurement only: garbage sums): every gather lands in the table's first 1 MB
+#define ZKR_GIDX(i) ((i) & 0x1fffu)
+#else
+#define ZKR_GIDX(i) (i)
+#endif
+#ifdef ZKR_EXP_OLD_LOOP   // TEMPORARY (round-6 A/B): round 5's loop
+  if (PREFETCH) {
+    if (o0 < o1) {
+      uint32_t e = entries[o0];
+      Affine<F> p = load_pod(points + (e >> 1));
+      for (uint32_t j = o0 + 1; j < o1; j++) {
+        uint32_t en = entries[j];
+        Affine<F> pn = load_pod(points + (en >> 1));
+        if (!p.is_inf()) acc = add_mixed29<C>(acc, unpack_affine(p), (e & 1) != 0);
+        e = en;
+        p = pn;
+      }
+      if (!p.is_inf()) acc = add_mixed29<C>(acc, unpack_affine(p), (e & 1) != 0);
+    }
+  } else {
+    uint32_t e = o0 < o1 ? entries[o0] : 0u;
+    for (uint32_t j = o0; j < o1; j++) {
+      uint32_t en = j + 1 < o1 ? entries[j + 1] : 0u;
+      Affine<F> p = load_pod(points + (e >> 1));
+      if (!p.is_inf()) acc = add_mixed29<C>(acc, unpack_affine(p), (e & 1) != 0);
+      e = en;
+    }
+  }
+  if (false) {
+#else
   if (o0 < o1) {
+#endif
     const uint32_t last = o1 - 1;
     uint32_t e = entries[o0], e1 = entries[min(o0 + 1, last)];
     if (PREFETCH) {
-      Affine<F> p = load_pod(points + (e >> 1));
+      Affine<F> p = load_pod(points + ZKR_GIDX(e >> 1));
       for (uint32_t j = o0; j < o1; j++) {
         const uint32_t e2 = entries[min(j + 2, last)];
-        const Affine<F> pn = load_pod(points + (e1 >> 1));
+        const Affine<F> pn = load_pod(points + ZKR_GIDX(e1 >> 1));
         if (!p.is_inf()) acc = add_mixed29<C>(acc, unpack_affine(p), (e & 1) != 0);  // infinity: placeholder of a shared-support table
         e = e1; e1 = e2; p = pn;
       }
@@ -616,8 +647,8 @@ static __global__ __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per
       // (one word each), so that the load at the top of the next step finds them in L2 with their translation in place
       for (uint32_t j = o0; j < o1; j++) {
         const uint32_t e2 = entries[min(j + 2, last)];
-        const Affine<F> p = load_pod(points + (e >> 1));
-        const uint32_t *nx = reinterpret_cast<const uint32_t *>(points + (e1 >> 1));
+        const Affine<F> p = load_pod(points + ZKR_GIDX(e >> 1));
+        const uint32_t *nx = reinterpret_cast<const uint32_t *>(points + ZKR_GIDX(e1 >> 1));
         uint32_t touch = 0;
 #pragma unroll
         for (unsigned l = 0; l < sizeof(Affine<F>) / 64; l++) touch |= nx[16 * l];

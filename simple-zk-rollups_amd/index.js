@@ -51,7 +51,9 @@ const signalsInRange = (ps) => ps.every((x) => { const v = BigInt(x); return v >
 // of the setup --, the last 4 KiB and 64 blocks of 4 KiB spread evenly in between: 0.3 MB whatever the size, < 0.1 ms) and confirmed
 // by comparing the caller's buffer with the buffer the entry was built from, byte for byte (Buffer.compare = memcmp: ~8 ms for the tx
 // circuit's 57 MB, against ~50 ms for a SHA-256 of it); the SAME buffer object is recognised without the comparison.  The entry
-// keeps a reference to that buffer (it must not be rewritten in place afterwards; the reference's callers build a new one per call).
+// keeps a private copy of the bytes it was built from (what other buffers are compared with) and the caller's object (identity
+// only).  Contract of the identity shortcut: a buffer handed to the library is not rewritten in place while its key is cached --
+// the reference's callers build a new buffer per call (common.ts:28) and always take the comparison.
 // ZKR_KEY_FINGERPRINT=sampled: the sampled digest alone (two keys of one setup that differ in a lone coefficient alias);
 // =full: a SHA-256 of every byte instead of the comparison (nothing retained).
 const FP_BLOCK = 4096, FP_STRIDED = 64;
@@ -80,11 +82,11 @@ function keyFingerprint(buf, full) {
 // replicas (their device memory goes with the handles).
 const KEY_CACHE_SLOTS = 2;
 const MAX_SHARD_SETS = 2;    // device lists whose shards an entry keeps (least recently used dropped)
-const keyCache = new Map();  // "fingerprint#variant" -> Map("device#ordinal" -> native key handle; "ref" -> the buffer the entry was built from), in recency order
+const keyCache = new Map();  // "fingerprint#variant" -> Map("device#ordinal" -> native key handle; "ref" -> a private copy of the buffer the entry was built from, "src" -> that buffer object), in recency order
 const keyCacheStats = { loads: 0, hits: 0, replications: 0, compares: 0 };
 // a whole-key replica of the entry (any device), or undefined: the source of device-to-device copies and of shards
 function anyReplica(ent) {
-  for (const [slot, key] of ent) if (slot !== "ref" && !slot.startsWith("shards:")) return key;
+  for (const [slot, key] of ent) if (slot !== "ref" && slot !== "src" && !slot.startsWith("shards:")) return key;
   return undefined;
 }
 function cacheEntry(provingKeyBin) {
@@ -95,14 +97,23 @@ function cacheEntry(provingKeyBin) {
   for (const [k, ent] of keyCache) {
     if (!k.startsWith(fp + "#")) continue;
     top = Math.max(top, Number(k.slice(fp.length + 1)));
+    if (!exact) { found = k; break; }
     const ref = ent.get("ref");
-    if (!exact || ref === provingKeyBin) { found = k; break; }
+    if (ref === undefined) continue;  // an entry made under ZKR_KEY_FINGERPRINT=sampled / full keeps no bytes: another variant to an exact lookup
+    if (ent.get("src") === provingKeyBin) { found = k; break; }  // the very object the entry was built from (see the contract above)
     keyCacheStats.compares++;
-    if (Buffer.compare(bytesOf(ref), u8) === 0) { found = k; break; }
+    if (Buffer.compare(ref, u8) === 0) { found = k; break; }
   }
   let ent;
   if (found !== undefined) { ent = keyCache.get(found); keyCache.delete(found); }  // re-insert: most recently used last
-  else { found = fp + "#" + (top + 1); ent = new Map(); if (exact) ent.set("ref", provingKeyBin); }
+  else {
+    found = fp + "#" + (top + 1);
+    ent = new Map();
+    // ADVICE r5: the bytes an entry is compared against are a PRIVATE copy -- the caller's buffer is mutable, and a buffer
+    // rewritten in place after the load would make a later, different key compare equal to it; the caller's object itself is kept
+    // for the identity shortcut only
+    if (exact) { ent.set("ref", Buffer.from(u8)); ent.set("src", provingKeyBin); }
+  }
   keyCache.set(found, ent);
   while (keyCache.size > KEY_CACHE_SLOTS) keyCache.delete(keyCache.keys().next().value);
   return ent;
@@ -503,7 +514,8 @@ module.exports = {
   binarifyR1cs, verifyingKeyFromBytes, solidityVerifyingKey, solidityVerifyingKeySource,
   // which form the last sharded proof took and why ({form: "split" | "replicated" | "none", reason}); how a key handle came to its device
   shardedLastForm: () => native().shardedLastForm(), keyReplication: (key) => native().keyReplication(key),
-  keyCacheStats: () => Object.assign({ shardedLastForm: addon ? native().shardedLastForm() : { form: "none", reason: "" } }, { entries: keyCache.size, handles: Array.from(keyCache.values()).reduce((a, e) => a + Array.from(e.entries()).reduce((b, [k, v]) => b + (k === "ref" ? 0 : Array.isArray(v) ? v.length : 1), 0), 0) }, keyCacheStats), clearKeyCache, keyFingerprint,
+  keyCacheStats: () => Object.assign({ shardedLastForm: addon ? native().shardedLastForm() : { form: "none", reason: "" } }, { entries: keyCache.size, handles: Array.from(keyCache.values()).reduce((a, e) => a + Array.from(e.entries()).reduce((b, [k, v]) => b + (k === "ref" || k === "src" ? 0 : Array.isArray(v) ? v.length : 1), 0), 0) }, keyCacheStats), clearKeyCache, keyFingerprint,
+  _cacheEntry: cacheEntry,  // the cache's lookup alone (no device involved): tests/test_node_host.py
   multiHash, multiHashBatch, buildBalanceTree, hashLeftRight, genPublicKey, formatPrivKeyForBabyJub, sign, verify, RollupCircuit, WithdrawCircuit,
   deviceCount: () => { native(); return deviceCount; },
   version: () => native().version(),

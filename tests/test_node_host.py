@@ -79,6 +79,28 @@ def test_js_and_python_key_fingerprints_cover_the_whole_buffer():
     """, str(n)).stdout
     res = json.loads(out)
     assert res == {"ab": True, "ac": False, "dflt": True, "ac_full": True, "small": True}
+    # the JS cache's lookup: the entry compares against a PRIVATE copy, so a caller who rewrites its buffer in place and
+    # then passes a NEW buffer with the new content gets a new entry (not the device key built from the old content); an entry made
+    # under ZKR_KEY_FINGERPRINT=sampled keeps no bytes and is skipped by a later exact lookup instead of throwing
+    out = _node("""
+      const z = require('./index.js');
+      const n = Number(process.argv[1]);
+      const a = Buffer.alloc(n, 7);
+      const ea = z._cacheEntry(a);
+      const same = z._cacheEntry(a) === ea, c0 = z.keyCacheStats().compares;
+      const copy = Buffer.from(a), hit = z._cacheEntry(copy) === ea, c1 = z.keyCacheStats().compares;
+      a[5000 + 4096 * 3] ^= 1;                                        // rewritten in place, between sampled blocks: same sampled digest
+      const fresh = Buffer.from(a), other = z._cacheEntry(fresh) !== ea;
+      const old = z._cacheEntry(copy) === ea;                         // the old content still finds the old entry
+      z.clearKeyCache();
+      process.env.ZKR_KEY_FINGERPRINT = 'sampled';
+      const es = z._cacheEntry(copy);
+      delete process.env.ZKR_KEY_FINGERPRINT;
+      let threw = false, ex;
+      try { ex = z._cacheEntry(copy); } catch (e) { threw = true; }
+      console.log(JSON.stringify({same, hit, compared: c1 - c0, other, old, threw, separate: ex !== es, private_copy: ea.get('ref') !== copy && ea.get('src') !== undefined}));
+    """, str(n)).stdout
+    assert json.loads(out) == {"same": True, "hit": True, "compared": 1, "other": True, "old": True, "threw": False, "separate": True, "private_copy": True}
     a = bytes([7]) * n
     b = bytearray(a)
     for i in range(8192, n - 8192, 997):

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <vector>
 template <int BYTES>
 __global__ __launch_bounds__(256) void gather(const uint4 *tbl, const uint32_t *idx, uint32_t per_thread, uint32_t nthreads, uint4 *out) {
@@ -23,11 +24,19 @@ __global__ __launch_bounds__(256) void gather(const uint4 *tbl, const uint32_t *
   }
   out[t] = acc;
 }
-int main() {
+// gather_bw <bytes> <table MB> <seq 0|1> <lds KB>: that one configuration only (four launches) -- what a counter pass wants:
+//   rocprofv3 --kernel-trace --pmc FETCH_SIZE -- tools/bin/gather_bw 64 832 0 80
+// requests 2^19 x 26 gathers of `bytes` (+ 4 B of index each): the known byte count FETCH_SIZE is calibrated against for THIS access
+// pattern (profiles/r6_*_fetch_size_calibration.md)
+int main(int argc, char **argv) {
   const uint32_t nthreads = 1u << 19, per = 26;
+  const bool one = argc == 5;
+  const int one_bytes = one ? atoi(argv[1]) : 0, one_seq = one ? atoi(argv[3]) : 0;
+  const size_t one_mb = one ? (size_t)atoi(argv[2]) : 0, one_lds = one ? (size_t)atoi(argv[4]) * 1024 : 0;
   uint4 *out; hipMalloc(&out, (size_t)nthreads * 16);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (size_t lds : {(size_t)0, (size_t)80 * 1024}) for (int bytes : {64, 128}) for (size_t mb : {64, 832}) for (int seq = 0; seq < 2; seq++) {
+    if (one && (bytes != one_bytes || mb != one_mb || seq != one_seq || lds != one_lds)) continue;
     size_t n = mb * 1024 * 1024 / bytes;
     uint4 *tbl; hipMalloc(&tbl, n * bytes); hipMemset(tbl, 1, n * bytes);
     std::vector<uint32_t> idx((size_t)nthreads * per);
