@@ -118,11 +118,6 @@ ZKR_HD XYZZ29<C> dbl_xyzz29(const XYZZ29<C> &p) {
 #else
 #define ZKR_PIN_ORDER() ((void)0)
 #endif
-#ifdef ZKR_EXP_NO_PIN_MIXED   // TEMPORARY (round-6 A/B)
-#define ZKR_PIN_MIXED() ((void)0)
-#else
-#define ZKR_PIN_MIXED() ZKR_PIN_ORDER()
-#endif
 // acc + q (q affine, not infinity: callers filter); neg_q adds -q.  The sign goes into the product Y2 ZZZ1 as a factor
 // without its carry sweep (field29.hpp U29), as do Q - X3 and -Y1 in the Y coordinate: three sweeps and a select less per
 // addition; the negated y itself is only formed on the rare paths that store it.
@@ -134,9 +129,9 @@ ZKR_HD XYZZ29<C> add_mixed29(const XYZZ29<C> &acc, const Affine29<C> &q, bool ne
     return make_xyzz<C>(q.x, qy, C::one(), C::one());
   }
   auto u2 = mul(q.x, acc.zz);
-  ZKR_PIN_MIXED();
+  ZKR_PIN_ORDER();
   auto s2 = mul_cneg(q.y, neg_q, acc.zzz);
-  ZKR_PIN_MIXED();
+  ZKR_PIN_ORDER();
   auto p = sub(u2, acc.x);
   auto r = sub(s2, acc.y);
   auto pp = sqr(p);
@@ -148,15 +143,15 @@ ZKR_HD XYZZ29<C> add_mixed29(const XYZZ29<C> &acc, const Affine29<C> &q, bool ne
     }
     return XYZZ29<C>::inf();
   }
-  ZKR_PIN_MIXED();
+  ZKR_PIN_ORDER();
   auto ppp = mul(p, pp);
-  ZKR_PIN_MIXED();
+  ZKR_PIN_ORDER();
   auto qq = mul(acc.x, pp);
-  ZKR_PIN_MIXED();
+  ZKR_PIN_ORDER();
   auto zz3 = mul(acc.zz, pp);
-  ZKR_PIN_MIXED();
+  ZKR_PIN_ORDER();
   auto zzz3 = mul(acc.zzz, ppp);
-  ZKR_PIN_MIXED();
+  ZKR_PIN_ORDER();
   auto x3 = sub_sub_dbl(sqr(r), ppp, qq);  // R^2 - P^3 - 2 Q, one carry sweep
   auto y3 = mul_sub(r, sub_factor(qq, x3), acc.y, ppp);
   return make_xyzz<C>(x3, y3, zz3, zzz3);

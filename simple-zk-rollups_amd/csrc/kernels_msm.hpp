@@ -548,117 +548,55 @@ static __global__ __launch_bounds__(SCAN_THREADS) void msm_order_kernel(const ui
 
 // bucket accumulation: thread per bucket, buckets taken in `order` (fullest first): the 64 lanes of a
 // wavefront get buckets of (almost) equal occupancy, so no lane idles while another finishes, and the long
-// buckets start first.  The next entry and its point are fetched while the current addition runs.
-//
-// One launch, several tables (round 6).  A launch is a list of up to ACC_MAX_JOBS tables over the same kind of point; workgroup
-// b works on the job whose block range holds b.  Why: a table's launch ends with its emptiest buckets, and the stream's next
-// launch starts only when the last of them is done -- with ~4 workgroups per resident slot and jobs of 50 .. 5 additions the
-// slots finish up to one small job apart (profiles/r6_01_census_isolated.md: 1.76 of 2 wavefronts resident per SIMD over an
-// isolated launch; a list-scheduling model of the same bucket sizes gives 0.90-0.93).  The three tables that multiply the
-// witness and wait for nothing else (B1, A, C) therefore go into ONE launch: the slots B1's tail frees take A's fullest buckets
-// at once, and a proof pays three launch tails (B2, B1 + A + C, H) instead of five.
-constexpr int ACC_ONTO = 1, ACC_ZERO_BIG = 2;  // flags of an accumulation job's `onto`
+// buckets start first.
+// The chain is software-pipelined: the entry index runs TWO additions ahead and -- AHEAD: G1, 64-byte points -- the point ONE,
+// so a gather's address has been in a register for a whole addition when the gather is issued; for the 128-byte G2 points a
+// second point in registers would spill, there only the index runs ahead.  Loads past the end of a chain re-read its last
+// entry / point (no branch around a load, nothing out of bounds).
+// Round 6 measured around this loop: B1 + A + C in ONE launch (the launch tails it removes are where the other
+// streams' kernels found room: -3 %), two points ahead, the next point through the LDS DMA path, aligned non-temporal loads, the
+// G2 launch on a stream of its own -- all within +-1 % of this form; with every gather redirected into 1 MB of its table
+// (garbage sums) the pipelined rate is 8.6 % higher: that is all the memory side costs (profiles/r6_07_fake_gather_bound.txt).
+constexpr int ACC_ONTO = 1, ACC_ZERO_BIG = 2;  // flags of the accumulation kernels' `onto` argument
 constexpr int ACC_THREADS = 256;
-constexpr int ACC_MAX_JOBS = 3;
-template <class F> struct AccumJob {
-  const Affine<F> *points;   // the table's window levels
-  const uint32_t *offsets, *entries, *counts, *order;  // the digit sort it walks (possibly another table's over the same signals)
-  XYZZ<F> *buckets;
-  uint32_t nb;               // buckets (of every fused proof, end to end)
-  int onto;
-};
-template <class F> struct AccumJobs {
-  AccumJob<F> job[ACC_MAX_JOBS];
-  uint32_t first_block[ACC_MAX_JOBS + 1];  // job j owns workgroups [first_block[j], first_block[j + 1])
-  int n;
-};
-template <class F, int MINW, bool PREFETCH = true>
-static __global__ __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per_eu(MINW, MINW))) void msm_accum_kernel(AccumJobs<F> jobs) {
+template <class F, int MINW, bool AHEAD>
+static __global__ __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per_eu(MINW, MINW))) void msm_accum_kernel(const Affine<F> *points, const uint32_t *offsets, const uint32_t *entries,
+                                                                     uint32_t nb, const uint32_t *counts, const uint32_t *order, XYZZ<F> *buckets, int onto) {
   using C = typename CoordOf<F>::C;
-  // the job of this workgroup: uniform, so the selects below are scalar
-  AccumJob<F> job = jobs.job[0];
-  uint32_t first = 0;
-  if (jobs.n > 1 && blockIdx.x >= jobs.first_block[1]) { job = jobs.job[1]; first = jobs.first_block[1]; }
-  if (jobs.n > 2 && blockIdx.x >= jobs.first_block[2]) { job = jobs.job[2]; first = jobs.first_block[2]; }
-  const Affine<F> *points = job.points;
-  const uint32_t *entries = job.entries;
-  const uint32_t t = (blockIdx.x - first) * ACC_THREADS + threadIdx.x;
-  if (t >= job.nb) return;
-  const uint32_t b = job.order[t];
+  const uint32_t t = blockIdx.x * ACC_THREADS + threadIdx.x;
+  if (t >= nb) return;
+  const uint32_t b = order[t];
   // msm_big_kernel owns an oversized bucket.  ACC_ZERO_BIG: its slot is cleared here, because the partial sums will be ADDED
   // to it later (the first table of a shared bucket set: see ACC_ONTO)
-  if (job.counts[b] == BIG_MARK) {
-    if (job.onto & ACC_ZERO_BIG) store_pod(job.buckets + b, XYZZ<F>::inf());
+  if (counts[b] == BIG_MARK) {
+    if (onto & ACC_ZERO_BIG) store_pod(buckets + b, XYZZ<F>::inf());
     return;
   }
-  uint32_t o0 = job.offsets[b], o1 = job.offsets[b + 1];
+  uint32_t o0 = offsets[b], o1 = offsets[b + 1];
   // ACC_ONTO: the bucket set already holds another table's sums over the same bucket geometry (C before H: only C + H is
   // ever needed, so one bucket set and ONE reduction chain serve both tables)
-  XYZZ29<C> acc = (job.onto & ACC_ONTO) ? unpack_xyzz(load_pod(job.buckets + b)) : XYZZ29<C>::inf();
-  // Software pipeline of the chain (round 6): the entry index runs TWO additions ahead and the point ONE, so the gather's address
-  // has been in a register for a whole addition when the gather is issued.  Before, index and point were loaded back to back at
-  // the top of every step and the wave stood still for the index load's latency (s_waitcnt vmcnt(0) between the two: 15 % of a
-  // wavefront's cycles in SQ_WAIT_ANY, profiles/r6_01_census_isolated.md).  The loads past the end of the chain re-read its last
-  // entry / point (no branch around a load, nothing out of bounds).
-#ifdef ZKR_EXP_FAKE_GATHER   // TEMPORARY (round-6 bound, measurement only: garbage sums): every gather lands in the table's first 1 MB
-#define ZKR_GIDX(i) ((i) & 0x1fffu)
-#else
-#define ZKR_GIDX(i) (i)
-#endif
-#ifdef ZKR_EXP_OLD_LOOP   // TEMPORARY (round-6 A/B): round 5's loop
-  if (PREFETCH) {
-    if (o0 < o1) {
-      uint32_t e = entries[o0];
-      Affine<F> p = load_pod(points + (e >> 1));
-      for (uint32_t j = o0 + 1; j < o1; j++) {
-        uint32_t en = entries[j];
-        Affine<F> pn = load_pod(points + (en >> 1));
-        if (!p.is_inf()) acc = add_mixed29<C>(acc, unpack_affine(p), (e & 1) != 0);
-        e = en;
-        p = pn;
-      }
-      if (!p.is_inf()) acc = add_mixed29<C>(acc, unpack_affine(p), (e & 1) != 0);
-    }
-  } else {
-    uint32_t e = o0 < o1 ? entries[o0] : 0u;
-    for (uint32_t j = o0; j < o1; j++) {
-      uint32_t en = j + 1 < o1 ? entries[j + 1] : 0u;
-      Affine<F> p = load_pod(points + (e >> 1));
-      if (!p.is_inf()) acc = add_mixed29<C>(acc, unpack_affine(p), (e & 1) != 0);
-      e = en;
-    }
-  }
-  if (false) {
-#else
+  XYZZ29<C> acc = (onto & ACC_ONTO) ? unpack_xyzz(load_pod(buckets + b)) : XYZZ29<C>::inf();
   if (o0 < o1) {
-#endif
     const uint32_t last = o1 - 1;
     uint32_t e = entries[o0], e1 = entries[min(o0 + 1, last)];
-    if (PREFETCH) {
-      Affine<F> p = load_pod(points + ZKR_GIDX(e >> 1));
+    if (AHEAD) {
+      Affine<F> p = load_pod(points + (e >> 1));
       for (uint32_t j = o0; j < o1; j++) {
         const uint32_t e2 = entries[min(j + 2, last)];
-        const Affine<F> pn = load_pod(points + ZKR_GIDX(e1 >> 1));
+        const Affine<F> pn = load_pod(points + (e1 >> 1));
         if (!p.is_inf()) acc = add_mixed29<C>(acc, unpack_affine(p), (e & 1) != 0);  // infinity: placeholder of a shared-support table
         e = e1; e1 = e2; p = pn;
       }
     } else {
-      // wide points (G2: 128 B): a second point in registers would spill; the NEXT point's two cache lines are touched instead
-      // (one word each), so that the load at the top of the next step finds them in L2 with their translation in place
       for (uint32_t j = o0; j < o1; j++) {
         const uint32_t e2 = entries[min(j + 2, last)];
-        const Affine<F> p = load_pod(points + ZKR_GIDX(e >> 1));
-        const uint32_t *nx = reinterpret_cast<const uint32_t *>(points + ZKR_GIDX(e1 >> 1));
-        uint32_t touch = 0;
-#pragma unroll
-        for (unsigned l = 0; l < sizeof(Affine<F>) / 64; l++) touch |= nx[16 * l];
+        const Affine<F> p = load_pod(points + (e >> 1));
         if (!p.is_inf()) acc = add_mixed29<C>(acc, unpack_affine(p), (e & 1) != 0);
-        asm volatile("" ::"v"(touch));  // the touches are waited for here, after the addition, not before it
         e = e1; e1 = e2;
       }
     }
   }
-  store_pod(job.buckets + b, pack_xyzz<F>(acc));
+  store_pod(buckets + b, pack_xyzz<F>(acc));
 }
 
 // The same for small bucket sets (circuits of 2^17 constraints and below: fewer buckets than the chip has lanes):
@@ -711,13 +649,12 @@ constexpr int BIG_SPLIT = 8;
 constexpr int BIG_SLOTS = 64;  // bucket slots per launch round (grid = BIG_SLOTS * BIG_SPLIT)
 
 // The oversized-bucket and reduction kernels below are few, long-running wavefronts that must find room on SIMDs whose register
-// file the accumulations already hold (two wavefronts of 176 VGPRs for G1, of 248 for G2, out of 512).  Round 6 builds them to
-// FIT: the G1 forms in 160 VGPRs -- beside BOTH accumulation wavefronts of a SIMD, a third resident wavefront that displaces
-// nothing -- and the G2 forms in 320, beside ONE (the Fq2 running sums of reduce1 took 394 before: its workgroups could only start
-// on CUs that had drained completely, i.e. in the tail of an accumulation launch, and then kept a quarter of the chip to
-// themselves at one dependent chain per SIMD; profiles/r6_03_steady_timeline_r5.md).  The bodies are templates over the field; the
-// kernels are instantiated per field because the register cap is an attribute (amdgpu_num_vgpr counts half of the unified file
-// on gfx950: 80 -> 160, 160 -> 320).  No kernel spills (tools/kernel_resources.py).
+// file the accumulations already hold (two wavefronts of 176 VGPRs for G1, of 248 for G2, out of 512).  Since round 6 they FIT:
+// with the group law's products in written order (curve29.hpp ZKR_PIN_ORDER) the G1 forms take 125-160 VGPRs -- beside BOTH
+// accumulation wavefronts of a SIMD, a third resident wavefront that displaces nothing -- and the G2 forms 242-331, beside ONE
+// (the Fq2 running sums of reduce1 took 394 before: its workgroups could only start on CUs that had drained completely, i.e. in
+// the tail of an accumulation launch; profiles/r6_03_steady_timeline_r5.md).  No kernel spills; tests/test_kernel_resources.py
+// holds the register counts.
 template <class F>
 __device__ __forceinline__ void msm_big_body(const Affine<F> *points, const uint32_t *offsets, const uint32_t *entries,
                                              const uint32_t *big_list, const uint32_t *big_count, uint32_t big_cap, XYZZ<F> *partials) {
@@ -776,44 +713,21 @@ __device__ __forceinline__ void msm_big_finish_body(const XYZZ<F> *partials, con
 //             in parallel), and adds the tasks in an LDS tree -> the MSM result
 // group_out: R[ng] then T[ng];  task_out: [ntask][S] with ntask = log2(ng) + 2.
 //
-// reduce1 keeps NEITHER running sum in registers across an addition (round 6): the suffix sums run_j = B_j + ... + B_{g-1} are
-// written back over the buckets they end at (the bucket set is dead once its reduction has read it: the next accumulation starts
-// from infinity) and read again by the next step; T waits in LDS (word w of lane t at [w][t]: conflict-free).  Either addition
-// then has two operands that die inside it, which is what the register cap above needs; the price is a packed store + load and
-// 2 x 36 / 72 LDS words per bucket, against ~6 000 / 12 000 instructions of the two additions.
-template <class P>
-__device__ __forceinline__ void lds_park(uint32_t *lds, const P &v) {
-  static_assert(sizeof(P) % 4 == 0, "made of 32-bit words");
-  const uint32_t *src = reinterpret_cast<const uint32_t *>(&v);
-#pragma unroll
-  for (unsigned w = 0; w < sizeof(P) / 4; w++) lds[w * MSM_THREADS + threadIdx.x] = src[w];
-}
-template <class P>
-__device__ __forceinline__ P lds_unpark(const uint32_t *lds) {
-  P v;
-  uint32_t *dst = reinterpret_cast<uint32_t *>(&v);
-#pragma unroll
-  for (unsigned w = 0; w < sizeof(P) / 4; w++) dst[w] = lds[w * MSM_THREADS + threadIdx.x];
-  return v;
-}
-template <class F> constexpr size_t reduce1_lds_bytes() { return sizeof(XYZZ29<typename CoordOf<F>::C>) * MSM_THREADS; }
 template <class F>
-__device__ __forceinline__ void msm_reduce1_body(XYZZ<F> *buckets, MsmGeom g, XYZZ<F> *group_out) {
+__device__ __forceinline__ void msm_reduce1_body(const XYZZ<F> *buckets, MsmGeom g, XYZZ<F> *group_out) {
   __builtin_amdgcn_s_setprio(ZKR_RED_PRIO);
-  extern __shared__ __attribute__((aligned(16))) uint32_t s_park[];
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t ng = (g.nbw >> g.glog) * g.batch, gs = 1u << g.glog;  // groups of every bucket set of the batch, end to end
   if (t >= ng) return;
   using C = typename CoordOf<F>::C;
-  XYZZ<F> *B = buckets + (size_t)t * gs;
-  lds_park(s_park, unpack_xyzz(load_pod(B + gs - 1)));  // T = run = the last bucket
+  const XYZZ<F> *B = buckets + (size_t)t * gs;
+  XYZZ29<C> run = unpack_xyzz(load_pod(B + gs - 1)), T = run;
   for (int j = (int)gs - 2; j >= 0; j--) {
-    const XYZZ29<C> run = add_full29<C>(unpack_xyzz(load_pod(B + j + 1)), unpack_xyzz(load_pod(B + j)), [&]() { return unpack_xyzz(load_pod(B + j)); });
-    store_pod(B + j, pack_xyzz<F>(run));  // the suffix sum, in place
-    lds_park(s_park, add_full29<C>(run, lds_unpark<XYZZ29<C>>(s_park), [&]() { return lds_unpark<XYZZ29<C>>(s_park); }));  // T += run
+    run = add_full29<C>(run, unpack_xyzz(load_pod(B + j)), [&]() { return unpack_xyzz(load_pod(B + j)); });
+    T = add_full29<C>(T, run, [&]() { return run; });
   }
-  copy_pod(group_out + t, B);
-  store_pod(group_out + (size_t)ng + t, pack_xyzz<F>(lds_unpark<XYZZ29<C>>(s_park)));
+  store_pod(group_out + t, pack_xyzz<F>(run));
+  store_pod(group_out + (size_t)ng + t, pack_xyzz<F>(T));
 }
 
 template <class F>
@@ -887,48 +801,22 @@ __device__ __forceinline__ void msm_reduce3_body(const XYZZ<F> *task_out, MsmGeo
   }
 }
 
-// TEMPORARY (round-6 A/B, removed before the round ends): -DZKR_EXP_FAT_CHAIN builds the same kernels with round 5's register
-// ALLOCATIONS (a clobbered high register: 200 VGPRs for the G1 forms, 394 for the G2 forms) -- same instructions, old footprint
-#ifdef ZKR_EXP_FAT_CHAIN
-#define ZKR_RED_ATTR(NV) __attribute__((amdgpu_waves_per_eu(1, 2)))
-#define ZKR_RED_FAT(NV) do { if (NV == 80) asm volatile("" ::: "v167"); else asm volatile("" ::: "v255", "a59"); } while (0)
-#define ZKR_RED_FAT1(NV) do { if (NV == 80) asm volatile("" ::: "v199"); else asm volatile("" ::: "v255", "a137"); } while (0)
-#else
-#define ZKR_RED_ATTR(NV) __attribute__((amdgpu_num_vgpr(NV)))
-#define ZKR_RED_FAT(NV) ((void)0)
-#define ZKR_RED_FAT1(NV) ((void)0)
-#endif
-#define ZKR_RED_KERNELS(F, SFX, NV)                                                                                                                          \
-  static __global__ __launch_bounds__(MSM_THREADS) ZKR_RED_ATTR(NV) void msm_big_kernel_##SFX(                                           \
-      const Affine<F> *points, const uint32_t *offsets, const uint32_t *entries, const uint32_t *big_list, const uint32_t *big_count, uint32_t big_cap,       \
-      XYZZ<F> *partials) { ZKR_RED_FAT(NV); msm_big_body<F>(points, offsets, entries, big_list, big_count, big_cap, partials); }                                              \
-  static __global__ __launch_bounds__(64) ZKR_RED_ATTR(NV) void msm_big_finish_kernel_##SFX(                                             \
-      const XYZZ<F> *partials, const uint32_t *big_list, const uint32_t *big_count, uint32_t big_cap, XYZZ<F> *buckets, int onto) {                          \
-    ZKR_RED_FAT(NV); msm_big_finish_body<F>(partials, big_list, big_count, big_cap, buckets, onto); }                                                                         \
-  static __global__ __launch_bounds__(MSM_THREADS) ZKR_RED_ATTR(NV) void msm_reduce1_kernel_##SFX(XYZZ<F> *buckets, MsmGeom g,           \
-      XYZZ<F> *group_out) { ZKR_RED_FAT1(NV); msm_reduce1_body<F>(buckets, g, group_out); }                                                                                    \
-  static __global__ __launch_bounds__(MSM_THREADS) ZKR_RED_ATTR(NV) void msm_reduce2_kernel_##SFX(const XYZZ<F> *group_out, MsmGeom g,   \
-      XYZZ<F> *task_out) { ZKR_RED_FAT(NV); msm_reduce2_body<F>(group_out, g, task_out); }                                                                                    \
-  static __global__ __launch_bounds__(MSM_THREADS) ZKR_RED_ATTR(NV) void msm_reduce3_kernel_##SFX(const XYZZ<F> *task_out, MsmGeom g,    \
-      XYZZ<F> *result) { ZKR_RED_FAT(NV); msm_reduce3_body<F>(task_out, g, result); }
-ZKR_RED_KERNELS(Fq, g1, 80)
-ZKR_RED_KERNELS(Fq2, g2, 160)
-#undef ZKR_RED_KERNELS
-template <class F> struct RedKernels;
-template <> struct RedKernels<Fq> {
-  static constexpr auto big = msm_big_kernel_g1;
-  static constexpr auto big_finish = msm_big_finish_kernel_g1;
-  static constexpr auto reduce1 = msm_reduce1_kernel_g1;
-  static constexpr auto reduce2 = msm_reduce2_kernel_g1;
-  static constexpr auto reduce3 = msm_reduce3_kernel_g1;
-};
-template <> struct RedKernels<Fq2> {
-  static constexpr auto big = msm_big_kernel_g2;
-  static constexpr auto big_finish = msm_big_finish_kernel_g2;
-  static constexpr auto reduce1 = msm_reduce1_kernel_g2;
-  static constexpr auto reduce2 = msm_reduce2_kernel_g2;
-  static constexpr auto reduce3 = msm_reduce3_kernel_g2;
-};
+template <class F>
+static __global__ __launch_bounds__(MSM_THREADS) void msm_big_kernel(const Affine<F> *points, const uint32_t *offsets, const uint32_t *entries, const uint32_t *big_list,
+                                                                    const uint32_t *big_count, uint32_t big_cap, XYZZ<F> *partials) {
+  msm_big_body<F>(points, offsets, entries, big_list, big_count, big_cap, partials);
+}
+template <class F>
+static __global__ __launch_bounds__(64) void msm_big_finish_kernel(const XYZZ<F> *partials, const uint32_t *big_list, const uint32_t *big_count, uint32_t big_cap,
+                                                                   XYZZ<F> *buckets, int onto) {
+  msm_big_finish_body<F>(partials, big_list, big_count, big_cap, buckets, onto);
+}
+template <class F>
+static __global__ __launch_bounds__(MSM_THREADS) void msm_reduce1_kernel(const XYZZ<F> *buckets, MsmGeom g, XYZZ<F> *group_out) { msm_reduce1_body<F>(buckets, g, group_out); }
+template <class F>
+static __global__ __launch_bounds__(MSM_THREADS) void msm_reduce2_kernel(const XYZZ<F> *group_out, MsmGeom g, XYZZ<F> *task_out) { msm_reduce2_body<F>(group_out, g, task_out); }
+template <class F>
+static __global__ __launch_bounds__(MSM_THREADS) void msm_reduce3_kernel(const XYZZ<F> *task_out, MsmGeom g, XYZZ<F> *result) { msm_reduce3_body<F>(task_out, g, result); }
 
 // ---------------------------------------------------------------- window tables (key load)
 // tbl[k * n + i] = 2^(ck) * tbl[i] for k = 1..K-1, affine, x 2^261; level 0 comes in the key's radix (x 2^256, the wire

@@ -395,9 +395,8 @@ static int calc_h_split_phases(zkr_key *k, ProofSlot &sl, hipStream_t s, ShardGr
 
 // ------------------------------------------------------------------ MSM driver
 template <class F> struct MsmCfg;
-template <> struct MsmCfg<Fq> { static constexpr int ACC_W = 2, SPLIT_W = 2; static constexpr bool ACC_PREFETCH = true; static constexpr const char *ACC_STAGE = "msm_accum_g1"; };
-template <> struct MsmCfg<Fq2> { static constexpr int ACC_W = 2, SPLIT_W = 1; static constexpr bool ACC_PREFETCH = false;  // a second 128-byte point in flight only costs spills (same speed)
-  static constexpr const char *ACC_STAGE = "msm_accum_g2"; };
+template <> struct MsmCfg<Fq> { static constexpr int ACC_W = 2, SPLIT_W = 2; static constexpr bool ACC_AHEAD = true; static constexpr const char *ACC_STAGE = "msm_accum_g1"; };
+template <> struct MsmCfg<Fq2> { static constexpr int ACC_W = 2, SPLIT_W = 1; static constexpr bool ACC_AHEAD = false; static constexpr const char *ACC_STAGE = "msm_accum_g2"; };  // a second 128-byte point in registers spills
 
 // digit records of one scalar vector, split by bucket range; shared by every table over those scalars
 // nbat vectors of n scalars end to end (fused batch; nbat = 1: one proof)
@@ -455,64 +454,33 @@ static int msm_sort_enqueue(Prof pf, hipStream_t s, const uint32_t *rank, const 
   return 0;
 }
 
-// bucket accumulation of up to ACC_MAX_JOBS point tables over finished sorts in ONE launch (kernels_msm.hpp msm_accum_kernel: the
-// tables' workgroups end to end, so a table's launch tail is filled by the next table's fullest buckets).  `srt` may belong to
-// another table with the same point set (B1 and B2 share a sort); `buckets`: where the sums land (the table's own set, a set behind
-// another table's, or -- ACC_ONTO -- a set that already holds another table's sums).
-template <class F> struct AccumTable {
-  const Affine<F> *pts;
-  uint32_t n;                // points (0: the table is empty, skipped)
-  const MsmPlan *pl;
-  const MsmWorkspace *srt;
-  void *buckets;
-  int onto;
-};
+// bucket accumulation of one point table over a finished sort (`srt` may belong to another table with the same point set: B1 and
+// B2 share one); `buckets`: where the sums land (the table's own set, a set behind another table's, or -- ACC_ONTO -- a set that
+// already holds another table's sums)
 template <class F>
-static int msm_accum_enqueue(Prof pf, hipStream_t s, int nbat, const AccumTable<F> *tabs, int ntab) {
-  AccumJobs<F> jobs;
-  memset(&jobs, 0, sizeof(jobs));
-  unsigned grid = 0;
-  int sp = -1;
-  for (int i = 0; i < ntab; i++) {
-    const AccumTable<F> &t = tabs[i];
-    if (t.n == 0) continue;
-    const uint32_t nb = t.pl->nb * (uint32_t)nbat;
-    // small bucket sets: several lanes per bucket (kernels_msm.hpp msm_accum_split_kernel), one launch per table.
-    // lanes per bucket by bucket count, from single-proof latencies: 2^11 / 2^13 / 2^15 buckets (circuits of 2^12 / 2^14 / 2^16):
-    // 1.52 / 1.31 / 1.33, 1.83 / 1.64 / 1.68, 1.76 / 1.69 / 2.00 ms at 2 / 4 / 8 lanes; the tx circuit's 2^16 buckets: 2.30 / 2.02 /
-    // 2.15 / 2.52 ms at 1 / 2 / 4 / 8 (and 631 against 614 unfused pipelined proofs/s at 2 / 4)
-    const int split = nb <= (1u << 15) ? 4 : nb <= (1u << 17) ? 2 : 1;
-    if (split > 1) {
-      const unsigned sgrid = (unsigned)(((size_t)nb * split + ACC_THREADS - 1) / ACC_THREADS);
-      int ssp = prof_begin(pf, s, MsmCfg<F>::ACC_STAGE);
-      // (the Fq2 form is built for ONE wavefront per SIMD: its lane exchange holds two XYZZ points of 72 words, and the budget for
-      // two spilled 170-200 B per lane; a tx proof measures the same either way, profiles/r4_11_tx_single_split_w_g2.txt)
-      if (split == 2) msm_accum_split_kernel<F, MsmCfg<F>::SPLIT_W, 2><<<sgrid, ACC_THREADS, 0, s>>>(t.pts, t.srt->offsets, t.srt->entries, nb, t.srt->counts, t.srt->order, (XYZZ<F> *)t.buckets, t.onto);
-      else msm_accum_split_kernel<F, MsmCfg<F>::SPLIT_W, 4><<<sgrid, ACC_THREADS, 0, s>>>(t.pts, t.srt->offsets, t.srt->entries, nb, t.srt->counts, t.srt->order, (XYZZ<F> *)t.buckets, t.onto);
-      prof_end(pf, s, ssp);
-      continue;
-    }
-    AccumJob<F> &j = jobs.job[jobs.n];
-    j.points = t.pts; j.offsets = t.srt->offsets; j.entries = t.srt->entries; j.counts = t.srt->counts; j.order = t.srt->order;
-    j.buckets = (XYZZ<F> *)t.buckets; j.nb = nb; j.onto = t.onto;
-    jobs.first_block[jobs.n] = grid;
-    grid += (nb + ACC_THREADS - 1) / ACC_THREADS;
-    jobs.first_block[++jobs.n] = grid;
-  }
-  if (jobs.n) {
-    sp = prof_begin(pf, s, MsmCfg<F>::ACC_STAGE);
+static int msm_accum_enqueue(Prof pf, hipStream_t s, const Affine<F> *pts, uint32_t n, int nbat, const MsmPlan &pl, const MsmWorkspace &srt, void *buckets, int onto = 0) {
+  if (n == 0) return 0;
+  const uint32_t nb = pl.nb * (uint32_t)nbat;
+  int sp = prof_begin(pf, s, MsmCfg<F>::ACC_STAGE);
+  // small bucket sets: several lanes per bucket (kernels_msm.hpp msm_accum_split_kernel).
+  // lanes per bucket by bucket count, from single-proof latencies: 2^11 / 2^13 / 2^15 buckets (circuits of 2^12 / 2^14 / 2^16):
+  // 1.52 / 1.31 / 1.33, 1.83 / 1.64 / 1.68, 1.76 / 1.69 / 2.00 ms at 2 / 4 / 8 lanes; the tx circuit's 2^16 buckets: 2.30 / 2.02 /
+  // 2.15 / 2.52 ms at 1 / 2 / 4 / 8 (and 631 against 614 unfused pipelined proofs/s at 2 / 4)
+  const int split = nb <= (1u << 15) ? 4 : nb <= (1u << 17) ? 2 : 1;
+  if (split > 1) {
+    const unsigned sgrid = (unsigned)(((size_t)nb * split + ACC_THREADS - 1) / ACC_THREADS);
+    // (the Fq2 form is built for ONE wavefront per SIMD: its lane exchange holds two XYZZ points of 72 words, and the budget for
+    // two spilled 170-200 B per lane; a tx proof measures the same either way, profiles/r4_11_tx_single_split_w_g2.txt)
+    if (split == 2) msm_accum_split_kernel<F, MsmCfg<F>::SPLIT_W, 2><<<sgrid, ACC_THREADS, 0, s>>>(pts, srt.offsets, srt.entries, nb, srt.counts, srt.order, (XYZZ<F> *)buckets, onto);
+    else msm_accum_split_kernel<F, MsmCfg<F>::SPLIT_W, 4><<<sgrid, ACC_THREADS, 0, s>>>(pts, srt.offsets, srt.entries, nb, srt.counts, srt.order, (XYZZ<F> *)buckets, onto);
+  } else {
     // two wavefronts per SIMD for both G1 and G2 (amdgpu_waves_per_eu pins the register budget): with three G1 wavefronts the
     // other streams' kernels find no registers beside them, one loses the latency cover (HISTORY.md 7b)
-    msm_accum_kernel<F, MsmCfg<F>::ACC_W, MsmCfg<F>::ACC_PREFETCH><<<grid, ACC_THREADS, 0, s>>>(jobs);
-    prof_end(pf, s, sp);
+    msm_accum_kernel<F, MsmCfg<F>::ACC_W, MsmCfg<F>::ACC_AHEAD><<<(nb + ACC_THREADS - 1) / ACC_THREADS, ACC_THREADS, 0, s>>>(pts, srt.offsets, srt.entries, nb, srt.counts, srt.order, (XYZZ<F> *)buckets, onto);
   }
+  prof_end(pf, s, sp);
   ZKR_HIP_CHECK(hipGetLastError());
   return 0;
-}
-template <class F>
-static int msm_accum_enqueue(Prof pf, hipStream_t s, const Affine<F> *pts, uint32_t n, int nbat, const MsmPlan &pl, const MsmWorkspace &srt, MsmWorkspace &ws, int onto = 0) {
-  const AccumTable<F> t{pts, n, &pl, &srt, ws.buckets, onto};
-  return msm_accum_enqueue<F>(pf, s, nbat, &t, 1);
 }
 
 // oversized buckets (digit +-1 of 0/1-heavy witnesses): needs only the sort, so it runs beside the table's accumulation
@@ -520,7 +488,7 @@ template <class F>
 static int msm_big_enqueue(Prof pf, hipStream_t s, const Affine<F> *pts, uint32_t n, const MsmPlan &pl, const MsmWorkspace &srt, MsmWorkspace &ws) {
   if (n == 0) return 0;
   int sp = prof_begin(pf, s, "msm_big");
-  RedKernels<F>::big<<<BIG_SLOTS * BIG_SPLIT, MSM_THREADS, MSM_THREADS * sizeof(XYZZ<F>), s>>>(pts, srt.offsets, srt.entries, srt.big_list, srt.big_count,
+  msm_big_kernel<F><<<BIG_SLOTS * BIG_SPLIT, MSM_THREADS, MSM_THREADS * sizeof(XYZZ<F>), s>>>(pts, srt.offsets, srt.entries, srt.big_list, srt.big_count,
                                                                                                              BIG_CAP, (XYZZ<F> *)ws.big_partials);
   prof_end(pf, s, sp);
   ZKR_HIP_CHECK(hipGetLastError());
@@ -532,7 +500,7 @@ template <class F>
 static int msm_big_finish_enqueue(Prof pf, hipStream_t s, uint32_t n, const MsmWorkspace &srt, MsmWorkspace &ws, bool onto = false) {
   if (n == 0) return 0;
   int sp = prof_begin(pf, s, "msm_big");
-  RedKernels<F>::big_finish<<<BIG_CAP / 64, 64, 0, s>>>((const XYZZ<F> *)ws.big_partials, srt.big_list, srt.big_count, BIG_CAP, (XYZZ<F> *)ws.buckets, onto ? 1 : 0);
+  msm_big_finish_kernel<F><<<BIG_CAP / 64, 64, 0, s>>>((const XYZZ<F> *)ws.big_partials, srt.big_list, srt.big_count, BIG_CAP, (XYZZ<F> *)ws.buckets, onto ? 1 : 0);
   prof_end(pf, s, sp);
   ZKR_HIP_CHECK(hipGetLastError());
   return 0;
@@ -582,9 +550,9 @@ static int msm_reduce_enqueue(Prof pf, hipStream_t s, uint32_t n, int nbat, int 
   int sp = prof_begin(pf, s, "msm_reduce");
   uint32_t ngroups = (pl.nbw >> glog) * (uint32_t)nset;
   uint32_t ntask = (uint32_t)(pl.c - 1 - glog) + 2;
-  RedKernels<F>::reduce1<<<(ngroups + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, reduce1_lds_bytes<F>(), s>>>((XYZZ<F> *)ws.buckets, g, (XYZZ<F> *)ws.group_out);
-  RedKernels<F>::reduce2<<<dim3(ntask * S, nset), MSM_THREADS, MSM_THREADS * sizeof(XYZZ<F>), s>>>((const XYZZ<F> *)ws.group_out, g, (XYZZ<F> *)ws.task_out);
-  RedKernels<F>::reduce3<<<nset, MSM_THREADS, MSM_THREADS * sizeof(XYZZ<F>), s>>>((const XYZZ<F> *)ws.task_out, g, (XYZZ<F> *)ws.result);
+  msm_reduce1_kernel<F><<<(ngroups + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, s>>>((const XYZZ<F> *)ws.buckets, g, (XYZZ<F> *)ws.group_out);
+  msm_reduce2_kernel<F><<<dim3(ntask * S, nset), MSM_THREADS, MSM_THREADS * sizeof(XYZZ<F>), s>>>((const XYZZ<F> *)ws.group_out, g, (XYZZ<F> *)ws.task_out);
+  msm_reduce3_kernel<F><<<nset, MSM_THREADS, MSM_THREADS * sizeof(XYZZ<F>), s>>>((const XYZZ<F> *)ws.task_out, g, (XYZZ<F> *)ws.result);
   prof_end(pf, s, sp);
   ZKR_HIP_CHECK(hipMemcpyAsync(ws.h_result, ws.result, sizeof(XYZZ<F>) * nset, hipMemcpyDeviceToHost, s));
   ZKR_HIP_CHECK(hipGetLastError());
@@ -600,7 +568,7 @@ static int msm_enqueue(Prof pf, hipStream_t s, const Affine<F> *pts, const uint3
   if ((rc = msm_digits_enqueue(pf, s, scalars, n_scalars, 1, pl, ws.own_dig))) return rc;
   if ((rc = msm_sort_enqueue(pf, s, rank, ws.own_dig, n_scalars, n, 1, pl, ws))) return rc;
   if ((rc = msm_big_enqueue<F>(pf, s, pts, n, pl, ws, ws))) return rc;
-  if ((rc = msm_accum_enqueue<F>(pf, s, pts, n, 1, pl, ws, ws))) return rc;
+  if ((rc = msm_accum_enqueue<F>(pf, s, pts, n, 1, pl, ws, ws.buckets))) return rc;
   if ((rc = msm_big_finish_enqueue<F>(pf, s, n, ws, ws))) return rc;
   return msm_reduce_enqueue<F>(pf, s, n, 1, 1, pl, ws, ws);
 }
@@ -772,76 +740,66 @@ static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *const *d_ws
   for (const ProofSlot &o : k->slot)
     if (&o != &sl && o.busy) alone = false;
   hipStream_t last = s;
-  // One accumulation launch for the tables of `ts` (one G2 table, or up to three G1 tables: kernels_msm.hpp msm_accum_kernel) and
-  // the chain of each: (1) the chain's stream waits for the table's sort and takes its oversized buckets (they need only the
-  // sort and run beside the accumulation), (2) the launch on the accumulation stream, (3) oversized-bucket sums into the buckets
-  // and the bucket reduction, on the chain's stream again.
-  auto accum_group = [&](std::initializer_list<int> ts) -> int {
+  // One table: (1) its chain's stream waits for the table's sort and takes its oversized buckets (they need only the sort and run
+  // beside the accumulation), (2) the accumulation on the accumulation stream, (3) oversized-bucket sums into the buckets and
+  // the bucket reduction, on the chain's stream again.
+  auto accum_table = [&](int t) -> int {
     int rc;
-    const int t0 = *ts.begin();
-    for (int t : ts) {
-      hipStream_t rs = red_of(t);
-      last = rs;
-      const MsmWorkspace &srt = sl.ws[sort_src[t]];
-      const void *pts = ar + h.off_pts[t];
-      if (!serial) ZKR_HIP_CHECK(hipStreamWaitEvent(rs, sl.ev_sorted[sort_src[t]], 0));
-      // partial sums into the table's OWN partials buffer.  C's, when C shares H's bucket set, may have been enqueued in front of
-      // every chain (c_big_first)
-      if (t == T_C && c_big_first) continue;
+    hipStream_t rs = red_of(t);
+    last = rs;
+    const MsmWorkspace &srt = sl.ws[sort_src[t]];
+    const void *pts = ar + h.off_pts[t];
+    if (!serial) ZKR_HIP_CHECK(hipStreamWaitEvent(rs, sl.ev_sorted[sort_src[t]], 0));
+    // partial sums into the table's OWN partials buffer.  C's, when C shares H's bucket set, may have been enqueued in front of
+    // every chain (c_big_first)
+    if (!(t == T_C && c_big_first)) {
       if (t == T_B2) rc = msm_big_enqueue<Fq2>(pf, rs, (const G2Affine *)pts, h.npts[t], k->plan[t], srt, sl.ws[t]);
       else rc = msm_big_enqueue<Fq>(pf, rs, (const G1Affine *)pts, h.npts[t], k->plan[t], srt, sl.ws[t]);
       if (rc) return rc;
       if (t == T_C && merge_ch && !serial) ZKR_HIP_CHECK(hipEventRecord(sl.ev_h, rs));  // C's partial sums are on their way: H's chain adds them in
     }
-    if (!serial)
-      for (int t : ts) ZKR_HIP_CHECK(hipStreamWaitEvent(s, sl.ev_sorted[sort_src[t]], 0));
-    if (t0 == T_B2) {
-      if ((rc = msm_accum_enqueue<Fq2>(pf, s, (const G2Affine *)(ar + h.off_pts[T_B2]), h.npts[T_B2], nbat, k->plan[T_B2], sl.ws[sort_src[T_B2]], sl.ws[T_B2]))) return rc;
-    } else {
-      AccumTable<Fq> tabs[ACC_MAX_JOBS];
-      int nt = 0;
-      for (int t : ts) {
-        if (nt == ACC_MAX_JOBS) { set_error("accumulation group of more than %d tables", ACC_MAX_JOBS); return ZKR_ERR_ARG; }
-        // whose bucket set the table lands in: H onto C's (merge_ch), A behind B1's sets (joint chain); its oversized-bucket sums stay its own.
-        // Shared set: C's accumulation clears the slots of ITS oversized buckets (their sums are added after H's accumulation, so
-        // H's accumulation waits for nothing but C's, in front of it on the same stream)
-        void *buckets = t == T_H && merge_ch ? sl.ws[T_C].buckets : sl.ws[t].buckets;
-        if (joint_ab && t == T_A) buckets = (char *)sl.ws[T_B1].buckets + (size_t)nbat * k->plan[T_B1].nb * sizeof(G1XYZZ);
-        const int flags = t == T_H && merge_ch ? ACC_ONTO : (t == T_C && merge_ch ? ACC_ZERO_BIG : 0);
-        tabs[nt++] = AccumTable<Fq>{(const G1Affine *)(ar + h.off_pts[t]), h.npts[t], &k->plan[t], &sl.ws[sort_src[t]], buckets, flags};
-      }
-      if ((rc = msm_accum_enqueue<Fq>(pf, s, nbat, tabs, nt))) return rc;
+    if (!serial) ZKR_HIP_CHECK(hipStreamWaitEvent(s, sl.ev_sorted[sort_src[t]], 0));
+    // whose bucket set the table lands in: H onto C's (merge_ch), A behind B1's sets (joint chain); its oversized-bucket sums stay its
+    // own.  Shared set: C's accumulation clears the slots of ITS oversized buckets (their sums are added after H's accumulation, so
+    // H's accumulation waits for nothing but C's, in front of it on the same stream)
+    void *buckets = t == T_H && merge_ch ? sl.ws[T_C].buckets : sl.ws[t].buckets;
+    if (joint_ab && t == T_A) buckets = (char *)sl.ws[T_B1].buckets + (size_t)nbat * k->plan[T_B1].nb * sizeof(G1XYZZ);
+    const int flags = t == T_H && merge_ch ? ACC_ONTO : (t == T_C && merge_ch ? ACC_ZERO_BIG : 0);
+    if (t == T_B2) rc = msm_accum_enqueue<Fq2>(pf, s, (const G2Affine *)pts, h.npts[t], nbat, k->plan[t], srt, buckets);
+    else rc = msm_accum_enqueue<Fq>(pf, s, (const G1Affine *)pts, h.npts[t], nbat, k->plan[t], srt, buckets, flags);
+    if (rc) return rc;
+    if (!serial) ZKR_HIP_CHECK(hipEventRecord(sl.ev_done[t], s));
+    if (t == T_C && merge_ch) return 0;             // reduced with H
+    if (joint_ab && t == T_B1) return 0;            // reduced with A, by A's turn on this stream (B1's oversized-bucket sums are on their way on it)
+    if (!serial) ZKR_HIP_CHECK(hipStreamWaitEvent(rs, sl.ev_done[t], 0));
+    if (t == T_B2) {
+      if ((rc = msm_big_finish_enqueue<Fq2>(pf, rs, h.npts[t], srt, sl.ws[t]))) return rc;
+      return result_event(t, rs, msm_reduce_enqueue<Fq2>(pf, rs, h.npts[t], nbat, 1, k->plan[t], srt, sl.ws[t]));
     }
-    if (!serial) ZKR_HIP_CHECK(hipEventRecord(sl.ev_done[t0], s));
-    for (int t : ts) {
-      hipStream_t rs = red_of(t);
-      const MsmWorkspace &srt = sl.ws[sort_src[t]];
-      if (t == T_C && merge_ch) continue;             // reduced with H
-      if (joint_ab && t == T_B1) continue;            // reduced with A, by A's turn on this stream (B1's oversized-bucket sums are on their way on it)
-      if (!serial) ZKR_HIP_CHECK(hipStreamWaitEvent(rs, sl.ev_done[t0], 0));
-      if (t == T_B2) {
-        if ((rc = msm_big_finish_enqueue<Fq2>(pf, rs, h.npts[t], srt, sl.ws[t]))) return rc;
-        if ((rc = result_event(t, rs, msm_reduce_enqueue<Fq2>(pf, rs, h.npts[t], nbat, 1, k->plan[t], srt, sl.ws[t])))) return rc;
-      } else if (t == T_H && merge_ch) {  // both tables' oversized buckets are ADDED to what the shared set holds: C's partial sums (its own sort's list), then H's
-        if (!serial) ZKR_HIP_CHECK(hipStreamWaitEvent(rs, sl.ev_h, 0));
-        MsmWorkspace mixc = sl.ws[T_C];   // C's workspace: its partials, its buckets
-        if ((rc = msm_big_finish_enqueue<Fq>(pf, rs, h.npts[T_C], sl.ws[sort_src[T_C]], mixc, true))) return rc;
-        MsmWorkspace mix = sl.ws[T_C];
-        mix.big_partials = sl.ws[t].big_partials;
-        if ((rc = msm_big_finish_enqueue<Fq>(pf, rs, h.npts[t], srt, mix, true))) return rc;
-        if ((rc = result_event(t, rs, msm_reduce_enqueue<Fq>(pf, rs, h.npts[t], nbat, 1, k->plan[t], srt, mixc, alone)))) return rc;
-      } else if (joint_ab && t == T_A) {
-        // the stream is in order: B1's partial sums (enqueued at B1's turn) are done; both accumulations have run (B1's in this launch or an earlier one)
-        MsmWorkspace dst = sl.ws[t];
-        dst.buckets = (char *)sl.ws[T_B1].buckets + (size_t)nbat * k->plan[T_B1].nb * sizeof(G1XYZZ);
-        if ((rc = msm_big_finish_enqueue<Fq>(pf, rs, h.npts[T_B1], sl.ws[sort_src[T_B1]], sl.ws[T_B1]))) return rc;
-        if ((rc = msm_big_finish_enqueue<Fq>(pf, rs, h.npts[T_A], srt, dst))) return rc;
-        if ((rc = result_event(T_A, rs, msm_reduce_enqueue<Fq>(pf, rs, h.npts[T_B1], nbat, 2, k->plan[T_B1], sl.ws[sort_src[T_B1]], sl.ws[T_B1])))) return rc;
-      } else {
-        if ((rc = msm_big_finish_enqueue<Fq>(pf, rs, h.npts[t], srt, sl.ws[t]))) return rc;
-        if ((rc = result_event(t, rs, msm_reduce_enqueue<Fq>(pf, rs, h.npts[t], nbat, 1, k->plan[t], srt, sl.ws[t], alone && t == T_H)))) return rc;
-      }
+    if (t == T_H && merge_ch) {  // both tables' oversized buckets are ADDED to what the shared set holds: C's partial sums (its own sort's list), then H's
+      if (!serial) ZKR_HIP_CHECK(hipStreamWaitEvent(rs, sl.ev_h, 0));
+      MsmWorkspace mixc = sl.ws[T_C];   // C's workspace: its partials, its buckets
+      if ((rc = msm_big_finish_enqueue<Fq>(pf, rs, h.npts[T_C], sl.ws[sort_src[T_C]], mixc, true))) return rc;
+      MsmWorkspace mix = sl.ws[T_C];
+      mix.big_partials = sl.ws[t].big_partials;
+      if ((rc = msm_big_finish_enqueue<Fq>(pf, rs, h.npts[t], srt, mix, true))) return rc;
+      return result_event(t, rs, msm_reduce_enqueue<Fq>(pf, rs, h.npts[t], nbat, 1, k->plan[t], srt, mixc, alone));
     }
+    if (joint_ab && t == T_A) {
+      // the stream is in order: B1's partial sums (enqueued at B1's turn) are done; both accumulations ran on the one accumulation
+      // stream, A's last (ev_done[T_A] is waited for above)
+      MsmWorkspace dst = sl.ws[t];
+      dst.buckets = buckets;
+      if ((rc = msm_big_finish_enqueue<Fq>(pf, rs, h.npts[T_B1], sl.ws[sort_src[T_B1]], sl.ws[T_B1]))) return rc;
+      if ((rc = msm_big_finish_enqueue<Fq>(pf, rs, h.npts[T_A], srt, dst))) return rc;
+      return result_event(T_A, rs, msm_reduce_enqueue<Fq>(pf, rs, h.npts[T_B1], nbat, 2, k->plan[T_B1], sl.ws[sort_src[T_B1]], sl.ws[T_B1]));
+    }
+    if ((rc = msm_big_finish_enqueue<Fq>(pf, rs, h.npts[t], srt, sl.ws[t]))) return rc;
+    return result_event(t, rs, msm_reduce_enqueue<Fq>(pf, rs, h.npts[t], nbat, 1, k->plan[t], srt, sl.ws[t], alone && t == T_H));
+  };
+  auto chains = [&](std::initializer_list<int> ts) -> int {
+    for (int t : ts)
+      if (int rc = accum_table(t)) return rc;
     return 0;
   };
   // C shares H's bucket set and has no chain of its own: its oversized-bucket partial sums (needed by H's chain, which adds them
@@ -865,26 +823,20 @@ static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *const *d_ws
   if ((rc = msm_digits_enqueue(pf, sw, sl.d_w + h.sc_lo[0], h.sc_n[0], nbat, k->plan[T_A], sl.dig_w, true))) return rc;
   if ((rc = sort_table(T_B1))) return rc;
   if (!share_b && (rc = sort_table(T_B2))) return rc;
-  if (early && ((rc = accum_group({T_B2})) || (rc = accum_group({T_B1})))) return rc;
+  if (early && (rc = chains({T_B2, T_B1}))) return rc;
   if ((rc = sort_table(T_A))) return rc;
   if (!share_ac && (rc = sort_table(T_C))) return rc;
-  if (early && ((rc = c_big()) || (rc = accum_group({T_A, T_C})))) return rc;
+  if (early && ((rc = c_big()) || (rc = chains({T_A, T_C})))) return rc;
   if (split_h) rc = calc_h_split(k, sl, sp, *group, shard_group_part, enqueue_lock);
   else rc = calc_h_device(k, sl, sp, nbat);
   if (rc) return rc;
   if ((rc = msm_digits_enqueue(pf, sp, sl.d_h + h.sc_lo[1], h.sc_n[1], nbat, k->plan[T_H], sl.dig_h, true))) return rc;
   if ((rc = sort_table(T_H))) return rc;
-  // accumulations + reduction chains: B2 first (its chain is the longest), then the three G1 tables of the witness in ONE launch, then H
-  static const int exp_merge = getenv("ZKR_EXP_MERGE") ? atoi(getenv("ZKR_EXP_MERGE")) : 3;  // TEMPORARY (round-6 A/B): 3 = B1 + A + C, 2 = B1 + A | C, 1 = B1 | A + C, 0 = one launch per table
-  if (!early) {
-    if ((rc = c_big()) || (rc = accum_group({T_B2}))) return rc;
-    if (exp_merge == 3) rc = accum_group({T_B1, T_A, T_C});
-    else if (exp_merge == 2) { if (!(rc = accum_group({T_B1, T_A}))) rc = accum_group({T_C}); }
-    else if (exp_merge == 1) { if (!(rc = accum_group({T_B1}))) rc = accum_group({T_A, T_C}); }
-    else { if (!(rc = accum_group({T_B1})) && !(rc = accum_group({T_A}))) rc = accum_group({T_C}); }
-    if (rc) return rc;
-  }
-  if ((rc = accum_group({T_H}))) return rc;
+  // accumulations + reduction chains: B2 first (its chain is the longest), one launch per table (B1 + A + C in ONE launch measured
+  // 3 % slower: the launch tails it removes are where the other streams' kernels find room, profiles/r6_03_ab_groupings.txt)
+  if (early) rc = chains({T_H});
+  else { if ((rc = c_big())) return rc; rc = chains({T_B2, T_B1, T_A, T_C, T_H}); }
+  if (rc) return rc;
   // completion = every reduction stream done (prove_collect waits for the events on the host).  No stream is made
   // to wait for another, so nothing of the next proof queues behind this one's tail.
   prof_end(pf, last, tot);

@@ -35,10 +35,11 @@ int main(int argc, char **argv) {
   const size_t one_mb = one ? (size_t)atoi(argv[2]) : 0, one_lds = one ? (size_t)atoi(argv[4]) * 1024 : 0;
   uint4 *out; hipMalloc(&out, (size_t)nthreads * 16);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (size_t lds : {(size_t)0, (size_t)80 * 1024}) for (int bytes : {64, 128}) for (size_t mb : {64, 832}) for (int seq = 0; seq < 2; seq++) {
+  for (size_t lds : {(size_t)0, (size_t)80 * 1024}) for (int bytes : {64, 128}) for (size_t mb : {(size_t)64, (size_t)832, (size_t)17408, (size_t)69632}) for (int seq = 0; seq < 2; seq++) {
+    if (!one && mb > 832) continue;  // the large tables (a 256-level G1 table of 2^20 points: 17 GB; four of them) only on request
     if (one && (bytes != one_bytes || mb != one_mb || seq != one_seq || lds != one_lds)) continue;
     size_t n = mb * 1024 * 1024 / bytes;
-    uint4 *tbl; hipMalloc(&tbl, n * bytes); hipMemset(tbl, 1, n * bytes);
+    uint4 *tbl; hipMalloc(&tbl, n * bytes); if (hipMemset(tbl, 1, n * bytes) != hipSuccess) { printf("table of %zu MB: allocation failed\n", mb); return 1; }
     std::vector<uint32_t> idx((size_t)nthreads * per);
     uint64_t st = 88172645463325252ull;
     for (size_t i = 0; i < idx.size(); i++) { st ^= st << 13; st ^= st >> 7; st ^= st << 17; idx[i] = seq ? (uint32_t)(i % n) : (uint32_t)((st >> 11) % n); }
