@@ -22,6 +22,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "simple-zk-rollups_amd", "python"))
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+ROUND = 6                                  # the counter files bench.py quotes must be THIS round's (profiles/r6_*): older kernels' traffic is not carried over
+PMC_FILE = "r%d_pmc_traffic.json" % ROUND  # HBM traffic per kernel (tools/profile_round6.sh part b)
+CENSUS_FILE = "r%d_valu_census.json" % ROUND  # VALU wave-instructions per proof by SQ counters (profiles/summarize_census.py)
 # Group additions in units of one Fq Montgomery multiplication of the hot path (csrc/field29.hpp: 9 x 29-bit limbs, 162
 # 32x32 multiply-adds: 81 for the product, 81 for the reduction).  A square takes its off-diagonal products once (45 + 81),
 # the Y coordinate of an addition is a difference of two products with ONE reduction (2 x 81 + 81), an Fq2 product is two
@@ -716,18 +719,21 @@ def roofline_record(key, info, prof, per_proof_s, device_state, log_m, shape, lo
     ms_total, launches = prof[st]
     avg_ms = ms_total / max(launches, 1)
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-    traffic, traffic_src, proof_traffic, pmc_file = None, None, None, None
-    try:  # HBM bytes per launch from the committed PMC passes (bench.py cannot collect PMCs itself)
-        pmc_file = next(f for f in ("r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+    traffic, traffic_src, proof_traffic, pmc_file = None, "no PMC pass of round %d under profiles/ (%s): traffic is not carried over from older kernels" % (ROUND, PMC_FILE), None, PMC_FILE
+    census_busy, census_src = None, None
+    try:  # HBM bytes per launch from the committed PMC passes (bench.py cannot collect PMCs itself) -- THIS round's only: an older
+          # file describes older kernels
         pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
+        if pmc.get("round") != ROUND:
+            raise ValueError("stale PMC file")
         if pmc["config"]["log_m"] == log_m and shape == "rollup":
             # whole proof: every kernel of the proving path (not key build), per ingest_kernel launch = per proof
             skip = ("precompute", "fixed_base", "twiddle", "gather", "fq_mul_bench", "rocclr_copy")
             per_run = sum(v["hbm_bytes_per_launch"] * v["launches"] for k, v in pmc["kernels"].items() if not any(x in k for x in skip))
             proof_traffic = per_run / pmc["kernels"]["ingest_kernel"]["launches"]
             traffic = pmc["kernels"][dom]["hbm_bytes_per_launch"]
-            traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 read correction; %s)" % (
-                pmc_file, pmc.get("schedule", "isolated kernels"))
+            traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x %.3f, the factor calibrated on this kernel's access pattern: %s; %s)" % (
+                pmc_file, pmc["calibration"][pmc["kernels"][dom]["pattern"]], pmc["calibration_source"], pmc.get("schedule", "isolated kernels"))
     except Exception:
         pass
     # the kernels of the path that STREAM (SURVEY 8(d) regime 1), each against the HBM peak: algorithmic bytes per launch
@@ -751,7 +757,7 @@ def roofline_record(key, info, prof, per_proof_s, device_state, log_m, shape, lo
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "note": "Pippenger bucket accumulation is integer-VALU bound (v_mad_u64_u32), not HBM bound; see valu. traffic > algorithmic bytes by design: "
                         "the kernel gathers one precomputed 64-byte multiple per window (13 per point, 832 B) instead of re-deriving it, "
-                        "plus the 4-byte entries; the PMC figure applies the x2 read rule, an upper bound for 64-byte gathers. "
+                        "plus the 4-byte entries; traffic = FETCH_SIZE x the factor calibrated on random 64-byte gathers + WRITE_SIZE (traffic_source). "
                         "avg_launch_ms is measured with two proofs in flight (the kernel shares the chip with the other streams); isolated it runs 0.79 ms"}
     try:
         legacy = None
@@ -799,12 +805,31 @@ def roofline_record(key, info, prof, per_proof_s, device_state, log_m, shape, lo
                          "sclk_mhz_sampled": mhz})
     except Exception as e:  # microbench is informative only
         roofline["valu"] = {"error": str(e)}
+    # ratios the record should carry itself: measured HBM traffic over algorithmic bytes, kernel and proof
+    roofline["traffic_over_algorithmic"] = (traffic / bytes_per_launch) if traffic else None
+    # VALU-busy fraction of the timed step by COUNTERS: SQ_INSTS_VALU of every kernel of a proof (isolated pass: dispatch-mode counters
+    # serialise anyway; SQ_ACTIVE_INST_VALU charges one quad-cycle per instruction) x 4 cycles / (1024 SIMDs x sampled clock x step)
+    try:
+        cen = json.load(open(os.path.join(ROOT, "profiles", CENSUS_FILE)))
+        mhz = (device_state or {}).get("sclk_mhz_mean")
+        if cen.get("round") == ROUND and cen["config"]["log_m"] == log_m and shape == "rollup" and mhz:
+            roofline["valu_busy_step"] = 4.0 * cen["valu_wave_instructions_per_proof"] / (1024 * mhz * 1e6 * per_proof_s)
+            roofline["valu_wave_instructions_per_proof"] = cen["valu_wave_instructions_per_proof"]
+            roofline["valu_busy_source"] = "profiles/%s (rocprofv3 --pmc SQ_INSTS_VALU ..., isolated kernels) x 4 cycles / (1024 SIMDs x sclk sampled in this run x ms_per_step)" % CENSUS_FILE
+    except Exception:
+        pass
     whole = None if proof_traffic is None else {
         "bytes_per_proof": proof_traffic, "GBps_per_gpu": proof_traffic / per_proof_s / 1e9,
         "frac_of_peak": proof_traffic / per_proof_s / 1e9 / HBM_PEAK_GBPS,
-        "source": "sum over the proving kernels of profiles/%s (x2 read rule: an upper bound for the 64-byte gathers)" % pmc_file}
+        "source": "sum over the proving kernels of profiles/%s (FETCH_SIZE x the factor calibrated per access pattern + WRITE_SIZE)" % pmc_file}
     if whole:
-        roofline.update({"hbm_traffic_GB_per_proof": whole["bytes_per_proof"] / 1e9, "hbm_traffic_frac_proof": whole["frac_of_peak"]})
+        # B_proof = B_spmv + B_ntt + B_msm, every base point, scalar, QAP entry and vector element once
+        n_, m_, p_ = info["nVars"], info["domainSize"], N_PUBLIC
+        b_proof = (36.0 * (info["nnzA"] + info["nnzB"]) + 32.0 * n_ + 64.0 * m_) + 576.0 * m_ + (
+            64.0 * (info["ptsA"] + info["ptsB1"] + info["ptsC"] + info["ptsH"]) + 128.0 * info["ptsB2"] + 32.0 * n_ + 32.0 * m_)
+        whole["algorithmic_bytes_per_proof"] = b_proof
+        roofline.update({"hbm_traffic_GB_per_proof": whole["bytes_per_proof"] / 1e9, "hbm_traffic_frac_proof": whole["frac_of_peak"],
+                         "algorithmic_GB_per_proof": b_proof / 1e9, "hbm_traffic_over_algorithmic_proof": whole["bytes_per_proof"] / b_proof})
     for k, v in streaming.items():   # the streaming kernels' fractions of the HBM peak as scalars: hbm_frac_ingest, _spmv, _ntt_pass, _combine_h
         roofline["hbm_frac_" + k.split("_kernel")[0].split(" ")[0]] = v["frac_of_hbm_peak"]
     return roofline, whole

@@ -1,6 +1,6 @@
 """VALU census of one proof from a rocprofv3 --pmc pass that carried several SQ counters at once (rocpd SQLite).
 
-python profiles/summarize_census.py <db> <launches_per_proof.json|auto|-> [step_ms sclk_ghz]   (auto: launches / number of G2 accumulations)
+python profiles/summarize_census.py <db> <launches_per_proof.json|auto|-> [step_ms sclk_ghz [out.json log_m round]]   (auto: launches / number of G2 accumulations)
 
 Per kernel (per launch, counters summed over their per-XCD / per-SE records): duration, SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU,
 SQ_BUSY_CYCLES, SQ_WAVE_CYCLES, SQ_WAIT_INST_ANY, SQ_WAIT_ANY, SQ_ACTIVE_INST_ANY and the derived
@@ -78,3 +78,13 @@ if per_proof:
     if step_ms:
         print("VALU-busy fraction of a %.3f ms step at %.2f GHz over %d SIMDs: %.3f" % (step_ms, sclk / 1e9, SIMDS, 4 * tot_active / (SIMDS * sclk * step_ms * 1e-3)))
         print("step time at 100 %% VALU-busy: %.3f ms" % (4 * tot_active / (SIMDS * sclk) * 1e3))
+
+if per_proof and len(sys.argv) > 5:
+    out = {"source": "rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU ... GRBM_GUI_ACTIVE (one pass) -- ZKR_SERIAL=1 python3 bench.py --steps 2 --warmup 1 --no-pipeline (isolated kernels)",
+           "config": {"log_m": int(sys.argv[6]), "n_public": 73}, "round": int(sys.argv[7]),
+           "valu_wave_instructions_per_proof": tot_insts, "valu_active_quad_cycles_per_proof": tot_active, "launches_per_proof": per_proof, "kernels": {}}
+    for k, n, dur, c in rows:
+        if k in per_proof:
+            out["kernels"][k] = {"launches": n, "avg_us": dur * 1e6, "SQ_INSTS_VALU_per_launch": c.get("SQ_INSTS_VALU", 0.0), "SQ_WAVE_CYCLES_per_launch": c.get("SQ_WAVE_CYCLES", 0.0),
+                                "SQ_WAIT_ANY_per_launch": c.get("SQ_WAIT_ANY", 0.0), "SQ_WAIT_INST_ANY_per_launch": c.get("SQ_WAIT_INST_ANY", 0.0), "GRBM_GUI_ACTIVE_per_launch": c.get("GRBM_GUI_ACTIVE", 0.0)}
+    json.dump(out, open(sys.argv[5], "w"), indent=1)

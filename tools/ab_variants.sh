@@ -1,6 +1,6 @@
 # Same-box comparison of variants of the library / its knobs (run through gpurun):
 #   bash tools/ab_variants.sh <rounds> "name:ENV=val,ENV=val" ...       (an empty assignment list = the shipped defaults)
-# e.g. bash tools/ab_variants.sh 3 "shipped:" "ntt256:ZKR_HIP_LIB=tools/bin/libzkr_hip_ntt256.so" "acc1:ZKR_ACC_W_G1=1"
+# e.g. bash tools/ab_variants.sh 3 "shipped:" "r5:ZKR_HIP_LIB=tools/bin/libzkr_hip_r5.so" "c19:ZKR_MSM_C=19"   (library builds under tools/bin/, or the few knobs the library keeps: INTEGRATION.md)
 # The boxes of the pool differ by +-3 % among themselves: only numbers from one call are comparable.
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
 N=$1; shift
