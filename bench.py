@@ -758,7 +758,7 @@ def roofline_record(key, info, prof, per_proof_s, device_state, log_m, shape, lo
                 "note": "Pippenger bucket accumulation is integer-VALU bound (v_mad_u64_u32), not HBM bound; see valu. traffic > algorithmic bytes by design: "
                         "the kernel gathers one precomputed 64-byte multiple per window (13 per point, 832 B) instead of re-deriving it, "
                         "plus the 4-byte entries; traffic = FETCH_SIZE x the factor calibrated on random 64-byte gathers + WRITE_SIZE (traffic_source). "
-                        "avg_launch_ms is measured with two proofs in flight (the kernel shares the chip with the other streams); isolated it runs 0.79 ms"}
+                        "avg_launch_ms is measured with two proofs in flight (the kernel shares the chip with the other streams); isolated it runs 0.76 ms"}
     try:
         legacy = None
         if peak_gmul is None:

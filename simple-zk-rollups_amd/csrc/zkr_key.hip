@@ -238,7 +238,7 @@ void msm_ws_free(MsmWorkspace &ws) {
 // 940 against 1 040 proofs/s, the real circuit at 2^20 133 against 154; with GPU_MAX_HW_QUEUES=8 they came back:
 // tools/bench_leg_interference*.sh).  One set per device never moves.  Two keys proving at the same time share the streams: the
 // launches of one proof are enqueued under the device's enqueue lock, so every cross-stream wait points at work enqueued before it
-// and the shared streams cannot wait for each other in a circle.  ZKR_PRIVATE_STREAMS=1: a set per key as before (A/B).
+// and the shared streams cannot wait for each other in a circle.
 namespace {
 struct DeviceStreams {
   hipStream_t accum = nullptr, prep = nullptr, aux = nullptr, red[N_TABLES] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -257,7 +257,7 @@ static int make_streams(DeviceStreams &ds, int n_red) {
   if (!ds.prep) ZKR_HIP_CHECK(hipStreamCreateWithPriority(&ds.prep, hipStreamNonBlocking, prio_hi));
   for (int j = 0; j < n_red; j++)
     if (!ds.red[j]) ZKR_HIP_CHECK(hipStreamCreateWithPriority(&ds.red[j], hipStreamNonBlocking, prio_hi));
-  // one more for C's oversized-bucket sums (and, ZKR_H_CHAIN_AUX, the proof's last chain).  At the MIDDLE priority: a fifth
+  // one more for C's oversized-bucket sums in a lone proof of a small circuit, and for a shard's witness-side sorts.  At the MIDDLE priority: a fifth
   // high-priority stream made the next one created -- the witness builder's (rollup_gpu.hip) -- share a hardware queue with the
   // preparation stream: its 28 ms kernel then stalled every proof behind it (facade pipeline 623 against 840 batches/s, tools/ab_hw_queues2.sh)
   if (!ds.aux) ZKR_HIP_CHECK(hipStreamCreateWithPriority(&ds.aux, hipStreamNonBlocking, (prio_lo + prio_hi) / 2));

@@ -658,7 +658,7 @@ static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *const *d_ws
   //        same sort (h.share_b), then A, C, H, each waiting only for its table's sort.  Every accumulation
   //        saturates the VALUs on its own;
   //   red[0] : oversized-bucket and reduction chain of the G2 table;  red[1] : those of the four G1 tables (more
-  //        streams with ZKR_RED_STREAMS; one stream for all five chains is the bottleneck with two proofs in
+  //        streams measured slower, HISTORY.md 7b; one stream for all five chains is the bottleneck with two proofs in
   //        flight: ~6 ms of serialised launches per proof).  Few long-running wavefronts at raised wave priority
   //        that run under the following accumulations; the oversized buckets need only the sort and run beside
   //        the accumulation.

@@ -1,5 +1,6 @@
 # Round-6 measurement set on one MI355X (run through gpurun):  bash tools/profile_round6.sh <part> <tag>   -> gpurun_out/<tag>/
 #   part a: the default bench as the driver runs it (wall time recorded) + the synchronous leg
+#   part c: bench lines of the other BASELINE sizes (2^22 with its 8-shard legs, 2^24 rollup-shaped and dense) and the in-process two-replica rehearsal
 #   part b: ONE set for DESIGN.md section 5: kernel stats of the benchmarked command (rocprofv3 --kernel-trace --stats), queue occupancy,
 #           steady-state timeline of one proof period, isolated kernel durations (ZKR_SERIAL=1), HBM traffic (FETCH_SIZE / WRITE_SIZE in
 #           separate --pmc passes, calibrated per access pattern: profiles/summarize_pmc.py), the VALU census (SQ counters, one pass)
@@ -30,4 +31,13 @@ if [ $PART = b ]; then
   STEP=$(python3 -c "import json; print(json.load(open('$O/bench_traced.json'))['ms_per_step'])")
   python3 profiles/summarize_census.py $(find $O/cs -name "*.db" | head -1) auto $STEP 2.27 $O/valu_census.json 20 6 > $O/valu_census.md; rm -rf $O/cs
   head -14 $O/kernel_stats.md | cut -c1-160; head -12 $O/pmc_traffic.md; tail -4 $O/valu_census.md
+fi
+if [ $PART = c ]; then
+  python3 bench.py --log-m 22 --steps 20 $LIGHT --shards 8 > $O/bench_2_22.json 2>/dev/null
+  python3 bench.py --log-m 24 --steps 6 --warmup 1 $LIGHT --shards 8 > $O/bench_2_24_rollup.json 2>/dev/null
+  python3 bench.py --log-m 24 --shape dense --steps 6 --warmup 1 $LIGHT --shards 8 > $O/bench_2_24_dense.json 2>/dev/null
+  python3 bench.py --gpus 2 --inproc --devices 0,0 --steps 20 --warmup 3 > $O/bench_inproc_0_0.json 2>/dev/null
+  for f in bench_2_22 bench_2_24_rollup bench_2_24_dense bench_inproc_0_0; do python3 -c "
+import json; d=json.load(open('$O/$f.json')); s=d.get('intra_proof_sharding') or {}
+print('$f', round(d['value'],2), 'proofs/s', round(d['ms_per_step'],2), 'ms', '| shards:', s.get('parts'), 'whole', s.get('whole_key_sync_proof_ms') and round(s['whole_key_sync_proof_ms'],2), 'slowest', s.get('slowest_shard_ms') and round(s['slowest_shard_ms'],2), 'form', s.get('form'))"; done
 fi
