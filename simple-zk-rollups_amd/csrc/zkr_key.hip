@@ -173,6 +173,8 @@ static int arena_rows_check(const unsigned char *arena, const ArenaHeader &h) {
 // cap: proofs a fused batch can hold (cap bucket sets end to end; kernels_msm.hpp msm_digits_count_kernel)
 // sets: bucket sets (with their reduction buffers) the workspace holds per proof -- 2 for B1, whose chain also reduces A's buckets
 // (prove_submit_enqueue joint_ab)
+// sets: bucket sets (and reduction buffers) per proof -- 2 in B1's workspace when A is accumulated behind B1's sets and reduced with
+// them in one chain, 0 in A's own workspace then: it keeps only what its sort and its oversized buckets need
 static int alloc_msm_ws(MsmWorkspace &ws, size_t n, const MsmPlan &pl, size_t xyzz_bytes, size_t cap = 1, size_t sets = 1) {
   size_t nb = pl.nb * cap;
   ZKR_HIP_CHECK(hipMalloc(&ws.counts, (nb + 1) * 4));
@@ -185,14 +187,16 @@ static int alloc_msm_ws(MsmWorkspace &ws, size_t n, const MsmPlan &pl, size_t xy
   ZKR_HIP_CHECK(hipMalloc(&ws.big_count, 16));  // [0] oversized buckets, [1] total entries, [2] tile ticket (kernels_msm.hpp SortScratch)
   ZKR_HIP_CHECK(hipMalloc(&ws.block_sums, (nb / SCAN_BLOCK + 2) * 8));  // one 64-bit look-back word per scan tile (msm_scan_fused_kernel)
   ZKR_HIP_CHECK(hipMalloc(&ws.big_partials, (size_t)BIG_CAP * BIG_SPLIT * xyzz_bytes));
-  ZKR_HIP_CHECK(hipMalloc(&ws.buckets, nb * sets * xyzz_bytes));
-  // sized for the plan's groups AND for the smaller groups of a latency-mode chain (zkr_prove.hip msm_reduce_enqueue: groups of
-  // 2^LAT_GLOG buckets when nothing else is in flight), whose task sums take up to 16 splits
-  const int g_min = pl.glog < LAT_GLOG ? pl.glog : LAT_GLOG;
-  ZKR_HIP_CHECK(hipMalloc(&ws.group_out, (size_t)(pl.nbw >> g_min) * cap * sets * 2 * xyzz_bytes));
-  ZKR_HIP_CHECK(hipMalloc(&ws.task_out, (size_t)(pl.c + 2) * (pl.S > 16 ? pl.S : 16) * cap * sets * xyzz_bytes));
-  ZKR_HIP_CHECK(hipMalloc(&ws.result, xyzz_bytes * cap * sets));
-  ZKR_HIP_CHECK(hipHostMalloc(&ws.h_result, xyzz_bytes * cap * sets, hipHostMallocDefault));
+  if (sets) {
+    ZKR_HIP_CHECK(hipMalloc(&ws.buckets, nb * sets * xyzz_bytes));
+    // sized for the plan's groups AND for the smaller groups of a latency-mode chain (zkr_prove.hip msm_reduce_enqueue: groups of
+    // 2^LAT_GLOG buckets when nothing else is in flight), whose task sums take up to 16 splits
+    const int g_min = pl.glog < LAT_GLOG ? pl.glog : LAT_GLOG;
+    ZKR_HIP_CHECK(hipMalloc(&ws.group_out, (size_t)(pl.nbw >> g_min) * cap * sets * 2 * xyzz_bytes));
+    ZKR_HIP_CHECK(hipMalloc(&ws.task_out, (size_t)(pl.c + 2) * (pl.S > 16 ? pl.S : 16) * cap * sets * xyzz_bytes));
+    ZKR_HIP_CHECK(hipMalloc(&ws.result, xyzz_bytes * cap * sets));
+    ZKR_HIP_CHECK(hipHostMalloc(&ws.h_result, xyzz_bytes * cap * sets, hipHostMallocDefault));
+  }
   ws.max_nb = nb;
   ws.max_entries = n * pl.K * cap;
   ws.sets = sets;
@@ -323,7 +327,8 @@ int key_alloc_workspace(zkr_key *k) {
     Fr **vecs[5] = {&sl.va, &sl.vb, &sl.ca, &sl.cb, &sl.d_h};
     for (auto v : vecs) ZKR_HIP_CHECK(hipMalloc(v, (size_t)h.m * 32 * cap));
     for (int t = 0; t < N_TABLES; t++) {
-      const size_t sets = t == T_B1 && h.npts[T_A] && h.npts[T_B1] && same_reduce_geometry(k->plan[T_A], k->plan[T_B1]) ? 2 : 1;
+      const bool joint_ab = h.npts[T_A] && h.npts[T_B1] && same_reduce_geometry(k->plan[T_A], k->plan[T_B1]);  // A reduced with B1 (zkr_prove.hip)
+      const size_t sets = joint_ab ? (t == T_B1 ? 2 : t == T_A ? 0 : 1) : 1;
       int rc = alloc_msm_ws(sl.ws[t], h.npts[t], k->plan[t], t == T_B2 ? sizeof(G2XYZZ) : sizeof(G1XYZZ), cap, sets);
       if (rc) return rc;
     }

@@ -716,7 +716,7 @@ static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *const *d_ws
   // accumulation has ended, profiles/r4_05_timeline_one_tx_proof.txt).  A is accumulated into the bucket sets BEHIND B1's (B1's
   // workspace holds two sets per proof when the two tables' geometry agrees) and one launch set reduces both: a chain of latency-bound
   // launches less per proof.
-  const bool joint_ab = !serial && h.npts[T_A] && h.npts[T_B1] && same_reduce_geometry(k->plan[T_A], k->plan[T_B1]) && sl.ws[T_B1].sets == 2;
+  const bool joint_ab = h.npts[T_A] && h.npts[T_B1] && same_reduce_geometry(k->plan[T_A], k->plan[T_B1]) && sl.ws[T_B1].sets == 2;  // (the serial schedule too: A's workspace has no reduction buffers then)
   sl.joint_ab = joint_ab;
   for (int t = 0; t < N_TABLES; t++) sl.res_pending[t] = false;
   auto result_event = [&](int t, hipStream_t rs, int rc) -> int {  // after a table's reduction chain (its D2H copy is the last thing enqueued)
