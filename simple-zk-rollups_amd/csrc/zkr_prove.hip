@@ -732,13 +732,13 @@ static int prove_submit_enqueue(zkr_key *k, ProofSlot &sl, const Fr *const *d_ws
   // (HISTORY.md 7b / 13: a tx proof 2.13-2.40 against 1.98 ms, 2^20 the same).
   ShardGroup *const group = shard_group;
   const bool split_h = group && group->split_h && !serial && nbat == 1 && h.shard_parts == group->parts && h.shard_part == shard_group_part;
-  const bool early = split_h;
   // C's oversized-bucket sums on the auxiliary stream for ONE proof of a key that can fuse batches (the latency case; c_big below)
   const bool c_big_first = merge_ch && !serial && nbat == 1 && sl.cap > 1;
   // nothing else of this key in flight (the caller holds the key's lock: with_free_slot): this proof's last chain is latency
   bool alone = !serial;
   for (const ProofSlot &o : k->slot)
     if (&o != &sl && o.busy) alone = false;
+  const bool early = split_h;  // (for a lone 2^20 / 2^22 proof the early hand-over measures the same: profiles/r6_16_lone_proof_early_handover.txt)
   hipStream_t last = s;
   // One table: (1) its chain's stream waits for the table's sort and takes its oversized buckets (they need only the sort and run
   // beside the accumulation), (2) the accumulation on the accumulation stream, (3) oversized-bucket sums into the buckets and
