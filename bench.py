@@ -732,8 +732,9 @@ def roofline_record(key, info, prof, per_proof_s, device_state, log_m, shape, lo
             per_run = sum(v["hbm_bytes_per_launch"] * v["launches"] for k, v in pmc["kernels"].items() if not any(x in k for x in skip))
             proof_traffic = per_run / pmc["kernels"]["ingest_kernel"]["launches"]
             traffic = pmc["kernels"][dom]["hbm_bytes_per_launch"]
-            traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x %.3f, the factor calibrated on this kernel's access pattern: %s; %s)" % (
-                pmc_file, pmc["calibration"][pmc["kernels"][dom]["pattern"]], pmc["calibration_source"], pmc.get("schedule", "isolated kernels"))
+            # (short first: the driver's record keeps 120 characters of a string)
+            traffic_src = "profiles/%s: FETCH_SIZE x %.3f (calibrated on %s) + WRITE_SIZE, separate --pmc passes, %s; calibration: %s" % (
+                pmc_file, pmc["calibration"][pmc["kernels"][dom]["pattern"]], pmc["kernels"][dom]["pattern"], pmc.get("schedule", "isolated kernels"), pmc["calibration_source"])
     except Exception:
         pass
     # the kernels of the path that STREAM (SURVEY 8(d) regime 1), each against the HBM peak: algorithmic bytes per launch

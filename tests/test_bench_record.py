@@ -103,3 +103,34 @@ def test_multi_rank_line_schema_and_what_counts_as_measured():
     assert b.shards_share_a_gpu([0, 1, 2, 3], ["0000:%02x:00.0" % (0x10 + i) for i in range(4)]) is False
     leg = dict(d["intra_proof_sharding"], rehearsal_on_one_gpu=b.shards_share_a_gpu([0, 1], [one, "0000:f5:00.0"]))
     assert b.sharding_scalars(leg)["sharded_measured"] is True
+
+
+def test_round_6_default_line_carries_ratios_counters_and_denominators():
+    """The default line as recorded on the round's last tree (profiles/r6_21_bench_default.json): the scalars VERDICT r5 asked for are
+    there, consistent with each other, and the counter files they come from are THIS round's."""
+    b = _bench()
+    d = json.load(open(os.path.join(ROOT, "profiles", "r6_21_bench_default.json")))
+    roof, cpu, cfg = _driver_view(d["roofline"]), _driver_view(d["cpu_baseline"]), _driver_view(d["config"])
+    for obj in (d["config"], d["roofline"], d["cpu_baseline"]):
+        flat = [k for k, v in obj.items() if not isinstance(v, (dict, list))]
+        assert len({k[:40] for k in flat}) == len(flat)
+    # roofline: the contract form, the calibrated traffic and its ratios, the counter-based busy fraction
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12 and roof["kernel"] == "msm_accum_kernel<Fq>" and roof["launches_per_proof"] == 4.0
+    assert abs(roof["traffic_over_algorithmic"] - roof["traffic"] / roof["algorithmic_bytes_per_launch"]) < 1e-9 and 5 < roof["traffic_over_algorithmic"] < 15
+    assert abs(roof["hbm_traffic_over_algorithmic_proof"] - roof["hbm_traffic_GB_per_proof"] / roof["algorithmic_GB_per_proof"]) < 1e-9
+    assert "r%d_pmc_traffic.json" % b.ROUND in roof["traffic_source"] and "x 0.797" in roof["traffic_source"]      # inside the 120 characters the driver keeps
+    busy = 4.0 * roof["valu_wave_instructions_per_proof"] / (1024 * roof["sclk_mhz_sampled"] * 1e6 * d["ms_per_step"] * 1e-3)
+    assert abs(roof["valu_busy_step"] - busy) < 1e-9 and 0.7 < busy < 0.9
+    # the committed counter files bench.py reads are this round's, and agree with what the line says
+    pmc = json.load(open(os.path.join(ROOT, "profiles", b.PMC_FILE)))
+    cen = json.load(open(os.path.join(ROOT, "profiles", b.CENSUS_FILE)))
+    assert pmc["round"] == b.ROUND == cen["round"] and cen["valu_wave_instructions_per_proof"] == roof["valu_wave_instructions_per_proof"]
+    assert pmc["kernels"]["msm_accum_kernel<Fq>"]["pattern"] == "gather64" and pmc["kernels"]["msm_accum_kernel<Fq2>"]["pattern"] == "gather128"
+    assert abs(pmc["kernels"]["msm_accum_kernel<Fq>"]["hbm_bytes_per_launch"] - roof["traffic"]) < 1.0
+    # cpu_baseline: the north star's denominator and ratios
+    assert cpu["snarkjs_style_sample_log_m"] == 12 and cpu["speedup_vs_snarkjs_style"] > 50 and cpu["cpu_and_gpu_proofs_identical"] is True
+    assert abs(cpu["speedup_vs_c_1thread"] * cpu["value"] - d["value"]) < 1e-9 and cpu["all_threads_cores"] >= 1
+    # config: the reference's calling pattern and the other BASELINE config
+    for k in ("sync_latency_ms", "host_buffer_sync_proofs_per_s", "rate_2_22_proofs_per_s", "tx_single_proof_ms", "tx_fused_proofs_per_s", "withdraw_single_proof_ms", "sharded_ms"):
+        assert isinstance(cfg.get(k), float), k
+    assert d["metric"].startswith("Groth16 proofs/sec") and d["unit"] == "proofs/s" and d["dtype"] and d["vs_baseline"] is None and d["scaling"] == "weak"
